@@ -1,0 +1,54 @@
+/*
+ * include/mistralrs_quant.h -- C ABI of libmistralrsquant.so (gfx950 / MI355X).
+ *
+ * Drop-in for the static library `libmistralrsquant.a` that mistralrs-quant's build.rs links
+ * (mistralrs-quant/build.rs:220-228,247-249).  Every entry point below has the SAME symbol name
+ * and argument list as the CUDA launcher it replaces; `stream` carries a hipStream_t where the
+ * reference passes a cudaStream_t.  Rust-side declarations: mistralrs-quant/src/gguf/ffi.rs,
+ * src/rotary/ffi.rs, src/utils/ffi.rs.  Reference-side binding: see INTEGRATION.md.
+ *
+ * Contract: the caller owns every buffer (inputs, outputs, scratch); nothing here
+ * allocates or frees device memory; every call only enqueues work on `stream` (graph-capturable);
+ * pointers are raw device addresses; weights are unmodified GGUF block bytes, row-major [N][K/blk].
+ */
+#ifndef MISTRALRS_QUANT_H
+#define MISTRALRS_QUANT_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- activation -> Q8_1 (36-byte blocks: half d, half sum(x), 32 x int8), rows zero-padded to
+ *      kx_padded (a multiple of 512: MATRIX_ROW_PADDING, fast_mmvq.rs:21).
+ *      replaces mmvq_gguf.cu:1606-1641; caller: gguf/fast_mmvq.rs:340-383 */
+void launch_mmvq_gguf_quantize_q8_1_bf16(const void *x, void *vy, int kx, int kx_padded, int num_rows, void *stream);
+void launch_mmvq_gguf_quantize_q8_1_f16(const void *x, void *vy, int kx, int kx_padded, int num_rows, void *stream);
+void launch_mmvq_gguf_quantize_q8_1_f32(const void *x, void *vy, int kx, int kx_padded, int num_rows, void *stream);
+
+/* ---- decode GEMV, batch 1..8:  dst[j*stride_col_dst + row] = W[row,:] . y_j
+ *      <t> in q4_0 q4_1 q5_0 q5_1 q8_0 q2_k q3_k q4_k q5_k q6_k ; <d> in f32 f16 bf16
+ *      replaces mmvq_gguf.cu:1322-1600 (MMVQ_LAUNCHER_PLAIN / _FUSED_GLU / _FUSED_QKV);
+ *      callers: gguf/fast_mmvq.rs:299 (plain), :472 (fused_glu), :682 (fused_qkv).
+ *      ncols_x = K (unpadded), stride_col_y = Q8_1 blocks per batch column (kx_padded/32).
+ *      fused_glu: dst = act(gate.y) * (up.y), activation codes 0 silu 1 gelu 2 relu 3 gelu_erf 4 sigmoid
+ *      fused_qkv: X_dst[j*nrows_X + row] */
+#define MRS_DECL_MMVQ(t, d)                                                                                        \
+  void launch_mmvq_gguf_##t##_##d##_plain(const void *vx, const void *vy, void *dst, int ncols_x, int nrows_x,     \
+                                          int stride_col_y, int stride_col_dst, int b_size, void *stream);        \
+  void launch_mmvq_gguf_##t##_##d##_fused_glu(const void *vx_gate, const void *vx_up, const void *vy, void *dst,   \
+                                              int ncols_x, int nrows_x, int stride_col_y, int stride_col_dst,      \
+                                              int b_size, int activation, void *stream);                           \
+  void launch_mmvq_gguf_##t##_##d##_fused_qkv(const void *vx_q, const void *vx_k, const void *vx_v, const void *vy, \
+                                              void *q_dst, void *k_dst, void *v_dst, int ncols_x, int nrows_q,     \
+                                              int nrows_k, int nrows_v, int stride_col_y, int b_size, void *stream);
+#define MRS_DECL_MMVQ_T(t) MRS_DECL_MMVQ(t, f32) MRS_DECL_MMVQ(t, f16) MRS_DECL_MMVQ(t, bf16)
+MRS_DECL_MMVQ_T(q4_0) MRS_DECL_MMVQ_T(q4_1) MRS_DECL_MMVQ_T(q5_0) MRS_DECL_MMVQ_T(q5_1) MRS_DECL_MMVQ_T(q8_0)
+MRS_DECL_MMVQ_T(q2_k) MRS_DECL_MMVQ_T(q3_k) MRS_DECL_MMVQ_T(q4_k) MRS_DECL_MMVQ_T(q5_k) MRS_DECL_MMVQ_T(q6_k)
+#undef MRS_DECL_MMVQ_T
+#undef MRS_DECL_MMVQ
+
+#ifdef __cplusplus
+}
+#endif
+#endif

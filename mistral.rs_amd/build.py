@@ -1,0 +1,116 @@
+"""Build the gfx950 shared libraries in-tree with hipcc (no cmake, no torch extension).
+
+    python mistral.rs_amd/build.py [-j N] [--force]
+
+Outputs (git-ignored, shipped to the GPU box by gpurun):
+    mistral.rs_amd/lib/libmistralrsquant.so            <- replaces libmistralrsquant.a
+    mistral.rs_amd/lib/libmistralrspagedattention.so   <- replaces libmistralrspagedattention.a
+    mistral.rs_amd/lib/libmistralrscuda.so             <- replaces libmistralrscuda.a (hot-path subset)
+    mistral.rs_amd/lib/libmrs_hip_ext.so               <- MI355X-native extras (fused decode path, host runtime)
+(the three reference static libs: mistralrs-quant/build.rs:220-249, mistralrs-paged-attn/build.rs:146-215,
+ mistralrs-core/build.rs:59-70)
+"""
+from __future__ import annotations
+
+import argparse
+import concurrent.futures as cf
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIB = os.path.join(HERE, "lib")
+ARCH = "gfx950"
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+CXXFLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
+            "-I" + CSRC, "-I" + os.path.join(os.path.dirname(HERE), "include")]
+
+MMVQ_TYPES = {"q4_0": 2, "q4_1": 3, "q5_0": 6, "q5_1": 7, "q8_0": 8,
+              "q2_k": 10, "q3_k": 11, "q4_k": 12, "q5_k": 13, "q6_k": 14}
+
+
+def _tu(src, obj=None, defines=()):
+    return (src, obj or os.path.splitext(src)[0] + ".o", tuple(defines))
+
+
+def libraries():
+    quant = [_tu("mmvq_quantize.hip")]
+    quant += [_tu("mmvq_inst.hip", f"mmvq_{tag}.o", (f"-DMRS_TAG={tag}", f"-DMRS_TYPE={tid}"))
+              for tag, tid in MMVQ_TYPES.items()]
+    libs = {"libmistralrsquant.so": quant}
+    # optional translation units are picked up as soon as the file exists
+    optional = {
+        "libmistralrsquant.so": ["quant_ops.hip", "mmq.hip", "moe.hip", "hqq.hip"],
+        "libmistralrspagedattention.so": ["paged_attention.hip", "kv_cache_ops.hip"],
+        "libmistralrscuda.so": ["core_ops.hip"],
+        "libmrs_hip_ext.so": ["ext_decode.hip", "ext_gemm.hip", "ext_attn_prefill.hip", "ext_comm.hip",
+                              "host/runtime.cpp"],
+    }
+    for lib, srcs in optional.items():
+        for s in srcs:
+            if os.path.exists(os.path.join(CSRC, s)):
+                libs.setdefault(lib, []).append(_tu(s, os.path.basename(os.path.splitext(s)[0]) + ".o"))
+    return libs
+
+
+def _headers_mtime():
+    m = 0.0
+    for root, _, files in os.walk(CSRC):
+        if root.startswith(OBJ):
+            continue
+        for f in files:
+            if f.endswith((".cuh", ".h", ".hpp")):
+                m = max(m, os.path.getmtime(os.path.join(root, f)))
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    if os.path.isdir(inc):
+        for f in os.listdir(inc):
+            m = max(m, os.path.getmtime(os.path.join(inc, f)))
+    return m
+
+
+def _compile(src, obj, defines, force, hdr_m):
+    s, o = os.path.join(CSRC, src), os.path.join(OBJ, obj)
+    if not force and os.path.exists(o) and os.path.getmtime(o) >= max(os.path.getmtime(s), hdr_m):
+        return o, False
+    cmd = [HIPCC, *CXXFLAGS, *defines, "-c", s, "-o", o]
+    if src.endswith(".cpp"):
+        cmd = [HIPCC, "-x", "hip", *CXXFLAGS, *defines, "-c", s, "-o", o]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src} {defines}:\n{r.stderr[-4000:]}")
+    return o, True
+
+
+def build(jobs: int | None = None, force: bool = False, verbose: bool = True) -> dict:
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(LIB, exist_ok=True)
+    libs = libraries()
+    hdr_m = _headers_mtime()
+    jobs = jobs or min(16, os.cpu_count() or 4)
+    out = {}
+    with cf.ThreadPoolExecutor(jobs) as ex:
+        futs = {name: [ex.submit(_compile, *tu, force, hdr_m) for tu in tus] for name, tus in libs.items()}
+        for name, fl in futs.items():
+            res = [f.result() for f in fl]
+            objs = [o for o, _ in res]
+            target = os.path.join(LIB, name)
+            if force or any(ch for _, ch in res) or not os.path.exists(target):
+                cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", target, *objs]
+                r = subprocess.run(cmd, capture_output=True, text=True)
+                if r.returncode != 0:
+                    raise RuntimeError(f"link failed for {name}:\n{r.stderr[-4000:]}")
+                if verbose:
+                    print(f"[build] linked {name} ({len(objs)} objects)", file=sys.stderr)
+            out[name] = target
+    return out
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("-j", type=int, default=None)
+    ap.add_argument("--force", action="store_true")
+    a = ap.parse_args()
+    for k, v in build(a.j, a.force).items():
+        print(k, "->", v)

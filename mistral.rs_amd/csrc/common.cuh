@@ -1,0 +1,91 @@
+// common.cuh -- shared device helpers for the gfx950 (CDNA4, wave64) kernels.
+// Written for MI355X only: 64-lane wavefronts are assumed everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MRS_WAVE 64
+
+namespace mrs {
+
+// ---------------------------------------------------------------------------------- dtypes
+struct bf16_t { uint16_t v; };
+using f16_t = _Float16;
+
+__device__ __forceinline__ float bf16_bits_to_float(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
+__device__ __forceinline__ uint16_t float_to_bf16_bits(float f) {  // round-to-nearest-even
+  uint32_t x = __float_as_uint(f);
+  if ((x & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((x >> 16) | 0x40);
+  x += 0x7fffu + ((x >> 16) & 1u);
+  return (uint16_t)(x >> 16);
+}
+
+template <class T> struct cvt;
+template <> struct cvt<float> {
+  static __device__ __forceinline__ float to_f(float x) { return x; }
+  static __device__ __forceinline__ float from_f(float x) { return x; }
+};
+template <> struct cvt<bf16_t> {
+  static __device__ __forceinline__ float to_f(bf16_t x) { return bf16_bits_to_float(x.v); }
+  static __device__ __forceinline__ bf16_t from_f(float x) { return bf16_t{float_to_bf16_bits(x)}; }
+};
+template <> struct cvt<f16_t> {
+  static __device__ __forceinline__ float to_f(f16_t x) { return (float)x; }
+  static __device__ __forceinline__ f16_t from_f(float x) { return (f16_t)x; }
+};
+template <class T> __device__ __forceinline__ float to_f(T x) { return cvt<T>::to_f(x); }
+template <class T> __device__ __forceinline__ T from_f(float x) { return cvt<T>::from_f(x); }
+// round a float through T (what `(dst_t)x` then `(float)` does in the reference kernels)
+template <class T> __device__ __forceinline__ float round_to(float x) { return to_f<T>(from_f<T>(x)); }
+
+__device__ __forceinline__ float half_bits_to_float(uint16_t h) {
+  return (float)__builtin_bit_cast(_Float16, h);
+}
+__device__ __forceinline__ uint16_t float_to_half_bits(float f) {
+  return __builtin_bit_cast(uint16_t, (_Float16)f);
+}
+
+// ---------------------------------------------------------------------------------- wave ops
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+template <class T> __device__ __forceinline__ T wave_sum(T x) {
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) x += __shfl_xor(x, m, 64);
+  return x;
+}
+__device__ __forceinline__ float wave_max(float x) {
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) x = fmaxf(x, __shfl_xor(x, m, 64));
+  return x;
+}
+
+// signed 4x int8 dot with int32 accumulate (v_dot4_i32_i8)
+__device__ __forceinline__ int dot4(int a, int b, int c) { return __builtin_amdgcn_sdot4(a, b, c, false); }
+
+// 16-byte load with only 2-byte guaranteed alignment (GGUF blocks are 2-byte aligned: 34/210/110 B).
+// gfx950 global memory tolerates unaligned dword accesses; the packed typedef makes hipcc emit
+// one global_load_dwordx4 rather than byte loads.
+typedef int int4_a2 __attribute__((ext_vector_type(4), aligned(2)));
+typedef int int2_a2 __attribute__((ext_vector_type(2), aligned(2)));
+typedef int int1_a2 __attribute__((aligned(2)));
+typedef int int4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef int int4_a16 __attribute__((ext_vector_type(4), aligned(16)));
+
+__device__ __forceinline__ int4 ld16_a2(const void *p) { int4_a2 v = *(const int4_a2 *)p; return make_int4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ int4 ld16_a4(const void *p) { int4_a4 v = *(const int4_a4 *)p; return make_int4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ int4 ld16_a16(const void *p) { int4_a16 v = *(const int4_a16 *)p; return make_int4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ int ld4_a2(const void *p) { return *(const int1_a2 *)p; }
+__device__ __forceinline__ uint16_t ld2(const void *p) { return *(const uint16_t *)p; }
+
+// GLU activations -- codes as mistralrs-quant/src/utils/ops.rs:2601-2607 / mmvq_gguf.cu:44-85
+__device__ __forceinline__ float glu_act(float x, int act) {
+  switch (act) {
+  case 1: { const float x3 = x * x * x; return 0.5f * x * (1.0f + tanhf(0.7978845608f * (x + 0.044715f * x3))); }
+  case 2: return fmaxf(x, 0.0f);
+  case 3: return x * 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  case 4: return 1.0f / (1.0f + expf(-x));
+  default: return x / (1.0f + expf(-x));
+  }
+}
+
+}  // namespace mrs

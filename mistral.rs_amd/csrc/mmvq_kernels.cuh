@@ -1,0 +1,155 @@
+// mmvq_kernels.cuh -- __global__ kernels + host launch helpers behind the reference's
+// `launch_mmvq_gguf_<type>_<dst>_{plain,fused_glu,fused_qkv}` C ABI
+// (declared in mistralrs-quant/src/gguf/ffi.rs, defined in kernels/mmvq_gguf/mmvq_gguf.cu:1322-1600).
+#pragma once
+#include "mmvq_core.cuh"
+
+namespace mrs {
+
+enum : int { DST_F32 = 0, DST_F16 = 1, DST_BF16 = 2 };
+enum : int { MODE_PLAIN = 0, MODE_GLU = 1, MODE_QKV = 2 };
+
+struct MmvqArgs {
+  const uint8_t *w[3];  // plain: w[0]; glu: gate, up; qkv: q, k, v
+  void *dst[3];
+  int nrows[3];
+  const uint8_t *y;  // Q8_1 blocks [b][stride_col_y]
+  int ncols_x;       // K
+  int stride_col_y;  // Q8_1 blocks per batch column
+  int stride_col_dst;
+  int activation;
+  int dst_kind;
+};
+
+__device__ __forceinline__ void store_dst(void *dst, size_t idx, float v, int kind) {
+  if (kind == DST_F32) ((float *)dst)[idx] = v;
+  else if (kind == DST_F16) ((f16_t *)dst)[idx] = (f16_t)v;
+  else ((uint16_t *)dst)[idx] = float_to_bf16_bits(v);
+}
+__device__ __forceinline__ float round_kind(float v, int kind) {
+  if (kind == DST_F32) return v;
+  if (kind == DST_F16) return (float)(f16_t)v;
+  return bf16_bits_to_float(float_to_bf16_bits(v));
+}
+
+template <int TYPE, int NCOLS, int MODE>
+__global__ void __launch_bounds__(256) mmvq_kernel(const MmvqArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const ActLds act = stage_q8_1<TYPE, NCOLS>(smem, a.y, a.ncols_x, a.stride_col_y);
+  __syncthreads();
+
+  const int K = a.ncols_x;
+  const int nslices = K / 32;
+  const size_t row_bytes = (size_t)(K / Fmt<TYPE>::BLK) * Fmt<TYPE>::TS;
+  const int total_rows = (MODE == MODE_QKV) ? a.nrows[0] + a.nrows[1] + a.nrows[2] : a.nrows[0];
+  const int chunk = (total_rows + gridDim.x - 1) / gridDim.x;
+  const int row0 = blockIdx.x * chunk;
+  const int row1 = min(row0 + chunk, total_rows);
+  const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int lane = lane_id();
+
+  for (int r = row0 + wave; r < row1; r += nwaves) {
+    if constexpr (MODE == MODE_GLU) {
+      // reference: mmvq_core_fused_glu_impl (mmvq_gguf.cu:794-873): both projections are rounded
+      // to dst_t, the activation runs in f32 on the rounded gate, is rounded again, then multiplied.
+      float g[NCOLS], u[NCOLS];
+      row_dot2<TYPE, NCOLS>(a.w[0] + (size_t)r * row_bytes, a.w[1] + (size_t)r * row_bytes, nslices, act, g, u);
+      if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < NCOLS; ++c) {
+          const float gv = round_kind(g[c], a.dst_kind), uv = round_kind(u[c], a.dst_kind);
+          const float av = round_kind(glu_act(gv, a.activation), a.dst_kind);
+          store_dst(a.dst[0], (size_t)c * a.stride_col_dst + r, av * uv, a.dst_kind);
+        }
+      }
+    } else {
+      const uint8_t *w = a.w[0];
+      void *dst = a.dst[0];
+      int lr = r, stride = a.stride_col_dst;
+      if constexpr (MODE == MODE_QKV) {  // mmvq_core_fused_qkv_impl (:875-996): dst[j*nrows_x + row]
+        if (r >= a.nrows[0] + a.nrows[1]) { lr = r - a.nrows[0] - a.nrows[1]; w = a.w[2]; dst = a.dst[2]; stride = a.nrows[2]; }
+        else if (r >= a.nrows[0]) { lr = r - a.nrows[0]; w = a.w[1]; dst = a.dst[1]; stride = a.nrows[1]; }
+        else { stride = a.nrows[0]; }
+      }
+      float acc[NCOLS];
+      row_dot<TYPE, NCOLS>(w + (size_t)lr * row_bytes, nslices, act, acc);
+      if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < NCOLS; ++c) store_dst(dst, (size_t)c * stride + lr, acc[c], a.dst_kind);
+      }
+    }
+  }
+}
+
+inline int mmvq_grid(int total_rows, int waves_per_wg) {
+  // >= 1 row per wave; at most 4 workgroups of 256 threads per CU on the 256 CUs of an MI355X
+  int g = (total_rows + waves_per_wg - 1) / waves_per_wg;
+  if (g > 1024) g = 1024;
+  if (g < 1) g = 1;
+  return g;
+}
+
+template <int TYPE, int MODE> struct MmvqLaunch {
+  template <int NCOLS> static void go(const MmvqArgs &a, int total_rows, hipStream_t s) {
+    const size_t lds = act_lds_bytes(a.ncols_x, NCOLS, Fmt<TYPE>::HAS_OFFSET);
+    static bool attr_done = false;  // > 64 KiB of dynamic LDS needs the opt-in once per kernel
+    if (lds > 65536 && !attr_done) {
+      hipFuncSetAttribute((const void *)mmvq_kernel<TYPE, NCOLS, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_done = true;
+    }
+    hipLaunchKernelGGL((mmvq_kernel<TYPE, NCOLS, MODE>), dim3(mmvq_grid(total_rows, 4)), dim3(256), lds, s, a);
+  }
+  static void run(const MmvqArgs &a, int b_size, hipStream_t s) {
+    const int total_rows = (MODE == MODE_QKV) ? a.nrows[0] + a.nrows[1] + a.nrows[2] : a.nrows[0];
+    if (total_rows <= 0) return;
+    switch (b_size) {
+    case 1: go<1>(a, total_rows, s); break;
+    case 2: go<2>(a, total_rows, s); break;
+    case 3: go<3>(a, total_rows, s); break;
+    case 4: go<4>(a, total_rows, s); break;
+    case 5: go<5>(a, total_rows, s); break;
+    case 6: go<6>(a, total_rows, s); break;
+    case 7: go<7>(a, total_rows, s); break;
+    case 8: go<8>(a, total_rows, s); break;
+    default: break;  // the reference launcher silently ignores b_size outside 1..8 as well
+    }
+  }
+};
+
+}  // namespace mrs
+
+// Defines the nine C-ABI launchers of one GGUF type (3 dst dtypes x plain / fused_glu / fused_qkv).
+#define MRS_MMVQ_LAUNCHERS_DST(tag, TYPE, dtag, DKIND)                                                              \
+  extern "C" void launch_mmvq_gguf_##tag##_##dtag##_plain(const void *vx, const void *vy, void *dst, int ncols_x,   \
+                                                         int nrows_x, int stride_col_y, int stride_col_dst,        \
+                                                         int b_size, void *stream) {                               \
+    mrs::MmvqArgs a{};                                                                                              \
+    a.w[0] = (const uint8_t *)vx; a.dst[0] = dst; a.nrows[0] = nrows_x; a.y = (const uint8_t *)vy;                  \
+    a.ncols_x = ncols_x; a.stride_col_y = stride_col_y; a.stride_col_dst = stride_col_dst; a.dst_kind = DKIND;      \
+    mrs::MmvqLaunch<TYPE, mrs::MODE_PLAIN>::run(a, b_size, (hipStream_t)stream);                                    \
+  }                                                                                                                 \
+  extern "C" void launch_mmvq_gguf_##tag##_##dtag##_fused_glu(const void *vx_gate, const void *vx_up,              \
+                                                             const void *vy, void *dst, int ncols_x, int nrows_x,  \
+                                                             int stride_col_y, int stride_col_dst, int b_size,     \
+                                                             int activation, void *stream) {                       \
+    mrs::MmvqArgs a{};                                                                                              \
+    a.w[0] = (const uint8_t *)vx_gate; a.w[1] = (const uint8_t *)vx_up; a.dst[0] = dst; a.nrows[0] = nrows_x;       \
+    a.y = (const uint8_t *)vy; a.ncols_x = ncols_x; a.stride_col_y = stride_col_y;                                  \
+    a.stride_col_dst = stride_col_dst; a.activation = activation; a.dst_kind = DKIND;                               \
+    mrs::MmvqLaunch<TYPE, mrs::MODE_GLU>::run(a, b_size, (hipStream_t)stream);                                      \
+  }                                                                                                                 \
+  extern "C" void launch_mmvq_gguf_##tag##_##dtag##_fused_qkv(                                                      \
+      const void *vx_q, const void *vx_k, const void *vx_v, const void *vy, void *q_dst, void *k_dst, void *v_dst, \
+      int ncols_x, int nrows_q, int nrows_k, int nrows_v, int stride_col_y, int b_size, void *stream) {            \
+    mrs::MmvqArgs a{};                                                                                              \
+    a.w[0] = (const uint8_t *)vx_q; a.w[1] = (const uint8_t *)vx_k; a.w[2] = (const uint8_t *)vx_v;                 \
+    a.dst[0] = q_dst; a.dst[1] = k_dst; a.dst[2] = v_dst;                                                           \
+    a.nrows[0] = nrows_q; a.nrows[1] = nrows_k; a.nrows[2] = nrows_v;                                               \
+    a.y = (const uint8_t *)vy; a.ncols_x = ncols_x; a.stride_col_y = stride_col_y; a.dst_kind = DKIND;              \
+    mrs::MmvqLaunch<TYPE, mrs::MODE_QKV>::run(a, b_size, (hipStream_t)stream);                                      \
+  }
+
+#define MRS_MMVQ_LAUNCHERS(tag, TYPE)                    \
+  MRS_MMVQ_LAUNCHERS_DST(tag, TYPE, f32, mrs::DST_F32)   \
+  MRS_MMVQ_LAUNCHERS_DST(tag, TYPE, f16, mrs::DST_F16)   \
+  MRS_MMVQ_LAUNCHERS_DST(tag, TYPE, bf16, mrs::DST_BF16)

@@ -1,0 +1,84 @@
+/*
+ * oracle/ggml_oracle.h -- TEST INFRASTRUCTURE ONLY (not shipped, not on the product path).
+ *
+ * CPU restatement of the arithmetic underneath mistral.rs' quantized hot path:
+ * GGML block formats, activation quantizers, the GPU (Q8_1) and CPU (Q8_K / Q8_0)
+ * dot-product semantics, and the glue ops (RMSNorm, RoPE, SiLU-GLU, attention).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+ *
+ * PARITY STATUS: "parity unpinned" for everything that lives in candle (CPU QMatMul,
+ * quantizers): candle@35d7ae7 is a git dependency that is not vendored under
+ * /root/reference and there is no Rust toolchain here.  Block decode and the MMVQ
+ * integer dot products are pinned against the reference's own device functions
+ * compiled for the host (oracle/_ref, see oracle/Makefile + oracle/ref_shim/).
+ */
+#ifndef GGML_ORACLE_H
+#define GGML_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ggml type ids -- reference: mistralrs-quant/src/gguf/archive.rs:73-160 */
+enum orc_type {
+  ORC_F32 = 0, ORC_F16 = 1, ORC_Q4_0 = 2, ORC_Q4_1 = 3, ORC_Q5_0 = 6, ORC_Q5_1 = 7,
+  ORC_Q8_0 = 8, ORC_Q8_1 = 9, ORC_Q2_K = 10, ORC_Q3_K = 11, ORC_Q4_K = 12,
+  ORC_Q5_K = 13, ORC_Q6_K = 14, ORC_Q8_K = 15, ORC_BF16 = 30
+};
+
+int orc_block_size(int type);   /* elements per block  (0 = unknown type) */
+int orc_type_size(int type);    /* bytes per block */
+
+float    orc_fp16_to_fp32(uint16_t h);
+uint16_t orc_fp32_to_fp16(float f);      /* round-to-nearest-even */
+float    orc_bf16_to_fp32(uint16_t h);
+uint16_t orc_fp32_to_bf16(float f);      /* round-to-nearest-even */
+
+/* weights: blocks <-> f32 */
+void orc_dequantize_row(int type, const void *blocks, float *out, int64_t k);
+int  orc_quantize_row(int type, const float *x, void *blocks, int64_t k); /* 0 ok, -1 unsupported */
+/* fill n_blocks of `type` with random-but-valid block bytes (finite, sane scales) */
+void orc_random_blocks(int type, void *blocks, int64_t n_blocks, uint64_t seed, float d_scale);
+
+/* activations */
+/* GPU semantics (mmvq_gguf.cu:1220-1250): rows padded with zeros to kx_padded, d=amax/127,
+ * q=roundf(x/d), ds = (half d, half sum(x)) */
+void orc_quantize_q8_1(const float *x, void *y, int kx, int kx_padded, int rows);
+void orc_quantize_q8_K(const float *x, void *y, int64_t k); /* candle BlockQ8K::from_float */
+
+/* matmul oracles: W [N, K] packed row-major, X [B, K] f32, out [B, N] */
+/* A: exact: dequantize W to f32, accumulate in f64 */
+void orc_matmul_exact(int type, const void *W, int N, int K, const float *X, int B, float *out);
+/* C: GPU-MMVQ semantics: integer dots against Q8_1 blocks (stride_col_y blocks per batch col),
+ *    float combination done in f64 (order-free reference for any f32 summation order) */
+void orc_matmul_q8_1(int type, const void *W, int N, int K, const void *y_q8_1,
+                     int stride_col_y, int B, float *out);
+/* same, also returns mag = SUM |terms| per output (what f32 accumulation error scales with) */
+void orc_matmul_q8_1_ex(int type, const void *W, int N, int K, const void *y_q8_1,
+                        int stride_col_y, int B, float *out, float *mag);
+/* B: candle-CPU semantics: rows of X quantized to the vec_dot partner (Q8_K for K-quants,
+ *    Q8_0 for Q4_0/Q5_0/Q8_0, Q8_1 for Q4_1/Q5_1), f32 accumulation in ggml generic order */
+void orc_matmul_cpu(int type, const void *W, int N, int K, const float *X, int B, float *out);
+
+/* glue ops (f32) */
+void orc_rms_norm(const float *x, const float *w, float *out, int rows, int d, float eps);
+/* rope: x [tokens, heads, head_dim] in place; cos/sin [max_pos, rot_dim/2]; positions [tokens] */
+void orc_rope(float *x, const float *cos_t, const float *sin_t, const int32_t *positions,
+              int tokens, int heads, int head_dim, int rot_dim, int neox);
+float orc_glu_act(float x, int act); /* 0 silu 1 gelu(tanh) 2 relu 3 gelu_erf 4 sigmoid */
+void orc_fused_glu(const float *a, const float *b, float *out, int64_t n, int act);
+/* causal softmax attention, GQA. q [T, H, hd], k/v [S, KVH, hd], out [T, H, hd];
+ * query t attends keys 0..(S-T+t) ; f32 inputs, f64 softmax */
+void orc_attention(const float *q, const float *k, const float *v, float *out, int T, int S,
+                   int H, int KVH, int hd, float scale, float softcap);
+
+void orc_set_threads(int n);
+int  orc_get_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,227 @@
+"""oracle/oracle.py -- TEST INFRASTRUCTURE ONLY.
+
+ctypes/numpy front-end of the CPU oracle (oracle/ggml_oracle.c, oracle/llama_oracle.c).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module;
+nothing under mistral.rs_amd/ does (tests/test_no_oracle_in_product.py enforces it).
+
+Parity status: see the header of ggml_oracle.h ("parity unpinned" for the candle-resident
+CPU arithmetic; block decode + MMVQ dots pinned against oracle/_ref when it is built).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libggml_oracle.so")
+
+# ggml type ids (reference: mistralrs-quant/src/gguf/archive.rs:73-160)
+F32, F16, Q4_0, Q4_1, Q5_0, Q5_1, Q8_0, Q8_1 = 0, 1, 2, 3, 6, 7, 8, 9
+Q2_K, Q3_K, Q4_K, Q5_K, Q6_K, Q8_K, BF16 = 10, 11, 12, 13, 14, 15, 30
+TYPE_NAMES = {Q4_0: "q4_0", Q4_1: "q4_1", Q5_0: "q5_0", Q5_1: "q5_1", Q8_0: "q8_0",
+              Q2_K: "q2_k", Q3_K: "q3_k", Q4_K: "q4_k", Q5_K: "q5_k", Q6_K: "q6_k"}
+MMVQ_TYPES = tuple(TYPE_NAMES)
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle (gcc).  Building the checker is not using it."""
+    srcs = [os.path.join(_HERE, f) for f in ("ggml_oracle.c", "llama_oracle.c", "ggml_oracle.h")]
+    if (not force and os.path.exists(_LIB_PATH)
+            and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-C", _HERE, "libggml_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_fp16_to_fp32.restype = C.c_float
+        _lib.orc_fp16_to_fp32.argtypes = [C.c_uint16]
+        _lib.orc_fp32_to_fp16.restype = C.c_uint16
+        _lib.orc_fp32_to_fp16.argtypes = [C.c_float]
+        _lib.orc_glu_act.restype = C.c_float
+        _lib.orc_glu_act.argtypes = [C.c_float, C.c_int]
+    return _lib
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def block_size(t: int) -> int:
+    return lib().orc_block_size(t)
+
+
+def type_size(t: int) -> int:
+    return lib().orc_type_size(t)
+
+
+def row_bytes(t: int, k: int) -> int:
+    assert k % block_size(t) == 0, (t, k)
+    return k // block_size(t) * type_size(t)
+
+
+def set_threads(n: int) -> None:
+    lib().orc_set_threads(int(n))
+
+
+def get_threads() -> int:
+    return lib().orc_get_threads()
+
+
+# ---------------------------------------------------------------- weights
+def quantize(t: int, w: np.ndarray) -> np.ndarray:
+    """w [N, K] f32 -> packed uint8 [N, row_bytes]."""
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    n, k = w.shape
+    out = np.zeros((n, row_bytes(t, k)), dtype=np.uint8)
+    rc = lib().orc_quantize_row(t, _p(w), _p(out), C.c_int64(n * k))
+    if rc != 0:
+        raise ValueError(f"oracle has no quantizer for ggml type {t}")
+    return out
+
+
+def dequantize(t: int, blocks: np.ndarray, k: int) -> np.ndarray:
+    blocks = np.ascontiguousarray(blocks, dtype=np.uint8)
+    n = blocks.size // row_bytes(t, k)
+    out = np.empty((n, k), dtype=np.float32)
+    lib().orc_dequantize_row(t, _p(blocks), _p(out), C.c_int64(n * k))
+    return out
+
+
+def random_blocks(t: int, n: int, k: int, seed: int = 0, d_scale: float = 0.01) -> np.ndarray:
+    out = np.zeros((n, row_bytes(t, k)), dtype=np.uint8)
+    lib().orc_random_blocks(t, _p(out), C.c_int64(n * (k // block_size(t))), C.c_uint64(seed),
+                            C.c_float(d_scale))
+    return out
+
+
+# ---------------------------------------------------------------- activations
+def pad512(k: int) -> int:
+    return (k + 511) // 512 * 512
+
+
+def quantize_q8_1(x: np.ndarray, k_padded: int | None = None) -> np.ndarray:
+    """x [B, K] f32 -> uint8 [B, k_padded/32*36] (GPU semantics)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    b, k = x.shape
+    kp = pad512(k) if k_padded is None else k_padded
+    out = np.zeros((b, kp // 32 * 36), dtype=np.uint8)
+    lib().orc_quantize_q8_1(_p(x), _p(out), k, kp, b)
+    return out
+
+
+def quantize_q8_K(x: np.ndarray) -> np.ndarray:
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    b, k = x.shape
+    out = np.zeros((b, k // 256 * 292), dtype=np.uint8)
+    lib().orc_quantize_q8_K(_p(x), _p(out), C.c_int64(b * k))
+    return out
+
+
+# ---------------------------------------------------------------- matmul oracles
+def matmul_exact(t: int, w: np.ndarray, n: int, k: int, x: np.ndarray) -> np.ndarray:
+    x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, k)
+    out = np.empty((x.shape[0], n), dtype=np.float32)
+    lib().orc_matmul_exact(t, _p(w), n, k, _p(x), x.shape[0], _p(out))
+    return out
+
+
+def matmul_q8_1(t: int, w: np.ndarray, n: int, k: int, y: np.ndarray) -> np.ndarray:
+    """y: Q8_1 bytes [B, stride*36] as produced by quantize_q8_1."""
+    y = np.ascontiguousarray(y, dtype=np.uint8)
+    b = y.shape[0]
+    out = np.empty((b, n), dtype=np.float32)
+    lib().orc_matmul_q8_1(t, _p(w), n, k, _p(y), y.shape[1] // 36, b, _p(out))
+    return out
+
+
+def matmul_q8_1_mag(t: int, w: np.ndarray, n: int, k: int, y: np.ndarray):
+    """(out, mag): mag = SUM |terms| per output, the scale f32 accumulation error grows with."""
+    y = np.ascontiguousarray(y, dtype=np.uint8)
+    b = y.shape[0]
+    out = np.empty((b, n), dtype=np.float32)
+    mag = np.empty((b, n), dtype=np.float32)
+    lib().orc_matmul_q8_1_ex(t, _p(w), n, k, _p(y), y.shape[1] // 36, b, _p(out), _p(mag))
+    return out, mag
+
+
+def matmul_cpu(t: int, w: np.ndarray, n: int, k: int, x: np.ndarray) -> np.ndarray:
+    x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, k)
+    out = np.empty((x.shape[0], n), dtype=np.float32)
+    lib().orc_matmul_cpu(t, _p(w), n, k, _p(x), x.shape[0], _p(out))
+    return out
+
+
+# ---------------------------------------------------------------- glue
+def rms_norm(x: np.ndarray, w: np.ndarray, eps: float) -> np.ndarray:
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    out = np.empty_like(x)
+    d = x.shape[-1]
+    lib().orc_rms_norm(_p(x), _p(w), _p(out), x.size // d, d, C.c_float(eps))
+    return out
+
+
+def rope(x: np.ndarray, cos: np.ndarray, sin: np.ndarray, positions: np.ndarray, neox: bool) -> np.ndarray:
+    """x [tokens, heads, head_dim] -> rotated copy."""
+    x = np.array(x, dtype=np.float32, order="C", copy=True)
+    cos = np.ascontiguousarray(cos, dtype=np.float32)
+    sin = np.ascontiguousarray(sin, dtype=np.float32)
+    pos = np.ascontiguousarray(positions, dtype=np.int32)
+    t, h, hd = x.shape
+    lib().orc_rope(_p(x), _p(cos), _p(sin), _p(pos), t, h, hd, cos.shape[1] * 2, int(neox))
+    return x
+
+
+def fused_glu(a: np.ndarray, b: np.ndarray, act: int = 0) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    out = np.empty_like(a)
+    lib().orc_fused_glu(_p(a), _p(b), _p(out), C.c_int64(a.size), act)
+    return out
+
+
+def attention(q, k, v, scale: float, softcap: float = 1.0) -> np.ndarray:
+    """q [T,H,hd], k/v [S,KVH,hd] f32; causal with the T queries at the END of the S keys."""
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    k = np.ascontiguousarray(k, dtype=np.float32)
+    v = np.ascontiguousarray(v, dtype=np.float32)
+    t, h, hd = q.shape
+    s, kvh, _ = k.shape
+    out = np.empty_like(q)
+    lib().orc_attention(_p(q), _p(k), _p(v), _p(out), t, s, h, kvh, hd, C.c_float(scale), C.c_float(softcap))
+    return out
+
+
+# ---------------------------------------------------------------- dtype helpers
+def to_bf16_bits(x: np.ndarray) -> np.ndarray:
+    """f32 -> bf16 bit pattern (uint16), round-to-nearest-even."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    r = ((u >> 16) & 1) + 0x7FFF
+    return ((u + r) >> 16).astype(np.uint16)
+
+
+def from_bf16_bits(b: np.ndarray) -> np.ndarray:
+    return (b.astype(np.uint32) << 16).view(np.float32)
+
+
+def round_bf16(x: np.ndarray) -> np.ndarray:
+    return from_bf16_bits(to_bf16_bits(x))
+
+
+def patterned(n: int, salt: int, scale: float) -> np.ndarray:
+    """The reference tests' deterministic input pattern (fast_mmq.rs:1545-1554):
+    ((i*37 + salt*19) % 211 / 105 - 1) * scale."""
+    i = np.arange(n, dtype=np.int64)
+    return (((i * 37 + salt * 19) % 211).astype(np.float32) / 105.0 - 1.0) * np.float32(scale)
