@@ -48,6 +48,25 @@ MRS_DECL_MMVQ_T(q2_k) MRS_DECL_MMVQ_T(q3_k) MRS_DECL_MMVQ_T(q4_k) MRS_DECL_MMVQ_
 #undef MRS_DECL_MMVQ_T
 #undef MRS_DECL_MMVQ
 
+/* ---- RoPE, in place, arithmetic in the tensor dtype.  `rot_dim` = number of rotated PAIRS (= cos/sin row
+ *      length); is_neox: pairs (i, i+rot_dim) else interleaved (2i, 2i+1); dtype 0 f16, 1 bf16, 2 f32.
+ *      replaces kernels/rotary/rotary.cu:122-196 ; Rust: src/rotary/ffi.rs ; caller rotary/mod.rs:851 */
+void rotary_embedding(void *query, void *key, void *cos_cache, void *sin_cache, int32_t is_neox, int32_t head_size,
+                      int64_t num_tokens, int32_t rot_dim, int32_t num_heads, int32_t num_kv_heads, int64_t query_stride,
+                      int64_t key_stride, uint32_t dtype, int64_t stream);
+void rotary_embedding_positions(void *query, void *key, void *cos_cache, void *sin_cache, void *positions,
+                                int32_t is_neox, int32_t head_size, int64_t num_tokens, int32_t rot_dim, int32_t seq_len,
+                                int32_t num_heads, int32_t num_kv_heads, int64_t query_stride, int64_t key_stride,
+                                uint32_t dtype, int64_t stream);
+
+/* ---- out = T(act(float a)) * b, strided rows.  replaces kernels/ops/ops.cu:946-971 ; Rust: src/utils/ffi.rs:274-306 */
+void fused_glu_f16(const void *a, const void *b, void *output, uint32_t rows, uint32_t cols, uint32_t a_row_stride,
+                   uint32_t b_row_stride, int activation, void *stream);
+void fused_glu_bf16(const void *a, const void *b, void *output, uint32_t rows, uint32_t cols, uint32_t a_row_stride,
+                    uint32_t b_row_stride, int activation, void *stream);
+void fused_glu_f32(const void *a, const void *b, void *output, uint32_t rows, uint32_t cols, uint32_t a_row_stride,
+                   uint32_t b_row_stride, int activation, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,10 +40,15 @@ def libraries():
     quant += [_tu("mmvq_inst.hip", f"mmvq_{tag}.o", (f"-DMRS_TAG={tag}", f"-DMRS_TYPE={tid}"))
               for tag, tid in MMVQ_TYPES.items()]
     libs = {"libmistralrsquant.so": quant}
+    pa = [_tu("kv_cache_ops.hip")]
+    for tag, t, ct, abi in (("f16", "mrs::f16_t", "mrs::f16_t", True), ("bf16", "mrs::bf16_t", "mrs::bf16_t", True),
+                            ("f32", "float", "float", True), ("f32_bf16", "float", "mrs::bf16_t", False)):
+        d = [f"-DMRS_PA_TAG={tag}", f"-DMRS_PA_T={t}", f"-DMRS_PA_CT={ct}"] + (["-DMRS_PA_EXPORT_ABI"] if abi else [])
+        pa.append(_tu("paged_attention.hip", f"paged_attention_{tag}.o", d))
+    libs["libmistralrspagedattention.so"] = pa
     # optional translation units are picked up as soon as the file exists
     optional = {
         "libmistralrsquant.so": ["quant_ops.hip", "mmq.hip", "moe.hip", "hqq.hip"],
-        "libmistralrspagedattention.so": ["paged_attention.hip", "kv_cache_ops.hip"],
         "libmistralrscuda.so": ["core_ops.hip"],
         "libmrs_hip_ext.so": ["ext_decode.hip", "ext_gemm.hip", "ext_attn_prefill.hip", "ext_comm.hip",
                               "host/runtime.cpp"],

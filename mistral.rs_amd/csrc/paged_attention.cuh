@@ -1,0 +1,281 @@
+// paged_attention.cuh -- decode attention over the paged KV cache, gfx950 / wave64.
+//
+// Semantics: mistralrs-paged-attn/src/cuda/pagedattention.cuh:110-486 (v1/v2 kernel) and :516-660
+// (v2 reduce): one query token per sequence; f32 logits; softmax with inv = 1/(sum + 1e-6);
+// masked logits zeroed; optional ALiBi, softcap (1.0 = off), attention sinks; probabilities are
+// rounded to the query dtype before P.V (ROUND_P) exactly like the reference's from_float(logits_vec).
+//
+// MI355X design (differs from the CUDA kernel on purpose):
+//   * GQA-aware: one workgroup serves G query heads that share a KV head, so every K/V byte is read
+//     from HBM once per group instead of once per query head (the reference launches one block per
+//     query head: 4x (8B) .. 8x (70B) more KV traffic);
+//   * wave64 mapping: a wave owns one 16/32-token KV block per iteration.  For Q.K^T lane l handles
+//     token l % BS and every LPT-th 16-byte chunk of the head dim (the K layout
+//     [blk][kvh][hd/x][BS][x] makes the 32 lanes of a chunk read one contiguous 512-byte span);
+//     for P.V lane l handles V row l / LPR (+ 64/LPR per step) and 16 bytes of tokens, so one wave
+//     load covers 1 KiB of contiguous V rows;
+//   * q for the G heads lives in LDS as f32 and is re-read per chunk (broadcast ds_read_b128);
+//     logits for the G heads live in LDS; softmax reductions use LDS + xor butterflies.
+#pragma once
+#include "common.cuh"
+#include <float.h>
+
+namespace mrs {
+
+template <class CT> __device__ __forceinline__ void unpack16(const int4 &raw, float *out);
+template <> __device__ __forceinline__ void unpack16<bf16_t>(const int4 &raw, float *o) {
+  const unsigned w[4] = {(unsigned)raw.x, (unsigned)raw.y, (unsigned)raw.z, (unsigned)raw.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { o[2 * i] = __uint_as_float(w[i] << 16); o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
+template <> __device__ __forceinline__ void unpack16<f16_t>(const int4 &raw, float *o) {
+  const unsigned w[4] = {(unsigned)raw.x, (unsigned)raw.y, (unsigned)raw.z, (unsigned)raw.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { o[2 * i] = half_bits_to_float((uint16_t)(w[i] & 0xffff)); o[2 * i + 1] = half_bits_to_float((uint16_t)(w[i] >> 16)); }
+}
+template <> __device__ __forceinline__ void unpack16<float>(const int4 &raw, float *o) {
+  o[0] = __int_as_float(raw.x); o[1] = __int_as_float(raw.y); o[2] = __int_as_float(raw.z); o[3] = __int_as_float(raw.w);
+}
+
+struct PagedAttnArgs {
+  float *exp_sums;    // v2: [seqs, heads, max_parts]
+  float *max_logits;  // v2
+  void *out;          // v1: [seqs, heads, hd] ; v2: tmp_out [seqs, heads, max_parts, hd]
+  const void *q;      // [seqs, heads, hd] with row stride q_stride
+  const void *k_cache, *v_cache;
+  const uint32_t *block_tables, *context_lens;
+  const float *alibi_slopes, *sinks;
+  int num_heads, num_kv_heads, max_num_blocks_per_seq, q_stride, kv_block_stride, kv_head_stride;
+  int logits_stride;  // padded tokens per head in LDS
+  float scale, softcapping;
+};
+
+// NW waves per workgroup
+template <class T, class CT, int HD, int BS, int G, int PART, bool ROUND_P, int NW = 4>
+__global__ void __launch_bounds__(NW * 64) paged_attention_kernel(const PagedAttnArgs a) {
+  constexpr int X = 16 / sizeof(CT);        // elements per 16 bytes
+  constexpr int NCH = HD / X;               // 16-byte chunks of the head dim
+  constexpr int LPT = 64 / BS;              // lanes per token in Q.K^T
+  constexpr int LPR = BS / X;               // lanes per V row
+  constexpr int RPI = 64 / LPR;             // V rows per wave step
+  constexpr int NI = (HD + RPI - 1) / RPI;  // steps over the head dim
+  static_assert(BS * LPT == 64 && LPR * X == BS && LPR >= 1, "unsupported block size");
+
+  const int seq = blockIdx.y, part = blockIdx.z, max_parts = gridDim.z;
+  const uint32_t ctx = a.context_lens[seq];
+  if (PART > 0 && (uint32_t)(part * PART) >= ctx) return;
+  const int num_ctx_blocks = (ctx + BS - 1) / BS;
+  const int blocks_per_part = PART > 0 ? PART / BS : num_ctx_blocks;
+  const int start_block = PART > 0 ? part * blocks_per_part : 0;
+  const int end_block = min(start_block + blocks_per_part, num_ctx_blocks);
+  const int start_tok = start_block * BS;
+  const int ntok = min(start_tok + (end_block - start_block) * BS, (int)ctx) - start_tok;
+
+  const int head0 = blockIdx.x * G;
+  const int kvh = head0 / (a.num_heads / a.num_kv_heads);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *q_s = (float *)smem;                   // [G][HD]
+  float *logits = q_s + G * HD;                 // [G][logits_stride]   (reused as out_s[NW][G][HD])
+  float *red = logits + (size_t)max(G * a.logits_stride, NW * G * HD);  // [2][G][NW]
+  const int LS = a.logits_stride;
+
+  const T *q = (const T *)a.q + (size_t)seq * a.q_stride + (size_t)head0 * HD;
+  for (int i = tid; i < G * HD; i += NW * 64) q_s[i] = to_f<T>(q[i]);
+  __syncthreads();
+
+  const uint32_t *block_table = a.block_tables + (size_t)seq * a.max_num_blocks_per_seq;
+  const CT *kc = (const CT *)a.k_cache + (size_t)kvh * a.kv_head_stride;
+  const CT *vc = (const CT *)a.v_cache + (size_t)kvh * a.kv_head_stride;
+
+  // ---------------------------------------------------------------- Q.K^T
+  float qk_max[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) qk_max[g] = -FLT_MAX;
+  const int tok_in_blk = lane % BS, cpart = lane / BS;
+  for (int b = start_block + wave; b < end_block; b += NW) {
+    const CT *kb = kc + (size_t)block_table[b] * a.kv_block_stride + tok_in_blk * X;
+    float acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = 0.f;
+#pragma unroll
+    for (int c0 = 0; c0 < NCH; c0 += LPT) {
+      const int c = c0 + cpart;
+      if (NCH % LPT == 0 || c < NCH) {
+        float kf[X];
+        unpack16<CT>(ld16_a16(kb + (size_t)c * BS * X), kf);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const float *qg = q_s + g * HD + c * X;
+#pragma unroll
+          for (int j = 0; j < X; ++j) acc[g] = fmaf(qg[j], kf[j], acc[g]);
+        }
+      }
+    }
+    const int token = b * BS + tok_in_blk;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      float v = acc[g];
+#pragma unroll
+      for (int m = BS; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+      float qk = a.scale * v;
+      if (a.softcapping != 1.0f) qk = tanhf(qk / a.softcapping) * a.softcapping;
+      if (a.alibi_slopes) { const float s = a.alibi_slopes[head0 + g]; qk += (s != 0.f) ? s * (float)(token - (int)ctx + 1) : 0.f; }
+      const bool masked = token >= (int)ctx;
+      if (cpart == 0) logits[g * LS + token - start_tok] = masked ? 0.f : qk;
+      if (!masked) qk_max[g] = fmaxf(qk_max[g], qk);
+    }
+  }
+  // max over the workgroup
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const float m = wave_max(qk_max[g]);
+    if (lane == 0) red[g * NW + wave] = m;
+  }
+  __syncthreads();
+  float gmax[G], esum[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    float m = red[g * NW];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) m = fmaxf(m, red[g * NW + w]);
+    if (PART == 0 && a.sinks) m = fmaxf(m, a.sinks[head0 + g]);
+    gmax[g] = m;
+    float s = 0.f;
+    for (int i = tid; i < ntok; i += NW * 64) { const float e = __expf(logits[g * LS + i] - m); logits[g * LS + i] = e; s += e; }
+    s = wave_sum(s);
+    if (lane == 0) red[G * NW + g * NW + wave] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += red[G * NW + g * NW + w];
+    if (PART == 0 && a.sinks) s += __expf(a.sinks[head0 + g] - gmax[g]);
+    esum[g] = s;
+    const float inv = 1.0f / (s + 1e-6f);
+    for (int i = tid; i < ntok; i += NW * 64) logits[g * LS + i] *= inv;
+  }
+  __syncthreads();
+  if (PART > 0 && tid < G) {
+    const size_t o = ((size_t)seq * a.num_heads + head0 + tid) * max_parts + part;
+    float m = 0.f, s = 0.f;
+#pragma unroll
+    for (int g = 0; g < G; ++g) if (g == tid) { m = gmax[g]; s = esum[g]; }
+    a.max_logits[o] = m;
+    a.exp_sums[o] = s;
+  }
+
+  // ---------------------------------------------------------------- P.V
+  float acc[G][NI];
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) acc[g][i] = 0.f;
+  const int vrow0 = lane / LPR, vtok0 = (lane % LPR) * X;
+  for (int b = start_block + wave; b < end_block; b += NW) {
+    const CT *vb = vc + (size_t)block_table[b] * a.kv_block_stride + vtok0;
+    const int token0 = b * BS + vtok0;
+    float p[G][X];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int j = 0; j < X; ++j) {
+        const float pv = logits[g * LS + token0 - start_tok + j];
+        p[g][j] = ROUND_P ? round_to<T>(pv) : pv;
+      }
+    const bool last = (b == num_ctx_blocks - 1);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int row = vrow0 + i * RPI;
+      if (HD % RPI == 0 || row < HD) {
+        float vf[X];
+        unpack16<CT>(ld16_a16(vb + (size_t)row * BS), vf);
+        if (last) {
+#pragma unroll
+          for (int j = 0; j < X; ++j) vf[j] = (token0 + j < (int)ctx) ? vf[j] : 0.f;  // stale slots may hold NaNs
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+          for (int j = 0; j < X; ++j) acc[g][i] = fmaf(p[g][j], vf[j], acc[g][i]);
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      float v = acc[g][i];
+#pragma unroll
+      for (int m = 1; m < LPR; m <<= 1) v += __shfl_xor(v, m, 64);
+      acc[g][i] = v;
+    }
+  __syncthreads();  // logits are dead: reuse as out_s[NW][G][HD]
+  float *out_s = logits;
+  if (lane % LPR == 0) {
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int row = vrow0 + i * RPI;
+        if (HD % RPI == 0 || row < HD) out_s[(wave * G + g) * HD + row] = acc[g][i];
+      }
+  }
+  __syncthreads();
+  T *out = (T *)a.out;
+  for (int i = tid; i < G * HD; i += NW * 64) {
+    const int g = i / HD, d = i % HD;
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += out_s[(w * G + g) * HD + d];
+    const size_t o = PART > 0 ? (((size_t)seq * a.num_heads + head0 + g) * max_parts + part) * HD + d
+                              : ((size_t)seq * a.num_heads + head0 + g) * HD + d;
+    out[o] = from_f<T>(s);
+  }
+}
+
+// v2 reduce: merge the per-partition partial outputs (pagedattention.cuh:516-660). grid (heads, seqs)
+template <class T, int HD, int PART>
+__global__ void __launch_bounds__(128) paged_attention_reduce_kernel(T *__restrict__ out, const float *__restrict__ exp_sums,
+                                                                     const float *__restrict__ max_logits, const T *__restrict__ tmp_out,
+                                                                     const uint32_t *__restrict__ context_lens, int max_parts,
+                                                                     const float *__restrict__ sinks) {
+  const int num_heads = gridDim.x, head = blockIdx.x, seq = blockIdx.y;
+  const int nparts = (context_lens[seq] + PART - 1) / PART;
+  const T *tmp = tmp_out + ((size_t)seq * num_heads + head) * max_parts * HD;
+  T *o = out + ((size_t)seq * num_heads + head) * HD;
+  if (nparts == 1 && sinks == nullptr) {
+    for (int i = threadIdx.x; i < HD; i += blockDim.x) o[i] = tmp[i];
+    return;
+  }
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *s_max = (float *)smem, *s_sum = s_max + nparts;
+  __shared__ float red[4];
+  const float *ml = max_logits + ((size_t)seq * num_heads + head) * max_parts;
+  const float *es = exp_sums + ((size_t)seq * num_heads + head) * max_parts;
+  float m = -FLT_MAX;
+  for (int i = threadIdx.x; i < nparts; i += blockDim.x) { s_max[i] = ml[i]; m = fmaxf(m, ml[i]); }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(red[0], red[1]);
+  if (sinks) m = fmaxf(m, sinks[head]);
+  float gs = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += blockDim.x) { const float r = es[i] * expf(s_max[i] - m); s_sum[i] = r; gs += r; }
+  gs = wave_sum(gs);
+  if ((threadIdx.x & 63) == 0) red[2 + (threadIdx.x >> 6)] = gs;
+  __syncthreads();
+  gs = red[2] + red[3];
+  if (sinks) gs += __expf(sinks[head] - m);
+  const float inv = 1.0f / (gs + 1e-6f);
+  for (int i = threadIdx.x; i < HD; i += blockDim.x) {
+    float acc = 0.f;
+    for (int j = 0; j < nparts; ++j) acc += to_f<T>(tmp[(size_t)j * HD + i]) * s_sum[j] * inv;
+    o[i] = from_f<T>(acc);
+  }
+}
+
+}  // namespace mrs

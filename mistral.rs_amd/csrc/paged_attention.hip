@@ -1,0 +1,165 @@
+// paged_attention.hip -- C-ABI launchers `paged_attention_v1_{f16,bf16,f32}` / `paged_attention_v2_*`.
+// Replaces mistralrs-paged-attn/src/cuda/pagedattention_v{1,2}_{f16,bf16,f32}.cu (+ launchers in
+// pagedattention.cuh:685-880).  Rust FFI: mistralrs-paged-attn/src/cuda/ffi.rs:269-378; caller:
+// backend/paged_attention.rs:103-410 (v1 when one 512-token partition or seqs*heads > 512, else v2).
+//
+// One translation unit per (query dtype, cache dtype) pair: build passes
+//   -DMRS_PA_T=mrs::bf16_t -DMRS_PA_CT=mrs::bf16_t -DMRS_PA_TAG=bf16 [-DMRS_PA_EXPORT_ABI]
+#include "paged_attention.cuh"
+#include <stdio.h>
+#include <stdlib.h>
+
+namespace mrs {
+
+constexpr int PA_PARTITION = 512;  // paged_attention.rs:302-307 sizes the v2 workspace for 512-token partitions
+constexpr int PA_NW = 4;
+constexpr size_t PA_LDS_MAX = 150 * 1024;
+
+static void pa_check(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { fprintf(stderr, "HIP error in %s: %s\n", what, hipGetErrorString(e)); exit((int)e); }
+}
+
+static size_t pa_lds_bytes(int G, int HD, int LS) {
+  const size_t body = (size_t)G * LS > (size_t)PA_NW * G * HD ? (size_t)G * LS : (size_t)PA_NW * G * HD;
+  return ((size_t)G * HD + body + 2 * (size_t)G * PA_NW) * sizeof(float);
+}
+
+template <class T, class CT, int HD, int BS, int G, int PART>
+static void pa_launch(const PagedAttnArgs &a, int num_seqs, int max_parts, hipStream_t s) {
+  auto kern = paged_attention_kernel<T, CT, HD, BS, G, PART, true, PA_NW>;
+  const size_t lds = pa_lds_bytes(G, HD, a.logits_stride);
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  hipLaunchKernelGGL(kern, dim3(a.num_heads / G, num_seqs, PART > 0 ? max_parts : 1), dim3(PA_NW * 64), lds, s, a);
+}
+
+template <class T, class CT, int HD, int BS, int PART>
+static void pa_pick_g(const PagedAttnArgs &a, int num_seqs, int max_parts, hipStream_t s) {
+  const int qpk = a.num_heads / a.num_kv_heads;
+  auto fits = [&](int G) { return qpk % G == 0 && pa_lds_bytes(G, HD, a.logits_stride) <= PA_LDS_MAX; };
+  if constexpr (HD <= 128 && BS >= 16) {
+    if (fits(8)) return pa_launch<T, CT, HD, BS, 8, PART>(a, num_seqs, max_parts, s);
+    if (fits(4)) return pa_launch<T, CT, HD, BS, 4, PART>(a, num_seqs, max_parts, s);
+    if (fits(2)) return pa_launch<T, CT, HD, BS, 2, PART>(a, num_seqs, max_parts, s);
+  }
+  if (!fits(1)) {
+    fprintf(stderr, "paged_attention (gfx950): context of %d tokens does not fit the 160 KiB LDS logits buffer; use v2\n", a.logits_stride);
+    exit(2);
+  }
+  pa_launch<T, CT, HD, BS, 1, PART>(a, num_seqs, max_parts, s);
+}
+
+template <class T, class CT, int BS, int PART>
+static void pa_pick_hd(const PagedAttnArgs &a, int head_size, int num_seqs, int max_parts, hipStream_t s) {
+  switch (head_size) {  // the reference's head-size table (pagedattention.cuh:712-745)
+  case 64: pa_pick_g<T, CT, 64, BS, PART>(a, num_seqs, max_parts, s); break;
+  case 80: pa_pick_g<T, CT, 80, BS, PART>(a, num_seqs, max_parts, s); break;
+  case 96: pa_pick_g<T, CT, 96, BS, PART>(a, num_seqs, max_parts, s); break;
+  case 112: pa_pick_g<T, CT, 112, BS, PART>(a, num_seqs, max_parts, s); break;
+  case 128: pa_pick_g<T, CT, 128, BS, PART>(a, num_seqs, max_parts, s); break;
+  case 192: pa_pick_g<T, CT, 192, BS, PART>(a, num_seqs, max_parts, s); break;
+  case 256: pa_pick_g<T, CT, 256, BS, PART>(a, num_seqs, max_parts, s); break;
+  case 512: pa_pick_g<T, CT, 512, BS, PART>(a, num_seqs, max_parts, s); break;
+  default: break;  // silently ignored by the reference as well
+  }
+}
+
+template <class T, int PART> static void pa_reduce(void *out, const float *exp_sums, const float *max_logits, const void *tmp_out,
+                                                   const uint32_t *context_lens, int max_parts, const float *sinks, int head_size,
+                                                   int num_heads, int num_seqs, hipStream_t s) {
+  const dim3 grid(num_heads, num_seqs), block(128);
+  const size_t lds = 2 * (size_t)max_parts * sizeof(float);
+#define RED(HD) hipLaunchKernelGGL((paged_attention_reduce_kernel<T, HD, PART>), grid, block, lds, s, (T *)out, exp_sums, max_logits, (const T *)tmp_out, context_lens, max_parts, sinks)
+  switch (head_size) {
+  case 64: RED(64); break; case 80: RED(80); break; case 96: RED(96); break; case 112: RED(112); break;
+  case 128: RED(128); break; case 192: RED(192); break; case 256: RED(256); break; case 512: RED(512); break;
+  default: break;
+  }
+#undef RED
+}
+
+template <class T, class CT>
+void paged_attention_dispatch(bool v2, void *out, float *exp_sums, float *max_logits, void *tmp_out, const void *query,
+                              const void *key_cache, const void *value_cache, const void *alibi_slopes, int num_kv_heads,
+                              float scale, float softcapping, const uint32_t *block_tables, const uint32_t *context_lens,
+                              int block_size, int max_context_len, int num_seqs, int num_heads, int head_size,
+                              int max_num_blocks_per_seq, int q_stride, int kv_block_stride, int kv_head_stride,
+                              hipStream_t stream, const float *sinks) {
+  if (num_seqs <= 0 || num_heads <= 0) return;
+  PagedAttnArgs a{};
+  a.exp_sums = exp_sums; a.max_logits = max_logits; a.out = v2 ? tmp_out : out; a.q = query;
+  a.k_cache = key_cache; a.v_cache = value_cache; a.block_tables = block_tables; a.context_lens = context_lens;
+  a.alibi_slopes = (const float *)alibi_slopes; a.sinks = sinks;
+  a.num_heads = num_heads; a.num_kv_heads = num_kv_heads; a.max_num_blocks_per_seq = max_num_blocks_per_seq;
+  a.q_stride = q_stride; a.kv_block_stride = kv_block_stride; a.kv_head_stride = kv_head_stride;
+  a.scale = scale; a.softcapping = softcapping;
+  const int max_parts = (max_context_len + PA_PARTITION - 1) / PA_PARTITION;
+  a.logits_stride = v2 ? PA_PARTITION : (max_context_len + block_size - 1) / block_size * block_size;
+  if (a.logits_stride < block_size) a.logits_stride = block_size;
+#define BS_CASE(BS)                                                                                    \
+  case BS:                                                                                             \
+    if (v2) pa_pick_hd<T, CT, BS, PA_PARTITION>(a, head_size, num_seqs, max_parts, stream);            \
+    else pa_pick_hd<T, CT, BS, 0>(a, head_size, num_seqs, max_parts, stream);                          \
+    break;
+  switch (block_size) { BS_CASE(8) BS_CASE(16) BS_CASE(32) default: break; }
+#undef BS_CASE
+  if (v2) pa_reduce<T, PA_PARTITION>(out, exp_sums, max_logits, tmp_out, context_lens, max_parts, sinks, head_size, num_heads, num_seqs, stream);
+  pa_check(v2 ? "paged_attention_v2" : "paged_attention_v1");
+}
+
+}  // namespace mrs
+
+using mrs::bf16_t;
+using mrs::f16_t;
+
+#define PA_CAT_(a, b) a##b
+#define PA_CAT(a, b) PA_CAT_(a, b)
+
+// MI355X-native entry: explicit (query dtype, cache dtype) pair, used by the fused decode path
+extern "C" void PA_CAT(mrs_paged_attention_, MRS_PA_TAG)(
+    int v2, void *out, float *exp_sums, float *max_logits, void *tmp_out, const void *query, const void *key_cache,
+    const void *value_cache, const void *alibi_slopes, int num_kv_heads, float scale, float softcapping,
+    const uint32_t *block_tables, const uint32_t *context_lens, int block_size, int max_context_len, int num_seqs,
+    int num_heads, int head_size, int max_num_blocks_per_seq, int q_stride, int kv_block_stride, int kv_head_stride,
+    void *stream, const float *sinks) {
+  mrs::paged_attention_dispatch<MRS_PA_T, MRS_PA_CT>(v2 != 0, out, exp_sums, max_logits, tmp_out, query, key_cache, value_cache,
+                                                     alibi_slopes, num_kv_heads, scale, softcapping, block_tables, context_lens,
+                                                     block_size, max_context_len, num_seqs, num_heads, head_size,
+                                                     max_num_blocks_per_seq, q_stride, kv_block_stride, kv_head_stride,
+                                                     (hipStream_t)stream, sinks);
+}
+
+#ifdef MRS_PA_EXPORT_ABI
+// The reference ABI: query dtype in the symbol name, cache dtype code 0 f16 / 1 bf16 / 2 f32 / 3 fp8-e4m3.
+// Like the reference, a non-fp8 cache is read as the query dtype (pagedattention_v1_bf16.cu:22-29).
+static void pa_abi_guard(uint32_t cache_dtype) {
+  if (cache_dtype == 3) { fprintf(stderr, "paged_attention (gfx950): fp8 KV cache not supported yet\n"); exit(2); }
+}
+extern "C" void PA_CAT(paged_attention_v1_, MRS_PA_TAG)(
+    void *out, void *query, void *key_cache, void *value_cache, void *alibi_slopes, int32_t num_kv_heads, float scale,
+    float softcapping, uint32_t *block_tables, uint32_t *context_lens, int32_t block_size, int32_t max_context_len,
+    int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t max_num_blocks_per_seq, int32_t q_stride,
+    int32_t kv_block_stride, int32_t kv_head_stride, hipStream_t stream, uint32_t cache_dtype, float *k_scale,
+    float *v_scale, const float *sinks) {
+  (void)k_scale; (void)v_scale;
+  pa_abi_guard(cache_dtype);
+  mrs::paged_attention_dispatch<MRS_PA_T, MRS_PA_CT>(false, out, nullptr, nullptr, nullptr, query, key_cache, value_cache, alibi_slopes,
+                                                     num_kv_heads, scale, softcapping, block_tables, context_lens, block_size,
+                                                     max_context_len, num_seqs, num_heads, head_size, max_num_blocks_per_seq,
+                                                     q_stride, kv_block_stride, kv_head_stride, stream, sinks);
+}
+extern "C" void PA_CAT(paged_attention_v2_, MRS_PA_TAG)(
+    void *out, float *exp_sums, float *max_logits, void *tmp_out, void *query, void *key_cache, void *value_cache,
+    void *alibi_slopes, int32_t num_kv_heads, float scale, float softcapping, uint32_t *block_tables,
+    uint32_t *context_lens, int32_t block_size, int32_t max_context_len, int32_t num_seqs, int32_t num_heads,
+    int32_t head_size, int32_t max_num_blocks_per_seq, int32_t q_stride, int32_t kv_block_stride, int32_t kv_head_stride,
+    hipStream_t stream, uint32_t cache_dtype, float *k_scale, float *v_scale, const float *sinks) {
+  (void)k_scale; (void)v_scale;
+  pa_abi_guard(cache_dtype);
+  mrs::paged_attention_dispatch<MRS_PA_T, MRS_PA_CT>(true, out, exp_sums, max_logits, tmp_out, query, key_cache, value_cache,
+                                                     alibi_slopes, num_kv_heads, scale, softcapping, block_tables, context_lens,
+                                                     block_size, max_context_len, num_seqs, num_heads, head_size,
+                                                     max_num_blocks_per_seq, q_stride, kv_block_stride, kv_head_stride, stream, sinks);
+}
+#endif

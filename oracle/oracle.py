@@ -225,3 +225,57 @@ def patterned(n: int, salt: int, scale: float) -> np.ndarray:
     ((i*37 + salt*19) % 211 / 105 - 1) * scale."""
     i = np.arange(n, dtype=np.int64)
     return (((i * 37 + salt * 19) % 211).astype(np.float32) / 105.0 - 1.0) * np.float32(scale)
+
+
+# ---------------------------------------------------------------- paged KV cache (numpy, small cases)
+def kv_cache_write(key_cache: np.ndarray, value_cache: np.ndarray, key: np.ndarray, value: np.ndarray,
+                   slot_mapping: np.ndarray) -> None:
+    """reshape_and_cache semantics (reshape_and_cache_kernel.cu): K [nb,kvh,hd/x,bs,x], V [nb,kvh,hd,bs];
+    negative slots are skipped."""
+    nb, kvh, hdx, bs, x = key_cache.shape
+    for t, slot in enumerate(slot_mapping):
+        if slot < 0:
+            continue
+        b, o = divmod(int(slot), bs)
+        key_cache[b, :, :, o, :] = key[t].reshape(kvh, hdx, x)
+        value_cache[b, :, :, o] = value[t]
+
+
+def kv_cache_gather(key_cache: np.ndarray, value_cache: np.ndarray, block_table: np.ndarray, ctx: int):
+    """-> dense K, V [ctx, kvh, hd] for one sequence."""
+    nb, kvh, hdx, bs, x = key_cache.shape
+    ks, vs = [], []
+    for pos in range(ctx):
+        b, o = int(block_table[pos // bs]), pos % bs
+        ks.append(key_cache[b, :, :, o, :].reshape(kvh, hdx * x))
+        vs.append(value_cache[b, :, :, o])
+    return np.stack(ks), np.stack(vs)
+
+
+def paged_attention_ref(q, key_cache, value_cache, block_tables, context_lens, scale, softcap=1.0, alibi=None,
+                        sinks=None, round_p=None):
+    """Decode attention semantics of pagedattention.cuh:110-486: one query per sequence, softmax over the
+    context with inv = 1/(sum + 1e-6), optional sink logit, probabilities optionally rounded through
+    `round_p(array)->array` (the reference rounds them to the query dtype) before P.V.  f64 arithmetic."""
+    q = np.asarray(q, dtype=np.float64)
+    seqs, heads, hd = q.shape
+    kvh = key_cache.shape[1]
+    out = np.zeros((seqs, heads, hd))
+    for s in range(seqs):
+        ctx = int(context_lens[s])
+        k, v = kv_cache_gather(key_cache.astype(np.float64), value_cache.astype(np.float64), block_tables[s], ctx)
+        for h in range(heads):
+            g = h // (heads // kvh)
+            logit = scale * (k[:, g, :] @ q[s, h])
+            if softcap != 1.0:
+                logit = np.tanh(logit / softcap) * softcap
+            if alibi is not None and alibi[h] != 0:
+                logit = logit + alibi[h] * (np.arange(ctx) - ctx + 1)
+            m = logit.max() if sinks is None else max(logit.max(), float(sinks[h]))
+            e = np.exp(logit - m)
+            den = e.sum() + (np.exp(float(sinks[h]) - m) if sinks is not None else 0.0)
+            p = e * (1.0 / (den + 1e-6))
+            if round_p is not None:
+                p = round_p(p.astype(np.float32)).astype(np.float64)
+            out[s, h] = p @ v[:, g, :]
+    return out.astype(np.float32)
