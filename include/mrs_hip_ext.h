@@ -1,0 +1,99 @@
+/*
+ * include/mrs_hip_ext.h -- C ABI of libmrs_hip_ext.so: MI355X-native additions that have no counterpart
+ * symbol in the reference (fused decode kernels + the host-side model runner written in C++ because the
+ * reference host is compiled Rust and there is no Rust toolchain here).
+ *
+ * Everything is plain pointers + sizes, asynchronous on the given hipStream_t (void *stream), never
+ * allocates device memory.  Functions returning int use 0 = ok, <0 = refused (mrs_last_error() says why).
+ */
+#ifndef MRS_HIP_EXT_H
+#define MRS_HIP_EXT_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- fused decode kernels (ext_decode.hip)
+ * Activations/residual stream f32, weights raw GGUF blocks (types q4_k q5_k q6_k q8_0), KV cache bf16 in the
+ * reference's paged layout.  Each call replaces a run of reference launches (models/llama.rs:68-157,243-260):
+ *   mrs_decode_qkv        = RmsNorm + quantize_q8_1 + fused_qkv GEMV + rotary_embedding_positions + reshape_and_cache
+ *   mrs_decode_gate_up    = RmsNorm + quantize_q8_1 + fused_glu GEMV + quantize_q8_1 (of the GLU output)
+ *   mrs_decode_proj       = plain GEMV (+ residual add)
+ *   mrs_decode_norm_proj  = RmsNorm + quantize_q8_1 + plain GEMV (final norm + lm_head)
+ * and produces bit-identical results to that sequence of C-ABI launches. */
+int mrs_decode_gemv_supported(int ggml_type);
+int mrs_decode_qkv(const void *wq, const void *wk, const void *wv, int tq, int tk, int tv, int nq, int nk, int nv, int K,
+                   const float *h, const float *norm_w, float eps, float *q_out, void *k_cache, void *v_cache,
+                   const int64_t *slot_mapping, const int32_t *positions, const float *cos_t, const float *sin_t,
+                   int head_dim, int rot_pairs, int num_kv_heads, int block_size, int b, void *stream);
+int mrs_decode_gate_up(const void *wg, const void *wu, int type, int n, int K, const float *h, const float *norm_w, float eps,
+                       int activation, void *y_out, int y_out_stride, int b, void *stream);
+int mrs_decode_proj(const void *w, int type, int n, int K, const void *y_q8_1, int stride_col_y, float *out, int out_stride,
+                    int accumulate, int b, void *stream);
+int mrs_decode_norm_proj(const void *w, int type, int n, int K, const float *h, const float *norm_w, float eps, float *out,
+                         int out_stride, int b, void *stream);
+/* quantized (or f32/f16/bf16) embedding rows -> f32; role of QuantMethod::embedding_forward (lib.rs:1561, gguf/mod.rs:436) */
+int mrs_embedding(const void *table, int type, const int32_t *ids, float *out, int K, int tokens, void *stream);
+/* f32 rows -> Q8_1 blocks: same bytes as launch_mmvq_gguf_quantize_q8_1_f32 with kx_padded = 32*stride_blocks */
+int mrs_quantize_rows_q8_1(const float *x, void *y, int K, int stride_blocks, int rows, void *stream);
+/* greedy top-1 (first maximum wins) + on-device advance of the decode state, so a captured decode step
+ * replays with no host work (role of sample_causal_gen greedy, pipeline/mod.rs:2485 + inputs_processor slot math
+ * pipeline/inputs_processor.rs:900-922). scratch: 8*b bytes, zero-initialised once. */
+int mrs_sample_greedy_advance(const float *logits, int vocab, int b, int32_t *next_ids, int32_t *tokens_out,
+                              int tokens_out_stride, int32_t *step_counter, int32_t *positions, uint32_t *context_lens,
+                              int64_t *slot_mapping, const uint32_t *block_tables, int max_blocks, int block_size,
+                              void *scratch, void *stream);
+
+/* ---------------------------------------------------------------- host-side model runner (host/runtime.cpp)
+ * C++ mirror of mistralrs-core/src/models/llama.rs (Llama / CausalSelfAttention / Mlp / Block) on top of
+ * QuantMethod objects (mistralrs-quant/src/lib.rs:1515-1688, gguf/mod.rs GgufMatMul), exposed through handles. */
+typedef struct {
+  int32_t hidden_size, intermediate_size, num_layers, num_heads, num_kv_heads, head_dim, vocab_size;
+  int32_t rot_dim;            /* rotated dims per head (<= head_dim) */
+  int32_t rope_interleaved;   /* 1: GGUF llama/mistral pairing (2i,2i+1); 0: neox halves */
+  float rms_eps;
+  int32_t block_size;         /* paged KV block size (tokens) */
+  int32_t max_blocks_per_seq;
+  int32_t max_batch;          /* decode batch capacity (<= 8) */
+  int32_t max_context_len;
+  int32_t use_fused;          /* 1: ext_decode fused kernels when the weight types allow; 0: reference launch sequence */
+  int32_t world_size, rank;   /* tensor parallel (1, 0 = single GPU) */
+} mrs_llama_config;
+
+typedef struct {  /* all device pointers, owned by the caller */
+  int32_t *input_ids;       /* [max_batch] */
+  int32_t *positions;       /* [max_batch] */
+  uint32_t *context_lens;   /* [max_batch] */
+  int64_t *slot_mapping;    /* [max_batch] */
+  uint32_t *block_tables;   /* [max_batch, max_blocks_per_seq] */
+  int32_t *tokens_out;      /* [max_batch, tokens_out_stride] generated ids */
+  int32_t tokens_out_stride;
+  int32_t *step_counter;    /* [1] */
+  const float *cos_table;   /* [max_pos, rot_dim/2] f32 */
+  const float *sin_table;
+  float *logits;            /* [max_batch, vocab] */
+  void *workspace;          /* scratch, >= mrs_llama_workspace_bytes() */
+  size_t workspace_bytes;
+} mrs_llama_buffers;
+
+size_t mrs_llama_workspace_bytes(const mrs_llama_config *cfg);
+void *mrs_llama_create(const mrs_llama_config *cfg);
+void mrs_llama_destroy(void *model);
+/* name = GGUF tensor name ("token_embd.weight", "blk.3.attn_q.weight", "output_norm.weight", ...: the binding table of
+ * mistralrs-core/src/gguf/normal_bindings.rs:40-220); shape [n_rows, n_cols]; data stays owned by the caller */
+int mrs_llama_set_tensor(void *model, const char *name, const void *dev_ptr, int ggml_type, int64_t n_rows, int64_t n_cols);
+int mrs_llama_set_kv_cache(void *model, int layer, void *key_cache, void *value_cache);
+int mrs_llama_set_buffers(void *model, const mrs_llama_buffers *bufs);
+/* one decode step for b sequences: embedding -> L x Block -> norm -> lm_head -> greedy sample + state advance */
+int mrs_llama_decode_step(void *model, int b, void *stream);
+/* same graph without sampling: leaves logits [b, vocab] (parity tests read them) */
+int mrs_llama_forward_logits(void *model, int b, void *stream);
+/* bytes of weights + KV streamed from HBM by one decode step at the given context (roofline numerator) */
+double mrs_llama_decode_bytes(void *model, int b, int context_len);
+const char *mrs_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

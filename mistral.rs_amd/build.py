@@ -97,12 +97,15 @@ def build(jobs: int | None = None, force: bool = False, verbose: bool = True) ->
     out = {}
     with cf.ThreadPoolExecutor(jobs) as ex:
         futs = {name: [ex.submit(_compile, *tu, force, hdr_m) for tu in tus] for name, tus in libs.items()}
-        for name, fl in futs.items():
+        for name, fl in sorted(futs.items(), key=lambda kv: kv[0] == "libmrs_hip_ext.so"):  # ext links last
             res = [f.result() for f in fl]
             objs = [o for o, _ in res]
             target = os.path.join(LIB, name)
             if force or any(ch for _, ch in res) or not os.path.exists(target):
                 cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", target, *objs]
+                if name == "libmrs_hip_ext.so":  # the runner calls the drop-in symbols of the other three
+                    cmd += ["-L" + LIB, "-lmistralrsquant", "-lmistralrspagedattention", "-lmistralrscuda",
+                            "-Wl,-rpath,$ORIGIN", "-ldl"]
                 r = subprocess.run(cmd, capture_output=True, text=True)
                 if r.returncode != 0:
                     raise RuntimeError(f"link failed for {name}:\n{r.stderr[-4000:]}")

@@ -77,6 +77,16 @@ __device__ __forceinline__ int4 ld16_a16(const void *p) { int4_a16 v = *(const i
 __device__ __forceinline__ int ld4_a2(const void *p) { return *(const int1_a2 *)p; }
 __device__ __forceinline__ uint16_t ld2(const void *p) { return *(const uint16_t *)p; }
 
+// RoPE rotation of one pair: every product and the final sum round to T (the reference does the arithmetic
+// in the tensor dtype, rotary.cu:9-33) and nothing is FMA-contracted, so the fused decode epilogue, the
+// standalone rotary kernel and the CPU oracle agree bit-for-bit.  Results still need from_f<T>().
+template <class T> __device__ __forceinline__ void rope_pair(float x, float y, float c, float s, float &xo, float &yo) {
+#pragma clang fp contract(off)
+  const float xc = round_to<T>(x * c), ys = round_to<T>(y * s), yc = round_to<T>(y * c), xs = round_to<T>(x * s);
+  xo = xc - ys;
+  yo = yc + xs;
+}
+
 // GLU activations -- codes as mistralrs-quant/src/utils/ops.rs:2601-2607 / mmvq_gguf.cu:44-85
 __device__ __forceinline__ float glu_act(float x, int act) {
   switch (act) {

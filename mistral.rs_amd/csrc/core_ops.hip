@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(RN_THREADS) rms_norm_kernel(const T *__restric
           store_vec<T>(residual_dst + row + (size_t)v * N, cache[j]);
         }
 #pragma unroll
-        for (int i = 0; i < N; ++i) sum += cache[j][i] * cache[j][i];
+        for (int i = 0; i < N; ++i) sum = fmaf(cache[j][i], cache[j][i], sum);
       }
     }
     for (int v = tid + RN_MAXV * RN_THREADS; v < nvec; v += RN_THREADS) {  // very long rows: uncached tail
@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(RN_THREADS) rms_norm_kernel(const T *__restric
         store_vec<T>(residual_dst + row + (size_t)v * N, t);
       }
 #pragma unroll
-      for (int i = 0; i < N; ++i) sum += t[i] * t[i];
+      for (int i = 0; i < N; ++i) sum = fmaf(t[i], t[i], sum);
     }
     const float inv = rsqrtf(block_sum_256(sum, red) / (float)ncols + eps);
     const float sc = (MODE == 2 && scale) ? to_f<T>(scale[0]) : 1.0f;

@@ -1,0 +1,426 @@
+// ext_decode.hip -- MI355X-native fused decode path (not in the reference ABI; exported as mrs_*).
+//
+// The reference issues ~9 launches + 2 norms per decoder layer in decode: quantize, fused
+// QKV GEMV, RoPE, reshape_and_cache, paged attention, quantize, o_proj GEMV, add, norm, quantize,
+// gate/up GEMV(+GLU), quantize, down GEMV, add.  At batch 1 every GEMV is a 2-12 us HBM stream, so
+// the ~1.5 us kernel boundaries and the tiny elementwise launches are a large fraction of the token
+// time on MI355X.  Here each layer is FIVE launches built from the same GEMV core (mmvq_core.cuh):
+//
+//   1. qkv      prologue: RMSNorm(h)*w -> Q8_1 in LDS      epilogue: RoPE(q,k) -> q (f32), k/v -> paged cache
+//   2. attn     paged attention over the cache (ext: split-KV + merge) -> Q8_1 blocks for o_proj
+//   3. o_proj   prologue: stage Q8_1                        epilogue: h += W_o . attn
+//   4. gate/up  prologue: RMSNorm(h)*w -> Q8_1 in LDS      epilogue: silu(g)*u -> Q8_1 blocks
+//   5. down     prologue: stage Q8_1                        epilogue: h += W_d . act
+//
+// Numerics are those of the reference CPU path's dataflow (f32 residual stream, f32 norm / RoPE / SiLU,
+// SURVEY 3.4) combined with the reference GPU path's Q8_1 activation quantisation (mmvq_gguf.cu), and are
+// bit-identical to running the unfused C-ABI kernels in sequence (tests/test_ext_decode.py).
+#include "mmvq_core.cuh"
+#include <stdio.h>
+#include <stdlib.h>
+
+namespace mrs {
+
+enum : int { PRO_Q8_1 = 0, PRO_NORM = 1 };
+enum : int { EPI_STORE = 0, EPI_RESID_ADD = 1, EPI_GLU_Q8_1 = 2, EPI_QKV_ROPE = 3 };
+
+struct DecodeGemvArgs {
+  const uint8_t *w[3];
+  int wtype[3];
+  int nrows[3];
+  int K;
+  // prologue
+  const uint8_t *y_q8_1;  // PRO_Q8_1: [b][stride_col_y] blocks
+  int stride_col_y;
+  const float *x;         // PRO_NORM: [b][K] f32 residual stream
+  const float *norm_w;    // [K]
+  float eps;
+  // epilogue
+  float *out;             // STORE / RESID_ADD: out[c*out_stride + row]
+  int out_stride;
+  uint8_t *y_out;         // GLU_Q8_1: [b][y_out_stride] Q8_1 blocks
+  int y_out_stride;
+  int activation;
+  float *q_out;           // QKV_ROPE: [b][nrows[0]]
+  void *k_cache, *v_cache;
+  const int64_t *slot_mapping;  // [b]
+  const int32_t *positions;     // [b]
+  const float *cos_t, *sin_t;   // [max_pos][rot_pairs]
+  int head_dim, rot_pairs, num_kv_heads, block_size, cache_x;
+  int rows_per_wg;
+};
+
+// fixed-order block reduction shared by the fused prologue and the standalone norm+quantize kernel
+template <int NT> __device__ __forceinline__ float block_sum_fixed(float v, float *red) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) s += red[w];
+  __syncthreads();
+  return s;
+}
+
+// RMSNorm(x)*w -> Q8_1 activation image in LDS (same bytes the C-ABI quantizer would produce from the
+// f32 normed row): q [col][K] int8, d8 [col][K/32] = float(half(amax/127)), S [col][K/16] = d8 * sum(q).
+// xs: f32 scratch [K] in LDS.
+template <int NCOLS, int NT>
+__device__ __forceinline__ ActLds stage_norm_q8_1(char *smem, const float *__restrict__ x, const float *__restrict__ nw, int K, float eps) {
+  const int runs = K / 16, nblk = K / 32;
+  int8_t *q = (int8_t *)smem;
+  float *d8 = (float *)(smem + (size_t)NCOLS * K);
+  float *S = d8 + (size_t)NCOLS * nblk;
+  float *xs = S + (size_t)NCOLS * runs;
+  float *red = xs + K;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int c = 0; c < NCOLS; ++c) {
+    const float *xr = x + (size_t)c * K;
+    float ss = 0.f;
+    for (int i = tid * 4; i < K; i += NT * 4) {
+      const float4 v = *(const float4 *)(xr + i);
+      *(float4 *)(xs + i) = v;
+      ss = fmaf(v.x, v.x, ss); ss = fmaf(v.y, v.y, ss); ss = fmaf(v.z, v.z, ss); ss = fmaf(v.w, v.w, ss);
+    }
+    const float inv = rsqrtf(block_sum_fixed<NT>(ss, red) / (float)K + eps);  // (barrier inside: xs visible)
+    for (int e = wave * 64 + lane; e < K; e += NT) {  // a wave owns two adjacent 32-blocks per step
+      const float v = xs[e] * inv * nw[e];
+      float amax = fabsf(v);
+#pragma unroll
+      for (int m = 16; m > 0; m >>= 1) amax = fmaxf(amax, __shfl_xor(amax, m, 64));
+      const float d = amax / 127.0f;
+      const int qi = amax == 0.0f ? 0 : (int)roundf(v / d);
+      q[(size_t)c * K + e] = (int8_t)qi;
+      int su = qi;
+#pragma unroll
+      for (int m = 8; m > 0; m >>= 1) su += __shfl_xor(su, m, 64);
+      const float dh = half_bits_to_float(float_to_half_bits(d));
+      if ((e & 31) == 0) d8[c * nblk + (e >> 5)] = dh;
+      if ((e & 15) == 0) S[c * runs + (e >> 4)] = dh * (float)su;
+    }
+    __syncthreads();
+  }
+  return ActLds{(const int4 *)q, d8, S, runs};
+}
+
+__host__ __device__ inline size_t norm_lds_bytes(int K, int ncols) {
+  return (size_t)ncols * ((size_t)K + (size_t)(K / 32) * 4 + (size_t)(K / 16) * 4) + (size_t)K * 4 + 64;
+}
+
+// wave-uniform runtime dispatch over the formats the fused path supports (K-quants + Q8_0)
+#define MRS_HOT_TYPE_SWITCH(t, ...)                              \
+  switch (t) {                                                   \
+  case T_Q4_K: { constexpr int TT = T_Q4_K; __VA_ARGS__ } break; \
+  case T_Q5_K: { constexpr int TT = T_Q5_K; __VA_ARGS__ } break; \
+  case T_Q6_K: { constexpr int TT = T_Q6_K; __VA_ARGS__ } break; \
+  case T_Q8_0: { constexpr int TT = T_Q8_0; __VA_ARGS__ } break; \
+  default: break;                                                \
+  }
+
+__device__ __forceinline__ size_t hot_row_bytes(int t, int K) {
+  switch (t) {
+  case T_Q4_K: return (size_t)(K / 256) * 144;
+  case T_Q5_K: return (size_t)(K / 256) * 176;
+  case T_Q6_K: return (size_t)(K / 256) * 210;
+  default: return (size_t)(K / 32) * 34;
+  }
+}
+
+template <int NCOLS, int PRO, int EPI, int NT>
+__global__ void __launch_bounds__(NT) decode_gemv_kernel(const DecodeGemvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NW = NT / 64;
+  const int K = a.K;
+  ActLds act;
+  size_t act_bytes;
+  if constexpr (PRO == PRO_NORM) { act = stage_norm_q8_1<NCOLS, NT>(smem, a.x, a.norm_w, K, a.eps); act_bytes = norm_lds_bytes(K, NCOLS); }
+  else { act = stage_q8_1<T_Q4_K, NCOLS>(smem, a.y_q8_1, K, a.stride_col_y); act_bytes = act_lds_bytes(K, NCOLS, true); __syncthreads(); }
+  float *out_s = (float *)(smem + ((act_bytes + 15) & ~(size_t)15));  // EPI_GLU_Q8_1: [rows_per_wg][NCOLS]
+
+  const int nslices = K / 32;
+  const int total_rows = (EPI == EPI_QKV_ROPE) ? a.nrows[0] + a.nrows[1] + a.nrows[2] : a.nrows[0];
+  const int row0 = blockIdx.x * a.rows_per_wg;
+  const int row1 = min(row0 + a.rows_per_wg, total_rows);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+
+  if constexpr (EPI == EPI_GLU_Q8_1) {
+    const size_t rb = hot_row_bytes(a.wtype[0], K);
+    for (int r = row0 + wave; r < row1; r += NW) {
+      float g[NCOLS], u[NCOLS];
+      MRS_HOT_TYPE_SWITCH(a.wtype[0], (row_dot2<TT, NCOLS>(a.w[0] + (size_t)r * rb, a.w[1] + (size_t)r * rb, nslices, act, g, u));)
+      if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < NCOLS; ++c) out_s[(r - row0) * NCOLS + c] = glu_act(g[c], a.activation) * u[c];
+      }
+    }
+    __syncthreads();
+    // quantize this workgroup's rows (a multiple of 32) to Q8_1 blocks: lane <-> row inside a 32-block
+    const int nblk = (row1 - row0) / 32;
+    for (int i = threadIdx.x; i < nblk * 32 * NCOLS; i += NT) {
+      const int c = i / (nblk * 32), e = i % (nblk * 32);
+      const float v = out_s[e * NCOLS + c];
+      float amax = fabsf(v), sum = v;
+#pragma unroll
+      for (int m = 16; m > 0; m >>= 1) { amax = fmaxf(amax, __shfl_xor(amax, m, 64)); sum += __shfl_xor(sum, m, 64); }
+      const float d = amax / 127.0f;
+      uint8_t *blk = a.y_out + ((size_t)c * a.y_out_stride + (row0 + e) / 32) * 36;
+      ((int8_t *)(blk + 4))[e & 31] = amax == 0.0f ? (int8_t)0 : (int8_t)roundf(v / d);
+      if ((e & 31) == 0) { ((uint16_t *)blk)[0] = float_to_half_bits(d); ((uint16_t *)blk)[1] = float_to_half_bits(sum); }
+    }
+  } else if constexpr (EPI == EPI_QKV_ROPE) {
+    for (int r = row0 + 2 * wave; r < row1; r += 2 * NW) {  // interleaved RoPE pairs (2i, 2i+1) stay in one wave
+      int m = 0, lr = r;
+      if (r >= a.nrows[0] + a.nrows[1]) { m = 2; lr = r - a.nrows[0] - a.nrows[1]; }
+      else if (r >= a.nrows[0]) { m = 1; lr = r - a.nrows[0]; }
+      const size_t rb = hot_row_bytes(a.wtype[m], K);
+      const uint8_t *w0 = a.w[m] + (size_t)lr * rb;
+      float v0[NCOLS], v1[NCOLS];
+      MRS_HOT_TYPE_SWITCH(a.wtype[m], (row_dot2<TT, NCOLS>(w0, w0 + rb, nslices, act, v0, v1));)
+      if (lane == 0) {
+        const int head = lr / a.head_dim, d = lr % a.head_dim, pair = d >> 1;
+#pragma unroll
+        for (int c = 0; c < NCOLS; ++c) {
+          float x = v0[c], y = v1[c];
+          if (m < 2 && pair < a.rot_pairs) {
+            const size_t ti = (size_t)a.positions[c] * a.rot_pairs + pair;
+            const float cs = a.cos_t[ti], sn = a.sin_t[ti];
+            float xr, yr;
+            rope_pair<float>(x, y, cs, sn, xr, yr);
+            x = xr; y = yr;
+          }
+          if (m == 0) {
+            a.q_out[(size_t)c * a.nrows[0] + lr] = x;
+            a.q_out[(size_t)c * a.nrows[0] + lr + 1] = y;
+          } else {
+            const int64_t slot = a.slot_mapping[c];
+            if (slot >= 0) {
+              const int64_t blk = slot / a.block_size, off = slot % a.block_size;
+              uint16_t *kc = (uint16_t *)a.k_cache, *vc = (uint16_t *)a.v_cache;
+              if (m == 1) {
+                const int X = a.cache_x;
+                const int64_t base = ((blk * a.num_kv_heads + head) * (a.head_dim / X) + d / X) * a.block_size * X + off * X + d % X;
+                kc[base] = float_to_bf16_bits(x);
+                kc[base + 1] = float_to_bf16_bits(y);  // d is even and X is even: same 16-byte group
+              } else {
+                const int64_t base = ((blk * a.num_kv_heads + head) * a.head_dim + d) * a.block_size + off;
+                vc[base] = float_to_bf16_bits(x);
+                vc[base + a.block_size] = float_to_bf16_bits(y);
+              }
+            }
+          }
+        }
+      }
+    }
+  } else {
+    const size_t rb = hot_row_bytes(a.wtype[0], K);
+    for (int r = row0 + wave; r < row1; r += NW) {
+      float acc[NCOLS];
+      MRS_HOT_TYPE_SWITCH(a.wtype[0], (row_dot<TT, NCOLS>(a.w[0] + (size_t)r * rb, nslices, act, acc));)
+      if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < NCOLS; ++c) {
+          float *o = a.out + (size_t)c * a.out_stride + r;
+          if constexpr (EPI == EPI_RESID_ADD) *o = *o + acc[c]; else *o = acc[c];
+        }
+      }
+    }
+  }
+}
+
+static bool hot_type(int t) { return t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_Q8_0; }
+
+template <int PRO, int EPI> struct DecodeLaunch {
+  static constexpr int NT = 256;
+  template <int NCOLS> static int go(DecodeGemvArgs a, hipStream_t s) {
+    const int total = (EPI == EPI_QKV_ROPE) ? a.nrows[0] + a.nrows[1] + a.nrows[2] : a.nrows[0];
+    constexpr int NW = NT / 64;
+    const int unit = (EPI == EPI_GLU_Q8_1) ? 32 : (EPI == EPI_QKV_ROPE ? 2 * NW : NW);
+    int per = (total + 1023) / 1024;              // at most 1024 workgroups (4 per CU)
+    per = (per + unit - 1) / unit * unit;
+    a.rows_per_wg = per;
+    const int grid = (total + per - 1) / per;
+    size_t lds = (PRO == PRO_NORM) ? norm_lds_bytes(a.K, NCOLS) : act_lds_bytes(a.K, NCOLS, true);
+    lds = (lds + 15) & ~(size_t)15;
+    if (EPI == EPI_GLU_Q8_1) lds += (size_t)per * NCOLS * sizeof(float);
+    if (lds > 160 * 1024) return -2;
+    auto kern = decode_gemv_kernel<NCOLS, PRO, EPI, NT>;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, s, a);
+    return 0;
+  }
+  static int run(const DecodeGemvArgs &a, int b, hipStream_t s) {
+    switch (b) {
+    case 1: return go<1>(a, s); case 2: return go<2>(a, s); case 3: return go<3>(a, s); case 4: return go<4>(a, s);
+    case 5: return go<5>(a, s); case 6: return go<6>(a, s); case 7: return go<7>(a, s); case 8: return go<8>(a, s);
+    default: return -1;
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// small kernels of the decode step
+
+template <int TYPE> __device__ __forceinline__ void dequant_slice(const uint8_t *row, int s, float *o) {
+  const Slice sl = load_slice<TYPE>(row, s);
+  int ra, rb;
+  slice_runs<TYPE>(s, ra, rb);
+  const int8_t *qa = (const int8_t *)&sl.qa, *qb = (const int8_t *)&sl.qb;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { o[ra * 16 + j] = sl.sa * (float)qa[j] - sl.oa; o[rb * 16 + j] = sl.sb * (float)qb[j] - sl.ob; }
+}
+
+// token ids -> f32 rows of the (quantized) embedding table. grid = tokens
+template <int NT>
+__global__ void __launch_bounds__(NT) embedding_kernel(const uint8_t *__restrict__ table, int type, const int32_t *__restrict__ ids,
+                                                       float *__restrict__ out, int K) {
+  const int tok = blockIdx.x;
+  float *o = out + (size_t)tok * K;
+  const int64_t id = ids[tok];
+  if (type == 0) { const float *src = (const float *)table + id * K; for (int i = threadIdx.x; i < K; i += NT) o[i] = src[i]; return; }
+  if (type == 1) { const uint16_t *src = (const uint16_t *)table + id * K; for (int i = threadIdx.x; i < K; i += NT) o[i] = half_bits_to_float(src[i]); return; }
+  if (type == 30) { const uint16_t *src = (const uint16_t *)table + id * K; for (int i = threadIdx.x; i < K; i += NT) o[i] = bf16_bits_to_float(src[i]); return; }
+  const uint8_t *row = table + (size_t)id * hot_row_bytes(type, K);
+  for (int s = threadIdx.x; s < K / 32; s += NT) {
+    MRS_HOT_TYPE_SWITCH(type, dequant_slice<TT>(row, s, o);)
+  }
+}
+
+// greedy sampling: argmax over [b][vocab] logits (first max wins, like candle's argmax), then advance the
+// device-resident decode state so the next graph replay needs no host work:
+//   next_ids[c] = argmax ; tokens_out[c][step] = argmax ; positions[c]++ ; context_lens[c]++ ;
+//   slot_mapping[c] = block_table[c][pos / bs] * bs + pos % bs
+struct SampleArgs {
+  const float *logits; int vocab; int b;
+  int32_t *next_ids; int32_t *tokens_out; int tokens_out_stride; int32_t *step_counter;
+  int32_t *positions; uint32_t *context_lens; int64_t *slot_mapping; const uint32_t *block_tables; int max_blocks; int block_size;
+  unsigned long long *scratch;  // [b] packed (value, index) maxima, zeroed by the launcher
+};
+
+__device__ __forceinline__ unsigned long long pack_max(float v, int idx) {
+  unsigned u = __float_as_uint(v);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // order-preserving map
+  return ((unsigned long long)u << 32) | (unsigned)(0x7fffffff - idx);  // ties -> smaller index
+}
+
+__global__ void __launch_bounds__(256) argmax_partial_kernel(const SampleArgs a) {
+  const int c = blockIdx.y;
+  const float *l = a.logits + (size_t)c * a.vocab;
+  unsigned long long best = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < a.vocab; i += gridDim.x * 256) {
+    const unsigned long long p = pack_max(l[i], i);
+    best = p > best ? p : best;
+  }
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) { const unsigned long long o = __shfl_xor(best, m, 64); best = o > best ? o : best; }
+  if ((threadIdx.x & 63) == 0) atomicMax(a.scratch + c, best);
+}
+
+__global__ void __launch_bounds__(64) sample_advance_kernel(const SampleArgs a) {
+  const int c = threadIdx.x;
+  if (c >= a.b) return;
+  const int idx = 0x7fffffff - (int)(a.scratch[c] & 0xffffffffu);
+  a.scratch[c] = 0;
+  a.next_ids[c] = idx;
+  const int step = *a.step_counter;
+  if (a.tokens_out) a.tokens_out[(size_t)c * a.tokens_out_stride + step] = idx;
+  const int pos = a.positions[c] + 1;
+  a.positions[c] = pos;
+  a.context_lens[c] = (uint32_t)pos + 1;
+  a.slot_mapping[c] = (int64_t)a.block_tables[(size_t)c * a.max_blocks + pos / a.block_size] * a.block_size + pos % a.block_size;
+  __syncthreads();
+  if (c == 0) *a.step_counter = step + 1;
+}
+
+// f32 [rows][K] -> Q8_1 blocks, same bytes as launch_mmvq_gguf_quantize_q8_1_f32 (used after attention)
+__global__ void __launch_bounds__(256) quantize_rows_kernel(const float *__restrict__ x, uint8_t *__restrict__ y, int K, int stride_blocks) {
+  const int c = blockIdx.y;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= stride_blocks * 32) return;
+  const float v = e < K ? x[(size_t)c * K + e] : 0.0f;
+  float amax = fabsf(v), sum = v;
+#pragma unroll
+  for (int m = 16; m > 0; m >>= 1) { amax = fmaxf(amax, __shfl_xor(amax, m, 64)); sum += __shfl_xor(sum, m, 64); }
+  const float d = amax / 127.0f;
+  uint8_t *blk = y + ((size_t)c * stride_blocks + e / 32) * 36;
+  ((int8_t *)(blk + 4))[e & 31] = amax == 0.0f ? (int8_t)0 : (int8_t)roundf(v / d);
+  if ((e & 31) == 0) { ((uint16_t *)blk)[0] = float_to_half_bits(d); ((uint16_t *)blk)[1] = float_to_half_bits(sum); }
+}
+
+}  // namespace mrs
+
+using namespace mrs;
+
+// ---- C entry points (declared in include/mrs_hip_ext.h) -----------------------------------------
+extern "C" int mrs_decode_gemv_supported(int ggml_type) { return hot_type(ggml_type) ? 1 : 0; }
+
+// QKV: h [b][K] f32 --RMSNorm*norm_w--> Q8_1 (LDS) --> q (f32, RoPE'd), k (RoPE'd) / v -> paged bf16 cache
+extern "C" int mrs_decode_qkv(const void *wq, const void *wk, const void *wv, int tq, int tk, int tv, int nq, int nk, int nv, int K,
+                              const float *h, const float *norm_w, float eps, float *q_out, void *k_cache, void *v_cache,
+                              const int64_t *slot_mapping, const int32_t *positions, const float *cos_t, const float *sin_t,
+                              int head_dim, int rot_pairs, int num_kv_heads, int block_size, int b, void *stream) {
+  if (!hot_type(tq) || !hot_type(tk) || !hot_type(tv) || (nq | nk | nv | head_dim) & 1) return -1;
+  DecodeGemvArgs a{};
+  a.w[0] = (const uint8_t *)wq; a.w[1] = (const uint8_t *)wk; a.w[2] = (const uint8_t *)wv;
+  a.wtype[0] = tq; a.wtype[1] = tk; a.wtype[2] = tv; a.nrows[0] = nq; a.nrows[1] = nk; a.nrows[2] = nv; a.K = K;
+  a.x = h; a.norm_w = norm_w; a.eps = eps; a.q_out = q_out; a.k_cache = k_cache; a.v_cache = v_cache;
+  a.slot_mapping = slot_mapping; a.positions = positions; a.cos_t = cos_t; a.sin_t = sin_t; a.head_dim = head_dim;
+  a.rot_pairs = rot_pairs; a.num_kv_heads = num_kv_heads; a.block_size = block_size; a.cache_x = 8;
+  return DecodeLaunch<PRO_NORM, EPI_QKV_ROPE>::run(a, b, (hipStream_t)stream);
+}
+
+// gate/up: h --RMSNorm--> Q8_1 (LDS) --> act(gate.x)*up.x --> Q8_1 blocks y_out [b][y_out_stride]
+extern "C" int mrs_decode_gate_up(const void *wg, const void *wu, int type, int n, int K, const float *h, const float *norm_w,
+                                  float eps, int activation, void *y_out, int y_out_stride, int b, void *stream) {
+  if (!hot_type(type) || n % 32) return -1;
+  DecodeGemvArgs a{};
+  a.w[0] = (const uint8_t *)wg; a.w[1] = (const uint8_t *)wu; a.wtype[0] = a.wtype[1] = type; a.nrows[0] = n; a.K = K;
+  a.x = h; a.norm_w = norm_w; a.eps = eps; a.activation = activation; a.y_out = (uint8_t *)y_out; a.y_out_stride = y_out_stride;
+  return DecodeLaunch<PRO_NORM, EPI_GLU_Q8_1>::run(a, b, (hipStream_t)stream);
+}
+
+// row-parallel projections (o_proj, down): y Q8_1 --> out[c*out_stride + r] (+)= W.y
+extern "C" int mrs_decode_proj(const void *w, int type, int n, int K, const void *y_q8_1, int stride_col_y, float *out,
+                               int out_stride, int accumulate, int b, void *stream) {
+  if (!hot_type(type)) return -1;
+  DecodeGemvArgs a{};
+  a.w[0] = (const uint8_t *)w; a.wtype[0] = type; a.nrows[0] = n; a.K = K; a.y_q8_1 = (const uint8_t *)y_q8_1;
+  a.stride_col_y = stride_col_y; a.out = out; a.out_stride = out_stride;
+  return accumulate ? DecodeLaunch<PRO_Q8_1, EPI_RESID_ADD>::run(a, b, (hipStream_t)stream)
+                    : DecodeLaunch<PRO_Q8_1, EPI_STORE>::run(a, b, (hipStream_t)stream);
+}
+
+// final norm + lm_head: h --RMSNorm--> Q8_1 (LDS) --> logits f32 [b][n]
+extern "C" int mrs_decode_norm_proj(const void *w, int type, int n, int K, const float *h, const float *norm_w, float eps,
+                                    float *out, int out_stride, int b, void *stream) {
+  if (!hot_type(type)) return -1;
+  DecodeGemvArgs a{};
+  a.w[0] = (const uint8_t *)w; a.wtype[0] = type; a.nrows[0] = n; a.K = K; a.x = h; a.norm_w = norm_w; a.eps = eps;
+  a.out = out; a.out_stride = out_stride;
+  return DecodeLaunch<PRO_NORM, EPI_STORE>::run(a, b, (hipStream_t)stream);
+}
+
+extern "C" int mrs_embedding(const void *table, int type, const int32_t *ids, float *out, int K, int tokens, void *stream) {
+  if (!(hot_type(type) || type == 0 || type == 1 || type == 30) || tokens <= 0) return -1;
+  hipLaunchKernelGGL((embedding_kernel<256>), dim3(tokens), dim3(256), 0, (hipStream_t)stream, (const uint8_t *)table, type, ids, out, K);
+  return 0;
+}
+
+extern "C" int mrs_quantize_rows_q8_1(const float *x, void *y, int K, int stride_blocks, int rows, void *stream) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(quantize_rows_kernel, dim3((stride_blocks * 32 + 255) / 256, rows), dim3(256), 0, (hipStream_t)stream, x, (uint8_t *)y, K, stride_blocks);
+  return 0;
+}
+
+extern "C" int mrs_sample_greedy_advance(const float *logits, int vocab, int b, int32_t *next_ids, int32_t *tokens_out,
+                                         int tokens_out_stride, int32_t *step_counter, int32_t *positions,
+                                         uint32_t *context_lens, int64_t *slot_mapping, const uint32_t *block_tables,
+                                         int max_blocks, int block_size, void *scratch, void *stream) {
+  if (b <= 0 || b > 64) return -1;
+  SampleArgs a{logits, vocab, b, next_ids, tokens_out, tokens_out_stride, step_counter, positions, context_lens, slot_mapping,
+               block_tables, max_blocks, block_size, (unsigned long long *)scratch};
+  int gx = (vocab + 255) / 256; if (gx > 128) gx = 128;
+  hipLaunchKernelGGL(argmax_partial_kernel, dim3(gx, b), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(sample_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
+  return 0;
+}

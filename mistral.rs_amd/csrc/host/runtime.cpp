@@ -1,0 +1,414 @@
+// host/runtime.cpp -- host-side model runner for the quantized decode path (C++ because the reference host
+// is compiled Rust and no Rust toolchain exists here; see INTEGRATION.md for the Rust-side binding).
+//
+// Mirrors, with the same names and call order:
+//   trait QuantMethod ............ mistralrs-quant/src/lib.rs:1515-1688
+//   GgufMatMul ................... mistralrs-quant/src/gguf/mod.rs:43-52,298-323,436-479
+//   try_fused_quantized_{qkv,gate_up}  mistralrs-quant/src/lib.rs:1839,1949 (fusion policy: equal dtypes, no bias)
+//   RmsNorm / Mlp / CausalSelfAttention / Block / Llama  mistralrs-core/src/models/llama.rs:68-157,243-260,487-518
+//   PagedAttention::forward (decode)  mistralrs-core/src/paged_attention/layers/paged_attention.rs:1477-1561
+//   tensor-name bindings ......... mistralrs-core/src/gguf/normal_bindings.rs:40-220
+// Two execution modes over identical numerics:
+//   use_fused = 0 : the reference's launch sequence through the drop-in C-ABI symbols (launch_mmvq_*,
+//                   rotary_embedding_positions, reshape_and_cache, paged attention, add_rms_norm_*)
+//   use_fused = 1 : the MI355X fused kernels of ext_decode.hip (5 launches per layer)
+// The runner never allocates device memory: every buffer comes from the caller (mrs_llama_buffers).
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cmath>
+#include <cstring>
+#include <algorithm>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../../include/mistralrs_core.h"
+#include "../../../include/mistralrs_paged_attn.h"
+#include "../../../include/mistralrs_quant.h"
+#include "../../../include/mrs_hip_ext.h"
+
+namespace mrs_host {
+
+static thread_local std::string g_last_error;
+static int fail(const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return -1;
+}
+
+// ---------------------------------------------------------------------------------------------- dtypes
+enum GgmlDType : int { F32 = 0, F16 = 1, Q4_0 = 2, Q4_1 = 3, Q5_0 = 6, Q5_1 = 7, Q8_0 = 8, Q8_1 = 9, Q2K = 10, Q3K = 11,
+                       Q4K = 12, Q5K = 13, Q6K = 14, Q8K = 15, BF16 = 30 };
+struct DTypeInfo { int id, block, bytes; const char *tag; };
+static const DTypeInfo kTypes[] = {{F32, 1, 4, "f32"}, {F16, 1, 2, "f16"}, {Q4_0, 32, 18, "q4_0"}, {Q4_1, 32, 20, "q4_1"},
+                                   {Q5_0, 32, 22, "q5_0"}, {Q5_1, 32, 24, "q5_1"}, {Q8_0, 32, 34, "q8_0"}, {Q2K, 256, 84, "q2_k"},
+                                   {Q3K, 256, 110, "q3_k"}, {Q4K, 256, 144, "q4_k"}, {Q5K, 256, 176, "q5_k"},
+                                   {Q6K, 256, 210, "q6_k"}, {BF16, 1, 2, "bf16"}};
+static const DTypeInfo *type_info(int id) {
+  for (const auto &t : kTypes) if (t.id == id) return &t;
+  return nullptr;
+}
+static bool mmvq_supports(int id) { return id == Q4_0 || id == Q4_1 || id == Q5_0 || id == Q5_1 || id == Q8_0 || (id >= Q2K && id <= Q6K); }
+
+constexpr int MATRIX_ROW_PADDING = 512;  // fast_mmvq.rs:21
+constexpr int MMVQ_MAX_BATCH = 8;        // fast_mmvq.rs:52
+static int pad_to(int v, int m) { return (v + m - 1) / m * m; }
+
+// candle `QTensor`: packed GGUF blocks [rows][cols/blk] resident in HBM
+struct QTensor {
+  const void *data = nullptr;
+  int dtype = -1;
+  int64_t rows = 0, cols = 0;
+  size_t nbytes() const { const auto *t = type_info(dtype); return t ? (size_t)rows * (cols / t->block) * t->bytes : 0; }
+};
+
+// f32 activation view [b, k] + the per-model Q8_1 scratch (the `workspace_ensure` slot of fast_mmvq.rs:70-112)
+struct Scratch { void *q8; size_t q8_bytes; };
+
+// ---------------------------------------------------------------------------------------------- QuantMethod
+class QuantMethod {
+ public:
+  virtual ~QuantMethod() = default;
+  virtual const char *name() const = 0;
+  // forward_raw: a [b, K] f32 -> out [b, N] f32
+  virtual int forward_raw(const float *a, int b, float *out, const Scratch &ws, hipStream_t s) const = 0;
+  virtual int embedding_forward_raw(const int32_t *ids, int n, float *out, hipStream_t s) const {
+    (void)ids; (void)n; (void)out; (void)s;
+    return fail("%s does not support `embedding_forward`. Please raise an issue.", name());
+  }
+  virtual const QTensor *get_qtensor() const { return nullptr; }
+  virtual bool has_bias() const { return false; }
+};
+
+typedef void (*plain_fn)(const void *, const void *, void *, int, int, int, int, int, void *);
+typedef void (*glu_fn)(const void *, const void *, const void *, void *, int, int, int, int, int, int, void *);
+typedef void (*qkv_fn)(const void *, const void *, const void *, const void *, void *, void *, void *, int, int, int, int, int, int, void *);
+
+static void *lookup(const std::string &sym) {  // resolved once per (symbol) and cached
+  static std::vector<std::pair<std::string, void *>> cache;
+  for (auto &e : cache) if (e.first == sym) return e.second;
+  void *p = dlsym(RTLD_DEFAULT, sym.c_str());
+  if (!p) { fail("missing HIP symbol %s (is libmistralrsquant.so loaded?)", sym.c_str()); return nullptr; }
+  cache.emplace_back(sym, p);
+  return p;
+}
+
+class GgufMatMul : public QuantMethod {
+ public:
+  explicit GgufMatMul(const QTensor &w) : w_(w) {}
+  const char *name() const override { return "gguf"; }
+  const QTensor *get_qtensor() const override { return &w_; }
+
+  // try_fast_forward (gguf/mod.rs:298-323): b in 1..8 -> MMVQ.  (b > 8 -> GEMM: prefill path, ext_gemm)
+  int forward_raw(const float *a, int b, float *out, const Scratch &ws, hipStream_t s) const override {
+    if (!mmvq_supports(w_.dtype)) return fail("fast_mmvq: unsupported quant dtype %d", w_.dtype);
+    if (b <= 0 || b > MMVQ_MAX_BATCH) return fail("fast_mmvq: batch size %d out of supported range 1..=%d", b, MMVQ_MAX_BATCH);
+    const int k = (int)w_.cols, kp = pad_to(k, MATRIX_ROW_PADDING), stride = kp / 32;
+    if ((size_t)b * stride * 36 > ws.q8_bytes) return fail("fast_mmvq: Q8_1 workspace too small");
+    launch_mmvq_gguf_quantize_q8_1_f32(a, ws.q8, k, kp, b, s);
+    auto fn = (plain_fn)lookup(std::string("launch_mmvq_gguf_") + type_info(w_.dtype)->tag + "_f32_plain");
+    if (!fn) return -1;
+    fn(w_.data, ws.q8, out, k, (int)w_.rows, stride, (int)w_.rows, b, s);
+    return 0;
+  }
+  int embedding_forward_raw(const int32_t *ids, int n, float *out, hipStream_t s) const override {
+    if (mrs_embedding(w_.data, w_.dtype, ids, out, (int)w_.cols, n, s) != 0)
+      return fail("gguf embedding_forward: unsupported dtype %d", w_.dtype);
+    return 0;
+  }
+
+ private:
+  QTensor w_;
+};
+
+// try_fused_quantized_qkv (lib.rs:1949): one shared Q8_1 activation, one launch; requires equal dtypes
+static int try_fused_quantized_qkv(const QuantMethod &q, const QuantMethod &k, const QuantMethod &v, const float *x, int b,
+                                   float *qo, float *ko, float *vo, const Scratch &ws, hipStream_t s) {
+  const QTensor *tq = q.get_qtensor(), *tk = k.get_qtensor(), *tv = v.get_qtensor();
+  if (!tq || !tk || !tv || tq->dtype != tk->dtype || tq->dtype != tv->dtype || !mmvq_supports(tq->dtype)) return 1;  // not fused
+  const int kk = (int)tq->cols, kp = pad_to(kk, MATRIX_ROW_PADDING), stride = kp / 32;
+  launch_mmvq_gguf_quantize_q8_1_f32(x, ws.q8, kk, kp, b, s);
+  auto fn = (qkv_fn)lookup(std::string("launch_mmvq_gguf_") + type_info(tq->dtype)->tag + "_f32_fused_qkv");
+  if (!fn) return -1;
+  fn(tq->data, tk->data, tv->data, ws.q8, qo, ko, vo, kk, (int)tq->rows, (int)tk->rows, (int)tv->rows, stride, b, s);
+  return 0;
+}
+
+// try_fused_quantized_gate_up (lib.rs:1839)
+static int try_fused_quantized_gate_up(const QuantMethod &g, const QuantMethod &u, const float *x, int b, float *out, int act,
+                                       const Scratch &ws, hipStream_t s) {
+  const QTensor *tg = g.get_qtensor(), *tu = u.get_qtensor();
+  if (!tg || !tu || tg->dtype != tu->dtype || tg->rows != tu->rows || !mmvq_supports(tg->dtype)) return 1;
+  const int kk = (int)tg->cols, kp = pad_to(kk, MATRIX_ROW_PADDING), stride = kp / 32;
+  launch_mmvq_gguf_quantize_q8_1_f32(x, ws.q8, kk, kp, b, s);
+  auto fn = (glu_fn)lookup(std::string("launch_mmvq_gguf_") + type_info(tg->dtype)->tag + "_f32_fused_glu");
+  if (!fn) return -1;
+  fn(tg->data, tu->data, ws.q8, out, kk, (int)tg->rows, stride, (int)tg->rows, b, act, s);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- model
+struct Block {
+  std::unique_ptr<GgufMatMul> q_proj, k_proj, v_proj, o_proj, gate_proj, up_proj, down_proj;
+  const float *input_layernorm = nullptr, *post_attention_layernorm = nullptr;
+  void *key_cache = nullptr, *value_cache = nullptr;
+};
+
+struct Workspace {  // carve-up of the caller's scratch
+  float *h, *xn, *q, *k, *v, *attn, *proj, *act;
+  void *y_a, *y_b;          // Q8_1 scratch (hidden-sized rows / ffn-sized rows)
+  size_t y_a_bytes, y_b_bytes;
+  void *attn_ws;            // v2 partials
+  float *exp_sums, *max_logits;
+  void *sample_scratch;
+};
+
+class Llama {
+ public:
+  explicit Llama(const mrs_llama_config &c) : cfg(c), blocks(c.num_layers) {}
+  mrs_llama_config cfg;
+  std::vector<Block> blocks;
+  std::unique_ptr<GgufMatMul> wte, lm_head;
+  const float *ln_f = nullptr;
+  mrs_llama_buffers bufs{};
+  Workspace ws{};
+  bool have_bufs = false;
+
+  static size_t align(size_t v) { return (v + 255) & ~(size_t)255; }
+  static size_t workspace_bytes(const mrs_llama_config &c) {
+    const size_t B = c.max_batch, d = c.hidden_size, nq = (size_t)c.num_heads * c.head_dim, nkv = (size_t)c.num_kv_heads * c.head_dim;
+    const size_t ya = B * (pad_to((int)std::max(d, nq), MATRIX_ROW_PADDING) / 32) * 36;
+    const size_t yb = B * (pad_to(c.intermediate_size, MATRIX_ROW_PADDING) / 32) * 36;
+    const size_t parts = (c.max_context_len + 511) / 512;
+    size_t t = 0;
+    t += align(B * d * 4) * 3;            // h, xn, proj
+    t += align(B * nq * 4) * 2;           // q, attn
+    t += align(B * nkv * 4) * 2;          // k, v
+    t += align(B * (size_t)c.intermediate_size * 4);  // act
+    t += align(ya) + align(yb);
+    t += align(B * c.num_heads * parts * c.head_dim * 4) + 2 * align(B * c.num_heads * parts * 4);
+    t += align(B * 8);
+    return t + 4096;
+  }
+
+  int set_buffers(const mrs_llama_buffers &b) {
+    if (b.workspace_bytes < workspace_bytes(cfg)) return fail("workspace too small: %zu < %zu", b.workspace_bytes, workspace_bytes(cfg));
+    bufs = b;
+    const size_t B = cfg.max_batch, d = cfg.hidden_size, nq = (size_t)cfg.num_heads * cfg.head_dim, nkv = (size_t)cfg.num_kv_heads * cfg.head_dim;
+    char *p = (char *)(((uintptr_t)b.workspace + 255) & ~(uintptr_t)255);
+    auto take = [&](size_t n) { char *r = p; p += align(n); return r; };
+    ws.h = (float *)take(B * d * 4); ws.xn = (float *)take(B * d * 4); ws.proj = (float *)take(B * d * 4);
+    ws.q = (float *)take(B * nq * 4); ws.attn = (float *)take(B * nq * 4);
+    ws.k = (float *)take(B * nkv * 4); ws.v = (float *)take(B * nkv * 4);
+    ws.act = (float *)take(B * (size_t)cfg.intermediate_size * 4);
+    ws.y_a_bytes = B * (pad_to((int)std::max(d, nq), MATRIX_ROW_PADDING) / 32) * 36;
+    ws.y_b_bytes = B * (pad_to(cfg.intermediate_size, MATRIX_ROW_PADDING) / 32) * 36;
+    ws.y_a = take(ws.y_a_bytes); ws.y_b = take(ws.y_b_bytes);
+    const size_t parts = (cfg.max_context_len + 511) / 512;
+    ws.attn_ws = take(B * cfg.num_heads * parts * cfg.head_dim * 4);
+    ws.exp_sums = (float *)take(B * cfg.num_heads * parts * 4);
+    ws.max_logits = (float *)take(B * cfg.num_heads * parts * 4);
+    ws.sample_scratch = take(B * 8);
+    // zero once: Q8_1 padding blocks beyond K are never written by the fused epilogues; sample scratch must start at 0
+    if (hipMemset(b.workspace, 0, b.workspace_bytes) != hipSuccess) return fail("hipMemset(workspace) failed");
+    have_bufs = true;
+    return 0;
+  }
+
+  int check_ready(int b) const {
+    if (!have_bufs) return fail("mrs_llama_set_buffers was not called");
+    if (b <= 0 || b > cfg.max_batch || b > MMVQ_MAX_BATCH) return fail("decode batch %d out of range 1..=%d", b, cfg.max_batch);
+    if (!wte || !lm_head || !ln_f) return fail("model is missing token_embd / output / output_norm");
+    for (size_t i = 0; i < blocks.size(); ++i) {
+      const Block &bl = blocks[i];
+      if (!bl.q_proj || !bl.k_proj || !bl.v_proj || !bl.o_proj || !bl.gate_proj || !bl.up_proj || !bl.down_proj ||
+          !bl.input_layernorm || !bl.post_attention_layernorm)
+        return fail("layer %zu is missing tensors", i);
+      if (!bl.key_cache || !bl.value_cache) return fail("layer %zu has no KV cache", i);
+    }
+    return 0;
+  }
+
+  bool fused_ok() const {
+    if (!cfg.use_fused || !cfg.rope_interleaved) return false;
+    auto hot = [](const std::unique_ptr<GgufMatMul> &m) { return mrs_decode_gemv_supported(m->get_qtensor()->dtype) != 0; };
+    if (!hot(lm_head)) return false;
+    for (const Block &bl : blocks) {
+      if (!hot(bl.q_proj) || !hot(bl.k_proj) || !hot(bl.v_proj) || !hot(bl.o_proj) || !hot(bl.gate_proj) || !hot(bl.down_proj)) return false;
+      if (bl.gate_proj->get_qtensor()->dtype != bl.up_proj->get_qtensor()->dtype) return false;
+      if (cfg.intermediate_size % 32) return false;
+    }
+    return true;
+  }
+
+  // PagedAttention::forward, decode branch (run_decode): attention over the cache that already holds this token
+  int paged_attention_decode(const Block &bl, int b, hipStream_t s) const {
+    const int hd = cfg.head_dim, bs = cfg.block_size, kvh = cfg.num_kv_heads;
+    const int kv_block_stride = kvh * hd * bs, kv_head_stride = hd * bs;
+    const int eff_max = std::min(cfg.max_blocks_per_seq * bs, cfg.max_context_len);
+    const int parts = (eff_max + 511) / 512;
+    const bool use_v1 = (parts == 1 || b * cfg.num_heads > 512);  // paged_attention.rs:302-307
+    mrs_paged_attention_f32_bf16(use_v1 ? 0 : 1, ws.attn, ws.exp_sums, ws.max_logits, ws.attn_ws, ws.q, bl.key_cache, bl.value_cache,
+                                 nullptr, kvh, 1.0f / sqrtf((float)hd), 1.0f, bufs.block_tables, bufs.context_lens, bs, eff_max, b,
+                                 cfg.num_heads, hd, cfg.max_blocks_per_seq, cfg.num_heads * hd, kv_block_stride, kv_head_stride, s, nullptr);
+    return 0;
+  }
+
+  // ---- reference launch sequence (models/llama.rs:487-518 driving the C-ABI kernels one by one)
+  int forward_unfused(int b, hipStream_t s) const {
+    const int d = cfg.hidden_size, hd = cfg.head_dim, nq = cfg.num_heads * hd, nkv = cfg.num_kv_heads * hd;
+    const Scratch sa{ws.y_a, ws.y_a_bytes}, sb{ws.y_b, ws.y_b_bytes};
+    const int64_t st = (int64_t)(intptr_t)s;
+    if (wte->embedding_forward_raw(bufs.input_ids, b, ws.h, s)) return -1;
+    mrs_rms_norm_f32(ws.h, blocks[0].input_layernorm, ws.xn, b, d, cfg.rms_eps, st);
+    for (size_t li = 0; li < blocks.size(); ++li) {
+      const Block &bl = blocks[li];
+      // CausalSelfAttention::forward (llama.rs:68-157): qkv_projections -> rotary -> paged attention -> o_proj
+      int rc = try_fused_quantized_qkv(*bl.q_proj, *bl.k_proj, *bl.v_proj, ws.xn, b, ws.q, ws.k, ws.v, sa, s);
+      if (rc < 0) return -1;
+      if (rc == 1) {  // mixed dtypes (Q4_K_M: attn_v is often Q6_K): three GEMVs, as the reference falls back to
+        if (bl.q_proj->forward_raw(ws.xn, b, ws.q, sa, s) || bl.k_proj->forward_raw(ws.xn, b, ws.k, sa, s) ||
+            bl.v_proj->forward_raw(ws.xn, b, ws.v, sa, s)) return -1;
+      }
+      rotary_embedding_positions(ws.q, ws.k, (void *)bufs.cos_table, (void *)bufs.sin_table, bufs.positions,
+                                 cfg.rope_interleaved ? 0 : 1, hd, b, cfg.rot_dim / 2, cfg.max_context_len, cfg.num_heads,
+                                 cfg.num_kv_heads, nq, nkv, 2, st);
+      reshape_and_cache(ws.k, ws.v, bl.key_cache, bl.value_cache, bufs.slot_mapping, b, cfg.num_kv_heads, hd, cfg.block_size, 8,
+                        nkv, nkv, s, 2, 1, nullptr, nullptr);
+      paged_attention_decode(bl, b, s);
+      if (bl.o_proj->forward_raw(ws.attn, b, ws.proj, sa, s)) return -1;
+      // Block::forward (llama.rs:243-260): x = attn + residual ; mlp(rms_norm(x)) + x
+      add_rms_norm_f32(ws.proj, ws.h, bl.post_attention_layernorm, ws.h, ws.xn, b, d, cfg.rms_eps, st);
+      // Mlp::forward -> quantized_ffn (ops.rs:5036): fused gate/up + act, then down
+      rc = try_fused_quantized_gate_up(*bl.gate_proj, *bl.up_proj, ws.xn, b, ws.act, 0, sa, s);
+      if (rc < 0) return -1;
+      if (rc == 1) return fail("gate/up with different dtypes are not supported yet");
+      if (bl.down_proj->forward_raw(ws.act, b, ws.proj, sb, s)) return -1;
+      const float *next_norm = li + 1 < blocks.size() ? blocks[li + 1].input_layernorm : ln_f;
+      add_rms_norm_f32(ws.proj, ws.h, next_norm, ws.h, ws.xn, b, d, cfg.rms_eps, st);
+    }
+    return lm_head->forward_raw(ws.xn, b, bufs.logits, sa, s);
+  }
+
+  // ---- MI355X fused sequence: 5 launches per layer (+ attention reduce / quantize)
+  int forward_fused(int b, hipStream_t s) const {
+    const int d = cfg.hidden_size, hd = cfg.head_dim, nq = cfg.num_heads * hd, nkv = cfg.num_kv_heads * hd, ff = cfg.intermediate_size;
+    const int stride_q = pad_to(nq, MATRIX_ROW_PADDING) / 32, stride_f = pad_to(ff, MATRIX_ROW_PADDING) / 32;
+    if (wte->embedding_forward_raw(bufs.input_ids, b, ws.h, s)) return -1;
+    for (const Block &bl : blocks) {
+      const QTensor *q = bl.q_proj->get_qtensor(), *k = bl.k_proj->get_qtensor(), *v = bl.v_proj->get_qtensor();
+      if (mrs_decode_qkv(q->data, k->data, v->data, q->dtype, k->dtype, v->dtype, nq, nkv, nkv, d, ws.h, bl.input_layernorm,
+                         cfg.rms_eps, ws.q, bl.key_cache, bl.value_cache, bufs.slot_mapping, bufs.positions, bufs.cos_table,
+                         bufs.sin_table, hd, cfg.rot_dim / 2, cfg.num_kv_heads, cfg.block_size, b, s))
+        return fail("mrs_decode_qkv refused the layer");
+      paged_attention_decode(bl, b, s);
+      mrs_quantize_rows_q8_1(ws.attn, ws.y_a, nq, stride_q, b, s);
+      const QTensor *o = bl.o_proj->get_qtensor();
+      if (mrs_decode_proj(o->data, o->dtype, d, nq, ws.y_a, stride_q, ws.h, d, 1, b, s)) return fail("mrs_decode_proj(o) refused");
+      const QTensor *g = bl.gate_proj->get_qtensor(), *u = bl.up_proj->get_qtensor(), *dn = bl.down_proj->get_qtensor();
+      if (mrs_decode_gate_up(g->data, u->data, g->dtype, ff, d, ws.h, bl.post_attention_layernorm, cfg.rms_eps, 0, ws.y_b, stride_f, b, s))
+        return fail("mrs_decode_gate_up refused");
+      if (mrs_decode_proj(dn->data, dn->dtype, d, ff, ws.y_b, stride_f, ws.h, d, 1, b, s)) return fail("mrs_decode_proj(down) refused");
+    }
+    const QTensor *lm = lm_head->get_qtensor();
+    if (mrs_decode_norm_proj(lm->data, lm->dtype, cfg.vocab_size, d, ws.h, ln_f, cfg.rms_eps, bufs.logits, cfg.vocab_size, b, s))
+      return fail("mrs_decode_norm_proj refused");
+    return 0;
+  }
+
+  int forward_logits(int b, hipStream_t s) const {
+    if (check_ready(b)) return -1;
+    return fused_ok() ? forward_fused(b, s) : forward_unfused(b, s);
+  }
+
+  int decode_step(int b, hipStream_t s) const {
+    if (forward_logits(b, s)) return -1;
+    if (mrs_sample_greedy_advance(bufs.logits, cfg.vocab_size, b, bufs.input_ids, bufs.tokens_out, bufs.tokens_out_stride,
+                                  bufs.step_counter, bufs.positions, bufs.context_lens, bufs.slot_mapping, bufs.block_tables,
+                                  cfg.max_blocks_per_seq, cfg.block_size, ws.sample_scratch, s))
+      return fail("mrs_sample_greedy_advance refused");
+    return 0;
+  }
+
+  double decode_bytes(int b, int ctx) const {
+    double t = 0;
+    for (const Block &bl : blocks)
+      for (const auto *m : {&bl.q_proj, &bl.k_proj, &bl.v_proj, &bl.o_proj, &bl.gate_proj, &bl.up_proj, &bl.down_proj})
+        if (*m) t += (double)(*m)->get_qtensor()->nbytes();
+    if (lm_head) t += (double)lm_head->get_qtensor()->nbytes();
+    if (wte) { const auto *ti = type_info(wte->get_qtensor()->dtype); t += (double)b * (wte->get_qtensor()->cols / ti->block) * ti->bytes; }
+    t += (double)b * 2.0 * cfg.num_layers * cfg.num_kv_heads * cfg.head_dim * (double)ctx * 2.0;  // bf16 K + V
+    return t;
+  }
+};
+
+// GGUF tensor name -> model slot (gguf/normal_bindings.rs:40-220)
+static int bind_tensor(Llama &m, const std::string &name, const void *p, int type, int64_t rows, int64_t cols) {
+  const auto *ti = type_info(type);
+  if (!ti) return fail("tensor %s: unsupported ggml dtype %d", name.c_str(), type);
+  if (cols % ti->block) return fail("tensor %s: %lld columns is not a multiple of the block size %d", name.c_str(), (long long)cols, ti->block);
+  auto norm = [&](const float *&slot) { if (type != F32) return fail("tensor %s: norm weights must be F32", name.c_str()); slot = (const float *)p; return 0; };
+  auto lin = [&](std::unique_ptr<GgufMatMul> &slot, int64_t er, int64_t ec) {
+    if (rows != er || cols != ec) return fail("tensor %s: shape [%lld, %lld], expected [%lld, %lld]", name.c_str(), (long long)rows, (long long)cols, (long long)er, (long long)ec);
+    slot.reset(new GgufMatMul(QTensor{p, type, rows, cols}));
+    return 0;
+  };
+  const auto &c = m.cfg;
+  const int64_t d = c.hidden_size, nq = (int64_t)c.num_heads * c.head_dim, nkv = (int64_t)c.num_kv_heads * c.head_dim, ff = c.intermediate_size;
+  if (name == "token_embd.weight") return lin(m.wte, c.vocab_size, d);
+  if (name == "output.weight") return lin(m.lm_head, c.vocab_size, d);
+  if (name == "output_norm.weight") return norm(m.ln_f);
+  int layer = -1, consumed = 0;
+  if (sscanf(name.c_str(), "blk.%d.%n", &layer, &consumed) == 1 && consumed > 0) {
+    if (layer < 0 || layer >= c.num_layers) return fail("tensor %s: layer out of range", name.c_str());
+    Block &b = m.blocks[layer];
+    const std::string rest = name.substr(consumed);
+    if (rest == "attn_norm.weight") return norm(b.input_layernorm);
+    if (rest == "ffn_norm.weight") return norm(b.post_attention_layernorm);
+    if (rest == "attn_q.weight") return lin(b.q_proj, nq, d);
+    if (rest == "attn_k.weight") return lin(b.k_proj, nkv, d);
+    if (rest == "attn_v.weight") return lin(b.v_proj, nkv, d);
+    if (rest == "attn_output.weight") return lin(b.o_proj, d, nq);
+    if (rest == "ffn_gate.weight") return lin(b.gate_proj, ff, d);
+    if (rest == "ffn_up.weight") return lin(b.up_proj, ff, d);
+    if (rest == "ffn_down.weight") return lin(b.down_proj, d, ff);
+  }
+  return fail("tensor %s: no binding for this name", name.c_str());
+}
+
+}  // namespace mrs_host
+
+using mrs_host::Llama;
+
+extern "C" const char *mrs_last_error(void) { return mrs_host::g_last_error.c_str(); }
+extern "C" size_t mrs_llama_workspace_bytes(const mrs_llama_config *cfg) { return Llama::workspace_bytes(*cfg); }
+extern "C" void *mrs_llama_create(const mrs_llama_config *cfg) {
+  if (!cfg || cfg->num_layers <= 0 || cfg->hidden_size <= 0 || cfg->num_heads <= 0 || cfg->num_kv_heads <= 0 ||
+      cfg->num_heads % cfg->num_kv_heads || cfg->head_dim <= 0 || cfg->max_batch <= 0 || cfg->max_batch > 8 ||
+      cfg->rot_dim > cfg->head_dim || (cfg->rot_dim & 1)) {
+    mrs_host::fail("mrs_llama_create: invalid config");
+    return nullptr;
+  }
+  return new Llama(*cfg);
+}
+extern "C" void mrs_llama_destroy(void *m) { delete (Llama *)m; }
+extern "C" int mrs_llama_set_tensor(void *m, const char *name, const void *p, int type, int64_t rows, int64_t cols) {
+  return mrs_host::bind_tensor(*(Llama *)m, name, p, type, rows, cols);
+}
+extern "C" int mrs_llama_set_kv_cache(void *m, int layer, void *k, void *v) {
+  Llama &l = *(Llama *)m;
+  if (layer < 0 || layer >= l.cfg.num_layers) return mrs_host::fail("kv cache: layer %d out of range", layer);
+  l.blocks[layer].key_cache = k; l.blocks[layer].value_cache = v;
+  return 0;
+}
+extern "C" int mrs_llama_set_buffers(void *m, const mrs_llama_buffers *b) { return ((Llama *)m)->set_buffers(*b); }
+extern "C" int mrs_llama_decode_step(void *m, int b, void *stream) { return ((Llama *)m)->decode_step(b, (hipStream_t)stream); }
+extern "C" int mrs_llama_forward_logits(void *m, int b, void *stream) { return ((Llama *)m)->forward_logits(b, (hipStream_t)stream); }
+extern "C" double mrs_llama_decode_bytes(void *m, int b, int ctx) { return ((Llama *)m)->decode_bytes(b, ctx); }

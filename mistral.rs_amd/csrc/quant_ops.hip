@@ -23,8 +23,10 @@ __global__ void __launch_bounds__(512) rotary_kernel(T *__restrict__ query, T *_
     const int yi = NEOX ? rot_dim + rot_offset : 2 * rot_offset + 1;
     const float c = to_f<T>(cos_ptr[rot_offset]), s = to_f<T>(sin_ptr[rot_offset]);
     const float x = to_f<T>(arr[xi]), y = to_f<T>(arr[yi]);
-    arr[xi] = from_f<T>(round_to<T>(x * c) - round_to<T>(y * s));
-    arr[yi] = from_f<T>(round_to<T>(y * c) + round_to<T>(x * s));
+    float xo, yo;
+    rope_pair<T>(x, y, c, s, xo, yo);
+    arr[xi] = from_f<T>(xo);
+    arr[yi] = from_f<T>(yo);
   };
   const int nq = num_heads * rot_dim;
   for (int i = threadIdx.x; i < nq; i += blockDim.x) apply(query + token * query_stride + (int64_t)(i / rot_dim) * head_size, i % rot_dim);

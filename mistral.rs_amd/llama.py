@@ -1,0 +1,280 @@
+"""Python handle on the C++ model runner (csrc/host/runtime.cpp) + the host-side pieces either side of it:
+RoPE tables (mirror of mistralrs-core/src/layers.rs:1044-1182 `Llama3RotaryEmbedding`), paged-KV bookkeeping
+for a fixed batch (slot mapping rule of pipeline/inputs_processor.rs:900-922), and a HIP-graph decode loop
+(role of pipeline/cuda_graph.rs).  PyTorch only owns device buffers and the stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import _lib
+from .gguf.qtensor import GgmlDType, QTensor
+
+
+@dataclass
+class RopeScaling:  # Llama3RopeConfig (layers.rs:1030-1042)
+    rope_type: str = "default"  # default | llama3 | linear
+    factor: float = 1.0
+    low_freq_factor: float | None = None
+    high_freq_factor: float | None = None
+    original_max_position_embeddings: int | None = None
+
+
+@dataclass
+class LlamaConfig:
+    hidden_size: int
+    intermediate_size: int
+    num_layers: int
+    num_heads: int
+    num_kv_heads: int
+    vocab_size: int
+    head_dim: int | None = None
+    rms_eps: float = 1e-5
+    rope_theta: float = 500000.0
+    rope_scaling: RopeScaling | None = None
+    rope_interleaved: bool = True  # GGUF llama/mistral: adjacent pairs (gguf/normal_registry.rs:446-461)
+    max_position_embeddings: int = 8192
+    block_size: int = 32  # paged_attention/mod.rs:44
+    max_batch: int = 1
+    max_context_len: int = 1024
+    use_fused: bool = True
+
+    def __post_init__(self):
+        if self.head_dim is None:
+            self.head_dim = self.hidden_size // self.num_heads
+
+    @property
+    def max_blocks_per_seq(self) -> int:
+        return (self.max_context_len + self.block_size - 1) // self.block_size + 1
+
+    @classmethod
+    def llama3_8b(cls, **kw):
+        return cls(hidden_size=4096, intermediate_size=14336, num_layers=32, num_heads=32, num_kv_heads=8, vocab_size=128256,
+                   rope_theta=500000.0, rope_scaling=RopeScaling("llama3", 8.0, 1.0, 4.0, 8192), **kw)
+
+
+def rope_tables(cfg: LlamaConfig, freq_factors: np.ndarray | None = None):
+    """cos/sin [max_pos, head_dim/2] f32, following new_llama3_with_factors (layers.rs:1071-1182):
+    f32 inv_freq, t (f32) outer inv_freq (f32), then cos/sin."""
+    hd = cfg.head_dim
+    inv = (1.0 / np.power(np.float32(cfg.rope_theta), np.arange(0, hd, 2, dtype=np.float32) / np.float32(hd))).astype(np.float32)
+    rs = cfg.rope_scaling
+    if freq_factors is not None:
+        inv = (inv / np.asarray(freq_factors, dtype=np.float32)).astype(np.float32)
+    elif rs is not None and rs.rope_type == "llama3":
+        lo = np.float32(rs.original_max_position_embeddings) / np.float32(rs.low_freq_factor)
+        hi = np.float32(rs.original_max_position_embeddings) / np.float32(rs.high_freq_factor)
+        out = []
+        for f in inv:
+            wl = np.float32(2.0 * math.pi) / f
+            if wl < hi:
+                out.append(f)
+            elif wl > lo:
+                out.append(f / np.float32(rs.factor))
+            else:
+                sm = (np.float32(rs.original_max_position_embeddings) / wl - np.float32(rs.low_freq_factor)) / \
+                     (np.float32(rs.high_freq_factor) - np.float32(rs.low_freq_factor))
+                out.append((np.float32(1.0) - sm) * f / np.float32(rs.factor) + sm * f)
+        inv = np.array(out, dtype=np.float32)
+    elif rs is not None and rs.rope_type == "linear":
+        inv = (inv / np.float32(rs.factor)).astype(np.float32)
+    t = np.arange(cfg.max_position_embeddings, dtype=np.float32)[:, None]
+    freqs = (t * inv[None, :]).astype(np.float32)
+    return np.cos(freqs).astype(np.float32), np.sin(freqs).astype(np.float32)
+
+
+class _Cfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("hidden_size", "intermediate_size", "num_layers", "num_heads", "num_kv_heads", "head_dim",
+                                         "vocab_size", "rot_dim", "rope_interleaved")] + [("rms_eps", C.c_float)] + \
+               [(n, C.c_int32) for n in ("block_size", "max_blocks_per_seq", "max_batch", "max_context_len", "use_fused", "world_size", "rank")]
+
+
+class _Bufs(C.Structure):
+    _fields_ = [("input_ids", C.c_void_p), ("positions", C.c_void_p), ("context_lens", C.c_void_p), ("slot_mapping", C.c_void_p),
+                ("block_tables", C.c_void_p), ("tokens_out", C.c_void_p), ("tokens_out_stride", C.c_int32), ("step_counter", C.c_void_p),
+                ("cos_table", C.c_void_p), ("sin_table", C.c_void_p), ("logits", C.c_void_p), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_size_t)]
+
+
+class Llama:
+    """Quantized Llama/Mistral decoder on one MI355X.  Weights are registered under their GGUF tensor names."""
+
+    def __init__(self, cfg: LlamaConfig, device: torch.device, max_new_tokens: int = 4096, freq_factors=None):
+        self.cfg, self.device = cfg, device
+        L = _lib.load("ext")
+        _lib.load("quant"); _lib.load("paged_attn"); _lib.load("core")
+        self._L = L
+        L.mrs_llama_create.restype = C.c_void_p
+        L.mrs_llama_create.argtypes = [C.POINTER(_Cfg)]
+        L.mrs_llama_workspace_bytes.restype = C.c_size_t
+        L.mrs_llama_workspace_bytes.argtypes = [C.POINTER(_Cfg)]
+        L.mrs_llama_destroy.argtypes = [C.c_void_p]
+        L.mrs_llama_set_tensor.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64]
+        L.mrs_llama_set_kv_cache.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.mrs_llama_set_buffers.argtypes = [C.c_void_p, C.POINTER(_Bufs)]
+        L.mrs_llama_decode_step.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.mrs_llama_forward_logits.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.mrs_llama_decode_bytes.restype = C.c_double
+        L.mrs_llama_decode_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.mrs_last_error.restype = C.c_char_p
+        c = _Cfg(cfg.hidden_size, cfg.intermediate_size, cfg.num_layers, cfg.num_heads, cfg.num_kv_heads, cfg.head_dim,
+                 cfg.vocab_size, cfg.head_dim, int(cfg.rope_interleaved), cfg.rms_eps, cfg.block_size, cfg.max_blocks_per_seq,
+                 cfg.max_batch, cfg.max_context_len, int(cfg.use_fused), 1, 0)
+        self._c = c
+        self._h = L.mrs_llama_create(C.byref(c))
+        if not self._h:
+            raise ValueError(self._err())
+        self._keep: dict = {}
+        B, dev = cfg.max_batch, device
+        # paged KV cache, bf16, reference layout (cache_engine.rs:458-484); blocks for max_batch full sequences
+        self.num_blocks = B * cfg.max_blocks_per_seq
+        x = 8
+        self.key_caches = [torch.zeros(self.num_blocks, cfg.num_kv_heads, cfg.head_dim // x, cfg.block_size, x, dtype=torch.bfloat16, device=dev)
+                           for _ in range(cfg.num_layers)]
+        self.value_caches = [torch.zeros(self.num_blocks, cfg.num_kv_heads, cfg.head_dim, cfg.block_size, dtype=torch.bfloat16, device=dev)
+                             for _ in range(cfg.num_layers)]
+        for i, (k, v) in enumerate(zip(self.key_caches, self.value_caches)):
+            self._chk(L.mrs_llama_set_kv_cache(self._h, i, k.data_ptr(), v.data_ptr()))
+        cos, sin = rope_tables(cfg, freq_factors)
+        self.cos, self.sin = torch.from_numpy(cos).to(dev), torch.from_numpy(sin).to(dev)
+        self.input_ids = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.positions = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.context_lens = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.slot_mapping = torch.zeros(B, dtype=torch.int64, device=dev)
+        # sequence s owns blocks [s*max_blocks, (s+1)*max_blocks)
+        self.block_tables = (torch.arange(B * cfg.max_blocks_per_seq, dtype=torch.int32, device=dev)).reshape(B, cfg.max_blocks_per_seq).contiguous()
+        self.tokens_out = torch.zeros(B, max_new_tokens, dtype=torch.int32, device=dev)
+        self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.logits = torch.zeros(B, cfg.vocab_size, dtype=torch.float32, device=dev)
+        self.workspace = torch.empty(L.mrs_llama_workspace_bytes(C.byref(c)), dtype=torch.uint8, device=dev)
+        b = _Bufs(self.input_ids.data_ptr(), self.positions.data_ptr(), self.context_lens.data_ptr(), self.slot_mapping.data_ptr(),
+                  self.block_tables.data_ptr(), self.tokens_out.data_ptr(), max_new_tokens, self.step_counter.data_ptr(),
+                  self.cos.data_ptr(), self.sin.data_ptr(), self.logits.data_ptr(), self.workspace.data_ptr(), self.workspace.numel())
+        self._chk(L.mrs_llama_set_buffers(self._h, C.byref(b)))
+        self._graph = None
+
+    # -------------------------------------------------------------------------------------------------
+    def _err(self) -> str:
+        return (self._L.mrs_last_error() or b"").decode()
+
+    def _chk(self, rc: int):
+        if rc != 0:
+            raise ValueError(self._err())
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._L.mrs_llama_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def set_tensor(self, name: str, t) -> None:
+        """t: QTensor (packed GGUF blocks) or an f32 torch tensor (norm weights)."""
+        if isinstance(t, QTensor):
+            self._keep[name] = t
+            self._chk(self._L.mrs_llama_set_tensor(self._h, name.encode(), t.data.data_ptr(), t.dtype.id, t.shape[0], t.shape[1]))
+        else:
+            t = t.to(self.device, torch.float32).contiguous()
+            self._keep[name] = t
+            rows, cols = (1, t.numel()) if t.dim() == 1 else t.shape
+            self._chk(self._L.mrs_llama_set_tensor(self._h, name.encode(), t.data_ptr(), 0, rows, cols))
+
+    def decode_bytes(self, b: int, context_len: int) -> float:
+        return float(self._L.mrs_llama_decode_bytes(self._h, b, context_len))
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream().cuda_stream
+
+    def set_state(self, token_ids, positions) -> None:
+        """Point the decode state at `token_ids[s]` to be processed at `positions[s]` (context = position + 1)."""
+        b = len(token_ids)
+        cfg = self.cfg
+        pos = np.asarray(positions, dtype=np.int64)
+        if pos.max() >= cfg.max_context_len:
+            raise ValueError("position beyond max_context_len")
+        bt = self.block_tables[:b].cpu().numpy()
+        slots = bt[np.arange(b), pos // cfg.block_size].astype(np.int64) * cfg.block_size + pos % cfg.block_size
+        self.input_ids[:b] = torch.tensor(np.asarray(token_ids, dtype=np.int32), device=self.device)
+        self.positions[:b] = torch.tensor(pos.astype(np.int32), device=self.device)
+        self.context_lens[:b] = torch.tensor((pos + 1).astype(np.int32), device=self.device)
+        self.slot_mapping[:b] = torch.tensor(slots, device=self.device)
+
+    def forward_logits(self, b: int) -> torch.Tensor:
+        self._chk(self._L.mrs_llama_forward_logits(self._h, b, self._stream()))
+        return self.logits[:b]
+
+    def decode_step(self, b: int = 1) -> None:
+        self._chk(self._L.mrs_llama_decode_step(self._h, b, self._stream()))
+
+    def capture_decode_graph(self, b: int = 1) -> None:
+        """Capture one decode step (forward + greedy sample + state advance) into a HIP graph."""
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):  # warm-up outside capture (lazy module loads, attribute sets)
+            saved = [t.clone() for t in (self.input_ids, self.positions, self.context_lens, self.slot_mapping, self.step_counter)]
+            self.decode_step(b)
+            torch.cuda.current_stream().synchronize()
+            for t, v in zip((self.input_ids, self.positions, self.context_lens, self.slot_mapping, self.step_counter), saved):
+                t.copy_(v)
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.decode_step(b)
+        self._graph = g
+        for t, v in zip((self.input_ids, self.positions, self.context_lens, self.slot_mapping, self.step_counter), saved):
+            t.copy_(v)
+
+    def replay(self) -> None:
+        self._graph.replay()
+
+    # chunked prefill through the batch<=8 decode kernels: the chunk's tokens act as `b` sequences that share one
+    # block table, each attending to [0, its position] (K/V of the whole chunk are in the cache before attention).
+    def prefill_chunked(self, tokens, start_pos: int = 0, chunk: int = 8) -> torch.Tensor:
+        cfg = self.cfg
+        chunk = min(chunk, cfg.max_batch, 8)
+        saved_bt = self.block_tables.clone()
+        self.block_tables[:] = self.block_tables[0:1].expand_as(self.block_tables)
+        last = None
+        for i in range(0, len(tokens), chunk):
+            ids = tokens[i:i + chunk]
+            self.set_state(ids, [start_pos + i + j for j in range(len(ids))])
+            last = self.forward_logits(len(ids))[len(ids) - 1].clone()
+        self.block_tables.copy_(saved_bt)
+        return last
+
+
+def random_qtensor(dtype: GgmlDType, n: int, k: int, device, seed: int, w_std: float = 0.02) -> QTensor:
+    """Random-but-valid GGUF blocks generated ON THE GPU (no CPU quantizer, no oracle): random quants and
+    sub-scales, block super-scales chosen so the dequantized weights are ~zero-mean with std ~ w_std.
+    Used for synthetic benchmark models (there is no network for real checkpoints)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    ts, blk = dtype.type_size, dtype.block_size
+    nb = n * (k // blk)
+    raw = torch.randint(0, 256, (nb, ts), dtype=torch.uint8, device=device, generator=g)
+    half = raw.view(torch.int16).view(nb, ts // 2)
+
+    def f16bits(val: float, jitter: bool = True):
+        v = torch.full((nb,), val, dtype=torch.float32, device=device)
+        if jitter:
+            v = v * (0.75 + 0.5 * torch.rand(nb, device=device, generator=g))
+        return v.to(torch.float16).view(torch.int16)
+    if dtype == GgmlDType.Q4K or dtype == GgmlDType.Q5K:
+        qmax = 15 if dtype == GgmlDType.Q4K else 31
+        d = w_std / (31.5 * qmax * 0.36)
+        half[:, 0] = f16bits(d)
+        half[:, 1] = f16bits(d * qmax / 2.0)
+    elif dtype == GgmlDType.Q6K:
+        half[:, 104] = f16bits(w_std / (74.0 * 18.5))
+    elif dtype == GgmlDType.Q8_0:
+        half[:, 0] = f16bits(w_std / 74.0)
+    elif dtype in (GgmlDType.Q4_0, GgmlDType.Q5_0):
+        half[:, 0] = f16bits(w_std / (4.6 if dtype == GgmlDType.Q4_0 else 9.2))
+    else:
+        raise ValueError(f"random_qtensor: {dtype.name} not implemented")
+    return QTensor(dtype, (n, k), raw.view(-1))

@@ -1,0 +1,102 @@
+"""oracle/llama_ref.py -- TEST INFRASTRUCTURE ONLY.
+
+CPU restatement of the Llama / Mistral decoder graph as the reference drives it
+(mistralrs-core/src/models/llama.rs:68-157 CausalSelfAttention, :243-260 Block, :487-518 forward_embeds),
+token by token with an eager KV cache.  `mode` selects the matmul arithmetic:
+  "q8_1"  the GPU path's dataflow: activations quantized to Q8_1 (mmvq_gguf.cu), integer dots (oracle C)
+  "cpu"   the reference CPU path: candle QMatMul = Q8_K / Q8_0 activations (oracle B; parity unpinned)
+  "exact" dequantized weights, f64 accumulation (oracle A)
+Everything else is f32 like the CPU path: RMSNorm, interleaved/neox RoPE, SiLU-GLU, softmax attention.
+`kv_dtype` in {"f32", "bf16", "f16"} rounds K/V on the way into the cache.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import oracle as O
+
+
+def _round(x, dt):
+    if dt == "bf16":
+        return O.round_bf16(x)
+    if dt == "f16":
+        return x.astype(np.float16).astype(np.float32)
+    return x
+
+
+class LlamaRef:
+    def __init__(self, cfg, weights: dict, cos: np.ndarray, sin: np.ndarray, mode: str = "q8_1", kv_dtype: str = "bf16"):
+        """cfg: object with hidden_size, intermediate_size, num_layers, num_heads, num_kv_heads, head_dim, vocab_size,
+        rms_eps, rope_interleaved.  weights: GGUF name -> (ggml_type, packed uint8 [N, row_bytes]) or f32 array."""
+        self.cfg, self.w, self.cos, self.sin, self.mode, self.kv_dtype = cfg, weights, cos, sin, mode, kv_dtype
+        self.k = [[] for _ in range(cfg.num_layers)]
+        self.v = [[] for _ in range(cfg.num_layers)]
+
+    def linear(self, name: str, x: np.ndarray) -> np.ndarray:
+        t, packed = self.w[name]
+        n = packed.shape[0]
+        k = x.shape[-1]
+        if self.mode == "q8_1":
+            return O.matmul_q8_1(t, packed, n, k, O.quantize_q8_1(x.reshape(-1, k)))
+        if self.mode == "cpu":
+            return O.matmul_cpu(t, packed, n, k, x.reshape(-1, k))
+        return O.matmul_exact(t, packed, n, k, x.reshape(-1, k))
+
+    def embed(self, ids) -> np.ndarray:
+        t, packed = self.w["token_embd.weight"]
+        return O.dequantize(t, packed[np.asarray(ids)], self.cfg.hidden_size)
+
+    def step(self, token: int, pos: int) -> np.ndarray:
+        """Process one token at position `pos` (the cache must hold positions < pos). Returns logits [vocab]."""
+        c = self.cfg
+        hd, H, KVH = c.head_dim, c.num_heads, c.num_kv_heads
+        h = self.embed([token]).astype(np.float32)  # [1, d]
+        for l in range(c.num_layers):
+            p = f"blk.{l}."
+            xn = O.rms_norm(h, self.w[p + "attn_norm.weight"], c.rms_eps)
+            q = self.linear(p + "attn_q.weight", xn).reshape(1, H, hd)
+            k = self.linear(p + "attn_k.weight", xn).reshape(1, KVH, hd)
+            v = self.linear(p + "attn_v.weight", xn).reshape(1, KVH, hd)
+            posv = np.array([pos], dtype=np.int32)
+            q = O.rope(q, self.cos, self.sin, posv, not c.rope_interleaved)
+            k = O.rope(k, self.cos, self.sin, posv, not c.rope_interleaved)
+            assert len(self.k[l]) == pos, "cache out of sync with position"
+            self.k[l].append(_round(k[0], self.kv_dtype))
+            self.v[l].append(_round(v[0], self.kv_dtype))
+            att = O.attention(q, np.stack(self.k[l]), np.stack(self.v[l]), 1.0 / np.sqrt(hd))
+            h = h + self.linear(p + "attn_output.weight", att.reshape(1, H * hd))
+            xn = O.rms_norm(h, self.w[p + "ffn_norm.weight"], c.rms_eps)
+            g = self.linear(p + "ffn_gate.weight", xn)
+            u = self.linear(p + "ffn_up.weight", xn)
+            h = h + self.linear(p + "ffn_down.weight", O.fused_glu(g, u, 0))
+        xn = O.rms_norm(h, self.w["output_norm.weight"], c.rms_eps)
+        return self.linear("output.weight", xn)[0]
+
+    def run(self, tokens, start_pos: int = 0) -> np.ndarray:
+        return np.stack([self.step(int(t), start_pos + i) for i, t in enumerate(tokens)])
+
+
+def synth_weights(cfg, types: dict, seed: int = 0, w_std: float = 0.05) -> dict:
+    """Deterministic synthetic checkpoint quantized with the oracle's quantizers.
+    types: role -> ggml type id for {embd, q, k, v, o, gate, up, down, output}."""
+    rng = np.random.default_rng(seed)
+    d, ff, hd = cfg.hidden_size, cfg.intermediate_size, cfg.head_dim
+    nq, nkv = cfg.num_heads * hd, cfg.num_kv_heads * hd
+
+    def lin(role, n, k):
+        return (types[role], O.quantize(types[role], (rng.standard_normal((n, k)) * w_std).astype(np.float32)))
+
+    w = {"token_embd.weight": lin("embd", cfg.vocab_size, d), "output.weight": lin("output", cfg.vocab_size, d),
+         "output_norm.weight": (1 + 0.01 * rng.standard_normal(d)).astype(np.float32)}
+    for l in range(cfg.num_layers):
+        p = f"blk.{l}."
+        w[p + "attn_norm.weight"] = (1 + 0.01 * rng.standard_normal(d)).astype(np.float32)
+        w[p + "ffn_norm.weight"] = (1 + 0.01 * rng.standard_normal(d)).astype(np.float32)
+        w[p + "attn_q.weight"] = lin("q", nq, d)
+        w[p + "attn_k.weight"] = lin("k", nkv, d)
+        w[p + "attn_v.weight"] = lin("v", nkv, d)
+        w[p + "attn_output.weight"] = lin("o", d, nq)
+        w[p + "ffn_gate.weight"] = lin("gate", ff, d)
+        w[p + "ffn_up.weight"] = lin("up", ff, d)
+        w[p + "ffn_down.weight"] = lin("down", d, ff)
+    return w
