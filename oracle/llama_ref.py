@@ -5,6 +5,7 @@ CPU restatement of the Llama / Mistral decoder graph as the reference drives it
 token by token with an eager KV cache.  `mode` selects the matmul arithmetic:
   "q8_1"  the GPU path's dataflow: activations quantized to Q8_1 (mmvq_gguf.cu), integer dots (oracle C)
   "cpu"   the reference CPU path: candle QMatMul = Q8_K / Q8_0 activations (oracle B; parity unpinned)
+  "cpu_fast"  as "cpu" with vectorisable dot loops + OpenMP rows (b = 1 only; used as cpu_baseline)
   "exact" dequantized weights, f64 accumulation (oracle A)
 Everything else is f32 like the CPU path: RMSNorm, interleaved/neox RoPE, SiLU-GLU, softmax attention.
 `kv_dtype` in {"f32", "bf16", "f16"} rounds K/V on the way into the cache.
@@ -40,6 +41,8 @@ class LlamaRef:
             return O.matmul_q8_1(t, packed, n, k, O.quantize_q8_1(x.reshape(-1, k)))
         if self.mode == "cpu":
             return O.matmul_cpu(t, packed, n, k, x.reshape(-1, k))
+        if self.mode == "cpu_fast":  # same arithmetic, throughput-oriented (bench.py cpu_baseline)
+            return O.gemv_cpu_fast(t, packed, n, k, x.reshape(-1, k))
         return O.matmul_exact(t, packed, n, k, x.reshape(-1, k))
 
     def embed(self, ids) -> np.ndarray:

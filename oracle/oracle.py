@@ -163,6 +163,15 @@ def matmul_cpu(t: int, w: np.ndarray, n: int, k: int, x: np.ndarray) -> np.ndarr
     return out
 
 
+def gemv_cpu_fast(t: int, w: np.ndarray, n: int, k: int, x: np.ndarray) -> np.ndarray:
+    """b = 1 reference-CPU-path matvec, vectorisable + OpenMP (llama_oracle.c): the cpu_baseline kernel."""
+    x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
+    out = np.empty((1, n), dtype=np.float32)
+    if lib().orc_gemv_cpu_fast(t, _p(w), n, k, _p(x), _p(out)) != 0:
+        return matmul_cpu(t, w, n, k, x)
+    return out
+
+
 # ---------------------------------------------------------------- glue
 def rms_norm(x: np.ndarray, w: np.ndarray, eps: float) -> np.ndarray:
     x = np.ascontiguousarray(x, dtype=np.float32)
