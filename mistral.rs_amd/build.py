@@ -24,7 +24,7 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "lib")
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-CXXFLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
+CXXFLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-ffp-contract=off",
             "-I" + CSRC, "-I" + os.path.join(os.path.dirname(HERE), "include")]
 
 MMVQ_TYPES = {"q4_0": 2, "q4_1": 3, "q5_0": 6, "q5_1": 7, "q8_0": 8,

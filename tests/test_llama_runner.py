@@ -100,7 +100,9 @@ def test_batched_decode_matches_single(oracle, dev):
         for pos in range(5):
             m1.set_state([s[pos]], [pos])
             l1 = m1.forward_logits(1)[0].clone()
-        assert torch.equal(l1, lb[i]), f"sequence {i}: batched step differs from the single-sequence step"
+        nd = int((l1 != lb[i]).sum())
+        assert nd == 0, (f"sequence {i}: batched step differs from the single-sequence step in {nd}/{l1.numel()} logits, "
+                         f"max |diff| {float((l1 - lb[i]).abs().max()):.3e}")
 
 
 def test_graph_decode_loop_and_chunked_prefill(oracle, dev):
