@@ -43,7 +43,7 @@ def libraries():
     pa = [_tu("kv_cache_ops.hip")]
     for tag, t, ct, abi in (("f16", "mrs::f16_t", "mrs::f16_t", True), ("bf16", "mrs::bf16_t", "mrs::bf16_t", True),
                             ("f32", "float", "float", True), ("f32_bf16", "float", "mrs::bf16_t", False)):
-        d = [f"-DMRS_PA_TAG={tag}", f"-DMRS_PA_T={t}", f"-DMRS_PA_CT={ct}"] + (["-DMRS_PA_EXPORT_ABI"] if abi else [])
+        d = [f"-DMRS_PA_TAG={tag}", f"-DMRS_PA_T={t}", f"-DMRS_PA_CT={ct}"] + (["-DMRS_PA_EXPORT_ABI"] if abi else ["-DMRS_PA_DECODE_Q8_1"])
         pa.append(_tu("paged_attention.hip", f"paged_attention_{tag}.o", d))
     libs["libmistralrspagedattention.so"] = pa
     # optional translation units are picked up as soon as the file exists

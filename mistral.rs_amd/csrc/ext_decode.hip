@@ -62,49 +62,62 @@ template <int NT> __device__ __forceinline__ float block_sum_fixed(float v, floa
   return s;
 }
 
-// RMSNorm(x)*w -> Q8_1 activation image in LDS (same bytes the C-ABI quantizer would produce from the
-// f32 normed row): q [col][K] int8, d8 [col][K/32] = float(half(amax/127)), S [col][K/16] = d8 * sum(q).
-// xs: f32 scratch [K] in LDS.
+// RMSNorm(x)*w -> Q8_1 activation image in LDS, hot-format layout of mmvq_core.cuh (same values the C-ABI quantizer
+// would produce from the f32 normed row): q pieces (swizzled), d8 = float(half(amax/127)), S = d8 * sum(q over each
+// 16-run).  xs: f32 scratch [K] in LDS.
+// The sum of squares always runs on the first 256 threads in a fixed order, so kernels with different workgroup sizes
+// (and the standalone mrs_rms_norm kernel) produce bit-identical norms.
 template <int NCOLS, int NT>
 __device__ __forceinline__ ActLds stage_norm_q8_1(char *smem, const float *__restrict__ x, const float *__restrict__ nw, int K, float eps) {
   const int runs = K / 16, nblk = K / 32;
-  int8_t *q = (int8_t *)smem;
-  float *d8 = (float *)(smem + (size_t)NCOLS * K);
-  float *S = d8 + (size_t)NCOLS * nblk;
-  float *xs = S + (size_t)NCOLS * runs;
+  const ActLds v = act_view<NCOLS>(smem, K);
+  int8_t *q = (int8_t *)v.q;
+  float *d8 = (float *)v.d8, *S = (float *)v.S;
+  float *xs = (float *)(smem + act_lds_bytes(K, NCOLS));
   float *red = xs + K;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   for (int c = 0; c < NCOLS; ++c) {
     const float *xr = x + (size_t)c * K;
     float ss = 0.f;
-    for (int i = tid * 4; i < K; i += NT * 4) {
-      const float4 v = *(const float4 *)(xr + i);
-      *(float4 *)(xs + i) = v;
-      ss = fmaf(v.x, v.x, ss); ss = fmaf(v.y, v.y, ss); ss = fmaf(v.z, v.z, ss); ss = fmaf(v.w, v.w, ss);
+    if (tid < 256) {
+      for (int i = tid * 4; i < K; i += 256 * 4) {
+        const float4 v4 = *(const float4 *)(xr + i);
+        *(float4 *)(xs + i) = v4;
+        ss = fmaf(v4.x, v4.x, ss); ss = fmaf(v4.y, v4.y, ss); ss = fmaf(v4.z, v4.z, ss); ss = fmaf(v4.w, v4.w, ss);
+      }
+      ss = wave_sum(ss);
+      if ((tid & 63) == 0) red[tid >> 6] = ss;
     }
-    const float inv = rsqrtf(block_sum_fixed<NT>(ss, red) / (float)K + eps);  // (barrier inside: xs visible)
-    for (int e = wave * 64 + lane; e < K; e += NT) {  // a wave owns two adjacent 32-blocks per step
-      const float v = xs[e] * inv * nw[e];
-      float amax = fabsf(v);
-#pragma unroll
-      for (int m = 16; m > 0; m >>= 1) amax = fmaxf(amax, __shfl_xor(amax, m, 64));
+    __syncthreads();  // xs and red visible
+    const float inv = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)K + eps);  // same order as block_sum_256 (core_ops.hip)
+    // quantize: a thread owns 4 consecutive values, 8 threads own one Q8_1 block (all cross-lane steps are DPP)
+    for (int e = tid * 4; e < K; e += NT * 4) {
+      const float4 xv = *(const float4 *)(xs + e);
+      const float4 wv = *(const float4 *)(nw + e);
+      const float v0 = xv.x * inv * wv.x, v1 = xv.y * inv * wv.y, v2 = xv.z * inv * wv.z, v3 = xv.w * inv * wv.w;
+      float amax = fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3)));
+      amax = fmaxf(amax, dpp_mov<0xB1>(amax));
+      amax = fmaxf(amax, dpp_mov<0x4E>(amax));
+      amax = fmaxf(amax, dpp_mov<0x141>(amax));  // 8 lanes = one 32-value block
       const float d = amax / 127.0f;
-      const int qi = amax == 0.0f ? 0 : (int)roundf(v / d);
-      q[(size_t)c * K + e] = (int8_t)qi;
-      int su = qi;
-#pragma unroll
-      for (int m = 8; m > 0; m >>= 1) su += __shfl_xor(su, m, 64);
+      int q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+      if (amax != 0.0f) { q0 = (int)roundf(v0 / d); q1 = (int)roundf(v1 / d); q2 = (int)roundf(v2 / d); q3 = (int)roundf(v3 / d); }
+      const int piece = e >> 4;
+      *(int *)(q + (size_t)c * K + (size_t)swz(piece) * 16 + (e & 15)) = (q0 & 0xff) | ((q1 & 0xff) << 8) | ((q2 & 0xff) << 16) | ((q3 & 0xff) << 24);
+      int s = (q0 + q1) + (q2 + q3);
+      s += __builtin_amdgcn_update_dpp(0, s, 0xB1, 0xf, 0xf, false);
+      s += __builtin_amdgcn_update_dpp(0, s, 0x4E, 0xf, 0xf, false);  // 4 lanes = one 16-run
       const float dh = half_bits_to_float(float_to_half_bits(d));
+      if ((e & 15) == 0) S[c * runs + piece] = dh * (float)s;
       if ((e & 31) == 0) d8[c * nblk + (e >> 5)] = dh;
-      if ((e & 15) == 0) S[c * runs + (e >> 4)] = dh * (float)su;
     }
     __syncthreads();
   }
-  return ActLds{(const int4 *)q, d8, S, runs};
+  return v;
 }
 
 __host__ __device__ inline size_t norm_lds_bytes(int K, int ncols) {
-  return (size_t)ncols * ((size_t)K + (size_t)(K / 32) * 4 + (size_t)(K / 16) * 4) + (size_t)K * 4 + 64;
+  return act_lds_bytes(K, ncols) + (size_t)K * 4 + 64;
 }
 
 // wave-uniform runtime dispatch over the formats the fused path supports (K-quants + Q8_0)
@@ -131,28 +144,35 @@ __global__ void __launch_bounds__(NT) decode_gemv_kernel(const DecodeGemvArgs a)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NW = NT / 64;
   const int K = a.K;
-  ActLds act;
-  size_t act_bytes;
-  if constexpr (PRO == PRO_NORM) { act = stage_norm_q8_1<NCOLS, NT>(smem, a.x, a.norm_w, K, a.eps); act_bytes = norm_lds_bytes(K, NCOLS); }
-  else { act = stage_q8_1<T_Q4_K, NCOLS>(smem, a.y_q8_1, K, a.stride_col_y); act_bytes = act_lds_bytes(K, NCOLS, true); __syncthreads(); }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const size_t act_bytes = (PRO == PRO_NORM) ? norm_lds_bytes(K, NCOLS) : act_lds_bytes(K, NCOLS, true);
   float *out_s = (float *)(smem + ((act_bytes + 15) & ~(size_t)15));  // EPI_GLU_Q8_1: [rows_per_wg][NCOLS]
-
-  const int nslices = K / 32;
+  auto pro = [&]() -> ActLds {
+    if constexpr (PRO == PRO_NORM) {
+      return stage_norm_q8_1<NCOLS, NT>(smem, a.x, a.norm_w, K, a.eps);
+    } else {
+      const ActLds act = stage_q8_1<T_Q4_K, NCOLS>(smem, a.y_q8_1, K, a.stride_col_y);
+      __syncthreads();
+      return act;
+    }
+  };
   const int total_rows = (EPI == EPI_QKV_ROPE) ? a.nrows[0] + a.nrows[1] + a.nrows[2] : a.nrows[0];
   const int row0 = blockIdx.x * a.rows_per_wg;
   const int row1 = min(row0 + a.rows_per_wg, total_rows);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 
   if constexpr (EPI == EPI_GLU_Q8_1) {
     const size_t rb = hot_row_bytes(a.wtype[0], K);
-    for (int r = row0 + wave; r < row1; r += NW) {
-      float g[NCOLS], u[NCOLS];
-      MRS_HOT_TYPE_SWITCH(a.wtype[0], (row_dot2<TT, NCOLS>(a.w[0] + (size_t)r * rb, a.w[1] + (size_t)r * rb, nslices, act, g, u));)
+    const int rpw = a.rows_per_wg / NW;
+    const int first = row0 + wave * rpw;
+    const int nrows = max(0, min(rpw, row1 - first));
+    auto rowptr = [&](int r, const uint8_t *&pA, const uint8_t *&pB) { pA = a.w[0] + (size_t)r * rb; pB = a.w[1] + (size_t)r * rb; };
+    auto epi = [&](int r, float(&acc)[2][NCOLS]) {
       if (lane == 0) {
 #pragma unroll
-        for (int c = 0; c < NCOLS; ++c) out_s[(r - row0) * NCOLS + c] = glu_act(g[c], a.activation) * u[c];
+        for (int c = 0; c < NCOLS; ++c) out_s[(r - row0) * NCOLS + c] = glu_act(acc[0][c], a.activation) * acc[1][c];
       }
-    }
+    };
+    MRS_HOT_TYPE_SWITCH(a.wtype[0], (stream_rows_auto<TT, NCOLS, true>(first, nrows, 1, K, rpw, rowptr, pro, epi));)
     __syncthreads();
     // quantize this workgroup's rows (a multiple of 32) to Q8_1 blocks: lane <-> row inside a 32-block
     const int nblk = (row1 - row0) / 32;
@@ -168,19 +188,23 @@ __global__ void __launch_bounds__(NT) decode_gemv_kernel(const DecodeGemvArgs a)
       if ((e & 31) == 0) { ((uint16_t *)blk)[0] = float_to_half_bits(d); ((uint16_t *)blk)[1] = float_to_half_bits(sum); }
     }
   } else if constexpr (EPI == EPI_QKV_ROPE) {
-    for (int r = row0 + 2 * wave; r < row1; r += 2 * NW) {  // interleaved RoPE pairs (2i, 2i+1) stay in one wave
-      int m = 0, lr = r;
-      if (r >= a.nrows[0] + a.nrows[1]) { m = 2; lr = r - a.nrows[0] - a.nrows[1]; }
-      else if (r >= a.nrows[0]) { m = 1; lr = r - a.nrows[0]; }
-      const size_t rb = hot_row_bytes(a.wtype[m], K);
-      const uint8_t *w0 = a.w[m] + (size_t)lr * rb;
-      float v0[NCOLS], v1[NCOLS];
-      MRS_HOT_TYPE_SWITCH(a.wtype[m], (row_dot2<TT, NCOLS>(w0, w0 + rb, nslices, act, v0, v1));)
+    // the host guarantees that a workgroup's rows lie inside ONE of q / k / v (rows_per_wg divides nq and nk)
+    int m = 0, base = 0;
+    if (row0 >= a.nrows[0] + a.nrows[1]) { m = 2; base = a.nrows[0] + a.nrows[1]; }
+    else if (row0 >= a.nrows[0]) { m = 1; base = a.nrows[0]; }
+    const size_t rb = hot_row_bytes(a.wtype[m], K);
+    const uint8_t *wm = a.w[m];
+    const int ppw = a.rows_per_wg / (2 * NW);  // interleaved RoPE pairs (2i, 2i+1) stay in one wave
+    const int first = row0 + wave * 2 * ppw;
+    const int npairs = max(0, min(ppw, (row1 - first) / 2));
+    auto rowptr = [&](int r, const uint8_t *&pA, const uint8_t *&pB) { pA = wm + (size_t)(r - base) * rb; pB = pA + rb; };
+    auto epi = [&](int r, float(&acc)[2][NCOLS]) {
       if (lane == 0) {
+        const int lr = r - base;
         const int head = lr / a.head_dim, d = lr % a.head_dim, pair = d >> 1;
 #pragma unroll
         for (int c = 0; c < NCOLS; ++c) {
-          float x = v0[c], y = v1[c];
+          float x = acc[0][c], y = acc[1][c];
           if (m < 2 && pair < a.rot_pairs) {
             const size_t ti = (size_t)a.positions[c] * a.rot_pairs + pair;
             const float cs = a.cos_t[ti], sn = a.sin_t[ti];
@@ -198,45 +222,61 @@ __global__ void __launch_bounds__(NT) decode_gemv_kernel(const DecodeGemvArgs a)
               uint16_t *kc = (uint16_t *)a.k_cache, *vc = (uint16_t *)a.v_cache;
               if (m == 1) {
                 const int X = a.cache_x;
-                const int64_t base = ((blk * a.num_kv_heads + head) * (a.head_dim / X) + d / X) * a.block_size * X + off * X + d % X;
-                kc[base] = float_to_bf16_bits(x);
-                kc[base + 1] = float_to_bf16_bits(y);  // d is even and X is even: same 16-byte group
+                const int64_t o = ((blk * a.num_kv_heads + head) * (a.head_dim / X) + d / X) * a.block_size * X + off * X + d % X;
+                kc[o] = float_to_bf16_bits(x);
+                kc[o + 1] = float_to_bf16_bits(y);  // d is even and X is even: same 16-byte group
               } else {
-                const int64_t base = ((blk * a.num_kv_heads + head) * a.head_dim + d) * a.block_size + off;
-                vc[base] = float_to_bf16_bits(x);
-                vc[base + a.block_size] = float_to_bf16_bits(y);
+                const int64_t o = ((blk * a.num_kv_heads + head) * a.head_dim + d) * a.block_size + off;
+                vc[o] = float_to_bf16_bits(x);
+                vc[o + a.block_size] = float_to_bf16_bits(y);
               }
             }
           }
         }
       }
-    }
+    };
+    MRS_HOT_TYPE_SWITCH(a.wtype[m], (stream_rows_auto<TT, NCOLS, true>(first, npairs, 2, K, ppw, rowptr, pro, epi));)
   } else {
     const size_t rb = hot_row_bytes(a.wtype[0], K);
-    for (int r = row0 + wave; r < row1; r += NW) {
-      float acc[NCOLS];
-      MRS_HOT_TYPE_SWITCH(a.wtype[0], (row_dot<TT, NCOLS>(a.w[0] + (size_t)r * rb, nslices, act, acc));)
+    const int rpw = a.rows_per_wg / NW;
+    const int first = row0 + wave * rpw;
+    const int nrows = max(0, min(rpw, row1 - first));
+    auto rowptr = [&](int r, const uint8_t *&pA, const uint8_t *&pB) { pA = a.w[0] + (size_t)r * rb; pB = pA; };
+    auto epi = [&](int r, float(&acc)[1][NCOLS]) {
       if (lane == 0) {
 #pragma unroll
         for (int c = 0; c < NCOLS; ++c) {
           float *o = a.out + (size_t)c * a.out_stride + r;
-          if constexpr (EPI == EPI_RESID_ADD) *o = *o + acc[c]; else *o = acc[c];
+          if constexpr (EPI == EPI_RESID_ADD) *o = *o + acc[0][c]; else *o = acc[0][c];
         }
       }
-    }
+    };
+    MRS_HOT_TYPE_SWITCH(a.wtype[0], (stream_rows_auto<TT, NCOLS, false>(first, nrows, 1, K, rpw, rowptr, pro, epi));)
   }
 }
 
 static bool hot_type(int t) { return t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_Q8_0; }
 
 template <int PRO, int EPI> struct DecodeLaunch {
-  static constexpr int NT = 256;
+  static constexpr int NT = (EPI == EPI_GLU_Q8_1) ? 512 : 256;
   template <int NCOLS> static int go(DecodeGemvArgs a, hipStream_t s) {
     const int total = (EPI == EPI_QKV_ROPE) ? a.nrows[0] + a.nrows[1] + a.nrows[2] : a.nrows[0];
     constexpr int NW = NT / 64;
-    const int unit = (EPI == EPI_GLU_Q8_1) ? 32 : (EPI == EPI_QKV_ROPE ? 2 * NW : NW);
-    int per = (total + 1023) / 1024;              // at most 1024 workgroups (4 per CU)
-    per = (per + unit - 1) / unit * unit;
+    int per;
+    if (EPI == EPI_GLU_Q8_1) {
+      per = 32 * ((total / 32 + 511) / 512);  // whole Q8_1 output blocks per workgroup, <= 512 workgroups
+      if (per < 32) per = 32;
+    } else if (EPI == EPI_QKV_ROPE) {
+      int ppw = (total / 2 + 4095) / 4096;  // RoPE pairs per wave
+      if (ppw < 1) ppw = 1;
+      per = 2 * NW * ppw;
+      while (per > 2 * NW && (a.nrows[0] % per || a.nrows[1] % per)) per -= 2 * NW;
+      if (a.nrows[0] % per || a.nrows[1] % per) return -3;  // a workgroup must not straddle q/k/v
+    } else {
+      int rpw = (total + 4095) / 4096;
+      if (rpw < 1) rpw = 1;
+      per = NW * rpw;
+    }
     a.rows_per_wg = per;
     const int grid = (total + per - 1) / per;
     size_t lds = (PRO == PRO_NORM) ? norm_lds_bytes(a.K, NCOLS) : act_lds_bytes(a.K, NCOLS, true);

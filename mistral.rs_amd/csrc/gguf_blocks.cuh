@@ -168,6 +168,92 @@ template <int TYPE> __device__ __forceinline__ Slice load_slice(const uint8_t *_
   return r;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Split form of load_slice for software pipelining: load_raw() only ISSUES the global loads of one slice
+// (the registers it returns are not touched until decode_raw()), so a wave can keep several slices of
+// the NEXT rows in flight while it decodes and accumulates the current ones.  decode_raw(load_raw(...))
+// == load_slice(...) bit for bit.  The hot formats (Q4_K, Q5_K, Q6_K, Q8_0) have a true split; the other
+// formats decode at load time (their Raw IS the Slice).
+template <int TYPE> struct Raw { Slice s; };
+template <> struct Raw<T_Q4_K> { int4 hdr, qs; };
+template <> struct Raw<T_Q5_K> { int4 hdr, qs, qh; };
+template <> struct Raw<T_Q6_K> { int4 ql, qh; int2 sc; unsigned d; };
+template <> struct Raw<T_Q8_0> { int4 qa, qb; unsigned d; };
+
+__device__ __forceinline__ int2 ld8_a2(const void *p) { int2_a2 v = *(const int2_a2 *)p; return make_int2(v.x, v.y); }
+
+template <int TYPE> __device__ __forceinline__ Raw<TYPE> load_raw(const uint8_t *__restrict__ row, int s) {
+  Raw<TYPE> r;
+  if constexpr (TYPE == T_Q4_K) {
+    const uint8_t *blk = row + (size_t)(s >> 3) * 144;
+    r.hdr = ld16nt_a4(blk);
+    r.qs = ld16nt_a4(blk + 16 + (s & 7) * 16);
+  } else if constexpr (TYPE == T_Q5_K) {
+    const uint8_t *blk = row + (size_t)(s >> 3) * 176;
+    r.hdr = ld16nt_a4(blk);
+    r.qh = ld16nt_a4(blk + 16 + 16 * (s & 1));
+    r.qs = ld16nt_a4(blk + 48 + (s & 7) * 16);
+  } else if constexpr (TYPE == T_Q6_K) {
+    const uint8_t *blk = row + (size_t)(s >> 3) * 210;
+    const int l = s & 7, h = l >> 2, m = l & 3;
+    r.ql = ld16_a2(blk + l * 16);
+    r.qh = ld16_a2(blk + 128 + h * 32 + 16 * (m & 1));
+    r.sc = ld8_a2(blk + 192 + h * 8);
+    r.d = ld2(blk + 208);
+  } else if constexpr (TYPE == T_Q8_0) {
+    const uint8_t *blk = row + (size_t)s * 34;
+    r.d = ld2(blk);
+    r.qa = ld16_a2(blk + 2);
+    r.qb = ld16_a2(blk + 18);
+  } else {
+    r.s = load_slice<TYPE>(row, s);
+  }
+  return r;
+}
+
+template <int TYPE> __device__ __forceinline__ Slice decode_raw(const Raw<TYPE> &w, int s) {
+  Slice r;
+  if constexpr (TYPE == T_Q4_K || TYPE == T_Q5_K) {
+    const int l = s & 7, c = l >> 1;
+    const int4 hdr = w.hdr;
+    const float d = half_bits_to_float((uint16_t)(hdr.x & 0xffff));
+    const float dmin = half_bits_to_float((uint16_t)((unsigned)hdr.x >> 16));
+    // branch-free k4(g) for the sub-block pair (2c, 2c+1): 16-bit lanes A = scales16[c&1], B = scales16[(c&1)+2],
+    // C = scales16[(c&1)+4]; c < 2: sc = A & 0x3f3f, m = B & 0x3f3f; else sc = (C & 0x0f0f) | ((A >> 2) & 0x3030),
+    // m = ((C >> 4) & 0x0f0f) | ((B >> 2) & 0x3030)   (same bit surgery as vec_dot_q4_K_q8_1, mmvq_gguf.cu:600-607)
+    const int sh = 16 * (c & 1);
+    const unsigned A = (unsigned)hdr.y >> sh, B = (unsigned)hdr.z >> sh, C = (unsigned)hdr.w >> sh;
+    const unsigned scH = (C & 0x0f0fu) | ((A >> 2) & 0x3030u), mH = ((C >> 4) & 0x0f0fu) | ((B >> 2) & 0x3030u);
+    const unsigned sc = (c < 2) ? (A & 0x3f3fu) : scH, mm = (c < 2) ? (B & 0x3f3fu) : mH;
+    const unsigned sc0 = sc & 0xff, sc1 = (sc >> 8) & 0xff, m0 = mm & 0xff, m1 = (mm >> 8) & 0xff;
+    r.qa = and4(w.qs, 0x0F0F0F0F);
+    r.qb = and4(shr4(w.qs, 4), 0x0F0F0F0F);
+    if constexpr (TYPE == T_Q5_K) {
+      r.qa = or4(r.qa, shl4(and4(shr4(w.qh, 2 * c), 0x01010101), 4));
+      r.qb = or4(r.qb, shl4(and4(shr4(w.qh, 2 * c + 1), 0x01010101), 4));
+    }
+    r.sa = d * (float)sc0; r.sb = d * (float)sc1;
+    r.oa = dmin * (float)m0; r.ob = dmin * (float)m1;
+  } else if constexpr (TYPE == T_Q6_K) {
+    const int l = s & 7, m = l & 3, qt = m >> 1;
+    const int gi = qt * 2 + (m & 1);  // scale byte index inside this half's 8 scales; partner at +4
+    const float d = half_bits_to_float((uint16_t)w.d);
+    const int sc_lo = (int)(int8_t)(((unsigned)w.sc.x >> (8 * gi)) & 0xff);
+    const int sc_hi = (int)(int8_t)(((unsigned)w.sc.y >> (8 * gi)) & 0xff);
+    const float s0 = d * (float)sc_lo, s1 = d * (float)sc_hi;
+    r.qa = or4(and4(w.ql, 0x0F0F0F0F), shl4(and4(shr4(w.qh, 2 * qt), 0x03030303), 4));
+    r.qb = or4(and4(shr4(w.ql, 4), 0x0F0F0F0F), shl4(and4(shr4(w.qh, 2 * qt + 4), 0x03030303), 4));
+    r.sa = s0; r.sb = s1; r.oa = 32.0f * s0; r.ob = 32.0f * s1;
+  } else if constexpr (TYPE == T_Q8_0) {
+    const float d = half_bits_to_float((uint16_t)w.d);
+    r.qa = w.qa; r.qb = w.qb; r.sa = r.sb = d; r.oa = r.ob = 0.0f;
+  } else {
+    r = w.s;
+  }
+  return r;
+}
+
 __device__ __forceinline__ int dot16(int4 q, int4 u) {
   return dot4(q.w, u.w, dot4(q.z, u.z, dot4(q.y, u.y, dot4(q.x, u.x, 0))));
 }

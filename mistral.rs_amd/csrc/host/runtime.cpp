@@ -186,7 +186,7 @@ class Llama {
     const size_t B = c.max_batch, d = c.hidden_size, nq = (size_t)c.num_heads * c.head_dim, nkv = (size_t)c.num_kv_heads * c.head_dim;
     const size_t ya = B * (pad_to((int)std::max(d, nq), MATRIX_ROW_PADDING) / 32) * 36;
     const size_t yb = B * (pad_to(c.intermediate_size, MATRIX_ROW_PADDING) / 32) * 36;
-    const size_t parts = (c.max_context_len + 511) / 512;
+    const size_t parts = (c.max_context_len + 127) / 128;  // mrs_decode_attention_part() (<= the reference's 512)
     size_t t = 0;
     t += align(B * d * 4) * 3;            // h, xn, proj
     t += align(B * nq * 4) * 2;           // q, attn
@@ -211,7 +211,7 @@ class Llama {
     ws.y_a_bytes = B * (pad_to((int)std::max(d, nq), MATRIX_ROW_PADDING) / 32) * 36;
     ws.y_b_bytes = B * (pad_to(cfg.intermediate_size, MATRIX_ROW_PADDING) / 32) * 36;
     ws.y_a = take(ws.y_a_bytes); ws.y_b = take(ws.y_b_bytes);
-    const size_t parts = (cfg.max_context_len + 511) / 512;
+    const size_t parts = (cfg.max_context_len + 127) / 128;
     ws.attn_ws = take(B * cfg.num_heads * parts * cfg.head_dim * 4);
     ws.exp_sums = (float *)take(B * cfg.num_heads * parts * 4);
     ws.max_logits = (float *)take(B * cfg.num_heads * parts * 4);
@@ -308,8 +308,16 @@ class Llama {
                          cfg.rms_eps, ws.q, bl.key_cache, bl.value_cache, bufs.slot_mapping, bufs.positions, bufs.cos_table,
                          bufs.sin_table, hd, cfg.rot_dim / 2, cfg.num_kv_heads, cfg.block_size, b, s))
         return fail("mrs_decode_qkv refused the layer");
-      paged_attention_decode(bl, b, s);
-      mrs_quantize_rows_q8_1(ws.attn, ws.y_a, nq, stride_q, b, s);
+      {
+        const int bs = cfg.block_size, kvh = cfg.num_kv_heads;
+        const int eff_max = std::min(cfg.max_blocks_per_seq * bs, cfg.max_context_len);
+        if (mrs_decode_attention_q8_1_f32_bf16(ws.y_a, stride_q, ws.exp_sums, ws.max_logits, ws.attn_ws, ws.q, bl.key_cache, bl.value_cache, kvh,
+                                               1.0f / sqrtf((float)hd), bufs.block_tables, bufs.context_lens, bs, eff_max, b, cfg.num_heads, hd,
+                                               cfg.max_blocks_per_seq, cfg.num_heads * hd, kvh * hd * bs, hd * bs, s)) {
+          paged_attention_decode(bl, b, s);  // shapes outside the split kernel: reference-partitioned attention + quantize
+          mrs_quantize_rows_q8_1(ws.attn, ws.y_a, nq, stride_q, b, s);
+        }
+      }
       const QTensor *o = bl.o_proj->get_qtensor();
       if (mrs_decode_proj(o->data, o->dtype, d, nq, ws.y_a, stride_q, ws.h, d, 1, b, s)) return fail("mrs_decode_proj(o) refused");
       const QTensor *g = bl.gate_proj->get_qtensor(), *u = bl.up_proj->get_qtensor(), *dn = bl.down_proj->get_qtensor();

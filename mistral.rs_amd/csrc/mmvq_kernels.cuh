@@ -19,6 +19,7 @@ struct MmvqArgs {
   int stride_col_dst;
   int activation;
   int dst_kind;
+  int rows_per_wave;
 };
 
 __device__ __forceinline__ void store_dst(void *dst, size_t idx, float v, int kind) {
@@ -35,58 +36,65 @@ __device__ __forceinline__ float round_kind(float v, int kind) {
 template <int TYPE, int NCOLS, int MODE>
 __global__ void __launch_bounds__(256) mmvq_kernel(const MmvqArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const ActLds act = stage_q8_1<TYPE, NCOLS>(smem, a.y, a.ncols_x, a.stride_col_y);
-  __syncthreads();
-
   const int K = a.ncols_x;
-  const int nslices = K / 32;
   const size_t row_bytes = (size_t)(K / Fmt<TYPE>::BLK) * Fmt<TYPE>::TS;
   const int total_rows = (MODE == MODE_QKV) ? a.nrows[0] + a.nrows[1] + a.nrows[2] : a.nrows[0];
-  const int chunk = (total_rows + gridDim.x - 1) / gridDim.x;
-  const int row0 = blockIdx.x * chunk;
-  const int row1 = min(row0 + chunk, total_rows);
-  const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-  const int lane = lane_id();
-
-  for (int r = row0 + wave; r < row1; r += nwaves) {
-    if constexpr (MODE == MODE_GLU) {
-      // reference: mmvq_core_fused_glu_impl (mmvq_gguf.cu:794-873): both projections are rounded
-      // to dst_t, the activation runs in f32 on the rounded gate, is rounded again, then multiplied.
-      float g[NCOLS], u[NCOLS];
-      row_dot2<TYPE, NCOLS>(a.w[0] + (size_t)r * row_bytes, a.w[1] + (size_t)r * row_bytes, nslices, act, g, u);
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  const int rpw = a.rows_per_wave;  // contiguous rows per wave: each wave streams one contiguous byte range
+  const int first = (blockIdx.x * 4 + wave) * rpw;
+  const int nrows = max(0, min(rpw, total_rows - first));
+  auto pro = [&]() {
+    const ActLds act = stage_q8_1<TYPE, NCOLS>(smem, a.y, K, a.stride_col_y);
+    __syncthreads();
+    return act;
+  };
+  if constexpr (MODE == MODE_GLU) {
+    // reference: mmvq_core_fused_glu_impl (mmvq_gguf.cu:794-873): both projections are rounded
+    // to dst_t, the activation runs in f32 on the rounded gate, is rounded again, then multiplied.
+    auto rowptr = [&](int r, const uint8_t *&pA, const uint8_t *&pB) { pA = a.w[0] + (size_t)r * row_bytes; pB = a.w[1] + (size_t)r * row_bytes; };
+    auto epi = [&](int r, float(&acc)[2][NCOLS]) {
       if (lane == 0) {
 #pragma unroll
         for (int c = 0; c < NCOLS; ++c) {
-          const float gv = round_kind(g[c], a.dst_kind), uv = round_kind(u[c], a.dst_kind);
+          const float gv = round_kind(acc[0][c], a.dst_kind), uv = round_kind(acc[1][c], a.dst_kind);
           const float av = round_kind(glu_act(gv, a.activation), a.dst_kind);
           store_dst(a.dst[0], (size_t)c * a.stride_col_dst + r, av * uv, a.dst_kind);
         }
       }
-    } else {
-      const uint8_t *w = a.w[0];
-      void *dst = a.dst[0];
-      int lr = r, stride = a.stride_col_dst;
-      if constexpr (MODE == MODE_QKV) {  // mmvq_core_fused_qkv_impl (:875-996): dst[j*nrows_x + row]
-        if (r >= a.nrows[0] + a.nrows[1]) { lr = r - a.nrows[0] - a.nrows[1]; w = a.w[2]; dst = a.dst[2]; stride = a.nrows[2]; }
-        else if (r >= a.nrows[0]) { lr = r - a.nrows[0]; w = a.w[1]; dst = a.dst[1]; stride = a.nrows[1]; }
-        else { stride = a.nrows[0]; }
+    };
+    stream_rows_auto<TYPE, NCOLS, true>(first, nrows, 1, K, rpw, rowptr, pro, epi);
+  } else {
+    // MODE_QKV: mmvq_core_fused_qkv_impl (:875-996): virtual row r -> (matrix, local row), dst[j*nrows_x + row]
+    auto locate = [&](int r, int &m, int &lr) {
+      m = 0; lr = r;
+      if constexpr (MODE == MODE_QKV) {
+        if (r >= a.nrows[0] + a.nrows[1]) { m = 2; lr = r - a.nrows[0] - a.nrows[1]; }
+        else if (r >= a.nrows[0]) { m = 1; lr = r - a.nrows[0]; }
       }
-      float acc[NCOLS];
-      row_dot<TYPE, NCOLS>(w + (size_t)lr * row_bytes, nslices, act, acc);
+    };
+    auto rowptr = [&](int r, const uint8_t *&pA, const uint8_t *&pB) {
+      int m, lr;
+      locate(r, m, lr);
+      pA = a.w[m] + (size_t)lr * row_bytes;
+      pB = pA;
+    };
+    auto epi = [&](int r, float(&acc)[1][NCOLS]) {
       if (lane == 0) {
+        int m, lr;
+        locate(r, m, lr);
+        const int stride = (MODE == MODE_QKV) ? a.nrows[m] : a.stride_col_dst;
 #pragma unroll
-        for (int c = 0; c < NCOLS; ++c) store_dst(dst, (size_t)c * stride + lr, acc[c], a.dst_kind);
+        for (int c = 0; c < NCOLS; ++c) store_dst(a.dst[m], (size_t)c * stride + lr, acc[0][c], a.dst_kind);
       }
-    }
+    };
+    stream_rows_auto<TYPE, NCOLS, false>(first, nrows, 1, K, rpw, rowptr, pro, epi);
   }
 }
 
-inline int mmvq_grid(int total_rows, int waves_per_wg) {
-  // >= 1 row per wave; at most 4 workgroups of 256 threads per CU on the 256 CUs of an MI355X
-  int g = (total_rows + waves_per_wg - 1) / waves_per_wg;
-  if (g > 1024) g = 1024;
-  if (g < 1) g = 1;
-  return g;
+// rows per wave so that the grid is ~16 waves on each of the 256 CUs (all resident at once: no tail wave)
+inline int mmvq_rows_per_wave(int total_rows) {
+  int r = (total_rows + 4095) / 4096;
+  return r < 1 ? 1 : r;
 }
 
 template <int TYPE, int MODE> struct MmvqLaunch {
@@ -97,7 +105,10 @@ template <int TYPE, int MODE> struct MmvqLaunch {
       hipFuncSetAttribute((const void *)mmvq_kernel<TYPE, NCOLS, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr_done = true;
     }
-    hipLaunchKernelGGL((mmvq_kernel<TYPE, NCOLS, MODE>), dim3(mmvq_grid(total_rows, 4)), dim3(256), lds, s, a);
+    MmvqArgs b = a;
+    b.rows_per_wave = mmvq_rows_per_wave(total_rows);
+    const int grid = (total_rows + 4 * b.rows_per_wave - 1) / (4 * b.rows_per_wave);
+    hipLaunchKernelGGL((mmvq_kernel<TYPE, NCOLS, MODE>), dim3(grid), dim3(256), lds, s, b);
   }
   static void run(const MmvqArgs &a, int b_size, hipStream_t s) {
     const int total_rows = (MODE == MODE_QKV) ? a.nrows[0] + a.nrows[1] + a.nrows[2] : a.nrows[0];

@@ -278,4 +278,40 @@ __global__ void __launch_bounds__(128) paged_attention_reduce_kernel(T *__restri
   }
 }
 
+// MI355X decode path: merge the split-KV partials (as paged_attention_reduce_kernel) and emit the result directly as
+// Q8_1 blocks (the o_proj GEMV's activation format: same bytes as launch_mmvq_gguf_quantize_q8_1_f32 on the f32
+// attention output).  grid (heads, seqs), block HD threads (HD % 32 == 0); y: [seq][stride_blocks] blocks.
+template <int HD, int PART>
+__global__ void __launch_bounds__(HD) paged_attention_reduce_q8_1_kernel(uint8_t *__restrict__ y, int stride_blocks, const float *__restrict__ exp_sums,
+                                                                         const float *__restrict__ max_logits, const float *__restrict__ tmp_out,
+                                                                         const uint32_t *__restrict__ context_lens, int max_parts) {
+  const int num_heads = gridDim.x, head = blockIdx.x, seq = blockIdx.y, i = threadIdx.x;
+  const int nparts = (context_lens[seq] + PART - 1) / PART;
+  const float *tmp = tmp_out + ((size_t)seq * num_heads + head) * max_parts * HD;
+  const float *ml = max_logits + ((size_t)seq * num_heads + head) * max_parts;
+  const float *es = exp_sums + ((size_t)seq * num_heads + head) * max_parts;
+  float v;
+  if (nparts == 1) {
+    v = tmp[i];
+  } else {
+    float m = -FLT_MAX;
+    for (int j = 0; j < nparts; ++j) m = fmaxf(m, ml[j]);  // every thread walks the (few) partitions: no barrier needed
+    float gs = 0.f, acc = 0.f;
+    for (int j = 0; j < nparts; ++j) {
+      const float r = es[j] * expf(ml[j] - m);
+      gs += r;
+      acc += tmp[(size_t)j * HD + i] * r;
+    }
+    v = acc * (1.0f / (gs + 1e-6f));
+  }
+  float amax = fabsf(v), sum = v;
+#pragma unroll
+  for (int mk = 16; mk > 0; mk >>= 1) { amax = fmaxf(amax, __shfl_xor(amax, mk, 64)); sum += __shfl_xor(sum, mk, 64); }
+  const float d = amax / 127.0f;
+  const int e = head * HD + i;
+  uint8_t *blk = y + ((size_t)seq * stride_blocks + e / 32) * 36;
+  ((int8_t *)(blk + 4))[e & 31] = amax == 0.0f ? (int8_t)0 : (int8_t)roundf(v / d);
+  if ((e & 31) == 0) { ((uint16_t *)blk)[0] = float_to_half_bits(d); ((uint16_t *)blk)[1] = float_to_half_bits(sum); }
+}
+
 }  // namespace mrs

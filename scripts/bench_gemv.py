@@ -38,7 +38,7 @@ def main():
     from mistralrs_amd.gguf import fast_mmvq
     from mistralrs_amd.llama import random_qtensor
     dev = torch.device("cuda:0")
-    st = torch.cuda.current_stream().cuda_stream
+    stream = [torch.cuda.current_stream().cuda_stream]
     vp, ci = C.c_void_p, C.c_int
     tags = {d.tag: d for d in GgmlDType}
     shapes = [s for s in SHAPES if not a.shapes or s[0] in a.shapes.split(",")]
@@ -58,24 +58,37 @@ def main():
             fn = _lib.sym("quant", f"launch_mmvq_gguf_{tag}_f32_plain", [vp, vp, vp, ci, ci, ci, ci, ci, vp])
 
             def launch_abi(i):
-                fn(ws[i % nbuf].data.data_ptr(), y.data_ptr(), out.data_ptr(), k, n, stride, n, a.b, st)
+                fn(ws[i % nbuf].data.data_ptr(), y.data_ptr(), out.data_ptr(), k, n, stride, n, a.b, stream[0])
             cases = [("abi_plain", launch_abi)]
             if ext is not None and ext.mrs_decode_gemv_supported(dt.id):
                 ext.mrs_decode_proj.argtypes = [vp, ci, ci, ci, vp, ci, vp, ci, ci, ci, vp]
 
                 def launch_ext(i):
-                    ext.mrs_decode_proj(ws[i % nbuf].data.data_ptr(), dt.id, n, k, y.data_ptr(), stride, out.data_ptr(), n, 0, a.b, st)
+                    ext.mrs_decode_proj(ws[i % nbuf].data.data_ptr(), dt.id, n, k, y.data_ptr(), stride, out.data_ptr(), n, 0, a.b, stream[0])
                 cases.append(("ext_proj", launch_ext))
             for cname, launch in cases:
                 for i in range(nbuf):
                     launch(i)
                 torch.cuda.synchronize()
+                # HIP graph of the nbuf launches: device-side back-to-back issue, no host launch cost in the timing
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.stream(side):
+                    saved = stream[0]
+                    with torch.cuda.graph(g, stream=side):
+                        stream[0] = torch.cuda.current_stream().cuda_stream
+                        for i in range(nbuf):
+                            launch(i)
+                    stream[0] = saved
+                torch.cuda.current_stream().wait_stream(side)
+                g.replay()
+                torch.cuda.synchronize()
                 best = 1e9
                 for _ in range(a.reps):
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                    for i in range(nbuf):
-                        launch(i)
+                    g.replay()
                     e1.record()
                     torch.cuda.synchronize()
                     best = min(best, e0.elapsed_time(e1) / 1e3 / nbuf)

@@ -1,7 +1,9 @@
 """GPU parity: the C++ model runner (reference launch sequence AND the fused MI355X path) vs the oracle.
 
-  * fused (5 launches/layer) vs unfused (reference launch order through the drop-in C-ABI symbols):
-    BIT-IDENTICAL logits and KV caches -- same arithmetic, different launch structure;
+  * fused (6 launches/layer) vs unfused (reference launch order through the drop-in C-ABI symbols): same GEMV / norm /
+    RoPE arithmetic (layer-0 KV cache bit-identical); the fused path splits the KV range of decode attention into
+    128-token partitions instead of the reference's 512, so from the first attention on the two differ by f32
+    summation order (and the int8 rounding flips that follow) -- same tolerance as against the oracle;
   * both vs oracle/llama_ref.py "q8_1" mode (same dataflow in numpy/C, f64 combination): the dataflow has
     discrete steps (int8 activation rounding, bf16 KV rounding), so a sub-ulp difference (rsqrt / exp
     approximations, f32 summation order) either leaves the logits equal to ~1e-6 or flips an isolated
@@ -55,7 +57,7 @@ def test_fused_equals_reference_sequence_and_oracle(oracle, dev, mix):
     _, _, mu, _, _ = _mk(oracle, dev, False, types)
     ref = llama_ref.LlamaRef(cfg, w, cos, sin, mode="q8_1", kv_dtype="bf16")
     toks = _tokens(12)
-    rels = []
+    rels, fus = [], []
     for pos, t in enumerate(toks):
         want = ref.step(t, pos)
         outs = []
@@ -63,7 +65,9 @@ def test_fused_equals_reference_sequence_and_oracle(oracle, dev, mix):
             m.set_state([t], [pos])
             outs.append(m.forward_logits(1)[0].clone())
         torch.cuda.synchronize()
-        assert torch.equal(outs[0], outs[1]), f"fused != reference launch sequence at position {pos}"
+        fu = float((outs[0] - outs[1]).abs().max() / outs[1].abs().max())
+        assert fu <= 3e-2, f"fused vs reference launch sequence at position {pos}: rel {fu:.3e}"
+        fus.append(fu)
         got = outs[0].cpu().numpy()
         rel = np.abs(got - want).max() / np.abs(want).max()
         rels.append(rel)
@@ -72,8 +76,11 @@ def test_fused_equals_reference_sequence_and_oracle(oracle, dev, mix):
         if top2[1] - top2[0] > 2 * max(rel, 1e-4) * np.abs(want).max():
             assert int(got.argmax()) == int(want.argmax())
     assert np.mean(np.array(rels) <= 1e-4) >= 0.75, rels
+    assert np.mean(np.array(fus) <= 1e-4) >= 0.5, fus
+    assert torch.equal(mf.key_caches[0], mu.key_caches[0]) and torch.equal(mf.value_caches[0], mu.value_caches[0])
     for l in range(cfg.num_layers):
-        assert torch.equal(mf.key_caches[l], mu.key_caches[l]) and torch.equal(mf.value_caches[l], mu.value_caches[l])
+        for a_, b_ in ((mf.key_caches[l], mu.key_caches[l]), (mf.value_caches[l], mu.value_caches[l])):
+            assert float((a_.float() - b_.float()).abs().max()) <= 3e-2 * float(b_.float().abs().max())
         kref = np.stack(ref.k[l])  # [T, kvh, hd]
         from oracle import oracle as O
         kc, vc = O.kv_cache_gather(mf.key_caches[l].float().cpu().numpy(), mf.value_caches[l].float().cpu().numpy(),
