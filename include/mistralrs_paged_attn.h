@@ -73,12 +73,12 @@ void mrs_paged_attention_f32_bf16(int v2, void *out, float *exp_sums, float *max
                                   const uint32_t *context_lens, int block_size, int max_context_len, int num_seqs,
                                   int num_heads, int head_size, int max_num_blocks_per_seq, int q_stride,
                                   int kv_block_stride, int kv_head_stride, void *stream, const float *sinks);
-/* MI355X-native decode attention of the fused path: split-KV over mrs_decode_attention_part()-token partitions, then one
+/* MI355X-native decode attention of the fused path: split-KV (one wave per 32-token KV chunk of a GQA group), then one
  * merge kernel that writes the result as Q8_1 blocks (o_proj's activation format).  Replaces the run
  * paged_attention_v1/v2 -> launch_mmvq_gguf_quantize_q8_1 of the reference decode step (paged_attention.rs:1477-1561,
- * fast_mmvq.rs:340-383).  Workspace sizes use max_parts = ceil(max_context_len / part).  Returns 0, or -1 if the shape is
+ * fast_mmvq.rs:340-383).  Workspace sizes use max_parts = mrs_decode_attention_max_splits(max_context_len).  Returns 0, or -1 if the shape is
  * not supported (block_size 32, head_size 64/128). */
-int mrs_decode_attention_part(void);
+int mrs_decode_attention_max_splits(int max_context_len);
 int mrs_decode_attention_q8_1_f32_bf16(void *y_q8_1, int y_stride_blocks, float *exp_sums, float *max_logits, void *tmp_out,
                                        const void *query, const void *key_cache, const void *value_cache, int num_kv_heads,
                                        float scale, const uint32_t *block_tables, const uint32_t *context_lens, int block_size,

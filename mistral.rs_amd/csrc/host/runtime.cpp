@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cmath>
 #include <cstring>
@@ -186,7 +187,7 @@ class Llama {
     const size_t B = c.max_batch, d = c.hidden_size, nq = (size_t)c.num_heads * c.head_dim, nkv = (size_t)c.num_kv_heads * c.head_dim;
     const size_t ya = B * (pad_to((int)std::max(d, nq), MATRIX_ROW_PADDING) / 32) * 36;
     const size_t yb = B * (pad_to(c.intermediate_size, MATRIX_ROW_PADDING) / 32) * 36;
-    const size_t parts = (c.max_context_len + 127) / 128;  // mrs_decode_attention_part() (<= the reference's 512)
+    const size_t parts = (size_t)mrs_decode_attention_max_splits(c.max_context_len);  // >= the reference's 512-token partitions
     size_t t = 0;
     t += align(B * d * 4) * 3;            // h, xn, proj
     t += align(B * nq * 4) * 2;           // q, attn
@@ -211,7 +212,7 @@ class Llama {
     ws.y_a_bytes = B * (pad_to((int)std::max(d, nq), MATRIX_ROW_PADDING) / 32) * 36;
     ws.y_b_bytes = B * (pad_to(cfg.intermediate_size, MATRIX_ROW_PADDING) / 32) * 36;
     ws.y_a = take(ws.y_a_bytes); ws.y_b = take(ws.y_b_bytes);
-    const size_t parts = (cfg.max_context_len + 127) / 128;
+    const size_t parts = (size_t)mrs_decode_attention_max_splits(cfg.max_context_len);
     ws.attn_ws = take(B * cfg.num_heads * parts * cfg.head_dim * 4);
     ws.exp_sums = (float *)take(B * cfg.num_heads * parts * 4);
     ws.max_logits = (float *)take(B * cfg.num_heads * parts * 4);
@@ -298,17 +299,20 @@ class Llama {
   }
 
   // ---- MI355X fused sequence: 5 launches per layer (+ attention reduce / quantize)
+  // experiment hook (scripts/exp): MRS_ABLATE bit mask skips kernel classes so their in-graph cost can be measured
+  static int ablate() { static int v = -1; if (v < 0) { const char *e = getenv("MRS_ABLATE"); v = e ? atoi(e) : 0; } return v; }
   int forward_fused(int b, hipStream_t s) const {
+    const int ab = ablate();
     const int d = cfg.hidden_size, hd = cfg.head_dim, nq = cfg.num_heads * hd, nkv = cfg.num_kv_heads * hd, ff = cfg.intermediate_size;
     const int stride_q = pad_to(nq, MATRIX_ROW_PADDING) / 32, stride_f = pad_to(ff, MATRIX_ROW_PADDING) / 32;
     if (wte->embedding_forward_raw(bufs.input_ids, b, ws.h, s)) return -1;
     for (const Block &bl : blocks) {
       const QTensor *q = bl.q_proj->get_qtensor(), *k = bl.k_proj->get_qtensor(), *v = bl.v_proj->get_qtensor();
-      if (mrs_decode_qkv(q->data, k->data, v->data, q->dtype, k->dtype, v->dtype, nq, nkv, nkv, d, ws.h, bl.input_layernorm,
+      if (!(ab & 1) && mrs_decode_qkv(q->data, k->data, v->data, q->dtype, k->dtype, v->dtype, nq, nkv, nkv, d, ws.h, bl.input_layernorm,
                          cfg.rms_eps, ws.q, bl.key_cache, bl.value_cache, bufs.slot_mapping, bufs.positions, bufs.cos_table,
                          bufs.sin_table, hd, cfg.rot_dim / 2, cfg.num_kv_heads, cfg.block_size, b, s))
         return fail("mrs_decode_qkv refused the layer");
-      {
+      if (!(ab & 2)) {
         const int bs = cfg.block_size, kvh = cfg.num_kv_heads;
         const int eff_max = std::min(cfg.max_blocks_per_seq * bs, cfg.max_context_len);
         if (mrs_decode_attention_q8_1_f32_bf16(ws.y_a, stride_q, ws.exp_sums, ws.max_logits, ws.attn_ws, ws.q, bl.key_cache, bl.value_cache, kvh,
@@ -319,14 +323,14 @@ class Llama {
         }
       }
       const QTensor *o = bl.o_proj->get_qtensor();
-      if (mrs_decode_proj(o->data, o->dtype, d, nq, ws.y_a, stride_q, ws.h, d, 1, b, s)) return fail("mrs_decode_proj(o) refused");
+      if (!(ab & 4) && mrs_decode_proj(o->data, o->dtype, d, nq, ws.y_a, stride_q, ws.h, d, 1, b, s)) return fail("mrs_decode_proj(o) refused");
       const QTensor *g = bl.gate_proj->get_qtensor(), *u = bl.up_proj->get_qtensor(), *dn = bl.down_proj->get_qtensor();
-      if (mrs_decode_gate_up(g->data, u->data, g->dtype, ff, d, ws.h, bl.post_attention_layernorm, cfg.rms_eps, 0, ws.y_b, stride_f, b, s))
+      if (!(ab & 8) && mrs_decode_gate_up(g->data, u->data, g->dtype, ff, d, ws.h, bl.post_attention_layernorm, cfg.rms_eps, 0, ws.y_b, stride_f, b, s))
         return fail("mrs_decode_gate_up refused");
-      if (mrs_decode_proj(dn->data, dn->dtype, d, ff, ws.y_b, stride_f, ws.h, d, 1, b, s)) return fail("mrs_decode_proj(down) refused");
+      if (!(ab & 16) && mrs_decode_proj(dn->data, dn->dtype, d, ff, ws.y_b, stride_f, ws.h, d, 1, b, s)) return fail("mrs_decode_proj(down) refused");
     }
     const QTensor *lm = lm_head->get_qtensor();
-    if (mrs_decode_norm_proj(lm->data, lm->dtype, cfg.vocab_size, d, ws.h, ln_f, cfg.rms_eps, bufs.logits, cfg.vocab_size, b, s))
+    if (!(ab & 32) && mrs_decode_norm_proj(lm->data, lm->dtype, cfg.vocab_size, d, ws.h, ln_f, cfg.rms_eps, bufs.logits, cfg.vocab_size, b, s))
       return fail("mrs_decode_norm_proj refused");
     return 0;
   }

@@ -3,6 +3,7 @@
 // (declared in mistralrs-quant/src/gguf/ffi.rs, defined in kernels/mmvq_gguf/mmvq_gguf.cu:1322-1600).
 #pragma once
 #include "mmvq_core.cuh"
+#include <stdlib.h>
 
 namespace mrs {
 
@@ -92,8 +93,14 @@ __global__ void __launch_bounds__(256) mmvq_kernel(const MmvqArgs a) {
 }
 
 // rows per wave so that the grid is ~16 waves on each of the 256 CUs (all resident at once: no tail wave)
+inline int mmvq_target_waves() {
+  static int v = 0;
+  if (!v) { const char *e = getenv("MRS_MMVQ_WAVES"); v = e ? atoi(e) : 4096; if (v < 256) v = 256; }
+  return v;
+}
 inline int mmvq_rows_per_wave(int total_rows) {
-  int r = (total_rows + 4095) / 4096;
+  const int t = mmvq_target_waves();
+  int r = (total_rows + t - 1) / t;
   return r < 1 ? 1 : r;
 }
 

@@ -37,6 +37,10 @@ template <> __device__ __forceinline__ void unpack16<float>(const int4 &raw, flo
   o[0] = __int_as_float(raw.x); o[1] = __int_as_float(raw.y); o[2] = __int_as_float(raw.z); o[3] = __int_as_float(raw.w);
 }
 
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+
 struct PagedAttnArgs {
   float *exp_sums;    // v2: [seqs, heads, max_parts]
   float *max_logits;  // v2
@@ -304,6 +308,167 @@ __global__ void __launch_bounds__(HD) paged_attention_reduce_q8_1_kernel(uint8_t
     }
     v = acc * (1.0f / (gs + 1e-6f));
   }
+  float amax = fabsf(v), sum = v;
+#pragma unroll
+  for (int mk = 16; mk > 0; mk >>= 1) { amax = fmaxf(amax, __shfl_xor(amax, mk, 64)); sum += __shfl_xor(sum, mk, 64); }
+  const float d = amax / 127.0f;
+  const int e = head * HD + i;
+  uint8_t *blk = y + ((size_t)seq * stride_blocks + e / 32) * 36;
+  ((int8_t *)(blk + 4))[e & 31] = amax == 0.0f ? (int8_t)0 : (int8_t)roundf(v / d);
+  if ((e & 31) == 0) { ((uint16_t *)blk)[0] = float_to_half_bits(d); ((uint16_t *)blk)[1] = float_to_half_bits(sum); }
+}
+
+// =====================================================================================================
+// MI355X decode attention v3 ("wave per KV chunk"): the batch-1 decode step at a few hundred tokens of context is
+// a latency chain, not a bandwidth problem (3 MB of KV for Llama-3-8B at ctx 768), so the kernel has NO workgroup
+// barrier and no LDS logits: every wave owns `bpw` consecutive 32-token KV blocks of one (sequence, kv-head) and
+// runs an online-softmax over them for all G query heads of the GQA group, reading each K/V byte once.
+//   * Q.K^T: lane (t = lane & 31, half = lane >> 5) owns token t and 64 of the 128 head dims (8 coalesced 16-byte
+//     chunks of the [hd/8][32][8] K layout); q (f32, G heads) is staged once per wave in LDS and read as broadcasts;
+//   * P.V: lane owns V rows d = lane and lane + 64 ([hd][32] layout: one 64-byte row = 4 x 16 B), probabilities go
+//     through a 512-byte wave-private LDS tile (written by the token lanes, read back as broadcasts);
+//   * K and V loads of a block are issued together, before any arithmetic;
+//   * output: un-normalised partial o[g][d], running max m[g] and sum l[g] per (seq, head, split) for the merge kernel.
+// Semantics = pagedattention.cuh:110-486 with f32 probabilities rounded to the KV dtype before P.V (ROUND_P).
+template <int G>
+__global__ void __launch_bounds__(256) decode_attn_wave_kernel(const float *__restrict__ q, const uint16_t *__restrict__ k_cache,
+                                                               const uint16_t *__restrict__ v_cache, const uint32_t *__restrict__ block_tables,
+                                                               const uint32_t *__restrict__ context_lens, float *__restrict__ part_o,
+                                                               float *__restrict__ part_m, float *__restrict__ part_l, int num_heads,
+                                                               int num_kv_heads, int max_blocks_per_seq, int q_stride, int kv_block_stride,
+                                                               int kv_head_stride, int bpw, int max_splits, float scale) {
+  constexpr int HD = 128, BS = 32;
+  __shared__ __attribute__((aligned(16))) float q_s[4][G * HD];  // per wave
+  __shared__ __attribute__((aligned(16))) float p_s[4][G * BS];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int kvh = blockIdx.x, seq = blockIdx.y;
+  const int split = blockIdx.z * 4 + wave;
+  const int ctx = (int)context_lens[seq];
+  const int nblk = (ctx + BS - 1) / BS;
+  const int b0 = split * bpw, b1 = min(b0 + bpw, nblk);
+  if (b0 >= nblk) return;  // wave-uniform; no barriers anywhere in this kernel
+  const int head0 = kvh * G;
+  // q -> LDS (wave-private)
+  const float *qg = q + (size_t)seq * q_stride + (size_t)head0 * HD;
+  for (int i = lane * 4; i < G * HD; i += 256) *(float4 *)(q_s[wave] + i) = *(const float4 *)(qg + i);
+  const uint32_t *bt = block_tables + (size_t)seq * max_blocks_per_seq;
+  const int t = lane & 31, half = lane >> 5;
+  float m[G], l[G], o0[G], o1[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) { m[g] = -FLT_MAX; l[g] = 0.f; o0[g] = 0.f; o1[g] = 0.f; }
+  for (int b = b0; b < b1; ++b) {
+    const size_t base = (size_t)bt[b] * kv_block_stride + (size_t)kvh * kv_head_stride;
+    const uint16_t *kb = k_cache + base + (size_t)(half * 8) * BS * 8 + t * 8;
+    const uint16_t *vb = v_cache + base;
+    int4 kr[8], vr[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) kr[c] = *(const int4 *)(kb + (size_t)c * BS * 8);
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) vr[r * 4 + c] = *(const int4 *)(vb + (size_t)(lane + 64 * r) * BS + c * 8);
+    // ---- scores for token t, all G heads
+    float s[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) s[g] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float kf[8];
+      unpack16<bf16_t>(kr[c], kf);
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float4 qa = *(const float4 *)(q_s[wave] + g * HD + (half * 8 + c) * 8);
+        const float4 qb = *(const float4 *)(q_s[wave] + g * HD + (half * 8 + c) * 8 + 4);
+        s[g] = fmaf(qa.x, kf[0], s[g]); s[g] = fmaf(qa.y, kf[1], s[g]); s[g] = fmaf(qa.z, kf[2], s[g]); s[g] = fmaf(qa.w, kf[3], s[g]);
+        s[g] = fmaf(qb.x, kf[4], s[g]); s[g] = fmaf(qb.y, kf[5], s[g]); s[g] = fmaf(qb.z, kf[6], s[g]); s[g] = fmaf(qb.w, kf[7], s[g]);
+      }
+    }
+    const bool valid = b * BS + t < ctx;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      float v = s[g] + __shfl_xor(s[g], 32, 64);  // the two dim-halves of token t
+      v = valid ? v * scale : -FLT_MAX;
+      // block max over the 32 tokens (all DPP inside 16 lanes, one swizzle across the two rows of 16)
+      float mx = v;
+      mx = fmaxf(mx, dpp_f<0xB1>(mx)); mx = fmaxf(mx, dpp_f<0x4E>(mx)); mx = fmaxf(mx, dpp_f<0x141>(mx)); mx = fmaxf(mx, dpp_f<0x140>(mx));
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      const float mn = fmaxf(m[g], mx);
+      const float p = valid ? __expf(v - mn) : 0.f;
+      const float pr = bf16_bits_to_float(float_to_bf16_bits(p));  // reference: probabilities cast to the KV dtype before P.V
+      float ps = p;
+      ps += dpp_f<0xB1>(ps); ps += dpp_f<0x4E>(ps); ps += dpp_f<0x141>(ps); ps += dpp_f<0x140>(ps);
+      ps += __shfl_xor(ps, 16, 64);
+      const float alpha = __expf(m[g] - mn);
+      l[g] = l[g] * alpha + ps;
+      o0[g] *= alpha; o1[g] *= alpha;
+      m[g] = mn;
+      if (half == 0) p_s[wave][g * BS + t] = pr;
+    }
+    // ---- P.V for rows d = lane, lane + 64 (wave-private LDS: same-wave LDS ops are ordered, no barrier needed)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float vf[8];
+        unpack16<bf16_t>(vr[r * 4 + c], vf);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vf[j] = (b * BS + c * 8 + j < ctx) ? vf[j] : 0.f;  // stale slots may hold NaNs
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const float4 pa = *(const float4 *)(p_s[wave] + g * BS + c * 8);
+          const float4 pb = *(const float4 *)(p_s[wave] + g * BS + c * 8 + 4);
+          float acc = r == 0 ? o0[g] : o1[g];
+          acc = fmaf(pa.x, vf[0], acc); acc = fmaf(pa.y, vf[1], acc); acc = fmaf(pa.z, vf[2], acc); acc = fmaf(pa.w, vf[3], acc);
+          acc = fmaf(pb.x, vf[4], acc); acc = fmaf(pb.y, vf[5], acc); acc = fmaf(pb.z, vf[6], acc); acc = fmaf(pb.w, vf[7], acc);
+          if (r == 0) o0[g] = acc; else o1[g] = acc;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const size_t pi = ((size_t)seq * num_heads + head0 + g) * max_splits + split;
+    part_o[pi * HD + lane] = o0[g];
+    part_o[pi * HD + lane + 64] = o1[g];
+    if (lane == 0) { part_m[pi] = m[g]; part_l[pi] = l[g]; }
+  }
+}
+
+// merge of the per-split partials + Q8_1 quantisation of the attention output (o_proj's activation format).
+// grid (heads, seqs), 128 threads (thread = head dim)
+template <int HD>
+__global__ void __launch_bounds__(HD) decode_attn_merge_q8_1_kernel(uint8_t *__restrict__ y, int stride_blocks, const float *__restrict__ part_o,
+                                                                     const float *__restrict__ part_m, const float *__restrict__ part_l,
+                                                                     const uint32_t *__restrict__ context_lens, int bpw, int max_splits) {
+  const int num_heads = gridDim.x, head = blockIdx.x, seq = blockIdx.y, i = threadIdx.x;
+  const int nblk = ((int)context_lens[seq] + 31) / 32;
+  const int ns = (nblk + bpw - 1) / bpw;  // <= 64 (DEC_MAX_SPLITS)
+  const size_t p0 = ((size_t)seq * num_heads + head) * max_splits;
+  // split weights r_j = exp(m_j - max m) once per workgroup (lane j <-> split j), then ONE pass over the partial outputs
+  // with independent loads in flight (the naive per-thread loop is a chain of ns dependent L2 round trips)
+  __shared__ float r_s[64];
+  __shared__ float gs_s;
+  if (i < 64) {
+    const float mj = i < ns ? part_m[p0 + i] : -FLT_MAX;
+    const float lj = i < ns ? part_l[p0 + i] : 0.f;
+    const float mx = wave_max(mj);
+    const float r = i < ns ? __expf(mj - mx) : 0.f;
+    r_s[i] = r;
+    const float g = wave_sum(lj * r);
+    if (i == 0) gs_s = g;
+  }
+  __syncthreads();
+  const float gs = gs_s;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  const float *po = part_o + p0 * HD + i;
+  int j = 0;
+  for (; j + 4 <= ns; j += 4) {
+    const float v0 = po[(size_t)(j + 0) * HD], v1 = po[(size_t)(j + 1) * HD], v2 = po[(size_t)(j + 2) * HD], v3 = po[(size_t)(j + 3) * HD];
+    a0 = fmaf(v0, r_s[j], a0); a1 = fmaf(v1, r_s[j + 1], a1); a2 = fmaf(v2, r_s[j + 2], a2); a3 = fmaf(v3, r_s[j + 3], a3);
+  }
+  for (; j < ns; ++j) a0 = fmaf(po[(size_t)j * HD], r_s[j], a0);
+  const float acc = (a0 + a1) + (a2 + a3);
+  const float v = acc * (1.0f / (gs + 1e-6f));
   float amax = fabsf(v), sum = v;
 #pragma unroll
   for (int mk = 16; mk > 0; mk >>= 1) { amax = fmaxf(amax, __shfl_xor(amax, mk, 64)); sum += __shfl_xor(sum, mk, 64); }

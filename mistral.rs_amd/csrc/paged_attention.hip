@@ -131,34 +131,61 @@ extern "C" void PA_CAT(mrs_paged_attention_, MRS_PA_TAG)(
 }
 
 #ifdef MRS_PA_DECODE_Q8_1
-// MI355X decode attention for the fused path: split-KV over DEC_PART-token partitions (many more workgroups than the
-// reference's 512-token v2 partitions: a batch-1 decode at context ~700 would otherwise run on 16 of the 256 CUs),
-// then ONE merge kernel that writes Q8_1 blocks for o_proj.  Workspace: tmp_out [seqs, heads, max_parts, hd] f32,
-// exp_sums / max_logits [seqs, heads, max_parts] with max_parts = ceil(max_context_len / DEC_PART).
-namespace mrs { constexpr int DEC_PART = 128; }
-extern "C" int mrs_decode_attention_part(void) { return mrs::DEC_PART; }
+// MI355X decode attention for the fused path.  head_size 128 / block 32 / bf16 cache: the wave-per-KV-chunk kernel
+// (paged_attention.cuh, "decode attention v3") + one merge kernel that writes Q8_1 blocks for o_proj.  Other shapes:
+// the reference-style kernel over DEC_PART-token partitions + merge.  Workspace (caller-owned):
+//   tmp_out [seqs, heads, max_splits, hd] f32, exp_sums / max_logits [seqs, heads, max_splits]
+//   with max_splits = mrs_decode_attention_max_splits(max_context_len).
+namespace mrs {
+constexpr int DEC_PART = 128;
+constexpr int DEC_MAX_SPLITS = 64;
+static int dec_bpw(int max_context_len) {  // KV blocks (32 tokens) per wave
+  const int nblk = (max_context_len + 31) / 32;
+  return nblk <= DEC_MAX_SPLITS ? 1 : (nblk + DEC_MAX_SPLITS - 1) / DEC_MAX_SPLITS;
+}
+}  // namespace mrs
+extern "C" int mrs_decode_attention_max_splits(int max_context_len) {
+  const int nblk = (max_context_len + 31) / 32, bpw = mrs::dec_bpw(max_context_len);
+  const int v3 = (nblk + bpw - 1) / bpw, v2 = (max_context_len + mrs::DEC_PART - 1) / mrs::DEC_PART;
+  return v3 > v2 ? v3 : v2;
+}
 extern "C" int PA_CAT(mrs_decode_attention_q8_1_, MRS_PA_TAG)(
     void *y_q8_1, int y_stride_blocks, float *exp_sums, float *max_logits, void *tmp_out, const void *query, const void *key_cache,
     const void *value_cache, int num_kv_heads, float scale, const uint32_t *block_tables, const uint32_t *context_lens, int block_size,
     int max_context_len, int num_seqs, int num_heads, int head_size, int max_num_blocks_per_seq, int q_stride, int kv_block_stride,
     int kv_head_stride, void *stream) {
   using namespace mrs;
-  if (block_size != 32 || (head_size != 128 && head_size != 64) || num_seqs <= 0) return -1;
+  if (block_size != 32 || (head_size != 128 && head_size != 64) || num_seqs <= 0 || num_heads % num_kv_heads) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  const int max_splits = mrs_decode_attention_max_splits(max_context_len);
+  const int qpk = num_heads / num_kv_heads;
+  if (head_size == 128 && (qpk == 1 || qpk == 2 || qpk == 4 || qpk == 8)) {
+    const int bpw = dec_bpw(max_context_len);
+    const int nsplit = ((max_context_len + 31) / 32 + bpw - 1) / bpw;
+    const dim3 grid(num_kv_heads, num_seqs, (nsplit + 3) / 4);
+#define DEC(G) hipLaunchKernelGGL((decode_attn_wave_kernel<G>), grid, dim3(256), 0, s, (const float *)query, (const uint16_t *)key_cache,          \
+                                  (const uint16_t *)value_cache, block_tables, context_lens, (float *)tmp_out, max_logits, exp_sums, num_heads, \
+                                  num_kv_heads, max_num_blocks_per_seq, q_stride, kv_block_stride, kv_head_stride, bpw, max_splits, scale)
+    switch (qpk) { case 1: DEC(1); break; case 2: DEC(2); break; case 4: DEC(4); break; default: DEC(8); break; }
+#undef DEC
+    hipLaunchKernelGGL(decode_attn_merge_q8_1_kernel<128>, dim3(num_heads, num_seqs), dim3(128), 0, s, (uint8_t *)y_q8_1, y_stride_blocks,
+                       (const float *)tmp_out, max_logits, exp_sums, context_lens, bpw, max_splits);
+    pa_check("mrs_decode_attention_q8_1 (v3)");
+    return 0;
+  }
   PagedAttnArgs a{};
   a.exp_sums = exp_sums; a.max_logits = max_logits; a.out = tmp_out; a.q = query; a.k_cache = key_cache; a.v_cache = value_cache;
   a.block_tables = block_tables; a.context_lens = context_lens; a.num_heads = num_heads; a.num_kv_heads = num_kv_heads;
   a.max_num_blocks_per_seq = max_num_blocks_per_seq; a.q_stride = q_stride; a.kv_block_stride = kv_block_stride;
   a.kv_head_stride = kv_head_stride; a.scale = scale; a.softcapping = 1.0f; a.logits_stride = DEC_PART;
-  const int max_parts = (max_context_len + DEC_PART - 1) / DEC_PART;
-  hipStream_t s = (hipStream_t)stream;
   if (head_size == 128) {
-    pa_pick_g<MRS_PA_T, MRS_PA_CT, 128, 32, DEC_PART>(a, num_seqs, max_parts, s);
+    pa_pick_g<MRS_PA_T, MRS_PA_CT, 128, 32, DEC_PART>(a, num_seqs, max_splits, s);
     hipLaunchKernelGGL((paged_attention_reduce_q8_1_kernel<128, DEC_PART>), dim3(num_heads, num_seqs), dim3(128), 0, s, (uint8_t *)y_q8_1,
-                       y_stride_blocks, exp_sums, max_logits, (const float *)tmp_out, context_lens, max_parts);
+                       y_stride_blocks, exp_sums, max_logits, (const float *)tmp_out, context_lens, max_splits);
   } else {
-    pa_pick_g<MRS_PA_T, MRS_PA_CT, 64, 32, DEC_PART>(a, num_seqs, max_parts, s);
+    pa_pick_g<MRS_PA_T, MRS_PA_CT, 64, 32, DEC_PART>(a, num_seqs, max_splits, s);
     hipLaunchKernelGGL((paged_attention_reduce_q8_1_kernel<64, DEC_PART>), dim3(num_heads, num_seqs), dim3(64), 0, s, (uint8_t *)y_q8_1,
-                       y_stride_blocks, exp_sums, max_logits, (const float *)tmp_out, context_lens, max_parts);
+                       y_stride_blocks, exp_sums, max_logits, (const float *)tmp_out, context_lens, max_splits);
   }
   pa_check("mrs_decode_attention_q8_1");
   return 0;

@@ -177,3 +177,33 @@ def copy_blocks(key_caches: list, value_caches: list, block_mapping: dict) -> No
     fn(kp.data_ptr(), vp.data_ptr(), bm.data_ptr(), len(key_caches), len(pairs), key_caches[0][0].numel(),
        value_caches[0][0].numel(), _stream())
     torch.cuda.current_stream().synchronize()  # keep kp/vp/bm alive until the copy ran
+
+
+def decode_attention_q8_1(q: torch.Tensor, key_cache: torch.Tensor, value_cache: torch.Tensor, block_tables: torch.Tensor,
+                          context_lens: torch.Tensor, max_context_len: int, softmax_scale: float) -> tuple[torch.Tensor, int]:
+    """MI355X-native decode attention of the fused path (mrs_decode_attention_q8_1_f32_bf16): f32 q [seqs, heads, hd]
+    over a bf16 paged cache -> Q8_1 blocks [seqs, stride_blocks * 36] uint8 (o_proj's activation format).
+    Returns (blocks, stride_blocks).  Raises ValueError for shapes the kernel refuses."""
+    if q.dtype != torch.float32 or key_cache.dtype != torch.bfloat16 or q.dim() != 3:
+        raise ValueError("decode_attention_q8_1: f32 query [seqs, heads, hd] over a bf16 cache")
+    num_seqs, num_heads, head_size = q.shape
+    nb, kvh, hs_x, block_size, x = key_cache.shape
+    max_blocks = block_tables.shape[1]
+    eff_max = min(max_blocks * block_size, max_context_len)
+    L = _lib.load("paged_attn")
+    L.mrs_decode_attention_max_splits.argtypes = [_i]
+    splits = L.mrs_decode_attention_max_splits(eff_max)
+    nq = num_heads * head_size
+    stride_blocks = _align_up(nq, 512) // 32
+    y = torch.zeros(num_seqs, stride_blocks * 36, dtype=torch.uint8, device=q.device)
+    tmp = torch.empty(num_seqs * num_heads * splits * head_size, dtype=torch.float32, device=q.device)
+    es = torch.empty(num_seqs * num_heads * splits, dtype=torch.float32, device=q.device)
+    ml = torch.empty_like(es)
+    fn = _lib.sym("paged_attn", "mrs_decode_attention_q8_1_f32_bf16",
+                  [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp] + [_i] * 9 + [_vp], _i)
+    rc = fn(y.data_ptr(), stride_blocks, es.data_ptr(), ml.data_ptr(), tmp.data_ptr(), q.data_ptr(), key_cache.data_ptr(),
+            value_cache.data_ptr(), kvh, softmax_scale, block_tables.data_ptr(), context_lens.data_ptr(), block_size, eff_max,
+            num_seqs, num_heads, head_size, max_blocks, q.stride(0), key_cache.stride(0), key_cache.stride(1), _stream())
+    if rc != 0:
+        raise ValueError("decode_attention_q8_1: unsupported shape (block_size 32, head_size 64/128)")
+    return y, stride_blocks

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--ext", action="store_true", help="also time the fused ext_decode kernels")
     ap.add_argument("--shapes", default="")
+    ap.add_argument("--nbuf", type=int, default=0, help="force the number of rotating weight buffers (2 => Infinity-Cache resident)")
     a = ap.parse_args()
     import torch
     import mistralrs_amd  # noqa: F401
@@ -50,7 +51,9 @@ def main():
         for name, n, k in shapes:
             nbytes = n * dt.row_bytes(k)
             nbuf = max(2, min(96, (1 << 30) // nbytes + 1))
-            ws = [random_qtensor(dt, n, k, dev, 17 + i) for i in range(nbuf)]
+            ws = [random_qtensor(dt, n, k, dev, 17 + i) for i in range(a.nbuf or nbuf)]
+            if a.nbuf:
+                ws = (ws * (nbuf // len(ws) + 1))[:nbuf]  # same launch count, but only a.nbuf distinct buffers (Infinity-Cache resident)
             x = torch.randn(a.b, k, device=dev)
             y, stride = fast_mmvq.quantize_q8_1(x, k, a.b)
             y = y.clone()

@@ -3,13 +3,15 @@ here = os.path.dirname(os.path.abspath(__file__))
 lib = C.CDLL(os.path.join(here, "stream_test.so"))
 lib.stream_launch.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]
 dev = torch.device("cuda:0")
-sink = torch.zeros(4, dtype=torch.int32, device=dev)
+sink = torch.zeros(8 + 4096 * 64, dtype=torch.int32, device=dev)
+import sys
+MODE = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 for mb, wgs in ((1, 256), (9, 1024), (33, 1024)):
     nb = mb * 1024 * 1024
     nbuf = 64 if mb < 20 else 32
     bufs = [torch.randint(0, 255, (nb,), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     def run(st):
-        for b in bufs: lib.stream_launch(2, 4, b.data_ptr(), nb, sink.data_ptr(), wgs, st)
+        for b in bufs: lib.stream_launch(MODE, 4, b.data_ptr(), nb, sink.data_ptr(), wgs, st)
     run(torch.cuda.current_stream().cuda_stream); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); run(torch.cuda.current_stream().cuda_stream); e1.record(); torch.cuda.synchronize()

@@ -164,3 +164,42 @@ def test_paged_attention_error_behaviour(dev):
         paged_attn.paged_attention(torch.zeros(2, 4, 128, dtype=torch.bfloat16, device=dev), kc, vc, bt, cl, 32, 1.0)
     with pytest.raises(ValueError, match="context_lens"):
         paged_attn.paged_attention(torch.zeros(1, 4, 128, dtype=torch.bfloat16, device=dev), kc, vc, bt, torch.ones(3, dtype=torch.int32, device=dev), 32, 1.0)
+
+
+@pytest.mark.parametrize("heads,kvh,hd", [(32, 8, 128), (8, 8, 128), (16, 2, 128), (8, 4, 64)])
+def test_decode_attention_q8_1(oracle, dev, heads, kvh, hd):
+    """MI355X decode attention (wave-per-KV-chunk split + merge -> Q8_1) vs the oracle attention: the dequantized Q8_1
+    output must sit within half a quantisation step (+ the f32-vs-f64 softmax tolerance) of the f64 reference."""
+    import torch
+    from mistralrs_amd import paged_attn
+    rng = np.random.default_rng(heads * 131 + kvh)
+    ctxs, bs = [1, 31, 32, 33, 700, 2500], 32
+    seqs = len(ctxs)
+    max_blocks = (max(ctxs) + bs - 1) // bs + 1
+    nb = seqs * max_blocks + 3
+    kc, vc, kct, vct = _mk_cache(rng, dev, "bf16", nb, kvh, hd, bs)
+    bt = rng.permutation(nb)[: seqs * max_blocks].reshape(seqs, max_blocks).astype(np.int32)
+    for s, c in enumerate(ctxs):
+        if c % bs:
+            vc[bt[s, c // bs], :, :, c % bs:] = np.nan  # stale slots past the context must be ignored
+    vct = torch.from_numpy(vc).to(dev).to(torch.bfloat16)
+    q = (rng.standard_normal((seqs, heads, hd)) * 2.0).astype(np.float32)
+    y, stride = paged_attn.decode_attention_q8_1(torch.from_numpy(q).to(dev), kct, vct, torch.from_numpy(bt).to(dev),
+                                                 torch.from_numpy(np.array(ctxs, dtype=np.int32)).to(dev), max(ctxs), 1.0 / np.sqrt(hd))
+    want = oracle.paged_attention_ref(q, kc, np.nan_to_num(vc, nan=0.0), bt, ctxs, 1.0 / np.sqrt(hd), 1.0, None, None,
+                                      round_p=lambda p: round_through(p, "bf16")).reshape(seqs, heads * hd)
+    blocks = y.cpu().numpy().reshape(seqs, stride, 36)
+    d = blocks[:, :, :2].copy().view(np.float16).astype(np.float32)[:, :, 0]
+    qs = blocks[:, :, 4:].view(np.int8).astype(np.float32)
+    got = (qs * d[:, :, None]).reshape(seqs, -1)[:, : heads * hd]
+    dfull = np.repeat(d, 32, axis=1)[:, : heads * hd]
+    amax = np.abs(want.reshape(seqs, -1, 32)).max(axis=2)
+    np.testing.assert_allclose(d[:, : heads * hd // 32], amax / 127.0, rtol=1e-2, atol=1e-5)  # block scales follow the reference value
+    # probabilities are bf16-rounded before P.V (reference semantics) but un-normalised (online softmax), the oracle rounds the
+    # normalised ones: each differs from the exact p by <= 2^-9 relative, so the outputs by <= 2^-8 * sum_t p_t |v_t|
+    pabs = oracle.paged_attention_ref(q, kc, np.abs(np.nan_to_num(vc, nan=0.0)), bt, ctxs, 1.0 / np.sqrt(hd), 1.0, None, None).reshape(seqs, heads * hd)
+    tol = 0.5 * dfull * 1.01 + 2.0 ** -8 * pabs + 3e-5 * np.abs(np.nan_to_num(vc)).max()
+    err = np.abs(got - want)
+    bad = err > tol
+    assert np.isfinite(got).all() and not bad.any(), (f"{int(bad.sum())} outside tolerance; worst excess {float((err - tol).max()):.3e} at seq "
+                                                        f"{np.argwhere(bad)[:4].tolist()} err {err[bad][:4]} tol {tol[bad][:4]} d {dfull[bad][:4]}")
