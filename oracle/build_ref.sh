@@ -1,6 +1,25 @@
 #!/bin/sh
-# oracle/build_ref.sh <reference root> -- placeholder until the host-compiled reference device
-# functions land (see oracle/ref_shim/).  Outputs only into oracle/_ref/.
+# oracle/build_ref.sh <reference root> -- TEST INFRASTRUCTURE ONLY.
+# Compiles the reference's OWN device functions for the host, from the sources where they lie under <reference root>:
+#   _ref/libref_mmvq.so   <- head of mistralrs-quant/kernels/mmvq_gguf/mmvq_gguf.cu (block structs + vec_dot_*_q8_1,
+#                            up to the "Core mat-vec-q template" marker) + ref_shim/mmvq_driver.inc
+#   _ref/libref_affine.so <- head of kernels/gguf_affine_packed/marlin_gguf_affine_repack.cu (block structs, get_quant,
+#                            get_affine_params: the in-tree GGUF format spec) + ref_shim/affine_driver.inc
+# The reference text is STREAMED into g++ (stdin); nothing from /root/reference is written into this repo.
+# Outputs only into oracle/_ref/ (git-ignored, shipped to the GPU box by gpurun like the other built .so files).
 set -e
-mkdir -p "$(dirname "$0")/_ref"
-exit 0
+REF="$1"
+HERE="$(cd "$(dirname "$0")" && pwd)"
+OUT="$HERE/_ref"
+mkdir -p "$OUT"
+CXX="${CXX:-g++}"
+FLAGS="-x c++ -std=c++17 -O2 -fPIC -shared -fno-fast-math -ffp-contract=off -w"
+MMVQ="$REF/mistralrs-quant/kernels/mmvq_gguf/mmvq_gguf.cu"
+AFF_DIR="$REF/mistralrs-quant/kernels/gguf_affine_packed"
+( cat "$HERE/ref_shim/cuda_shim.h"
+  awk '/Core mat-vec-q template/{exit} {print}' "$MMVQ" | grep -v '#include "cuda_'
+  cat "$HERE/ref_shim/mmvq_driver.inc" ) | $CXX $FLAGS -o "$OUT/libref_mmvq.so" -
+( cat "$HERE/ref_shim/cuda_shim.h"
+  awk '/^template <typename T> struct Scalar;/{exit} {print}' "$AFF_DIR/marlin_gguf_affine_repack.cu" | grep -v '#include <cuda'
+  cat "$HERE/ref_shim/affine_driver.inc" ) | $CXX $FLAGS -I"$AFF_DIR" -o "$OUT/libref_affine.so" -
+echo "oracle/_ref: built libref_mmvq.so libref_affine.so from $REF"

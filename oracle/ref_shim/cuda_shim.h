@@ -1,0 +1,52 @@
+// oracle/ref_shim/cuda_shim.h -- TEST INFRASTRUCTURE ONLY.
+// Minimal host stand-ins for the CUDA device vocabulary used by the reference's *device functions*
+// (block decode + MMVQ vec_dot in mistralrs-quant/kernels/mmvq_gguf/mmvq_gguf.cu, format spec in
+// kernels/gguf_affine_packed/marlin_gguf_affine_repack.cu), so that oracle/build_ref.sh can compile those functions
+// FROM THE REFERENCE TREE (streamed into g++, never copied into this repo) into oracle/_ref/*.so and the
+// tests can pin the oracle against the reference's own arithmetic.  Nothing here is product code.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#define __device__
+#define __host__
+#define __global__
+#define __forceinline__ inline
+#define __align__(n) alignas(n)
+#define __launch_bounds__(...)
+
+struct float2 { float x, y; };
+
+static inline float shim_h2f(uint16_t h) {  // IEEE binary16 -> binary32, exact
+  const uint32_t s = (uint32_t)(h & 0x8000) << 16, e = (h >> 10) & 31, m = h & 1023;
+  uint32_t b;
+  if (e == 0) {
+    if (m == 0) b = s;
+    else { int sh = 0; uint32_t mm = m; while (!(mm & 1024)) { mm <<= 1; ++sh; } b = s | ((uint32_t)(113 - sh) << 23) | ((mm & 1023) << 13); }
+  } else if (e == 31) b = s | 0x7f800000u | (m << 13);
+  else b = s | ((e + 112) << 23) | (m << 13);
+  float f; memcpy(&f, &b, 4); return f;
+}
+struct __half { uint16_t bits; operator float() const { return shim_h2f(bits); } };
+struct __half2 { __half x, y; };
+typedef __half half;
+typedef __half2 half2;
+static inline float __half2float(__half h) { return shim_h2f(h.bits); }
+static inline __half __low2half(__half2 v) { return v.x; }
+static inline __half __high2half(__half2 v) { return v.y; }
+static inline float __low2float(__half2 v) { return shim_h2f(v.x.bits); }
+static inline float __high2float(__half2 v) { return shim_h2f(v.y.bits); }
+static inline float2 __half22float2(__half2 v) { return float2{shim_h2f(v.x.bits), shim_h2f(v.y.bits)}; }
+// per-byte signed saturating subtract (CUDA SIMD intrinsic)
+static inline int __vsubss4(int a, int b) {
+  uint32_t r = 0;
+  for (int i = 0; i < 4; ++i) {
+    int d = (int)(int8_t)((uint32_t)a >> (8 * i)) - (int)(int8_t)((uint32_t)b >> (8 * i));
+    d = d > 127 ? 127 : (d < -128 ? -128 : d);
+    r |= (uint32_t)(uint8_t)(int8_t)d << (8 * i);
+  }
+  return (int)r;
+}
+template <class T> static inline T __shfl_xor_sync(unsigned, T v, int, int = 32) { return v; }  // only referenced by helpers the driver never calls
+static inline float normcdff(float x) { return 0.5f * erfcf(-x * 0.70710678118654752440f); }

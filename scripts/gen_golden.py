@@ -1,0 +1,47 @@
+#!/usr/bin/env python
+"""Generate the frozen golden vectors under tests/golden/ (run in the build container, where /root/reference exists).
+
+Expected values come from the REFERENCE'S OWN device functions compiled for the host (oracle/_ref: vec_dot_*_q8_1 and the
+affine format spec), NOT from the oracle, so the fixtures pin both the oracle (tests -m "not gpu") and the HIP kernels
+(tests -m gpu) to the reference arithmetic even on the GPU box, where /root/reference does not exist.
+
+    python scripts/gen_golden.py        # rewrites tests/golden/*.npz (small: a few KB each)
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import oracle as O  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+TYPES = [2, 3, 6, 7, 8, 10, 11, 12, 13, 14]
+
+
+def main():
+    O.build()
+    mm = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_mmvq.so"))
+    af = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_affine.so"))
+    os.makedirs(GOLD, exist_ok=True)
+    for t in TYPES:
+        rng = np.random.default_rng(1000 + t)
+        n, k, b = 6, 1024, 3
+        w = O.random_blocks(t, n, k, seed=7000 + t, d_scale=0.02)
+        # reference test pattern (fast_mmq.rs:1545-1554) for one row + gaussian rows with very different magnitudes
+        x = np.stack([O.patterned(k, 3, 1.0), rng.standard_normal(k) * 0.05, rng.standard_normal(k) * 40.0]).astype(np.float32)
+        y = O.quantize_q8_1(x)
+        out = np.empty((b, n), dtype=np.float64)
+        assert mm.ref_mmvq(t, w.ctypes.data_as(C.c_void_p), n, k, y.ctypes.data_as(C.c_void_p), y.shape[1] // 36, b, out.ctypes.data_as(C.c_void_p)) == 0
+        deq = np.empty((n, k), dtype=np.float32)
+        assert af.ref_dequantize(t, w.ctypes.data_as(C.c_void_p), n, k, deq.ctypes.data_as(C.c_void_p)) == 0
+        _, mag = O.matmul_q8_1_mag(t, w, n, k, y)
+        np.savez_compressed(os.path.join(GOLD, f"mmvq_{O.TYPE_NAMES[t]}.npz"), type=np.int32(t), n=np.int32(n), k=np.int32(k), w=w, x=x,
+                            y_q8_1=y, out_ref=out, mag=mag, dequant_ref=deq)
+        print(f"golden: mmvq_{O.TYPE_NAMES[t]}.npz  out[0,:3]={out[0,:3]}")
+
+
+if __name__ == "__main__":
+    main()

@@ -24,8 +24,12 @@ def main():
             rows.append(r)
     else:
         for r in csv.DictReader(open(a.path)):
-            rows.append((r["Kernel_Name"], int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), int(r.get("Grid_Size", 0) or 0),
-                         int(r.get("Workgroup_Size", 0) or 0), int(r.get("LDS_Block_Size", 0) or 0), int(r.get("VGPR_Count", 0) or 0)))
+            def dim(prefix):
+                if prefix in r:
+                    return int(r[prefix] or 0)
+                return int(r.get(prefix + "_X", 0) or 0) * max(1, int(r.get(prefix + "_Y", 1) or 1)) * max(1, int(r.get(prefix + "_Z", 1) or 1))
+            rows.append((r["Kernel_Name"], int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), dim("Grid_Size"), dim("Workgroup_Size"),
+                         int(r.get("LDS_Block_Size", 0) or 0), int(r.get("VGPR_Count", 0) or 0)))
     agg = collections.OrderedDict()
     for name, dur, grid, wg, lds, vgpr in rows:
         if a.match and a.match not in name:
