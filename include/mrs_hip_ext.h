@@ -45,6 +45,14 @@ int mrs_sample_greedy_advance(const float *logits, int vocab, int b, int32_t *ne
                               int64_t *slot_mapping, const uint32_t *block_tables, int max_blocks, int block_size,
                               void *scratch, void *stream);
 
+/* ---------------------------------------------------------------- prefill GEMM (ext_gemm.hip)
+ * out[m*ldo + n] (+)= sum_k bf16(x[m*ldx + k]) * bf16(dequant(W)[n][k]),  f32 accumulate on the bf16 matrix cores.
+ * W: raw GGUF blocks [N][K/blk] (q4_k q5_k q6_k q8_0); x f32 [M][ldx]; role of fast_mmq::{plain,fused_qkv,fused_glu,fused_ffn}
+ * (mistralrs-quant/src/gguf/fast_mmq.rs:528-635,762-821) at the raw-activation boundary (hard part 7).
+ * Returns 0, -1 for an unsupported type / shape (K % 256 for K-quants, K % 64 for Q8_0, ldx % 4). */
+int mrs_gemm_q_f32(const void *w, int ggml_type, int N, int K, const float *x, int ldx, float *out, int ldo, int M, int accumulate,
+                   void *stream);
+
 /* ---------------------------------------------------------------- host-side model runner (host/runtime.cpp)
  * C++ mirror of mistralrs-core/src/models/llama.rs (Llama / CausalSelfAttention / Mlp / Block) on top of
  * QuantMethod objects (mistralrs-quant/src/lib.rs:1515-1688, gguf/mod.rs GgufMatMul), exposed through handles. */
@@ -89,6 +97,27 @@ int mrs_llama_set_buffers(void *model, const mrs_llama_buffers *bufs);
 int mrs_llama_decode_step(void *model, int b, void *stream);
 /* same graph without sampling: leaves logits [b, vocab] (parity tests read them) */
 int mrs_llama_forward_logits(void *model, int b, void *stream);
+/* Prefill of T prompt tokens of ONE sequence (role of the prompt branch of Llama::forward_embeds + PagedAttention::forward,
+ * models/llama.rs:487-518, paged_attention/layers/paged_attention.rs:1413-1475): per layer RMSNorm -> q/k/v GEMMs (bf16 MFMA,
+ * mrs_gemm_q_f32) -> RoPE -> reshape_and_cache -> causal attention over the freshly written pages -> o_proj GEMM (+residual) ->
+ * RMSNorm -> gate/up GEMMs -> SiLU*up -> down GEMM (+residual); lm_head only for the last token (ctx.logits, llama.rs:514-517).
+ * All pointers are device pointers owned by the caller; positions[t] = start + t; slot_mapping[t] as inputs_processor.rs:900-922;
+ * block_tables: T identical rows [T][max_blocks] (every prompt token attends through the sequence's table with its own
+ * context_lens[t] = positions[t] + 1). */
+typedef struct {
+  const int32_t *token_ids;     /* [T] */
+  const int32_t *positions;     /* [T] */
+  const int64_t *slot_mapping;  /* [T] */
+  const uint32_t *block_tables; /* [T, max_blocks_per_seq] */
+  const uint32_t *context_lens; /* [T] */
+  float *logits;                /* [vocab] logits of the last prompt token */
+  void *workspace;              /* >= mrs_llama_prefill_workspace_bytes(cfg, T) */
+  size_t workspace_bytes;
+} mrs_llama_prefill_args;
+size_t mrs_llama_prefill_workspace_bytes(const mrs_llama_config *cfg, int T);
+int mrs_llama_prefill(void *model, const mrs_llama_prefill_args *args, int T, void *stream);
+/* floating-point operations of one prefill of T tokens starting at an empty context (MFMA roofline numerator) */
+double mrs_llama_prefill_flops(void *model, int T);
 /* bytes of weights + KV streamed from HBM by one decode step at the given context (roofline numerator) */
 double mrs_llama_decode_bytes(void *model, int b, int context_len);
 const char *mrs_last_error(void);

@@ -335,6 +335,84 @@ class Llama {
     return 0;
   }
 
+  // ---- prefill: T prompt tokens of one sequence through the bf16-MFMA GEMMs (role of fast_mmq::* + the prompt branch
+  //      of PagedAttention::forward).  Buffers are carved from the caller's prefill workspace.
+  static size_t prefill_workspace_bytes(const mrs_llama_config &c, int T) {
+    const size_t t = (size_t)T, d = c.hidden_size, nq = (size_t)c.num_heads * c.head_dim, nkv = (size_t)c.num_kv_heads * c.head_dim;
+    const size_t ff = c.intermediate_size;
+    size_t b = 0;
+    b += align(t * d * 4) * 2;        // h, xn
+    b += align(t * nq * 4) * 2;       // q, attn
+    b += align(t * nkv * 4) * 2;      // k, v
+    b += align(t * ff * 4) * 3;       // gate, up, act
+    b += align((pad_to((int)d, MATRIX_ROW_PADDING) / 32) * 36);  // Q8_1 scratch of the last-token lm_head GEMV
+    return b + 4096;
+  }
+  int prefill(const mrs_llama_prefill_args &pa, int T, hipStream_t s) const {
+    if (T <= 0) return fail("prefill: T must be positive");
+    if (!wte || !lm_head || !ln_f) return fail("model is missing token_embd / output / output_norm");
+    if (pa.workspace_bytes < prefill_workspace_bytes(cfg, T)) return fail("prefill workspace too small");
+    const int d = cfg.hidden_size, hd = cfg.head_dim, nq = cfg.num_heads * hd, nkv = cfg.num_kv_heads * hd, ff = cfg.intermediate_size;
+    const size_t t = (size_t)T;
+    char *p = (char *)(((uintptr_t)pa.workspace + 255) & ~(uintptr_t)255);
+    auto take = [&](size_t n) { char *r = p; p += align(n); return r; };
+    float *h = (float *)take(t * d * 4), *xn = (float *)take(t * d * 4);
+    float *q = (float *)take(t * nq * 4), *attn = (float *)take(t * nq * 4);
+    float *k = (float *)take(t * nkv * 4), *v = (float *)take(t * nkv * 4);
+    float *g = (float *)take(t * ff * 4), *u = (float *)take(t * ff * 4), *act = (float *)take(t * ff * 4);
+    const int64_t st = (int64_t)(intptr_t)s;
+    auto gemm = [&](const GgufMatMul &m, const float *x, int K, float *out, int N, int acc) -> int {
+      const QTensor *w = m.get_qtensor();
+      if (mrs_gemm_q_f32(w->data, w->dtype, N, K, x, K, out, N, T, acc, s)) return fail("prefill: no GEMM for ggml dtype %d (K=%d)", w->dtype, K);
+      return 0;
+    };
+    if (wte->embedding_forward_raw(pa.token_ids, T, h, s)) return -1;
+    const int bs = cfg.block_size, kvh = cfg.num_kv_heads;
+    const int eff_max = std::min(cfg.max_blocks_per_seq * bs, cfg.max_context_len);
+    const int parts = (eff_max + 511) / 512;
+    const bool use_v1 = (parts == 1 || (long)T * cfg.num_heads > 512);  // paged_attention.rs:302-307
+    if (!use_v1) return fail("prefill: context too long for the v1 attention path of this round");
+    for (size_t li = 0; li < blocks.size(); ++li) {
+      const Block &bl = blocks[li];
+      if (!bl.q_proj || !bl.key_cache) return fail("layer %zu is incomplete", li);
+      mrs_rms_norm_f32(h, bl.input_layernorm, xn, T, d, cfg.rms_eps, st);
+      if (gemm(*bl.q_proj, xn, d, q, nq, 0) || gemm(*bl.k_proj, xn, d, k, nkv, 0) || gemm(*bl.v_proj, xn, d, v, nkv, 0)) return -1;
+      rotary_embedding_positions(q, k, (void *)bufs.cos_table, (void *)bufs.sin_table, (void *)pa.positions, cfg.rope_interleaved ? 0 : 1, hd, T,
+                                 cfg.rot_dim / 2, cfg.max_context_len, cfg.num_heads, cfg.num_kv_heads, nq, nkv, 2, st);
+      reshape_and_cache(k, v, bl.key_cache, bl.value_cache, (int64_t *)pa.slot_mapping, T, cfg.num_kv_heads, hd, bs, 8, nkv, nkv, s, 2, 1, nullptr, nullptr);
+      // causal attention: prompt token t = "sequence" t reading the pages just written, context_lens[t] = pos + 1
+      mrs_paged_attention_f32_bf16(0, attn, nullptr, nullptr, nullptr, q, bl.key_cache, bl.value_cache, nullptr, kvh, 1.0f / sqrtf((float)hd), 1.0f,
+                                   pa.block_tables, pa.context_lens, bs, eff_max, T, cfg.num_heads, hd, cfg.max_blocks_per_seq, nq, kvh * hd * bs,
+                                   hd * bs, s, nullptr);
+      if (gemm(*bl.o_proj, attn, nq, h, d, 1)) return -1;
+      mrs_rms_norm_f32(h, bl.post_attention_layernorm, xn, T, d, cfg.rms_eps, st);
+      if (gemm(*bl.gate_proj, xn, d, g, ff, 0) || gemm(*bl.up_proj, xn, d, u, ff, 0)) return -1;
+      fused_glu_f32(g, u, act, (uint32_t)T, (uint32_t)ff, (uint32_t)ff, (uint32_t)ff, 0, s);
+      if (gemm(*bl.down_proj, act, ff, h, d, 1)) return -1;
+    }
+    // ctx.logits: only the last prompt token reaches lm_head (llama.rs:514-517)
+    const QTensor *lm = lm_head->get_qtensor();
+    if (mrs_decode_gemv_supported(lm->dtype)) {
+      if (mrs_decode_norm_proj(lm->data, lm->dtype, cfg.vocab_size, d, h + (t - 1) * d, ln_f, cfg.rms_eps, pa.logits, cfg.vocab_size, 1, s))
+        return fail("prefill: lm_head refused");
+    } else {
+      mrs_rms_norm_f32(h + (t - 1) * d, ln_f, xn, 1, d, cfg.rms_eps, st);
+      const Scratch sc{take((size_t)(pad_to(d, MATRIX_ROW_PADDING) / 32) * 36), (size_t)(pad_to(d, MATRIX_ROW_PADDING) / 32) * 36};
+      if (lm_head->forward_raw(xn, 1, pa.logits, sc, s)) return -1;
+    }
+    return 0;
+  }
+  double prefill_flops(int T) const {
+    double w = 0;
+    for (const Block &bl : blocks)
+      for (const auto *m : {&bl.q_proj, &bl.k_proj, &bl.v_proj, &bl.o_proj, &bl.gate_proj, &bl.up_proj, &bl.down_proj})
+        if (*m) w += (double)(*m)->get_qtensor()->rows * (double)(*m)->get_qtensor()->cols;
+    double f = 2.0 * T * w;
+    if (lm_head) f += 2.0 * (double)lm_head->get_qtensor()->rows * (double)lm_head->get_qtensor()->cols;
+    f += 4.0 * cfg.num_layers * cfg.num_heads * cfg.head_dim * (double)T * (double)T / 2.0;  // QK^T + PV, causal
+    return f;
+  }
+
   int forward_logits(int b, hipStream_t s) const {
     if (check_ready(b)) return -1;
     return fused_ok() ? forward_fused(b, s) : forward_unfused(b, s);
@@ -424,3 +502,10 @@ extern "C" int mrs_llama_set_buffers(void *m, const mrs_llama_buffers *b) { retu
 extern "C" int mrs_llama_decode_step(void *m, int b, void *stream) { return ((Llama *)m)->decode_step(b, (hipStream_t)stream); }
 extern "C" int mrs_llama_forward_logits(void *m, int b, void *stream) { return ((Llama *)m)->forward_logits(b, (hipStream_t)stream); }
 extern "C" double mrs_llama_decode_bytes(void *m, int b, int ctx) { return ((Llama *)m)->decode_bytes(b, ctx); }
+extern "C" size_t mrs_llama_prefill_workspace_bytes(const mrs_llama_config *cfg, int T) { return Llama::prefill_workspace_bytes(*cfg, T); }
+extern "C" int mrs_llama_prefill(void *m, const mrs_llama_prefill_args *a, int T, void *stream) {
+  Llama &l = *(Llama *)m;
+  if (!l.have_bufs) return mrs_host::fail("mrs_llama_set_buffers was not called");
+  return l.prefill(*a, T, (hipStream_t)stream);
+}
+extern "C" double mrs_llama_prefill_flops(void *m, int T) { return ((Llama *)m)->prefill_flops(T); }

@@ -94,6 +94,11 @@ class _Cfg(C.Structure):
                [(n, C.c_int32) for n in ("block_size", "max_blocks_per_seq", "max_batch", "max_context_len", "use_fused", "world_size", "rank")]
 
 
+class _PrefillArgs(C.Structure):
+    _fields_ = [("token_ids", C.c_void_p), ("positions", C.c_void_p), ("slot_mapping", C.c_void_p), ("block_tables", C.c_void_p),
+                ("context_lens", C.c_void_p), ("logits", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
 class _Bufs(C.Structure):
     _fields_ = [("input_ids", C.c_void_p), ("positions", C.c_void_p), ("context_lens", C.c_void_p), ("slot_mapping", C.c_void_p),
                 ("block_tables", C.c_void_p), ("tokens_out", C.c_void_p), ("tokens_out_stride", C.c_int32), ("step_counter", C.c_void_p),
@@ -121,6 +126,11 @@ class Llama:
         L.mrs_llama_forward_logits.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.mrs_llama_decode_bytes.restype = C.c_double
         L.mrs_llama_decode_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.mrs_llama_prefill_workspace_bytes.restype = C.c_size_t
+        L.mrs_llama_prefill_workspace_bytes.argtypes = [C.POINTER(_Cfg), C.c_int]
+        L.mrs_llama_prefill.argtypes = [C.c_void_p, C.POINTER(_PrefillArgs), C.c_int, C.c_void_p]
+        L.mrs_llama_prefill_flops.restype = C.c_double
+        L.mrs_llama_prefill_flops.argtypes = [C.c_void_p, C.c_int]
         L.mrs_last_error.restype = C.c_char_p
         c = _Cfg(cfg.hidden_size, cfg.intermediate_size, cfg.num_layers, cfg.num_heads, cfg.num_kv_heads, cfg.head_dim,
                  cfg.vocab_size, cfg.head_dim, int(cfg.rope_interleaved), cfg.rms_eps, cfg.block_size, cfg.max_blocks_per_seq,
@@ -232,6 +242,33 @@ class Llama:
 
     def replay(self) -> None:
         self._graph.replay()
+
+    def prefill(self, tokens, start_pos: int = 0, seq: int = 0) -> torch.Tensor:
+        """Prompt processing of one sequence on the bf16 matrix cores (mrs_llama_prefill): returns the last token's logits
+        [vocab] and leaves K/V of every prompt token in the sequence's pages.  Mirrors the prompt branch of the reference
+        (PagedAttention::forward try_regular_prompt + reshape_and_cache, paged_attention.rs:1413-1475)."""
+        cfg, dev = self.cfg, self.device
+        T = len(tokens)
+        if start_pos + T > cfg.max_context_len:
+            raise ValueError("prompt does not fit max_context_len")
+        pos = torch.arange(start_pos, start_pos + T, dtype=torch.int32, device=dev)
+        bt_row = self.block_tables[seq].to(torch.int64)
+        slots = (bt_row[(pos // cfg.block_size).long()] * cfg.block_size + (pos % cfg.block_size).long()).to(torch.int64)
+        bts = self.block_tables[seq:seq + 1].expand(T, -1).contiguous()
+        ctx = (pos + 1).to(torch.int32)
+        ids = torch.tensor(np.asarray(tokens, dtype=np.int32), device=dev)
+        need = self._L.mrs_llama_prefill_workspace_bytes(C.byref(self._c), T)
+        if getattr(self, "_prefill_ws", None) is None or self._prefill_ws.numel() < need:
+            self._prefill_ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        out = torch.empty(cfg.vocab_size, dtype=torch.float32, device=dev)
+        a = _PrefillArgs(ids.data_ptr(), pos.data_ptr(), slots.data_ptr(), bts.data_ptr(), ctx.data_ptr(), out.data_ptr(),
+                         self._prefill_ws.data_ptr(), self._prefill_ws.numel())
+        self._chk(self._L.mrs_llama_prefill(self._h, C.byref(a), T, self._stream()))
+        self._prefill_keep = (ids, pos, slots, bts, ctx)  # keep alive until the stream has consumed them
+        return out
+
+    def prefill_flops(self, T: int) -> float:
+        return float(self._L.mrs_llama_prefill_flops(self._h, T))
 
     # chunked prefill through the batch<=8 decode kernels: the chunk's tokens act as `b` sequences that share one
     # block table, each attending to [0, its position] (K/V of the whole chunk are in the cache before attention).

@@ -1,0 +1,39 @@
+#!/usr/bin/env python
+"""Prefill GEMM microbenchmark: TFLOP/s of mrs_gemm_q_f32 on the Llama-3-8B shapes at T tokens."""
+import argparse, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--t", type=int, default=512)
+    ap.add_argument("--types", default="q4_k,q6_k")
+    a = ap.parse_args()
+    import torch
+    import mistralrs_amd  # noqa: F401
+    from mistralrs_amd.gguf import GgmlDType, fast_gemm
+    from mistralrs_amd.llama import random_qtensor
+    dev = torch.device("cuda:0")
+    tags = {d.tag: d for d in GgmlDType}
+    for tag in a.types.split(","):
+        for name, n, k in (("q", 4096, 4096), ("qkv", 6144, 4096), ("gate_up", 28672, 4096), ("down", 4096, 14336)):
+            w = random_qtensor(tags[tag], n, k, dev, 5)
+            x = torch.randn(a.t, k, device=dev)
+            out = torch.empty(a.t, n, device=dev)
+            fast_gemm.plain(w, x, out=out)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 10
+            e0.record()
+            for _ in range(reps):
+                fast_gemm.plain(w, x, out=out)
+            e1.record(); torch.cuda.synchronize()
+            t = e0.elapsed_time(e1) / 1e3 / reps
+            fl = 2.0 * a.t * n * k
+            print(json.dumps({"type": tag, "shape": name, "T": a.t, "N": n, "K": k, "us": round(t * 1e6, 1), "TFLOPs": round(fl / t / 1e12, 1),
+                              "frac_2.5PF": round(fl / t / 2.5e15, 3)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()

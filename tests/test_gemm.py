@@ -1,0 +1,51 @@
+"""GPU parity: the prefill GEMM (fused block-dequant -> bf16 MFMA, f32 accumulate) vs oracle A.
+
+Expected value = sum_k bf16(x) * bf16(dequant(W)) evaluated in f64 (the kernel's defined arithmetic: both operands are
+rounded to bf16 once, products and sums are f32 on the matrix cores).  Tolerance: f32 accumulation of K terms in the MFMA's
+order, 2^-19 * sum|terms| (>= 8 eps sqrt(K) for K <= 16384); the distance to the exact-dequant f32 matmul is checked against
+the bf16 input-rounding bound 2^-8 * sum|terms| (what "MFMA on the bf16 prefill GEMM" costs in accuracy).
+"""
+import numpy as np
+import pytest
+
+from tests.util import round_through
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("tname", ["Q4_K", "Q5_K", "Q6_K", "Q8_0"])
+@pytest.mark.parametrize("m,n,k", [(512, 256, 1024), (130, 384, 512), (1, 128, 256), (37, 200, 2048)])
+def test_prefill_gemm_vs_oracle(oracle, dev, tname, m, n, k):
+    import torch
+    from mistralrs_amd.gguf import GgmlDType, QTensor, fast_gemm
+    t = getattr(oracle, tname)
+    rng = np.random.default_rng(m * 7 + n + k)
+    w = oracle.random_blocks(t, n, k, seed=n + k, d_scale=0.02)
+    x = (rng.standard_normal((m, k)) * rng.uniform(0.2, 3.0, (m, 1))).astype(np.float32)
+    wt = QTensor.from_numpy(GgmlDType.from_id(t), (n, k), w, dev)
+    got = fast_gemm.plain(wt, torch.from_numpy(x).to(dev)).cpu().numpy().astype(np.float64)
+    wd = oracle.dequantize(t, w, k)
+    xb, wb = round_through(x, "bf16").astype(np.float64), round_through(wd, "bf16").astype(np.float64)
+    want = xb @ wb.T
+    mag = np.abs(xb) @ np.abs(wb).T
+    err = np.abs(got - want)
+    assert (err <= 2.0 ** -19 * mag + 1e-30).all(), float((err / (2.0 ** -19 * mag + 1e-30)).max())
+    exact = x.astype(np.float64) @ wd.astype(np.float64).T
+    assert (np.abs(got - exact) <= 2.0 ** -8 * mag + 1e-30).all()
+
+
+def test_prefill_gemm_accumulate_and_errors(oracle, dev):
+    import torch
+    from mistralrs_amd.gguf import GgmlDType, QTensor, fast_gemm
+    t = oracle.Q4_K
+    w = oracle.random_blocks(t, 128, 512, seed=3, d_scale=0.02)
+    wt = QTensor.from_numpy(GgmlDType.from_id(t), (128, 512), w, dev)
+    x = torch.randn(40, 512, device=dev)
+    base = torch.randn(40, 128, device=dev)
+    o1 = fast_gemm.plain(wt, x)
+    o2 = fast_gemm.plain(wt, x, out=base.clone(), accumulate=True)
+    assert torch.equal(o2, base + o1)
+    with pytest.raises(ValueError, match="shape mismatch"):
+        fast_gemm.plain(wt, torch.randn(4, 256, device=dev))
+    with pytest.raises(ValueError, match="unsupported quant dtype"):
+        fast_gemm.plain(QTensor.from_numpy(GgmlDType.Q4_0, (32, 64), oracle.random_blocks(oracle.Q4_0, 32, 64), dev), torch.randn(4, 64, device=dev))

@@ -165,3 +165,39 @@ def test_runner_error_behaviour(oracle, dev):
         m.set_tensor("blk.0.attn_k.weight", QTensor.from_numpy(GgmlDType.from_id(t), (p.shape[0], 256), p, dev))
     with pytest.raises(ValueError, match="out of range"):
         m.forward_logits(9)
+
+
+def test_mfma_prefill_matches_decode_path_and_oracle(oracle, dev):
+    """Prompt processing on the bf16 matrix cores (mrs_llama_prefill) vs the token-by-token decode path and the oracle.
+    The prefill GEMMs round activations and dequantized weights to bf16 (f32 accumulate) where the decode path quantizes
+    activations to int8 (Q8_1): two different, both documented, approximations of the exact product (north_star: MFMA only on
+    the bf16 prefill GEMM).  Bars: last-token logits within 3e-2 * max|logit| of the decode path and of the oracle's exact-dequant
+    f32 reference (mode "exact"); K/V pages of layer 0 within one bf16 ulp scale of the decode path's; greedy token identical
+    outside near-ties; decoding on from the prefilled cache works."""
+    import torch
+    from oracle import llama_ref
+    cfg, w, m, cos, sin = _mk(oracle, dev, True, Q4KM(oracle), hd=128, heads=4, kvh=2, hidden=512, ff=1024, vocab=512)
+    _, _, md, _, _ = _mk(oracle, dev, True, Q4KM(oracle), hd=128, heads=4, kvh=2, hidden=512, ff=1024, vocab=512)
+    toks = _tokens(70, 3)
+    last = m.prefill(toks, 0).cpu().numpy()
+    for pos, t in enumerate(toks):
+        md.set_state([t], [pos])
+        ld = md.forward_logits(1)[0].clone()
+    ld = ld.cpu().numpy()
+    ref = llama_ref.LlamaRef(cfg, w, cos, sin, mode="exact", kv_dtype="bf16")
+    for pos, t in enumerate(toks):
+        want = ref.step(t, pos)
+    scale = np.abs(want).max()
+    assert np.abs(last - ld).max() <= 3e-2 * scale, np.abs(last - ld).max() / scale
+    assert np.abs(last - want).max() <= 3e-2 * scale, np.abs(last - want).max() / scale
+    top2 = np.sort(want)[-2:]
+    if top2[1] - top2[0] > 6e-2 * scale:
+        assert int(last.argmax()) == int(want.argmax())
+    k0, kd = m.key_caches[0].float(), md.key_caches[0].float()
+    assert float((k0 - kd).abs().max()) <= 2.0 ** -6 * float(kd.abs().max())
+    # continue decoding from the prefilled pages
+    nxt = int(last.argmax())
+    m.set_state([nxt], [len(toks)])
+    l2 = m.forward_logits(1)[0].cpu().numpy()
+    w2 = ref.step(nxt, len(toks))
+    assert np.abs(l2 - w2).max() <= 3e-2 * np.abs(w2).max()
