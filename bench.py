@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--prompt-len", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--small", action="store_true", help="tiny config (smoke / CI), not the benchmark")
+    ap.add_argument("--tp", action="store_true", help="N > 1: ONE model sharded tensor-parallel over the N GPUs (RCCL all-reduce) instead of N replicas")
     a = ap.parse_args()
 
     import torch
@@ -146,7 +147,16 @@ def main():
     else:
         cfg = LlamaConfig.llama3_8b(max_batch=8, max_context_len=max_ctx, max_position_embeddings=max(8192, max_ctx))
         name = "Llama-3-8B"
+    tp = a.tp and world > 1
+    if tp:  # column / row parallel shards (mistralrs-quant/src/distributed/layers.rs): local heads, kv heads, ffn
+        from mistralrs_amd import distributed as D
+        cfg.head_dim = cfg.head_dim  # keep the global head_dim
+        cfg.num_heads, cfg.num_kv_heads, cfg.intermediate_size = D.local_dims(cfg.num_heads, cfg.num_kv_heads, cfg.intermediate_size, world)
+        cfg.tp_world_size, cfg.tp_rank = world, rank
     model = build_model(cfg, dev, seed=rank, max_new_tokens=a.warmup + a.steps + 8)
+    if tp:
+        from mistralrs_amd import distributed as D
+        model.set_comm(D.RcclComm(rank, world, dev))
     torch.cuda.synchronize()
 
     def sync():
@@ -218,13 +228,13 @@ def main():
 
     avg_ctx = a.prompt_len + a.warmup + a.steps / 2
     step_bytes = model.decode_bytes(1, int(avg_ctx))
-    tok_s = world * a.steps / t_all
+    tok_s = (1 if tp else world) * a.steps / t_all  # TP: the N GPUs decode ONE sequence
     out = {
         "metric": "decode_tokens_per_sec", "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": a.steps,
-        "warmup": a.warmup, "ms_per_step": round(1e3 * t_all / a.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "warmup": a.warmup, "ms_per_step": round(1e3 * t_all / a.steps, 4), "higher_is_better": True, "scaling": "strong" if tp else "weak",
         "vs_baseline": None, "dtype": "q4_k/q6_k weights x q8_1 activations (int8 dot, f32 accumulate)", "data": "synthetic",
         "config": {"workload": f"{name} GGUF Q4_K_M, TP=1, {a.prompt_len} prefill / {a.steps} decode, batch 1, paged KV bf16 (block 32)",
-                   "parallelism": "tp1" if world == 1 else f"replicas x{world}"},
+                   "parallelism": "tp1" if world == 1 else (f"tp{world}" if tp else f"replicas x{world}")},
         "prefill_tokens_per_sec": round(a.prompt_len / ttft, 1), "ttft_ms": round(1e3 * ttft, 2),
         "prefill_roofline": {"bound": "mfma", "achieved": round(prefill_flops / ttft / 1e12, 1), "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s",
                              "frac": round(prefill_flops / ttft / MFMA_PEAK, 4), "flops": prefill_flops,

@@ -31,6 +31,11 @@ int mrs_decode_gate_up(const void *wg, const void *wu, int type, int n, int K, c
                        int activation, void *y_out, int y_out_stride, int b, void *stream);
 int mrs_decode_proj(const void *w, int type, int n, int K, const void *y_q8_1, int stride_col_y, float *out, int out_stride,
                     int accumulate, int b, void *stream);
+/* tensor parallelism: out = out * resid_scale + W.y with resid_scale = 1 / world_size, followed by ONE sum all-reduce of `out`
+ * (role of RowParallelLayer::forward + SumAllReduce, distributed/layers.rs:965-975, with the residual add kept fused) */
+int mrs_decode_proj_scaled(const void *w, int type, int n, int K, const void *y_q8_1, int stride_col_y, float *out, int out_stride,
+                           float resid_scale, int b, void *stream);
+int mrs_vec_add_f32(float *a, const float *b, size_t n, void *stream); /* a += b */
 int mrs_decode_norm_proj(const void *w, int type, int n, int K, const float *h, const float *norm_w, float eps, float *out,
                          int out_stride, int b, void *stream);
 /* quantized (or f32/f16/bf16) embedding rows -> f32; role of QuantMethod::embedding_forward (lib.rs:1561, gguf/mod.rs:436) */
@@ -120,6 +125,13 @@ int mrs_llama_prefill(void *model, const mrs_llama_prefill_args *args, int T, vo
 double mrs_llama_prefill_flops(void *model, int T);
 /* bytes of weights + KV streamed from HBM by one decode step at the given context (roofline numerator) */
 double mrs_llama_decode_bytes(void *model, int b, int context_len);
+/* ---------------------------------------------------------------- RCCL over xGMI (ext_comm.hip), one process per GPU
+ * replaces Comm::from_device / all_reduce(Sum) of mistralrs-quant/src/distributed/mod.rs:244-303,511-809 */
+int mrs_comm_unique_id(void *out128);                            /* rank 0: ncclGetUniqueId -> 128 bytes */
+void *mrs_comm_init(const void *id128, int rank, int world);     /* ncclCommInitRank on the current device; NULL on error */
+int mrs_comm_all_reduce_sum_f32(void *comm, float *buf, size_t count, void *stream); /* in place, asynchronous on stream */
+void mrs_comm_destroy(void *comm);
+int mrs_llama_set_comm(void *model, void *comm);                 /* required when cfg.world_size > 1 */
 const char *mrs_last_error(void);
 
 #ifdef __cplusplus

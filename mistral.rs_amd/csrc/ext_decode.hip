@@ -48,6 +48,7 @@ struct DecodeGemvArgs {
   const float *cos_t, *sin_t;   // [max_pos][rot_pairs]
   int head_dim, rot_pairs, num_kv_heads, block_size, cache_x;
   int rows_per_wg;
+  float resid_scale;      // RESID_ADD: out = out * resid_scale + W.y  (1 = plain residual add; 1/world under tensor parallelism)
 };
 
 // fixed-order block reduction shared by the fused prologue and the standalone norm+quantize kernel
@@ -247,7 +248,7 @@ __global__ void __launch_bounds__(NT) decode_gemv_kernel(const DecodeGemvArgs a)
 #pragma unroll
         for (int c = 0; c < NCOLS; ++c) {
           float *o = a.out + (size_t)c * a.out_stride + r;
-          if constexpr (EPI == EPI_RESID_ADD) *o = *o + acc[0][c]; else *o = acc[0][c];
+          if constexpr (EPI == EPI_RESID_ADD) *o = *o * a.resid_scale + acc[0][c]; else *o = acc[0][c];
         }
       }
     };
@@ -425,9 +426,35 @@ extern "C" int mrs_decode_proj(const void *w, int type, int n, int K, const void
   if (!hot_type(type)) return -1;
   DecodeGemvArgs a{};
   a.w[0] = (const uint8_t *)w; a.wtype[0] = type; a.nrows[0] = n; a.K = K; a.y_q8_1 = (const uint8_t *)y_q8_1;
-  a.stride_col_y = stride_col_y; a.out = out; a.out_stride = out_stride;
+  a.stride_col_y = stride_col_y; a.out = out; a.out_stride = out_stride; a.resid_scale = 1.0f;
   return accumulate ? DecodeLaunch<PRO_Q8_1, EPI_RESID_ADD>::run(a, b, (hipStream_t)stream)
                     : DecodeLaunch<PRO_Q8_1, EPI_STORE>::run(a, b, (hipStream_t)stream);
+}
+
+// same with out = out * resid_scale + W.y (tensor parallelism: resid_scale = 1 / world_size before the sum all-reduce of out)
+extern "C" int mrs_decode_proj_scaled(const void *w, int type, int n, int K, const void *y_q8_1, int stride_col_y, float *out,
+                                      int out_stride, float resid_scale, int b, void *stream) {
+  if (!hot_type(type)) return -1;
+  DecodeGemvArgs a{};
+  a.w[0] = (const uint8_t *)w; a.wtype[0] = type; a.nrows[0] = n; a.K = K; a.y_q8_1 = (const uint8_t *)y_q8_1;
+  a.stride_col_y = stride_col_y; a.out = out; a.out_stride = out_stride; a.resid_scale = resid_scale;
+  return DecodeLaunch<PRO_Q8_1, EPI_RESID_ADD>::run(a, b, (hipStream_t)stream);
+}
+
+namespace mrs {
+__global__ void __launch_bounds__(256) vec_add_kernel(float *__restrict__ a, const float *__restrict__ b, size_t n) {
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) {
+    if (i + 4 <= n) { float4 x = *(float4 *)(a + i); const float4 y = *(const float4 *)(b + i); x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w; *(float4 *)(a + i) = x; }
+    else for (size_t j = i; j < n; ++j) a[j] += b[j];
+  }
+}
+}  // namespace mrs
+// a += b (residual add after a row-parallel all-reduce in the prefill path)
+extern "C" int mrs_vec_add_f32(float *a, const float *b, size_t n, void *stream) {
+  if (!n) return 0;
+  size_t g = (n / 4 + 255) / 256; if (g > 2048) g = 2048; if (g < 1) g = 1;
+  hipLaunchKernelGGL(mrs::vec_add_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, a, b, n);
+  return 0;
 }
 
 // final norm + lm_head: h --RMSNorm--> Q8_1 (LDS) --> logits f32 [b][n]

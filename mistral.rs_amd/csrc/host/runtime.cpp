@@ -34,7 +34,7 @@
 namespace mrs_host {
 
 static thread_local std::string g_last_error;
-static int fail(const char *fmt, ...) {
+int fail(const char *fmt, ...) {  // external linkage: shared with ext_comm.hip
   char buf[512];
   va_list ap;
   va_start(ap, fmt);
@@ -181,6 +181,14 @@ class Llama {
   mrs_llama_buffers bufs{};
   Workspace ws{};
   bool have_bufs = false;
+  void *comm = nullptr;  // RCCL communicator (ext_comm.hip) when cfg.world_size > 1
+
+  // SumAllReduce of a row-parallel output (distributed/layers.rs:965-975), in place on the runner's stream
+  int all_reduce(float *buf, size_t count, hipStream_t s) const {
+    if (cfg.world_size <= 1) return 0;
+    if (!comm) return fail("tensor parallel world_size %d but no communicator was set (mrs_llama_set_comm)", cfg.world_size);
+    return mrs_comm_all_reduce_sum_f32(comm, buf, count, s);
+  }
 
   static size_t align(size_t v) { return (v + 255) & ~(size_t)255; }
   static size_t workspace_bytes(const mrs_llama_config &c) {
@@ -284,14 +292,14 @@ class Llama {
       reshape_and_cache(ws.k, ws.v, bl.key_cache, bl.value_cache, bufs.slot_mapping, b, cfg.num_kv_heads, hd, cfg.block_size, 8,
                         nkv, nkv, s, 2, 1, nullptr, nullptr);
       paged_attention_decode(bl, b, s);
-      if (bl.o_proj->forward_raw(ws.attn, b, ws.proj, sa, s)) return -1;
+      if (bl.o_proj->forward_raw(ws.attn, b, ws.proj, sa, s) || all_reduce(ws.proj, (size_t)b * d, s)) return -1;
       // Block::forward (llama.rs:243-260): x = attn + residual ; mlp(rms_norm(x)) + x
       add_rms_norm_f32(ws.proj, ws.h, bl.post_attention_layernorm, ws.h, ws.xn, b, d, cfg.rms_eps, st);
       // Mlp::forward -> quantized_ffn (ops.rs:5036): fused gate/up + act, then down
       rc = try_fused_quantized_gate_up(*bl.gate_proj, *bl.up_proj, ws.xn, b, ws.act, 0, sa, s);
       if (rc < 0) return -1;
       if (rc == 1) return fail("gate/up with different dtypes are not supported yet");
-      if (bl.down_proj->forward_raw(ws.act, b, ws.proj, sb, s)) return -1;
+      if (bl.down_proj->forward_raw(ws.act, b, ws.proj, sb, s) || all_reduce(ws.proj, (size_t)b * d, s)) return -1;
       const float *next_norm = li + 1 < blocks.size() ? blocks[li + 1].input_layernorm : ln_f;
       add_rms_norm_f32(ws.proj, ws.h, next_norm, ws.h, ws.xn, b, d, cfg.rms_eps, st);
     }
@@ -303,6 +311,7 @@ class Llama {
   static int ablate() { static int v = -1; if (v < 0) { const char *e = getenv("MRS_ABLATE"); v = e ? atoi(e) : 0; } return v; }
   int forward_fused(int b, hipStream_t s) const {
     const int ab = ablate();
+    const float rs = 1.0f / (float)std::max(1, (int)cfg.world_size);
     const int d = cfg.hidden_size, hd = cfg.head_dim, nq = cfg.num_heads * hd, nkv = cfg.num_kv_heads * hd, ff = cfg.intermediate_size;
     const int stride_q = pad_to(nq, MATRIX_ROW_PADDING) / 32, stride_f = pad_to(ff, MATRIX_ROW_PADDING) / 32;
     if (wte->embedding_forward_raw(bufs.input_ids, b, ws.h, s)) return -1;
@@ -323,11 +332,13 @@ class Llama {
         }
       }
       const QTensor *o = bl.o_proj->get_qtensor();
-      if (!(ab & 4) && mrs_decode_proj(o->data, o->dtype, d, nq, ws.y_a, stride_q, ws.h, d, 1, b, s)) return fail("mrs_decode_proj(o) refused");
+      // TP: h <- h / world + W_o . attn on every rank, then ONE sum all-reduce of h gives h + sum of the partials (division by a
+      // power of two is exact), so the residual add stays fused and nothing else crosses GPUs
+      if (!(ab & 4) && (mrs_decode_proj_scaled(o->data, o->dtype, d, nq, ws.y_a, stride_q, ws.h, d, rs, b, s) || all_reduce(ws.h, (size_t)b * d, s))) return fail("o_proj failed: %s", g_last_error.c_str());
       const QTensor *g = bl.gate_proj->get_qtensor(), *u = bl.up_proj->get_qtensor(), *dn = bl.down_proj->get_qtensor();
       if (!(ab & 8) && mrs_decode_gate_up(g->data, u->data, g->dtype, ff, d, ws.h, bl.post_attention_layernorm, cfg.rms_eps, 0, ws.y_b, stride_f, b, s))
         return fail("mrs_decode_gate_up refused");
-      if (!(ab & 16) && mrs_decode_proj(dn->data, dn->dtype, d, ff, ws.y_b, stride_f, ws.h, d, 1, b, s)) return fail("mrs_decode_proj(down) refused");
+      if (!(ab & 16) && (mrs_decode_proj_scaled(dn->data, dn->dtype, d, ff, ws.y_b, stride_f, ws.h, d, rs, b, s) || all_reduce(ws.h, (size_t)b * d, s))) return fail("down_proj failed: %s", g_last_error.c_str());
     }
     const QTensor *lm = lm_head->get_qtensor();
     if (!(ab & 32) && mrs_decode_norm_proj(lm->data, lm->dtype, cfg.vocab_size, d, ws.h, ln_f, cfg.rms_eps, bufs.logits, cfg.vocab_size, b, s))
@@ -384,11 +395,15 @@ class Llama {
       mrs_paged_attention_f32_bf16(0, attn, nullptr, nullptr, nullptr, q, bl.key_cache, bl.value_cache, nullptr, kvh, 1.0f / sqrtf((float)hd), 1.0f,
                                    pa.block_tables, pa.context_lens, bs, eff_max, T, cfg.num_heads, hd, cfg.max_blocks_per_seq, nq, kvh * hd * bs,
                                    hd * bs, s, nullptr);
-      if (gemm(*bl.o_proj, attn, nq, h, d, 1)) return -1;
+      if (cfg.world_size > 1) {  // row-parallel: partial -> all-reduce -> residual add (bias-free)
+        if (gemm(*bl.o_proj, attn, nq, xn, d, 0) || all_reduce(xn, t * d, s) || mrs_vec_add_f32(h, xn, t * d, s)) return -1;
+      } else if (gemm(*bl.o_proj, attn, nq, h, d, 1)) return -1;
       mrs_rms_norm_f32(h, bl.post_attention_layernorm, xn, T, d, cfg.rms_eps, st);
       if (gemm(*bl.gate_proj, xn, d, g, ff, 0) || gemm(*bl.up_proj, xn, d, u, ff, 0)) return -1;
       fused_glu_f32(g, u, act, (uint32_t)T, (uint32_t)ff, (uint32_t)ff, (uint32_t)ff, 0, s);
-      if (gemm(*bl.down_proj, act, ff, h, d, 1)) return -1;
+      if (cfg.world_size > 1) {
+        if (gemm(*bl.down_proj, act, ff, xn, d, 0) || all_reduce(xn, t * d, s) || mrs_vec_add_f32(h, xn, t * d, s)) return -1;
+      } else if (gemm(*bl.down_proj, act, ff, h, d, 1)) return -1;
     }
     // ctx.logits: only the last prompt token reaches lm_head (llama.rs:514-517)
     const QTensor *lm = lm_head->get_qtensor();
@@ -509,3 +524,4 @@ extern "C" int mrs_llama_prefill(void *m, const mrs_llama_prefill_args *a, int T
   return l.prefill(*a, T, (hipStream_t)stream);
 }
 extern "C" double mrs_llama_prefill_flops(void *m, int T) { return ((Llama *)m)->prefill_flops(T); }
+extern "C" int mrs_llama_set_comm(void *m, void *comm) { ((Llama *)m)->comm = comm; return 0; }

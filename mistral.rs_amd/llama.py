@@ -43,6 +43,8 @@ class LlamaConfig:
     max_batch: int = 1
     max_context_len: int = 1024
     use_fused: bool = True
+    tp_world_size: int = 1  # tensor parallel: num_heads / num_kv_heads / intermediate_size are the LOCAL (per-rank) sizes
+    tp_rank: int = 0
 
     def __post_init__(self):
         if self.head_dim is None:
@@ -131,10 +133,11 @@ class Llama:
         L.mrs_llama_prefill.argtypes = [C.c_void_p, C.POINTER(_PrefillArgs), C.c_int, C.c_void_p]
         L.mrs_llama_prefill_flops.restype = C.c_double
         L.mrs_llama_prefill_flops.argtypes = [C.c_void_p, C.c_int]
+        L.mrs_llama_set_comm.argtypes = [C.c_void_p, C.c_void_p]
         L.mrs_last_error.restype = C.c_char_p
         c = _Cfg(cfg.hidden_size, cfg.intermediate_size, cfg.num_layers, cfg.num_heads, cfg.num_kv_heads, cfg.head_dim,
                  cfg.vocab_size, cfg.head_dim, int(cfg.rope_interleaved), cfg.rms_eps, cfg.block_size, cfg.max_blocks_per_seq,
-                 cfg.max_batch, cfg.max_context_len, int(cfg.use_fused), 1, 0)
+                 cfg.max_batch, cfg.max_context_len, int(cfg.use_fused), cfg.tp_world_size, cfg.tp_rank)
         self._c = c
         self._h = L.mrs_llama_create(C.byref(c))
         if not self._h:
@@ -183,6 +186,11 @@ class Llama:
                 self._h = None
         except Exception:
             pass
+
+    def set_comm(self, comm) -> None:
+        """Attach the RCCL communicator (distributed.RcclComm) used for the row-parallel sum all-reduces."""
+        self._comm = comm
+        self._chk(self._L.mrs_llama_set_comm(self._h, comm.handle))
 
     def set_tensor(self, name: str, t) -> None:
         """t: QTensor (packed GGUF blocks) or an f32 torch tensor (norm weights)."""

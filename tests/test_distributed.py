@@ -1,0 +1,152 @@
+"""Tensor-parallel path.
+
+CPU (always run):
+  * shard math mirrors mistralrs-quant/src/distributed/layers.rs:2657-2733 (KV-head replication, error text) and the blocked
+    column slicing rule (uqff/mod.rs:277-284);
+  * world_size-2 gloo run (two real processes): every rank shards a small quantized decoder block column / row parallel, runs
+    the oracle matmuls on its shard and sum-all-reduces the row-parallel partials over torch.distributed -- the result equals the
+    unsharded block (exact matmul oracle, f64-accumulated: only the all-reduce's f32 additions differ).
+GPU (-m gpu): the RCCL communicator of the C++ runner initialises and all-reduces on one rank (world_size 1), and a runner with
+  that communicator attached reproduces the plain runner bit for bit.  Multi-GPU RCCL runs are the driver's (bench.py --tp).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_kv_shard_rules():
+    import mistralrs_amd  # noqa: F401
+    from mistralrs_amd import distributed as D
+    # partitioned kv heads
+    s = D.compute_kv_shard(8, 128, rank=3, world_size=4)
+    assert (s.dim, s.rank, s.world_size, s.offset) == (0, 3, 4, None) and s.bounds(8 * 128) == (768, 1024)
+    assert D.compute_n_kv_groups(8, 32, 4) == 4
+    # replicated kv heads: world 16 > 8 kv heads, 2 ranks share a head (Llama-3-70B at TP=16)
+    for rank in range(16):
+        s = D.compute_kv_shard(8, 128, rank, 16)
+        assert s.offset == (rank // 2) * 128 and s.length == 128
+    assert D.compute_n_kv_groups(8, 64, 16) == 4
+    assert D.local_dims(64, 8, 28672, 8) == (8, 1, 3584) and D.local_dims(64, 8, 28672, 16) == (4, 1, 1792)
+    with pytest.raises(ValueError, match="must be divisible by tensor parallel size"):
+        D.validate_tp_head_layout(32, 8, 3)
+    with pytest.raises(ValueError, match="when KV heads are replicated"):
+        D.compute_kv_shard(8, 128, 0, 12)
+    with pytest.raises(ValueError, match="Total number of KV heads must be greater than 0"):
+        D.validate_tp_kv_heads(0, 2)
+
+
+def test_shard_qtensor_blocks(oracle):
+    import torch
+    import mistralrs_amd  # noqa: F401
+    from mistralrs_amd import distributed as D
+    from mistralrs_amd.gguf import GgmlDType, QTensor
+    for t, dt in ((oracle.Q4_K, GgmlDType.Q4K), (oracle.Q6_K, GgmlDType.Q6K), (oracle.Q8_0, GgmlDType.Q8_0)):
+        n, k = 8, 1024
+        w = oracle.random_blocks(t, n, k, seed=5)
+        full = oracle.dequantize(t, w, k)
+        qt = QTensor(dt, (n, k), torch.from_numpy(w.reshape(-1)))
+        for rank in range(2):
+            rows = D.shard_qtensor(qt, D.Shard(0, rank, 2))
+            np.testing.assert_array_equal(oracle.dequantize(t, rows.data.numpy().reshape(rows.shape[0], -1), k), full[rank * 4:(rank + 1) * 4])
+            cols = D.shard_qtensor(qt, D.Shard(1, rank, 2))
+            np.testing.assert_array_equal(oracle.dequantize(t, cols.data.numpy().reshape(n, -1), k // 2), full[:, rank * 512:(rank + 1) * 512])
+        off = D.shard_qtensor(qt, D.Shard(0, 0, 4, offset=2, length=3))
+        np.testing.assert_array_equal(oracle.dequantize(t, off.data.numpy().reshape(3, -1), k), full[2:5])
+    with pytest.raises(ValueError, match="not a multiple of the block size"):
+        D.shard_qtensor(QTensor(GgmlDType.Q4K, (4, 768), torch.zeros(4 * 3 * 144, dtype=torch.uint8)), D.Shard(1, 0, 2))
+
+
+def _tp_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import mistralrs_amd  # noqa: F401
+    from mistralrs_amd import distributed as D
+    from mistralrs_amd.gguf import GgmlDType, QTensor
+    from oracle import oracle as O
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    rng = np.random.default_rng(0)  # same data on every rank
+    d, ff, heads, kvh, hd = 512, 1024, 4, 2, 128
+    types = {"attn_q": (O.Q4_K, heads * hd, d), "attn_k": (O.Q4_K, kvh * hd, d), "attn_v": (O.Q6_K, kvh * hd, d), "attn_output": (O.Q4_K, d, heads * hd),
+             "ffn_gate": (O.Q4_K, ff, d), "ffn_up": (O.Q4_K, ff, d), "ffn_down": (O.Q6_K, d, ff)}
+    w = {k: (t, O.random_blocks(t, n, kk, seed=11 + i, d_scale=0.02), n, kk) for i, (k, (t, n, kk)) in enumerate(types.items())}
+    x = rng.standard_normal((3, d)).astype(np.float32)
+
+    def lin(name, inp, shard):
+        t, packed, n, kk = w[name]
+        qt = QTensor(GgmlDType.from_id(t), (n, kk), torch.from_numpy(packed.reshape(-1)))
+        if shard is not None:
+            qt = D.shard_qtensor(qt, shard)
+        return O.matmul_exact(t, qt.data.numpy().reshape(qt.shape[0], -1), qt.shape[0], qt.shape[1], inp)
+
+    def block(rank, world):
+        total = {"num_kv_heads": kvh, "head_dim": hd}
+        sh = lambda nm: D.llama_tensor_shard(f"blk.0.{nm}.weight", total, rank, world)
+        qv = lin("attn_q", x, sh("attn_q"))          # stand-in for attention: the value path only (q is projected and dropped)
+        v = lin("attn_v", x, sh("attn_v"))
+        groups = D.compute_n_kv_groups(kvh, heads, world)
+        att = np.repeat(v.reshape(3, -1, hd), groups, axis=1).reshape(3, -1) + 0.0 * qv  # every local q head reads its kv head's v
+        o = lin("attn_output", att, sh("attn_output"))
+        o = D.SumAllReduce()(torch.from_numpy(o)).numpy()
+        h = x + o
+        g, u = lin("ffn_gate", h, sh("ffn_gate")), lin("ffn_up", h, sh("ffn_up"))
+        a = O.fused_glu(g, u, 0)
+        dn = lin("ffn_down", a, sh("ffn_down"))
+        dn = D.SumAllReduce()(torch.from_numpy(dn)).numpy()
+        return h + dn
+
+    got = block(rank, world)
+    if rank == 0:
+        # unsharded reference computed without any collective
+        qv = lin("attn_q", x, None); v = lin("attn_v", x, None)
+        att = np.repeat(v.reshape(3, kvh, hd), heads // kvh, axis=1).reshape(3, -1)
+        h = x + lin("attn_output", att, None)
+        want = h + lin("ffn_down", O.fused_glu(lin("ffn_gate", h, None), lin("ffn_up", h, None), 0), None)
+        q.put((float(np.abs(got - want).max()), float(np.abs(want).max())))
+    dist.destroy_process_group()
+
+
+def test_tensor_parallel_block_world2_gloo(oracle):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_tp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    err, scale = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert err <= 2e-5 * scale, (err, scale)
+
+
+@pytest.mark.gpu
+def test_rccl_comm_world1_and_runner(oracle, dev):
+    import torch
+    import torch.distributed as dist
+    from mistralrs_amd import distributed as D
+    from tests.test_llama_runner import Q4KM, _mk, _tokens
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29631", rank=0, world_size=1, device_id=dev)
+        created = True
+    try:
+        comm = D.RcclComm(0, 1, dev)
+        t = torch.arange(1000, dtype=torch.float32, device=dev)
+        comm.all_reduce_(t)
+        torch.cuda.synchronize()
+        assert torch.equal(t, torch.arange(1000, dtype=torch.float32, device=dev))
+        cfg, w, m, cos, sin = _mk(oracle, dev, True, Q4KM(oracle))
+        _, _, m2, _, _ = _mk(oracle, dev, True, Q4KM(oracle))
+        m2.set_comm(comm)
+        for pos, tok in enumerate(_tokens(6)):
+            m.set_state([tok], [pos]); m2.set_state([tok], [pos])
+            assert torch.equal(m.forward_logits(1), m2.forward_logits(1))
+    finally:
+        if created:
+            dist.destroy_process_group()
