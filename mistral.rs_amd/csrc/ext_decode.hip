@@ -242,17 +242,24 @@ __global__ void __launch_bounds__(NT) decode_gemv_kernel(const DecodeGemvArgs a)
     const int rpw = a.rows_per_wg / NW;
     const int first = row0 + wave * rpw;
     const int nrows = max(0, min(rpw, row1 - first));
-    auto rowptr = [&](int r, const uint8_t *&pA, const uint8_t *&pB) { pA = a.w[0] + (size_t)r * rb; pB = pA; };
-    auto epi = [&](int r, float(&acc)[1][NCOLS]) {
-      if (lane == 0) {
+    auto rowptr = [&](int r, const uint8_t *&pA, const uint8_t *&pB) { pA = a.w[0] + (size_t)r * rb; pB = pA + rb; };
+    auto put = [&](int r, const float(&v)[NCOLS]) {
 #pragma unroll
-        for (int c = 0; c < NCOLS; ++c) {
-          float *o = a.out + (size_t)c * a.out_stride + r;
-          if constexpr (EPI == EPI_RESID_ADD) *o = *o * a.resid_scale + acc[0][c]; else *o = acc[0][c];
-        }
+      for (int c = 0; c < NCOLS; ++c) {
+        float *o = a.out + (size_t)c * a.out_stride + r;
+        if constexpr (EPI == EPI_RESID_ADD) *o = *o * a.resid_scale + v[c]; else *o = v[c];
       }
     };
-    MRS_HOT_TYPE_SWITCH(a.wtype[0], (stream_rows_auto<TT, NCOLS, false>(first, nrows, 1, K, rpw, rowptr, pro, epi));)
+    auto epi = [&](int r, float(&acc)[1][NCOLS]) { if (lane == 0) put(r, acc[0]); };
+    auto epi2 = [&](int r, float(&acc)[2][NCOLS]) { if (lane == 0) { put(r, acc[0]); put(r + 1, acc[1]); } };
+    const bool pair_ok = ((rpw | a.nrows[0]) & 1) == 0;  // the host rounds rows-per-wave up to even for the paired-row formats
+    MRS_HOT_TYPE_SWITCH(a.wtype[0],
+      if constexpr (PairQ<TT>::value) {
+        if (pair_ok) stream_rows_auto<TT, NCOLS, true>(first, nrows / 2, 2, K, rpw / 2, rowptr, pro, epi2);
+        else stream_rows_auto<TT, NCOLS, false>(first, nrows, 1, K, rpw, rowptr, pro, epi);
+      } else {
+        stream_rows_auto<TT, NCOLS, false>(first, nrows, 1, K, rpw, rowptr, pro, epi);
+      })
   }
 }
 
@@ -276,6 +283,7 @@ template <int PRO, int EPI> struct DecodeLaunch {
     } else {
       int rpw = (total + 4095) / 4096;
       if (rpw < 1) rpw = 1;
+      if ((a.wtype[0] == T_Q4_K || a.wtype[0] == T_Q5_K) && (total & 1) == 0 && (rpw & 1)) ++rpw;  // paired rows
       per = NW * rpw;
     }
     a.rows_per_wg = per;

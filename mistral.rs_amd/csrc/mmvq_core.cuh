@@ -207,6 +207,45 @@ __device__ __forceinline__ void accumulate_wide(const RawW<TYPE> &w, int u, cons
   }
 }
 
+// ------------------------------------------------------------------------------------------ paired rows (Q4_K / Q5_K)
+// Two rows A, B are streamed with the coalesced one-16-byte-piece-per-lane loads of the slice path (lanes 2k and 2k+1 hold
+// the two pieces of quarter k of a superblock, for BOTH rows).  A DPP lane swap then gives the even lane both pieces of row
+// A's quarter and the odd lane both pieces of row B's quarter, so every lane runs the 64-weight "wide" arithmetic (one
+// scale/min decode, one set of activation reads per 64 weights) on one row.  Even lanes accumulate row A, odd lanes row B.
+template <int TYPE> struct PairQ { static constexpr bool value = (TYPE == T_Q4_K || TYPE == T_Q5_K); };
+
+__device__ __forceinline__ int dpp_swap1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false); }  // quad_perm [1,0,3,2]
+__device__ __forceinline__ int4 dpp_swap1(int4 v) { return make_int4(dpp_swap1(v.x), dpp_swap1(v.y), dpp_swap1(v.z), dpp_swap1(v.w)); }
+__device__ __forceinline__ int4 sel4(bool c, int4 a, int4 b) { return make_int4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w); }
+
+template <int TYPE> __device__ __forceinline__ RawW<TYPE> make_pair_unit(const Raw<TYPE> &a, const Raw<TYPE> &b, bool odd) {
+  RawW<TYPE> w;
+  const int4 sa = dpp_swap1(a.qs), sb = dpp_swap1(b.qs);
+  w.hdr = sel4(odd, b.hdr, a.hdr);
+  w.q0 = sel4(odd, sb, a.qs);   // piece 2k   : even lane's own (row A) / even partner's (row B)
+  w.q1 = sel4(odd, b.qs, sa);   // piece 2k+1 : odd partner's (row A) / odd lane's own (row B)
+  if constexpr (TYPE == T_Q5_K) {
+    const int4 ha = dpp_swap1(a.qh), hb = dpp_swap1(b.qh);
+    w.h0 = sel4(odd, hb, a.qh);
+    w.h1 = sel4(odd, b.qh, ha);
+  }
+  return w;
+}
+
+// sums over the even / odd lanes of the wave (rows A / B): rotations by 2, 4, 8 inside each row of 16, then the four rows
+template <int CTRL> __device__ __forceinline__ float dpp_movf(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ void wave_sum_parity(float v, float &even, float &odd) {
+  v += dpp_movf<0x122>(v);  // row_ror:2
+  v += dpp_movf<0x124>(v);  // row_ror:4
+  v += dpp_movf<0x128>(v);  // row_ror:8  -> lane l holds the sum over the lanes of its row with l's parity
+  const int b = __builtin_bit_cast(int, v);
+  auto rl = [&](int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, l)); };
+  even = (rl(0) + rl(16)) + (rl(32) + rl(48));
+  odd = (rl(1) + rl(17)) + (rl(33) + rl(49));
+}
+
 // ------------------------------------------------------------------------------------------ wave reduction
 // on the VALU (DPP), no LDS traffic: quads -> rows of 16 -> the four rows via readlane.
 template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
@@ -283,7 +322,11 @@ __device__ __forceinline__ void stream_rows(int first_row, int nrows, int row_st
         const int s = cj * 64 + lane;
         const bool live = FULL ? true : (s < nunits);
         const int sc = FULL ? s : min(s, nunits - 1);
-        if constexpr (Wide<TYPE>::value) {
+        constexpr bool PAIR = DUAL && PairQ<TYPE>::value;
+        if constexpr (PAIR) {
+          const RawW<TYPE> w = make_pair_unit<TYPE>(b[u][0], b[u][1], (lane & 1) != 0);
+          accumulate_wide<TYPE, NCOLS>(w, sc >> 1, act, acc[0], live);  // acc[0]: this lane's row (A on even lanes, B on odd lanes)
+        } else if constexpr (Wide<TYPE>::value) {
 #pragma unroll
           for (int m = 0; m < NM; ++m) accumulate_wide<TYPE, NCOLS>(b[u][m], sc, act, acc[m], live);
         } else {
@@ -296,10 +339,15 @@ __device__ __forceinline__ void stream_rows(int first_row, int nrows, int row_st
           }
         }
         if (++cj == ipr) {
+          if constexpr (PAIR) {
 #pragma unroll
-          for (int m = 0; m < NM; ++m)
+            for (int c = 0; c < NCOLS; ++c) { float e, o; wave_sum_parity(acc[0][c], e, o); acc[0][c] = e; acc[1][c] = o; }
+          } else {
 #pragma unroll
-            for (int c = 0; c < NCOLS; ++c) acc[m][c] = wave_sum_dpp(acc[m][c]);
+            for (int m = 0; m < NM; ++m)
+#pragma unroll
+              for (int c = 0; c < NCOLS; ++c) acc[m][c] = wave_sum_dpp(acc[m][c]);
+          }
           epi(first_row + ci * row_step, acc);
 #pragma unroll
           for (int m = 0; m < NM; ++m)

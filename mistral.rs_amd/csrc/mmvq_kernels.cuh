@@ -77,18 +77,27 @@ __global__ void __launch_bounds__(256) mmvq_kernel(const MmvqArgs a) {
       int m, lr;
       locate(r, m, lr);
       pA = a.w[m] + (size_t)lr * row_bytes;
-      pB = pA;
+      pB = pA + row_bytes;  // row pairs (paired-row path): r + 1 lies in the same matrix (every row count is even there)
     };
-    auto epi = [&](int r, float(&acc)[1][NCOLS]) {
-      if (lane == 0) {
-        int m, lr;
-        locate(r, m, lr);
-        const int stride = (MODE == MODE_QKV) ? a.nrows[m] : a.stride_col_dst;
+    auto store_row = [&](int r, const float(&v)[NCOLS]) {
+      int m, lr;
+      locate(r, m, lr);
+      const int stride = (MODE == MODE_QKV) ? a.nrows[m] : a.stride_col_dst;
 #pragma unroll
-        for (int c = 0; c < NCOLS; ++c) store_dst(a.dst[m], (size_t)c * stride + lr, acc[0][c], a.dst_kind);
-      }
+      for (int c = 0; c < NCOLS; ++c) store_dst(a.dst[m], (size_t)c * stride + lr, v[c], a.dst_kind);
     };
-    stream_rows_auto<TYPE, NCOLS, false>(first, nrows, 1, K, rpw, rowptr, pro, epi);
+    bool paired = false;
+    if constexpr (PairQ<TYPE>::value) {  // Q4_K / Q5_K: two rows per step, 64-weight arithmetic per lane (mmvq_core.cuh)
+      paired = ((rpw | a.nrows[0] | a.nrows[1] | a.nrows[2]) & 1) == 0;
+      if (paired) {
+        auto epi2 = [&](int r, float(&acc)[2][NCOLS]) { if (lane == 0) { store_row(r, acc[0]); store_row(r + 1, acc[1]); } };
+        stream_rows_auto<TYPE, NCOLS, true>(first, nrows / 2, 2, K, rpw / 2, rowptr, pro, epi2);
+      }
+    }
+    if (!paired) {
+      auto epi = [&](int r, float(&acc)[1][NCOLS]) { if (lane == 0) store_row(r, acc[0]); };
+      stream_rows_auto<TYPE, NCOLS, false>(first, nrows, 1, K, rpw, rowptr, pro, epi);
+    }
   }
 }
 
@@ -98,10 +107,12 @@ inline int mmvq_target_waves() {
   if (!v) { const char *e = getenv("MRS_MMVQ_WAVES"); v = e ? atoi(e) : 4096; if (v < 256) v = 256; }
   return v;
 }
-inline int mmvq_rows_per_wave(int total_rows) {
+inline int mmvq_rows_per_wave(int total_rows, bool want_even) {
   const int t = mmvq_target_waves();
   int r = (total_rows + t - 1) / t;
-  return r < 1 ? 1 : r;
+  if (r < 1) r = 1;
+  if (want_even && (r & 1)) ++r;  // paired-row formats walk two rows per step
+  return r;
 }
 
 template <int TYPE, int MODE> struct MmvqLaunch {
@@ -113,7 +124,7 @@ template <int TYPE, int MODE> struct MmvqLaunch {
       attr_done = true;
     }
     MmvqArgs b = a;
-    b.rows_per_wave = mmvq_rows_per_wave(total_rows);
+    b.rows_per_wave = mmvq_rows_per_wave(total_rows, PairQ<TYPE>::value && MODE != MODE_GLU);
     const int grid = (total_rows + 4 * b.rows_per_wave - 1) / (4 * b.rows_per_wave);
     hipLaunchKernelGGL((mmvq_kernel<TYPE, NCOLS, MODE>), dim3(grid), dim3(256), lds, s, b);
   }

@@ -107,8 +107,14 @@ def test_fused_qkv_matches_oracle_and_plain(oracle, dev, tag, dt, b):
     for o, (t, p), n, qt in zip(outs, ws, (nq, nk, nv), qts):
         want, mag = oracle.matmul_q8_1_mag(t, p, n, k, y)
         assert_close_accum(to_np(o), round_through(want, dt) if dt != "f32" else want, mag, dt, k // 16, f"qkv {tag}")
-        # reference test: fused == three independent projections (bit-identical here: same kernel maths)
-        assert torch.equal(o, fast_mmvq.plain(qt, xs))
+        # reference test: fused == three independent projections.  Bit-identical whenever both launches take the same arithmetic
+        # path; Q4_K / Q5_K use the paired-row (64-weight) path only when every row count of the launch is even (nk = 33 here
+        # makes the fused launch fall back to the 32-weight path), then the two agree to f32 summation order
+        sep = fast_mmvq.plain(qt, xs)
+        if tag in ("q4_k", "q5_k"):
+            assert_close_accum(to_np(o), to_np(sep), mag, dt, k // 16, f"qkv vs plain {tag}")
+        else:
+            assert torch.equal(o, sep)
 
 
 @pytest.mark.parametrize("tag", ALL_TYPES)
