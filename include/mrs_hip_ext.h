@@ -57,6 +57,9 @@ int mrs_sample_greedy_advance(const float *logits, int vocab, int b, int32_t *ne
  * Returns 0, -1 for an unsupported type / shape (K % 256 for K-quants, K % 64 for Q8_0, ldx % 4). */
 int mrs_gemm_q_f32(const void *w, int ggml_type, int N, int K, const float *x, int ldx, float *out, int ldo, int M, int accumulate,
                    void *stream);
+/* same for up to 3 weight matrices of ONE type that share x (q/k/v, gate/up: role of fast_mmq::{fused_qkv,fused_glu}) */
+int mrs_gemm_q_f32_multi(int nseg, const void *const *w, const int *N, float *const *out, const int *ldo, int ggml_type, int K,
+                         const float *x, int ldx, int M, int accumulate, void *stream);
 
 /* ---------------------------------------------------------------- host-side model runner (host/runtime.cpp)
  * C++ mirror of mistralrs-core/src/models/llama.rs (Llama / CausalSelfAttention / Mlp / Block) on top of

@@ -17,6 +17,7 @@
 // LDS is double buffered: global loads of step i+1 are issued before the MFMAs of step i, decoded/converted after them.
 #include "gguf_blocks.cuh"
 #include <stdio.h>
+#include <stdlib.h>
 
 namespace mrs {
 
@@ -25,8 +26,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int GM = 128, GN = 128, GK = 64, GT = 256;
 
+// two f32 -> packed bf16 (RNE): one v_cvt_pk_bf16_f32 on gfx950 (the bit-twiddling RNE of common.cuh costs ~6 VALU per value)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
-  return (unsigned)float_to_bf16_bits(a) | ((unsigned)float_to_bf16_bits(b) << 16);
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 
 // raw registers of one 32-weight sub-block (row r, k in [kb*64 + half*32, +32))
@@ -91,8 +96,8 @@ template <int TYPE> __device__ __forceinline__ void gemm_decode_w(const RawG<TYP
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const unsigned v = ((q[i] >> (4 * half)) & 0x0f0f0f0fu) | hb[i];
-      o[2 * i] = pack_bf16(s * (float)(v & 0xff) - m, s * (float)((v >> 8) & 0xff) - m);
-      o[2 * i + 1] = pack_bf16(s * (float)((v >> 16) & 0xff) - m, s * (float)(v >> 24) - m);
+      o[2 * i] = pack_bf16(fmaf(s, (float)(v & 0xff), -m), fmaf(s, (float)((v >> 8) & 0xff), -m));
+      o[2 * i + 1] = pack_bf16(fmaf(s, (float)((v >> 16) & 0xff), -m), fmaf(s, (float)(v >> 24), -m));
     }
   } else if constexpr (TYPE == T_Q6_K) {
     const int c = kb & 3, qt = (c & 1) * 2 + half;
@@ -107,8 +112,9 @@ template <int TYPE> __device__ __forceinline__ void gemm_decode_w(const RawG<TYP
       const unsigned lo = (qt < 2 ? ql[i] : (ql[i] >> 4)) & 0x0f0f0f0fu;
       const unsigned v = lo | (((qh[i] >> (2 * qt)) & 0x03030303u) << 4);
       const float s = i < 4 ? s0 : s1;  // 16 weights per scale
-      o[2 * i] = pack_bf16(s * (float)((int)(v & 0xff) - 32), s * (float)((int)((v >> 8) & 0xff) - 32));
-      o[2 * i + 1] = pack_bf16(s * (float)((int)((v >> 16) & 0xff) - 32), s * (float)((int)(v >> 24) - 32));
+      const float m = 32.0f * s;  // w = s * (q - 32) = fma(s, q, -32 s): exact in f32 (q <= 63, s has <= 19 significant bits)
+      o[2 * i] = pack_bf16(fmaf(s, (float)(v & 0xff), -m), fmaf(s, (float)((v >> 8) & 0xff), -m));
+      o[2 * i + 1] = pack_bf16(fmaf(s, (float)((v >> 16) & 0xff), -m), fmaf(s, (float)(v >> 24), -m));
     }
   } else {
     const float d = half_bits_to_float((uint16_t)w.d);
@@ -121,111 +127,161 @@ template <int TYPE> __device__ __forceinline__ void gemm_decode_w(const RawG<TYP
   }
 }
 
+// up to 3 weight matrices of the same type that share the activations (q/k/v, gate/up): one launch, more workgroups in flight
 struct GemmArgs {
-  const uint8_t *w;
+  const uint8_t *w[3];
+  float *out[3];
+  int N[3], ldo[3], tile0[3];  // tile0[s]: first n-tile of segment s
+  int nseg;
   const float *x;
-  float *out;
-  int M, N, K, ldx, ldo, accumulate;
+  int M, K, ldx, accumulate;
   size_t row_bytes;
 };
 
-// LDS tile [128 rows][64 k] bf16 = 8 chunks of 16 B per row, chunk index XOR (row & 7)
+// LDS tile [rows][64 k] bf16 = 8 chunks of 16 B per row, chunk index XOR (row & 7)
 __device__ __forceinline__ int tile_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
-template <int TYPE>
+// TM = token rows per workgroup tile: 128 (wave = 64 x 64) or 64 (wave = 32 x 64; twice the workgroups for shapes that
+// would otherwise leave CUs idle, at twice the weight-decode work per FLOP)
+template <int TYPE, int PF, int TM>
 __global__ void __launch_bounds__(GT) gemm_q_kernel(const GemmArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A 16 KB | B 16 KB]
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A TM x 64 bf16 | B 128 x 64 bf16]
+  constexpr int MI = TM / 64;  // 32-row MFMA tiles per wave along m
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int m0 = blockIdx.y * GM, n0 = blockIdx.x * GN;
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;  // wave's 64 x 64 sub-tile
-  // staging roles: A: thread -> row ar = tid / 2, 32 consecutive k (half ah); B: row br = tid / 2, sub-block half bh
+  int seg = 0;
+  if (a.nseg > 2 && (int)blockIdx.x >= a.tile0[2]) seg = 2;
+  else if (a.nseg > 1 && (int)blockIdx.x >= a.tile0[1]) seg = 1;
+  const int segN = a.N[seg], segldo = a.ldo[seg];
+  const uint8_t *segw = a.w[seg];
+  float *segout = a.out[seg];
+  const int m0 = blockIdx.y * TM, n0 = ((int)blockIdx.x - a.tile0[seg]) * GN;
+  const int wm = (wave >> 1) * (TM / 2), wn = (wave & 1) * 64;  // wave's (TM/2) x 64 sub-tile
+  // staging roles.  A (activations): 16 consecutive lanes cover one 256-byte row segment (64 f32), so a load instruction of a
+  // wave reads 4 whole segments (fully used cache lines); thread -> column chunk xc = tid % 16 (4 floats), rows xr0 + 16 i.
+  // B (weights): thread -> row ar = tid / 2, 32-weight sub-block ah = tid % 2 of the 64-k slab.
   const int ar = tid >> 1, ah = tid & 1;
-  const bool a_live = m0 + ar < a.M;
-  const float *xrow = a.x + (size_t)min(m0 + ar, a.M - 1) * a.ldx + ah * 32;
-  const uint8_t *wrow = a.w + (size_t)min(n0 + ar, a.N - 1) * a.row_bytes;
+  const int xc = tid & 15, xr0 = tid >> 4;
+  const float *xbase = a.x + xc * 4;
+  const uint8_t *wrow = segw + (size_t)min(n0 + ar, segN - 1) * a.row_bytes;
   const int nk = a.K / GK;
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 xa[8];
-  RawG<TYPE> wb;
-  auto issue = [&](int kb) {
+  // Two staging register sets: the loads of step kb+2 are issued before the MFMAs of step kb, while step kb+1 (issued one
+  // iteration earlier) is converted / decoded into the other LDS buffer after them -- a full iteration of latency cover.
+  // Loads are unconditional (k index clamped): a load inside a conditional block makes hipcc drain the whole vmcnt queue.
+  constexpr int XR = TM / 16;  // activation rows staged per thread
+  float4 xa[PF][XR];
+  RawG<TYPE> wb[PF];
+  auto issue = [&](int set, int kb_raw) {
+    const int kb = min(kb_raw, nk - 1);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) xa[i] = *(const float4 *)(xrow + (size_t)kb * GK + i * 4);
-    wb = gemm_load_w<TYPE>(wrow, kb, ah);
+    for (int i = 0; i < XR; ++i) {
+      const int m = min(m0 + xr0 + 16 * i, a.M - 1);
+      xa[set][i] = *(const float4 *)(xbase + (size_t)m * a.ldx + (size_t)kb * GK);
+    }
+    wb[set] = gemm_load_w<TYPE>(wrow, kb, ah);
   };
-  auto commit = [&](int kb, char *buf) {
-    char *A = buf, *B = buf + GM * GK * 2;
+  auto commit = [&](int set, int kb_raw, char *buf) {
+    const int kb = min(kb_raw, nk - 1);
+    char *A = buf, *B = buf + TM * GK * 2;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      int4 v;
-      if (a_live) {
-        v.x = (int)pack_bf16(xa[2 * c].x, xa[2 * c].y); v.y = (int)pack_bf16(xa[2 * c].z, xa[2 * c].w);
-        v.z = (int)pack_bf16(xa[2 * c + 1].x, xa[2 * c + 1].y); v.w = (int)pack_bf16(xa[2 * c + 1].z, xa[2 * c + 1].w);
-      } else {
-        v = make_int4(0, 0, 0, 0);
-      }
-      *(int4 *)(A + tile_off(ar, ah * 4 + c)) = v;
+    for (int i = 0; i < XR; ++i) {
+      const int row = xr0 + 16 * i;
+      const bool live = m0 + row < a.M;
+      int2 v;
+      v.x = live ? (int)pack_bf16(xa[set][i].x, xa[set][i].y) : 0;
+      v.y = live ? (int)pack_bf16(xa[set][i].z, xa[set][i].w) : 0;
+      *(int2 *)(A + tile_off(row, xc >> 1) + (xc & 1) * 8) = v;  // 4 bf16 = half of a 16-byte chunk
     }
     unsigned o[16];
-    gemm_decode_w<TYPE>(wb, kb, ah, o);
+    gemm_decode_w<TYPE>(wb[set], kb, ah, o);
 #pragma unroll
     for (int c = 0; c < 4; ++c) *(int4 *)(B + tile_off(ar, ah * 4 + c)) = make_int4((int)o[4 * c], (int)o[4 * c + 1], (int)o[4 * c + 2], (int)o[4 * c + 3]);
   };
-
-  issue(0);
-  commit(0, smem);
-  __syncthreads();
   const int frow = lane & 31, fk = lane >> 5;  // fragment: row / column index, which 8-k half of a 16-k slab
-  for (int kb = 0; kb < nk; ++kb) {
-    char *cur = smem + (kb & 1) * (2 * GM * GK * 2);
-    char *nxt = smem + ((kb + 1) & 1) * (2 * GM * GK * 2);
-    if (kb + 1 < nk) issue(kb + 1);
-    const char *A = cur, *B = cur + GM * GK * 2;
+  auto mfma_tile = [&](const char *buf) {
+    const char *A = buf, *B = buf + TM * GK * 2;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {  // four 16-k slabs
-      bf16x8 af[2], bfr[2];
+      bf16x8 af[MI], bfr[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = *(const bf16x8 *)(A + tile_off(wm + i * 32 + frow, ks * 2 + fk));
+      for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8 *)(A + tile_off(wm + i * 32 + frow, ks * 2 + fk));
 #pragma unroll
       for (int j = 0; j < 2; ++j) bfr[j] = *(const bf16x8 *)(B + tile_off(wn + j * 32 + frow, ks * 2 + fk));
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
-    if (kb + 1 < nk) commit(kb + 1, nxt);
+  };
+  char *buf0 = smem, *buf1 = smem + (TM + GN) * GK * 2;
+  if constexpr (PF == 2) {
+    issue(0, 0);
+    issue(1, 1);
+    commit(0, 0, buf0);
     __syncthreads();
+    for (int kb = 0; kb < nk; kb += 2) {
+      issue(0, kb + 2);
+      mfma_tile(buf0);
+      commit(1, kb + 1, buf1);
+      __syncthreads();
+      if (kb + 1 >= nk) break;
+      issue(1, kb + 3);
+      mfma_tile(buf1);
+      commit(0, kb + 2, buf0);
+      __syncthreads();
+    }
+  } else {  // one staging set (fewer registers: two workgroups per CU overlap each other's MFMA and staging phases)
+    issue(0, 0);
+    commit(0, 0, buf0);
+    __syncthreads();
+    for (int kb = 0; kb < nk; kb += 2) {
+      issue(0, kb + 1);
+      mfma_tile(buf0);
+      commit(0, kb + 1, buf1);
+      __syncthreads();
+      if (kb + 1 >= nk) break;
+      issue(0, kb + 2);
+      mfma_tile(buf1);
+      commit(0, kb + 2, buf0);
+      __syncthreads();
+    }
   }
   // C layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int n = n0 + wn + j * 32 + (lane & 31);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m < a.M && n < a.N) {
-          float *p = a.out + (size_t)m * a.ldo + n;
+        if (m < a.M && n < segN) {
+          float *p = segout + (size_t)m * segldo + n;
           *p = a.accumulate ? *p + acc[i][j][r] : acc[i][j][r];
         }
       }
     }
 }
 
-template <int TYPE> static int gemm_launch(const GemmArgs &a, hipStream_t s) {
-  auto kern = gemm_q_kernel<TYPE>;
-  constexpr size_t lds = 2 * 2 * GM * GK * 2;  // 64 KiB
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-  hipLaunchKernelGGL(kern, dim3((a.N + GN - 1) / GN, (a.M + GM - 1) / GM), dim3(GT), lds, s, a);
+template <int TYPE, int TM> static void gemm_launch_tm(const GemmArgs &a, int tiles, hipStream_t s) {
+  auto kern = gemm_q_kernel<TYPE, 2, TM>;
+  constexpr size_t lds = 2 * (TM + GN) * GK * 2;  // 64 KiB (TM 128) / 48 KiB (TM 64)
+  hipLaunchKernelGGL(kern, dim3(tiles, (a.M + TM - 1) / TM), dim3(GT), lds, s, a);
+}
+template <int TYPE> static int gemm_launch(GemmArgs a, hipStream_t s) {
+  int tiles = 0;
+  for (int i = 0; i < a.nseg; ++i) { a.tile0[i] = tiles; tiles += (a.N[i] + GN - 1) / GN; }
+  // fewer than one workgroup per CU with 128-row tiles: halve the tile height (deterministic, unlike split-K atomics)
+  if (a.M > 64 && tiles * ((a.M + 127) / 128) < 256) gemm_launch_tm<TYPE, 64>(a, tiles, s);
+  else gemm_launch_tm<TYPE, 128>(a, tiles, s);
   return 0;
 }
 
@@ -233,13 +289,18 @@ template <int TYPE> static int gemm_launch(const GemmArgs &a, hipStream_t s) {
 
 using namespace mrs;
 
-// out[m*ldo + n] (+)= sum_k bf16(x[m*ldx + k]) * bf16(W[n][k]);  W: raw GGUF blocks [N][K/blk] of type q4_k / q5_k / q6_k / q8_0.
-// Returns 0, or -1 for an unsupported type / shape (K % 256 for the K-quants, K % 64 for Q8_0).
-extern "C" int mrs_gemm_q_f32(const void *w, int ggml_type, int N, int K, const float *x, int ldx, float *out, int ldo, int M, int accumulate,
-                              void *stream) {
-  if (M <= 0 || N <= 0) return 0;
+// Up to 3 weight matrices of ONE type sharing the activations: out_s[m*ldo_s + n] (+)= sum_k bf16(x[m*ldx + k]) * bf16(W_s[n][k]).
+extern "C" int mrs_gemm_q_f32_multi(int nseg, const void *const *w, const int *N, float *const *out, const int *ldo, int ggml_type, int K,
+                                    const float *x, int ldx, int M, int accumulate, void *stream) {
+  if (nseg < 1 || nseg > 3) return -1;
+  if (M <= 0) return 0;
   if (K <= 0 || K % 64 || ((ggml_type == T_Q4_K || ggml_type == T_Q5_K || ggml_type == T_Q6_K) && K % 256) || (ldx & 3)) return -1;
-  GemmArgs a{(const uint8_t *)w, x, out, M, N, K, ldx, ldo, accumulate, 0};
+  GemmArgs a{};
+  a.nseg = nseg; a.x = x; a.M = M; a.K = K; a.ldx = ldx; a.accumulate = accumulate;
+  for (int i = 0; i < nseg; ++i) {
+    if (N[i] <= 0) return -1;
+    a.w[i] = (const uint8_t *)w[i]; a.out[i] = out[i]; a.N[i] = N[i]; a.ldo[i] = ldo[i];
+  }
   switch (ggml_type) {
   case T_Q4_K: a.row_bytes = (size_t)(K / 256) * 144; return gemm_launch<T_Q4_K>(a, (hipStream_t)stream);
   case T_Q5_K: a.row_bytes = (size_t)(K / 256) * 176; return gemm_launch<T_Q5_K>(a, (hipStream_t)stream);
@@ -247,4 +308,12 @@ extern "C" int mrs_gemm_q_f32(const void *w, int ggml_type, int N, int K, const 
   case T_Q8_0: a.row_bytes = (size_t)(K / 32) * 34; return gemm_launch<T_Q8_0>(a, (hipStream_t)stream);
   default: return -1;
   }
+}
+
+// out[m*ldo + n] (+)= sum_k bf16(x[m*ldx + k]) * bf16(W[n][k]);  W: raw GGUF blocks [N][K/blk] of type q4_k / q5_k / q6_k / q8_0.
+// Returns 0, or -1 for an unsupported type / shape (K % 256 for the K-quants, K % 64 for Q8_0).
+extern "C" int mrs_gemm_q_f32(const void *w, int ggml_type, int N, int K, const float *x, int ldx, float *out, int ldo, int M, int accumulate,
+                              void *stream) {
+  if (N <= 0) return 0;
+  return mrs_gemm_q_f32_multi(1, &w, &N, &out, &ldo, ggml_type, K, x, ldx, M, accumulate, stream);
 }

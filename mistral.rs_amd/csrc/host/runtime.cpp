@@ -22,6 +22,7 @@
 #include <cmath>
 #include <cstring>
 #include <algorithm>
+#include <initializer_list>
 #include <memory>
 #include <string>
 #include <vector>
@@ -377,6 +378,23 @@ class Llama {
       if (mrs_gemm_q_f32(w->data, w->dtype, N, K, x, K, out, N, T, acc, s)) return fail("prefill: no GEMM for ggml dtype %d (K=%d)", w->dtype, K);
       return 0;
     };
+    // projections that share their input run as ONE launch per weight type (fast_mmq::fused_qkv / fused_glu role)
+    auto gemm_multi = [&](std::initializer_list<const GgufMatMul *> ms, const float *x, int K, std::initializer_list<float *> outs,
+                          std::initializer_list<int> Ns) -> int {
+      std::vector<const GgufMatMul *> m(ms);
+      std::vector<float *> o(outs);
+      std::vector<int> n(Ns);
+      std::vector<bool> done(m.size(), false);
+      for (size_t i = 0; i < m.size(); ++i) {
+        if (done[i]) continue;
+        const int ty = m[i]->get_qtensor()->dtype;
+        const void *w[3]; float *oo[3]; int nn[3], ld[3], c = 0;
+        for (size_t j = i; j < m.size(); ++j)
+          if (!done[j] && m[j]->get_qtensor()->dtype == ty) { w[c] = m[j]->get_qtensor()->data; oo[c] = o[j]; nn[c] = n[j]; ld[c] = n[j]; ++c; done[j] = true; }
+        if (mrs_gemm_q_f32_multi(c, w, nn, oo, ld, ty, K, x, K, T, 0, s)) return fail("prefill: no GEMM for ggml dtype %d (K=%d)", ty, K);
+      }
+      return 0;
+    };
     if (wte->embedding_forward_raw(pa.token_ids, T, h, s)) return -1;
     const int bs = cfg.block_size, kvh = cfg.num_kv_heads;
     const int eff_max = std::min(cfg.max_blocks_per_seq * bs, cfg.max_context_len);
@@ -387,7 +405,7 @@ class Llama {
       const Block &bl = blocks[li];
       if (!bl.q_proj || !bl.key_cache) return fail("layer %zu is incomplete", li);
       mrs_rms_norm_f32(h, bl.input_layernorm, xn, T, d, cfg.rms_eps, st);
-      if (gemm(*bl.q_proj, xn, d, q, nq, 0) || gemm(*bl.k_proj, xn, d, k, nkv, 0) || gemm(*bl.v_proj, xn, d, v, nkv, 0)) return -1;
+      if (gemm_multi({bl.q_proj.get(), bl.k_proj.get(), bl.v_proj.get()}, xn, d, {q, k, v}, {nq, nkv, nkv})) return -1;
       rotary_embedding_positions(q, k, (void *)bufs.cos_table, (void *)bufs.sin_table, (void *)pa.positions, cfg.rope_interleaved ? 0 : 1, hd, T,
                                  cfg.rot_dim / 2, cfg.max_context_len, cfg.num_heads, cfg.num_kv_heads, nq, nkv, 2, st);
       reshape_and_cache(k, v, bl.key_cache, bl.value_cache, (int64_t *)pa.slot_mapping, T, cfg.num_kv_heads, hd, bs, 8, nkv, nkv, s, 2, 1, nullptr, nullptr);
@@ -399,7 +417,7 @@ class Llama {
         if (gemm(*bl.o_proj, attn, nq, xn, d, 0) || all_reduce(xn, t * d, s) || mrs_vec_add_f32(h, xn, t * d, s)) return -1;
       } else if (gemm(*bl.o_proj, attn, nq, h, d, 1)) return -1;
       mrs_rms_norm_f32(h, bl.post_attention_layernorm, xn, T, d, cfg.rms_eps, st);
-      if (gemm(*bl.gate_proj, xn, d, g, ff, 0) || gemm(*bl.up_proj, xn, d, u, ff, 0)) return -1;
+      if (gemm_multi({bl.gate_proj.get(), bl.up_proj.get()}, xn, d, {g, u}, {ff, ff})) return -1;
       fused_glu_f32(g, u, act, (uint32_t)T, (uint32_t)ff, (uint32_t)ff, (uint32_t)ff, 0, s);
       if (cfg.world_size > 1) {
         if (gemm(*bl.down_proj, act, ff, xn, d, 0) || all_reduce(xn, t * d, s) || mrs_vec_add_f32(h, xn, t * d, s)) return -1;
