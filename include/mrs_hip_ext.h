@@ -128,6 +128,12 @@ int mrs_llama_prefill(void *model, const mrs_llama_prefill_args *args, int T, vo
 double mrs_llama_prefill_flops(void *model, int T);
 /* bytes of weights + KV streamed from HBM by one decode step at the given context (roofline numerator) */
 double mrs_llama_decode_bytes(void *model, int b, int context_len);
+/* ---------------------------------------------------------------- in-situ quantization (ext_isq.hip)
+ * dense f32 (0) / f16 (1) / bf16 (30) weights [n_elements] -> GGML Q8_0 blocks (34 B per 32), the per-block rule of candle's
+ * QTensor::quantize(.., Q8_0) that `generate_isq!` runs on the CPU (mistralrs-quant/src/utils/isq.rs:323-361), on the device.
+ * Returns 0, -1 if n_elements % 32 != 0 or the dtype is unknown. */
+int mrs_isq_quantize_q8_0(const void *src, int src_dtype, void *dst, long long n_elements, void *stream);
+
 /* ---------------------------------------------------------------- RCCL over xGMI (ext_comm.hip), one process per GPU
  * replaces Comm::from_device / all_reduce(Sum) of mistralrs-quant/src/distributed/mod.rs:244-303,511-809 */
 int mrs_comm_unique_id(void *out128);                            /* rank 0: ncclGetUniqueId -> 128 bytes */

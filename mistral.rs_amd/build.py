@@ -50,7 +50,7 @@ def libraries():
     optional = {
         "libmistralrsquant.so": ["quant_ops.hip", "mmq.hip", "moe.hip", "hqq.hip"],
         "libmistralrscuda.so": ["core_ops.hip"],
-        "libmrs_hip_ext.so": ["ext_decode.hip", "ext_gemm.hip", "ext_attn_prefill.hip", "ext_comm.hip",
+        "libmrs_hip_ext.so": ["ext_decode.hip", "ext_gemm.hip", "ext_attn_prefill.hip", "ext_comm.hip", "ext_isq.hip",
                               "host/runtime.cpp"],
     }
     for lib, srcs in optional.items():
