@@ -266,22 +266,26 @@ __global__ void __launch_bounds__(NT) decode_gemv_kernel(const DecodeGemvArgs a)
 static bool hot_type(int t) { return t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_Q8_0; }
 
 template <int PRO, int EPI> struct DecodeLaunch {
-  static constexpr int NT = (EPI == EPI_GLU_Q8_1) ? 512 : 256;
+  // kernels with the RMSNorm+Q8_1 prologue pay it once per workgroup: fat workgroups (8 waves), about one per CU (measured:
+  // 224 x 512-thread workgroups for gate/up beat 448 by 0.14 ms per token); staged-Q8_1 kernels keep 4-wave workgroups
+  static constexpr int NT = (PRO == PRO_NORM) ? 512 : 256;
   template <int NCOLS> static int go(DecodeGemvArgs a, hipStream_t s) {
     const int total = (EPI == EPI_QKV_ROPE) ? a.nrows[0] + a.nrows[1] + a.nrows[2] : a.nrows[0];
     constexpr int NW = NT / 64;
     int per;
     if (EPI == EPI_GLU_Q8_1) {
-      per = 32 * ((total / 32 + 511) / 512);  // whole Q8_1 output blocks per workgroup, <= 512 workgroups
+      per = 32 * ((total / 32 + 255) / 256);  // whole Q8_1 output blocks per workgroup, <= 256 workgroups
+      { static int ov = -1; if (ov < 0) { const char *e = getenv("MRS_GLU_PER"); ov = e ? atoi(e) : 0; } if (ov > 0) per = ov; }
       if (per < 32) per = 32;
     } else if (EPI == EPI_QKV_ROPE) {
-      int ppw = (total / 2 + 4095) / 4096;  // RoPE pairs per wave
+      int ppw = (total / 2 + NW * 192 - 1) / (NW * 192);  // RoPE pairs per wave: <= 192 fat workgroups (measured optimum for 6144 rows)
       if (ppw < 1) ppw = 1;
+      { static int ov = -1; if (ov < 0) { const char *e = getenv("MRS_QKV_PPW"); ov = e ? atoi(e) : 0; } if (ov > 0) ppw = ov; }
       per = 2 * NW * ppw;
       while (per > 2 * NW && (a.nrows[0] % per || a.nrows[1] % per)) per -= 2 * NW;
       if (a.nrows[0] % per || a.nrows[1] % per) return -3;  // a workgroup must not straddle q/k/v
     } else {
-      int rpw = (total + 4095) / 4096;
+      int rpw = (PRO == PRO_NORM) ? (total + NW * 256 - 1) / (NW * 256) : (total + 4095) / 4096;
       if (rpw < 1) rpw = 1;
       if ((a.wtype[0] == T_Q4_K || a.wtype[0] == T_Q5_K) && (total & 1) == 0 && (rpw & 1)) ++rpw;  // paired rows
       per = NW * rpw;
