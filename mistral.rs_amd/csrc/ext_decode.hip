@@ -199,25 +199,44 @@ __global__ void __launch_bounds__(NT) decode_gemv_kernel(const DecodeGemvArgs a)
     const int first = row0 + wave * 2 * ppw;
     const int npairs = max(0, min(ppw, (row1 - first) / 2));
     auto rowptr = [&](int r, const uint8_t *&pA, const uint8_t *&pB) { pA = wm + (size_t)(r - base) * rb; pB = pA + rb; };
+    // epilogue operands are fetched up front (lane i <-> the wave's pair i) so that no dependent global load sits between the
+    // last dot product of a pair and its store: rotation (cos, sin) at this token's position and the cache slot
+    float pcs[NCOLS], psn[NCOLS];
+    {
+      const int lr_i = first - base + 2 * min(lane, max(npairs - 1, 0));
+      const int pair_i = (lr_i % a.head_dim) >> 1;
+      const bool rot = m < 2 && pair_i < a.rot_pairs;
+#pragma unroll
+      for (int c = 0; c < NCOLS; ++c) {
+        const size_t ti = (size_t)a.positions[c] * a.rot_pairs + (rot ? pair_i : 0);
+        const float cs = a.cos_t[ti], sn = a.sin_t[ti];
+        pcs[c] = rot ? cs : 1.0f;  // identity rotation for v and for unrotated dims (x*1 - y*0 = x exactly)
+        psn[c] = rot ? sn : 0.0f;
+      }
+    }
+    int64_t slots[NCOLS];
+#pragma unroll
+    for (int c = 0; c < NCOLS; ++c) slots[c] = m == 0 ? 0 : a.slot_mapping[c];
     auto epi = [&](int r, float(&acc)[2][NCOLS]) {
+      const int pi = (r - first) >> 1;  // wave-uniform
+      float cs[NCOLS], sn[NCOLS];
+#pragma unroll
+      for (int c = 0; c < NCOLS; ++c) {
+        cs[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pcs[c]), pi));
+        sn[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, psn[c]), pi));
+      }
       if (lane == 0) {
         const int lr = r - base;
-        const int head = lr / a.head_dim, d = lr % a.head_dim, pair = d >> 1;
+        const int head = lr / a.head_dim, d = lr % a.head_dim;
 #pragma unroll
         for (int c = 0; c < NCOLS; ++c) {
-          float x = acc[0][c], y = acc[1][c];
-          if (m < 2 && pair < a.rot_pairs) {
-            const size_t ti = (size_t)a.positions[c] * a.rot_pairs + pair;
-            const float cs = a.cos_t[ti], sn = a.sin_t[ti];
-            float xr, yr;
-            rope_pair<float>(x, y, cs, sn, xr, yr);
-            x = xr; y = yr;
-          }
+          float x, y;
+          rope_pair<float>(acc[0][c], acc[1][c], cs[c], sn[c], x, y);
           if (m == 0) {
             a.q_out[(size_t)c * a.nrows[0] + lr] = x;
             a.q_out[(size_t)c * a.nrows[0] + lr + 1] = y;
           } else {
-            const int64_t slot = a.slot_mapping[c];
+            const int64_t slot = slots[c];
             if (slot >= 0) {
               const int64_t blk = slot / a.block_size, off = slot % a.block_size;
               uint16_t *kc = (uint16_t *)a.k_cache, *vc = (uint16_t *)a.v_cache;
@@ -243,15 +262,30 @@ __global__ void __launch_bounds__(NT) decode_gemv_kernel(const DecodeGemvArgs a)
     const int first = row0 + wave * rpw;
     const int nrows = max(0, min(rpw, row1 - first));
     auto rowptr = [&](int r, const uint8_t *&pA, const uint8_t *&pB) { pA = a.w[0] + (size_t)r * rb; pB = pA + rb; };
-    auto put = [&](int r, const float(&v)[NCOLS]) {
+    // residual values are fetched up front (lane i <-> the wave's row i): no dependent load between a row's reduction and its store
+    float hold[NCOLS];
+#pragma unroll
+    for (int c = 0; c < NCOLS; ++c) hold[c] = 0.0f;
+    if constexpr (EPI == EPI_RESID_ADD) {
+      if (lane < nrows) {
+#pragma unroll
+        for (int c = 0; c < NCOLS; ++c) hold[c] = a.out[(size_t)c * a.out_stride + first + lane];
+      }
+    }
+    auto put = [&](int r, const float(&v)[NCOLS]) {  // called by every lane (readlane is wave-wide), lane 0 stores
 #pragma unroll
       for (int c = 0; c < NCOLS; ++c) {
         float *o = a.out + (size_t)c * a.out_stride + r;
-        if constexpr (EPI == EPI_RESID_ADD) *o = *o * a.resid_scale + v[c]; else *o = v[c];
+        if constexpr (EPI == EPI_RESID_ADD) {
+          const float old = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hold[c]), r - first));
+          if (lane == 0) *o = old * a.resid_scale + v[c];
+        } else {
+          if (lane == 0) *o = v[c];
+        }
       }
     };
-    auto epi = [&](int r, float(&acc)[1][NCOLS]) { if (lane == 0) put(r, acc[0]); };
-    auto epi2 = [&](int r, float(&acc)[2][NCOLS]) { if (lane == 0) { put(r, acc[0]); put(r + 1, acc[1]); } };
+    auto epi = [&](int r, float(&acc)[1][NCOLS]) { put(r, acc[0]); };
+    auto epi2 = [&](int r, float(&acc)[2][NCOLS]) { put(r, acc[0]); put(r + 1, acc[1]); };
     const bool pair_ok = ((rpw | a.nrows[0]) & 1) == 0;  // the host rounds rows-per-wave up to even for the paired-row formats
     MRS_HOT_TYPE_SWITCH(a.wtype[0],
       if constexpr (PairQ<TT>::value) {
@@ -268,7 +302,9 @@ static bool hot_type(int t) { return t == T_Q4_K || t == T_Q5_K || t == T_Q6_K |
 template <int PRO, int EPI> struct DecodeLaunch {
   // kernels with the RMSNorm+Q8_1 prologue pay it once per workgroup: fat workgroups (8 waves), about one per CU (measured:
   // 224 x 512-thread workgroups for gate/up beat 448 by 0.14 ms per token); staged-Q8_1 kernels keep 4-wave workgroups
-  static constexpr int NT = (PRO == PRO_NORM) ? 512 : 256;
+  // fat 8-wave workgroups, about one per CU: every workgroup pays the activation prologue (RMSNorm+Q8_1, or staging the Q8_1
+  // blocks) once, and measured decode time falls monotonically from 1024 x 4-wave to 256 x 8-wave workgroups (2.15 -> 2.09 ms)
+  static constexpr int NT = 512;
   template <int NCOLS> static int go(DecodeGemvArgs a, hipStream_t s) {
     const int total = (EPI == EPI_QKV_ROPE) ? a.nrows[0] + a.nrows[1] + a.nrows[2] : a.nrows[0];
     constexpr int NW = NT / 64;
@@ -280,13 +316,16 @@ template <int PRO, int EPI> struct DecodeLaunch {
     } else if (EPI == EPI_QKV_ROPE) {
       int ppw = (total / 2 + NW * 192 - 1) / (NW * 192);  // RoPE pairs per wave: <= 192 fat workgroups (measured optimum for 6144 rows)
       if (ppw < 1) ppw = 1;
+      if (ppw > 64) ppw = 64;  // epilogue operands are prefetched one pair per lane
       { static int ov = -1; if (ov < 0) { const char *e = getenv("MRS_QKV_PPW"); ov = e ? atoi(e) : 0; } if (ov > 0) ppw = ov; }
       per = 2 * NW * ppw;
       while (per > 2 * NW && (a.nrows[0] % per || a.nrows[1] % per)) per -= 2 * NW;
       if (a.nrows[0] % per || a.nrows[1] % per) return -3;  // a workgroup must not straddle q/k/v
     } else {
-      int rpw = (PRO == PRO_NORM) ? (total + NW * 256 - 1) / (NW * 256) : (total + 4095) / 4096;
+      static int tgt = 0; if (!tgt) { const char *e = getenv("MRS_PROJ_WGS"); tgt = e ? atoi(e) : 256; }
+      int rpw = (total + NW * tgt - 1) / (NW * tgt);
       if (rpw < 1) rpw = 1;
+      if (rpw > 64) rpw = 64;  // epilogue operands are prefetched one row per lane
       if ((a.wtype[0] == T_Q4_K || a.wtype[0] == T_Q5_K) && (total & 1) == 0 && (rpw & 1)) ++rpw;  // paired rows
       per = NW * rpw;
     }
