@@ -50,6 +50,19 @@ int mrs_sample_greedy_advance(const float *logits, int vocab, int b, int32_t *ne
                               int64_t *slot_mapping, const uint32_t *block_tables, int max_blocks, int block_size,
                               void *scratch, void *stream);
 
+/* ---------------------------------------------------------------- mixture of experts, decode (Mixtral: SparseMoeBlock::forward,
+ * mistralrs-core/src/models/mixtral.rs:280-304; router = moe_router_topk, ops.rs:259-336; expert GEMVs = the indexed kernels of
+ * mistralrs-quant/kernels/indexed_moe/indexed_moe.cu:892-1150).  Experts are stacked [E][N][K/blk] packed GGUF blocks
+ * (ffn_{gate,up,down}_exps); the expert id of a launch is read ON THE DEVICE (expert_sel), so a captured decode graph follows
+ * the routing of each new token.  One token per launch (b = 1). */
+int mrs_moe_router_topk(const float *x_normed, const float *gate_w /* f32 [E][K] */, int tokens, int n_experts, int K, int top_k,
+                        int renormalize, int32_t *ids /* [tokens][top_k] */, float *weights /* [tokens][top_k] */,
+                        float *logits_out /* optional [tokens][E] */, void *stream);
+int mrs_moe_decode_gate_up(const void *wg, const void *wu, size_t expert_stride_bytes, const int32_t *expert_sel, int type, int n, int K,
+                           const float *h, const float *norm_w, float eps, int activation, void *y_out, int y_out_stride, void *stream);
+int mrs_moe_decode_down(const void *w, size_t expert_stride_bytes, const int32_t *expert_sel, const float *topk_weight, int type, int n, int K,
+                        const void *y_q8_1, int stride_col_y, float *out, void *stream);
+
 /* ---------------------------------------------------------------- prefill GEMM (ext_gemm.hip)
  * out[m*ldo + n] (+)= sum_k bf16(x[m*ldx + k]) * bf16(dequant(W)[n][k]),  f32 accumulate on the bf16 matrix cores.
  * W: raw GGUF blocks [N][K/blk] (q4_k q5_k q6_k q8_0); x f32 [M][ldx]; role of fast_mmq::{plain,fused_qkv,fused_glu,fused_ffn}

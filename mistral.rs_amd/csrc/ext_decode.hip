@@ -49,6 +49,11 @@ struct DecodeGemvArgs {
   int head_dim, rot_pairs, num_kv_heads, block_size, cache_x;
   int rows_per_wg;
   float resid_scale;      // RESID_ADD: out = out * resid_scale + W.y  (1 = plain residual add; 1/world under tensor parallelism)
+  // mixture of experts (stacked expert weights [E][N][K/blk], models/mixtral.rs:236-304): the expert of this launch is read on the
+  // device, so a captured graph replays with new routing; acc_scale (the renormalised top-k weight) multiplies W.y in RESID_ADD
+  const int32_t *expert_sel;  // nullptr = dense layer
+  size_t expert_stride;       // bytes between experts
+  const float *acc_scale;     // nullptr = 1
 };
 
 // fixed-order block reduction shared by the fused prologue and the standalone norm+quantize kernel
@@ -160,13 +165,14 @@ __global__ void __launch_bounds__(NT) decode_gemv_kernel(const DecodeGemvArgs a)
   const int total_rows = (EPI == EPI_QKV_ROPE) ? a.nrows[0] + a.nrows[1] + a.nrows[2] : a.nrows[0];
   const int row0 = blockIdx.x * a.rows_per_wg;
   const int row1 = min(row0 + a.rows_per_wg, total_rows);
+  const size_t eoff = a.expert_sel ? (size_t)(*a.expert_sel) * a.expert_stride : 0;  // wave-uniform scalar load
 
   if constexpr (EPI == EPI_GLU_Q8_1) {
     const size_t rb = hot_row_bytes(a.wtype[0], K);
     const int rpw = a.rows_per_wg / NW;
     const int first = row0 + wave * rpw;
     const int nrows = max(0, min(rpw, row1 - first));
-    auto rowptr = [&](int r, const uint8_t *&pA, const uint8_t *&pB) { pA = a.w[0] + (size_t)r * rb; pB = a.w[1] + (size_t)r * rb; };
+    auto rowptr = [&](int r, const uint8_t *&pA, const uint8_t *&pB) { pA = a.w[0] + eoff + (size_t)r * rb; pB = a.w[1] + eoff + (size_t)r * rb; };
     auto epi = [&](int r, float(&acc)[2][NCOLS]) {
       if (lane == 0) {
 #pragma unroll
@@ -261,7 +267,8 @@ __global__ void __launch_bounds__(NT) decode_gemv_kernel(const DecodeGemvArgs a)
     const int rpw = a.rows_per_wg / NW;
     const int first = row0 + wave * rpw;
     const int nrows = max(0, min(rpw, row1 - first));
-    auto rowptr = [&](int r, const uint8_t *&pA, const uint8_t *&pB) { pA = a.w[0] + (size_t)r * rb; pB = pA + rb; };
+    auto rowptr = [&](int r, const uint8_t *&pA, const uint8_t *&pB) { pA = a.w[0] + eoff + (size_t)r * rb; pB = pA + rb; };
+    const float ascale = a.acc_scale ? *a.acc_scale : 1.0f;
     // residual values are fetched up front (lane i <-> the wave's row i): no dependent load between a row's reduction and its store
     float hold[NCOLS];
 #pragma unroll
@@ -278,7 +285,7 @@ __global__ void __launch_bounds__(NT) decode_gemv_kernel(const DecodeGemvArgs a)
         float *o = a.out + (size_t)c * a.out_stride + r;
         if constexpr (EPI == EPI_RESID_ADD) {
           const float old = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hold[c]), r - first));
-          if (lane == 0) *o = old * a.resid_scale + v[c];
+          if (lane == 0) *o = old * a.resid_scale + v[c] * ascale;  // ascale == 1 outside MoE: bit-identical to the dense path
         } else {
           if (lane == 0) *o = v[c];
         }
@@ -490,6 +497,74 @@ extern "C" int mrs_decode_proj_scaled(const void *w, int type, int n, int K, con
   a.w[0] = (const uint8_t *)w; a.wtype[0] = type; a.nrows[0] = n; a.K = K; a.y_q8_1 = (const uint8_t *)y_q8_1;
   a.stride_col_y = stride_col_y; a.out = out; a.out_stride = out_stride; a.resid_scale = resid_scale;
   return DecodeLaunch<PRO_Q8_1, EPI_RESID_ADD>::run(a, b, (hipStream_t)stream);
+}
+
+// ---- mixture of experts, decode (b = 1 token per launch; the reference's indexed GEMV: kernels/indexed_moe/indexed_moe.cu:892-1150,
+//      moe_gemv_fused_gate_up / moe_gemv_down_aggregate) -- same GEMV kernels, expert chosen on the device
+extern "C" int mrs_moe_decode_gate_up(const void *wg, const void *wu, size_t expert_stride_bytes, const int32_t *expert_sel, int type, int n, int K,
+                                      const float *h, const float *norm_w, float eps, int activation, void *y_out, int y_out_stride, void *stream) {
+  if (!hot_type(type) || n % 32 || !expert_sel) return -1;
+  DecodeGemvArgs a{};
+  a.w[0] = (const uint8_t *)wg; a.w[1] = (const uint8_t *)wu; a.wtype[0] = a.wtype[1] = type; a.nrows[0] = n; a.K = K;
+  a.x = h; a.norm_w = norm_w; a.eps = eps; a.activation = activation; a.y_out = (uint8_t *)y_out; a.y_out_stride = y_out_stride;
+  a.expert_sel = expert_sel; a.expert_stride = expert_stride_bytes;
+  return DecodeLaunch<PRO_NORM, EPI_GLU_Q8_1>::run(a, 1, (hipStream_t)stream);
+}
+// out += topk_weight * (W_down[expert] . y)
+extern "C" int mrs_moe_decode_down(const void *w, size_t expert_stride_bytes, const int32_t *expert_sel, const float *topk_weight, int type, int n, int K,
+                                   const void *y_q8_1, int stride_col_y, float *out, void *stream) {
+  if (!hot_type(type) || !expert_sel) return -1;
+  DecodeGemvArgs a{};
+  a.w[0] = (const uint8_t *)w; a.wtype[0] = type; a.nrows[0] = n; a.K = K; a.y_q8_1 = (const uint8_t *)y_q8_1; a.stride_col_y = stride_col_y;
+  a.out = out; a.out_stride = n; a.resid_scale = 1.0f; a.expert_sel = expert_sel; a.expert_stride = expert_stride_bytes; a.acc_scale = topk_weight;
+  return DecodeLaunch<PRO_Q8_1, EPI_RESID_ADD>::run(a, 1, (hipStream_t)stream);
+}
+
+namespace mrs {
+// router: logits = gate_w [E][K] (f32) . x [K]; softmax over all experts -> top-k -> renormalise (moe_router_topk, ops.rs:259-336,
+// Mixtral settings: models/mixtral.rs:286-300).  One workgroup per token, wave e computes logit e (E <= 16 waves ... loops otherwise).
+__global__ void __launch_bounds__(256) moe_router_kernel(const float *__restrict__ x, const float *__restrict__ gate_w, int E, int K, int top_k,
+                                                         int renormalize, int32_t *__restrict__ ids, float *__restrict__ weights, float *__restrict__ logits_out) {
+  __shared__ float lg[512];
+  const int tok = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float *xr = x + (size_t)tok * K;
+  for (int e = wave; e < E; e += 4) {
+    float s = 0.f;
+    for (int i = lane * 4; i < K; i += 256) {
+      const float4 a4 = *(const float4 *)(xr + i), w4 = *(const float4 *)(gate_w + (size_t)e * K + i);
+      s = fmaf(a4.x, w4.x, s); s = fmaf(a4.y, w4.y, s); s = fmaf(a4.z, w4.z, s); s = fmaf(a4.w, w4.w, s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) lg[e] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {  // E is tiny (8 for Mixtral): serial softmax / top-k, ties -> lower index (candle topk order)
+    float mx = -INFINITY;
+    for (int e = 0; e < E; ++e) mx = fmaxf(mx, lg[e]);
+    float den = 0.f;
+    for (int e = 0; e < E; ++e) den += expf(lg[e] - mx);
+    float sel = 0.f;
+    unsigned long long used = 0;
+    for (int k = 0; k < top_k; ++k) {
+      int best = -1; float bv = -INFINITY;
+      for (int e = 0; e < E; ++e) if (!((used >> e) & 1ull) && lg[e] > bv) { bv = lg[e]; best = e; }
+      used |= 1ull << best;
+      const float p = expf(bv - mx) / den;
+      ids[(size_t)tok * top_k + k] = best;
+      weights[(size_t)tok * top_k + k] = p;
+      sel += p;
+    }
+    if (renormalize) for (int k = 0; k < top_k; ++k) weights[(size_t)tok * top_k + k] /= sel;
+    if (logits_out) for (int e = 0; e < E; ++e) logits_out[(size_t)tok * E + e] = lg[e];
+  }
+}
+}  // namespace mrs
+extern "C" int mrs_moe_router_topk(const float *x, const float *gate_w, int tokens, int n_experts, int K, int top_k, int renormalize, int32_t *ids,
+                                   float *weights, float *logits_out, void *stream) {
+  if (tokens <= 0) return 0;
+  if (n_experts < 1 || n_experts > 64 || top_k < 1 || top_k > n_experts || (K & 3)) return -1;
+  hipLaunchKernelGGL(mrs::moe_router_kernel, dim3(tokens), dim3(256), 0, (hipStream_t)stream, x, gate_w, n_experts, K, top_k, renormalize, ids, weights, logits_out);
+  return 0;
 }
 
 namespace mrs {
