@@ -74,6 +74,14 @@ int mrs_gemm_q_f32(const void *w, int ggml_type, int N, int K, const float *x, i
 int mrs_gemm_q_f32_multi(int nseg, const void *const *w, const int *N, float *const *out, const int *ldo, int ggml_type, int K,
                          const float *x, int ldx, int M, int accumulate, void *stream);
 
+/* ---------------------------------------------------------------- causal prompt attention (ext_attn_prefill.hip)
+ * softmax(scale * Q K^T + causal) V on the bf16 matrix cores with K / V read straight from the paged cache (the chunk has been
+ * scattered with reshape_and_cache first); role of Sdpa::run_attention in the prompt branch of PagedAttention::forward
+ * (attention/mod.rs:254-372, paged_attention.rs:1413-1475).  head_size 128, block_size 32, bf16 cache; -1 otherwise. */
+int mrs_prefill_attention_f32_bf16(const float *q, const void *key_cache, const void *value_cache, const uint32_t *block_table, float *out,
+                                   int T, int start_pos, int num_heads, int num_kv_heads, int head_size, int block_size, int q_stride,
+                                   int o_stride, int kv_block_stride, int kv_head_stride, float scale, void *stream);
+
 /* ---------------------------------------------------------------- host-side model runner (host/runtime.cpp)
  * C++ mirror of mistralrs-core/src/models/llama.rs (Llama / CausalSelfAttention / Mlp / Block) on top of
  * QuantMethod objects (mistralrs-quant/src/lib.rs:1515-1688, gguf/mod.rs GgufMatMul), exposed through handles. */
@@ -132,6 +140,7 @@ typedef struct {
   const uint32_t *block_tables; /* [T, max_blocks_per_seq] */
   const uint32_t *context_lens; /* [T] */
   float *logits;                /* [vocab] logits of the last prompt token */
+  int32_t start_pos;            /* position of the first prompt token (= positions[0]) */
   void *workspace;              /* >= mrs_llama_prefill_workspace_bytes(cfg, T) */
   size_t workspace_bytes;
 } mrs_llama_prefill_args;

@@ -362,6 +362,7 @@ class Llama {
   }
   int prefill(const mrs_llama_prefill_args &pa, int T, hipStream_t s) const {
     if (T <= 0) return fail("prefill: T must be positive");
+    const int start_pos = pa.start_pos;
     if (!wte || !lm_head || !ln_f) return fail("model is missing token_embd / output / output_norm");
     if (pa.workspace_bytes < prefill_workspace_bytes(cfg, T)) return fail("prefill workspace too small");
     const int d = cfg.hidden_size, hd = cfg.head_dim, nq = cfg.num_heads * hd, nkv = cfg.num_kv_heads * hd, ff = cfg.intermediate_size;
@@ -409,7 +410,10 @@ class Llama {
       rotary_embedding_positions(q, k, (void *)bufs.cos_table, (void *)bufs.sin_table, (void *)pa.positions, cfg.rope_interleaved ? 0 : 1, hd, T,
                                  cfg.rot_dim / 2, cfg.max_context_len, cfg.num_heads, cfg.num_kv_heads, nq, nkv, 2, st);
       reshape_and_cache(k, v, bl.key_cache, bl.value_cache, (int64_t *)pa.slot_mapping, T, cfg.num_kv_heads, hd, bs, 8, nkv, nkv, s, 2, 1, nullptr, nullptr);
-      // causal attention: prompt token t = "sequence" t reading the pages just written, context_lens[t] = pos + 1
+      // causal attention over the pages just written: MFMA flash kernel (head_dim 128 / block 32), else prompt token t = "sequence" t
+      // of the decode-style kernel with context_lens[t] = pos + 1
+      if (mrs_prefill_attention_f32_bf16(q, bl.key_cache, bl.value_cache, pa.block_tables, attn, T, start_pos, cfg.num_heads, kvh, hd, bs, nq, nq,
+                                         kvh * hd * bs, hd * bs, 1.0f / sqrtf((float)hd), s) != 0)
       mrs_paged_attention_f32_bf16(0, attn, nullptr, nullptr, nullptr, q, bl.key_cache, bl.value_cache, nullptr, kvh, 1.0f / sqrtf((float)hd), 1.0f,
                                    pa.block_tables, pa.context_lens, bs, eff_max, T, cfg.num_heads, hd, cfg.max_blocks_per_seq, nq, kvh * hd * bs,
                                    hd * bs, s, nullptr);

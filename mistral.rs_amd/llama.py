@@ -98,7 +98,8 @@ class _Cfg(C.Structure):
 
 class _PrefillArgs(C.Structure):
     _fields_ = [("token_ids", C.c_void_p), ("positions", C.c_void_p), ("slot_mapping", C.c_void_p), ("block_tables", C.c_void_p),
-                ("context_lens", C.c_void_p), ("logits", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+                ("context_lens", C.c_void_p), ("logits", C.c_void_p), ("start_pos", C.c_int32), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_size_t)]
 
 
 class _Bufs(C.Structure):
@@ -269,7 +270,7 @@ class Llama:
         if getattr(self, "_prefill_ws", None) is None or self._prefill_ws.numel() < need:
             self._prefill_ws = torch.empty(need, dtype=torch.uint8, device=dev)
         out = torch.empty(cfg.vocab_size, dtype=torch.float32, device=dev)
-        a = _PrefillArgs(ids.data_ptr(), pos.data_ptr(), slots.data_ptr(), bts.data_ptr(), ctx.data_ptr(), out.data_ptr(),
+        a = _PrefillArgs(ids.data_ptr(), pos.data_ptr(), slots.data_ptr(), bts.data_ptr(), ctx.data_ptr(), out.data_ptr(), start_pos,
                          self._prefill_ws.data_ptr(), self._prefill_ws.numel())
         self._chk(self._L.mrs_llama_prefill(self._h, C.byref(a), T, self._stream()))
         self._prefill_keep = (ids, pos, slots, bts, ctx)  # keep alive until the stream has consumed them

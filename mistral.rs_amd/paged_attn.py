@@ -207,3 +207,24 @@ def decode_attention_q8_1(q: torch.Tensor, key_cache: torch.Tensor, value_cache:
     if rc != 0:
         raise ValueError("decode_attention_q8_1: unsupported shape (block_size 32, head_size 64/128)")
     return y, stride_blocks
+
+
+def prefill_attention(q: torch.Tensor, key_cache: torch.Tensor, value_cache: torch.Tensor, block_table: torch.Tensor, start_pos: int,
+                      softmax_scale: float) -> torch.Tensor:
+    """Causal prompt attention on the matrix cores (mrs_prefill_attention_f32_bf16): f32 q [T, heads, hd] at positions
+    start_pos .. start_pos+T-1 over the bf16 paged cache of ONE sequence (block_table [max_blocks] int32; keys 0 .. start_pos+T-1
+    already scattered with reshape_and_cache) -> f32 [T, heads, hd].  Role of Sdpa::run_attention in the prompt branch of
+    PagedAttention::forward (paged_attention.rs:1413-1475).  Raises ValueError for shapes the kernel refuses."""
+    if q.dtype != torch.float32 or key_cache.dtype != torch.bfloat16 or q.dim() != 3 or not q.is_contiguous():
+        raise ValueError("prefill_attention: contiguous f32 query [T, heads, hd] over a bf16 cache")
+    T, num_heads, head_size = q.shape
+    nb, kvh, hs_x, block_size, x = key_cache.shape
+    if block_table.dim() != 1 or block_table.numel() * block_size < start_pos + T:
+        raise ValueError("prefill_attention: block_table does not cover start_pos + T tokens")
+    out = torch.empty_like(q)
+    fn = _lib.sym("ext", "mrs_prefill_attention_f32_bf16", [_vp] * 5 + [_i] * 10 + [_f, _vp], _i)
+    rc = fn(q.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(), block_table.data_ptr(), out.data_ptr(), T, start_pos, num_heads, kvh,
+            head_size, block_size, q.stride(0), out.stride(0), key_cache.stride(0), key_cache.stride(1), softmax_scale, _stream())
+    if rc != 0:
+        raise ValueError("prefill_attention: unsupported shape (bf16 cache, block_size 32, head_size 128, heads/kv_heads in 1/2/4/8)")
+    return out

@@ -203,3 +203,41 @@ def test_decode_attention_q8_1(oracle, dev, heads, kvh, hd):
     bad = err > tol
     assert np.isfinite(got).all() and not bad.any(), (f"{int(bad.sum())} outside tolerance; worst excess {float((err - tol).max()):.3e} at seq "
                                                         f"{np.argwhere(bad)[:4].tolist()} err {err[bad][:4]} tol {tol[bad][:4]} d {dfull[bad][:4]}")
+
+
+@pytest.mark.parametrize("heads,kvh", [(32, 8), (8, 8), (16, 2), (8, 1)])
+@pytest.mark.parametrize("T,start", [(1, 0), (31, 0), (70, 0), (64, 45), (200, 333)])
+def test_prefill_attention(oracle, dev, heads, kvh, T, start):
+    """MFMA prompt attention over the paged cache vs the oracle (token t = a sequence of context start+t+1 on the same block
+    table): q and p rounded to bf16 as the reference's bf16 attention does; stale slots after the sequence end hold NaN."""
+    import torch
+    from mistralrs_amd import paged_attn
+    hd, bs = 128, 32
+    rng = np.random.default_rng(heads * 7 + kvh + T * 13 + start)
+    total = start + T
+    max_blocks = (total + bs - 1) // bs + 1
+    nb = max_blocks + 5
+    kc, vc, kct, vct = _mk_cache(rng, dev, "bf16", nb, kvh, hd, bs)
+    bt1 = rng.permutation(nb)[:max_blocks].astype(np.int32)
+    if total % bs:
+        vc[bt1[total // bs], :, :, total % bs:] = np.nan
+    vc[bt1[total // bs + 1:]] = np.nan
+    vct = torch.from_numpy(vc).to(dev).to(torch.bfloat16)
+    q = (rng.standard_normal((T, heads, hd)) * 2.0).astype(np.float32)
+    got = paged_attn.prefill_attention(torch.from_numpy(q).to(dev), kct, vct, torch.from_numpy(bt1).to(dev), start, 1.0 / np.sqrt(hd)).cpu().numpy()
+    ctxs = [start + t + 1 for t in range(T)]
+    bt = np.tile(bt1, (T, 1))
+    vz = np.nan_to_num(vc, nan=0.0)
+    qb = round_through(q, "bf16")
+    want = oracle.paged_attention_ref(qb, kc, vz, bt, ctxs, 1.0 / np.sqrt(hd), 1.0, None, None, round_p=lambda p: round_through(p, "bf16"))
+    pabs = oracle.paged_attention_ref(qb, kc, np.abs(vz), bt, ctxs, 1.0 / np.sqrt(hd), 1.0, None, None)
+    # kernel rounds the un-normalised p to bf16, the oracle the normalised p: each within 2^-8 relative (half an ulp of 8 significant
+    # bits), so the outputs differ by at most 2^-7 * sum_t p_t |v_t|
+    tol = 2.0 ** -7 * pabs + 1e-4 * np.abs(vz).max()
+    err = np.abs(got - want.reshape(got.shape))
+    tol = tol.reshape(got.shape)
+    bad = np.argwhere(err > tol)
+    assert np.isfinite(got).all() and len(bad) == 0, (f"{len(bad)} outside tolerance, first {bad[:6].tolist()} err {err[err > tol][:6]} "
+                                                       f"tol {tol[err > tol][:6]} got {got[err > tol][:6]}")
+    with pytest.raises(ValueError, match="block_table"):
+        paged_attn.prefill_attention(torch.from_numpy(q).to(dev), kct, vct, torch.from_numpy(bt1[:1]).to(dev), start + 64, 1.0)
