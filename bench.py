@@ -238,7 +238,7 @@ def main():
         "prefill_tokens_per_sec": round(a.prompt_len / ttft, 1), "ttft_ms": round(1e3 * ttft, 2),
         "prefill_roofline": {"bound": "mfma", "achieved": round(prefill_flops / ttft / 1e12, 1), "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s",
                              "frac": round(prefill_flops / ttft / MFMA_PEAK, 4), "flops": prefill_flops,
-                             "note": "fused block-dequant -> bf16 MFMA GEMMs (mrs_gemm_q_f32), whole prompt incl. attention and the host read-back of the first token"},
+                             "note": "fused block-dequant -> bf16 MFMA GEMMs (mrs_gemm_q_bf16_multi) + MFMA flash attention over the paged cache; whole prompt incl. the host read-back of the first token"},
         "device_ms_per_step": round(1e3 * dev_s / a.steps, 4),
         "step_bytes": int(step_bytes), "step_roofline_frac": round(step_bytes * (a.steps / t_all) / HBM_PEAK, 4),
         "roofline": {"bound": "hbm", "kernel": "decode_gemv_kernel<1, PRO_NORM, EPI_GLU_Q8_1> (fused RMSNorm+Q8_1+gate/up GEMV+SiLU*mul+Q8_1)",

@@ -74,6 +74,17 @@ int mrs_gemm_q_f32(const void *w, int ggml_type, int N, int K, const float *x, i
 int mrs_gemm_q_f32_multi(int nseg, const void *const *w, const int *N, float *const *out, const int *ldo, int ggml_type, int K,
                          const float *x, int ldx, int M, int accumulate, void *stream);
 
+/* Large-M variant (M > 128 is where it pays): bf16 activations in k-slab-major layout x[K/64][M][64] (written once per GEMM group by
+ * mrs_convert_f32_bf16_slabs: the A tile of a k-step is then one contiguous block instead of 256 rows 2*K bytes apart on the same L2
+ * channels), 256 x 128 x 64 tiles with 8 waves, split-K through `workspace` (f32 partials, summed in a fixed order) when the shape
+ * has fewer tiles than CUs.  workspace may be NULL (no split); mrs_gemm_q_bf16_workspace_bytes(M) always suffices.
+ * Same arithmetic as mrs_gemm_q_f32 except for the f32 summation order across k. */
+int mrs_gemm_q_bf16_multi(int nseg, const void *const *w, const int *N, float *const *out, const int *ldo, int ggml_type, int K,
+                          const void *x_slabs, int M, int accumulate, void *workspace, size_t workspace_bytes, void *stream);
+size_t mrs_gemm_q_bf16_workspace_bytes(int M);
+/* x f32 [M][ldx] -> bf16 (round to nearest even) slabs y[K/64][M][64]; K % 64 == 0, ldx % 4 == 0 */
+int mrs_convert_f32_bf16_slabs(const float *x, int ldx, int M, int K, void *y, void *stream);
+
 /* ---------------------------------------------------------------- causal prompt attention (ext_attn_prefill.hip)
  * softmax(scale * Q K^T + causal) V on the bf16 matrix cores with K / V read straight from the paged cache (the chunk has been
  * scattered with reshape_and_cache first); role of Sdpa::run_attention in the prompt branch of PagedAttention::forward

@@ -358,6 +358,7 @@ class Llama {
     b += align(t * nkv * 4) * 2;      // k, v
     b += align(t * ff * 4) * 3;       // gate, up, act
     b += align((pad_to((int)d, MATRIX_ROW_PADDING) / 32) * 36);  // Q8_1 scratch of the last-token lm_head GEMV
+    if (T > 128) b += align(t * std::max(std::max(d, nq), ff) * 2) + align(mrs_gemm_q_bf16_workspace_bytes(T));  // bf16 activations + split-K partials
     return b + 4096;
   }
   int prefill(const mrs_llama_prefill_args &pa, int T, hipStream_t s) const {
@@ -374,9 +375,25 @@ class Llama {
     float *k = (float *)take(t * nkv * 4), *v = (float *)take(t * nkv * 4);
     float *g = (float *)take(t * ff * 4), *u = (float *)take(t * ff * 4), *act = (float *)take(t * ff * 4);
     const int64_t st = (int64_t)(intptr_t)s;
+    // T > 128: the 256-row-tile kernel over bf16 activations (converted once per GEMM group), split-K partials in `part`
+    const bool big = T > 128 && !getenv("MRS_PREFILL_SMALL_TILES");
+    const size_t part_bytes = big ? mrs_gemm_q_bf16_workspace_bytes(T) : 0;
+    void *xb = big ? take(t * std::max(std::max(d, nq), ff) * 2) : nullptr, *part = big ? take(part_bytes) : nullptr;
+    const float *xb_src = nullptr;  // which f32 buffer xb currently mirrors
+    auto to_bf16 = [&](const float *x, int K) -> int {
+      if (xb_src == x) return 0;
+      xb_src = x;
+      return mrs_convert_f32_bf16_slabs(x, K, T, K, xb, s);
+    };
     auto gemm = [&](const GgufMatMul &m, const float *x, int K, float *out, int N, int acc) -> int {
       const QTensor *w = m.get_qtensor();
-      if (mrs_gemm_q_f32(w->data, w->dtype, N, K, x, K, out, N, T, acc, s)) return fail("prefill: no GEMM for ggml dtype %d (K=%d)", w->dtype, K);
+      int rc;
+      if (big) {
+        xb_src = nullptr;
+        rc = to_bf16(x, K) || mrs_gemm_q_bf16_multi(1, &w->data, &N, &out, &N, w->dtype, K, xb, T, acc, part, part_bytes, s);
+        xb_src = nullptr;
+      } else rc = mrs_gemm_q_f32(w->data, w->dtype, N, K, x, K, out, N, T, acc, s);
+      if (rc) return fail("prefill: no GEMM for ggml dtype %d (K=%d)", w->dtype, K);
       return 0;
     };
     // projections that share their input run as ONE launch per weight type (fast_mmq::fused_qkv / fused_glu role)
@@ -386,14 +403,18 @@ class Llama {
       std::vector<float *> o(outs);
       std::vector<int> n(Ns);
       std::vector<bool> done(m.size(), false);
+      xb_src = nullptr;
       for (size_t i = 0; i < m.size(); ++i) {
         if (done[i]) continue;
         const int ty = m[i]->get_qtensor()->dtype;
         const void *w[3]; float *oo[3]; int nn[3], ld[3], c = 0;
         for (size_t j = i; j < m.size(); ++j)
           if (!done[j] && m[j]->get_qtensor()->dtype == ty) { w[c] = m[j]->get_qtensor()->data; oo[c] = o[j]; nn[c] = n[j]; ld[c] = n[j]; ++c; done[j] = true; }
-        if (mrs_gemm_q_f32_multi(c, w, nn, oo, ld, ty, K, x, K, T, 0, s)) return fail("prefill: no GEMM for ggml dtype %d (K=%d)", ty, K);
+        const int rc = big ? (to_bf16(x, K) || mrs_gemm_q_bf16_multi(c, w, nn, oo, ld, ty, K, xb, T, 0, part, part_bytes, s))
+                           : mrs_gemm_q_f32_multi(c, w, nn, oo, ld, ty, K, x, K, T, 0, s);
+        if (rc) return fail("prefill: no GEMM for ggml dtype %d (K=%d)", ty, K);
       }
+      xb_src = nullptr;
       return 0;
     };
     if (wte->embedding_forward_raw(pa.token_ids, T, h, s)) return -1;

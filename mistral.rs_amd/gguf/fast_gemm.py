@@ -36,3 +36,53 @@ def plain(w: QTensor, xs: torch.Tensor, out: torch.Tensor | None = None, accumul
     if rc != 0:
         raise ValueError(f"fast_gemm: unsupported shape K={k} for {w.dtype.name}")
     return out.reshape(*xs.shape[:-1], n)
+
+
+def to_slabs(xs: torch.Tensor) -> torch.Tensor:
+    """f32 [M, K] -> bf16 slabs [K/64, M, 64] (mrs_convert_f32_bf16_slabs): the activation layout of `plain_bf16`."""
+    if xs.dtype != torch.float32 or not xs.is_cuda or xs.dim() != 2 or xs.stride(1) != 1:
+        raise ValueError("fast_gemm.to_slabs: f32 GPU matrix [M, K] with unit inner stride")
+    m, k = xs.shape
+    y = torch.empty(max(k // 64, 1), m, 64, dtype=torch.bfloat16, device=xs.device)
+    _lib.load("quant"); _lib.load("paged_attn"); _lib.load("core")
+    fn = _lib.sym("ext", "mrs_convert_f32_bf16_slabs", [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p], C.c_int)
+    if fn(xs.data_ptr(), xs.stride(0), m, k, y.data_ptr(), torch.cuda.current_stream().cuda_stream):
+        raise ValueError("fast_gemm.to_slabs: K must be a multiple of 64 and the row stride a multiple of 4")
+    return y
+
+
+def plain_bf16(w: QTensor, xs: torch.Tensor, out: torch.Tensor | None = None, accumulate: bool = False, split_k: bool = True,
+               workspace: torch.Tensor | None = None) -> torch.Tensor:
+    """Large-M path (mrs_gemm_q_bf16_multi): the activations are rounded to bf16 ONCE into k-slab-major layout (`to_slabs`; pass its
+    result to reuse it across weights), 256-row tiles, split-K partials when the shape has fewer tiles than CUs.  Same values as
+    `plain` up to f32 summation order.  Returns f32 [M, N]."""
+    if not supports(w.dtype):
+        raise ValueError(f"fast_gemm: unsupported quant dtype {w.dtype!r}")
+    if not xs.is_cuda or xs.dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("fast_gemm: input must be an f32 GPU matrix or the bf16 slabs of to_slabs()")
+    n, k = w.shape
+    if xs.dtype == torch.float32:
+        if xs.shape[-1] != k:
+            raise ValueError(f"fast_gemm: shape mismatch: weight [{n}, {k}] vs input tail {xs.shape[-1]}")
+        slabs = to_slabs(xs.reshape(-1, k).contiguous())
+    else:
+        if xs.dim() != 3 or xs.shape[2] != 64 or xs.shape[0] * 64 != k or not xs.is_contiguous():
+            raise ValueError(f"fast_gemm: shape mismatch: weight [{n}, {k}] vs slabs {tuple(xs.shape)}")
+        slabs = xs
+    m = slabs.shape[1]
+    st = torch.cuda.current_stream().cuda_stream
+    if out is None:
+        out = torch.empty(m, n, dtype=torch.float32, device=xs.device)
+        accumulate = False
+    wsb = _lib.sym("ext", "mrs_gemm_q_bf16_workspace_bytes", [C.c_int], C.c_size_t)(m) if split_k else 0
+    own = workspace is None or workspace.numel() * workspace.element_size() < wsb
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=xs.device) if own else workspace
+    wp, np_, op, ld = (C.c_void_p * 1)(w.data.data_ptr()), (C.c_int * 1)(n), (C.c_void_p * 1)(out.data_ptr()), (C.c_int * 1)(out.stride(0))
+    fn = _lib.sym("ext", "mrs_gemm_q_bf16_multi", [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                                   C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p], C.c_int)
+    rc = fn(1, wp, np_, op, ld, w.dtype.id, k, slabs.data_ptr(), m, int(accumulate), ws.data_ptr() if split_k else None, wsb, st)
+    if rc != 0:
+        raise ValueError(f"fast_gemm: unsupported shape K={k} for {w.dtype.name}")
+    if own or slabs is not xs:
+        torch.cuda.current_stream().synchronize()  # workspace / slabs stay alive until the launch ran
+    return out

@@ -9,6 +9,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--t", type=int, default=512)
     ap.add_argument("--types", default="q4_k,q6_k")
+    ap.add_argument("--big", action="store_true", help="256-row-tile kernel over bf16 activations (mrs_gemm_q_bf16_multi)")
     a = ap.parse_args()
     import torch
     import mistralrs_amd  # noqa: F401
@@ -21,13 +22,16 @@ def main():
             w = random_qtensor(tags[tag], n, k, dev, 5)
             x = torch.randn(a.t, k, device=dev)
             out = torch.empty(a.t, n, device=dev)
-            fast_gemm.plain(w, x, out=out)
+            ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+            xb = fast_gemm.to_slabs(x) if a.big else None
+            run = (lambda: fast_gemm.plain_bf16(w, xb, out=out, workspace=ws)) if a.big else (lambda: fast_gemm.plain(w, x, out=out))
+            run()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             reps = 10
             e0.record()
             for _ in range(reps):
-                fast_gemm.plain(w, x, out=out)
+                run()
             e1.record(); torch.cuda.synchronize()
             t = e0.elapsed_time(e1) / 1e3 / reps
             fl = 2.0 * a.t * n * k

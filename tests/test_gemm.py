@@ -49,3 +49,28 @@ def test_prefill_gemm_accumulate_and_errors(oracle, dev):
         fast_gemm.plain(wt, torch.randn(4, 256, device=dev))
     with pytest.raises(ValueError, match="unsupported quant dtype"):
         fast_gemm.plain(QTensor.from_numpy(GgmlDType.Q4_0, (32, 64), oracle.random_blocks(oracle.Q4_0, 32, 64), dev), torch.randn(4, 64, device=dev))
+
+
+@pytest.mark.parametrize("tname", ["Q4_K", "Q5_K", "Q6_K", "Q8_0"])
+@pytest.mark.parametrize("m,n,k,split", [(512, 256, 1024, True), (300, 384, 2048, True), (256, 128, 512, False), (130, 200, 4096, True), (1, 128, 256, True)])
+def test_prefill_gemm_large_m_vs_oracle(oracle, dev, tname, m, n, k, split):
+    """256-row-tile kernel (bf16 activations, ping-pong waves, split-K partials) against the same oracle and bounds."""
+    import torch
+    from mistralrs_amd.gguf import GgmlDType, QTensor, fast_gemm
+    t = getattr(oracle, tname)
+    rng = np.random.default_rng(m * 7 + n + k)
+    w = oracle.random_blocks(t, n, k, seed=n + k, d_scale=0.02)
+    x = (rng.standard_normal((m, k)) * rng.uniform(0.2, 3.0, (m, 1))).astype(np.float32)
+    wt = QTensor.from_numpy(GgmlDType.from_id(t), (n, k), w, dev)
+    xt = torch.from_numpy(x).to(dev)
+    got = fast_gemm.plain_bf16(wt, xt, split_k=split).cpu().numpy().astype(np.float64)
+    wd = oracle.dequantize(t, w, k)
+    xb, wb = round_through(x, "bf16").astype(np.float64), round_through(wd, "bf16").astype(np.float64)
+    want = xb @ wb.T
+    mag = np.abs(xb) @ np.abs(wb).T
+    err = np.abs(got - want)
+    assert (err <= 2.0 ** -19 * mag + 1e-30).all(), float((err / (2.0 ** -19 * mag + 1e-30)).max())
+    base = torch.randn(m, n, device=dev)
+    acc = fast_gemm.plain_bf16(wt, fast_gemm.to_slabs(xt), out=base.clone(), accumulate=True, split_k=split)
+    assert torch.equal(acc, base + torch.from_numpy(got.astype(np.float32)).to(dev))
+    assert torch.equal(fast_gemm.plain_bf16(wt, xt, split_k=split), torch.from_numpy(got.astype(np.float32)).to(dev))  # deterministic
