@@ -302,9 +302,6 @@ template <int TYPE> static int gemm_launch(GemmArgs a, hipStream_t s) {
 // partials that a second kernel sums in a fixed order (deterministic, unlike atomics).
 constexpr int HM = 256, HN = 128, HK = 64, HT = 512;
 
-#ifndef GV
-#define GV 0
-#endif
 template <int TYPE> struct RawH;
 template <> struct RawH<T_Q4_K> { int4 hdr, q; };
 template <> struct RawH<T_Q5_K> { int4 hdr, q, h; };
@@ -318,7 +315,7 @@ template <int TYPE> __device__ __forceinline__ RawH<TYPE> gemm_load_w16(const ui
   if constexpr (TYPE == T_Q4_K) {
     const uint8_t *blk = row + (size_t)(kb >> 2) * 144;
     r.hdr = ld16_a4(blk);
-    r.q = (GV & 8) ? ld16nt_a4(blk + 16 + c * 32 + (aq & 1) * 16) : ld16_a4(blk + 16 + c * 32 + (aq & 1) * 16);
+    r.q = ld16_a4(blk + 16 + c * 32 + (aq & 1) * 16);
   } else if constexpr (TYPE == T_Q5_K) {
     const uint8_t *blk = row + (size_t)(kb >> 2) * 176;
     r.hdr = ld16_a4(blk);
@@ -390,105 +387,127 @@ struct GemmBArgs {
   int N[3], ldo[3], tile0[3];
   int nseg;
   const uint16_t *x;  // bf16 k-slab-major [K/64][M][64]: the A tile of one k-step is ONE contiguous 128 B x rows block
-  int M, K, accumulate, splits, ldp;
-  float *partial;     // [splits][M][ldp] when splits > 1 (column = global n-tile * 128 + n)
+  int M, K, accumulate, splits, ldp, tn;
+  float *partial;     // [splits][M][ldp] when splits > 1 (column = global n-tile * tn + n)
   size_t row_bytes;
 };
 
-#ifndef GV
-#define GV 0
-#endif
-
-template <int TYPE>
+// NI = 128-column blocks per workgroup tile: 1 -> 256 x 128 (waves 4 x 2, 64 x 64 each), 2 -> 256 x 256 (waves 2 x 4, 128 x 64 each:
+// half the A traffic, LDS bytes and decode work per FLOP; needs >= ~200 column tiles of 256 to fill the chip without split-K).
+template <int TYPE, int NI>
 __global__ void __launch_bounds__(HT) gemm_qb_kernel(const GemmBArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A 256 x 64 bf16 | B 128 x 64 bf16] = 96 KiB
+  constexpr int TN = HN * NI, MI = 2 * NI, PF = NI == 1 ? 2 : 1;  // PF: staging register sets (prefetch distance in k-steps)
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A 256 x 64 bf16 | B TN x 64 bf16] = 96 / 128 KiB
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   int seg = 0;
   if (a.nseg > 2 && (int)blockIdx.x >= a.tile0[2]) seg = 2;
   else if (a.nseg > 1 && (int)blockIdx.x >= a.tile0[1]) seg = 1;
   const int segN = a.N[seg];
-  const int m0 = blockIdx.y * HM, n0 = ((int)blockIdx.x - a.tile0[seg]) * HN;
-  const int wm = (wave & 3) * 64, wn = (wave >> 2) * 64;
-  const bool mfma_first = (GV & 1) ? wave < 4 : true;  // waves w and w+4 share a SIMD (placement order 0,2,1,3 repeats every 4 waves)
-  const int ar = tid >> 2, aq = tid & 3;     // B: row, 16-weight quarter of the 64-k slab
+  const int m0 = blockIdx.y * HM, n0 = ((int)blockIdx.x - a.tile0[seg]) * TN;
+  const int wm = NI == 1 ? (wave & 3) * 64 : (wave & 1) * 128, wn = NI == 1 ? (wave >> 2) * 64 : (wave >> 1) * 64;
+  const int ar = tid >> 2, aq = tid & 3;     // B: rows ar + 128 j, 16-weight quarter of the 64-k slab
   const int xc = tid & 7, xr0 = tid >> 3;    // A: 16-byte chunk, rows xr0 + 64 i
-  const uint8_t *wrow = a.w[seg] + (size_t)min(n0 + ar, segN - 1) * a.row_bytes;
+  const uint8_t *wrow[NI];
+#pragma unroll
+  for (int jn = 0; jn < NI; ++jn) wrow[jn] = a.w[seg] + (size_t)min(n0 + ar + 128 * jn, segN - 1) * a.row_bytes;
   const int nk_all = a.K / HK;
   const int k_lo = (int)((long)nk_all * blockIdx.z / a.splits), k_hi = (int)((long)nk_all * (blockIdx.z + 1) / a.splits);
   const int nk = k_hi - k_lo;
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  int4 xa[2][4];
-  RawH<TYPE> wb[2];
-  const uint16_t *xrow[4];
+  // A tile: buffer loads with sc1 (agent scope = miss-always in the 32 KB vector L1, normal L2 hit).  The tile is used once per
+  // workgroup: with default loads its 32 KB per k-step flush the weight-block lines (re-used over 4 k-steps) out of L1 -- measured
+  // 2x on the whole kernel; nontemporal loads fix L1 but also drop the lines from L2, which every other column tile re-reads (-15 %).
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, (short)0, (int)((size_t)a.M * a.K * 2), 0x00020000);
+  unsigned xoff[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) xrow[i] = a.x + (size_t)min(m0 + xr0 + 64 * i, a.M - 1) * HK + xc * 8;
-  auto issue = [&](int set, int kb_raw) {
+  for (int i = 0; i < 4; ++i) xoff[i] = (unsigned)((min(m0 + xr0 + 64 * i, a.M - 1) * HK + xc * 8) * 2);
+  v4u xa[PF][4];
+  RawH<TYPE> wb[PF][NI];
+  auto issue = [&](int set, int kb_raw) {  // unconditional, k index clamped (a load under a branch makes hipcc drain vmcnt)
     const int kb = k_lo + min(kb_raw, nk - 1);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      // streaming (nontemporal) loads: the A tile is used once per workgroup; with default loads its 32 KB per k-step flush the
-      // weight-block lines out of the 32 KB vector L1 every step (measured 2x on the whole kernel)
-      if (GV & 16) xa[set][i] = *(const int4 *)(xrow[i] + (size_t)kb * a.M * HK);
-      else xa[set][i] = ld16nt_a4(xrow[i] + (size_t)kb * a.M * HK);
-    }
-    wb[set] = gemm_load_w16<TYPE>(wrow, kb, aq);
+    for (int i = 0; i < 4; ++i) xa[set][i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xoff[i] + (unsigned)kb * (unsigned)(a.M * HK * 2), 0, 16);
+#pragma unroll
+    for (int jn = 0; jn < NI; ++jn) wb[set][jn] = gemm_load_w16<TYPE>(wrow[jn], kb, aq);
   };
   auto commit = [&](int set, int kb_raw, char *buf) {
     const int kb = k_lo + min(kb_raw, nk - 1);
     char *A = buf, *B = buf + HM * HK * 2;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *(int4 *)(A + tile_off(xr0 + 64 * i, xc)) = xa[set][i];
-    unsigned o[8];
-    if constexpr ((GV & 2) && TYPE == T_Q4_K) { o[0] = wb[set].q.x; o[1] = wb[set].q.y; o[2] = wb[set].q.z; o[3] = wb[set].q.w; o[4] = wb[set].hdr.x; o[5] = wb[set].hdr.y; o[6] = wb[set].hdr.z; o[7] = wb[set].hdr.w; }
-    else gemm_decode_w16<TYPE>(wb[set], kb, aq, o);
-    *(int4 *)(B + tile_off(ar, aq * 2)) = make_int4((int)o[0], (int)o[1], (int)o[2], (int)o[3]);
-    *(int4 *)(B + tile_off(ar, aq * 2 + 1)) = make_int4((int)o[4], (int)o[5], (int)o[6], (int)o[7]);
+    for (int i = 0; i < 4; ++i) *(v4u *)(A + tile_off(xr0 + 64 * i, xc)) = xa[set][i];
+#pragma unroll
+    for (int jn = 0; jn < NI; ++jn) {
+      unsigned o[8];
+      gemm_decode_w16<TYPE>(wb[set][jn], kb, aq, o);
+      *(int4 *)(B + tile_off(ar + 128 * jn, aq * 2)) = make_int4((int)o[0], (int)o[1], (int)o[2], (int)o[3]);
+      *(int4 *)(B + tile_off(ar + 128 * jn, aq * 2 + 1)) = make_int4((int)o[4], (int)o[5], (int)o[6], (int)o[7]);
+    }
   };
   const int frow = lane & 31, fk = lane >> 5;
   auto mfma_tile = [&](const char *buf) {
     const char *A = buf, *B = buf + HM * HK * 2;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      bf16x8 af[2], bfr[2];
+      bf16x8 af[MI], bfr[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = *(const bf16x8 *)(A + tile_off(wm + i * 32 + frow, ks * 2 + fk));
+      for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8 *)(A + tile_off(wm + i * 32 + frow, ks * 2 + fk));
 #pragma unroll
       for (int j = 0; j < 2; ++j) bfr[j] = *(const bf16x8 *)(B + tile_off(wn + j * 32 + frow, ks * 2 + fk));
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { if (GV & 4) acc[i][j][0] += __builtin_bit_cast(float, (int)af[i][0] ^ (int)bfr[j][1]); else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0); }
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
   };
-  char *buf0 = smem, *buf1 = smem + (HM + HN) * HK * 2;
-  issue(0, 0);
-  issue(1, 1);
-  commit(0, 0, buf0);
-  __syncthreads();
-  for (int kb = 0; kb < nk; kb += 2) {
-    issue(0, kb + 2);
-    if (mfma_first) { mfma_tile(buf0); commit(1, kb + 1, buf1); } else { commit(1, kb + 1, buf1); mfma_tile(buf0); }
+  char *buf0 = smem, *buf1 = smem + (HM + TN) * HK * 2;
+  if constexpr (PF == 2) {
+    issue(0, 0);
+    issue(1, 1);
+    commit(0, 0, buf0);
     __syncthreads();
-    if (kb + 1 >= nk) break;
-    issue(1, kb + 3);
-    if (mfma_first) { mfma_tile(buf1); commit(0, kb + 2, buf0); } else { commit(0, kb + 2, buf0); mfma_tile(buf1); }
+    for (int kb = 0; kb < nk; kb += 2) {
+      issue(0, kb + 2);
+      mfma_tile(buf0);
+      commit(1, kb + 1, buf1);
+      __syncthreads();
+      if (kb + 1 >= nk) break;
+      issue(1, kb + 3);
+      mfma_tile(buf1);
+      commit(0, kb + 2, buf0);
+      __syncthreads();
+    }
+  } else {
+    issue(0, 0);
+    commit(0, 0, buf0);
     __syncthreads();
+    for (int kb = 0; kb < nk; kb += 2) {
+      issue(0, kb + 1);
+      mfma_tile(buf0);
+      commit(0, kb + 1, buf1);
+      __syncthreads();
+      if (kb + 1 >= nk) break;
+      issue(0, kb + 2);
+      mfma_tile(buf1);
+      commit(0, kb + 2, buf0);
+      __syncthreads();
+    }
   }
   float *obase;
   int ldo, ncol0;
-  if (a.splits > 1) { obase = a.partial + (size_t)blockIdx.z * a.M * a.ldp; ldo = a.ldp; ncol0 = (int)blockIdx.x * HN - n0; }
+  if (a.splits > 1) { obase = a.partial + (size_t)blockIdx.z * a.M * a.ldp; ldo = a.ldp; ncol0 = (int)blockIdx.x * TN - n0; }
   else { obase = a.out[seg]; ldo = a.ldo[seg]; ncol0 = 0; }
   const bool accum = a.accumulate && a.splits == 1;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int n = n0 + wn + j * 32 + (lane & 31);
@@ -510,9 +529,9 @@ __global__ void __launch_bounds__(256) gemm_splitk_reduce_kernel(const GemmBArgs
   if (idx >= (size_t)a.M * total_cols) return;
   const int m = (int)(idx / total_cols), gc = (int)(idx % total_cols);
   int seg = 0;
-  if (a.nseg > 2 && gc >= a.tile0[2] * HN) seg = 2;
-  else if (a.nseg > 1 && gc >= a.tile0[1] * HN) seg = 1;
-  const int n = gc - a.tile0[seg] * HN;
+  if (a.nseg > 2 && gc >= a.tile0[2] * a.tn) seg = 2;
+  else if (a.nseg > 1 && gc >= a.tile0[1] * a.tn) seg = 1;
+  const int n = gc - a.tile0[seg] * a.tn;
   if (n >= a.N[seg]) return;  // N % 4 == 0 is checked by the launcher for split launches
   float4 s = *(const float4 *)(a.partial + (size_t)m * a.ldp + gc);
   for (int z = 1; z < a.splits; ++z) {
@@ -536,28 +555,35 @@ __global__ void __launch_bounds__(256) convert_f32_bf16_slabs_kernel(const float
       make_int4((int)pack_bf16(a.x, a.y), (int)pack_bf16(a.z, a.w), (int)pack_bf16(b.x, b.y), (int)pack_bf16(b.z, b.w));
 }
 
-template <int TYPE> static int gemm_b_launch(GemmBArgs a, size_t ws_bytes, hipStream_t s) {
+template <int TYPE, int NI> static void gemm_b_launch_ni(GemmBArgs a, size_t ws_bytes, hipStream_t s) {
+  constexpr int TN = HN * NI;
   int tiles = 0;
   bool n4 = true;
-  for (int i = 0; i < a.nseg; ++i) { a.tile0[i] = tiles; tiles += (a.N[i] + HN - 1) / HN; n4 = n4 && a.N[i] % 4 == 0 && a.ldo[i] % 4 == 0; }
+  for (int i = 0; i < a.nseg; ++i) { a.tile0[i] = tiles; tiles += (a.N[i] + TN - 1) / TN; n4 = n4 && a.N[i] % 4 == 0 && a.ldo[i] % 4 == 0; }
   const int mt = (a.M + HM - 1) / HM, nk = a.K / HK;
   int splits = 1;
   if (const char *e = getenv("MRS_GEMM_SPLITS")) splits = atoi(e);
   else if (tiles * mt < 192) splits = std::min(std::min(8, 256 / (tiles * mt)), std::max(1, nk / 8));
-  a.ldp = tiles * HN;
+  a.ldp = tiles * TN;
+  a.tn = TN;
   if (!n4 || !a.partial) splits = 1;
   while (splits > 1 && (size_t)splits * a.M * a.ldp * 4 > ws_bytes) --splits;
   if (splits < 1) splits = 1;
   a.splits = splits;
-  constexpr size_t lds = 2 * (HM + HN) * HK * 2;
+  constexpr size_t lds = 2 * (HM + TN) * HK * 2;
   static bool attr = false;
-  auto kern = gemm_qb_kernel<TYPE>;
-  if (!attr) { hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  auto kern = gemm_qb_kernel<TYPE, NI>;
+  if (!attr) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
   hipLaunchKernelGGL(kern, dim3(tiles, mt, splits), dim3(HT), lds, s, a);
   if (splits > 1) {
     const size_t n4s = (size_t)a.M * a.ldp / 4;
     hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)((n4s + 255) / 256)), dim3(256), 0, s, a);
   }
+}
+template <int TYPE> static int gemm_b_launch(const GemmBArgs &a, size_t ws_bytes, hipStream_t s) {
+  // NI = 2 (256 x 256 tiles, 128 x 64 per wave) needs ~280 registers per lane with this staging scheme and spills under the 256 budget
+  // of a 512-thread workgroup (measured 3x slower); it stays un-instantiated until the A tile moves to LDS-DMA (round 2).
+  gemm_b_launch_ni<TYPE, 1>(a, ws_bytes, s);
   return 0;
 }
 
@@ -576,7 +602,7 @@ extern "C" int mrs_convert_f32_bf16_slabs(const float *x, int ldx, int M, int K,
 
 // Large-M GEMM over bf16 activations in k-slab-major layout x[K/64][M][64] (mrs_convert_f32_bf16_slabs): out_s[m*ldo_s + n] (+)= sum_k x[m][k] * bf16(W_s[n][k]).
 // workspace (may be NULL): split-K partials for shapes with fewer tiles than CUs; mrs_gemm_q_bf16_workspace_bytes() always suffices.
-extern "C" size_t mrs_gemm_q_bf16_workspace_bytes(int M) { return (size_t)M * 32768 * 4 / (size_t)((M + HM - 1) / HM) + 65536; }
+extern "C" size_t mrs_gemm_q_bf16_workspace_bytes(int M) { return (size_t)M * 65536 * 4 / (size_t)((M + HM - 1) / HM) + 65536; }
 extern "C" int mrs_gemm_q_bf16_multi(int nseg, const void *const *w, const int *N, float *const *out, const int *ldo, int ggml_type, int K,
                                      const void *x_slabs, int M, int accumulate, void *workspace, size_t workspace_bytes, void *stream) {
   if (nseg < 1 || nseg > 3) return -1;
