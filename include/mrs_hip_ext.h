@@ -84,6 +84,10 @@ int mrs_gemm_q_bf16_multi(int nseg, const void *const *w, const int *N, float *c
 size_t mrs_gemm_q_bf16_workspace_bytes(int M);
 /* x f32 [M][ldx] -> bf16 (round to nearest even) slabs y[K/64][M][64]; K % 64 == 0, ldx % 4 == 0 */
 int mrs_convert_f32_bf16_slabs(const float *x, int ldx, int M, int K, void *y, void *stream);
+/* producers that write the slabs directly: act(g) * u (role of fused_glu, utils/ops.rs:2953; activation codes of mistralrs_quant.h) and
+ * RMSNorm (role of the RmsNorm before q/k/v and gate/up; arithmetic of mrs_rms_norm_f32), each followed by the bf16 rounding */
+int mrs_glu_bf16_slabs(const float *g, const float *u, int ld, int M, int N, int activation, void *y, void *stream);
+int mrs_rms_norm_bf16_slabs(const float *x, const float *w, int M, int K, float eps, void *y, void *stream);
 
 /* ---------------------------------------------------------------- causal prompt attention (ext_attn_prefill.hip)
  * softmax(scale * Q K^T + causal) V on the bf16 matrix cores with K / V read straight from the paged cache (the chunk has been

@@ -555,6 +555,46 @@ __global__ void __launch_bounds__(256) convert_f32_bf16_slabs_kernel(const float
       make_int4((int)pack_bf16(a.x, a.y), (int)pack_bf16(a.z, a.w), (int)pack_bf16(b.x, b.y), (int)pack_bf16(b.z, b.w));
 }
 
+// Producers that write the slab layout directly (no f32 round trip + convert pass):
+// act(g) * u, f32 [M][ld] x2 -> bf16 slabs [N/64][M][64]; same arithmetic as fused_glu_f32 followed by the conversion
+__global__ void __launch_bounds__(256) glu_bf16_slabs_kernel(const float *__restrict__ g, const float *__restrict__ u, uint16_t *__restrict__ y,
+                                                             int ld, int M, int N, int activation) {
+  const int n8 = N / 8;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)M * n8) return;
+  const int m = (int)(i / n8), k = (int)(i % n8) * 8;
+  const float4 g0 = *(const float4 *)(g + (size_t)m * ld + k), g1 = *(const float4 *)(g + (size_t)m * ld + k + 4);
+  const float4 u0 = *(const float4 *)(u + (size_t)m * ld + k), u1 = *(const float4 *)(u + (size_t)m * ld + k + 4);
+  const float o0 = glu_act(g0.x, activation) * u0.x, o1 = glu_act(g0.y, activation) * u0.y, o2 = glu_act(g0.z, activation) * u0.z,
+              o3 = glu_act(g0.w, activation) * u0.w, o4 = glu_act(g1.x, activation) * u1.x, o5 = glu_act(g1.y, activation) * u1.y,
+              o6 = glu_act(g1.z, activation) * u1.z, o7 = glu_act(g1.w, activation) * u1.w;
+  *(int4 *)(y + ((size_t)(k >> 6) * M + m) * 64 + (k & 63)) = make_int4((int)pack_bf16(o0, o1), (int)pack_bf16(o2, o3), (int)pack_bf16(o4, o5), (int)pack_bf16(o6, o7));
+}
+
+// RMSNorm (x * rsqrt(mean(x^2) + eps) * w, the arithmetic and reduction order of mrs_rms_norm_f32) -> bf16 slabs; one workgroup per row
+__global__ void __launch_bounds__(256) rms_norm_bf16_slabs_kernel(const float *__restrict__ x, const float *__restrict__ w, uint16_t *__restrict__ y,
+                                                                  int M, int K, float eps) {
+  __shared__ float red[4];
+  const int m = blockIdx.x, tid = threadIdx.x;
+  const float *xr = x + (size_t)m * K;
+  float sum = 0.f;
+  for (int v = tid; v < K / 4; v += 256) {
+    const float4 t = *(const float4 *)(xr + v * 4);
+    sum = fmaf(t.x, t.x, sum); sum = fmaf(t.y, t.y, sum); sum = fmaf(t.z, t.z, sum); sum = fmaf(t.w, t.w, sum);
+  }
+  sum = wave_sum(sum);
+  if ((tid & 63) == 0) red[tid >> 6] = sum;
+  __syncthreads();
+  const float inv = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)K + eps);  // block_sum_256 order of core_ops.hip
+  for (int v = tid; v < K / 8; v += 256) {
+    const int k = v * 8;
+    const float4 a = *(const float4 *)(xr + k), b = *(const float4 *)(xr + k + 4), wa = *(const float4 *)(w + k), wb = *(const float4 *)(w + k + 4);
+    *(int4 *)(y + ((size_t)(k >> 6) * M + m) * 64 + (k & 63)) =
+        make_int4((int)pack_bf16(a.x * inv * wa.x, a.y * inv * wa.y), (int)pack_bf16(a.z * inv * wa.z, a.w * inv * wa.w),
+                  (int)pack_bf16(b.x * inv * wb.x, b.y * inv * wb.y), (int)pack_bf16(b.z * inv * wb.z, b.w * inv * wb.w));
+  }
+}
+
 template <int TYPE, int NI> static void gemm_b_launch_ni(GemmBArgs a, size_t ws_bytes, hipStream_t s) {
   constexpr int TN = HN * NI;
   int tiles = 0;
@@ -597,6 +637,22 @@ extern "C" int mrs_convert_f32_bf16_slabs(const float *x, int ldx, int M, int K,
   if (M <= 0) return 0;
   const size_t n = (size_t)M * (K / 8);
   hipLaunchKernelGGL(convert_f32_bf16_slabs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (uint16_t *)y, ldx, M, K);
+  return 0;
+}
+
+// act(g[m][n]) * u[m][n] (f32, row stride ld, N % 64 == 0) -> bf16 slabs y[N/64][M][64]: fused_glu + mrs_convert_f32_bf16_slabs in one pass
+extern "C" int mrs_glu_bf16_slabs(const float *g, const float *u, int ld, int M, int N, int activation, void *y, void *stream) {
+  if (N <= 0 || N % 64 || (ld & 3)) return -1;
+  if (M <= 0) return 0;
+  const size_t n = (size_t)M * (N / 8);
+  hipLaunchKernelGGL(glu_bf16_slabs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, u, (uint16_t *)y, ld, M, N, activation);
+  return 0;
+}
+// RMSNorm of x f32 [M][K] (contiguous rows, K % 64 == 0) with weight w [K] -> bf16 slabs y[K/64][M][64]: mrs_rms_norm_f32 + conversion
+extern "C" int mrs_rms_norm_bf16_slabs(const float *x, const float *w, int M, int K, float eps, void *y, void *stream) {
+  if (K <= 0 || K % 64) return -1;
+  if (M <= 0) return 0;
+  hipLaunchKernelGGL(rms_norm_bf16_slabs_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, x, w, (uint16_t *)y, M, K, eps);
   return 0;
 }
 

@@ -379,10 +379,12 @@ class Llama {
     const bool big = T > 128 && !getenv("MRS_PREFILL_SMALL_TILES");
     const size_t part_bytes = big ? mrs_gemm_q_bf16_workspace_bytes(T) : 0;
     void *xb = big ? take(t * std::max(std::max(d, nq), ff) * 2) : nullptr, *part = big ? take(part_bytes) : nullptr;
-    const float *xb_src = nullptr;  // which f32 buffer xb currently mirrors
+    const float *xb_src = nullptr;    // which f32 buffer xb currently mirrors (within one GEMM group)
+    const float *xb_ready = nullptr;  // set by a producer that wrote the slabs of that (never materialised) f32 buffer directly
     auto to_bf16 = [&](const float *x, int K) -> int {
       if (xb_src == x) return 0;
       xb_src = x;
+      if (xb_ready == x) { xb_ready = nullptr; return 0; }
       return mrs_convert_f32_bf16_slabs(x, K, T, K, xb, s);
     };
     auto gemm = [&](const GgufMatMul &m, const float *x, int K, float *out, int N, int acc) -> int {
@@ -426,7 +428,8 @@ class Llama {
     for (size_t li = 0; li < blocks.size(); ++li) {
       const Block &bl = blocks[li];
       if (!bl.q_proj || !bl.key_cache) return fail("layer %zu is incomplete", li);
-      mrs_rms_norm_f32(h, bl.input_layernorm, xn, T, d, cfg.rms_eps, st);
+      if (big) { if (mrs_rms_norm_bf16_slabs(h, bl.input_layernorm, T, d, cfg.rms_eps, xb, s)) return fail("prefill: hidden size must be a multiple of 64"); xb_ready = xn; }
+      else mrs_rms_norm_f32(h, bl.input_layernorm, xn, T, d, cfg.rms_eps, st);
       if (gemm_multi({bl.q_proj.get(), bl.k_proj.get(), bl.v_proj.get()}, xn, d, {q, k, v}, {nq, nkv, nkv})) return -1;
       rotary_embedding_positions(q, k, (void *)bufs.cos_table, (void *)bufs.sin_table, (void *)pa.positions, cfg.rope_interleaved ? 0 : 1, hd, T,
                                  cfg.rot_dim / 2, cfg.max_context_len, cfg.num_heads, cfg.num_kv_heads, nq, nkv, 2, st);
@@ -441,9 +444,11 @@ class Llama {
       if (cfg.world_size > 1) {  // row-parallel: partial -> all-reduce -> residual add (bias-free)
         if (gemm(*bl.o_proj, attn, nq, xn, d, 0) || all_reduce(xn, t * d, s) || mrs_vec_add_f32(h, xn, t * d, s)) return -1;
       } else if (gemm(*bl.o_proj, attn, nq, h, d, 1)) return -1;
-      mrs_rms_norm_f32(h, bl.post_attention_layernorm, xn, T, d, cfg.rms_eps, st);
+      if (big) { if (mrs_rms_norm_bf16_slabs(h, bl.post_attention_layernorm, T, d, cfg.rms_eps, xb, s)) return -1; xb_ready = xn; }
+      else mrs_rms_norm_f32(h, bl.post_attention_layernorm, xn, T, d, cfg.rms_eps, st);
       if (gemm_multi({bl.gate_proj.get(), bl.up_proj.get()}, xn, d, {g, u}, {ff, ff})) return -1;
-      fused_glu_f32(g, u, act, (uint32_t)T, (uint32_t)ff, (uint32_t)ff, (uint32_t)ff, 0, s);
+      if (big && ff % 64 == 0) { if (mrs_glu_bf16_slabs(g, u, ff, T, ff, 0, xb, s)) return -1; xb_ready = act; }
+      else fused_glu_f32(g, u, act, (uint32_t)T, (uint32_t)ff, (uint32_t)ff, (uint32_t)ff, 0, s);
       if (cfg.world_size > 1) {
         if (gemm(*bl.down_proj, act, ff, xn, d, 0) || all_reduce(xn, t * d, s) || mrs_vec_add_f32(h, xn, t * d, s)) return -1;
       } else if (gemm(*bl.down_proj, act, ff, h, d, 1)) return -1;

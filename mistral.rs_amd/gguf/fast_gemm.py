@@ -86,3 +86,29 @@ def plain_bf16(w: QTensor, xs: torch.Tensor, out: torch.Tensor | None = None, ac
     if own or slabs is not xs:
         torch.cuda.current_stream().synchronize()  # workspace / slabs stay alive until the launch ran
     return out
+
+
+def rms_norm_slabs(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
+    """RMSNorm of f32 [M, K] straight into the bf16 slab layout (mrs_rms_norm_bf16_slabs) == to_slabs(ops.rms_norm(x, w, eps))."""
+    if x.dtype != torch.float32 or weight.dtype != torch.float32 or x.dim() != 2 or not x.is_contiguous():
+        raise ValueError("fast_gemm.rms_norm_slabs: contiguous f32 matrix [M, K] and f32 weight")
+    m, k = x.shape
+    y = torch.empty(max(k // 64, 1), m, 64, dtype=torch.bfloat16, device=x.device)
+    _lib.load("quant"); _lib.load("paged_attn"); _lib.load("core")
+    fn = _lib.sym("ext", "mrs_rms_norm_bf16_slabs", [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p], C.c_int)
+    if fn(x.data_ptr(), weight.data_ptr(), m, k, eps, y.data_ptr(), torch.cuda.current_stream().cuda_stream):
+        raise ValueError("fast_gemm.rms_norm_slabs: K must be a multiple of 64")
+    return y
+
+
+def glu_slabs(g: torch.Tensor, u: torch.Tensor, activation: int = 0) -> torch.Tensor:
+    """act(g) * u of f32 [M, N] straight into the bf16 slab layout (mrs_glu_bf16_slabs) == to_slabs(ops.fused_glu(g, u, act))."""
+    if g.dtype != torch.float32 or g.shape != u.shape or g.dim() != 2 or g.stride(1) != 1 or u.stride() != g.stride():
+        raise ValueError("fast_gemm.glu_slabs: two f32 matrices [M, N] of equal shape and strides")
+    m, n = g.shape
+    y = torch.empty(max(n // 64, 1), m, 64, dtype=torch.bfloat16, device=g.device)
+    _lib.load("quant"); _lib.load("paged_attn"); _lib.load("core")
+    fn = _lib.sym("ext", "mrs_glu_bf16_slabs", [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p], C.c_int)
+    if fn(g.data_ptr(), u.data_ptr(), g.stride(0), m, n, int(activation), y.data_ptr(), torch.cuda.current_stream().cuda_stream):
+        raise ValueError("fast_gemm.glu_slabs: N must be a multiple of 64 and the row stride a multiple of 4")
+    return y

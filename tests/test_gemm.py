@@ -74,3 +74,25 @@ def test_prefill_gemm_large_m_vs_oracle(oracle, dev, tname, m, n, k, split):
     acc = fast_gemm.plain_bf16(wt, fast_gemm.to_slabs(xt), out=base.clone(), accumulate=True, split_k=split)
     assert torch.equal(acc, base + torch.from_numpy(got.astype(np.float32)).to(dev))
     assert torch.equal(fast_gemm.plain_bf16(wt, xt, split_k=split), torch.from_numpy(got.astype(np.float32)).to(dev))  # deterministic
+
+
+def test_slab_producers(dev):
+    """to_slabs is the layout [K/64][M][64] of the bf16-rounded matrix; the fused producers equal the unfused op + to_slabs bit for bit."""
+    import torch
+    from mistralrs_amd import ops
+    from mistralrs_amd.gguf import fast_gemm
+    torch.manual_seed(5)
+    x = torch.randn(77, 320, device=dev) * 3.0
+    want = x.to(torch.bfloat16).reshape(77, 5, 64).permute(1, 0, 2).contiguous()
+    assert torch.equal(fast_gemm.to_slabs(x), want)
+    wide = torch.randn(77, 400, device=dev)
+    assert torch.equal(fast_gemm.to_slabs(wide[:, 16:336]), wide[:, 16:336].to(torch.bfloat16).reshape(77, 5, 64).permute(1, 0, 2).contiguous())
+    w = torch.rand(320, device=dev) + 0.5
+    assert torch.equal(fast_gemm.rms_norm_slabs(x, w, 1e-5), fast_gemm.to_slabs(ops.rms_norm(x, w, 1e-5)))
+    g, u = torch.randn(77, 320, device=dev) * 4.0, torch.randn(77, 320, device=dev)
+    for act in (0, 1, 2):
+        assert torch.equal(fast_gemm.glu_slabs(g, u, act), fast_gemm.to_slabs(ops.fused_glu(g, u, act)))
+    with pytest.raises(ValueError, match="multiple of 64"):
+        fast_gemm.to_slabs(torch.randn(4, 96, device=dev))
+    with pytest.raises(ValueError, match="multiple of 64"):
+        fast_gemm.glu_slabs(torch.randn(4, 96, device=dev), torch.randn(4, 96, device=dev))
