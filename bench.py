@@ -114,6 +114,20 @@ def cpu_baseline(model, cfg, budget_s=12.0):
                       f"host reports {os.cpu_count()} logical CPUs"}
 
 
+def measured_traffic(model_name):
+    """HBM bytes per launch of the dominant kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE on this same command,
+    x2 gfx950 correction; scripts/profile_round.sh -> profiles/round1_hbm_traffic.json).  Counters cannot be read from inside the
+    timed process, so the figure is the last profiled one for this kernel and workload; null for any other workload."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_hbm_traffic.json")
+    try:
+        k = json.load(open(path))["kernels"]["void mrs::decode_gemv_kernel<1, 1, 2, 512>(mrs::DecodeGemvArgs)"]
+    except (OSError, KeyError, ValueError):
+        return {"traffic": None}
+    if "8B" not in model_name:
+        return {"traffic": None}
+    return {"traffic": int(k["read_bytes_per_launch"] + k["write_bytes_per_launch"]), "traffic_source": "profiles/round1_hbm_traffic.json"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -243,7 +257,7 @@ def main():
         "step_bytes": int(step_bytes), "step_roofline_frac": round(step_bytes * (a.steps / t_all) / HBM_PEAK, 4),
         "roofline": {"bound": "hbm", "kernel": "decode_gemv_kernel<1, PRO_NORM, EPI_GLU_Q8_1> (fused RMSNorm+Q8_1+gate/up GEMV+SiLU*mul+Q8_1)",
                      "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4),
-                     "bytes_per_launch": int(kern_bytes), "us_per_launch": round(kern_s * 1e6, 2), "traffic": None},
+                     "bytes_per_launch": int(kern_bytes), "us_per_launch": round(kern_s * 1e6, 2), **measured_traffic(name)},
         "greedy_tokens_head": [int(t) for t in toks[a.warmup: a.warmup + 8]],
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

@@ -1,0 +1,49 @@
+#!/usr/bin/env python
+"""Turn the rocprofv3 CSVs of scripts/profile_round.sh (gpurun_out/<tag>/{kt,fetch,write}) into the tracked evidence under profiles/:
+  profiles/<round>_kernel_stats.md     per-kernel table of the --kernel-trace --stats pass (bench.py defaults)
+  profiles/<round>_hbm_traffic.json    FETCH_SIZE / WRITE_SIZE per launch of every mrs:: kernel (separate --pmc passes);
+                                       read side doubled as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950
+    python scripts/make_profile_summary.py gpurun_out/final round1
+"""
+import collections, csv, glob, json, os, subprocess, sys
+
+
+def counters(d, name):
+    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    out = collections.defaultdict(list)
+    if not f:
+        return out
+    for r in csv.DictReader(open(f[0])):
+        if r["Counter_Name"] == name:
+            out[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return out
+
+
+def main():
+    src, tag = sys.argv[1], sys.argv[2]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    kt = glob.glob(os.path.join(src, "kt", "**", "*kernel_trace.csv"), recursive=True)[0]
+    table = subprocess.run([sys.executable, os.path.join(root, "scripts", "rocprof_summary.py"), kt, "--top", "40", "--match", "mrs::"],
+                           capture_output=True, text=True, check=True).stdout
+    with open(os.path.join(root, "profiles", f"{tag}_kernel_stats.md"), "w") as f:
+        f.write(f"# {tag}: `rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline` (MI355X, per-kernel, mrs:: kernels)\n\n")
+        f.write(table)
+    fetch, write = counters(os.path.join(src, "fetch"), "FETCH_SIZE"), counters(os.path.join(src, "write"), "WRITE_SIZE")
+    out = {}
+    for k, v in fetch.items():
+        if "mrs::" not in k:
+            continue
+        w = write.get(k, [0.0])
+        out[k] = {"launches": len(v), "fetch_size_kb_avg": sum(v) / len(v), "read_bytes_per_launch": 2.0 * 1024.0 * sum(v) / len(v),
+                  "write_size_kb_avg": sum(w) / len(w), "write_bytes_per_launch": 1024.0 * sum(w) / len(w)}
+    meta = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python bench.py --no-cpu-baseline --steps 32",
+            "correction": "FETCH_SIZE is in KB and counts 64 B per 128-B request on gfx950 for wide coalesced reads: read bytes = 2 * 1024 * FETCH_SIZE",
+            "kernels": out}
+    with open(os.path.join(root, "profiles", f"{tag}_hbm_traffic.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    for k, v in sorted(out.items(), key=lambda kv: -kv[1]["read_bytes_per_launch"] * kv[1]["launches"])[:12]:
+        print(f"{v['launches']:6d}  read {v['read_bytes_per_launch'] / 1e6:9.2f} MB  write {v['write_bytes_per_launch'] / 1e6:8.2f} MB  {k[:100]}")
+
+
+if __name__ == "__main__":
+    main()
