@@ -13,6 +13,7 @@
  */
 #ifndef MISTRALRS_QUANT_H
 #define MISTRALRS_QUANT_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -66,6 +67,26 @@ void fused_glu_bf16(const void *a, const void *b, void *output, uint32_t rows, u
                     uint32_t b_row_stride, int activation, void *stream);
 void fused_glu_f32(const void *a, const void *b, void *output, uint32_t rows, uint32_t cols, uint32_t a_row_stride,
                    uint32_t b_row_stride, int activation, void *stream);
+
+/* ---- HQQ: unpack + dequantize (axis-0 groups).  Wq [h][w] packed (u8; i32 with ten 3-bit fields for 3 bit), scale / zero [w] of the
+ *      output dtype, out [P*h][w], P = 1/2/4/8/10 values per packed element, most significant first:
+ *          out[(c*h + r)*w + j] = (T(q_c(r, j)) - zero[j]) * scale[j]     evaluated in T
+ *      NO stream argument (default stream), as the reference.  replaces kernels/hqq/hqq.cu:26-80,94-155,171-230,278-345,399-468 ;
+ *      Rust: src/hqq/ffi.rs:1-74 ; caller HqqLayer::dequantize (hqq/mod.rs:874-1090) <- forward / dequantize_w (:1092-1100,1163-1171) */
+#define MRS_DECL_HQQ(name)                                                                                     \
+  void dequantize_##name##_f32(const void *wq_packed, const void *scale, const void *zero, void *out, int h, int w);  \
+  void dequantize_##name##_f16(const void *wq_packed, const void *scale, const void *zero, void *out, int h, int w);  \
+  void dequantize_##name##_bf16(const void *wq_packed, const void *scale, const void *zero, void *out, int h, int w);
+MRS_DECL_HQQ(8bit_u8_kernel) MRS_DECL_HQQ(4bit_u8_kernel) MRS_DECL_HQQ(2bit_u8_kernel) MRS_DECL_HQQ(1bit_u8_kernel) MRS_DECL_HQQ(3bit_32_kernel)
+#undef MRS_DECL_HQQ
+/* ---- HQQ bit packing: input [num_input_elements rows][input_width] of unpacked values, output row r packs rows r + i*step
+ *      (step = rows / P), i = 0 most significant.  replaces kernels/hqq/hqq_bitpack.cu:7-206 ; Rust: src/hqq/bitpack_ffi.rs:1-40 ;
+ *      caller HqqBits::bitpack_type (hqq/mod.rs:150-400) */
+void launch_pack_1bit_kernel(const uint8_t *d_input, uint8_t *d_output, size_t num_input_elements, size_t input_width, void *stream);
+void launch_pack_2bit_kernel(const uint8_t *d_input, uint8_t *d_output, size_t num_input_elements, size_t input_width, void *stream);
+void launch_pack_3bit_kernel(const uint32_t *d_input, int32_t *d_output, size_t num_input_elements, size_t input_width, void *stream);
+void launch_pack_4bit_kernel(const uint8_t *d_input, uint8_t *d_output, size_t num_input_elements, size_t input_width, void *stream);
+void launch_pack_8bit_kernel(const uint8_t *d_input, uint8_t *d_output, size_t num_elements, void *stream);
 
 #ifdef __cplusplus
 }

@@ -17,6 +17,10 @@
 #define __launch_bounds__(...)
 
 struct float2 { float x, y; };
+// thread coordinates for the reference __global__ kernels that hqq_driver.inc runs one thread at a time
+struct ShimDim { unsigned x, y, z; };
+static thread_local ShimDim blockIdx, blockDim, threadIdx;
+#include <stddef.h>
 
 static inline float shim_h2f(uint16_t h) {  // IEEE binary16 -> binary32, exact
   const uint32_t s = (uint32_t)(h & 0x8000) << 16, e = (h >> 10) & 31, m = h & 1023;

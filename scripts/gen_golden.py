@@ -41,6 +41,23 @@ def main():
         np.savez_compressed(os.path.join(GOLD, f"mmvq_{O.TYPE_NAMES[t]}.npz"), type=np.int32(t), n=np.int32(n), k=np.int32(k), w=w, x=x,
                             y_q8_1=y, out_ref=out, mag=mag, dequant_ref=deq)
         print(f"golden: mmvq_{O.TYPE_NAMES[t]}.npz  out[0,:3]={out[0,:3]}")
+    # HQQ: expected values from the reference's own dequantize_* / pack_* kernels run on the host (oracle/_ref/libref_hqq.so)
+    hq = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_hqq.so"))
+    from oracle import hqq_oracle as H
+    for bits in (8, 4, 3, 2, 1):
+        rng = np.random.default_rng(4000 + bits)
+        p, w = H.PACK[bits], 52
+        h = 7
+        q = rng.integers(0, 2 ** bits, size=(p * h, w)).astype(np.uint32 if bits == 3 else np.uint8)
+        packed = np.zeros((h, w), dtype=np.int32 if bits == 3 else np.uint8)
+        assert hq.ref_hqq_pack(bits, q.ctypes.data_as(C.c_void_p), packed.ctypes.data_as(C.c_void_p), C.c_size_t(p * h), C.c_size_t(w)) == 0
+        scale = (rng.uniform(0.001, 0.05, w) * rng.choice([1.0, -1.0], w)).astype(np.float32)
+        zero = rng.uniform(0.0, 2 ** bits - 1.0, w).astype(np.float32)
+        out = np.empty((p * h, w), dtype=np.float32)
+        assert hq.ref_hqq_dequantize_f32(bits, packed.ctypes.data_as(C.c_void_p), scale.ctypes.data_as(C.c_void_p), zero.ctypes.data_as(C.c_void_p),
+                                         out.ctypes.data_as(C.c_void_p), h, w) == 0
+        np.savez_compressed(os.path.join(GOLD, f"hqq_{bits}bit.npz"), bits=np.int32(bits), q=q, packed_ref=packed, scale=scale, zero=zero, out_ref=out)
+        print(f"golden: hqq_{bits}bit.npz  out[0,:3]={out[0,:3]}")
 
 
 if __name__ == "__main__":
