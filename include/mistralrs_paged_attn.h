@@ -3,7 +3,8 @@
  *
  * Drop-in for `libmistralrspagedattention.a` (mistralrs-paged-attn/build.rs:146-158,213-215).
  * Same symbols and argument lists as mistralrs-paged-attn/src/cuda/ffi.rs; `stream` is a hipStream_t.
- * dtype codes: 0 = f16, 1 = bf16, 2 = f32, 3 = fp8-e4m3 cache (fp8 not built yet: aborts loudly).
+ * dtype codes: 0 = f16, 1 = bf16, 2 = f32, 3 = fp8-e4m3 cache (OCP E4M3FN; block sizes 16 / 32; needs k_scale / v_scale:
+ * stored = fp8_sat_rne(x / scale), read as T(float(fp8) * scale), quantization/fp8/nvidia/quant_utils.cuh:24-29,187-217).
  * Cache layouts (mistralrs-core/src/paged_attention/cache_engine.rs:458-484):
  *   K cache [num_blocks, kv_heads, head_size/x, block_size, x],  x = 16 / sizeof(cache element)
  *   V cache [num_blocks, kv_heads, head_size, block_size]
@@ -85,6 +86,12 @@ int mrs_decode_attention_q8_1_f32_bf16(void *y_q8_1, int y_stride_blocks, float 
                                        int max_context_len, int num_seqs, int num_heads, int head_size,
                                        int max_num_blocks_per_seq, int q_stride, int kv_block_stride, int kv_head_stride,
                                        void *stream);
+/* ffi.rs:484-510 ; update_kvscales.cu:46-150: *k_scales = max(*k_scales, absmax(k) / 240), same for v (fp8 KV-cache scale tracking,
+ * backend/scale_update.rs:81-105); k, v: num_elements values of the named dtype */
+void update_kv_scales_f32(void *k, void *v, const long num_elements, float *k_scales, float *v_scales, int64_t stream);
+void update_kv_scales_f16(void *k, void *v, const long num_elements, float *k_scales, float *v_scales, int64_t stream);
+void update_kv_scales_bf16(void *k, void *v, const long num_elements, float *k_scales, float *v_scales, int64_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,6 +45,9 @@ def libraries():
                             ("f32", "float", "float", True), ("f32_bf16", "float", "mrs::bf16_t", False)):
         d = [f"-DMRS_PA_TAG={tag}", f"-DMRS_PA_T={t}", f"-DMRS_PA_CT={ct}"] + (["-DMRS_PA_EXPORT_ABI"] if abi else ["-DMRS_PA_DECODE_Q8_1"])
         pa.append(_tu("paged_attention.hip", f"paged_attention_{tag}.o", d))
+    for tag, t in (("f16", "mrs::f16_t"), ("bf16", "mrs::bf16_t"), ("f32", "float")):  # fp8 (E4M3) cache read as query dtype `tag`
+        pa.append(_tu("paged_attention.hip", f"paged_attention_{tag}_fp8.o",
+                      [f"-DMRS_PA_TAG={tag}", f"-DMRS_PA_T={t}", "-DMRS_PA_CT=mrs::fp8_t", "-DMRS_PA_FP8"]))
     libs["libmistralrspagedattention.so"] = pa
     # optional translation units are picked up as soon as the file exists
     optional = {

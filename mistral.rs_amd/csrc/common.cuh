@@ -20,6 +20,29 @@ __device__ __forceinline__ uint16_t float_to_bf16_bits(float f) {  // round-to-n
   return (uint16_t)(x >> 16);
 }
 
+// FP8 E4M3 (OCP "E4M3FN": bias 7, no infinities, S.1111.111 = NaN, max 448) -- the KV-cache element of cache_dtype 3.  Conversions are
+// done in integer arithmetic so that the result is the defined one on every ASIC (the hardware fp8 converts differ between gfx942 FNUZ
+// and gfx950 OCP): decode is exact; encode is round-to-nearest-even with saturation to +-448 (the reference's __NV_SATFINITE,
+// quantization/fp8/nvidia/quant_utils.cuh:187-217), NaN -> 0x7f.
+struct fp8_t { uint8_t v; };
+__device__ __forceinline__ float fp8_e4m3_to_float(uint8_t v) {
+  const uint32_t s = (uint32_t)(v & 0x80) << 24, e = (v >> 3) & 15, m = v & 7;
+  if (e == 0) return __uint_as_float(s | __float_as_uint((float)m * 0.001953125f));  // subnormal: m * 2^-9
+  if (e == 15 && m == 7) return __uint_as_float(s | 0x7fc00000u);
+  return __uint_as_float(s | ((e + 120) << 23) | (m << 20));
+}
+__device__ __forceinline__ uint8_t float_to_fp8_e4m3(float x) {
+  const uint32_t b = __float_as_uint(x), sign = (b >> 24) & 0x80;
+  const float a = fabsf(x);
+  if (!(a == a)) return (uint8_t)(sign | 0x7f);
+  if (a >= 464.0f) return (uint8_t)(sign | 0x7e);           // >= halfway between 448 and the (absent) 480: saturate
+  if (a < 0.015625f) return (uint8_t)(sign | (uint32_t)rintf(a * 512.0f));  // below 2^-6: subnormal grid of 2^-9 (8 -> the first normal)
+  uint32_t r = __float_as_uint(a);
+  r += 0x7ffffu + ((r >> 20) & 1u);                         // RNE to 3 mantissa bits
+  const uint32_t code = (((r >> 23) - 120u) << 3) | ((r >> 20) & 7u);
+  return (uint8_t)(sign | (code > 0x7eu ? 0x7eu : code));
+}
+
 template <class T> struct cvt;
 template <> struct cvt<float> {
   static __device__ __forceinline__ float to_f(float x) { return x; }

@@ -37,6 +37,14 @@ template <> __device__ __forceinline__ void unpack16<float>(const int4 &raw, flo
   o[0] = __int_as_float(raw.x); o[1] = __int_as_float(raw.y); o[2] = __int_as_float(raw.z); o[3] = __int_as_float(raw.w);
 }
 
+template <> __device__ __forceinline__ void unpack16<fp8_t>(const int4 &raw, float *o) {  // 16 E4M3 values, exact
+  const unsigned w[4] = {(unsigned)raw.x, (unsigned)raw.y, (unsigned)raw.z, (unsigned)raw.w};
+#pragma unroll
+  for (int i = 0; i < 16; ++i) o[i] = fp8_e4m3_to_float((uint8_t)(w[i >> 2] >> (8 * (i & 3))));
+}
+template <class CT> struct is_fp8 { static constexpr bool value = false; };
+template <> struct is_fp8<fp8_t> { static constexpr bool value = true; };
+
 template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
 }
@@ -49,6 +57,7 @@ struct PagedAttnArgs {
   const void *k_cache, *v_cache;
   const uint32_t *block_tables, *context_lens;
   const float *alibi_slopes, *sinks;
+  const float *k_scale, *v_scale;  // fp8 cache: one f32 each (device); element = T(float(fp8) * scale) (quant_utils.cuh:24-29,79-88,135-145)
   int num_heads, num_kv_heads, max_num_blocks_per_seq, q_stride, kv_block_stride, kv_head_stride;
   int logits_stride;  // padded tokens per head in LDS
   float scale, softcapping;
@@ -92,6 +101,9 @@ __global__ void __launch_bounds__(NW * 64) paged_attention_kernel(const PagedAtt
   const uint32_t *block_table = a.block_tables + (size_t)seq * a.max_num_blocks_per_seq;
   const CT *kc = (const CT *)a.k_cache + (size_t)kvh * a.kv_head_stride;
   const CT *vc = (const CT *)a.v_cache + (size_t)kvh * a.kv_head_stride;
+  constexpr bool FP8 = is_fp8<CT>::value;
+  float ks = 1.0f, vs = 1.0f;
+  if constexpr (FP8) { ks = *a.k_scale; vs = *a.v_scale; }
 
   // ---------------------------------------------------------------- Q.K^T
   float qk_max[G];
@@ -109,6 +121,10 @@ __global__ void __launch_bounds__(NW * 64) paged_attention_kernel(const PagedAtt
       if (NCH % LPT == 0 || c < NCH) {
         float kf[X];
         unpack16<CT>(ld16_a16(kb + (size_t)c * BS * X), kf);
+        if constexpr (FP8) {
+#pragma unroll
+          for (int j = 0; j < X; ++j) kf[j] = round_to<T>(kf[j] * ks);
+        }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
           const float *qg = q_s + g * HD + c * X;
@@ -197,6 +213,10 @@ __global__ void __launch_bounds__(NW * 64) paged_attention_kernel(const PagedAtt
       if (HD % RPI == 0 || row < HD) {
         float vf[X];
         unpack16<CT>(ld16_a16(vb + (size_t)row * BS), vf);
+        if constexpr (FP8) {
+#pragma unroll
+          for (int j = 0; j < X; ++j) vf[j] = round_to<T>(vf[j] * vs);
+        }
         if (last) {
 #pragma unroll
           for (int j = 0; j < X; ++j) vf[j] = (token0 + j < (int)ctx) ? vf[j] : 0.f;  // stale slots may hold NaNs

@@ -85,9 +85,10 @@ void paged_attention_dispatch(bool v2, void *out, float *exp_sums, float *max_lo
                               float scale, float softcapping, const uint32_t *block_tables, const uint32_t *context_lens,
                               int block_size, int max_context_len, int num_seqs, int num_heads, int head_size,
                               int max_num_blocks_per_seq, int q_stride, int kv_block_stride, int kv_head_stride,
-                              hipStream_t stream, const float *sinks) {
+                              hipStream_t stream, const float *sinks, const float *k_scale = nullptr, const float *v_scale = nullptr) {
   if (num_seqs <= 0 || num_heads <= 0) return;
   PagedAttnArgs a{};
+  a.k_scale = k_scale; a.v_scale = v_scale;
   a.exp_sums = exp_sums; a.max_logits = max_logits; a.out = v2 ? tmp_out : out; a.q = query;
   a.k_cache = key_cache; a.v_cache = value_cache; a.block_tables = block_tables; a.context_lens = context_lens;
   a.alibi_slopes = (const float *)alibi_slopes; a.sinks = sinks;
@@ -102,7 +103,13 @@ void paged_attention_dispatch(bool v2, void *out, float *exp_sums, float *max_lo
     if (v2) pa_pick_hd<T, CT, BS, PA_PARTITION>(a, head_size, num_seqs, max_parts, stream);            \
     else pa_pick_hd<T, CT, BS, 0>(a, head_size, num_seqs, max_parts, stream);                          \
     break;
-  switch (block_size) { BS_CASE(8) BS_CASE(16) BS_CASE(32) default: break; }
+  if constexpr (sizeof(CT) == 1) {  // fp8 cache: 16 tokens per 16-byte group, block sizes 16 and 32
+    if (block_size != 16 && block_size != 32) { fprintf(stderr, "paged_attention (gfx950): fp8 KV cache needs block_size 16 or 32, got %d\n", block_size); exit(2); }
+    if (!k_scale || !v_scale) { fprintf(stderr, "paged_attention (gfx950): fp8 KV cache needs k_scale / v_scale\n"); exit(2); }
+    switch (block_size) { BS_CASE(16) BS_CASE(32) default: break; }
+  } else {
+    switch (block_size) { BS_CASE(8) BS_CASE(16) BS_CASE(32) default: break; }
+  }
 #undef BS_CASE
   if (v2) pa_reduce<T, PA_PARTITION>(out, exp_sums, max_logits, tmp_out, context_lens, max_parts, sinks, head_size, num_heads, num_seqs, stream);
   pa_check(v2 ? "paged_attention_v2" : "paged_attention_v1");
@@ -117,6 +124,7 @@ using mrs::f16_t;
 #define PA_CAT(a, b) PA_CAT_(a, b)
 
 // MI355X-native entry: explicit (query dtype, cache dtype) pair, used by the fused decode path
+#ifndef MRS_PA_FP8
 extern "C" void PA_CAT(mrs_paged_attention_, MRS_PA_TAG)(
     int v2, void *out, float *exp_sums, float *max_logits, void *tmp_out, const void *query, const void *key_cache,
     const void *value_cache, const void *alibi_slopes, int num_kv_heads, float scale, float softcapping,
@@ -129,7 +137,24 @@ extern "C" void PA_CAT(mrs_paged_attention_, MRS_PA_TAG)(
                                                      max_num_blocks_per_seq, q_stride, kv_block_stride, kv_head_stride,
                                                      (hipStream_t)stream, sinks);
 }
+#endif
 
+#ifdef MRS_PA_FP8
+// fp8 (E4M3) cache: same entry plus the two scale pointers; the reference-ABI exports of the matching query dtype forward here when
+// cache_dtype == 3 (pagedattention.cuh:752-790 picks the <scalar_t, uint8_t, kFp8E4M3> instantiation)
+extern "C" void PA_CAT(mrs_paged_attention_fp8_, MRS_PA_TAG)(
+    int v2, void *out, float *exp_sums, float *max_logits, void *tmp_out, const void *query, const void *key_cache,
+    const void *value_cache, const void *alibi_slopes, int num_kv_heads, float scale, float softcapping,
+    const uint32_t *block_tables, const uint32_t *context_lens, int block_size, int max_context_len, int num_seqs,
+    int num_heads, int head_size, int max_num_blocks_per_seq, int q_stride, int kv_block_stride, int kv_head_stride,
+    void *stream, const float *sinks, const float *k_scale, const float *v_scale) {
+  mrs::paged_attention_dispatch<MRS_PA_T, MRS_PA_CT>(v2 != 0, out, exp_sums, max_logits, tmp_out, query, key_cache, value_cache,
+                                                     alibi_slopes, num_kv_heads, scale, softcapping, block_tables, context_lens,
+                                                     block_size, max_context_len, num_seqs, num_heads, head_size,
+                                                     max_num_blocks_per_seq, q_stride, kv_block_stride, kv_head_stride,
+                                                     (hipStream_t)stream, sinks, k_scale, v_scale);
+}
+#endif
 #ifdef MRS_PA_DECODE_Q8_1
 // MI355X decode attention for the fused path.  head_size 128 / block 32 / bf16 cache: the wave-per-KV-chunk kernel
 // (paged_attention.cuh, "decode attention v3") + one merge kernel that writes Q8_1 blocks for o_proj.  Other shapes:
@@ -195,17 +220,23 @@ extern "C" int PA_CAT(mrs_decode_attention_q8_1_, MRS_PA_TAG)(
 #ifdef MRS_PA_EXPORT_ABI
 // The reference ABI: query dtype in the symbol name, cache dtype code 0 f16 / 1 bf16 / 2 f32 / 3 fp8-e4m3.
 // Like the reference, a non-fp8 cache is read as the query dtype (pagedattention_v1_bf16.cu:22-29).
-static void pa_abi_guard(uint32_t cache_dtype) {
-  if (cache_dtype == 3) { fprintf(stderr, "paged_attention (gfx950): fp8 KV cache not supported yet\n"); exit(2); }
-}
+extern "C" void PA_CAT(mrs_paged_attention_fp8_, MRS_PA_TAG)(
+    int v2, void *out, float *exp_sums, float *max_logits, void *tmp_out, const void *query, const void *key_cache,
+    const void *value_cache, const void *alibi_slopes, int num_kv_heads, float scale, float softcapping,
+    const uint32_t *block_tables, const uint32_t *context_lens, int block_size, int max_context_len, int num_seqs,
+    int num_heads, int head_size, int max_num_blocks_per_seq, int q_stride, int kv_block_stride, int kv_head_stride,
+    void *stream, const float *sinks, const float *k_scale, const float *v_scale);  // paged_attention_<tag>_fp8.o
 extern "C" void PA_CAT(paged_attention_v1_, MRS_PA_TAG)(
     void *out, void *query, void *key_cache, void *value_cache, void *alibi_slopes, int32_t num_kv_heads, float scale,
     float softcapping, uint32_t *block_tables, uint32_t *context_lens, int32_t block_size, int32_t max_context_len,
     int32_t num_seqs, int32_t num_heads, int32_t head_size, int32_t max_num_blocks_per_seq, int32_t q_stride,
     int32_t kv_block_stride, int32_t kv_head_stride, hipStream_t stream, uint32_t cache_dtype, float *k_scale,
     float *v_scale, const float *sinks) {
-  (void)k_scale; (void)v_scale;
-  pa_abi_guard(cache_dtype);
+  if (cache_dtype == 3)
+    return PA_CAT(mrs_paged_attention_fp8_, MRS_PA_TAG)(0, out, nullptr, nullptr, nullptr, query, key_cache, value_cache, alibi_slopes, num_kv_heads,
+                                                        scale, softcapping, block_tables, context_lens, block_size, max_context_len, num_seqs,
+                                                        num_heads, head_size, max_num_blocks_per_seq, q_stride, kv_block_stride, kv_head_stride,
+                                                        stream, sinks, k_scale, v_scale);
   mrs::paged_attention_dispatch<MRS_PA_T, MRS_PA_CT>(false, out, nullptr, nullptr, nullptr, query, key_cache, value_cache, alibi_slopes,
                                                      num_kv_heads, scale, softcapping, block_tables, context_lens, block_size,
                                                      max_context_len, num_seqs, num_heads, head_size, max_num_blocks_per_seq,
@@ -217,8 +248,11 @@ extern "C" void PA_CAT(paged_attention_v2_, MRS_PA_TAG)(
     uint32_t *context_lens, int32_t block_size, int32_t max_context_len, int32_t num_seqs, int32_t num_heads,
     int32_t head_size, int32_t max_num_blocks_per_seq, int32_t q_stride, int32_t kv_block_stride, int32_t kv_head_stride,
     hipStream_t stream, uint32_t cache_dtype, float *k_scale, float *v_scale, const float *sinks) {
-  (void)k_scale; (void)v_scale;
-  pa_abi_guard(cache_dtype);
+  if (cache_dtype == 3)
+    return PA_CAT(mrs_paged_attention_fp8_, MRS_PA_TAG)(1, out, exp_sums, max_logits, tmp_out, query, key_cache, value_cache, alibi_slopes,
+                                                        num_kv_heads, scale, softcapping, block_tables, context_lens, block_size, max_context_len,
+                                                        num_seqs, num_heads, head_size, max_num_blocks_per_seq, q_stride, kv_block_stride,
+                                                        kv_head_stride, stream, sinks, k_scale, v_scale);
   mrs::paged_attention_dispatch<MRS_PA_T, MRS_PA_CT>(true, out, exp_sums, max_logits, tmp_out, query, key_cache, value_cache,
                                                      alibi_slopes, num_kv_heads, scale, softcapping, block_tables, context_lens,
                                                      block_size, max_context_len, num_seqs, num_heads, head_size,

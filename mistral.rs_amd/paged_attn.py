@@ -14,6 +14,21 @@ import torch
 from . import _lib
 
 _CODE = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}
+_CACHE_CODE = {**_CODE, torch.uint8: 3}  # uint8 cache = fp8 E4M3 codes (cache_dtype 3): needs k_scale / v_scale (f32 scalars on the device)
+if hasattr(torch, "float8_e4m3fn"):
+    _CACHE_CODE[torch.float8_e4m3fn] = 3
+
+
+def _scales(cache: torch.Tensor, k_scale, v_scale):
+    """(k_scale ptr, v_scale ptr) for an fp8 cache, (None, None) otherwise; mirrors the Option<&Tensor> pair of the reference op."""
+    if _CACHE_CODE.get(cache.dtype) != 3:
+        return None, None
+    if k_scale is None or v_scale is None:
+        raise ValueError("an fp8 KV cache needs k_scale and v_scale")
+    for t in (k_scale, v_scale):
+        if t.dtype != torch.float32 or t.numel() != 1 or not t.is_cuda:
+            raise ValueError("k_scale / v_scale must be single-element f32 GPU tensors")
+    return k_scale.data_ptr(), v_scale.data_ptr()
 _TAG = {torch.float16: "f16", torch.bfloat16: "bf16", torch.float32: "f32"}
 _HEAD_SIZES = (64, 80, 96, 112, 128, 192, 256, 512)
 PARTITION_SIZE = 512
@@ -47,7 +62,7 @@ def kv_cache_shapes(num_blocks: int, num_kv_heads: int, head_size: int, block_si
 
 
 def reshape_and_cache(key: torch.Tensor, value: torch.Tensor, key_cache: torch.Tensor, value_cache: torch.Tensor,
-                      slot_mapping: torch.Tensor) -> None:
+                      slot_mapping: torch.Tensor, k_scale: torch.Tensor | None = None, v_scale: torch.Tensor | None = None) -> None:
     """key/value [num_tokens, kv_heads, head_size] (row stride may exceed kv_heads*head_size);
     slot_mapping int64 [num_tokens]; negative slots are skipped."""
     if key.dtype not in _CODE:
@@ -66,15 +81,16 @@ def reshape_and_cache(key: torch.Tensor, value: torch.Tensor, key_cache: torch.T
         raise ValueError("key/value must be contiguous within a token")
     fn = _lib.sym("paged_attn", "reshape_and_cache",
                   [_vp] * 5 + [_i] * 7 + [_vp, _u, _u, _vp, _vp])
+    ks, vs = _scales(key_cache, k_scale, v_scale)
     fn(key.data_ptr(), value.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(), slot_mapping.data_ptr(),
        num_tokens, num_heads, head_size, block_size, x, key.stride(0), value.stride(0), _stream(),
-       _CODE[key.dtype], _CODE[key_cache.dtype], None, None)
+       _CODE[key.dtype], _CACHE_CODE[key_cache.dtype], ks, vs)
 
 
 def paged_attention(q: torch.Tensor, key_cache: torch.Tensor, value_cache: torch.Tensor, block_tables: torch.Tensor,
                     context_lens: torch.Tensor, max_context_len: int, softmax_scale: float, softcapping: float = 1.0,
                     alibi_slopes: torch.Tensor | None = None, sinks: torch.Tensor | None = None,
-                    force: str | None = None) -> torch.Tensor:
+                    force: str | None = None, k_scale: torch.Tensor | None = None, v_scale: torch.Tensor | None = None) -> torch.Tensor:
     """q [num_seqs, num_heads, head_size] (row stride free) -> out, same shape.  block_tables uint32/int32
     [num_seqs, max_blocks], context_lens uint32/int32 [num_seqs].  `force` in {None, 'v1', 'v2'} (tests)."""
     if q.dtype not in _CODE:
@@ -104,7 +120,11 @@ def paged_attention(q: torch.Tensor, key_cache: torch.Tensor, value_cache: torch
     out = torch.empty(num_seqs, num_heads, head_size, dtype=q.dtype, device=q.device)
     al = alibi_slopes.data_ptr() if alibi_slopes is not None else None
     sk = sinks.data_ptr() if sinks is not None else None
-    mixed = key_cache.dtype != q.dtype
+    ks, vs = _scales(key_cache, k_scale, v_scale)
+    fp8 = ks is not None
+    if fp8 and block_size not in (16, 32):
+        raise ValueError("an fp8 KV cache needs block_size 16 or 32")
+    mixed = key_cache.dtype != q.dtype and not fp8
     if mixed and not (q.dtype == torch.float32 and key_cache.dtype == torch.bfloat16):
         raise ValueError(f"unsupported (query, cache) dtype pair ({q.dtype}, {key_cache.dtype})")
     common_tail = [_i, _f, _f, _vp, _vp] + [_i] * 9 + [_vp]
@@ -125,14 +145,14 @@ def paged_attention(q: torch.Tensor, key_cache: torch.Tensor, value_cache: torch
         fn = _lib.sym("paged_attn", f"paged_attention_v1_{_TAG[q.dtype]}", [_vp] * 5 + tail)
         fn(out.data_ptr(), q.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(), al, kvh, softmax_scale, softcapping,
            block_tables.data_ptr(), context_lens.data_ptr(), block_size, eff_max, num_seqs, num_heads, head_size,
-           max_blocks, q.stride(0), key_cache.stride(0), key_cache.stride(1), _stream(), _CODE[key_cache.dtype], None, None, sk)
+           max_blocks, q.stride(0), key_cache.stride(0), key_cache.stride(1), _stream(), _CACHE_CODE[key_cache.dtype], ks, vs, sk)
     else:
         tmp_out, exp_sums, max_logits = _paged_ws(q, num_seqs, num_heads, max_parts, head_size)
         fn = _lib.sym("paged_attn", f"paged_attention_v2_{_TAG[q.dtype]}", [_vp] * 8 + tail)
         fn(out.data_ptr(), exp_sums, max_logits, tmp_out, q.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(), al, kvh,
            softmax_scale, softcapping, block_tables.data_ptr(), context_lens.data_ptr(), block_size, eff_max, num_seqs,
            num_heads, head_size, max_blocks, q.stride(0), key_cache.stride(0), key_cache.stride(1), _stream(),
-           _CODE[key_cache.dtype], None, None, sk)
+           _CACHE_CODE[key_cache.dtype], ks, vs, sk)
     return out
 
 
@@ -148,7 +168,8 @@ def _paged_ws(q, num_seqs, num_heads, max_parts, head_size):
 
 
 def gather_kv_cache(key_cache: torch.Tensor, value_cache: torch.Tensor, block_table: torch.Tensor,
-                    cu_seq_lens: torch.Tensor, out_dtype: torch.dtype):
+                    cu_seq_lens: torch.Tensor, out_dtype: torch.dtype, k_scale: torch.Tensor | None = None,
+                    v_scale: torch.Tensor | None = None):
     """paged -> dense K/V [num_tokens, kv_heads, head_size]; cu_seq_lens int32 [num_seqs + 1]."""
     nb, kvh, hs_x, block_size, x = key_cache.shape
     head_size = hs_x * x
@@ -157,10 +178,24 @@ def gather_kv_cache(key_cache: torch.Tensor, value_cache: torch.Tensor, block_ta
     k_out = torch.empty(num_tokens, kvh, head_size, dtype=out_dtype, device=key_cache.device)
     v_out = torch.empty_like(k_out)
     fn = _lib.sym("paged_attn", "gather_kv_cache", [_vp] * 8 + [_i] * 7 + [_vp, _u, _u])
-    fn(key_cache.data_ptr(), value_cache.data_ptr(), k_out.data_ptr(), v_out.data_ptr(), None, None,
+    ks, vs = _scales(key_cache, k_scale, v_scale)
+    fn(key_cache.data_ptr(), value_cache.data_ptr(), k_out.data_ptr(), v_out.data_ptr(), ks, vs,
        block_table.data_ptr(), cu_seq_lens.data_ptr(), num_tokens, num_seqs, block_size, block_table.stride(0), kvh,
-       head_size, x, _stream(), _CODE[out_dtype], _CODE[key_cache.dtype])
+       head_size, x, _stream(), _CODE[out_dtype], _CACHE_CODE[key_cache.dtype])
     return k_out, v_out
+
+
+def update_kv_scales(key: torch.Tensor, value: torch.Tensor, k_scale: torch.Tensor, v_scale: torch.Tensor) -> None:
+    """k_scale = max(k_scale, absmax(key) / 240), same for v, in place (backend/scale_update.rs:81-105, update_kvscales.cu)."""
+    if key.dtype not in _CODE or value.dtype != key.dtype or key.numel() != value.numel():
+        raise ValueError("update_kv_scales: key / value must share dtype (f16 / bf16 / f32) and element count")
+    if not (key.is_contiguous() and value.is_contiguous()):
+        raise ValueError("update_kv_scales: key / value must be contiguous")
+    for t in (k_scale, v_scale):
+        if t.dtype != torch.float32 or t.numel() != 1:
+            raise ValueError("k_scale / v_scale must be single-element f32 tensors")
+    fn = _lib.sym("paged_attn", f"update_kv_scales_{_TAG[key.dtype]}", [_vp, _vp, C.c_long, _vp, _vp, C.c_int64])
+    fn(key.data_ptr(), value.data_ptr(), key.numel(), k_scale.data_ptr(), v_scale.data_ptr(), _stream())
 
 
 def copy_blocks(key_caches: list, value_caches: list, block_mapping: dict) -> None:

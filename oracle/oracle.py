@@ -288,3 +288,36 @@ def paged_attention_ref(q, key_cache, value_cache, block_tables, context_lens, s
                 p = round_p(p.astype(np.float32)).astype(np.float64)
             out[s, h] = p @ v[:, g, :]
     return out.astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------------- FP8 (E4M3) KV cache
+# OCP E4M3FN (bias 7, no inf, S.1111.111 = NaN, max 448): the storage format of cache_dtype 3.  The reference converts with the CUDA
+# intrinsics __nv_cvt_float_to_fp8(x / scale, __NV_SATFINITE, __NV_E4M3) and __nv_cvt_fp8_to_halfraw (mistralrs-paged-attn/src/cuda/
+# quantization/fp8/nvidia/quant_utils.cuh:24-29,79-88,135-145,187-217); their source is not in the tree, so this restates the format
+# definition ("parity unpinned" vs the intrinsic; cross-checked against torch.float8_e4m3fn for in-range values in tests/test_fp8_kv.py).
+def fp8_e4m3_decode(codes: np.ndarray) -> np.ndarray:
+    c = np.asarray(codes, dtype=np.uint8).astype(np.int32)
+    s, e, m = c >> 7, (c >> 3) & 15, c & 7
+    val = np.where(e == 0, m * 2.0 ** -9, (1.0 + m / 8.0) * np.exp2((e - 7).astype(np.float64)))
+    val = np.where((e == 15) & (m == 7), np.nan, val)
+    return (np.where(s == 1, -val, val)).astype(np.float32)
+
+
+_FP8_GRID = None
+
+
+def fp8_e4m3_encode(x: np.ndarray) -> np.ndarray:
+    """float -> E4M3 code: round to nearest, ties to the even code, saturate to +-448 (SATFINITE), NaN -> 0x7f | sign."""
+    global _FP8_GRID
+    if _FP8_GRID is None:
+        _FP8_GRID = fp8_e4m3_decode(np.arange(0, 0x7F, dtype=np.uint8)).astype(np.float64)  # 127 non-negative finite values, ascending
+    x = np.asarray(x, dtype=np.float32)
+    a = np.abs(x.astype(np.float64))
+    hi = np.clip(np.searchsorted(_FP8_GRID, a, side="left"), 0, len(_FP8_GRID) - 1)
+    lo = np.clip(hi - 1, 0, None)
+    dlo, dhi = a - _FP8_GRID[lo], _FP8_GRID[hi] - a
+    pick_hi = (dhi < dlo) | ((dhi == dlo) & (hi % 2 == 0))
+    code = np.where(pick_hi, hi, lo)
+    code = np.where(a >= _FP8_GRID[-1], len(_FP8_GRID) - 1, code)
+    code = np.where(np.isnan(a), 0x7F, code).astype(np.uint8)
+    return (code | (np.signbit(x).astype(np.uint8) << 7)).astype(np.uint8)
