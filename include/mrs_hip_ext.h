@@ -111,6 +111,8 @@ typedef struct {
   int32_t max_context_len;
   int32_t use_fused;          /* 1: ext_decode fused kernels when the weight types allow; 0: reference launch sequence */
   int32_t world_size, rank;   /* tensor parallel (1, 0 = single GPU) */
+  int32_t num_experts;        /* 0 = dense FFN; > 0: Mixtral-style sparse MoE FFN in every layer (models/mixtral.rs:236-304) */
+  int32_t num_experts_per_tok; /* top-k of the router (softmax over all experts -> top-k -> renormalise) */
 } mrs_llama_config;
 
 typedef struct {  /* all device pointers, owned by the caller */
@@ -133,7 +135,9 @@ size_t mrs_llama_workspace_bytes(const mrs_llama_config *cfg);
 void *mrs_llama_create(const mrs_llama_config *cfg);
 void mrs_llama_destroy(void *model);
 /* name = GGUF tensor name ("token_embd.weight", "blk.3.attn_q.weight", "output_norm.weight", ...: the binding table of
- * mistralrs-core/src/gguf/normal_bindings.rs:40-220); shape [n_rows, n_cols]; data stays owned by the caller */
+ * mistralrs-core/src/gguf/normal_bindings.rs:40-220); shape [n_rows, n_cols]; data stays owned by the caller.
+ * MoE layers: "blk.N.ffn_gate_inp.weight" (F32 router [E, hidden]) and the stacked experts "blk.N.ffn_{gate,up,down}_exps.weight"
+ * given as [E * rows_per_expert, cols] (rank-3 GGUF tensors flattened over the expert axis) */
 int mrs_llama_set_tensor(void *model, const char *name, const void *dev_ptr, int ggml_type, int64_t n_rows, int64_t n_cols);
 int mrs_llama_set_kv_cache(void *model, int layer, void *key_cache, void *value_cache);
 int mrs_llama_set_buffers(void *model, const mrs_llama_buffers *bufs);

@@ -159,6 +159,9 @@ static int try_fused_quantized_gate_up(const QuantMethod &g, const QuantMethod &
 // ---------------------------------------------------------------------------------------------- model
 struct Block {
   std::unique_ptr<GgufMatMul> q_proj, k_proj, v_proj, o_proj, gate_proj, up_proj, down_proj;
+  // sparse MoE FFN (cfg.num_experts > 0): router [E][hidden] f32 + experts stacked along the row axis, [E * n][k] packed blocks
+  const float *router = nullptr;
+  QTensor gate_exps, up_exps, down_exps;
   const float *input_layernorm = nullptr, *post_attention_layernorm = nullptr;
   void *key_cache = nullptr, *value_cache = nullptr;
 };
@@ -170,6 +173,9 @@ struct Workspace {  // carve-up of the caller's scratch
   void *attn_ws;            // v2 partials
   float *exp_sums, *max_logits;
   void *sample_scratch;
+  int32_t *moe_ids;         // [B][top_k]
+  float *moe_w;             // [B][top_k]
+  void *moe_y;              // [top_k] Q8_1 rows of the selected experts' activations
 };
 
 class Llama {
@@ -205,6 +211,10 @@ class Llama {
     t += align(ya) + align(yb);
     t += align(B * c.num_heads * parts * c.head_dim * 4) + 2 * align(B * c.num_heads * parts * 4);
     t += align(B * 8);
+    if (c.num_experts > 0) {
+      const size_t k = std::max(1, (int)c.num_experts_per_tok);
+      t += align(B * k * 4) * 2 + align(k * (pad_to(c.intermediate_size, MATRIX_ROW_PADDING) / 32) * 36);
+    }
     return t + 4096;
   }
 
@@ -226,6 +236,11 @@ class Llama {
     ws.exp_sums = (float *)take(B * cfg.num_heads * parts * 4);
     ws.max_logits = (float *)take(B * cfg.num_heads * parts * 4);
     ws.sample_scratch = take(B * 8);
+    if (cfg.num_experts > 0) {
+      const size_t k = std::max(1, (int)cfg.num_experts_per_tok);
+      ws.moe_ids = (int32_t *)take(B * k * 4); ws.moe_w = (float *)take(B * k * 4);
+      ws.moe_y = take(k * (pad_to(cfg.intermediate_size, MATRIX_ROW_PADDING) / 32) * 36);
+    }
     // zero once: Q8_1 padding blocks beyond K are never written by the fused epilogues; sample scratch must start at 0
     if (hipMemset(b.workspace, 0, b.workspace_bytes) != hipSuccess) return fail("hipMemset(workspace) failed");
     have_bufs = true;
@@ -238,8 +253,9 @@ class Llama {
     if (!wte || !lm_head || !ln_f) return fail("model is missing token_embd / output / output_norm");
     for (size_t i = 0; i < blocks.size(); ++i) {
       const Block &bl = blocks[i];
-      if (!bl.q_proj || !bl.k_proj || !bl.v_proj || !bl.o_proj || !bl.gate_proj || !bl.up_proj || !bl.down_proj ||
-          !bl.input_layernorm || !bl.post_attention_layernorm)
+      const bool ffn = cfg.num_experts > 0 ? (bl.router && bl.gate_exps.data && bl.up_exps.data && bl.down_exps.data)
+                                           : (bl.gate_proj && bl.up_proj && bl.down_proj);
+      if (!bl.q_proj || !bl.k_proj || !bl.v_proj || !bl.o_proj || !ffn || !bl.input_layernorm || !bl.post_attention_layernorm)
         return fail("layer %zu is missing tensors", i);
       if (!bl.key_cache || !bl.value_cache) return fail("layer %zu has no KV cache", i);
     }
@@ -251,9 +267,14 @@ class Llama {
     auto hot = [](const std::unique_ptr<GgufMatMul> &m) { return mrs_decode_gemv_supported(m->get_qtensor()->dtype) != 0; };
     if (!hot(lm_head)) return false;
     for (const Block &bl : blocks) {
-      if (!hot(bl.q_proj) || !hot(bl.k_proj) || !hot(bl.v_proj) || !hot(bl.o_proj) || !hot(bl.gate_proj) || !hot(bl.down_proj)) return false;
-      if (bl.gate_proj->get_qtensor()->dtype != bl.up_proj->get_qtensor()->dtype) return false;
+      if (!hot(bl.q_proj) || !hot(bl.k_proj) || !hot(bl.v_proj) || !hot(bl.o_proj)) return false;
       if (cfg.intermediate_size % 32) return false;
+      if (cfg.num_experts > 0) {
+        if (!mrs_decode_gemv_supported(bl.gate_exps.dtype) || !mrs_decode_gemv_supported(bl.down_exps.dtype) || bl.gate_exps.dtype != bl.up_exps.dtype) return false;
+        continue;
+      }
+      if (!hot(bl.gate_proj) || !hot(bl.down_proj)) return false;
+      if (bl.gate_proj->get_qtensor()->dtype != bl.up_proj->get_qtensor()->dtype) return false;
     }
     return true;
   }
@@ -336,6 +357,29 @@ class Llama {
       // TP: h <- h / world + W_o . attn on every rank, then ONE sum all-reduce of h gives h + sum of the partials (division by a
       // power of two is exact), so the residual add stays fused and nothing else crosses GPUs
       if (!(ab & 4) && (mrs_decode_proj_scaled(o->data, o->dtype, d, nq, ws.y_a, stride_q, ws.h, d, rs, b, s) || all_reduce(ws.h, (size_t)b * d, s))) return fail("o_proj failed: %s", g_last_error.c_str());
+      if (cfg.num_experts > 0) {
+        // SparseMoeBlock::forward (models/mixtral.rs:280-304): router on the normed hidden state, then per token the top-k experts'
+        // fused gate/up (+SiLU*up -> Q8_1) and down GEMVs, accumulated into h with the renormalised routing weights.  Expert ids and
+        // weights stay on the device (the kernels read them), so the step is graph-capturable.
+        if (cfg.world_size > 1) return fail("tensor-parallel MoE is not supported yet");
+        const int E = cfg.num_experts, tk = cfg.num_experts_per_tok;
+        const size_t g_stride = bl.gate_exps.nbytes() / E, d_stride = bl.down_exps.nbytes() / E;
+        const size_t y_row = (size_t)stride_f * 36;
+        mrs_rms_norm_f32(ws.h, bl.post_attention_layernorm, ws.xn, b, d, cfg.rms_eps, (int64_t)(intptr_t)s);
+        if (mrs_moe_router_topk(ws.xn, bl.router, b, E, d, tk, 1, ws.moe_ids, ws.moe_w, nullptr, s)) return fail("moe router refused (experts %d, top-k %d)", E, tk);
+        for (int t = 0; t < b; ++t) {
+          float *ht = ws.h + (size_t)t * d;
+          for (int sl = 0; sl < tk; ++sl)  // all of a token's expert activations are computed before h changes
+            if (mrs_moe_decode_gate_up(bl.gate_exps.data, bl.up_exps.data, g_stride, ws.moe_ids + t * tk + sl, bl.gate_exps.dtype, ff, d, ht,
+                                       bl.post_attention_layernorm, cfg.rms_eps, 0, (char *)ws.moe_y + sl * y_row, stride_f, s))
+              return fail("moe gate/up refused");
+          for (int sl = 0; sl < tk; ++sl)
+            if (mrs_moe_decode_down(bl.down_exps.data, d_stride, ws.moe_ids + t * tk + sl, ws.moe_w + t * tk + sl, bl.down_exps.dtype, d, ff,
+                                    (char *)ws.moe_y + sl * y_row, stride_f, ht, s))
+              return fail("moe down refused");
+        }
+        continue;
+      }
       const QTensor *g = bl.gate_proj->get_qtensor(), *u = bl.up_proj->get_qtensor(), *dn = bl.down_proj->get_qtensor();
       if (!(ab & 8) && mrs_decode_gate_up(g->data, u->data, g->dtype, ff, d, ws.h, bl.post_attention_layernorm, cfg.rms_eps, 0, ws.y_b, stride_f, b, s))
         return fail("mrs_decode_gate_up refused");
@@ -363,6 +407,7 @@ class Llama {
   }
   int prefill(const mrs_llama_prefill_args &pa, int T, hipStream_t s) const {
     if (T <= 0) return fail("prefill: T must be positive");
+    if (cfg.num_experts > 0) return fail("prefill: MoE models run their prompt through the decode kernels (prefill_chunked)");
     const int start_pos = pa.start_pos;
     if (!wte || !lm_head || !ln_f) return fail("model is missing token_embd / output / output_norm");
     if (pa.workspace_bytes < prefill_workspace_bytes(cfg, T)) return fail("prefill workspace too small");
@@ -478,6 +523,7 @@ class Llama {
 
   int forward_logits(int b, hipStream_t s) const {
     if (check_ready(b)) return -1;
+    if (cfg.num_experts > 0 && !fused_ok()) return fail("MoE layers need the fused decode path (interleaved RoPE, q4_k/q5_k/q6_k/q8_0 weights, use_fused)");
     return fused_ok() ? forward_fused(b, s) : forward_unfused(b, s);
   }
 
@@ -495,6 +541,10 @@ class Llama {
     for (const Block &bl : blocks)
       for (const auto *m : {&bl.q_proj, &bl.k_proj, &bl.v_proj, &bl.o_proj, &bl.gate_proj, &bl.up_proj, &bl.down_proj})
         if (*m) t += (double)(*m)->get_qtensor()->nbytes();
+    if (cfg.num_experts > 0)  // per token only the top-k experts of every layer are streamed (+ the router)
+      for (const Block &bl : blocks)
+        t += (double)b * cfg.num_experts_per_tok * (double)(bl.gate_exps.nbytes() + bl.up_exps.nbytes() + bl.down_exps.nbytes()) / cfg.num_experts +
+             (double)cfg.num_experts * cfg.hidden_size * 4.0;
     if (lm_head) t += (double)lm_head->get_qtensor()->nbytes();
     if (wte) { const auto *ti = type_info(wte->get_qtensor()->dtype); t += (double)b * (wte->get_qtensor()->cols / ti->block) * ti->bytes; }
     t += (double)b * 2.0 * cfg.num_layers * cfg.num_kv_heads * cfg.head_dim * (double)ctx * 2.0;  // bf16 K + V
@@ -532,6 +582,22 @@ static int bind_tensor(Llama &m, const std::string &name, const void *p, int typ
     if (rest == "ffn_gate.weight") return lin(b.gate_proj, ff, d);
     if (rest == "ffn_up.weight") return lin(b.up_proj, ff, d);
     if (rest == "ffn_down.weight") return lin(b.down_proj, d, ff);
+    // Mixtral (gguf/normal_bindings.rs, models/mixtral.rs:236-279): router + experts stacked over the leading axis
+    const int64_t E = c.num_experts;
+    auto exps = [&](QTensor &slot, int64_t er, int64_t ec) {
+      if (E <= 0) return fail("tensor %s: the config has no experts", name.c_str());
+      if (rows != E * er || cols != ec) return fail("tensor %s: shape [%lld, %lld], expected [%lld x %lld, %lld]", name.c_str(), (long long)rows, (long long)cols, (long long)E, (long long)er, (long long)ec);
+      slot = QTensor{p, type, rows, cols};
+      return 0;
+    };
+    if (rest == "ffn_gate_inp.weight") {
+      if (type != F32 || rows != E || cols != d) return fail("tensor %s: the router must be F32 [%lld, %lld]", name.c_str(), (long long)E, (long long)d);
+      b.router = (const float *)p;
+      return 0;
+    }
+    if (rest == "ffn_gate_exps.weight") return exps(b.gate_exps, ff, d);
+    if (rest == "ffn_up_exps.weight") return exps(b.up_exps, ff, d);
+    if (rest == "ffn_down_exps.weight") return exps(b.down_exps, d, ff);
   }
   return fail("tensor %s: no binding for this name", name.c_str());
 }
@@ -545,7 +611,8 @@ extern "C" size_t mrs_llama_workspace_bytes(const mrs_llama_config *cfg) { retur
 extern "C" void *mrs_llama_create(const mrs_llama_config *cfg) {
   if (!cfg || cfg->num_layers <= 0 || cfg->hidden_size <= 0 || cfg->num_heads <= 0 || cfg->num_kv_heads <= 0 ||
       cfg->num_heads % cfg->num_kv_heads || cfg->head_dim <= 0 || cfg->max_batch <= 0 || cfg->max_batch > 8 ||
-      cfg->rot_dim > cfg->head_dim || (cfg->rot_dim & 1)) {
+      cfg->rot_dim > cfg->head_dim || (cfg->rot_dim & 1) || cfg->num_experts < 0 ||
+      (cfg->num_experts > 0 && (cfg->num_experts_per_tok < 1 || cfg->num_experts_per_tok > cfg->num_experts))) {
     mrs_host::fail("mrs_llama_create: invalid config");
     return nullptr;
   }

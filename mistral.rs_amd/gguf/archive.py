@@ -182,7 +182,9 @@ class GgufArchive:
                   num_kv_heads=int(md.get(f"{arch}.attention.head_count_kv", heads)), vocab_size=int(vocab), head_dim=rope_dim,
                   rms_eps=float(md.get(f"{arch}.attention.layer_norm_rms_epsilon", 1e-5)), rope_theta=float(md.get(f"{arch}.rope.freq_base", 10000.0)),
                   rope_scaling=scaling, rope_interleaved=True,  # GGUF llama/mistral: adjacent pairs (normal_registry.rs:446-461)
-                  max_position_embeddings=int(md.get(f"{arch}.context_length", 8192)))
+                  max_position_embeddings=int(md.get(f"{arch}.context_length", 8192)),
+                  # Mixtral ships as architecture "llama" with expert_count / expert_used_count (gguf/normal_config.rs)
+                  num_experts=int(md.get(f"{arch}.expert_count", 0) or 0), num_experts_per_tok=int(md.get(f"{arch}.expert_used_count", 2) or 2))
         kw.update(overrides)
         return LlamaConfig(**kw)
 
@@ -204,8 +206,12 @@ def load_llama(path: str, device, **cfg_overrides):
         raw = torch.from_numpy(ar.tensor_bytes(name).copy())
         if t.dtype == GgmlDType.F32 and len(t.shape) == 1:
             m.set_tensor(name, raw.view(torch.float32))
+        elif t.dtype == GgmlDType.F32 and len(t.shape) == 2:  # MoE router ffn_gate_inp [experts, hidden]
+            m.set_tensor(name, raw.view(torch.float32).reshape(t.shape))
         elif len(t.shape) == 2:
             m.set_tensor(name, QTensor(t.dtype, t.shape, raw.to(device)))
+        elif len(t.shape) == 3 and name.endswith("_exps.weight"):  # stacked experts [E, n, k] -> [E * n, k] (same bytes)
+            m.set_tensor(name, QTensor(t.dtype, (t.shape[0] * t.shape[1], t.shape[2]), raw.to(device)))
         else:
             raise GgufError(f"tensor {name}: no binding for shape {t.shape} / {t.dtype.name}")
     if "output.weight" not in ar.tensors:

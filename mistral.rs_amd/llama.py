@@ -45,6 +45,8 @@ class LlamaConfig:
     use_fused: bool = True
     tp_world_size: int = 1  # tensor parallel: num_heads / num_kv_heads / intermediate_size are the LOCAL (per-rank) sizes
     tp_rank: int = 0
+    num_experts: int = 0           # > 0: Mixtral-style sparse MoE FFN in every layer (models/mixtral.rs:236-304)
+    num_experts_per_tok: int = 2   # router top-k
 
     def __post_init__(self):
         if self.head_dim is None:
@@ -53,6 +55,11 @@ class LlamaConfig:
     @property
     def max_blocks_per_seq(self) -> int:
         return (self.max_context_len + self.block_size - 1) // self.block_size + 1
+
+    @classmethod
+    def mixtral_8x7b(cls, **kw):
+        return cls(hidden_size=4096, intermediate_size=14336, num_layers=32, num_heads=32, num_kv_heads=8, vocab_size=32000,
+                   rope_theta=1e6, num_experts=8, num_experts_per_tok=2, **kw)
 
     @classmethod
     def llama3_8b(cls, **kw):
@@ -93,7 +100,8 @@ def rope_tables(cfg: LlamaConfig, freq_factors: np.ndarray | None = None):
 class _Cfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("hidden_size", "intermediate_size", "num_layers", "num_heads", "num_kv_heads", "head_dim",
                                          "vocab_size", "rot_dim", "rope_interleaved")] + [("rms_eps", C.c_float)] + \
-               [(n, C.c_int32) for n in ("block_size", "max_blocks_per_seq", "max_batch", "max_context_len", "use_fused", "world_size", "rank")]
+               [(n, C.c_int32) for n in ("block_size", "max_blocks_per_seq", "max_batch", "max_context_len", "use_fused", "world_size", "rank",
+                                         "num_experts", "num_experts_per_tok")]
 
 
 class _PrefillArgs(C.Structure):
@@ -138,7 +146,8 @@ class Llama:
         L.mrs_last_error.restype = C.c_char_p
         c = _Cfg(cfg.hidden_size, cfg.intermediate_size, cfg.num_layers, cfg.num_heads, cfg.num_kv_heads, cfg.head_dim,
                  cfg.vocab_size, cfg.head_dim, int(cfg.rope_interleaved), cfg.rms_eps, cfg.block_size, cfg.max_blocks_per_seq,
-                 cfg.max_batch, cfg.max_context_len, int(cfg.use_fused), cfg.tp_world_size, cfg.tp_rank)
+                 cfg.max_batch, cfg.max_context_len, int(cfg.use_fused), cfg.tp_world_size, cfg.tp_rank, cfg.num_experts,
+                 cfg.num_experts_per_tok if cfg.num_experts else 0)
         self._c = c
         self._h = L.mrs_llama_create(C.byref(c))
         if not self._h:

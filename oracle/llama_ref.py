@@ -69,11 +69,35 @@ class LlamaRef:
             att = O.attention(q, np.stack(self.k[l]), np.stack(self.v[l]), 1.0 / np.sqrt(hd))
             h = h + self.linear(p + "attn_output.weight", att.reshape(1, H * hd))
             xn = O.rms_norm(h, self.w[p + "ffn_norm.weight"], c.rms_eps)
+            if p + "ffn_gate_inp.weight" in self.w:
+                h = h + self.moe(p, xn)
+                continue
             g = self.linear(p + "ffn_gate.weight", xn)
             u = self.linear(p + "ffn_up.weight", xn)
             h = h + self.linear(p + "ffn_down.weight", O.fused_glu(g, u, 0))
         xn = O.rms_norm(h, self.w["output_norm.weight"], c.rms_eps)
         return self.linear("output.weight", xn)[0]
+
+    def moe(self, p: str, xn: np.ndarray) -> np.ndarray:
+        """SparseMoeBlock::forward (models/mixtral.rs:280-304) for one token: router logits = xn @ Wr^T (f32), softmax over all experts,
+        top-k (ties: lower index first), renormalise (moe_router_topk, ops.rs:259-336); y = sum_j w_j * down_j(silu(gate_j xn) * up_j xn)."""
+        c = self.cfg
+        logits = (xn.astype(np.float32) @ self.w[p + "ffn_gate_inp.weight"].astype(np.float32).T)[0].astype(np.float64)
+        pr = np.exp(logits - logits.max())
+        pr /= pr.sum()
+        ids = sorted(range(len(pr)), key=lambda e: (-pr[e], e))[: c.num_experts_per_tok]
+        wts = pr[ids] / pr[ids].sum()
+        self.last_route = (ids, wts)
+        out = np.zeros_like(xn, dtype=np.float64)
+        ff = c.intermediate_size
+        for e, wt in zip(ids, wts):
+            tg, pg = self.w[p + "ffn_gate_exps.weight"]
+            tu, pu = self.w[p + "ffn_up_exps.weight"]
+            td, pd = self.w[p + "ffn_down_exps.weight"]
+            self.w["_g"], self.w["_u"], self.w["_d"] = (tg, pg[e * ff:(e + 1) * ff]), (tu, pu[e * ff:(e + 1) * ff]), (td, pd[e * c.hidden_size:(e + 1) * c.hidden_size])
+            act = O.fused_glu(self.linear("_g", xn), self.linear("_u", xn), 0)
+            out += np.float64(np.float32(wt)) * self.linear("_d", act).astype(np.float64)
+        return out.astype(np.float32)
 
     def run(self, tokens, start_pos: int = 0) -> np.ndarray:
         return np.stack([self.step(int(t), start_pos + i) for i, t in enumerate(tokens)])
@@ -99,6 +123,13 @@ def synth_weights(cfg, types: dict, seed: int = 0, w_std: float = 0.05) -> dict:
         w[p + "attn_k.weight"] = lin("k", nkv, d)
         w[p + "attn_v.weight"] = lin("v", nkv, d)
         w[p + "attn_output.weight"] = lin("o", d, nq)
+        E = getattr(cfg, "num_experts", 0)
+        if E:  # Mixtral: F32 router + experts stacked over the leading axis
+            w[p + "ffn_gate_inp.weight"] = (rng.standard_normal((E, d)) * 0.5).astype(np.float32)
+            w[p + "ffn_gate_exps.weight"] = lin("gate", E * ff, d)
+            w[p + "ffn_up_exps.weight"] = lin("up", E * ff, d)
+            w[p + "ffn_down_exps.weight"] = lin("down", E * d, ff)
+            continue
         w[p + "ffn_gate.weight"] = lin("gate", ff, d)
         w[p + "ffn_up.weight"] = lin("up", ff, d)
         w[p + "ffn_down.weight"] = lin("down", d, ff)

@@ -95,3 +95,47 @@ def test_loaded_model_matches_direct_build(oracle, dev, tmp_path, tied):
     for pos, tok in enumerate([3, 77, 200, 511]):
         m.set_state([tok], [pos]); direct.set_state([tok], [pos])
         assert torch.equal(m.forward_logits(1), direct.forward_logits(1))
+
+
+@pytest.mark.gpu
+def test_mixtral_gguf_loads_and_matches_direct_build(oracle, dev, tmp_path):
+    """Mixtral-style file: architecture "llama" + expert_count / expert_used_count, F32 router, rank-3 stacked expert tensors."""
+    import torch
+    import mistralrs_amd  # noqa: F401
+    from mistralrs_amd.gguf import GgmlDType, QTensor, archive
+    from mistralrs_amd.llama import Llama, LlamaConfig
+    from oracle import llama_ref
+    cfg = LlamaConfig(hidden_size=256, intermediate_size=512, num_layers=2, num_heads=4, num_kv_heads=2, vocab_size=512, head_dim=64,
+                      rope_theta=10000.0, max_position_embeddings=256, max_batch=1, max_context_len=128, num_experts=4, num_experts_per_tok=2)
+    types = dict(embd=oracle.Q4_K, q=oracle.Q4_K, k=oracle.Q4_K, v=oracle.Q6_K, o=oracle.Q4_K, gate=oracle.Q4_K, up=oracle.Q4_K, down=oracle.Q6_K, output=oracle.Q6_K)
+    w = llama_ref.synth_weights(cfg, types, seed=9)
+    md = {"general.architecture": "llama", "llama.embedding_length": 256, "llama.feed_forward_length": 512, "llama.block_count": 2,
+          "llama.attention.head_count": 4, "llama.attention.head_count_kv": 2, "llama.attention.layer_norm_rms_epsilon": 1e-5,
+          "llama.rope.freq_base": 10000.0, "llama.rope.dimension_count": 64, "llama.context_length": 256, "llama.vocab_size": 512,
+          "llama.expert_count": 4, "llama.expert_used_count": 2}
+    tensors = {}
+    for name, val in w.items():
+        if isinstance(val, tuple):
+            dt = GgmlDType.from_id(val[0])
+            rows, cols = val[1].shape[0], val[1].shape[1] // dt.type_size * dt.block_size
+            shape = (4, rows // 4, cols) if name.endswith("_exps.weight") else (rows, cols)
+            tensors[name] = (dt, shape, val[1])
+        else:
+            tensors[name] = (GgmlDType.F32, val.shape, val.astype(np.float32).view(np.uint8))
+    path = os.path.join(str(tmp_path), "tiny_moe.gguf")
+    archive.write_gguf(path, md, tensors)
+    ar = archive.GgufArchive(path)
+    got_cfg = ar.llama_config(max_context_len=128, max_batch=1)
+    assert got_cfg.num_experts == 4 and got_cfg.num_experts_per_tok == 2 and ar.tensors["blk.0.ffn_gate_exps.weight"].shape == (4, 512, 256)
+    ar.close()
+    m = archive.load_llama(path, dev, max_context_len=128, max_batch=1)
+    direct = Llama(cfg, dev, max_new_tokens=16)
+    for name, val in w.items():
+        if isinstance(val, tuple):
+            dt = GgmlDType.from_id(val[0])
+            direct.set_tensor(name, QTensor.from_numpy(dt, (val[1].shape[0], val[1].shape[1] // dt.type_size * dt.block_size), val[1], dev))
+        else:
+            direct.set_tensor(name, torch.from_numpy(val))
+    for pos, tok in enumerate([3, 77, 200, 511]):
+        m.set_state([tok], [pos]); direct.set_state([tok], [pos])
+        assert torch.equal(m.forward_logits(1), direct.forward_logits(1))
