@@ -393,6 +393,9 @@ class Llama {
 
   // ---- prefill: T prompt tokens of one sequence through the bf16-MFMA GEMMs (role of fast_mmq::* + the prompt branch
   //      of PagedAttention::forward).  Buffers are carved from the caller's prefill workspace.
+  // prompts longer than this use the 256-row-tile GEMM over bf16 slabs (its L1-bypassing A loads beat the 128-row f32 kernel even when
+  // half of the tile rows are empty: TTFT 16.3 -> 10.1 ms at T = 128, 19.5 -> 8.3 ms at T = 64, 18.5 -> 7.7 ms at T = 32)
+  static int prefill_big_min() { static int v = -1; if (v < 0) { const char *e = getenv("MRS_PREFILL_BIG_MIN"); v = e ? atoi(e) : 16; } return v; }
   static size_t prefill_workspace_bytes(const mrs_llama_config &c, int T) {
     const size_t t = (size_t)T, d = c.hidden_size, nq = (size_t)c.num_heads * c.head_dim, nkv = (size_t)c.num_kv_heads * c.head_dim;
     const size_t ff = c.intermediate_size;
@@ -402,7 +405,7 @@ class Llama {
     b += align(t * nkv * 4) * 2;      // k, v
     b += align(t * ff * 4) * 3;       // gate, up, act
     b += align((pad_to((int)d, MATRIX_ROW_PADDING) / 32) * 36);  // Q8_1 scratch of the last-token lm_head GEMV
-    if (T > 128) b += align(t * std::max(std::max(d, nq), ff) * 2) + align(mrs_gemm_q_bf16_workspace_bytes(T));  // bf16 activations + split-K partials
+    if (T > prefill_big_min()) b += align(t * std::max(std::max(d, nq), ff) * 2) + align(mrs_gemm_q_bf16_workspace_bytes(T));  // bf16 activations + split-K partials
     return b + 4096;
   }
   int prefill(const mrs_llama_prefill_args &pa, int T, hipStream_t s) const {
@@ -421,7 +424,7 @@ class Llama {
     float *g = (float *)take(t * ff * 4), *u = (float *)take(t * ff * 4), *act = (float *)take(t * ff * 4);
     const int64_t st = (int64_t)(intptr_t)s;
     // T > 128: the 256-row-tile kernel over bf16 activations (converted once per GEMM group), split-K partials in `part`
-    const bool big = T > 128 && !getenv("MRS_PREFILL_SMALL_TILES");
+    const bool big = T > prefill_big_min() && !getenv("MRS_PREFILL_SMALL_TILES");
     const size_t part_bytes = big ? mrs_gemm_q_bf16_workspace_bytes(T) : 0;
     void *xb = big ? take(t * std::max(std::max(d, nq), ff) * 2) : nullptr, *part = big ? take(part_bytes) : nullptr;
     const float *xb_src = nullptr;    // which f32 buffer xb currently mirrors (within one GEMM group)
