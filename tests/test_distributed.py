@@ -150,3 +150,32 @@ def test_rccl_comm_world1_and_runner(oracle, dev):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_llama3_70b_tp8_placement_shapes():
+    """BASELINE configs[3] (Llama-3-70B Q4_K_M, TP=8): per-rank shapes as SURVEY 8a lists them (q 1024x8192, k/v 128x8192 = one KV head
+    per rank, o 8192x1024, gate/up 3584x8192, down 8192x3584) and every row-parallel cut on a 256-weight superblock boundary."""
+    from mistralrs_amd import distributed as D
+    d, ff, heads, kvh, hd, world = 8192, 28672, 64, 8, 128, 8
+    total = dict(num_kv_heads=kvh, head_dim=hd)
+    assert D.local_dims(heads, kvh, ff, world) == (8, 1, 3584)
+    full = {"blk.0.attn_q.weight": (heads * hd, d), "blk.0.attn_k.weight": (kvh * hd, d), "blk.0.attn_v.weight": (kvh * hd, d),
+            "blk.0.attn_output.weight": (d, heads * hd), "blk.0.ffn_gate.weight": (ff, d), "blk.0.ffn_up.weight": (ff, d),
+            "blk.0.ffn_down.weight": (d, ff)}
+    want = {"attn_q": (1024, 8192), "attn_k": (128, 8192), "attn_v": (128, 8192), "attn_output": (8192, 1024), "ffn_gate": (3584, 8192),
+            "ffn_up": (3584, 8192), "ffn_down": (8192, 3584)}
+    for rank in range(world):
+        covered = {}
+        for name, (n, k) in full.items():
+            sh = D.llama_tensor_shard(name, total, rank, world)
+            lo, hi = sh.bounds(n if sh.dim == 0 else k)
+            shape = (hi - lo, k) if sh.dim == 0 else (n, hi - lo)
+            assert shape == want[name.split(".")[2]], (name, rank, shape)
+            if sh.dim == 1:
+                assert lo % 256 == 0 and hi % 256 == 0, (name, rank, lo, hi)  # K-quant superblocks stay whole
+            covered[name] = (lo, hi)
+        assert covered["blk.0.attn_k.weight"] == (rank * hd, (rank + 1) * hd)  # KV head `rank`
+    for name in ("token_embd.weight", "output_norm.weight", "output.weight", "blk.3.attn_norm.weight"):
+        assert D.llama_tensor_shard(name, total, 3, world) is None  # replicated
+    with pytest.raises(ValueError):
+        D.local_dims(heads, kvh, ff, 7)
