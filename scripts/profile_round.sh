@@ -5,7 +5,7 @@ set -u
 export TMPDIR=/tmp
 OUT=gpurun_out/${1:-final}
 mkdir -p $OUT
-(timeout 1200 python -m pytest tests -q -m gpu 2>&1 | tail -4) > $OUT/pytest_gpu.log
+(timeout 1500 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3) > $OUT/pytest_gpu.log
 (timeout 900 python bench.py 2>&1 | tail -1) > $OUT/bench_default.log
 (timeout 300 python __graft_entry__.py smoke 2>&1 | tail -2) > $OUT/smoke.log
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o r -- python bench.py --no-cpu-baseline > $OUT/kt.log 2>&1
