@@ -5,6 +5,8 @@
 #                            up to the "Core mat-vec-q template" marker) + ref_shim/mmvq_driver.inc
 #   _ref/libref_affine.so <- head of kernels/gguf_affine_packed/marlin_gguf_affine_repack.cu (block structs, get_quant,
 #                            get_affine_params: the in-tree GGUF format spec) + ref_shim/affine_driver.inc
+#   _ref/libref_cache.so  <- kernels/rotary/rotary.cu (namespace vllm), reshape_and_cache_kernel.cu, gather_kv_cache_kernel.cu,
+#                            copy_blocks_kernel.cu kernels (f32 instantiations), run by ref_shim/cache_driver.inc
 #   _ref/libref_hqq.so    <- the __global__ kernel templates of kernels/hqq/hqq.cu (dequantize_*) and hqq_bitpack.cu (pack_*),
 #                            run one thread at a time by ref_shim/hqq_driver.inc
 # The reference text is STREAMED into g++ (stdin); nothing from /root/reference is written into this repo.
@@ -32,4 +34,17 @@ KERNELS='/^template <typename T>$/{t=$0; next} /^__global__ void /{if (t != "") 
   awk "$KERNELS" "$HQQ_DIR/hqq.cu"
   awk "$KERNELS" "$HQQ_DIR/hqq_bitpack.cu"
   cat "$HERE/ref_shim/hqq_driver.inc" ) | $CXX $FLAGS -o "$OUT/libref_hqq.so" -
-echo "oracle/_ref: built libref_mmvq.so libref_affine.so libref_hqq.so from $REF"
+# RoPE + paged-cache data movement: the rotary namespace block as a whole (no launch syntax inside), the three cache kernels by name
+PA_DIR="$REF/mistralrs-paged-attn/src/cuda"
+ONE='$0 ~ start {p=1; if (t != "") print t} /^template </{t=$0; if (!p) next} {if (!p) t=""} p{print} p && /^}$/{exit}'
+( cat "$HERE/ref_shim/cuda_shim.h"
+  echo '#define VLLM_LDG(arg) *(arg)'
+  awk '/^namespace vllm \{/{p=1} p{print} /^} \/\/ namespace vllm/{exit}' "$REF/mistralrs-quant/kernels/rotary/rotary.cu"
+  echo 'namespace vllm { enum class Fp8KVCacheDataType { kAuto, kFp8E4M3, kFp8E5M2 };'
+  echo 'namespace fp8 { template <class O, class I, Fp8KVCacheDataType K> static O scaled_convert(const I &, float) { return O{}; } }'
+  awk -v start='^__global__ void reshape_and_cache_kernel' "$ONE" "$PA_DIR/reshape_and_cache_kernel.cu"
+  awk -v start='^__global__ void gather_kv_cache_kernel' "$ONE" "$PA_DIR/gather_kv_cache_kernel.cu"
+  echo '}'
+  awk -v start='^copy_blocks_internal_kernel' '/^template </{t=$0; next} /^__device__ void$/{d=$0; next} $0 ~ start {p=1; print t; print d} p{print} p && /^}$/{exit}' "$PA_DIR/copy_blocks_kernel.cu"
+  cat "$HERE/ref_shim/cache_driver.inc" ) | $CXX $FLAGS -o "$OUT/libref_cache.so" -
+echo "oracle/_ref: built libref_mmvq.so libref_affine.so libref_hqq.so libref_cache.so from $REF"

@@ -15,6 +15,9 @@
 #define __forceinline__ inline
 #define __align__(n) alignas(n)
 #define __launch_bounds__(...)
+#ifndef __restrict__
+#define __restrict__ __restrict
+#endif
 
 struct float2 { float x, y; };
 // thread coordinates for the reference __global__ kernels that hqq_driver.inc runs one thread at a time

@@ -58,6 +58,37 @@ def main():
                                          out.ctypes.data_as(C.c_void_p), h, w) == 0
         np.savez_compressed(os.path.join(GOLD, f"hqq_{bits}bit.npz"), bits=np.int32(bits), q=q, packed_ref=packed, scale=scale, zero=zero, out_ref=out)
         print(f"golden: hqq_{bits}bit.npz  out[0,:3]={out[0,:3]}")
+    # RoPE + paged-cache data movement: outputs of the reference's own kernels run on the host (oracle/_ref/libref_cache.so)
+    ca = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_cache.so"))
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    rng = np.random.default_rng(77)
+    T, H, KVH, hd, pairs, max_pos = 6, 4, 2, 64, 24, 50  # partial rotary: 48 of 64 dims
+    q = rng.standard_normal((T, H, hd)).astype(np.float32)
+    k = rng.standard_normal((T, KVH, hd)).astype(np.float32)
+    ang = rng.uniform(0, 6.28, (max_pos, pairs))
+    cos, sin = np.cos(ang).astype(np.float32), np.sin(ang).astype(np.float32)
+    pos = rng.integers(0, max_pos, T).astype(np.uint32)
+    rope = {}
+    for neox in (0, 1):
+        qo, ko = q.copy(), k.copy()
+        ca.ref_rotary_f32(vp(qo), vp(ko), vp(cos), vp(sin), vp(pos), neox, hd, T, pairs, H, KVH, C.c_long(H * hd), C.c_long(KVH * hd))
+        rope[f"q_out_{neox}"], rope[f"k_out_{neox}"] = qo, ko
+    kvh, hd2, nb, bs, x, T2 = 3, 32, 6, 16, 4, 23
+    key = rng.standard_normal((T2, kvh, hd2)).astype(np.float32)
+    val = rng.standard_normal((T2, kvh, hd2)).astype(np.float32)
+    slots = rng.permutation(nb * bs)[:T2].astype(np.int64)
+    slots[7] = -1
+    kc = np.zeros((nb, kvh, hd2 // x, bs, x), np.float32)
+    vc = np.zeros((nb, kvh, hd2, bs), np.float32)
+    ca.ref_reshape_and_cache_f32(vp(key), vp(val), vp(kc), vp(vc), vp(slots), T2, kvh, hd2, bs, x, kvh * hd2, kvh * hd2)
+    tables = np.stack([rng.permutation(nb)[:3], rng.permutation(nb)[:3]]).astype(np.int32)
+    cu = np.array([0, bs + 5, 3 * bs + 5], dtype=np.int32)
+    n = int(cu[-1])
+    k_out, v_out = np.zeros((n, kvh, hd2), np.float32), np.zeros((n, kvh, hd2), np.float32)
+    ca.ref_gather_kv_cache_f32(vp(kc), vp(vc), vp(k_out), vp(v_out), vp(tables), vp(cu), n, 2, bs, 3, kvh, hd2, x)
+    np.savez_compressed(os.path.join(GOLD, "cache_ops.npz"), q=q, k=k, cos=cos, sin=sin, pos=pos, **rope, key=key, val=val, slots=slots,
+                        kc_ref=kc, vc_ref=vc, tables=tables, cu=cu, k_gather_ref=k_out, v_gather_ref=v_out)
+    print("golden: cache_ops.npz")
 
 
 if __name__ == "__main__":

@@ -48,3 +48,48 @@ def test_hip_kernels_reproduce_golden(dev, path):
     tol = 8 * 2.0 ** -23 * np.sqrt(k / 16) * g["mag"].astype(np.float64) + 2.0 ** -23 * np.abs(g["out_ref"]) + 1e-30
     err = np.abs(got - g["out_ref"])
     assert (err <= tol).all(), float((err / tol).max())
+
+
+# ---- RoPE + paged-cache data movement: outputs of the reference's own kernels (scripts/gen_golden.py via oracle/_ref/libref_cache.so)
+CACHE_GOLD = os.path.join(GOLD, "cache_ops.npz")
+
+
+def test_oracle_reproduces_cache_ops_golden(oracle):
+    g = np.load(CACHE_GOLD)
+    for neox in (0, 1):
+        np.testing.assert_array_equal(oracle.rope(g["q"], g["cos"], g["sin"], g["pos"].astype(np.int32), bool(neox)).view(np.uint32), g[f"q_out_{neox}"].view(np.uint32))
+        np.testing.assert_array_equal(oracle.rope(g["k"], g["cos"], g["sin"], g["pos"].astype(np.int32), bool(neox)).view(np.uint32), g[f"k_out_{neox}"].view(np.uint32))
+    kc, vc = np.zeros_like(g["kc_ref"]), np.zeros_like(g["vc_ref"])
+    oracle.kv_cache_write(kc, vc, g["key"], g["val"], g["slots"])
+    np.testing.assert_array_equal(kc, g["kc_ref"])
+    np.testing.assert_array_equal(vc, g["vc_ref"])
+    cu = g["cu"]
+    for s in range(2):
+        kg, vg = oracle.kv_cache_gather(g["kc_ref"], g["vc_ref"], g["tables"][s], int(cu[s + 1] - cu[s]))
+        np.testing.assert_array_equal(kg, g["k_gather_ref"][cu[s]:cu[s + 1]])
+        np.testing.assert_array_equal(vg, g["v_gather_ref"][cu[s]:cu[s + 1]])
+
+
+@pytest.mark.gpu
+def test_hip_rope_and_cache_ops_reproduce_reference_golden(dev):
+    """f32 instantiations of rotary_embedding_positions / reshape_and_cache / gather_kv_cache == the reference kernels, bit for bit."""
+    import torch
+    from mistralrs_amd import ops, paged_attn
+    g = np.load(CACHE_GOLD)
+    cos, sin = torch.from_numpy(g["cos"]).to(dev), torch.from_numpy(g["sin"]).to(dev)
+    pos = torch.from_numpy(g["pos"].astype(np.int32)).to(dev)
+    for neox in (0, 1):
+        q, k = torch.from_numpy(g["q"]).to(dev), torch.from_numpy(g["k"]).to(dev)
+        ops.apply_rotary_qk(q, k, cos, sin, bool(neox), pos)
+        np.testing.assert_array_equal(q.cpu().numpy().view(np.uint32), g[f"q_out_{neox}"].view(np.uint32))
+        np.testing.assert_array_equal(k.cpu().numpy().view(np.uint32), g[f"k_out_{neox}"].view(np.uint32))
+        q2, k2 = torch.from_numpy(g["q"]).to(dev), torch.from_numpy(g["k"]).to(dev)
+        ops.apply_rotary_qk(q2, k2, cos[pos.long()].contiguous(), sin[pos.long()].contiguous(), bool(neox))  # per-token rows, no positions
+        assert torch.equal(q2, q) and torch.equal(k2, k)
+    kc, vc = torch.zeros(g["kc_ref"].shape, device=dev), torch.zeros(g["vc_ref"].shape, device=dev)
+    paged_attn.reshape_and_cache(torch.from_numpy(g["key"]).to(dev), torch.from_numpy(g["val"]).to(dev), kc, vc, torch.from_numpy(g["slots"]).to(dev))
+    np.testing.assert_array_equal(kc.cpu().numpy(), g["kc_ref"])
+    np.testing.assert_array_equal(vc.cpu().numpy(), g["vc_ref"])
+    k_out, v_out = paged_attn.gather_kv_cache(kc, vc, torch.from_numpy(g["tables"]).to(dev), torch.from_numpy(g["cu"]).to(dev), torch.float32)
+    np.testing.assert_array_equal(k_out.cpu().numpy(), g["k_gather_ref"])
+    np.testing.assert_array_equal(v_out.cpu().numpy(), g["v_gather_ref"])

@@ -70,3 +70,76 @@ def test_glu_activations_match_reference(oracle):
         for v in xs:
             a, r = L.orc_glu_act(float(v), act), lib.ref_glu_activation(float(v), act)
             assert abs(a - r) <= 2e-6 * max(1.0, abs(r)), (act, float(v), a, r)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# RoPE and paged-cache data movement: the reference's own __global__ kernels (kernels/rotary/rotary.cu,
+# mistralrs-paged-attn/src/cuda/{reshape_and_cache,gather_kv_cache,copy_blocks}_kernel.cu, f32 instantiations) run on the host,
+# one thread at a time (oracle/ref_shim/cache_driver.inc -> libref_cache.so)
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+@pytest.mark.parametrize("neox", [False, True])
+@pytest.mark.parametrize("rot_pairs,hd", [(32, 64), (16, 64), (64, 128)])
+def test_rope_matches_reference_kernel(oracle, neox, rot_pairs, hd):
+    lib = _ref("libref_cache.so")
+    rng = np.random.default_rng(rot_pairs + hd + int(neox))
+    T, H, KVH, max_pos = 5, 3, 2, 40
+    q = rng.standard_normal((T, H, hd)).astype(np.float32)
+    k = rng.standard_normal((T, KVH, hd)).astype(np.float32)
+    ang = rng.uniform(0, 6.28, (max_pos, rot_pairs))
+    cos, sin = np.cos(ang).astype(np.float32), np.sin(ang).astype(np.float32)
+    pos = rng.integers(0, max_pos, T).astype(np.uint32)
+    want_q, want_k = q.copy(), k.copy()
+    lib.ref_rotary_f32(_vp(want_q), _vp(want_k), _vp(cos), _vp(sin), _vp(pos), int(neox), hd, T, rot_pairs, H, KVH, C.c_long(H * hd), C.c_long(KVH * hd))
+    np.testing.assert_array_equal(oracle.rope(q, cos, sin, pos.astype(np.int32), neox).view(np.uint32), want_q.view(np.uint32))
+    np.testing.assert_array_equal(oracle.rope(k, cos, sin, pos.astype(np.int32), neox).view(np.uint32), want_k.view(np.uint32))
+    # the positions-free entry takes cos/sin rows per token
+    want2 = q.copy()
+    k2 = k.copy()
+    lib.ref_rotary_f32(_vp(want2), _vp(k2), _vp(np.ascontiguousarray(cos[pos])), _vp(np.ascontiguousarray(sin[pos])), None, int(neox), hd, T, rot_pairs, H, KVH,
+                       C.c_long(H * hd), C.c_long(KVH * hd))
+    np.testing.assert_array_equal(want2.view(np.uint32), want_q.view(np.uint32))
+
+
+@pytest.mark.parametrize("bs,x", [(16, 4), (32, 4), (8, 8)])
+def test_cache_ops_match_reference_kernels(oracle, bs, x):
+    lib = _ref("libref_cache.so")
+    rng = np.random.default_rng(bs + x)
+    kvh, hd, nb, T = 3, 32, 7, 19
+    key = rng.standard_normal((T, kvh, hd)).astype(np.float32)
+    val = rng.standard_normal((T, kvh, hd)).astype(np.float32)
+    slots = rng.permutation(nb * bs)[:T].astype(np.int64)
+    slots[4] = -1
+    kc_ref = rng.standard_normal((nb, kvh, hd // x, bs, x)).astype(np.float32)
+    vc_ref = rng.standard_normal((nb, kvh, hd, bs)).astype(np.float32)
+    kc, vc = kc_ref.copy(), vc_ref.copy()
+    lib.ref_reshape_and_cache_f32(_vp(key), _vp(val), _vp(kc_ref), _vp(vc_ref), _vp(slots), T, kvh, hd, bs, x, kvh * hd, kvh * hd)
+    oracle.kv_cache_write(kc, vc, key, val, slots)
+    np.testing.assert_array_equal(kc, kc_ref)
+    np.testing.assert_array_equal(vc, vc_ref)
+    # gather two sequences of different lengths through their block tables
+    lens = [bs + 3, 2 * bs]
+    tables = np.stack([rng.permutation(nb)[:3], rng.permutation(nb)[:3]]).astype(np.int32)
+    cu = np.array([0, lens[0], lens[0] + lens[1]], dtype=np.int32)
+    n = int(cu[-1])
+    k_out, v_out = np.zeros((n, kvh, hd), np.float32), np.zeros((n, kvh, hd), np.float32)
+    lib.ref_gather_kv_cache_f32(_vp(kc), _vp(vc), _vp(k_out), _vp(v_out), _vp(tables), _vp(cu), n, 2, bs, 3, kvh, hd, x)
+    for s in range(2):
+        kg, vg = oracle.kv_cache_gather(kc, vc, tables[s], lens[s])
+        np.testing.assert_array_equal(kg, k_out[cu[s]:cu[s + 1]])
+        np.testing.assert_array_equal(vg, v_out[cu[s]:cu[s + 1]])
+    # copy_blocks: per-layer block copies src -> dst
+    layers_k = [rng.standard_normal((nb, 24)).astype(np.float32) for _ in range(2)]
+    layers_v = [rng.standard_normal((nb, 40)).astype(np.float32) for _ in range(2)]
+    want_k, want_v = [a.copy() for a in layers_k], [a.copy() for a in layers_v]
+    mapping = np.array([0, 5, 2, 6, 0, 3], dtype=np.int64)
+    for a in want_k + want_v:
+        for s_, d_ in mapping.reshape(-1, 2):
+            a[d_] = a[s_]
+    kp = np.array([a.ctypes.data for a in layers_k], dtype=np.int64)
+    vp = np.array([a.ctypes.data for a in layers_v], dtype=np.int64)
+    lib.ref_copy_blocks_f32(_vp(kp), _vp(vp), _vp(mapping), 2, 3, 24, 40)
+    for got, want in zip(layers_k + layers_v, want_k + want_v):
+        np.testing.assert_array_equal(got, want)
