@@ -141,7 +141,9 @@ __global__ void __launch_bounds__(NW * 64) paged_attention_kernel(const PagedAtt
       for (int m = BS; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
       float qk = a.scale * v;
       if (a.softcapping != 1.0f) qk = tanhf(qk / a.softcapping) * a.softcapping;
-      if (a.alibi_slopes) { const float s = a.alibi_slopes[head0 + g]; qk += (s != 0.f) ? s * (float)(token - (int)ctx + 1) : 0.f; }
+      // reference quirk kept for parity: context_len is uint32_t there (pagedattention.cuh:138), so `token_idx - context_len + 1` (:283) wraps:
+      // 0 for the last token, 2^32 - k for the k-th token before it (upstream vLLM: int, i.e. -k)
+      if (a.alibi_slopes) { const float s = a.alibi_slopes[head0 + g]; qk += (s != 0.f) ? s * (float)((uint32_t)token - ctx + 1u) : 0.f; }
       const bool masked = token >= (int)ctx;
       if (cpart == 0) logits[g * LS + token - start_tok] = masked ? 0.f : qk;
       if (!masked) qk_max[g] = fmaxf(qk_max[g], qk);

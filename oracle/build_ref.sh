@@ -7,6 +7,8 @@
 #                            get_affine_params: the in-tree GGUF format spec) + ref_shim/affine_driver.inc
 #   _ref/libref_cache.so  <- kernels/rotary/rotary.cu (namespace vllm), reshape_and_cache_kernel.cu, gather_kv_cache_kernel.cu,
 #                            copy_blocks_kernel.cu kernels (f32 instantiations), run by ref_shim/cache_driver.inc
+#   _ref/libref_pa.so     <- paged_attention_v1 / v2 / v2_reduce kernels (pagedattention.cuh:56-667 + attention/*.cuh, f32 path) executed
+#                            on host fibers with block barriers and warp shuffles (ref_shim/fiber_shim.h, pa_driver.inc)
 #   _ref/libref_hqq.so    <- the __global__ kernel templates of kernels/hqq/hqq.cu (dequantize_*) and hqq_bitpack.cu (pack_*),
 #                            run one thread at a time by ref_shim/hqq_driver.inc
 # The reference text is STREAMED into g++ (stdin); nothing from /root/reference is written into this repo.
@@ -47,4 +49,18 @@ ONE='$0 ~ start {p=1; if (t != "") print t} /^template </{t=$0; if (!p) next} {i
   echo '}'
   awk -v start='^copy_blocks_internal_kernel' '/^template </{t=$0; next} /^__device__ void$/{d=$0; next} $0 ~ start {p=1; print t; print d} p{print} p && /^}$/{exit}' "$PA_DIR/copy_blocks_kernel.cu"
   cat "$HERE/ref_shim/cache_driver.inc" ) | $CXX $FLAGS -o "$OUT/libref_cache.so" -
-echo "oracle/_ref: built libref_mmvq.so libref_affine.so libref_hqq.so libref_cache.so from $REF"
+# paged attention v1 / v2 / v2_reduce: the f32 path of the reference kernels on host fibers (ref_shim/fiber_shim.h).  Streamed: the
+# generic vector templates, the float32 dtype header, the fp8 enum header, the Q.K helper and pagedattention.cuh:56-667 (namespace vllm
+# up to the launch macros); includes / pragmas dropped, the dynamic shared-memory declaration pointed at the shim's buffer.
+ATT="$PA_DIR/attention"
+STRIP='/^#include/d; /^#pragma once/d'
+( cat "$HERE/ref_shim/cuda_shim.h" "$HERE/ref_shim/fiber_shim.h"
+  sed "$STRIP" "$ATT/attention_generic.cuh"; echo ''
+  sed "$STRIP" "$ATT/dtype_float32.cuh"; echo ''
+  sed "$STRIP" "$ATT/dtype_fp8.cuh"
+  echo ''  # the header has no trailing newline
+  echo 'namespace vllm { namespace fp8 { template <class O, class I, Fp8KVCacheDataType K> static O scaled_convert(const I &, float) { return O{}; } } }'
+  sed "$STRIP" "$ATT/attention_utils.cuh"; echo ''
+  sed -n '56,667p' "$PA_DIR/pagedattention.cuh" | sed 's/extern __shared__ char shared_mem\[\];/char *shared_mem = shim_fiber::dyn_smem;/'
+  cat "$HERE/ref_shim/pa_driver.inc" ) | $CXX $FLAGS -o "$OUT/libref_pa.so" -
+echo "oracle/_ref: built libref_mmvq.so libref_affine.so libref_hqq.so libref_cache.so libref_pa.so from $REF"

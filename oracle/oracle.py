@@ -265,7 +265,8 @@ def paged_attention_ref(q, key_cache, value_cache, block_tables, context_lens, s
                         sinks=None, round_p=None):
     """Decode attention semantics of pagedattention.cuh:110-486: one query per sequence, softmax over the
     context with inv = 1/(sum + 1e-6), optional sink logit, probabilities optionally rounded through
-    `round_p(array)->array` (the reference rounds them to the query dtype) before P.V.  f64 arithmetic."""
+    `round_p(array)->array` (the reference rounds them to the query dtype) before P.V.  f64 arithmetic.
+    Pinned to the reference kernels themselves (v1, v2 + reduce, f32) by tests/test_oracle_ref.py via oracle/_ref/libref_pa.so."""
     q = np.asarray(q, dtype=np.float64)
     seqs, heads, hd = q.shape
     kvh = key_cache.shape[1]
@@ -279,7 +280,13 @@ def paged_attention_ref(q, key_cache, value_cache, block_tables, context_lens, s
             if softcap != 1.0:
                 logit = np.tanh(logit / softcap) * softcap
             if alibi is not None and alibi[h] != 0:
-                logit = logit + alibi[h] * (np.arange(ctx) - ctx + 1)
+                # REFERENCE QUIRK, mirrored for parity: context_len is a uint32_t in the kernel (pagedattention.cuh:138), so the ALiBi
+                # distance `token_idx - context_len + 1` (:283) is evaluated in unsigned arithmetic: 0 for the last token, 2^32 - k for
+                # the k-th token before it; the f32 product and the f32 addition to qk are part of the observable result (the bias
+                # swamps qk).  Upstream vLLM has `int context_len` and gets the intended -k.
+                u = ((np.arange(ctx, dtype=np.int64) - ctx + 1) % (1 << 32)).astype(np.uint32)
+                bias = np.float32(alibi[h]) * u.astype(np.float32)
+                logit = (logit.astype(np.float32) + bias).astype(np.float32).astype(np.float64)
             m = logit.max() if sinks is None else max(logit.max(), float(sinks[h]))
             e = np.exp(logit - m)
             den = e.sum() + (np.exp(float(sinks[h]) - m) if sinks is not None else 0.0)

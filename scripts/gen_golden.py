@@ -21,6 +21,29 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 TYPES = [2, 3, 6, 7, 8, 10, 11, 12, 13, 14]
 
 
+PA_CASES = {
+    "gqa_sinks": dict(hd=128, bs=32, heads=8, kvh=2, ctxs=(1, 31, 33, 530), sinks=True),
+    "mha_alibi": dict(hd=64, bs=16, heads=4, kvh=4, ctxs=(1, 15, 17, 200), alibi=True),
+    "softcap": dict(hd=96, bs=8, heads=6, kvh=3, ctxs=(3, 8, 9, 70), softcap=6.0),
+}
+
+
+def paged_attn_case(hd, bs, heads, kvh, ctxs, sinks=False, alibi=False, softcap=1.0):
+    """Deterministic inputs from index formulas (shared with tests/test_golden.py): f32 K / V caches in the reference layouts (x = 4)."""
+    seqs = len(ctxs)
+    max_blocks = (max(ctxs) + bs - 1) // bs + 1
+    nb = seqs * max_blocks + 1
+    while np.gcd(7, nb) != 1:
+        nb += 1
+    bt = ((np.arange(seqs * max_blocks, dtype=np.int64) * 7 + 3) % nb).reshape(seqs, max_blocks).astype(np.uint32)
+    kc = O.patterned(nb * kvh * hd * bs, 5, 1.0).reshape(nb, kvh, hd // 4, bs, 4).astype(np.float32)
+    vc = O.patterned(nb * kvh * hd * bs, 11, 1.0).reshape(nb, kvh, hd, bs).astype(np.float32)
+    q = O.patterned(seqs * heads * hd, 2, 1.5).reshape(seqs, heads, hd).astype(np.float32)
+    al = (0.05 * (1 + np.arange(heads))).astype(np.float32) * np.float32(-1.0) if alibi else None
+    sk = (O.patterned(heads, 9, 1.0)).astype(np.float32) if sinks else None
+    return q, kc, vc, bt, list(ctxs), al, sk, np.float32(1.0 / np.sqrt(hd))
+
+
 def main():
     O.build()
     mm = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_mmvq.so"))
@@ -89,6 +112,27 @@ def main():
     np.savez_compressed(os.path.join(GOLD, "cache_ops.npz"), q=q, k=k, cos=cos, sin=sin, pos=pos, **rope, key=key, val=val, slots=slots,
                         kc_ref=kc, vc_ref=vc, tables=tables, cu=cu, k_gather_ref=k_out, v_gather_ref=v_out)
     print("golden: cache_ops.npz")
+    # paged attention: outputs of the reference's own v1 / v2 (+ reduce) kernels run on host fibers (oracle/_ref/libref_pa.so).  The
+    # inputs are index formulas (paged_attn_case below), so the fixture only stores the reference outputs.
+    pa = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_pa.so"))
+    outs = {}
+    for name, case in PA_CASES.items():
+        q, kc, vc, bt, ctxs, alibi, sinks, scale = paged_attn_case(**case)
+        seqs, heads, hd = q.shape
+        kvh, bs = kc.shape[1], kc.shape[3]
+        parts = (max(ctxs) + 511) // 512
+        for v2 in (0, 1):
+            out = np.zeros((seqs, heads, hd), np.float32)
+            es, ml = np.zeros((seqs, heads, parts), np.float32), np.zeros((seqs, heads, parts), np.float32)
+            tmp = np.zeros((seqs, heads, parts, hd), np.float32)
+            cl = np.array(ctxs, dtype=np.uint32)
+            rc = pa.ref_paged_attention_f32(v2, vp(out), vp(es), vp(ml), vp(tmp), vp(q), vp(kc), vp(vc), kvh, C.c_float(scale), C.c_float(case.get("softcap", 1.0)),
+                                            vp(bt), vp(cl), bs, max(ctxs), seqs, heads, hd, bt.shape[1], vp(alibi) if alibi is not None else None,
+                                            heads * hd, kvh * hd * bs, hd * bs, vp(sinks) if sinks is not None else None)
+            assert rc == 0
+            outs[f"{name}_v{1 + v2}"] = out
+    np.savez_compressed(os.path.join(GOLD, "paged_attn_ref.npz"), **outs)
+    print("golden: paged_attn_ref.npz", {k: v.shape for k, v in outs.items()})
 
 
 if __name__ == "__main__":

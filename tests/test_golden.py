@@ -93,3 +93,48 @@ def test_hip_rope_and_cache_ops_reproduce_reference_golden(dev):
     k_out, v_out = paged_attn.gather_kv_cache(kc, vc, torch.from_numpy(g["tables"]).to(dev), torch.from_numpy(g["cu"]).to(dev), torch.float32)
     np.testing.assert_array_equal(k_out.cpu().numpy(), g["k_gather_ref"])
     np.testing.assert_array_equal(v_out.cpu().numpy(), g["v_gather_ref"])
+
+
+# ---- paged attention: outputs of the reference's own v1 / v2 + reduce kernels (f32) run on host fibers (oracle/_ref/libref_pa.so);
+#      inputs are the index formulas of scripts/gen_golden.py:paged_attn_case, so only the reference outputs are stored
+def _pa_cases():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_golden", os.path.join(os.path.dirname(GOLD), "..", "scripts", "gen_golden.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+PA_GOLD = os.path.join(GOLD, "paged_attn_ref.npz")
+
+
+@pytest.mark.parametrize("name", ["gqa_sinks", "mha_alibi", "softcap"])
+def test_oracle_attention_reproduces_reference_kernel_golden(oracle, name):
+    gg = _pa_cases()
+    case = gg.PA_CASES[name]
+    q, kc, vc, bt, ctxs, alibi, sinks, scale = gg.paged_attn_case(**case)
+    ref = np.load(PA_GOLD)
+    want = oracle.paged_attention_ref(q, kc, vc, bt.astype(np.int32), ctxs, float(scale), float(case.get("softcap", 1.0)), alibi, sinks)
+    pabs = oracle.paged_attention_ref(q, kc, np.abs(vc), bt.astype(np.int32), ctxs, float(scale), float(case.get("softcap", 1.0)), alibi, sinks)
+    for v in ("v1", "v2"):
+        err = np.abs(ref[f"{name}_{v}"] - want)
+        assert (err <= 3e-5 * pabs + 1e-6).all(), (name, v, float(err.max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["gqa_sinks", "mha_alibi", "softcap"])
+def test_hip_attention_reproduces_reference_kernel_golden(oracle, dev, name):
+    """paged_attention_v1_f32 / v2_f32 (f32 cache) against the outputs of the reference's own kernels, to f32 summation order."""
+    import torch
+    from mistralrs_amd import paged_attn
+    gg = _pa_cases()
+    case = gg.PA_CASES[name]
+    q, kc, vc, bt, ctxs, alibi, sinks, scale = gg.paged_attn_case(**case)
+    ref = np.load(PA_GOLD)
+    pabs = oracle.paged_attention_ref(q, kc, np.abs(vc), bt.astype(np.int32), ctxs, float(scale), float(case.get("softcap", 1.0)), alibi, sinks)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev) if a is not None else None
+    for v in ("v1", "v2"):
+        got = paged_attn.paged_attention(t(q), t(kc), t(vc), t(bt.astype(np.int32)), t(np.array(ctxs, dtype=np.int32)), max(ctxs), float(scale),
+                                         softcapping=float(case.get("softcap", 1.0)), alibi_slopes=t(alibi), sinks=t(sinks), force=v).cpu().numpy()
+        err = np.abs(got - ref[f"{name}_{v}"])
+        assert np.isfinite(got).all() and (err <= 6e-5 * pabs + 2e-6).all(), (name, v, float(err.max()))

@@ -143,3 +143,48 @@ def test_cache_ops_match_reference_kernels(oracle, bs, x):
     lib.ref_copy_blocks_f32(_vp(kp), _vp(vp), _vp(mapping), 2, 3, 24, 40)
     for got, want in zip(layers_k + layers_v, want_k + want_v):
         np.testing.assert_array_equal(got, want)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Paged attention: the reference's own paged_attention_v1 / v2 / v2_reduce kernels (pagedattention.cuh:56-667, f32 path), executed on
+# host fibers with real block barriers and warp shuffles (oracle/ref_shim/fiber_shim.h -> libref_pa.so).  The oracle evaluates the same
+# semantics in f64; the kernels in f32 (exp evaluated exactly on the host), so the comparison is to f32 rounding of the sums.
+@pytest.mark.parametrize("hd,bs,heads,kvh", [(128, 32, 8, 2), (64, 16, 4, 4), (96, 8, 6, 3)])
+@pytest.mark.parametrize("variant", ["plain", "softcap", "alibi", "sinks"])
+@pytest.mark.parametrize("v2", [0, 1])
+def test_paged_attention_oracle_matches_reference_kernels(oracle, hd, bs, heads, kvh, variant, v2):
+    lib = _ref("libref_pa.so")
+    rng = np.random.default_rng(hd + bs + 7 * v2 + len(variant))
+    ctxs = [1, bs - 1, bs, 2 * bs + 3, 530] if v2 else [1, bs - 1, bs + 1, 77]
+    seqs = len(ctxs)
+    x = 4  # 16 bytes of f32
+    max_blocks = (max(ctxs) + bs - 1) // bs + 1
+    nb = seqs * max_blocks + 1
+    kc = rng.standard_normal((nb, kvh, hd // x, bs, x)).astype(np.float32)
+    vc = rng.standard_normal((nb, kvh, hd, bs)).astype(np.float32)
+    bt = rng.permutation(nb)[: seqs * max_blocks].reshape(seqs, max_blocks).astype(np.uint32)
+    for s, c in enumerate(ctxs):  # stale slots past the context may hold NaN: the kernels zero them (pagedattention.cuh:407-423)
+        if c % bs:
+            vc[bt[s, c // bs], :, :, c % bs:] = np.nan
+    q = (rng.standard_normal((seqs, heads, hd)) * 1.5).astype(np.float32)
+    scale = np.float32(1.0 / np.sqrt(hd))
+    softcap = np.float32(8.0 if variant == "softcap" else 1.0)
+    alibi = (-rng.uniform(0.01, 0.3, heads)).astype(np.float32) if variant == "alibi" else None
+    sinks = rng.standard_normal(heads).astype(np.float32) if variant == "sinks" else None
+    max_ctx = max(ctxs)
+    parts = (max_ctx + 511) // 512
+    out = np.zeros((seqs, heads, hd), np.float32)
+    es, ml = np.zeros((seqs, heads, parts), np.float32), np.zeros((seqs, heads, parts), np.float32)
+    tmp = np.zeros((seqs, heads, parts, hd), np.float32)
+    cl = np.array(ctxs, dtype=np.uint32)
+    rc = lib.ref_paged_attention_f32(v2, _vp(out), _vp(es), _vp(ml), _vp(tmp), _vp(q), _vp(kc), _vp(vc), kvh, C.c_float(scale), C.c_float(softcap),
+                                     _vp(bt), _vp(cl), bs, max_ctx, seqs, heads, hd, max_blocks, _vp(alibi) if alibi is not None else None,
+                                     heads * hd, kvh * hd * bs, hd * bs, _vp(sinks) if sinks is not None else None)
+    assert rc == 0
+    vz = np.nan_to_num(vc, nan=0.0)
+    want = oracle.paged_attention_ref(q, kc, vz, bt.astype(np.int32), ctxs, float(scale), float(softcap), alibi, sinks)
+    pabs = oracle.paged_attention_ref(q, kc, np.abs(vz), bt.astype(np.int32), ctxs, float(scale), float(softcap), alibi, sinks)
+    assert np.isfinite(out).all()
+    err = np.abs(out - want.reshape(out.shape))
+    tol = 3e-5 * pabs.reshape(out.shape) + 1e-6
+    assert (err <= tol).all(), float((err / tol).max())
