@@ -9,6 +9,8 @@
 #                            copy_blocks_kernel.cu kernels (f32 instantiations), run by ref_shim/cache_driver.inc
 #   _ref/libref_pa.so     <- paged_attention_v1 / v2 / v2_reduce kernels (pagedattention.cuh:56-667 + attention/*.cuh, f32 path) executed
 #                            on host fibers with block barriers and warp shuffles (ref_shim/fiber_shim.h, pa_driver.inc)
+#   _ref/libref_q8_1.so   <- mmvq_gguf_quantize_q8_1_f32 (mmvq_gguf.cu) on host fibers: the reference's Q8_1 activation quantizer
+#   _ref/libref_rms.so    <- add_rms_norm_* / rms_norm_residual_* kernels (mistralrs-core/src/cuda/sort.cu:148-428) on host fibers
 #   _ref/libref_hqq.so    <- the __global__ kernel templates of kernels/hqq/hqq.cu (dequantize_*) and hqq_bitpack.cu (pack_*),
 #                            run one thread at a time by ref_shim/hqq_driver.inc
 # The reference text is STREAMED into g++ (stdin); nothing from /root/reference is written into this repo.
@@ -20,6 +22,7 @@ OUT="$HERE/_ref"
 mkdir -p "$OUT"
 CXX="${CXX:-g++}"
 FLAGS="-x c++ -std=c++17 -O2 -fPIC -shared -fno-fast-math -ffp-contract=off -w"
+FIB="-DSHIM_FIBERS"
 MMVQ="$REF/mistralrs-quant/kernels/mmvq_gguf/mmvq_gguf.cu"
 AFF_DIR="$REF/mistralrs-quant/kernels/gguf_affine_packed"
 ( cat "$HERE/ref_shim/cuda_shim.h"
@@ -62,5 +65,18 @@ STRIP='/^#include/d; /^#pragma once/d'
   echo 'namespace vllm { namespace fp8 { template <class O, class I, Fp8KVCacheDataType K> static O scaled_convert(const I &, float) { return O{}; } } }'
   sed "$STRIP" "$ATT/attention_utils.cuh"; echo ''
   sed -n '56,667p' "$PA_DIR/pagedattention.cuh" | sed 's/extern __shared__ char shared_mem\[\];/char *shared_mem = shim_fiber::dyn_smem;/'
-  cat "$HERE/ref_shim/pa_driver.inc" ) | $CXX $FLAGS -o "$OUT/libref_pa.so" -
-echo "oracle/_ref: built libref_mmvq.so libref_affine.so libref_hqq.so libref_cache.so libref_pa.so from $REF"
+  cat "$HERE/ref_shim/pa_driver.inc" ) | $CXX $FLAGS $FIB -o "$OUT/libref_pa.so" -
+# Q8_1 activation quantizer: the reference's mmvq_gguf_quantize_q8_1_f32 kernel (mmvq_gguf.cu, after the fused-QKV type sets) with its
+# real warp reductions (butterfly order), on top of the same streamed head as libref_mmvq
+( cat "$HERE/ref_shim/cuda_shim.h" "$HERE/ref_shim/fiber_shim.h"
+  awk '/Core mat-vec-q template/{exit} {print}' "$MMVQ" | grep -v '#include "cuda_' | grep -v '^#define WARP_SIZE'
+  awk '/^mmvq_gguf_quantize_q8_1_f32\(/{p=1; print "extern \"C\" void"} p{print} p && /^}$/{exit}' "$MMVQ"
+  cat "$HERE/ref_shim/quantize_driver.inc" ) | $CXX $FLAGS $FIB -o "$OUT/libref_q8_1.so" -
+# add_rms_norm / rms_norm_residual (mistralrs-core/src/cuda/sort.cu): helpers + block reduction (:148-243), the residual kernels (:244-318),
+# the add kernels (:351-428); f32, f16 and bf16 instantiations through the shim's half / bf16 stand-ins
+SORT="$REF/mistralrs-core/src/cuda/sort.cu"
+( cat "$HERE/ref_shim/cuda_shim.h" "$HERE/ref_shim/fiber_shim.h"
+  sed -n '148,318p' "$SORT" | awk '/^template <typename T>$/{t=$0; next} /^void launch_/{skip=1} !skip{if (t != "") print t; print} {t=""} skip && /^}$/{skip=0}'
+  sed -n '351,428p' "$SORT"
+  cat "$HERE/ref_shim/rms_driver.inc" ) | $CXX $FLAGS $FIB -o "$OUT/libref_rms.so" -
+echo "oracle/_ref: built libref_mmvq.so libref_affine.so libref_hqq.so libref_cache.so libref_pa.so libref_q8_1.so libref_rms.so from $REF"

@@ -35,7 +35,30 @@ static inline float shim_h2f(uint16_t h) {  // IEEE binary16 -> binary32, exact
   else b = s | ((e + 112) << 23) | (m << 13);
   float f; memcpy(&f, &b, 4); return f;
 }
-struct __half { uint16_t bits; operator float() const { return shim_h2f(bits); } };
+static inline uint16_t shim_f2h(float f) {  // binary32 -> IEEE binary16, round to nearest even (what `(half)x` does on the device)
+  uint32_t b; memcpy(&b, &f, 4);
+  const uint32_t s = (b >> 16) & 0x8000u;
+  const uint32_t a = b & 0x7fffffffu;
+  if (a > 0x7f800000u) return (uint16_t)(s | 0x7e00u);             // NaN
+  if (a >= 0x477ff000u) return (uint16_t)(s | 0x7c00u);            // >= 65520 -> inf
+  if (a < 0x33000001u) return (uint16_t)s;                         // <= 2^-25 -> 0 (ties to even)
+  int e = (int)(a >> 23) - 127;
+  uint32_t m = (a & 0x7fffffu) | 0x800000u;
+  if (e < -14) {                                                    // subnormal half
+    const int sh = -14 - e + 13;                                   // bits to drop from the 24-bit significand
+    const uint32_t q = m >> sh, r = m & ((1u << sh) - 1u), half = 1u << (sh - 1);
+    return (uint16_t)(s | (q + ((r > half) || (r == half && (q & 1u)))));
+  }
+  const uint32_t q = m >> 13, r = m & 0x1fffu;
+  uint32_t h = ((uint32_t)(e + 15) << 10) + (q & 0x3ffu) + ((r > 0x1000u) || (r == 0x1000u && (q & 1u)));
+  return (uint16_t)(s | h);                                         // a mantissa carry bumps the exponent correctly
+}
+struct __half {
+  uint16_t bits;
+  __half() = default;
+  explicit __half(float f) : bits(shim_f2h(f)) {}
+  operator float() const { return shim_h2f(bits); }
+};
 struct __half2 { __half x, y; };
 typedef __half half;
 typedef __half2 half2;
@@ -55,5 +78,7 @@ static inline int __vsubss4(int a, int b) {
   }
   return (int)r;
 }
-template <class T> static inline T __shfl_xor_sync(unsigned, T v, int, int = 32) { return v; }  // only referenced by helpers the driver never calls
+#ifndef SHIM_FIBERS  /* libref_mmvq: only referenced by helpers its driver never calls; fiber_shim.h provides the real exchange */
+template <class T> static inline T __shfl_xor_sync(unsigned, T v, int, int = 32) { return v; }
+#endif
 static inline float normcdff(float x) { return 0.5f * erfcf(-x * 0.70710678118654752440f); }

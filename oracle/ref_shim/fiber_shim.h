@@ -84,10 +84,30 @@ static void run_block(unsigned threads, const std::function<void()> &k) {
 static inline void __syncthreads() { shim_fiber::block_barrier(); }
 template <class T> static inline T shim_shfl_xor(T v, int mask) { return shim_fiber::exchange(v, (int)(threadIdx.x % 32) ^ mask); }
 template <class T> static inline T shim_shfl(T v, int src) { return shim_fiber::exchange(v, src); }
+template <class T> static inline T __shfl_xor_sync(unsigned, T v, int mask, int = 32) { return shim_shfl_xor(v, mask); }
+template <class T> static inline T __shfl_down_sync(unsigned, T v, int delta, int = 32) {
+  const int lane = (int)(threadIdx.x % 32);
+  return shim_fiber::exchange(v, lane + delta < 32 ? lane + delta : lane);  // lanes past the end keep their own value
+}
+// bf16 stand-in (RNE from f32, exact widening) and the remaining half helpers for kernels templated on the 16-bit types
+struct __nv_bfloat16 {
+  uint16_t bits;
+  __nv_bfloat16() = default;
+  explicit __nv_bfloat16(float f) { uint32_t b; memcpy(&b, &f, 4); if ((b & 0x7fffffffu) > 0x7f800000u) bits = (uint16_t)((b >> 16) | 0x40); else { b += 0x7fffu + ((b >> 16) & 1u); bits = (uint16_t)(b >> 16); } }
+  operator float() const { uint32_t b = (uint32_t)bits << 16; float f; memcpy(&f, &b, 4); return f; }
+};
+static inline float __bfloat162float(__nv_bfloat16 v) { return (float)v; }
+static inline __nv_bfloat16 __float2bfloat16(float f) { return __nv_bfloat16(f); }
+static inline __half __float2half(float f) { return __half(f); }
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }  /* the device intrinsic is a 2-ulp approximation: compare to f32 tolerance */
+#include <algorithm>
+#include <type_traits>
 #define VLLM_LDG(arg) *(arg)
 #define VLLM_SHFL_XOR_SYNC(var, lane_mask) shim_shfl_xor(var, lane_mask)
 #define VLLM_SHFL_SYNC(var, src_lane) shim_shfl(var, src_lane)
+#ifndef WARP_SIZE
 #define WARP_SIZE 32
+#endif
 #define MAX(a, b) ((a) > (b) ? (a) : (b))
 #define MIN(a, b) ((a) < (b) ? (a) : (b))
 #define DIVIDE_ROUND_UP(a, b) (((a) + (b) - 1) / (b))

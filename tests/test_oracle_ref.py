@@ -188,3 +188,53 @@ def test_paged_attention_oracle_matches_reference_kernels(oracle, hd, bs, heads,
     err = np.abs(out - want.reshape(out.shape))
     tol = 3e-5 * pabs.reshape(out.shape) + 1e-6
     assert (err <= tol).all(), float((err / tol).max())
+
+
+@pytest.mark.parametrize("k", [32, 96, 512, 4096, 520])
+def test_q8_1_quantizer_matches_reference_kernel(oracle, k):
+    """The reference's mmvq_gguf_quantize_q8_1_f32 kernel with its real warp reductions (butterfly order), run on host fibers: block
+    scale d = half(amax / 127), quants roundf(x / d), and the half block sum, bit for bit; rows padded to 512 with zero blocks."""
+    lib = _ref("libref_q8_1.so")
+    rng = np.random.default_rng(k)
+    rows = 3
+    x = (rng.standard_normal((rows, k)) * rng.uniform(0.01, 30.0, (rows, 1))).astype(np.float32)
+    x[0, :32] = 0.0            # an all-zero block (amax == 0 branch)
+    if k >= 96:
+        x[1, 64:96] = np.float32(1e-30)  # denormal-scale block
+    kp = oracle.pad512(k)
+    want = np.zeros((rows, kp // 32 * 36), dtype=np.uint8)
+    lib.ref_quantize_q8_1_f32(_vp(x), _vp(want), k, kp, rows)
+    got = oracle.quantize_q8_1(x)
+    np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("rows,cols", [(3, 4096), (2, 1000), (1, 14336), (2, 24)])
+def test_rms_norm_family_matches_reference_kernels(oracle, dt, rows, cols):
+    """add_rms_norm_* / rms_norm_residual_* of mistralrs-core/src/cuda/sort.cu run on host fibers (block reduction with real barriers and
+    __shfl_down): the expected-value expressions that tests/test_glue_ops.py holds the HIP kernels to are the reference's results --
+    residual sum bit-exact, normed outputs to one ulp of the dtype (the f32 sum of squares is order-dependent, rsqrtf approximate)."""
+    from tests.util import ULP, round_through
+    import torch
+    lib = _ref("libref_rms.so")
+    code = {"f16": 0, "bf16": 1, "f32": 2}[dt]
+    td = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[dt]
+    rng = np.random.default_rng(cols + code)
+    x = round_through(rng.standard_normal((rows, cols)).astype(np.float32), dt)
+    r = round_through(rng.standard_normal((rows, cols)).astype(np.float32), dt)
+    w = round_through(1 + 0.1 * rng.standard_normal(cols).astype(np.float32), dt)
+    sc = round_through(np.array([0.5], np.float32), dt)
+    raw = lambda a: torch.from_numpy(a).to(td).contiguous()
+    xt, rt, wt, st = raw(x), raw(r), raw(w), raw(sc)
+    rd, nd, dst = torch.zeros_like(xt), torch.zeros_like(xt), torch.zeros_like(xt)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    eps = 1e-5
+    assert lib.ref_add_rms_norm(code, p(xt), p(rt), p(wt), p(rd), p(nd), rows, cols, C.c_float(eps)) == 0
+    assert lib.ref_rms_norm_residual(code, p(xt), p(rt), p(wt), p(st), p(dst), rows, cols, C.c_float(eps)) == 0
+    tol = lambda want: 1.01 * ULP[dt] * np.abs(want) + 4e-6 * np.abs(want) + 1e-7
+    s = round_through(x + r, dt)
+    np.testing.assert_array_equal(rd.float().numpy(), s)                      # residual_out = T(x + r)
+    want = oracle.rms_norm(s, w, eps)                                          # norm over the ROUNDED sum
+    assert (np.abs(nd.float().numpy() - (round_through(want, dt) if dt != "f32" else want)) <= tol(want)).all()
+    want = (r + oracle.rms_norm(x, w, eps)) * sc[0]                            # (residual + rms(x) * w) * scale
+    assert (np.abs(dst.float().numpy() - (round_through(want, dt) if dt != "f32" else want)) <= tol(want) + 4e-6 * np.abs(r)).all()
