@@ -11,6 +11,7 @@
 #                            on host fibers with block barriers and warp shuffles (ref_shim/fiber_shim.h, pa_driver.inc)
 #   _ref/libref_q8_1.so   <- mmvq_gguf_quantize_q8_1_f32 (mmvq_gguf.cu) on host fibers: the reference's Q8_1 activation quantizer
 #   _ref/libref_rms.so    <- add_rms_norm_* / rms_norm_residual_* kernels (mistralrs-core/src/cuda/sort.cu:148-428) on host fibers
+#   _ref/libref_mmvq_kernel.so <- the whole mmvq_gguf.cu kernel set (mmvq_core_impl, fused GLU; f32 destinations) on host fibers
 #   _ref/libref_hqq.so    <- the __global__ kernel templates of kernels/hqq/hqq.cu (dequantize_*) and hqq_bitpack.cu (pack_*),
 #                            run one thread at a time by ref_shim/hqq_driver.inc
 # The reference text is STREAMED into g++ (stdin); nothing from /root/reference is written into this repo.
@@ -72,6 +73,10 @@ STRIP='/^#include/d; /^#pragma once/d'
   awk '/Core mat-vec-q template/{exit} {print}' "$MMVQ" | grep -v '#include "cuda_' | grep -v '^#define WARP_SIZE'
   awk '/^mmvq_gguf_quantize_q8_1_f32\(/{p=1; print "extern \"C\" void"} p{print} p && /^}$/{exit}' "$MMVQ"
   cat "$HERE/ref_shim/quantize_driver.inc" ) | $CXX $FLAGS $FIB -o "$OUT/libref_q8_1.so" -
+# the complete MMVQ kernels (mmvq_core_impl + fused GLU, all 10 formats x batch 1..8): mmvq_gguf.cu up to its host-side launchers
+( cat "$HERE/ref_shim/cuda_shim.h" "$HERE/ref_shim/fiber_shim.h"
+  awk '/^\/\/ Host-side launchers/{exit} {print}' "$MMVQ" | grep -v '#include "cuda_' | grep -v '^#define WARP_SIZE'
+  cat "$HERE/ref_shim/mmvq_kernel_driver.inc" ) | $CXX $FLAGS $FIB -o "$OUT/libref_mmvq_kernel.so" -
 # add_rms_norm / rms_norm_residual (mistralrs-core/src/cuda/sort.cu): helpers + block reduction (:148-243), the residual kernels (:244-318),
 # the add kernels (:351-428); f32, f16 and bf16 instantiations through the shim's half / bf16 stand-ins
 SORT="$REF/mistralrs-core/src/cuda/sort.cu"
@@ -79,4 +84,4 @@ SORT="$REF/mistralrs-core/src/cuda/sort.cu"
   sed -n '148,318p' "$SORT" | awk '/^template <typename T>$/{t=$0; next} /^void launch_/{skip=1} !skip{if (t != "") print t; print} {t=""} skip && /^}$/{skip=0}'
   sed -n '351,428p' "$SORT"
   cat "$HERE/ref_shim/rms_driver.inc" ) | $CXX $FLAGS $FIB -o "$OUT/libref_rms.so" -
-echo "oracle/_ref: built libref_mmvq.so libref_affine.so libref_hqq.so libref_cache.so libref_pa.so libref_q8_1.so libref_rms.so from $REF"
+echo "oracle/_ref: built libref_mmvq.so libref_affine.so libref_hqq.so libref_cache.so libref_pa.so libref_q8_1.so libref_rms.so libref_mmvq_kernel.so from $REF"

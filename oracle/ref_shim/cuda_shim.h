@@ -56,7 +56,7 @@ static inline uint16_t shim_f2h(float f) {  // binary32 -> IEEE binary16, round 
 struct __half {
   uint16_t bits;
   __half() = default;
-  explicit __half(float f) : bits(shim_f2h(f)) {}
+  __half(float f) : bits(shim_f2h(f)) {}  // implicit, like the device type
   operator float() const { return shim_h2f(bits); }
 };
 struct __half2 { __half x, y; };

@@ -47,8 +47,9 @@ static void warp_barrier(int w, int lanes) {
 }
 template <class T> static T exchange(T v, int src_lane_of) {  // all live lanes of the warp call this together
   static_assert(sizeof(T) <= 8, "shuffle payload");
-  const int tid = threadIdx.x, w = tid / WARP;
-  const int lanes = (int)blockDim.x - w * WARP < WARP ? (int)blockDim.x - w * WARP : WARP;
+  const int nthreads = (int)(blockDim.x * blockDim.y);
+  const int tid = (int)(threadIdx.y * blockDim.x + threadIdx.x), w = tid / WARP;  // linear thread id: warps are 32 consecutive threads
+  const int lanes = nthreads - w * WARP < WARP ? nthreads - w * WARP : WARP;
   uint64_t bits = 0;
   memcpy(&bits, &v, sizeof(T));
   slot[tid] = bits;
@@ -59,9 +60,10 @@ template <class T> static T exchange(T v, int src_lane_of) {  // all live lanes 
   return r;
 }
 // run `k` for every thread of one block (blockIdx / gridDim are set by the caller)
-static void run_block(unsigned threads, const std::function<void()> &k) {
+static void run_block(unsigned dimx, unsigned dimy, const std::function<void()> &k) {
   kernel = k;
-  blockDim.x = threads; blockDim.y = blockDim.z = 1;
+  const unsigned threads = dimx * dimy;
+  blockDim.x = dimx; blockDim.y = dimy; blockDim.z = 1;
   if (fibers.size() < threads) fibers.resize(threads);
   live = (int)threads; bar_count = 0;
   for (auto &c : wbar_count) c = 0;
@@ -77,23 +79,24 @@ static void run_block(unsigned threads, const std::function<void()> &k) {
   }
   while (live > 0)
     for (unsigned t = 0; t < threads; ++t)
-      if (!fibers[t].done) { cur = (int)t; threadIdx.x = t; threadIdx.y = threadIdx.z = 0; swapcontext(&main_ctx, &fibers[t].ctx); }
+      if (!fibers[t].done) { cur = (int)t; threadIdx.x = t % dimx; threadIdx.y = t / dimx; threadIdx.z = 0; swapcontext(&main_ctx, &fibers[t].ctx); }
 }
+static void run_block(unsigned threads, const std::function<void()> &k) { run_block(threads, 1, k); }
 }  // namespace shim_fiber
 
 static inline void __syncthreads() { shim_fiber::block_barrier(); }
-template <class T> static inline T shim_shfl_xor(T v, int mask) { return shim_fiber::exchange(v, (int)(threadIdx.x % 32) ^ mask); }
+template <class T> static inline T shim_shfl_xor(T v, int mask) { return shim_fiber::exchange(v, (int)((threadIdx.y * blockDim.x + threadIdx.x) % 32) ^ mask); }
 template <class T> static inline T shim_shfl(T v, int src) { return shim_fiber::exchange(v, src); }
 template <class T> static inline T __shfl_xor_sync(unsigned, T v, int mask, int = 32) { return shim_shfl_xor(v, mask); }
 template <class T> static inline T __shfl_down_sync(unsigned, T v, int delta, int = 32) {
-  const int lane = (int)(threadIdx.x % 32);
+  const int lane = (int)((threadIdx.y * blockDim.x + threadIdx.x) % 32);
   return shim_fiber::exchange(v, lane + delta < 32 ? lane + delta : lane);  // lanes past the end keep their own value
 }
 // bf16 stand-in (RNE from f32, exact widening) and the remaining half helpers for kernels templated on the 16-bit types
 struct __nv_bfloat16 {
   uint16_t bits;
   __nv_bfloat16() = default;
-  explicit __nv_bfloat16(float f) { uint32_t b; memcpy(&b, &f, 4); if ((b & 0x7fffffffu) > 0x7f800000u) bits = (uint16_t)((b >> 16) | 0x40); else { b += 0x7fffu + ((b >> 16) & 1u); bits = (uint16_t)(b >> 16); } }
+  __nv_bfloat16(float f) { uint32_t b; memcpy(&b, &f, 4); if ((b & 0x7fffffffu) > 0x7f800000u) bits = (uint16_t)((b >> 16) | 0x40); else { b += 0x7fffu + ((b >> 16) & 1u); bits = (uint16_t)(b >> 16); } }
   operator float() const { uint32_t b = (uint32_t)bits << 16; float f; memcpy(&f, &b, 4); return f; }
 };
 static inline float __bfloat162float(__nv_bfloat16 v) { return (float)v; }

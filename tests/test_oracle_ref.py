@@ -238,3 +238,38 @@ def test_rms_norm_family_matches_reference_kernels(oracle, dt, rows, cols):
     assert (np.abs(nd.float().numpy() - (round_through(want, dt) if dt != "f32" else want)) <= tol(want)).all()
     want = (r + oracle.rms_norm(x, w, eps)) * sc[0]                            # (residual + rms(x) * w) * scale
     assert (np.abs(dst.float().numpy() - (round_through(want, dt) if dt != "f32" else want)) <= tol(want) + 4e-6 * np.abs(r)).all()
+
+
+@pytest.mark.parametrize("t", TYPES)
+@pytest.mark.parametrize("b", [1, 3, 8])
+def test_matvec_oracle_matches_reference_mmvq_kernels(oracle, t, b):
+    """The reference's complete MMVQ kernels (mmvq_core_impl and the fused-GLU variant, mmvq_gguf.cu:724-996, f32 destination) executed
+    on host fibers with the launch geometry of their launchers: the Q8_1 matvec oracle (f64 combination of the same terms) agrees to the
+    f32 accumulation bound the GPU tests hold the HIP kernels to, for every format and for the single-column, 2..4 and 5..8 batch shapes."""
+    lib = _ref("libref_mmvq_kernel.so")
+    rng = np.random.default_rng(31 * t + b)
+    n, k = 22, 1024
+    w = oracle.random_blocks(t, n, k, seed=300 + t, d_scale=0.02)
+    x = (rng.standard_normal((b, k)) * rng.uniform(0.2, 5.0, (b, 1))).astype(np.float32)
+    y = oracle.quantize_q8_1(x)
+    stride = y.shape[1] // 36
+    out = np.zeros((b, n), dtype=np.float32)
+    assert lib.ref_mmvq_kernel_plain_f32(t, _vp(w), _vp(y), _vp(out), k, n, stride, n, b) == 0
+    want, mag = oracle.matmul_q8_1_mag(t, w, n, k, y)
+    tol = 8 * 2.0 ** -23 * np.sqrt(k / 16) * mag.astype(np.float64) + 2.0 ** -23 * np.abs(want) + 1e-30
+    err = np.abs(out.astype(np.float64) - want)
+    assert (err <= tol).all(), float((err / tol).max())
+    # fused gate/up + activation: dst = act(gate . y) * (up . y)
+    wu = oracle.random_blocks(t, n, k, seed=900 + t, d_scale=0.02)
+    wantu, magu = oracle.matmul_q8_1_mag(t, wu, n, k, y)
+    for act in (0, 1, 2):
+        glu = np.zeros((b, n), dtype=np.float32)
+        assert lib.ref_mmvq_kernel_fused_glu_f32(t, _vp(w), _vp(wu), _vp(y), _vp(glu), k, n, stride, n, b, act) == 0
+        exp = oracle.fused_glu(want.astype(np.float32), wantu.astype(np.float32), act).astype(np.float64)
+        # error propagation: d(act(g) u) <= |u| dg (act' <= ~1.13) + |act(g)| du, plus f32 rounding of the product
+        ag = np.abs(oracle.fused_glu(want.astype(np.float32), np.ones_like(wantu, dtype=np.float32), act).astype(np.float64))
+        tg = 8 * 2.0 ** -23 * np.sqrt(k / 16) * mag
+        tu = 8 * 2.0 ** -23 * np.sqrt(k / 16) * magu
+        tolg = 1.2 * np.abs(wantu) * tg + ag * tu + 4 * 2.0 ** -23 * np.abs(exp) + 1e-30
+        errg = np.abs(glu.astype(np.float64) - exp)
+        assert (errg <= tolg).all(), (act, float((errg / tolg).max()))
