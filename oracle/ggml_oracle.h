@@ -9,9 +9,11 @@
  *
  * PARITY STATUS: "parity unpinned" for everything that lives in candle (CPU QMatMul,
  * quantizers): candle@35d7ae7 is a git dependency that is not vendored under
- * /root/reference and there is no Rust toolchain here.  Block decode and the MMVQ
- * integer dot products are pinned against the reference's own device functions
- * compiled for the host (oracle/_ref, see oracle/Makefile + oracle/ref_shim/).
+ * /root/reference and there is no Rust toolchain here.  PINNED against the reference's own
+ * device code compiled for / executed on the host (oracle/build_ref.sh -> oracle/_ref/*.so,
+ * oracle/ref_shim/: CUDA-vocabulary shim + a fiber runtime with block barriers and warp
+ * shuffles): block decode, the Q8_1 quantizer, the MMVQ dot products and complete kernels,
+ * GLU activations, the RMSNorm family, RoPE, paged-cache ops and paged attention v1 / v2 (f32).
  */
 #ifndef GGML_ORACLE_H
 #define GGML_ORACLE_H

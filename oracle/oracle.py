@@ -4,8 +4,11 @@ ctypes/numpy front-end of the CPU oracle (oracle/ggml_oracle.c, oracle/llama_ora
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module;
 nothing under mistral.rs_amd/ does (tests/test_no_oracle_in_product.py enforces it).
 
-Parity status: see the header of ggml_oracle.h ("parity unpinned" for the candle-resident
-CPU arithmetic; block decode + MMVQ dots pinned against oracle/_ref when it is built).
+Parity status (details: DESIGN.md section 2, tests/test_oracle_ref.py, tests/test_golden.py): PINNED against the reference's own code
+compiled for / executed on the host by oracle/build_ref.sh (oracle/_ref/*.so) -- block decode of all 10 formats, the Q8_1 quantizer,
+the MMVQ dot products and complete kernels, GLU activations, RMSNorm family, RoPE, paged-cache scatter / gather / copy, paged
+attention v1 / v2 (f32 path), HQQ pack / dequantize; "parity unpinned" for what lives in candle (CPU QMatMul arithmetic, oracle B),
+the FP8-E4M3 codec (CUDA intrinsics) and the 16-bit instantiations of attention.
 """
 from __future__ import annotations
 
