@@ -273,3 +273,27 @@ def test_matvec_oracle_matches_reference_mmvq_kernels(oracle, t, b):
         tolg = 1.2 * np.abs(wantu) * tg + ag * tu + 4 * 2.0 ** -23 * np.abs(exp) + 1e-30
         errg = np.abs(glu.astype(np.float64) - exp)
         assert (errg <= tolg).all(), (act, float((errg / tolg).max()))
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("act", [0, 1, 2, 3, 4])
+def test_fused_glu_matches_reference_kernels(oracle, dt, act):
+    """fused_glu_kernel (scalar, strided rows) and fused_glu_kernel_vec4 of mistralrs-quant/kernels/ops/ops.cu on the host: out =
+    T(act(float(a))) * b with the product rounded to T -- the expression tests/test_glue_ops.py holds the HIP kernel to."""
+    from tests.util import ULP, round_through
+    import torch
+    lib = _ref("libref_glu.so")
+    code = {"f16": 0, "bf16": 1, "f32": 2}[dt]
+    td = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[dt]
+    rng = np.random.default_rng(act + code)
+    for rows, cols, width in ((5, 1001, 2 * 1001), (4, 1024, 2 * 1024)):  # odd width -> scalar kernel; aligned -> vec4 kernel
+        wide = round_through((rng.standard_normal((rows, width)) * 3).astype(np.float32), dt)
+        wt = torch.from_numpy(wide).to(td).contiguous()
+        out = torch.zeros(rows, cols, dtype=td)
+        es = wt.element_size()
+        a_ptr, b_ptr = wt.data_ptr(), wt.data_ptr() + cols * es
+        assert lib.ref_fused_glu(code, C.c_void_p(a_ptr), C.c_void_p(b_ptr), C.c_void_p(out.data_ptr()), rows, cols, width, width, act) == 0
+        a, b = wide[:, :cols], wide[:, cols:]
+        want = round_through(round_through(oracle.fused_glu(a, np.ones_like(a), act), dt) * b, dt)
+        tol = 2 * ULP[dt] * np.abs(want) + 2e-6 * np.abs(b) * (np.abs(a) + 1)
+        assert (np.abs(out.float().numpy() - want) <= tol + 1e-30).all()
