@@ -25,6 +25,22 @@ extern "C" {
 MRS_DECL_NORMS(f32) MRS_DECL_NORMS(f16) MRS_DECL_NORMS(bf16)
 #undef MRS_DECL_NORMS
 
+/* MoE router: softmax / sigmoid / raw scores over n_experts logits per row -> top_k (ids, weights), ties to the lowest expert id.
+ * score_mode 0 raw, 1 softmax, 2 sigmoid; weight_mode 0 score, 1 softmax over the picked raw logits, 2 sigmoid(raw); optional
+ * selection_bias / expert_scale [n_experts] (NULL = none), clamp, renormalise by max(sum, norm_min), output_scale.  n_experts in
+ * {1,2,4,8,16,32,64,128,256,512,576}, other values are ignored like the reference's switch.
+ * replaces mistralrs-core/src/cuda/sort.cu:1097-1470 ; ffi.rs:523-579 ; caller ops.rs:259-336 (moe_router_topk) */
+#include <stdbool.h>
+void moe_router_topk_f32(const void *logits, float *weights, uint32_t *ids, const float *selection_bias, const float *expert_scale, int n_rows,
+                         int n_experts, int top_k, int score_mode, int weight_mode, bool renormalize, bool clamp_logits, float clamp_min,
+                         float clamp_max, float norm_min, float output_scale, int64_t stream);
+void moe_router_topk_f16(const void *logits, float *weights, uint32_t *ids, const float *selection_bias, const float *expert_scale, int n_rows,
+                         int n_experts, int top_k, int score_mode, int weight_mode, bool renormalize, bool clamp_logits, float clamp_min,
+                         float clamp_max, float norm_min, float output_scale, int64_t stream);
+void moe_router_topk_bf16(const void *logits, float *weights, uint32_t *ids, const float *selection_bias, const float *expert_scale, int n_rows,
+                          int n_experts, int top_k, int score_mode, int weight_mode, bool renormalize, bool clamp_logits, float clamp_min,
+                          float clamp_max, float norm_min, float output_scale, int64_t stream);
+
 #ifdef __cplusplus
 }
 #endif

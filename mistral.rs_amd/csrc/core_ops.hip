@@ -160,3 +160,123 @@ static void launch_rms(const void *x, const void *residual, const void *weight, 
 MRS_RMS_FAMILY(f32, float)
 MRS_RMS_FAMILY(f16, mrs::f16_t)
 MRS_RMS_FAMILY(bf16, mrs::bf16_t)
+
+// ---------------------------------------------------------------------------------------------------- MoE router top-k
+// moe_router_topk_{f32,f16,bf16}: drop-in for mistralrs-core/src/cuda/sort.cu:1097-1470 (Rust: cuda/ffi.rs:523-579; caller
+// ops.rs:259-336 moe_router_topk).  Per row of router logits [n_experts]: optional clamp, NaN -> -inf; score = raw / softmax /
+// sigmoid; selection = score (+ bias); top_k rounds of arg-max (ties: lowest expert id); weight = score / raw (then softmax over
+// the k picks) / sigmoid(raw); optional renormalisation by max(sum, norm_min); times output_scale (* expert_scale[id]).
+// n_experts outside {1,2,4,...,512,576} is silently ignored like the reference's switch.
+// wave64 mapping: a row is owned by 32 lanes (half a wave), expert e lives in lane e % 32 slot e / 32 -- the reference's layout, so the
+// strided partial sums and the xor-butterfly reductions (masks 16..1 never leave a 32-lane half) add in the reference's order.
+namespace mrs {
+constexpr int ROUTER_MAX_SLOTS = 18;  // 576 / 32
+__device__ __forceinline__ float half_sum32(float v) {
+#pragma unroll
+  for (int m = 16; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+__device__ __forceinline__ float half_max32(float v) {
+#pragma unroll
+  for (int m = 16; m > 0; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+  return v;
+}
+// softmax over the first `limit` entries (entry index = lane + 32 i); entries >= limit become 0 when use_limit
+__device__ __forceinline__ void router_softmax(float (&v)[ROUTER_MAX_SLOTS], int slots, int limit, bool use_limit, int lane) {
+  float mx = -INFINITY;
+  for (int i = 0; i < slots; ++i) if (!use_limit || lane + 32 * i < limit) mx = fmaxf(mx, v[i]);
+  mx = half_max32(mx);
+  float sum = 0.f;
+  for (int i = 0; i < slots; ++i) {
+    if (!use_limit || lane + 32 * i < limit) { v[i] = expf(v[i] - mx); sum += v[i]; } else v[i] = 0.f;
+  }
+  sum = half_sum32(sum);
+  const float inv = 1.0f / sum;
+  for (int i = 0; i < slots; ++i) if (!use_limit || lane + 32 * i < limit) v[i] *= inv;
+}
+
+template <class T>
+__global__ void __launch_bounds__(256) moe_router_topk_kernel(const T *__restrict__ logits, float *__restrict__ weights, uint32_t *__restrict__ ids,
+                                                              const float *__restrict__ bias, const float *__restrict__ expert_scale, int n_rows,
+                                                              int n_experts, int top_k, int score_mode, int weight_mode, bool renormalize,
+                                                              bool clamp_logits, float clamp_min, float clamp_max, float norm_min, float output_scale) {
+  const int lane = threadIdx.x & 31;
+  const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (row >= n_rows) return;  // whole 32-lane halves leave together; the shuffles below stay inside a half
+  logits += (size_t)row * n_experts; weights += (size_t)row * top_k; ids += (size_t)row * top_k;
+  const int slots = n_experts > 32 ? n_experts / 32 : 1;
+  float raw[ROUTER_MAX_SLOTS], score[ROUTER_MAX_SLOTS], sel[ROUTER_MAX_SLOTS], ow[ROUTER_MAX_SLOTS];
+  uint32_t oid[ROUTER_MAX_SLOTS];
+  for (int i = 0; i < slots; ++i) {
+    const int e = lane + 32 * i;
+    float v = e < n_experts ? to_f<T>(logits[e]) : -INFINITY;
+    if (clamp_logits && e < n_experts) v = fminf(fmaxf(v, clamp_min), clamp_max);
+    if (v != v) v = -INFINITY;
+    raw[i] = v; score[i] = v; ow[i] = 0.f; oid[i] = 0;
+  }
+  if (score_mode == 1) router_softmax(score, slots, n_experts, false, lane);
+  else if (score_mode == 2) for (int i = 0; i < slots; ++i) score[i] = 1.0f / (1.0f + expf(-score[i]));
+  for (int i = 0; i < slots; ++i) {
+    const int e = lane + 32 * i;
+    sel[i] = score[i];
+    if (bias && e < n_experts) sel[i] += bias[e];
+    if (sel[i] != sel[i]) sel[i] = -INFINITY;
+  }
+  for (int k = 0; k < top_k; ++k) {
+    float bs = sel[0], bsc = score[0], br = raw[0];
+    int be = lane;
+    for (int i = 1; i < slots; ++i) {
+      const int e = lane + 32 * i;
+      if (e < n_experts && sel[i] > bs) { bs = sel[i]; bsc = score[i]; br = raw[i]; be = e; }
+    }
+#pragma unroll
+    for (int m = 16; m > 0; m >>= 1) {
+      const float os = __shfl_xor(bs, m, 64), osc = __shfl_xor(bsc, m, 64), orw = __shfl_xor(br, m, 64);
+      const int oe = __shfl_xor(be, m, 64);
+      if (os > bs || (os == bs && oe < be)) { bs = os; bsc = osc; br = orw; be = oe; }
+    }
+    float out = bsc;
+    if (weight_mode == 1) out = br;
+    else if (weight_mode == 2) out = 1.0f / (1.0f + expf(-br));
+    if ((k & 31) == lane) { ow[k / 32] = out; oid[k / 32] = (uint32_t)be; }
+    if ((be & 31) == lane) sel[be / 32] = -INFINITY;
+  }
+  if (weight_mode == 1) router_softmax(ow, slots, top_k, true, lane);
+  if (renormalize) {
+    float sum = 0.f;
+    for (int i = 0; i < slots; ++i) if (lane + 32 * i < top_k) sum += ow[i];
+    sum = fmaxf(half_sum32(sum), norm_min);
+    const float inv = 1.0f / sum;
+    for (int i = 0; i < slots; ++i) ow[i] *= inv;
+  }
+  for (int i = 0; i < slots; ++i) {
+    const int idx = lane + 32 * i;
+    if (idx < top_k) {
+      float sc = output_scale;
+      if (expert_scale) sc *= expert_scale[oid[i]];
+      weights[idx] = ow[i] * sc;
+      ids[idx] = oid[i];
+    }
+  }
+}
+template <class T>
+static void launch_moe_router(const void *logits, float *weights, uint32_t *ids, const float *bias, const float *expert_scale, int n_rows, int n_experts,
+                              int top_k, int score_mode, int weight_mode, bool renormalize, bool clamp_logits, float clamp_min, float clamp_max,
+                              float norm_min, float output_scale, int64_t stream) {
+  if (n_rows <= 0) return;
+  switch (n_experts) { case 1: case 2: case 4: case 8: case 16: case 32: case 64: case 128: case 256: case 512: case 576: break; default: return; }
+  hipLaunchKernelGGL((moe_router_topk_kernel<T>), dim3((n_rows + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const T *)logits, weights, ids, bias,
+                     expert_scale, n_rows, n_experts, top_k, score_mode, weight_mode, renormalize, clamp_logits, clamp_min, clamp_max, norm_min,
+                     output_scale);
+}
+}  // namespace mrs
+#define MRS_ROUTER(tag, T)                                                                                                                       \
+  extern "C" void moe_router_topk_##tag(const void *logits, float *weights, uint32_t *ids, const float *selection_bias, const float *expert_scale, \
+                                        int n_rows, int n_experts, int top_k, int score_mode, int weight_mode, bool renormalize,                  \
+                                        bool clamp_logits, float clamp_min, float clamp_max, float norm_min, float output_scale, int64_t stream) { \
+    mrs::launch_moe_router<T>(logits, weights, ids, selection_bias, expert_scale, n_rows, n_experts, top_k, score_mode, weight_mode, renormalize,   \
+                              clamp_logits, clamp_min, clamp_max, norm_min, output_scale, stream);                                               \
+  }
+MRS_ROUTER(f32, float)
+MRS_ROUTER(f16, mrs::f16_t)
+MRS_ROUTER(bf16, mrs::bf16_t)

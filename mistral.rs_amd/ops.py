@@ -87,3 +87,29 @@ def rms_norm_residual(x: torch.Tensor, residual: torch.Tensor, weight: torch.Ten
     fn(x.data_ptr(), residual.data_ptr(), weight.data_ptr(), scale.data_ptr() if scale is not None else None,
        out.data_ptr(), x.numel() // x.shape[-1], x.shape[-1], eps, _stream())
     return out
+
+
+def moe_router_topk(logits: torch.Tensor, top_k: int, score_mode: int = 1, weight_mode: int = 0, renormalize: bool = True,
+                    selection_bias: torch.Tensor | None = None, expert_scale: torch.Tensor | None = None, clamp: tuple | None = None,
+                    norm_min: float = 0.0, output_scale: float = 1.0):
+    """`moe_router_topk` (mistralrs-core/src/ops.rs:259-336 over cuda/ffi.rs:523-579): logits [rows, n_experts] (f32 / f16 / bf16) ->
+    (ids uint32 [rows, top_k], weights f32 [rows, top_k]).  score_mode 0 raw / 1 softmax / 2 sigmoid; weight_mode 0 score / 1 softmax
+    over the picked raw logits / 2 sigmoid(raw).  Mixtral: softmax, weights = scores, renormalised."""
+    if logits.dim() != 2 or logits.dtype not in _TAG or not logits.is_contiguous():
+        raise ValueError("moe_router_topk: contiguous logits [rows, n_experts] in f32 / f16 / bf16")
+    rows, n_experts = logits.shape
+    if n_experts not in (1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 576):
+        raise ValueError(f"moe_router_topk: unsupported expert count {n_experts}")
+    if not 1 <= top_k <= n_experts:
+        raise ValueError(f"moe_router_topk: top_k {top_k} out of range for {n_experts} experts")
+    for t in (selection_bias, expert_scale):
+        if t is not None and (t.dtype != torch.float32 or t.numel() != n_experts or not t.is_contiguous()):
+            raise ValueError("moe_router_topk: selection_bias / expert_scale must be contiguous f32 [n_experts]")
+    ids = torch.empty(rows, top_k, dtype=torch.int32, device=logits.device)
+    weights = torch.empty(rows, top_k, dtype=torch.float32, device=logits.device)
+    import ctypes as C
+    fn = _lib.sym("core", f"moe_router_topk_{_TAG[logits.dtype]}", [_vp] * 5 + [_i] * 5 + [C.c_bool, C.c_bool, _f, _f, _f, _f, _l])
+    fn(logits.data_ptr(), weights.data_ptr(), ids.data_ptr(), selection_bias.data_ptr() if selection_bias is not None else None,
+       expert_scale.data_ptr() if expert_scale is not None else None, rows, n_experts, top_k, score_mode, weight_mode, bool(renormalize),
+       clamp is not None, float(clamp[0]) if clamp else 0.0, float(clamp[1]) if clamp else 0.0, float(norm_min), float(output_scale), _stream())
+    return ids, weights

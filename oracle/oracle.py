@@ -331,3 +331,97 @@ def fp8_e4m3_encode(x: np.ndarray) -> np.ndarray:
     code = np.where(a >= _FP8_GRID[-1], len(_FP8_GRID) - 1, code)
     code = np.where(np.isnan(a), 0x7F, code).astype(np.uint8)
     return (code | (np.signbit(x).astype(np.uint8) << 7)).astype(np.uint8)
+
+
+# ---------------------------------------------------------------------------------------------------- MoE router
+def moe_router_topk(logits: np.ndarray, top_k: int, score_mode: int = 1, weight_mode: int = 0, renormalize: bool = True, bias=None,
+                    expert_scale=None, clamp=None, norm_min: float = 0.0, output_scale: float = 1.0):
+    """moe_router_topk_kernel (mistralrs-core/src/cuda/sort.cu:1186-1357; caller ops.rs:259-336) per row of logits [rows, E], in f32 with
+    the kernel's summation structure (expert e in lane e % 32: strided partial sums, then an xor butterfly 16..1):
+    clamp, NaN -> -inf; score = raw (0) / softmax (1) / sigmoid (2); selection = score + bias, NaN -> -inf; top_k arg-max rounds, ties to
+    the lowest expert id; weight = score (0) / softmax over the picked raw logits (1) / sigmoid(raw) (2); renormalise by max(sum, norm_min);
+    * output_scale (* expert_scale[id]).  Returns (ids uint32 [rows, k], weights f32 [rows, k]).  Pinned to the reference kernel run on
+    the host (tests/test_oracle_ref.py)."""
+    f = np.float32
+    x = np.asarray(logits, dtype=np.float32)
+    rows, E = x.shape
+    slots = E // 32 if E > 32 else 1
+
+    def lane_view(v, fill):  # [slots, 32] with expert e at [e // 32, e % 32]
+        out = np.full(slots * 32, fill, dtype=np.float32)
+        out[:E] = v
+        return out.reshape(slots, 32)
+
+    def butterfly(v, op):  # 32 lanes, masks 16..1, every lane ends with the same value (the kernel's order)
+        v = v.astype(np.float32).copy()
+        for m in (16, 8, 4, 2, 1):
+            v = op(v, v[np.arange(32) ^ m]).astype(np.float32)
+        return v[0]
+
+    def softmax_lanes(v, limit):  # v [slots, 32]; entries >= limit (entry = lane + 32 i) are excluded when limit is not None
+        idx = np.arange(32)[None, :] + 32 * np.arange(v.shape[0])[:, None]
+        live = np.ones_like(v, dtype=bool) if limit is None else idx < limit
+        mx = np.full(32, -np.inf, dtype=np.float32)
+        for i in range(v.shape[0]):
+            mx = np.where(live[i], np.maximum(mx, v[i]), mx)
+        mx = butterfly(mx, np.maximum)
+        with np.errstate(invalid="ignore"):
+            ex = np.where(live, np.exp((v - mx).astype(np.float32)).astype(np.float32), f(0))
+        s = np.zeros(32, dtype=np.float32)
+        for i in range(v.shape[0]):
+            s = (s + np.where(live[i], ex[i], f(0))).astype(np.float32)
+        inv = f(1) / butterfly(s, np.add)
+        return np.where(live, (ex * inv).astype(np.float32), ex)
+
+    ids = np.zeros((rows, top_k), dtype=np.uint32)
+    wts = np.zeros((rows, top_k), dtype=np.float32)
+    for r in range(rows):
+        v = x[r].copy()
+        if clamp is not None:
+            v = np.minimum(np.maximum(v, f(clamp[0])), f(clamp[1])).astype(np.float32)
+        v = np.where(np.isnan(v), f(-np.inf), v)
+        raw = lane_view(v, -np.inf)
+        if score_mode == 1:
+            score = softmax_lanes(raw, None)
+        elif score_mode == 2:
+            with np.errstate(over="ignore"):
+                score = (f(1) / (f(1) + np.exp(-raw).astype(np.float32))).astype(np.float32)
+        else:
+            score = raw.copy()
+        sel = score.copy()
+        if bias is not None:
+            sel.reshape(-1)[:E] = (sel.reshape(-1)[:E] + np.asarray(bias, dtype=np.float32)).astype(np.float32)
+        sel = np.where(np.isnan(sel), f(-np.inf), sel).reshape(-1)
+        if E < 32:
+            sel[E:] = -np.inf  # lanes beyond the experts hold -inf logits in the kernel (sigmoid(-inf) = 0 is never selected before real ones unless all tie)
+        out = np.zeros(top_k, dtype=np.float32)
+        flat_score, flat_raw = score.reshape(-1), raw.reshape(-1)
+        for k in range(top_k):
+            best = int(np.flatnonzero(sel == sel.max())[0])  # ties: lowest expert id
+            ids[r, k] = best
+            if weight_mode == 1:
+                out[k] = flat_raw[best]
+            elif weight_mode == 2:
+                out[k] = f(1) / (f(1) + np.exp(-flat_raw[best], dtype=np.float32))
+            else:
+                out[k] = flat_score[best]
+            sel[best] = -np.inf
+        oslots = max(slots, (top_k + 31) // 32)
+        ow = np.zeros(oslots * 32, dtype=np.float32)
+        ow[:top_k] = out
+        ow = ow.reshape(oslots, 32)
+        if weight_mode == 1:
+            ow = softmax_lanes(ow, top_k)
+        if renormalize:
+            s = np.zeros(32, dtype=np.float32)
+            idx = np.arange(32)[None, :] + 32 * np.arange(oslots)[:, None]
+            for i in range(oslots):
+                s = (s + np.where(idx[i] < top_k, ow[i], f(0))).astype(np.float32)
+            tot = np.maximum(butterfly(s, np.add), f(norm_min))
+            ow = (ow * (f(1) / tot)).astype(np.float32)
+        w = ow.reshape(-1)[:top_k]
+        sc = np.full(top_k, f(output_scale), dtype=np.float32)
+        if expert_scale is not None:
+            sc = (sc * np.asarray(expert_scale, dtype=np.float32)[ids[r]]).astype(np.float32)
+        wts[r] = (w * sc).astype(np.float32)
+    return ids, wts

@@ -297,3 +297,47 @@ def test_fused_glu_matches_reference_kernels(oracle, dt, act):
         want = round_through(round_through(oracle.fused_glu(a, np.ones_like(a), act), dt) * b, dt)
         tol = 2 * ULP[dt] * np.abs(want) + 2e-6 * np.abs(b) * (np.abs(a) + 1)
         assert (np.abs(out.float().numpy() - want) <= tol + 1e-30).all()
+
+
+ROUTER_CASES = [
+    dict(E=8, k=2, score=1, weight=0, renorm=True),                       # Mixtral: softmax -> top-2 -> renormalise
+    dict(E=8, k=2, score=1, weight=0, renorm=False),
+    dict(E=64, k=6, score=2, weight=0, renorm=True, bias=True, norm_min=1e-20, oscale=2.5),   # DeepSeek-style sigmoid + bias
+    dict(E=128, k=8, score=0, weight=1, renorm=False),                    # top-k of raw logits, softmax over the picks
+    dict(E=256, k=8, score=2, weight=2, renorm=True, escale=True, clamp=(-3.0, 3.0)),
+    dict(E=576, k=40, score=1, weight=0, renorm=True),                    # more picks than lanes
+    dict(E=4, k=4, score=1, weight=1, renorm=True),
+    dict(E=1, k=1, score=1, weight=0, renorm=True),
+]
+
+
+def _router_inputs(case, rows=7, seed=0):
+    rng = np.random.default_rng(seed + case["E"])
+    x = (rng.standard_normal((rows, case["E"])) * 2).astype(np.float32)
+    x[0, :] = 0.25                       # a full tie: ids must come out as 0, 1, 2, ...
+    if case["E"] >= 8:
+        x[1, 3] = np.nan                 # NaN logits are never selected
+    bias = (rng.standard_normal(case["E"]) * 0.1).astype(np.float32) if case.get("bias") else None
+    esc = rng.uniform(0.5, 2.0, case["E"]).astype(np.float32) if case.get("escale") else None
+    return x, bias, esc
+
+
+@pytest.mark.parametrize("case", ROUTER_CASES, ids=[f"E{c['E']}k{c['k']}s{c['score']}w{c['weight']}" for c in ROUTER_CASES])
+def test_moe_router_oracle_matches_reference_kernel(oracle, case):
+    """moe_router_topk_kernel (sort.cu:1186-1357) on host fibers: ids identical (incl. tie and NaN rules), weights to f32 rounding."""
+    lib = _ref("libref_router.so")
+    x, bias, esc = _router_inputs(case)
+    rows, E, k = x.shape[0], case["E"], case["k"]
+    ids = np.zeros((rows, k), dtype=np.uint32)
+    w = np.zeros((rows, k), dtype=np.float32)
+    clamp = case.get("clamp")
+    rc = lib.ref_moe_router_topk_f32(_vp(x), _vp(w), _vp(ids), _vp(bias) if bias is not None else None, _vp(esc) if esc is not None else None,
+                                     rows, E, k, case["score"], case["weight"], int(case["renorm"]), int(clamp is not None),
+                                     C.c_float(clamp[0] if clamp else 0.0), C.c_float(clamp[1] if clamp else 0.0),
+                                     C.c_float(case.get("norm_min", 0.0)), C.c_float(case.get("oscale", 1.0)))
+    assert rc == 0
+    gi, gw = oracle.moe_router_topk(x, k, case["score"], case["weight"], case["renorm"], bias, esc, clamp, case.get("norm_min", 0.0), case.get("oscale", 1.0))
+    np.testing.assert_array_equal(gi, ids)
+    np.testing.assert_allclose(gw, w, rtol=3e-6, atol=1e-9)
+    if bias is None:
+        assert list(ids[0, : min(k, 4)]) == list(range(min(k, 4)))  # full tie: lowest expert ids first
