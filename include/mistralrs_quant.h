@@ -49,6 +49,18 @@ MRS_DECL_MMVQ_T(q2_k) MRS_DECL_MMVQ_T(q3_k) MRS_DECL_MMVQ_T(q4_k) MRS_DECL_MMVQ_
 #undef MRS_DECL_MMVQ_T
 #undef MRS_DECL_MMVQ
 
+/* ---- indexed MoE forward: out[task][row] = W[indices[task]][row] . y[input_dim1 == 1 ? task / topk : task], task = token * topk + slot.
+ *      all_weights: E stacked packed matrices [n][k / blk]; all_inputs: Q8_1 rows of k_padded / 32 blocks; all_outputs f32 [batch*topk][n].
+ *      replaces kernels/indexed_moe/indexed_moe.cu:806-1157 ; Rust: src/gguf/ffi.rs:100-260 ; caller gguf/cuda.rs:514-588
+ *      (qmatmul_indexed_moe_forward <- GgufMatMul::gather_forward_raw, gguf/mod.rs:485-516).  The q8_1-weight variant is not built. */
+#define MRS_DECL_IMOE(t)                                                                                                          \
+  void launch_indexed_moe_forward_##t##_q8_1(const void *all_weights, const void *all_inputs, const unsigned int *indices,         \
+                                             float *all_outputs, int n, int k, int batch, int topk, int k_padded, int input_dim1, \
+                                             void *stream);
+MRS_DECL_IMOE(q4_0) MRS_DECL_IMOE(q4_1) MRS_DECL_IMOE(q5_0) MRS_DECL_IMOE(q5_1) MRS_DECL_IMOE(q8_0)
+MRS_DECL_IMOE(q2k) MRS_DECL_IMOE(q3k) MRS_DECL_IMOE(q4k) MRS_DECL_IMOE(q5k) MRS_DECL_IMOE(q6k)
+#undef MRS_DECL_IMOE
+
 /* ---- RoPE, in place, arithmetic in the tensor dtype.  `rot_dim` = number of rotated PAIRS (= cos/sin row
  *      length); is_neox: pairs (i, i+rot_dim) else interleaved (2i, 2i+1); dtype 0 f16, 1 bf16, 2 f32.
  *      replaces kernels/rotary/rotary.cu:122-196 ; Rust: src/rotary/ffi.rs ; caller rotary/mod.rs:851 */

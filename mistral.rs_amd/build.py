@@ -37,7 +37,8 @@ def _tu(src, obj=None, defines=()):
 
 def libraries():
     quant = [_tu("mmvq_quantize.hip")]
-    quant += [_tu("mmvq_inst.hip", f"mmvq_{tag}.o", (f"-DMRS_TAG={tag}", f"-DMRS_TYPE={tid}"))
+    quant += [_tu("mmvq_inst.hip", f"mmvq_{tag}.o", (f"-DMRS_TAG={tag}", f"-DMRS_TYPE={tid}",
+                                                      "-DMRS_MOE_TAG=" + (tag.replace("_k", "k") if tag.endswith("_k") else tag)))
               for tag, tid in MMVQ_TYPES.items()]
     libs = {"libmistralrsquant.so": quant}
     pa = [_tu("kv_cache_ops.hip")]

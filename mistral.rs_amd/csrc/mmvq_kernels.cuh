@@ -21,6 +21,11 @@ struct MmvqArgs {
   int activation;
   int dst_kind;
   int rows_per_wave;
+  // indexed MoE forward (launch_indexed_moe_forward_<t>_q8_1, kernels/indexed_moe/indexed_moe.cu:806-890): blockIdx.y = task = token * topk + slot;
+  // weights of expert indices[task] (stride expert_stride bytes), Q8_1 row (input_dim1 == 1 ? token : task), f32 output row `task`
+  const uint32_t *indices;  // nullptr = dense launch
+  size_t expert_stride;
+  int topk, input_dim1;
 };
 
 __device__ __forceinline__ void store_dst(void *dst, size_t idx, float v, int kind) {
@@ -44,8 +49,18 @@ __global__ void __launch_bounds__(256) mmvq_kernel(const MmvqArgs a) {
   const int rpw = a.rows_per_wave;  // contiguous rows per wave: each wave streams one contiguous byte range
   const int first = (blockIdx.x * 4 + wave) * rpw;
   const int nrows = max(0, min(rpw, total_rows - first));
+  const uint8_t *ybase = a.y, *w0 = a.w[0];
+  void *dst0 = a.dst[0];
+  if constexpr (MODE == MODE_PLAIN && NCOLS == 1) {
+    if (a.indices) {  // wave-uniform
+      const int task = blockIdx.y;
+      w0 += (size_t)a.indices[task] * a.expert_stride;
+      ybase += (size_t)(a.input_dim1 == 1 ? task / a.topk : task) * a.stride_col_y * 36;
+      dst0 = (float *)a.dst[0] + (size_t)task * a.nrows[0];
+    }
+  }
   auto pro = [&]() {
-    const ActLds act = stage_q8_1<TYPE, NCOLS>(smem, a.y, K, a.stride_col_y);
+    const ActLds act = stage_q8_1<TYPE, NCOLS>(smem, ybase, K, a.stride_col_y);
     __syncthreads();
     return act;
   };
@@ -76,7 +91,7 @@ __global__ void __launch_bounds__(256) mmvq_kernel(const MmvqArgs a) {
     auto rowptr = [&](int r, const uint8_t *&pA, const uint8_t *&pB) {
       int m, lr;
       locate(r, m, lr);
-      pA = a.w[m] + (size_t)lr * row_bytes;
+      pA = (MODE == MODE_PLAIN ? w0 : a.w[m]) + (size_t)lr * row_bytes;
       pB = pA + row_bytes;  // row pairs (paired-row path): r + 1 lies in the same matrix (every row count is even there)
     };
     auto store_row = [&](int r, const float(&v)[NCOLS]) {
@@ -84,7 +99,7 @@ __global__ void __launch_bounds__(256) mmvq_kernel(const MmvqArgs a) {
       locate(r, m, lr);
       const int stride = (MODE == MODE_QKV) ? a.nrows[m] : a.stride_col_dst;
 #pragma unroll
-      for (int c = 0; c < NCOLS; ++c) store_dst(a.dst[m], (size_t)c * stride + lr, v[c], a.dst_kind);
+      for (int c = 0; c < NCOLS; ++c) store_dst(MODE == MODE_PLAIN ? dst0 : a.dst[m], (size_t)c * stride + lr, v[c], a.dst_kind);
     };
     bool paired = false;
     if constexpr (PairQ<TYPE>::value) {  // Q4_K / Q5_K: two rows per step, 64-weight arithmetic per lane (mmvq_core.cuh)
@@ -116,7 +131,7 @@ inline int mmvq_rows_per_wave(int total_rows, bool want_even) {
 }
 
 template <int TYPE, int MODE> struct MmvqLaunch {
-  template <int NCOLS> static void go(const MmvqArgs &a, int total_rows, hipStream_t s) {
+  template <int NCOLS> static void go(const MmvqArgs &a, int total_rows, hipStream_t s, int tasks = 1) {
     const size_t lds = act_lds_bytes(a.ncols_x, NCOLS, Fmt<TYPE>::HAS_OFFSET);
     static bool attr_done = false;  // > 64 KiB of dynamic LDS needs the opt-in once per kernel
     if (lds > 65536 && !attr_done) {
@@ -126,7 +141,7 @@ template <int TYPE, int MODE> struct MmvqLaunch {
     MmvqArgs b = a;
     b.rows_per_wave = mmvq_rows_per_wave(total_rows, PairQ<TYPE>::value && MODE != MODE_GLU);
     const int grid = (total_rows + 4 * b.rows_per_wave - 1) / (4 * b.rows_per_wave);
-    hipLaunchKernelGGL((mmvq_kernel<TYPE, NCOLS, MODE>), dim3(grid), dim3(256), lds, s, b);
+    hipLaunchKernelGGL((mmvq_kernel<TYPE, NCOLS, MODE>), dim3(grid, tasks), dim3(256), lds, s, b);
   }
   static void run(const MmvqArgs &a, int b_size, hipStream_t s) {
     const int total_rows = (MODE == MODE_QKV) ? a.nrows[0] + a.nrows[1] + a.nrows[2] : a.nrows[0];
@@ -182,3 +197,22 @@ template <int TYPE, int MODE> struct MmvqLaunch {
   MRS_MMVQ_LAUNCHERS_DST(tag, TYPE, f32, mrs::DST_F32)   \
   MRS_MMVQ_LAUNCHERS_DST(tag, TYPE, f16, mrs::DST_F16)   \
   MRS_MMVQ_LAUNCHERS_DST(tag, TYPE, bf16, mrs::DST_BF16)
+
+
+// launch_indexed_moe_forward_<moe tag>_q8_1 (mistralrs-quant/src/gguf/ffi.rs:100-260; kernels/indexed_moe/indexed_moe.cu:806-1157):
+// all_weights [E][n][k / blk] packed, all_inputs Q8_1 rows of k_padded / 32 blocks ([batch] when input_dim1 == 1, else [batch * topk]),
+// indices [batch * topk] expert ids, all_outputs f32 [batch * topk][n].  Caller: GgufMatMul::gather_forward_raw -> qmatmul_indexed_moe_forward
+// (gguf/mod.rs:485-516, gguf/cuda.rs:514-588).  Same dot-product arithmetic as the plain MMVQ launch of one expert.
+#define MRS_INDEXED_MOE_LAUNCHER(moetag, TYPE) MRS_INDEXED_MOE_LAUNCHER_(moetag, TYPE)  /* expand the tag macro before pasting */
+#define MRS_INDEXED_MOE_LAUNCHER_(moetag, TYPE)                                                                                        \
+  extern "C" void launch_indexed_moe_forward_##moetag##_q8_1(const void *all_weights, const void *all_inputs, const unsigned int *indices, \
+                                                             float *all_outputs, int n, int k, int batch, int topk, int k_padded,       \
+                                                             int input_dim1, void *stream) {                                          \
+    if (n <= 0 || batch <= 0 || topk <= 0) return;                                                                                    \
+    mrs::MmvqArgs a{};                                                                                                                \
+    a.w[0] = (const uint8_t *)all_weights; a.dst[0] = all_outputs; a.nrows[0] = n; a.y = (const uint8_t *)all_inputs;                  \
+    a.ncols_x = k; a.stride_col_y = k_padded / 32; a.stride_col_dst = n; a.dst_kind = mrs::DST_F32;                                    \
+    a.indices = indices; a.topk = topk; a.input_dim1 = input_dim1;                                                                    \
+    a.expert_stride = (size_t)n * (size_t)(k / mrs::Fmt<TYPE>::BLK) * mrs::Fmt<TYPE>::TS;                                              \
+    mrs::MmvqLaunch<TYPE, mrs::MODE_PLAIN>::go<1>(a, n, (hipStream_t)stream, batch * topk);                                           \
+  }

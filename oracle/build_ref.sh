@@ -14,6 +14,7 @@
 #   _ref/libref_mmvq_kernel.so <- the whole mmvq_gguf.cu kernel set (mmvq_core_impl, fused GLU; f32 destinations) on host fibers
 #   _ref/libref_glu.so    <- fused_glu_kernel / fused_glu_kernel_vec4 (mistralrs-quant/kernels/ops/ops.cu) in f32 / f16 / bf16
 #   _ref/libref_router.so <- moe_router_topk_kernel (mistralrs-core/src/cuda/sort.cu:1097-1357), f32 logits, all option combinations
+#   _ref/libref_imoe.so   <- indexed_moe_forward_<t>_q8_1 kernels (kernels/indexed_moe/indexed_moe.cu) on host fibers
 #   _ref/libref_hqq.so    <- the __global__ kernel templates of kernels/hqq/hqq.cu (dequantize_*) and hqq_bitpack.cu (pack_*),
 #                            run one thread at a time by ref_shim/hqq_driver.inc
 # The reference text is STREAMED into g++ (stdin); nothing from /root/reference is written into this repo.
@@ -79,6 +80,12 @@ STRIP='/^#include/d; /^#pragma once/d'
 ( cat "$HERE/ref_shim/cuda_shim.h" "$HERE/ref_shim/fiber_shim.h"
   awk '/^\/\/ Host-side launchers/{exit} {print}' "$MMVQ" | grep -v '#include "cuda_' | grep -v '^#define WARP_SIZE'
   cat "$HERE/ref_shim/mmvq_kernel_driver.inc" ) | $CXX $FLAGS $FIB -o "$OUT/libref_mmvq_kernel.so" -
+# indexed MoE forward (mistralrs-quant/kernels/indexed_moe/indexed_moe.cu): everything except the <<<>>> launchers
+IMOE="$REF/mistralrs-quant/kernels/indexed_moe/indexed_moe.cu"
+( cat "$HERE/ref_shim/cuda_shim.h" "$HERE/ref_shim/fiber_shim.h"
+  awk '/^\/\/ Launch wrapper for BF16 quantize/{p=0} /^\/\/ indexed_moe_forward template/{p=1} /^\/\/ =+ C wrapper functions/{exit} BEGIN{p=1} p{print}' "$IMOE" \
+    | grep -v '#include "cuda_' | grep -v '^#define WARP_SIZE'
+  cat "$HERE/ref_shim/imoe_driver.inc" ) | $CXX $FLAGS $FIB -o "$OUT/libref_imoe.so" -
 # MoE router (mistralrs-core/src/cuda/sort.cu): constants, warp reductions and moe_router_topk_kernel up to its launcher
 ( cat "$HERE/ref_shim/cuda_shim.h" "$HERE/ref_shim/fiber_shim.h"
   echo 'static inline float max(float a, float b) { return fmaxf(a, b); }'
@@ -96,4 +103,4 @@ SORT="$REF/mistralrs-core/src/cuda/sort.cu"
   sed -n '148,318p' "$SORT" | awk '/^template <typename T>$/{t=$0; next} /^void launch_/{skip=1} !skip{if (t != "") print t; print} {t=""} skip && /^}$/{skip=0}'
   sed -n '351,428p' "$SORT"
   cat "$HERE/ref_shim/rms_driver.inc" ) | $CXX $FLAGS $FIB -o "$OUT/libref_rms.so" -
-echo "oracle/_ref: built libref_mmvq.so libref_affine.so libref_hqq.so libref_cache.so libref_pa.so libref_q8_1.so libref_rms.so libref_mmvq_kernel.so libref_glu.so libref_router.so from $REF"
+echo "oracle/_ref: built libref_mmvq.so libref_affine.so libref_hqq.so libref_cache.so libref_pa.so libref_q8_1.so libref_rms.so libref_mmvq_kernel.so libref_glu.so libref_router.so libref_imoe.so from $REF"

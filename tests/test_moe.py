@@ -75,3 +75,33 @@ def test_moe_router_topk_abi_vs_oracle(oracle, dev, dt):
         np.testing.assert_allclose(got_w[same], gw[same], rtol=2e-5, atol=1e-8)
     with pytest.raises(ValueError, match="expert count"):
         ops.moe_router_topk(torch.zeros(2, 12, device=dev), 2)
+
+
+@pytest.mark.parametrize("tname", ["Q4_0", "Q4_1", "Q5_0", "Q5_1", "Q8_0", "Q2_K", "Q3_K", "Q4_K", "Q5_K", "Q6_K"])
+@pytest.mark.parametrize("input_dim1", [1, 2])
+def test_indexed_moe_forward_abi(oracle, dev, tname, input_dim1):
+    """Drop-in `launch_indexed_moe_forward_<t>_q8_1` (gguf/ffi.rs:100-260): per task the plain MMVQ result of the selected expert, within the
+    f32-accumulation bound of the oracle (itself pinned to the reference kernel, tests/test_oracle_ref.py)."""
+    import ctypes as C
+    import torch
+    from mistralrs_amd import _lib
+    from tests.test_oracle_ref import _imoe_case
+    t = getattr(oracle, tname)
+    E, n, k, batch, topk, w, idx, rng = _imoe_case(oracle, t, seed=4)
+    n = 12
+    rows_in = batch if input_dim1 == 1 else batch * topk
+    x = (rng.standard_normal((rows_in, k)) * rng.uniform(0.3, 4.0, (rows_in, 1))).astype(np.float32)
+    y = oracle.quantize_q8_1(x)
+    kp = oracle.pad512(k)
+    wt, yt, it = torch.from_numpy(w).to(dev), torch.from_numpy(y).to(dev), torch.from_numpy(idx.astype(np.int32)).to(dev)
+    out = torch.zeros(batch * topk, n, device=dev)
+    tag = oracle.TYPE_NAMES[t].replace("_k", "k")
+    fn = _lib.sym("quant", f"launch_indexed_moe_forward_{tag}_q8_1", [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_void_p])
+    fn(wt.data_ptr(), yt.data_ptr(), it.data_ptr(), out.data_ptr(), n, k, batch, topk, kp, input_dim1, torch.cuda.current_stream().cuda_stream)
+    got = out.cpu().numpy().astype(np.float64)
+    for task in range(batch * topk):
+        e = int(idx[task])
+        row = task // topk if input_dim1 == 1 else task
+        want, mag = oracle.matmul_q8_1_mag(t, w[e * n:(e + 1) * n], n, k, y[row:row + 1])
+        tol = 8 * 2.0 ** -23 * np.sqrt(k / 16) * mag[0].astype(np.float64) + 2.0 ** -23 * np.abs(want[0]) + 1e-30
+        assert (np.abs(got[task] - want[0]) <= tol).all(), task

@@ -341,3 +341,32 @@ def test_moe_router_oracle_matches_reference_kernel(oracle, case):
     np.testing.assert_allclose(gw, w, rtol=3e-6, atol=1e-9)
     if bias is None:
         assert list(ids[0, : min(k, 4)]) == list(range(min(k, 4)))  # full tie: lowest expert ids first
+
+
+def _imoe_case(oracle, t, seed=0):
+    rng = np.random.default_rng(seed + t)
+    E, n, k, batch, topk = 5, 12, 512, 3, 2
+    w = np.concatenate([oracle.random_blocks(t, n, k, seed=50 + e + t, d_scale=0.02) for e in range(E)], axis=0)  # [E*n, row_bytes]
+    idx = rng.integers(0, E, size=batch * topk).astype(np.uint32)
+    return E, n, k, batch, topk, w, idx, rng
+
+
+@pytest.mark.parametrize("t", TYPES)
+@pytest.mark.parametrize("input_dim1", [1, 2])
+def test_indexed_moe_forward_matches_reference_kernel(oracle, t, input_dim1):
+    """indexed_moe_forward_<t>_q8_1 (kernels/indexed_moe/indexed_moe.cu:806-1013) on host fibers == per task the Q8_1 matvec oracle with the
+    weights of expert indices[task]; input row = token (input_dim1 == 1: shared by the token's top-k slots) or task."""
+    lib = _ref("libref_imoe.so")
+    E, n, k, batch, topk, w, idx, rng = _imoe_case(oracle, t)
+    rows_in = batch if input_dim1 == 1 else batch * topk
+    x = (rng.standard_normal((rows_in, k)) * rng.uniform(0.3, 4.0, (rows_in, 1))).astype(np.float32)
+    y = oracle.quantize_q8_1(x)
+    kp = oracle.pad512(k)
+    out = np.zeros((batch * topk, n), dtype=np.float32)
+    assert lib.ref_indexed_moe_forward(t, _vp(w), _vp(y), _vp(idx), _vp(out), n, k, batch, topk, kp, input_dim1) == 0
+    for task in range(batch * topk):
+        e = int(idx[task])
+        row = task // topk if input_dim1 == 1 else task
+        want, mag = oracle.matmul_q8_1_mag(t, w[e * n:(e + 1) * n], n, k, y[row:row + 1])
+        tol = 8 * 2.0 ** -23 * np.sqrt(k / 16) * mag[0].astype(np.float64) + 2.0 ** -23 * np.abs(want[0]) + 1e-30
+        assert (np.abs(out[task].astype(np.float64) - want[0]) <= tol).all(), task
