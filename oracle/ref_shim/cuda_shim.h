@@ -59,6 +59,11 @@ struct __half {
   __half(float f) : bits(shim_f2h(f)) {}  // implicit, like the device type
   operator float() const { return shim_h2f(bits); }
 };
+#ifdef SHIM_HALF_OPS  /* device `__half` arithmetic: every + - * rounds to half (sm_53+ native ops are correctly rounded) */
+static inline __half operator+(__half a, __half b) { return __half((float)a + (float)b); }
+static inline __half operator-(__half a, __half b) { return __half((float)a - (float)b); }
+static inline __half operator*(__half a, __half b) { return __half((float)a * (float)b); }
+#endif
 struct __half2 { __half x, y; };
 typedef __half half;
 typedef __half2 half2;

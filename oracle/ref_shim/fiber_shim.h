@@ -99,6 +99,11 @@ struct __nv_bfloat16 {
   __nv_bfloat16(float f) { uint32_t b; memcpy(&b, &f, 4); if ((b & 0x7fffffffu) > 0x7f800000u) bits = (uint16_t)((b >> 16) | 0x40); else { b += 0x7fffu + ((b >> 16) & 1u); bits = (uint16_t)(b >> 16); } }
   operator float() const { uint32_t b = (uint32_t)bits << 16; float f; memcpy(&f, &b, 4); return f; }
 };
+#ifdef SHIM_HALF_OPS
+static inline __nv_bfloat16 operator+(__nv_bfloat16 a, __nv_bfloat16 b) { return __nv_bfloat16((float)a + (float)b); }
+static inline __nv_bfloat16 operator-(__nv_bfloat16 a, __nv_bfloat16 b) { return __nv_bfloat16((float)a - (float)b); }
+static inline __nv_bfloat16 operator*(__nv_bfloat16 a, __nv_bfloat16 b) { return __nv_bfloat16((float)a * (float)b); }
+#endif
 static inline float __bfloat162float(__nv_bfloat16 v) { return (float)v; }
 static inline __nv_bfloat16 __float2bfloat16(float f) { return __nv_bfloat16(f); }
 static inline __half __float2half(float f) { return __half(f); }

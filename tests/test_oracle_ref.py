@@ -370,3 +370,66 @@ def test_indexed_moe_forward_matches_reference_kernel(oracle, t, input_dim1):
         want, mag = oracle.matmul_q8_1_mag(t, w[e * n:(e + 1) * n], n, k, y[row:row + 1])
         tol = 8 * 2.0 ** -23 * np.sqrt(k / 16) * mag[0].astype(np.float64) + 2.0 ** -23 * np.abs(want[0]) + 1e-30
         assert (np.abs(out[task].astype(np.float64) - want[0]) <= tol).all(), task
+
+
+def _rope16(x, cos, sin, pos, neox, dt):
+    """RoPE with the arithmetic in the tensor dtype, as the reference's f16 / bf16 kernel instantiations run it (rotary.cu:9-33):
+    every product and the final sum / difference round to dt."""
+    from tests.util import round_through
+    r = lambda a: round_through(np.asarray(a, dtype=np.float32), dt)
+    out = x.copy()
+    pairs = cos.shape[1]
+    c, s = cos[pos][:, None, :], sin[pos][:, None, :]
+    if neox:
+        a, b = x[..., :pairs], x[..., pairs:2 * pairs]
+    else:
+        a, b = x[..., 0:2 * pairs:2], x[..., 1:2 * pairs:2]
+    xo, yo = r(r(a * c) - r(b * s)), r(r(b * c) + r(a * s))
+    if neox:
+        out[..., :pairs], out[..., pairs:2 * pairs] = xo, yo
+    else:
+        out[..., 0:2 * pairs:2], out[..., 1:2 * pairs:2] = xo, yo
+    return out
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("neox", [False, True])
+def test_rope_16bit_matches_reference_kernel(dt, neox):
+    from tests.util import round_through
+    import torch
+    lib = _ref("libref_half.so")
+    td = torch.float16 if dt == "f16" else torch.bfloat16
+    rng = np.random.default_rng(11 + int(neox))
+    T, H, KVH, hd, pairs, max_pos = 5, 3, 2, 64, 24, 40
+    q = round_through(rng.standard_normal((T, H, hd)).astype(np.float32), dt)
+    k = round_through(rng.standard_normal((T, KVH, hd)).astype(np.float32), dt)
+    ang = rng.uniform(0, 6.28, (max_pos, pairs))
+    cos, sin = round_through(np.cos(ang).astype(np.float32), dt), round_through(np.sin(ang).astype(np.float32), dt)
+    pos = rng.integers(0, max_pos, T).astype(np.uint32)
+    tq, tk, tc, ts = (torch.from_numpy(a).to(td).contiguous() for a in (q, k, cos, sin))
+    p = lambda t: C.c_void_p(t.data_ptr())
+    lib.ref_rotary_16(0 if dt == "f16" else 1, p(tq), p(tk), p(tc), p(ts), _vp(pos), int(neox), hd, T, pairs, H, KVH, C.c_long(H * hd), C.c_long(KVH * hd))
+    np.testing.assert_array_equal(tq.float().numpy(), _rope16(q, cos, sin, pos, neox, dt))
+    np.testing.assert_array_equal(tk.float().numpy(), _rope16(k, cos, sin, pos, neox, dt))
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("bits", [8, 4, 3, 2, 1])
+def test_hqq_16bit_dequantize_matches_reference_kernel(dt, bits):
+    """f16 / bf16 instantiations of the HQQ dequantize kernels (`(T(q) - zero) * scale` evaluated in T) == the oracle, bit for bit."""
+    from oracle import hqq_oracle as H
+    from tests.util import round_through
+    import torch
+    lib = _ref("libref_half.so")
+    td = torch.float16 if dt == "f16" else torch.bfloat16
+    rng = np.random.default_rng(bits)
+    h, w = 6, 40
+    q = rng.integers(0, 2 ** bits, size=(H.PACK[bits] * h, w)).astype(np.uint32 if bits == 3 else np.uint8)
+    packed = H.pack(bits, q)
+    scale = round_through((rng.uniform(0.001, 0.05, w) * rng.choice([1.0, -1.0], w)).astype(np.float32), dt)
+    zero = round_through(rng.uniform(0.0, 2 ** bits - 1.0, w).astype(np.float32), dt)
+    ts, tz = torch.from_numpy(scale).to(td), torch.from_numpy(zero).to(td)
+    out = torch.zeros(H.PACK[bits] * h, w, dtype=td)
+    pk = np.ascontiguousarray(packed)
+    assert lib.ref_hqq_dequantize_16(0 if dt == "f16" else 1, bits, _vp(pk), C.c_void_p(ts.data_ptr()), C.c_void_p(tz.data_ptr()), C.c_void_p(out.data_ptr()), h, w) == 0
+    np.testing.assert_array_equal(out.float().numpy().view(np.uint32), H.dequantize(bits, packed, scale, zero, dt).view(np.uint32))
