@@ -61,6 +61,51 @@ MRS_DECL_IMOE(q4_0) MRS_DECL_IMOE(q4_1) MRS_DECL_IMOE(q5_0) MRS_DECL_IMOE(q5_1) 
 MRS_DECL_IMOE(q2k) MRS_DECL_IMOE(q3k) MRS_DECL_IMOE(q4k) MRS_DECL_IMOE(q5k) MRS_DECL_IMOE(q6k)
 #undef MRS_DECL_IMOE
 
+/* ---- fused MoE decode pair (f32 in/out, Q8_1 activations, task = token * topk + slot, e = indices[task]):
+ *        gate_up:  out[task][row]   = (up_w[e][row] . y[token]) * act(gate_w[e][row] . y[token])   act_type 0 gelu_pytorch_tanh, else silu
+ *        down_agg: out[token][row] += topk_weights[task] * (w[e][row] . y[task])                    f32 atomics; caller zero-fills out
+ *      replaces kernels/indexed_moe/indexed_moe.cu:1336-1477,1618-1726 ; Rust: src/gguf/ffi.rs:520-890 ; caller gguf/cuda.rs:1427-1640
+ *      (moe_gemv_fused_gate_up / moe_gemv_down_aggregate <- FastExpertsWeights::forward_*, moe/experts/backends.rs:969-1100) */
+#define MRS_DECL_MOE_DECODE(t)                                                                                                      \
+  void launch_moe_gemv_fused_gate_up_##t##_q8_1(const void *gate_weights, const void *up_weights, const void *all_inputs,            \
+                                                const unsigned int *indices, float *all_outputs, int n, int k, int batch, int topk,  \
+                                                int k_padded, int act_type, void *stream);                                          \
+  void launch_moe_gemv_down_aggregate_##t##_q8_1(const void *all_weights, const void *all_inputs, const unsigned int *indices,       \
+                                                 const float *topk_weights, float *all_outputs, int n, int k, int batch, int topk,   \
+                                                 int k_padded, void *stream);
+MRS_DECL_MOE_DECODE(q4_0) MRS_DECL_MOE_DECODE(q4_1) MRS_DECL_MOE_DECODE(q5_0) MRS_DECL_MOE_DECODE(q5_1) MRS_DECL_MOE_DECODE(q8_0)
+MRS_DECL_MOE_DECODE(q2k) MRS_DECL_MOE_DECODE(q3k) MRS_DECL_MOE_DECODE(q4k) MRS_DECL_MOE_DECODE(q5k) MRS_DECL_MOE_DECODE(q6k)
+#undef MRS_DECL_MOE_DECODE
+
+/* ---- MoE prompt path: route dispatch -> grouped GEMM -> weighted reduce.
+ *      launch_moe_dispatch: counting sort of topk_ids[total_assignments] by expert: expert_bounds[num_experts + 1] (exclusive prefix of the
+ *        counts), sorted_token_ids[pos] = flat route index, sorted_source_ids[pos] = flat / topk (may be NULL); expert_counts /
+ *        expert_cursors [num_experts] are caller scratch and end up as counts / bounds[e + 1] like the reference's.  The order inside an
+ *        expert's segment is ascending flat index (the reference's atomic cursors leave it unspecified).
+ *      launch_moe_grouped_gemm_<t>: for sorted position ti in [bounds[e], bounds[e+1]), flat = sorted_token_ids[ti]:
+ *        y row = input_dim1 == 0 ? ti : input_dim1 == 1 ? flat / topk : flat ;  acc = W[e][row] . y ;
+ *        topk_weights ? atomicAdd(out[flat / topk][row], acc * topk_weights[flat]) : out[ti][row] = acc      (f32)
+ *      launch_moe_weighted_reduce_flat*: out[token][h] = sum_slot float(in[token][slot][h]) * w[token][slot], f32 accumulate, -> int status
+ *        (_flat: f32 -> f32, _flat_bf16: f32 -> bf16, _f16_input: f16 -> f16, _bf16_input: bf16 -> bf16)
+ *      replaces kernels/moe_grouped/moe_grouped.cu:630-1235 ; Rust: src/gguf/ffi.rs:285-500 ; callers gguf/cuda.rs:590-930,1340-1420 */
+void launch_moe_dispatch(const int32_t *topk_ids, int32_t *expert_bounds, int32_t *sorted_token_ids, int32_t *sorted_source_ids,
+                         int total_assignments, int num_experts, int topk, int32_t *expert_counts, int32_t *expert_cursors, void *stream);
+#define MRS_DECL_MOE_GROUPED(t)                                                                                                     \
+  void launch_moe_grouped_gemm_##t(const void *all_weights, const void *all_inputs, const int32_t *expert_bounds,                    \
+                                   const int32_t *sorted_token_ids, const float *topk_weights, float *all_outputs, int N, int K,     \
+                                   int K_padded, int num_experts, int topk, int input_dim1, void *stream);
+MRS_DECL_MOE_GROUPED(q4_0) MRS_DECL_MOE_GROUPED(q4_1) MRS_DECL_MOE_GROUPED(q5_0) MRS_DECL_MOE_GROUPED(q5_1) MRS_DECL_MOE_GROUPED(q8_0)
+MRS_DECL_MOE_GROUPED(q2k) MRS_DECL_MOE_GROUPED(q3k) MRS_DECL_MOE_GROUPED(q4k) MRS_DECL_MOE_GROUPED(q5k) MRS_DECL_MOE_GROUPED(q6k)
+#undef MRS_DECL_MOE_GROUPED
+int launch_moe_weighted_reduce_flat(const void *inputs, const float *topk_weights, void *outputs, int num_tokens, int hidden, int topk,
+                                    void *stream);
+int launch_moe_weighted_reduce_flat_bf16(const void *inputs, const float *topk_weights, void *outputs, int num_tokens, int hidden,
+                                         int topk, void *stream);
+int launch_moe_weighted_reduce_flat_f16_input(const void *inputs, const float *topk_weights, void *outputs, int num_tokens, int hidden,
+                                              int topk, void *stream);
+int launch_moe_weighted_reduce_flat_bf16_input(const void *inputs, const float *topk_weights, void *outputs, int num_tokens, int hidden,
+                                               int topk, void *stream);
+
 /* ---- RoPE, in place, arithmetic in the tensor dtype.  `rot_dim` = number of rotated PAIRS (= cos/sin row
  *      length); is_neox: pairs (i, i+rot_dim) else interleaved (2i, 2i+1); dtype 0 f16, 1 bf16, 2 f32.
  *      replaces kernels/rotary/rotary.cu:122-196 ; Rust: src/rotary/ffi.rs ; caller rotary/mod.rs:851 */

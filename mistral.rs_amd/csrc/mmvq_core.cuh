@@ -58,14 +58,14 @@ template <int NCOLS> __device__ __forceinline__ ActLds act_view(char *smem, int 
 // Stage Q8_1 blocks (36 B: half d, half sum(x), 32 x int8) from global memory into LDS.
 // y: [col][stride_col_y] blocks.  Reference layout: mmvq_gguf.cu:141-146 (block_q8_1).
 template <int TYPE, int NCOLS>
-__device__ __forceinline__ ActLds stage_q8_1(char *smem, const uint8_t *__restrict__ y, int K, int stride_col_y) {
+__device__ __forceinline__ ActLds stage_q8_1(char *smem, const uint8_t *__restrict__ y, int K, int stride_col_y, const int *col_rows = nullptr) {
   const int runs = K / 16, nblk = K / 32;
   const ActLds v = act_view<NCOLS>(smem, K);
   int4 *q = (int4 *)v.q;
   float *d8 = (float *)v.d8, *S = (float *)v.S;
   for (int i = threadIdx.x; i < NCOLS * runs; i += blockDim.x) {
     const int col = i / runs, run = i - col * runs;
-    const uint8_t *blk = y + ((size_t)col * stride_col_y + (run >> 1)) * 36;
+    const uint8_t *blk = y + ((size_t)(col_rows ? col_rows[col] : col) * stride_col_y + (run >> 1)) * 36;  // col_rows: gathered rows (grouped MoE)
     const int4 u = ld16_a4(blk + 4 + (run & 1) * 16);
     q[col * runs + swz(run)] = u;
     const unsigned ds = *(const unsigned *)blk;

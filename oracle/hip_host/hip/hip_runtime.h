@@ -1,0 +1,175 @@
+// oracle/hip_host/hip/hip_runtime.h -- TEST INFRASTRUCTURE ONLY (never linked into the product libraries).
+// A wave64 host stand-in for the slice of HIP / gfx950 device vocabulary that this repo's kernels use, so that the PRODUCT kernel sources
+// (mistral.rs_amd/csrc/*.cuh, *.hip) can be compiled for the host (oracle/build_hip_host.sh -> oracle/_hiphost/*.so) and executed thread by
+// thread before GPU time is spent on them: every thread of a workgroup is a fiber (ucontext), __syncthreads() is a workgroup barrier,
+// cross-lane operations (DPP, readlane, shuffles, ballots) are exchanges between the 64 fibers of a wave, `__shared__` variables are
+// function-local statics (one workgroup runs at a time), dynamic LDS is one global buffer, global memory is host memory.
+// What it checks: indexing, layouts, barriers, lane-exchange patterns, arithmetic order (same f32 operations, contraction off).
+// What it cannot check: occupancy, LDS capacity / bank conflicts, memory-model races between waves that the sequential schedule hides,
+// the device's transcendental functions (libm here).  tests/test_hip_host_emulation.py compares the emulated launchers with the oracle.
+#pragma once
+#include <algorithm>
+#include <functional>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ucontext.h>
+#include <vector>
+
+#define __device__
+#define __host__
+#define __global__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ static /* `extern __shared__ T name[];` lines are rewritten by build_hip_host.sh to point at hiphost::dyn_lds */
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct int2 { int x, y; };
+struct int4 { int x, y, z, w; };
+struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+static inline int2 make_int2(int x, int y) { return int2{x, y}; }
+static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+using std::max;
+using std::min;
+
+typedef void *hipStream_t;
+typedef int hipError_t;
+enum { hipSuccess = 0 };
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
+
+// ONE instance across the translation units of a library (C++17 inline variables): inline product functions such as mrs::lane_id() are
+// merged by the linker and must see the same thread coordinates as the launch that runs them
+inline thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+static const int warpSize = 64;
+
+static inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
+static inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }
+static inline int __mul24(int a, int b) { return (int)((uint32_t)((a << 8) >> 8) * (uint32_t)((b << 8) >> 8)); }  // v_mul_i32_i24
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline int __popc(unsigned v) { return __builtin_popcount(v); }
+template <class T> static inline T atomicAdd(T *p, T v) { const T o = *p; *p = o + v; return o; }  // fibers run one at a time
+
+namespace hiphost {
+constexpr int WAVE = 64, MAX_THREADS = 1024;
+struct Fiber { ucontext_t ctx; char *stack = nullptr; bool done = false; };
+inline std::vector<Fiber> fibers;
+inline ucontext_t main_ctx;
+inline int cur = 0, live = 0, bar_count = 0, bar_gen = 0;
+inline int wbar_count[MAX_THREADS / WAVE], wbar_gen[MAX_THREADS / WAVE];
+inline uint64_t slot[MAX_THREADS];
+inline std::function<void()> kernel;
+inline char dyn_lds[160 * 1024] __attribute__((aligned(16)));
+inline size_t dyn_lds_bytes = 0;  // size of the current launch (bounds are not enforced; launch() rejects > 160 KiB)
+
+static inline int linear_tid() { return (int)((threadIdx.z * blockDim.y + threadIdx.y) * blockDim.x + threadIdx.x); }
+static inline int nthreads() { return (int)(blockDim.x * blockDim.y * blockDim.z); }
+static void yield() { swapcontext(&fibers[cur].ctx, &main_ctx); }
+static void entry() { kernel(); fibers[cur].done = true; --live; }
+static void block_barrier() {
+  const int gen = bar_gen;
+  if (++bar_count >= live) { bar_count = 0; ++bar_gen; return; }
+  while (bar_gen == gen) yield();
+}
+static void wave_barrier(int w, int lanes) {
+  const int gen = wbar_gen[w];
+  if (++wbar_count[w] >= lanes) { wbar_count[w] = 0; ++wbar_gen[w]; return; }
+  while (wbar_gen[w] == gen) yield();
+}
+static inline int wave_lanes(int w) { const int n = nthreads() - w * WAVE; return n < WAVE ? n : WAVE; }
+// every lane of the wave (convergent code) calls this together: returns the value lane `src_lane` passed
+template <class T> static T exchange(T v, int src_lane) {
+  static_assert(sizeof(T) <= 8, "lane exchange payload");
+  const int tid = linear_tid(), w = tid / WAVE, lanes = wave_lanes(w);
+  uint64_t bits = 0;
+  memcpy(&bits, &v, sizeof(T));
+  slot[tid] = bits;
+  wave_barrier(w, lanes);
+  T r;
+  memcpy(&r, &slot[w * WAVE + (src_lane & (WAVE - 1))], sizeof(T));
+  wave_barrier(w, lanes);
+  return r;
+}
+static unsigned long long ballot(bool pred) {
+  const int tid = linear_tid(), w = tid / WAVE, lanes = wave_lanes(w);
+  slot[tid] = pred ? 1 : 0;
+  wave_barrier(w, lanes);
+  unsigned long long m = 0;
+  for (int l = 0; l < lanes; ++l) m |= (unsigned long long)(slot[w * WAVE + l] & 1) << l;
+  wave_barrier(w, lanes);
+  return m;
+}
+// v_mov_b32_dpp source lane for the controls this repo uses (all of them permutations inside a row of 16 lanes, row_mask = bank_mask = 0xf)
+static inline int dpp_src_lane(int lane, int ctrl) {
+  const int row = lane & ~15, i = lane & 15;
+  if (ctrl >= 0x000 && ctrl <= 0x0FF) return (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);  // quad_perm
+  if (ctrl >= 0x121 && ctrl <= 0x12F) return row | ((i - (ctrl - 0x120)) & 15);                // row_ror:n  (lane i reads lane i - n)
+  if (ctrl == 0x140) return row | (15 - i);                                                     // row_mirror
+  if (ctrl == 0x141) return row | (i & 8) | (7 - (i & 7));                                      // row_half_mirror
+  abort();  // a control this shim does not model
+}
+static inline int dpp(int v, int ctrl) { return exchange(v, dpp_src_lane(linear_tid() & (WAVE - 1), ctrl)); }
+
+static void run_block(const dim3 &block, const std::function<void()> &k) {
+  kernel = k;
+  blockDim = block;
+  const unsigned threads = block.x * block.y * block.z;
+  if (threads > (unsigned)MAX_THREADS) abort();
+  if (fibers.size() < threads) fibers.resize(threads);
+  live = (int)threads; bar_count = 0;
+  for (auto &c : wbar_count) c = 0;
+  for (unsigned t = 0; t < threads; ++t) {
+    Fiber &f = fibers[t];
+    if (!f.stack) f.stack = (char *)malloc(512 * 1024);
+    f.done = false;
+    getcontext(&f.ctx);
+    f.ctx.uc_stack.ss_sp = f.stack;
+    f.ctx.uc_stack.ss_size = 512 * 1024;
+    f.ctx.uc_link = &main_ctx;
+    makecontext(&f.ctx, (void (*)())entry, 0);
+  }
+  while (live > 0)
+    for (unsigned t = 0; t < threads; ++t)
+      if (!fibers[t].done) {
+        cur = (int)t;
+        threadIdx.x = t % block.x; threadIdx.y = (t / block.x) % block.y; threadIdx.z = t / (block.x * block.y);
+        swapcontext(&main_ctx, &fibers[t].ctx);
+      }
+}
+static void launch(const dim3 &grid, const dim3 &block, size_t lds, const std::function<void()> &k) {
+  if (lds > sizeof(dyn_lds)) abort();  // more dynamic LDS than a gfx950 workgroup can have
+  dyn_lds_bytes = lds;
+  gridDim = grid;
+  for (unsigned z = 0; z < grid.z; ++z)
+    for (unsigned y = 0; y < grid.y; ++y)
+      for (unsigned x = 0; x < grid.x; ++x) { blockIdx.x = x; blockIdx.y = y; blockIdx.z = z; run_block(block, k); }
+}
+}  // namespace hiphost
+
+static inline void __syncthreads() { hiphost::block_barrier(); }
+template <class T> static inline T __shfl_xor(T v, int mask, int = 64) { return hiphost::exchange(v, (hiphost::linear_tid() & 63) ^ mask); }
+template <class T> static inline T __shfl(T v, int src, int = 64) { return hiphost::exchange(v, src); }
+static inline unsigned long long __ballot(int pred) { return hiphost::ballot(pred != 0); }
+
+#define hipLaunchKernelGGL(K, G, B, LDS, STREAM, ...) hiphost::launch(dim3(G), dim3(B), (size_t)(LDS), [&] { K(__VA_ARGS__); })
+#define __builtin_amdgcn_update_dpp(OLD, SRC, CTRL, RMASK, BMASK, BOUND) hiphost::dpp((SRC), (CTRL))
+#define __builtin_amdgcn_readlane(V, L) hiphost::exchange((int)(V), (L))
+#define __builtin_amdgcn_sdot4(A, B, C, CLAMP) hiphost_sdot4((A), (B), (C))
+static inline int hiphost_sdot4(int a, int b, int c) {
+  for (int i = 0; i < 4; ++i) c += (int)(int8_t)((uint32_t)a >> (8 * i)) * (int)(int8_t)((uint32_t)b >> (8 * i));
+  return c;
+}

@@ -425,3 +425,103 @@ def moe_router_topk(logits: np.ndarray, top_k: int, score_mode: int = 1, weight_
             sc = (sc * np.asarray(expert_scale, dtype=np.float32)[ids[r]]).astype(np.float32)
         wts[r] = (w * sc).astype(np.float32)
     return ids, wts
+
+
+# ------------------------------------------------------------------------------------------------ MoE expert kernels (restatements)
+def _expert_rows(w: np.ndarray, e: int, n: int) -> np.ndarray:
+    return w[e * n:(e + 1) * n]
+
+
+def moe_act(x: np.ndarray, act_type: int) -> np.ndarray:
+    """MoE activation codes (indexed_moe.cu:1168-1177, gguf/cuda.rs:1427-1428): 0 = gelu_pytorch_tanh, anything else = silu; f32."""
+    x = np.asarray(x, dtype=np.float32)
+    f = np.float32
+    if act_type == 0:
+        x3 = (x * x * x).astype(np.float32)
+        inner = (f(0.7978845608028654) * (x + f(0.044715) * x3)).astype(np.float32)
+        return (f(0.5) * x * (f(1.0) + np.tanh(inner, dtype=np.float32))).astype(np.float32)
+    with np.errstate(over="ignore"):  # exp(-x) -> inf for very negative x: x / inf = -0, as on the device
+        return (x / (f(1.0) + np.exp(-x, dtype=np.float32))).astype(np.float32)
+
+
+def moe_gemv_fused_gate_up(t: int, gate_w: np.ndarray, up_w: np.ndarray, n: int, k: int, y: np.ndarray, indices: np.ndarray, topk: int,
+                           act_type: int, with_mag: bool = False):
+    """moe_gemv_fused_gate_up_impl (kernels/indexed_moe/indexed_moe.cu:1342-1407): task = token * topk + slot, e = indices[task],
+    out[task][row] = (up_w[e][row] . y[token]) * act(gate_w[e][row] . y[token]); y = Q8_1 rows per TOKEN.  gate_w / up_w: [E * n, row_bytes].
+    with_mag: also return (gate, gate_mag, up, up_mag) for error budgeting."""
+    tasks = len(indices)
+    out = np.empty((tasks, n), dtype=np.float32)
+    extra = []
+    for task in range(tasks):
+        e, tok = int(indices[task]), task // topk
+        g, gm = matmul_q8_1_mag(t, _expert_rows(gate_w, e, n), n, k, y[tok:tok + 1])
+        u, um = matmul_q8_1_mag(t, _expert_rows(up_w, e, n), n, k, y[tok:tok + 1])
+        out[task] = (u[0] * moe_act(g[0], act_type)).astype(np.float32)
+        extra.append((g[0], gm[0], u[0], um[0]))
+    return (out, extra) if with_mag else out
+
+
+def moe_gemv_down_aggregate(t: int, w: np.ndarray, n: int, k: int, y: np.ndarray, indices: np.ndarray, topk_weights: np.ndarray, topk: int,
+                            out: np.ndarray | None = None, with_mag: bool = False):
+    """moe_gemv_down_aggregate_impl (indexed_moe.cu:1420-1486): out[token][row] += (w[e][row] . y[task]) * topk_weights[task], slots added in
+    order (the device's atomics may retire in any order; for topk == 2 on a zero-filled output the sum is order-independent)."""
+    tasks = len(indices)
+    batch = tasks // topk
+    out = np.zeros((batch, n), dtype=np.float32) if out is None else out
+    mag = np.zeros((batch, n), dtype=np.float64)
+    tw = np.asarray(topk_weights, dtype=np.float32).reshape(-1)
+    for task in range(tasks):
+        e, tok = int(indices[task]), task // topk
+        d, m = matmul_q8_1_mag(t, _expert_rows(w, e, n), n, k, y[task:task + 1])
+        out[tok] = (out[tok] + (d[0] * tw[task]).astype(np.float32)).astype(np.float32)
+        mag[tok] += m[0].astype(np.float64) * abs(float(tw[task]))
+    return (out, mag) if with_mag else out
+
+
+def moe_dispatch(topk_ids: np.ndarray, num_experts: int, topk: int):
+    """launch_moe_dispatch (kernels/moe_grouped/moe_grouped.cu:630-676,1106-1132): counting sort of the flattened top-k ids by expert.
+    Returns (expert_bounds [E + 1], sorted_token_ids, sorted_source_ids, expert_counts, expert_cursors (final = bounds[1:])).
+    Order inside an expert's segment: ascending flat index (the reference's atomic cursors leave it unspecified; this is the order its
+    kernels produce when the threads run in index order)."""
+    ids = np.asarray(topk_ids, dtype=np.int32).reshape(-1)
+    counts = np.bincount(ids, minlength=num_experts).astype(np.int32)
+    bounds = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    order = np.argsort(ids, kind="stable").astype(np.int32)
+    return bounds, order, (order // topk).astype(np.int32), counts, bounds[1:].copy()
+
+
+def moe_weighted_reduce_flat(inputs: np.ndarray, topk_weights: np.ndarray, out_kind: str = "f32") -> np.ndarray:
+    """moe_weighted_reduce_flat_kernel (moe_grouped.cu:678-702): inputs [tokens, topk, hidden] (already widened to f32 exactly),
+    acc = sum over slots IN ORDER of in * w, f32 multiply then f32 add; result rounded to out_kind ('f32' | 'f16' | 'bf16')."""
+    x = np.asarray(inputs, dtype=np.float32)
+    w = np.asarray(topk_weights, dtype=np.float32)
+    acc = np.zeros((x.shape[0], x.shape[2]), dtype=np.float32)
+    for s in range(x.shape[1]):
+        acc = (acc + (x[:, s, :] * w[:, s:s + 1]).astype(np.float32)).astype(np.float32)
+    if out_kind == "f16":
+        return acc.astype(np.float16).astype(np.float32)
+    if out_kind == "bf16":
+        return round_bf16(acc)
+    return acc
+
+
+def moe_grouped_gemm(t: int, w: np.ndarray, n: int, k: int, y: np.ndarray, expert_bounds: np.ndarray, sorted_token_ids: np.ndarray,
+                     topk_weights, topk: int, input_dim1: int, out: np.ndarray):
+    """moe_tiled_gemm_impl (moe_grouped.cu:716-902): for sorted position ti of expert e, flat = sorted_token_ids[ti]:
+    y row = ti (input_dim1 == 0) | flat // topk (== 1) | flat (else); acc = w[e] . y_row;
+    topk_weights given: out[flat // topk] += acc * topk_weights[flat] (in ti order), else out[ti] = acc.  Returns (out, mag)."""
+    mag = np.zeros(out.shape, dtype=np.float64)
+    tw = None if topk_weights is None else np.asarray(topk_weights, dtype=np.float32).reshape(-1)
+    for e in range(len(expert_bounds) - 1):
+        for ti in range(int(expert_bounds[e]), int(expert_bounds[e + 1])):
+            flat = int(sorted_token_ids[ti])
+            row = ti if input_dim1 == 0 else (flat // topk if input_dim1 == 1 else flat)
+            d, m = matmul_q8_1_mag(t, _expert_rows(w, e, n), n, k, y[row:row + 1])
+            if tw is not None:
+                tok = flat // topk
+                out[tok] = (out[tok] + (d[0] * tw[flat]).astype(np.float32)).astype(np.float32)
+                mag[tok] += m[0].astype(np.float64) * abs(float(tw[flat]))
+            else:
+                out[ti] = d[0]
+                mag[ti] = m[0]
+    return out, mag
