@@ -13,6 +13,7 @@
  */
 #ifndef MISTRALRS_QUANT_H
 #define MISTRALRS_QUANT_H
+#include <stdbool.h>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -26,6 +27,12 @@ extern "C" {
 void launch_mmvq_gguf_quantize_q8_1_bf16(const void *x, void *vy, int kx, int kx_padded, int num_rows, void *stream);
 void launch_mmvq_gguf_quantize_q8_1_f16(const void *x, void *vy, int kx, int kx_padded, int num_rows, void *stream);
 void launch_mmvq_gguf_quantize_q8_1_f32(const void *x, void *vy, int kx, int kx_padded, int num_rows, void *stream);
+
+/* the MoE paths' copies of the same quantizer (kernels/indexed_moe/indexed_moe.cu:673-808,1016-1023 ; Rust: src/gguf/ffi.rs:16-60 ;
+ * callers gguf/cuda.rs:514-588,1340-1640).  launch_quantize_q8_1: f32 input, grid of `num_blocks_x` blocks of 256 columns per row */
+void launch_quantize_q8_1(const float *x, void *vy, int kx, int kx_padded, int num_blocks_x, int num_rows, void *stream);
+void launch_quantize_q8_1_bf16(const void *x, void *vy, int kx, int kx_padded, int num_rows, void *stream);
+void launch_quantize_q8_1_f16(const void *x, void *vy, int kx, int kx_padded, int num_rows, void *stream);
 
 /* ---- decode GEMV, batch 1..8:  dst[j*stride_col_dst + row] = W[row,:] . y_j
  *      <t> in q4_0 q4_1 q5_0 q5_1 q8_0 q2_k q3_k q4_k q5_k q6_k ; <d> in f32 f16 bf16
@@ -105,6 +112,13 @@ int launch_moe_weighted_reduce_flat_f16_input(const void *inputs, const float *t
                                               int topk, void *stream);
 int launch_moe_weighted_reduce_flat_bf16_input(const void *inputs, const float *topk_weights, void *outputs, int num_tokens, int hidden,
                                                int topk, void *stream);
+
+/* ---- dense (unquantized) decode GEMV:  Y[b][row] = T( sum_k A[row][k] X[b][k] + (has_bias ? bias[row] : 0) ), A [M, K], X [B, K], Y [B, M],
+ *      f32 accumulation, batch_size 1..8 (anything else runs batch 1, as the reference's dispatch).
+ *      replaces kernels/gemv/gemv.cu:50-282 ; Rust: src/gemv/ffi.rs:12-56 ; callers src/gemv/mod.rs:250-470 */
+void launch_gemv_bf16(const void *A, const void *X, const void *bias, void *Y, int M, int K, int batch_size, bool has_bias, void *stream);
+void launch_gemv_f16(const void *A, const void *X, const void *bias, void *Y, int M, int K, int batch_size, bool has_bias, void *stream);
+void launch_gemv_f32(const void *A, const void *X, const void *bias, void *Y, int M, int K, int batch_size, bool has_bias, void *stream);
 
 /* ---- RoPE, in place, arithmetic in the tensor dtype.  `rot_dim` = number of rotated PAIRS (= cos/sin row
  *      length); is_neox: pairs (i, i+rot_dim) else interleaved (2i, 2i+1); dtype 0 f16, 1 bf16, 2 f32.

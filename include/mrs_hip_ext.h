@@ -175,6 +175,67 @@ double mrs_llama_decode_bytes(void *model, int b, int context_len);
  * Returns 0, -1 if n_elements % 32 != 0 or the dtype is unknown. */
 int mrs_isq_quantize_q8_0(const void *src, int src_dtype, void *dst, long long n_elements, void *stream);
 
+/* ---------------------------------------------------------------- paged KV cache manager (host/kv_cache_manager.cpp; host code only)
+ * Block pool with prefix caching + per-request block tracking: the C++ counterpart of mistralrs-core/src/paged_attention/
+ * block_pool.rs:267-557 (BlockPool), kv_cache_manager.rs:43-437 (KVCacheManager) and block_hash.rs:121-306 (chain hashes over full
+ * blocks).  Same operations, argument meaning and outcomes; block ids are int64_t, -1 stands for the reference's `None`, -2 = the
+ * caller's output capacity is too small / an id is out of range (nothing is changed in that case).  Not thread safe (the reference
+ * calls it from the one engine thread per rank).  The tables it produces feed reshape_and_cache / paged_attention / mrs_llama_*. */
+uint64_t mrs_kv_siphash(const void *data, size_t n, uint64_t k0, uint64_t k1, int c_rounds, int d_rounds);
+/* hash_block_tokens: SipHash-1-3(key 0) over parent|0, len, tokens, then the optional extra keys AdapterGeneration (32 bytes) and CacheSalt */
+uint64_t mrs_kv_hash_block_tokens(int has_parent, uint64_t parent, const uint32_t *tokens, size_t n, const uint8_t *adapter_generation32,
+                                  const char *cache_salt);
+/* compute_new_block_hashes (n_existing = 0: compute_block_hashes): chain hashes of the full blocks after `existing`; -> count written */
+size_t mrs_kv_compute_block_hashes(const uint32_t *tokens, size_t n_tokens, size_t block_size, const uint64_t *existing, size_t n_existing,
+                                   const uint8_t *adapter_generation32, const char *cache_salt, uint64_t *out, size_t cap);
+void *mrs_kv_manager_create(size_t num_gpu_blocks, size_t block_size, int enable_caching, const uint32_t *group_ids, size_t n_groups);
+void mrs_kv_manager_destroy(void *mgr);
+size_t mrs_kv_null_block_id(void *mgr);
+size_t mrs_kv_block_size(void *mgr);
+double mrs_kv_usage(void *mgr);
+size_t mrs_kv_num_free_blocks(void *mgr);
+size_t mrs_kv_num_usable_blocks(void *mgr);
+size_t mrs_kv_num_gpu_blocks(void *mgr);
+int mrs_kv_caching_enabled(void *mgr);
+/* longest cached prefix (at most num_tokens - 1 tokens): -> number of block ids written, *num_computed_tokens = that * block_size */
+int64_t mrs_kv_get_computed_blocks(void *mgr, const uint64_t *hashes, size_t n_hashes, size_t num_tokens, int64_t *block_ids, size_t cap,
+                                   size_t *num_computed_tokens);
+/* -> number of NEW block ids written (0 if the request already has enough), -1 = not enough free blocks */
+int64_t mrs_kv_allocate_slots(void *mgr, uint64_t request_id, size_t num_tokens, const int64_t *computed_blocks, size_t n_computed,
+                              int64_t *new_block_ids, size_t cap);
+void mrs_kv_free(void *mgr, uint64_t request_id);
+void mrs_kv_trim_request_to_num_tokens(void *mgr, uint64_t request_id, size_t num_tokens);
+int mrs_kv_cache_blocks(void *mgr, uint64_t request_id, const uint64_t *hashes, size_t n_hashes, size_t num_computed_tokens);
+int64_t mrs_kv_get_block_ids(void *mgr, uint64_t request_id, int64_t *out, size_t cap);
+size_t mrs_kv_num_blocks_for_request(void *mgr, uint64_t request_id);
+int mrs_kv_has_request(void *mgr, uint64_t request_id);
+size_t mrs_kv_num_cached_blocks_for_request(void *mgr, uint64_t request_id);
+int mrs_kv_reset_prefix_cache(void *mgr);
+/* slots[i] = block * block_size + offset of token start_token + i (i64, what reshape_and_cache takes); -1 (_PAD_SLOT_ID) past the allocation */
+int mrs_kv_get_slot_mapping(void *mgr, uint64_t request_id, size_t start_token, size_t num_tokens, int64_t *slots);
+int mrs_kv_get_block_table(void *mgr, uint64_t request_id, size_t max_blocks, int32_t *table); /* zero padded */
+/* the pool on its own (BlockPool's public surface); mrs_kv_manager_pool(mgr) borrows the manager's pool */
+void *mrs_kv_pool_create(size_t num_gpu_blocks, int enable_caching, size_t hash_block_size);
+void mrs_kv_pool_destroy(void *pool);
+void *mrs_kv_manager_pool(void *mgr);
+size_t mrs_kv_pool_null_block_id(void *pool);
+size_t mrs_kv_pool_num_free_blocks(void *pool);
+size_t mrs_kv_pool_num_gpu_blocks(void *pool);
+double mrs_kv_pool_usage(void *pool);
+size_t mrs_kv_pool_num_cached_blocks(void *pool);
+size_t mrs_kv_pool_hash_block_size(void *pool);
+int mrs_kv_pool_caching_enabled(void *pool);
+int64_t mrs_kv_pool_block_ref_cnt(void *pool, int64_t block_id);
+int64_t mrs_kv_pool_num_block_hashes(void *pool, int64_t block_id);
+int64_t mrs_kv_pool_get_new_blocks(void *pool, size_t n, int64_t *out, size_t cap);
+int mrs_kv_pool_free_blocks(void *pool, const int64_t *ordered_block_ids, size_t n);
+int mrs_kv_pool_touch(void *pool, const int64_t *block_ids, size_t n);
+int mrs_kv_pool_cache_full_blocks(void *pool, const int64_t *block_ids, size_t n_ids, const uint64_t *hashes, size_t n_hashes,
+                                  size_t num_cached_blocks, size_t num_full_blocks, uint32_t group_id);
+int64_t mrs_kv_pool_get_cached_block(void *pool, uint64_t hash, const uint32_t *group_ids, size_t n_groups, int64_t *out);
+int mrs_kv_pool_reset_prefix_cache(void *pool);
+void mrs_kv_pool_set_ref_cnt_for_test(void *pool, int64_t block_id, uint32_t value);
+
 /* ---------------------------------------------------------------- RCCL over xGMI (ext_comm.hip), one process per GPU
  * replaces Comm::from_device / all_reduce(Sum) of mistralrs-quant/src/distributed/mod.rs:244-303,511-809 */
 int mrs_comm_unique_id(void *out128);                            /* rank 0: ncclGetUniqueId -> 128 bytes */

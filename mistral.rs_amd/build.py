@@ -52,10 +52,10 @@ def libraries():
     libs["libmistralrspagedattention.so"] = pa
     # optional translation units are picked up as soon as the file exists
     optional = {
-        "libmistralrsquant.so": ["quant_ops.hip", "mmq.hip", "moe.hip", "hqq.hip"],
+        "libmistralrsquant.so": ["quant_ops.hip", "mmq.hip", "moe.hip", "gemv.hip", "hqq.hip"],
         "libmistralrscuda.so": ["core_ops.hip"],
         "libmrs_hip_ext.so": ["ext_decode.hip", "ext_gemm.hip", "ext_attn_prefill.hip", "ext_comm.hip", "ext_isq.hip",
-                              "host/runtime.cpp"],
+                              "host/runtime.cpp", "host/kv_cache_manager.cpp"],
     }
     for lib, srcs in optional.items():
         for s in srcs:

@@ -30,9 +30,9 @@ __global__ void __launch_bounds__(256) quantize_q8_1_kernel(const T *__restrict_
   }
 }
 
-template <class T> static void launch_quantize(const void *x, void *vy, int kx, int kx_padded, int num_rows, void *stream) {
-  if (num_rows <= 0 || kx_padded <= 0) return;
-  dim3 grid((kx_padded + 255) / 256, num_rows, 1);
+template <class T> static void launch_quantize(const void *x, void *vy, int kx, int kx_padded, int num_rows, void *stream, int num_blocks_x = -1) {
+  if (num_rows <= 0 || kx_padded <= 0 || num_blocks_x == 0) return;
+  dim3 grid(num_blocks_x > 0 ? num_blocks_x : (kx_padded + 255) / 256, num_rows, 1);
   hipLaunchKernelGGL((quantize_q8_1_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T *)x, (uint8_t *)vy, kx, kx_padded);
 }
 
@@ -46,4 +46,17 @@ extern "C" void launch_mmvq_gguf_quantize_q8_1_f16(const void *x, void *vy, int 
 }
 extern "C" void launch_mmvq_gguf_quantize_q8_1_f32(const void *x, void *vy, int kx, int kx_padded, int num_rows, void *stream) {
   mrs::launch_quantize<float>(x, vy, kx, kx_padded, num_rows, stream);
+}
+
+// The MoE paths' own copies of the same quantizer (kernels/indexed_moe/indexed_moe.cu:673-808,1016-1023; Rust: src/gguf/ffi.rs:16-60;
+// callers gguf/cuda.rs:514-588,1340-1640): identical arithmetic (same 32-lane butterfly), f32 variant with a caller-supplied grid width
+// (`num_blocks_x` blocks of 256 columns; the callers pass ceil(kx_padded / 256)).
+extern "C" void launch_quantize_q8_1(const float *x, void *vy, int kx, int kx_padded, int num_blocks_x, int num_rows, void *stream) {
+  mrs::launch_quantize<float>(x, vy, kx, kx_padded, num_rows, stream, num_blocks_x > 0 ? num_blocks_x : 0);
+}
+extern "C" void launch_quantize_q8_1_bf16(const void *x, void *vy, int kx, int kx_padded, int num_rows, void *stream) {
+  mrs::launch_quantize<mrs::bf16_t>(x, vy, kx, kx_padded, num_rows, stream);
+}
+extern "C" void launch_quantize_q8_1_f16(const void *x, void *vy, int kx, int kx_padded, int num_rows, void *stream) {
+  mrs::launch_quantize<mrs::f16_t>(x, vy, kx, kx_padded, num_rows, stream);
 }

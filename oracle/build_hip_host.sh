@@ -1,8 +1,10 @@
 #!/bin/sh
 # oracle/build_hip_host.sh -- TEST INFRASTRUCTURE ONLY.
-# Compiles the PRODUCT kernel sources of libmistralrsquant.so (mistral.rs_amd/csrc: the MMVQ core with every launcher of the 10 GGUF types,
-# the Q8_1 quantizer, moe.hip) for the HOST on top of oracle/hip_host/hip/hip_runtime.h (wave64 fibers), so the launchers can be executed
-# and compared with the oracle without a GPU (tests/test_hip_host_emulation.py).  Output: oracle/_hiphost/libhiphost_quant.so (git-ignored).
+# Compiles the PRODUCT kernel sources (mistral.rs_amd/csrc: the MMVQ core with every launcher of the 10 GGUF types, the Q8_1 quantizer,
+# moe.hip, gemv.hip, quant_ops / core_ops / hqq / ext_isq, the fused decode kernels of ext_decode.hip, kv_cache_ops and the paged-attention
+# instantiations) for the HOST on top of oracle/hip_host/hip/hip_runtime.h (wave64 fibers), so the C-ABI launchers can be executed and
+# compared with the oracle without a GPU (tests/test_hip_host_emulation.py).  Output: oracle/_hiphost/libhiphost.so (git-ignored).
+# Not built: ext_gemm.hip / ext_attn_prefill.hip (MFMA builtins are not modelled), ext_comm.hip (RCCL), host/runtime.cpp (HIP runtime API).
 # The sources are copied into oracle/_hiphost/src with ONE textual change: `extern __shared__ ... name[];` (dynamic LDS) becomes a pointer to
 # the shim's LDS buffer.  Same flags that pin the arithmetic in the product build: -ffp-contract=off, no fast-math.
 set -e
@@ -10,19 +12,29 @@ HERE="$(cd "$(dirname "$0")" && pwd)"
 CSRC="$HERE/../mistral.rs_amd/csrc"
 OUT="$HERE/_hiphost"
 CXX="${HIPHOST_CXX:-/opt/rocm/lib/llvm/bin/clang++}"
+rm -rf "$OUT/obj"
 mkdir -p "$OUT/src" "$OUT/obj"
-for f in common.cuh gguf_blocks.cuh mmvq_core.cuh mmvq_kernels.cuh mmvq_inst.hip mmvq_quantize.hip moe.hip; do
-  sed -E 's/extern __shared__( __attribute__\(\(aligned\(16\)\)\))? ([A-Za-z_0-9]+) ([A-Za-z_0-9]+)\[\];/\2 *\3 = (\2 *)hiphost::dyn_lds;/' "$CSRC/$f" > "$OUT/src/$f"
+for f in "$CSRC"/*.cuh "$CSRC"/*.hip; do
+  sed -E 's/extern __shared__( __attribute__\(\(aligned\(16\)\)\))? ([A-Za-z_0-9]+) ([A-Za-z_0-9]+)\[\];/\2 *\3 = (\2 *)hiphost::dyn_lds;/' "$f" > "$OUT/src/$(basename "$f")"
 done
 FLAGS="-x c++ -std=c++17 -O1 -fPIC -march=native -fno-fast-math -ffp-contract=off -w -I$HERE/hip_host -I$OUT/src -I$HERE/../include"
 pids=""
+cc() { obj="$1"; src="$2"; shift 2; $CXX $FLAGS "$@" -c "$OUT/src/$src" -o "$OUT/obj/$obj.o" & pids="$pids $!"; }
 for spec in q4_0:2:q4_0 q4_1:3:q4_1 q5_0:6:q5_0 q5_1:7:q5_1 q8_0:8:q8_0 q2_k:10:q2k q3_k:11:q3k q4_k:12:q4k q5_k:13:q5k q6_k:14:q6k; do
   tag=${spec%%:*}; rest=${spec#*:}; tid=${rest%%:*}; moe=${rest#*:}
-  $CXX $FLAGS -DMRS_TAG=$tag -DMRS_TYPE=$tid -DMRS_MOE_TAG=$moe -c "$OUT/src/mmvq_inst.hip" -o "$OUT/obj/mmvq_$tag.o" &
-  pids="$pids $!"
+  cc mmvq_$tag mmvq_inst.hip -DMRS_TAG=$tag -DMRS_TYPE=$tid -DMRS_MOE_TAG=$moe
 done
-$CXX $FLAGS -c "$OUT/src/mmvq_quantize.hip" -o "$OUT/obj/mmvq_quantize.o" & pids="$pids $!"
-$CXX $FLAGS -c "$OUT/src/moe.hip" -o "$OUT/obj/moe.o" & pids="$pids $!"
+for f in mmvq_quantize moe gemv quant_ops core_ops hqq ext_isq ext_decode kv_cache_ops; do cc $f $f.hip; done
+# paged attention: the instantiations of mistral.rs_amd/build.py
+cc pa_f16 paged_attention.hip -DMRS_PA_TAG=f16 -DMRS_PA_T=mrs::f16_t -DMRS_PA_CT=mrs::f16_t -DMRS_PA_EXPORT_ABI
+cc pa_bf16 paged_attention.hip -DMRS_PA_TAG=bf16 -DMRS_PA_T=mrs::bf16_t -DMRS_PA_CT=mrs::bf16_t -DMRS_PA_EXPORT_ABI
+cc pa_f32 paged_attention.hip -DMRS_PA_TAG=f32 -DMRS_PA_T=float -DMRS_PA_CT=float -DMRS_PA_EXPORT_ABI
+cc pa_f32_bf16 paged_attention.hip -DMRS_PA_TAG=f32_bf16 -DMRS_PA_T=float -DMRS_PA_CT=mrs::bf16_t -DMRS_PA_DECODE_Q8_1
+cc pa_f16_fp8 paged_attention.hip -DMRS_PA_TAG=f16 -DMRS_PA_T=mrs::f16_t -DMRS_PA_CT=mrs::fp8_t -DMRS_PA_FP8
+cc pa_bf16_fp8 paged_attention.hip -DMRS_PA_TAG=bf16 -DMRS_PA_T=mrs::bf16_t -DMRS_PA_CT=mrs::fp8_t -DMRS_PA_FP8
+cc pa_f32_fp8 paged_attention.hip -DMRS_PA_TAG=f32 -DMRS_PA_T=float -DMRS_PA_CT=mrs::fp8_t -DMRS_PA_FP8
 for p in $pids; do wait $p; done
-$CXX -shared -o "$OUT/libhiphost_quant.so" "$OUT"/obj/*.o
-echo "oracle/_hiphost: built libhiphost_quant.so (product kernels of libmistralrsquant.so on wave64 host fibers)"
+# -Bsymbolic: inline / template symbols shared with the product libraries (loaded RTLD_GLOBAL in the same process) must bind to THIS library
+$CXX -shared -Wl,-Bsymbolic -o "$OUT/libhiphost.so" "$OUT"/obj/*.o
+rm -f "$OUT/libhiphost_quant.so"
+echo "oracle/_hiphost: built libhiphost.so (product kernels on wave64 host fibers)"

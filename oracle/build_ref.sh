@@ -17,6 +17,7 @@
 #   _ref/libref_imoe.so   <- indexed_moe_forward_<t>_q8_1 kernels (kernels/indexed_moe/indexed_moe.cu) on host fibers
 #   _ref/libref_moe_decode.so  <- moe_gemv_fused_gate_up_<t> / moe_gemv_down_aggregate_<t> (indexed_moe.cu:1157-1615) on host fibers
 #   _ref/libref_moe_grouped.so <- moe_dispatch_* / moe_weighted_reduce_flat / moe_grouped_gemm_<t> kernels (kernels/moe_grouped/moe_grouped.cu) on host fibers
+#   _ref/libref_gemv.so   <- gemv_kernel_batched (kernels/gemv/gemv.cu:50-160) in f32 / f16 / bf16, batch 1..8, on host fibers
 #   _ref/libref_half.so   <- f16 / bf16 instantiations of the HQQ dequantize kernels and of the rotary kernels (arithmetic in the tensor dtype)
 #   _ref/libref_hqq.so    <- the __global__ kernel templates of kernels/hqq/hqq.cu (dequantize_*) and hqq_bitpack.cu (pack_*),
 #                            run one thread at a time by ref_shim/hqq_driver.inc
@@ -100,6 +101,13 @@ IMOE="$REF/mistralrs-quant/kernels/indexed_moe/indexed_moe.cu"
     | grep -v '#include "cuda_' | grep -v '^#define WARP_SIZE' \
     | sed 's/extern __shared__ float weights\[\];/float *weights = (float *)shim_fiber::dyn_smem;/; s/extern __shared__ char smem\[\];/char *smem = shim_fiber::dyn_smem;/; s/extern __shared__ char smem_q8\[\];/char *smem_q8 = shim_fiber::dyn_smem;/'
   cat "$HERE/ref_shim/moe_grouped_driver.inc" ) | $CXX $FLAGS $FIB -o "$OUT/libref_moe_grouped.so" -
+# dense decode GEMV (kernels/gemv/gemv.cu): reduction helper, converters and the batched kernel template, up to the block-size selection
+( cat "$HERE/ref_shim/cuda_shim.h" "$HERE/ref_shim/fiber_shim.h"
+  echo '#define __CUDA_ARCH__ 800'
+  echo '#define __ldg(p) (*(p))'
+  echo 'struct __nv_bfloat162 { __nv_bfloat16 x, y; };'
+  awk '/^\/\/ Warp-level reduction sum/{p=1} /^\/\/ Block Size Selection/{exit} p{if (held != "") print held; held=$0}' "$REF/mistralrs-quant/kernels/gemv/gemv.cu"
+  cat "$HERE/ref_shim/gemv_driver.inc" ) | $CXX $FLAGS $FIB -o "$OUT/libref_gemv.so" -
 # 16-bit instantiations whose arithmetic runs in the tensor dtype (every operation rounds to half / bf16): HQQ dequantize and RoPE, with
 # the shim's half / bf16 operator set (-DSHIM_HALF_OPS)
 ( cat "$HERE/ref_shim/cuda_shim.h" "$HERE/ref_shim/fiber_shim.h"
@@ -124,4 +132,4 @@ SORT="$REF/mistralrs-core/src/cuda/sort.cu"
   sed -n '148,318p' "$SORT" | awk '/^template <typename T>$/{t=$0; next} /^void launch_/{skip=1} !skip{if (t != "") print t; print} {t=""} skip && /^}$/{skip=0}'
   sed -n '351,428p' "$SORT"
   cat "$HERE/ref_shim/rms_driver.inc" ) | $CXX $FLAGS $FIB -o "$OUT/libref_rms.so" -
-echo "oracle/_ref: built libref_mmvq.so libref_affine.so libref_hqq.so libref_cache.so libref_pa.so libref_q8_1.so libref_rms.so libref_mmvq_kernel.so libref_glu.so libref_router.so libref_imoe.so libref_moe_decode.so libref_moe_grouped.so libref_half.so from $REF"
+echo "oracle/_ref: built libref_mmvq.so libref_affine.so libref_hqq.so libref_cache.so libref_pa.so libref_q8_1.so libref_rms.so libref_mmvq_kernel.so libref_glu.so libref_router.so libref_imoe.so libref_moe_decode.so libref_moe_grouped.so libref_gemv.so libref_half.so from $REF"

@@ -63,6 +63,10 @@ static inline int __mul24(int a, int b) { return (int)((uint32_t)((a << 8) >> 8)
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 template <class T> static inline T atomicAdd(T *p, T v) { const T o = *p; *p = o + v; return o; }  // fibers run one at a time
+template <class T> static inline T atomicMax(T *p, T v) { const T o = *p; if (v > o) *p = v; return o; }
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }  // v_rsq_f32 is a ~1 ulp approximation: tolerance-level agreement only
+#define __expf(x) expf(x) /* glibc declares a non-static __expf */
+static inline const char *hipGetErrorString(hipError_t) { return "hip error (host emulation)"; }
 
 namespace hiphost {
 constexpr int WAVE = 64, MAX_THREADS = 1024;

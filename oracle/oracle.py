@@ -525,3 +525,16 @@ def moe_grouped_gemm(t: int, w: np.ndarray, n: int, k: int, y: np.ndarray, exper
                 out[ti] = d[0]
                 mag[ti] = m[0]
     return out, mag
+
+
+def gemv_dense(a: np.ndarray, x: np.ndarray, bias=None):
+    """Dense decode GEMV of gemv_kernel_batched (kernels/gemv/gemv.cu:50-160): y[b][row] = sum_k a[row][k] * x[b][k] + bias[row] with the
+    inputs already widened to f32.  Returns (y in f64 before the final rounding to T, mag = sum |terms|): the kernel accumulates with f32
+    fma in a thread-strided order and butterflies, so comparisons use the f32-accumulation bound on `mag` plus one rounding of T."""
+    a64, x64 = np.asarray(a, dtype=np.float64), np.asarray(x, dtype=np.float64)
+    y = x64 @ a64.T
+    mag = np.abs(x64) @ np.abs(a64).T
+    if bias is not None:
+        y = y + np.asarray(bias, dtype=np.float64)[None, :]
+        mag = mag + np.abs(np.asarray(bias, dtype=np.float64))[None, :]
+    return y, mag

@@ -32,7 +32,7 @@ class HostBackend:
     @classmethod
     def lib(cls):
         if cls._lib is None:
-            so = os.path.join(ROOT, "oracle", "_hiphost", "libhiphost_quant.so")
+            so = os.path.join(ROOT, "oracle", "_hiphost", "libhiphost.so")
             srcs = [os.path.join(ROOT, "mistral.rs_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "mistral.rs_amd", "csrc")) if f.endswith((".cuh", ".hip"))]
             srcs += [os.path.join(ROOT, "oracle", "hip_host", "hip", "hip_runtime.h"), os.path.join(ROOT, "oracle", "build_hip_host.sh")]
             if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):

@@ -1,5 +1,5 @@
 """CPU: the PRODUCT kernel sources of libmistralrsquant.so compiled for the host on wave64 fibers (oracle/hip_host/hip/hip_runtime.h,
-oracle/build_hip_host.sh -> oracle/_hiphost/libhiphost_quant.so; test infrastructure) and called through the same C-ABI symbols.
+oracle/build_hip_host.sh -> oracle/_hiphost/libhiphost.so; test infrastructure) and called through the same C-ABI symbols.
   * calibration: launchers that are parity-green on the MI355X (Q8_1 quantizer, plain / fused-GLU / fused-QKV MMVQ, indexed MoE forward)
     give the same answers here -- bit-exact where the GPU test is bit-exact -- so the emulation models DPP / readlane / ballot / barriers
     the way the device executes them;
@@ -121,3 +121,8 @@ def test_emulated_weighted_reduce(oracle, be, sym, in_dt, out_dt):
 @pytest.mark.parametrize("mode", ["gate_up", "down_weighted", "down_plain"])
 def test_emulated_grouped_gemm(oracle, be, tname, mode):
     M.check_grouped_gemm(oracle, be, tname, mode, k=512, tokens=40)
+
+
+@pytest.mark.parametrize("sym,dt", [("launch_quantize_q8_1", "f32"), ("launch_quantize_q8_1_f16", "f16"), ("launch_quantize_q8_1_bf16", "bf16")])
+def test_emulated_moe_quantize_q8_1(oracle, be, sym, dt):
+    M.check_quantize_q8_1(oracle, be, sym, dt)

@@ -132,3 +132,17 @@ def test_grouped_gemm_oracle_matches_reference_kernel(oracle, t, mode):
     got, mag = oracle.moe_grouped_gemm(t, w, n, k, y, bounds, sorted_tok, tw, topk, input_dim1, np.zeros(shape, dtype=np.float32))
     tol = _f32_tol(k, mag, got) + topk * 2.0 ** -23 * mag
     assert (np.abs(out.astype(np.float64) - got) <= tol).all()
+
+
+def test_imoe_quantize_q8_1_is_the_mmvq_quantizer(oracle):
+    """quantize_q8_1 of kernels/indexed_moe/indexed_moe.cu:673-708 (behind launch_quantize_q8_1*) on host fibers == the oracle's Q8_1 quantizer
+    (already pinned to mmvq_gguf_quantize_q8_1_f32), byte for byte -- so the HIP quantizer serves both symbol families."""
+    lib = _ref("libref_imoe.so")
+    rng = np.random.default_rng(8)
+    rows, k = 3, 700
+    x = (rng.standard_normal((rows, k)) * rng.uniform(0.01, 30.0, (rows, 1))).astype(np.float32)
+    x[1, 64:96] = 0.0   # an all-zero block
+    kp = oracle.pad512(k)
+    y = np.zeros((rows, kp // 32 * 36), dtype=np.uint8)
+    assert lib.ref_imoe_quantize_q8_1(_vp(x), _vp(y), k, kp, rows) == 0
+    np.testing.assert_array_equal(y, oracle.quantize_q8_1(x))

@@ -142,6 +142,21 @@ def check_grouped_gemm(oracle, be, tname, mode, k=1024, tokens=90):
     assert (np.abs(got - want) <= tol).all()
 
 
+def check_quantize_q8_1(oracle, be, sym, dt):
+    """launch_quantize_q8_1{,_f16,_bf16} (indexed_moe.cu:673-808,1016-1023): bit-exact Q8_1 blocks, rows zero-padded to kx_padded."""
+    rng = np.random.default_rng(len(sym))
+    rows, k = 3, 700
+    x = round_through((rng.standard_normal((rows, k)) * rng.uniform(0.01, 30.0, (rows, 1))).astype(np.float32), dt)
+    x[1, 64:96] = 0.0
+    kp = oracle.pad512(k)
+    xb, y = be.buf(x, None if dt == "f32" else dt), be.buf(np.full((rows, kp // 32 * 36), 0xAA, dtype=np.uint8))
+    if dt == "f32":
+        be.sym(sym, [P] * 2 + [I] * 4 + [P])(xb.ptr, y.ptr, k, kp, (kp + 255) // 256, rows, be.stream)
+    else:
+        be.sym(sym, [P] * 2 + [I] * 3 + [P])(xb.ptr, y.ptr, k, kp, rows, be.stream)
+    np.testing.assert_array_equal(y.numpy(), oracle.quantize_q8_1(x))
+
+
 # ------------------------------------------------------------------------------------------------------------------- on the MI355X
 @pytest.fixture
 def be(dev):
@@ -179,3 +194,9 @@ def test_moe_weighted_reduce_flat_abi(oracle, be, sym, in_dt, out_dt):
 @pytest.mark.parametrize("mode", ["gate_up", "down_weighted", "down_plain"])
 def test_moe_grouped_gemm_abi(oracle, be, tname, mode):
     check_grouped_gemm(oracle, be, tname, mode)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sym,dt", [("launch_quantize_q8_1", "f32"), ("launch_quantize_q8_1_f16", "f16"), ("launch_quantize_q8_1_bf16", "bf16")])
+def test_moe_quantize_q8_1_abi(oracle, be, sym, dt):
+    check_quantize_q8_1(oracle, be, sym, dt)
