@@ -174,6 +174,10 @@ double mrs_llama_decode_bytes(void *model, int b, int context_len);
  * QTensor::quantize(.., Q8_0) that `generate_isq!` runs on the CPU (mistralrs-quant/src/utils/isq.rs:323-361), on the device.
  * Returns 0, -1 if n_elements % 32 != 0 or the dtype is unknown. */
 int mrs_isq_quantize_q8_0(const void *src, int src_dtype, void *dst, long long n_elements, void *stream);
+/* the other GGML targets of `generate_isq!`, quantized on the device with GGML's reference arithmetic (bit-identical blocks):
+ * ggml_type 2 Q4_0, 3 Q4_1, 6 Q5_0, 7 Q5_1, 8 Q8_0, 12 Q4_K, 13 Q5_K, 14 Q6_K (one lane per sub-block, 8 / 16 lanes per K-quant superblock).
+ * Returns 0, -1 for an unknown dtype / type or n_elements not a multiple of the block size (32 / 256). */
+int mrs_isq_quantize(const void *src, int src_dtype, void *dst, long long n_elements, int ggml_type, void *stream);
 
 /* ---------------------------------------------------------------- paged KV cache manager (host/kv_cache_manager.cpp; host code only)
  * Block pool with prefix caching + per-request block tracking: the C++ counterpart of mistralrs-core/src/paged_attention/

@@ -25,6 +25,330 @@ __global__ void __launch_bounds__(256) isq_q8_0_kernel(const T *__restrict__ w, 
   if (l == 0) *(uint16_t *)b = float_to_half_bits(d);
 }
 
+
+// ------------------------------------------------------------------------------------------------ K-quants (Q4_K / Q5_K / Q6_K) + legacy 4/5-bit
+// The reference runs candle's QTensor::quantize (= GGML's quantize_row_q{4,5,6}_K_ref / q{4,5}_{0,1}_ref) on the host cores for every ISQ'd
+// tensor (utils/isq.rs:323-361): minutes for an 8B model.  Here the same search runs where the dense weight lives.  The arithmetic is GGML's,
+// operation for operation in f32 with contraction off (make_qkx2_quants: 21 / 16 candidate scales per 32-weight sub-block with the weights
+// av_x + |x|; make_qx_quants: 19 candidates per 16-weight sub-block), so the blocks are bit-identical to the oracle's restatement
+// (oracle/ggml_oracle.c: quantize_q4_5_K, quantize_q6_K, quantize_legacy; tests/test_isq.py).  Mapping: ONE LANE PER SUB-BLOCK -- the search over
+// a sub-block is sequential by definition -- 8 (Q4_K / Q5_K) or 16 (Q6_K) neighbouring lanes form a superblock; the cross-sub-block steps
+// (max scale / max min, 6-bit scale packing, nibble / high-bit interleaving) are wave exchanges inside that lane group.
+
+__device__ __forceinline__ int isq_nearest_int(float f) { return (int)rintf(f); }  // round half to even, as lrintf / ggml's magic-number trick
+
+// make_qkx2_quants(32, nmax, x, w, .., rmin, rdelta, nstep, use_mad = false): only the returned scale and *the_min matter to the callers
+// (the quants are recomputed after the 6-bit scale rounding), so L / Laux are not materialised: a candidate's quants are re-derived where needed.
+__device__ __forceinline__ float isq_make_qkx2(const float (&x)[32], const float (&w)[32], int nmax, float rmin, float rdelta, int nstep, float &the_min) {
+  float mn = x[0], mx = x[0], sum_w = w[0], sum_x = sum_w * x[0];
+#pragma unroll
+  for (int i = 1; i < 32; ++i) {
+    if (x[i] < mn) mn = x[i];
+    if (x[i] > mx) mx = x[i];
+    sum_w += w[i];
+    sum_x += w[i] * x[i];
+  }
+  if (mn > 0) mn = 0;
+  if (mx == mn) { the_min = -mn; return 0.f; }
+  float iscale = nmax / (mx - mn), scale = 1 / iscale, best_mad = 0;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const int l = max(0, min(nmax, isq_nearest_int(iscale * (x[i] - mn))));
+    float diff = scale * l + mn - x[i];
+    diff = diff * diff;
+    best_mad += w[i] * diff;
+  }
+  for (int is = 0; is <= nstep; ++is) {
+    iscale = (rmin + rdelta * is + nmax) / (mx - mn);
+    float sum_l = 0, sum_l2 = 0, sum_xl = 0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int l = max(0, min(nmax, isq_nearest_int(iscale * (x[i] - mn))));
+      sum_l += w[i] * l;
+      sum_l2 += w[i] * l * l;
+      sum_xl += w[i] * l * x[i];
+    }
+    const float D = sum_w * sum_l2 - sum_l * sum_l;
+    if (D > 0) {
+      float this_scale = (sum_w * sum_xl - sum_x * sum_l) / D;
+      float this_min = (sum_l2 * sum_x - sum_l * sum_xl) / D;
+      if (this_min > 0) { this_min = 0; this_scale = sum_xl / sum_l2; }
+      float mad = 0;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        const int l = max(0, min(nmax, isq_nearest_int(iscale * (x[i] - mn))));  // Laux[i]
+        float diff = this_scale * l + this_min - x[i];
+        diff = diff * diff;
+        mad += w[i] * diff;
+      }
+      if (mad < best_mad) { best_mad = mad; scale = this_scale; mn = this_min; }  // the following candidates use the updated min, as GGML does
+    }
+  }
+  the_min = -mn;
+  return scale;
+}
+
+// Q4_K (FIVE = false, 144 B) / Q5_K (FIVE = true, 176 B): 8 lanes per superblock, lane j = sub-block j
+template <class T, bool FIVE>
+__global__ void __launch_bounds__(256) isq_q45_k_kernel(const T *__restrict__ src, uint8_t *__restrict__ out, size_t nsuper) {
+  constexpr int NMAX = FIVE ? 31 : 15, TS = FIVE ? 176 : 144;
+  const int lane = threadIdx.x & 63, j = lane & 7, base = lane & ~7;
+  const size_t sb_raw = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 3;
+  const bool live = sb_raw < nsuper;           // whole 8-lane groups are live or not; dead groups compute on the last superblock
+  const size_t sb = live ? sb_raw : nsuper - 1;
+  float x[32], w[32];
+  const T *p = src + sb * 256 + (size_t)j * 32;
+  float sum_x2 = 0;
+#pragma unroll
+  for (int l = 0; l < 32; ++l) { x[l] = to_f<T>(p[l]); sum_x2 += x[l] * x[l]; }
+  const float av_x = sqrtf(sum_x2 / 32);
+#pragma unroll
+  for (int l = 0; l < 32; ++l) w[l] = av_x + fabsf(x[l]);
+  float mn_j;
+  const float sc_j = FIVE ? isq_make_qkx2(x, w, 31, -0.5f, 0.1f, 15, mn_j) : isq_make_qkx2(x, w, 15, -1.f, 0.1f, 20, mn_j);
+  float max_scale = sc_j > 0 ? sc_j : 0.f, max_min = mn_j > 0 ? mn_j : 0.f;  // `if (scales[j] > max_scale)` from +0: never -0, never NaN
+#pragma unroll
+  for (int m = 1; m < 8; m <<= 1) { max_scale = fmaxf(max_scale, __shfl_xor(max_scale, m, 64)); max_min = fmaxf(max_min, __shfl_xor(max_min, m, 64)); }
+  const float inv_scale = max_scale > 0 ? 63.f / max_scale : 0.f, inv_min = max_min > 0 ? 63.f / max_min : 0.f;
+  const int ls = min(63, isq_nearest_int(inv_scale * sc_j)), lm = min(63, isq_nearest_int(inv_min * mn_j));
+  // header (lane 0 of the group): half d, half dmin, 12 bytes of 6-bit scales / mins (get_scale_min_k4 layout)
+  const int mine = (ls & 0xff) | ((lm & 0xff) << 8);
+  int all[8];
+#pragma unroll
+  for (int g = 0; g < 8; ++g) all[g] = __shfl(mine, base + g, 64);
+  const uint16_t dbits = float_to_half_bits(max_scale / 63.f), mbits = float_to_half_bits(max_min / 63.f);
+  uint8_t *y = out + sb * TS;
+  uint8_t sc12[12];  // every lane builds the packed header (cheap) so that its own (sc, m) come out of the bytes exactly as a reader decodes them
+#pragma unroll
+  for (int g = 0; g < 12; ++g) sc12[g] = 0;
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    const int gls = all[g] & 0xff, glm = (all[g] >> 8) & 0xff;
+    if (g < 4) { sc12[g] = (uint8_t)gls; sc12[g + 4] = (uint8_t)glm; }
+    else {
+      sc12[g + 4] = (uint8_t)((gls & 0xF) | ((glm & 0xF) << 4));
+      sc12[g - 4] |= (uint8_t)((gls >> 4) << 6);
+      sc12[g] |= (uint8_t)((glm >> 4) << 6);
+    }
+  }
+  if (live && j == 0) {
+    uint32_t hw[4];
+    hw[0] = (uint32_t)dbits | ((uint32_t)mbits << 16);
+#pragma unroll
+    for (int g = 0; g < 3; ++g) hw[g + 1] = (uint32_t)sc12[4 * g] | ((uint32_t)sc12[4 * g + 1] << 8) | ((uint32_t)sc12[4 * g + 2] << 16) | ((uint32_t)sc12[4 * g + 3] << 24);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) ((uint32_t *)y)[g] = hw[g];  // blocks are 16-byte aligned (144 / 176 B strides)
+  }
+  // final quants against the ROUNDED scales (get_scale_min_k4 of the packed bytes): l = clamp(rne((x + dmin * m) / (d * sc)), 0, nmax); d * sc == 0 -> 0
+  int ksc = 0, km = 0;
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    if (g == j) {
+      if (g < 4) { ksc = sc12[g] & 63; km = sc12[g + 4] & 63; }
+      else { ksc = (sc12[g + 4] & 0xF) | ((sc12[g - 4] >> 6) << 4); km = (sc12[g + 4] >> 4) | ((sc12[g] >> 6) << 4); }
+    }
+  }
+  const float dd = half_bits_to_float(dbits), dmin = half_bits_to_float(mbits);
+  const float d = dd * (float)ksc, dm = dmin * (float)km;
+  uint32_t lo[8], hi[8];  // 32 quants: low nibbles one per byte, bit 4 one per byte
+#pragma unroll
+  for (int g = 0; g < 8; ++g) { lo[g] = 0; hi[g] = 0; }
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    int l = 0;
+    if (d != 0.f) l = max(0, min(NMAX, isq_nearest_int((x[i] + dm) / d)));
+    lo[i >> 2] |= (uint32_t)(l & 0xF) << (8 * (i & 3));
+    hi[i >> 2] |= (uint32_t)(l >> 4) << (8 * (i & 3));
+  }
+  // qs: byte l of pair c = L[2c][l] | L[2c+1][l] << 4: lanes 2c / 2c+1 swap their nibble words; the even lane writes bytes 0..15, the odd 16..31
+  uint8_t *qs = y + (FIVE ? 48 : 16) + (j >> 1) * 32;
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    const uint32_t other = (uint32_t)__shfl_xor((int)lo[g], 1, 64);
+    const uint32_t word = (j & 1) ? (other | (lo[g] << 4)) : (lo[g] | (other << 4));
+    const bool mine_to_write = (j & 1) ? g >= 4 : g < 4;
+    if (live && mine_to_write) ((uint32_t *)qs)[g] = word;
+  }
+  if constexpr (FIVE) {  // qh[l] bit j = bit 4 of L[j][l]: OR over the 8 lanes, lane g writes word g
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      uint32_t v = hi[g] << j;
+#pragma unroll
+      for (int m = 1; m < 8; m <<= 1) v |= (uint32_t)__shfl_xor((int)v, m, 64);
+      if (live && j == g) ((uint32_t *)(y + 16))[g] = v;
+    }
+  }
+}
+
+// Q6_K (210 B, 2-byte aligned): 16 lanes per superblock, lane ib = 16-weight sub-block ib
+template <class T>
+__global__ void __launch_bounds__(256) isq_q6_k_kernel(const T *__restrict__ src, uint8_t *__restrict__ out, size_t nsuper) {
+  const int lane = threadIdx.x & 63, ib = lane & 15, base = lane & ~15;
+  const size_t sb_raw = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+  const bool live = sb_raw < nsuper;
+  const size_t sb = live ? sb_raw : nsuper - 1;
+  float x[16];
+  const T *p = src + sb * 256 + (size_t)ib * 16;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) x[i] = to_f<T>(p[i]);
+  // make_qx_quants(16, 32, x, L): rmse_type 1, no weights
+  int L[16];
+  float scale;
+  {
+    float mx = 0, amax = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const float ax = fabsf(x[i]); if (ax > amax) { amax = ax; mx = x[i]; } }
+    if (amax < 1e-15f) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) L[i] = 0;
+      scale = 0.f;
+    } else {
+      float iscale = -32 / mx, sumlx = 0, suml2 = 0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int l = max(-32, min(31, isq_nearest_int(iscale * x[i])));
+        L[i] = l + 32;
+        const float w = x[i] * x[i];
+        sumlx += w * x[i] * l;
+        suml2 += w * l * l;
+      }
+      scale = suml2 ? sumlx / suml2 : 0.0f;
+      float best = scale * sumlx;
+      for (int is = -9; is <= 9; ++is) {
+        if (is == 0) continue;
+        iscale = -(32 + 0.1f * is) / mx;
+        sumlx = suml2 = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int l = max(-32, min(31, isq_nearest_int(iscale * x[i])));
+          const float w = x[i] * x[i];
+          sumlx += w * x[i] * l;
+          suml2 += w * l * l;
+        }
+        if (suml2 > 0 && sumlx * sumlx > best * suml2) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) L[i] = 32 + max(-32, min(31, isq_nearest_int(iscale * x[i])));
+          scale = sumlx / suml2;
+          best = scale * sumlx;
+        }
+      }
+    }
+  }
+  // the scale of largest magnitude, first sub-block on ties (`if (fabsf(s) > max_abs)`)
+  float best_abs = fabsf(scale), best_s = scale;
+  int best_i = ib;
+#pragma unroll
+  for (int m = 1; m < 16; m <<= 1) {
+    const float oa = __shfl_xor(best_abs, m, 64), os = __shfl_xor(best_s, m, 64);
+    const int oi = __shfl_xor(best_i, m, 64);
+    if (oa > best_abs || (oa == best_abs && oi < best_i)) { best_abs = oa; best_s = os; best_i = oi; }
+  }
+  uint8_t *y = out + sb * 210;
+  const bool zero_block = best_abs < 1e-15f;  // all-zero superblock: 210 zero bytes.  No early return: the lane exchanges below stay wave-uniform
+  const float iscale = -128.f / best_s;
+  const uint16_t dbits = zero_block ? (uint16_t)0 : float_to_half_bits(1 / iscale);
+  const int sc = zero_block ? 0 : min(127, isq_nearest_int(iscale * scale));
+  const float d = half_bits_to_float(dbits) * (float)(int8_t)sc;
+  if (zero_block) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) L[i] = 0;
+  } else if (d != 0.f) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) L[i] = max(-32, min(31, isq_nearest_int(x[i] / d))) + 32;
+  }
+  if (live) {
+    ((int8_t *)(y + 192))[ib] = (int8_t)sc;
+    if (ib == 0) *(uint16_t *)(y + 208) = dbits;
+  }
+  // interleave: half h = ib / 8, quarter qt = (ib % 8) / 2, parity par = ib % 2 (which 16 of the quarter's 32 columns)
+  //   ql[h*64 + (qt&1)*32 + par*16 + i] = lo4(L of quarter qt&1) | lo4(L of quarter (qt&1)+2) << 4   <- lanes ib and ib + 4
+  //   qh[h*32 + par*16 + i]            = sum over qt of (L >> 4) << 2 qt                               <- lanes ib, ib+2, ib+4, ib+6
+  uint32_t lo[4], hi[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) { lo[g] = 0; hi[g] = 0; }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    lo[i >> 2] |= (uint32_t)(L[i] & 0xF) << (8 * (i & 3));
+    hi[i >> 2] |= (uint32_t)(L[i] >> 4) << (8 * (i & 3));
+  }
+  const int h = ib >> 3, qt = (ib & 7) >> 1, par = ib & 1;
+  uint16_t *ql = (uint16_t *)(y + h * 64 + (qt & 1) * 32 + par * 16), *qh = (uint16_t *)(y + 128 + h * 32 + par * 16);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const uint32_t up = (uint32_t)__shfl((int)lo[g], base + ((ib + 4) & 15), 64);   // quarter qt + 2 (meaningful for qt < 2)
+    const uint32_t h1 = (uint32_t)__shfl((int)hi[g], base + ((ib + 2) & 15), 64), h2 = (uint32_t)__shfl((int)hi[g], base + ((ib + 4) & 15), 64),
+                   h3 = (uint32_t)__shfl((int)hi[g], base + ((ib + 6) & 15), 64);
+    if (live && qt < 2) { const uint32_t v = lo[g] | (up << 4); ql[2 * g] = (uint16_t)v; ql[2 * g + 1] = (uint16_t)(v >> 16); }
+    if (live && qt == 0) { const uint32_t v = hi[g] | (h1 << 2) | (h2 << 4) | (h3 << 6); qh[2 * g] = (uint16_t)v; qh[2 * g + 1] = (uint16_t)(v >> 16); }
+  }
+}
+
+// Q4_0 / Q5_0 / Q4_1 / Q5_1: one thread per 32-weight block (quantize_row_q{4,5}_{0,1}_ref)
+template <class T, int TYPE>
+__global__ void __launch_bounds__(256) isq_legacy_kernel(const T *__restrict__ src, uint8_t *__restrict__ out, size_t nblocks) {
+  const size_t blk = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (blk >= nblocks) return;
+  constexpr bool SYM = TYPE == 2 || TYPE == 6, FIVEB = TYPE == 6 || TYPE == 7;
+  constexpr int TS = TYPE == 2 ? 18 : TYPE == 3 ? 20 : TYPE == 6 ? 22 : 24;
+  float x[32];
+  const T *p = src + blk * 32;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) x[i] = to_f<T>(p[i]);
+  uint8_t *y = out + blk * TS;
+  uint8_t qs[16];
+  uint32_t qh = 0;
+  if constexpr (SYM) {
+    constexpr int HR = FIVEB ? 16 : 8, TOP = 2 * HR - 1;
+    float amax = 0, mx = 0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) if (fabsf(x[i]) > amax) { amax = fabsf(x[i]); mx = x[i]; }
+    const float d = mx / -(float)HR, id = d ? 1.f / d : 0.f;
+    *(uint16_t *)y = float_to_half_bits(d);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int x0 = min(TOP, (int)(int8_t)(x[i] * id + (HR + 0.5f))), x1 = min(TOP, (int)(int8_t)(x[i + 16] * id + (HR + 0.5f)));
+      qs[i] = (uint8_t)((x0 & 0xF) | ((x1 & 0xF) << 4));
+      qh |= (uint32_t)((x0 & 0x10) >> 4) << i;
+      qh |= (uint32_t)((x1 & 0x10) >> 4) << (i + 16);
+    }
+  } else {
+    constexpr int TOP = FIVEB ? 31 : 15;
+    float mn = x[0], mx = x[0];
+#pragma unroll
+    for (int i = 1; i < 32; ++i) { if (x[i] < mn) mn = x[i]; if (x[i] > mx) mx = x[i]; }  // comparisons, not v_min / v_max: the first of +0 / -0 stays, as in GGML
+    const float d = (mx - mn) / TOP, id = d ? 1.f / d : 0.f;
+    *(uint16_t *)y = float_to_half_bits(d);
+    *(uint16_t *)(y + 2) = float_to_half_bits(mn);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int x0 = min(TOP, (int)(uint8_t)((x[i] - mn) * id + 0.5f)), x1 = min(TOP, (int)(uint8_t)((x[i + 16] - mn) * id + 0.5f));
+      qs[i] = (uint8_t)((x0 & 0xF) | ((x1 & 0xF) << 4));
+      qh |= (uint32_t)((x0 & 0x10) >> 4) << i;
+      qh |= (uint32_t)((x1 & 0x10) >> 4) << (i + 16);
+    }
+  }
+  constexpr int HDR = SYM ? 2 : 4;
+  if constexpr (FIVEB) { *(uint16_t *)(y + HDR) = (uint16_t)qh; *(uint16_t *)(y + HDR + 2) = (uint16_t)(qh >> 16); }
+  uint16_t *q16 = (uint16_t *)(y + HDR + (FIVEB ? 4 : 0));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) q16[i] = (uint16_t)(qs[2 * i] | (qs[2 * i + 1] << 8));
+}
+
+template <class T> static int isq_dispatch(const T *src, uint8_t *dst, size_t n, int type, hipStream_t s) {
+  const dim3 block(256);
+  switch (type) {
+  case 8: { const size_t nb = n / 32; hipLaunchKernelGGL(isq_q8_0_kernel<T>, dim3((unsigned)((nb + 7) / 8)), block, 0, s, src, dst, nb); return 0; }
+  case 2: { const size_t nb = n / 32; hipLaunchKernelGGL((isq_legacy_kernel<T, 2>), dim3((unsigned)((nb + 255) / 256)), block, 0, s, src, dst, nb); return 0; }
+  case 3: { const size_t nb = n / 32; hipLaunchKernelGGL((isq_legacy_kernel<T, 3>), dim3((unsigned)((nb + 255) / 256)), block, 0, s, src, dst, nb); return 0; }
+  case 6: { const size_t nb = n / 32; hipLaunchKernelGGL((isq_legacy_kernel<T, 6>), dim3((unsigned)((nb + 255) / 256)), block, 0, s, src, dst, nb); return 0; }
+  case 7: { const size_t nb = n / 32; hipLaunchKernelGGL((isq_legacy_kernel<T, 7>), dim3((unsigned)((nb + 255) / 256)), block, 0, s, src, dst, nb); return 0; }
+  case 12: { const size_t nb = n / 256; hipLaunchKernelGGL((isq_q45_k_kernel<T, false>), dim3((unsigned)((nb + 31) / 32)), block, 0, s, src, dst, nb); return 0; }
+  case 13: { const size_t nb = n / 256; hipLaunchKernelGGL((isq_q45_k_kernel<T, true>), dim3((unsigned)((nb + 31) / 32)), block, 0, s, src, dst, nb); return 0; }
+  case 14: { const size_t nb = n / 256; hipLaunchKernelGGL((isq_q6_k_kernel<T>), dim3((unsigned)((nb + 15) / 16)), block, 0, s, src, dst, nb); return 0; }
+  default: return -1;
+  }
+}
+
 }  // namespace mrs
 
 // src: dense [N*K] elements, dtype 0 = f32, 1 = f16, 30 = bf16 (ggml ids); dst: N*K/32*34 bytes.  Returns 0 / -1.
@@ -38,6 +362,22 @@ extern "C" int mrs_isq_quantize_q8_0(const void *src, int src_dtype, void *dst, 
   case 0: hipLaunchKernelGGL(mrs::isq_q8_0_kernel<float>, grid, block, 0, s, (const float *)src, (uint8_t *)dst, nb); return 0;
   case 1: hipLaunchKernelGGL(mrs::isq_q8_0_kernel<mrs::f16_t>, grid, block, 0, s, (const mrs::f16_t *)src, (uint8_t *)dst, nb); return 0;
   case 30: hipLaunchKernelGGL(mrs::isq_q8_0_kernel<mrs::bf16_t>, grid, block, 0, s, (const mrs::bf16_t *)src, (uint8_t *)dst, nb); return 0;
+  default: return -1;
+  }
+}
+
+// ISQ to any GGML target of `generate_isq!` that the GGUF kernels read: ggml_type 2 Q4_0, 3 Q4_1, 6 Q5_0, 7 Q5_1, 8 Q8_0, 12 Q4_K, 13 Q5_K,
+// 14 Q6_K.  src dtype as above.  Returns 0, -1 for an unknown dtype / type or when n_elements is not a multiple of the block size (the
+// reference then falls back to another dtype: utils/isq.rs:249-287).  Blocks are bit-identical to GGML's reference quantizers.
+extern "C" int mrs_isq_quantize(const void *src, int src_dtype, void *dst, long long n_elements, int ggml_type, void *stream) {
+  if (n_elements <= 0) return 0;
+  const int blk = (ggml_type >= 12 && ggml_type <= 14) ? 256 : 32;
+  if (n_elements % blk) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  switch (src_dtype) {
+  case 0: return mrs::isq_dispatch<float>((const float *)src, (uint8_t *)dst, (size_t)n_elements, ggml_type, s);
+  case 1: return mrs::isq_dispatch<mrs::f16_t>((const mrs::f16_t *)src, (uint8_t *)dst, (size_t)n_elements, ggml_type, s);
+  case 30: return mrs::isq_dispatch<mrs::bf16_t>((const mrs::bf16_t *)src, (uint8_t *)dst, (size_t)n_elements, ggml_type, s);
   default: return -1;
   }
 }

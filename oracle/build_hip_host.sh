@@ -4,7 +4,7 @@
 # moe.hip, gemv.hip, quant_ops / core_ops / hqq / ext_isq, the fused decode kernels of ext_decode.hip, kv_cache_ops and the paged-attention
 # instantiations) for the HOST on top of oracle/hip_host/hip/hip_runtime.h (wave64 fibers), so the C-ABI launchers can be executed and
 # compared with the oracle without a GPU (tests/test_hip_host_emulation.py).  Output: oracle/_hiphost/libhiphost.so (git-ignored).
-# Not built: ext_gemm.hip / ext_attn_prefill.hip (MFMA builtins are not modelled), ext_comm.hip (RCCL), host/runtime.cpp (HIP runtime API).
+# Not built: ext_gemm.hip / ext_attn_prefill.hip (MFMA builtins are not modelled), ext_comm.hip (RCCL).
 # The sources are copied into oracle/_hiphost/src with ONE textual change: `extern __shared__ ... name[];` (dynamic LDS) becomes a pointer to
 # the shim's LDS buffer.  Same flags that pin the arithmetic in the product build: -ffp-contract=off, no fast-math.
 set -e
@@ -25,6 +25,12 @@ for spec in q4_0:2:q4_0 q4_1:3:q4_1 q5_0:6:q5_0 q5_1:7:q5_1 q8_0:8:q8_0 q2_k:10:
   cc mmvq_$tag mmvq_inst.hip -DMRS_TAG=$tag -DMRS_TYPE=$tid -DMRS_MOE_TAG=$moe
 done
 for f in mmvq_quantize moe gemv quant_ops core_ops hqq ext_isq ext_decode kv_cache_ops; do cc $f $f.hip; done
+# the C++ runner (plain host code: it finds the launchers with dlsym(RTLD_DEFAULT), so it only works in a process that loaded THIS library
+# RTLD_GLOBAL and not the product libraries -- `pytest --host-emulation`); its MFMA prefill entry points stay unresolved
+mkdir -p "$OUT/src/host"
+cp "$CSRC/host/runtime.cpp" "$OUT/src/host/runtime.cpp"
+$CXX $FLAGS -I"$HERE/../include" -c "$OUT/src/host/runtime.cpp" -o "$OUT/obj/runtime.o" & pids="$pids $!"
+gcc -O1 -fPIC -w -c "$HERE/hip_host/mfma_stubs.c" -o "$OUT/obj/mfma_stubs.o"
 # paged attention: the instantiations of mistral.rs_amd/build.py
 cc pa_f16 paged_attention.hip -DMRS_PA_TAG=f16 -DMRS_PA_T=mrs::f16_t -DMRS_PA_CT=mrs::f16_t -DMRS_PA_EXPORT_ABI
 cc pa_bf16 paged_attention.hip -DMRS_PA_TAG=bf16 -DMRS_PA_T=mrs::bf16_t -DMRS_PA_CT=mrs::bf16_t -DMRS_PA_EXPORT_ABI

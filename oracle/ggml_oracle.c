@@ -466,7 +466,7 @@ static void quantize_legacy(int type, const float *x, uint8_t *y, int64_t k) {
     } else { /* Q4_1 / Q5_1 */
       const int top = type == ORC_Q4_1 ? 15 : 31;
       float mn = x[0], mx = x[0];
-      for (int j = 1; j < 32; ++j) { mn = fminf(mn, x[j]); mx = fmaxf(mx, x[j]); }
+      for (int j = 1; j < 32; ++j) { if (x[j] < mn) mn = x[j]; if (x[j] > mx) mx = x[j]; } /* comparisons as GGML's quantize_row_q4_1_ref: the first of +0 / -0 stays (fminf leaves that open) */
       float d = (mx - mn) / top, id = d ? 1.f / d : 0.f;
       st16(y, orc_fp32_to_fp16(d));
       st16(y + 2, orc_fp32_to_fp16(mn));

@@ -48,6 +48,9 @@ typedef int hipError_t;
 enum { hipSuccess = 0 };
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipMemset(void *p, int v, size_t n) { memset(p, v, n); return hipSuccess; }  // "device" memory is host memory
+static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void *d, const void *s_, size_t n, int, hipStream_t) { memcpy(d, s_, n); return hipSuccess; }
 static inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
 
 // ONE instance across the translation units of a library (C++17 inline variables): inline product functions such as mrs::lane_id() are
@@ -83,16 +86,23 @@ inline size_t dyn_lds_bytes = 0;  // size of the current launch (bounds are not 
 static inline int linear_tid() { return (int)((threadIdx.z * blockDim.y + threadIdx.y) * blockDim.x + threadIdx.x); }
 static inline int nthreads() { return (int)(blockDim.x * blockDim.y * blockDim.z); }
 static void yield() { swapcontext(&fibers[cur].ctx, &main_ctx); }
-static void entry() { kernel(); fibers[cur].done = true; --live; }
-static void block_barrier() {
+inline int wave_live[MAX_THREADS / WAVE];  // fibers of each wave that have not returned yet: a barrier / exchange waits for those only
+static void entry() { kernel(); fibers[cur].done = true; --live; --wave_live[cur / WAVE]; }
+static void block_barrier() {  // threads that already returned do not take part (as on the device)
   const int gen = bar_gen;
-  if (++bar_count >= live) { bar_count = 0; ++bar_gen; return; }
-  while (bar_gen == gen) yield();
+  ++bar_count;
+  while (bar_gen == gen) {
+    if (bar_count >= live) { bar_count = 0; ++bar_gen; break; }
+    yield();
+  }
 }
-static void wave_barrier(int w, int lanes) {
+static void wave_barrier(int w, int /*lanes*/) {
   const int gen = wbar_gen[w];
-  if (++wbar_count[w] >= lanes) { wbar_count[w] = 0; ++wbar_gen[w]; return; }
-  while (wbar_gen[w] == gen) yield();
+  ++wbar_count[w];
+  while (wbar_gen[w] == gen) {
+    if (wbar_count[w] >= wave_live[w]) { wbar_count[w] = 0; ++wbar_gen[w]; break; }
+    yield();
+  }
 }
 static inline int wave_lanes(int w) { const int n = nthreads() - w * WAVE; return n < WAVE ? n : WAVE; }
 // every lane of the wave (convergent code) calls this together: returns the value lane `src_lane` passed
@@ -136,6 +146,7 @@ static void run_block(const dim3 &block, const std::function<void()> &k) {
   if (fibers.size() < threads) fibers.resize(threads);
   live = (int)threads; bar_count = 0;
   for (auto &c : wbar_count) c = 0;
+  for (int w = 0; w < MAX_THREADS / WAVE; ++w) { const int n = (int)threads - w * WAVE; wave_live[w] = n < 0 ? 0 : (n < WAVE ? n : WAVE); }
   for (unsigned t = 0; t < threads; ++t) {
     Fiber &f = fibers[t];
     if (!f.stack) f.stack = (char *)malloc(512 * 1024);

@@ -28,6 +28,7 @@ class HostBackend:
     name = "host-emulation"
     stream = None
     _lib = None
+    global_symbols = False  # `pytest --host-emulation` sets this: the C++ runner resolves launchers with dlsym(RTLD_DEFAULT)
 
     @classmethod
     def lib(cls):
@@ -37,7 +38,7 @@ class HostBackend:
             srcs += [os.path.join(ROOT, "oracle", "hip_host", "hip", "hip_runtime.h"), os.path.join(ROOT, "oracle", "build_hip_host.sh")]
             if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
                 subprocess.check_call(["sh", os.path.join(ROOT, "oracle", "build_hip_host.sh")], stdout=subprocess.DEVNULL)
-            cls._lib = C.CDLL(so)
+            cls._lib = C.CDLL(so, mode=C.RTLD_GLOBAL if cls.global_symbols else C.RTLD_LOCAL)
         return cls._lib
 
     def sym(self, name, argtypes, restype=None):

@@ -29,6 +29,7 @@ def _enter_host_emulation():
     from tests.abi_backends import HostBackend
     import mistralrs_amd  # noqa: F401
     from mistralrs_amd import _lib
+    HostBackend.global_symbols = True
     lib = HostBackend.lib()
     for key in ("quant", "paged_attn", "core", "ext"):
         _lib._cache[key] = lib
