@@ -28,7 +28,8 @@ for f in mmvq_quantize moe gemv quant_ops core_ops hqq ext_isq ext_decode kv_cac
 # the C++ runner (plain host code: it finds the launchers with dlsym(RTLD_DEFAULT), so it only works in a process that loaded THIS library
 # RTLD_GLOBAL and not the product libraries -- `pytest --host-emulation`); its MFMA prefill entry points stay unresolved
 mkdir -p "$OUT/src/host"
-cp "$CSRC/host/runtime.cpp" "$OUT/src/host/runtime.cpp"
+cp "$CSRC/host/runtime.cpp" "$CSRC/host/kv_cache_manager.cpp" "$OUT/src/host/"
+$CXX $FLAGS -c "$OUT/src/host/kv_cache_manager.cpp" -o "$OUT/obj/kv_cache_manager.o" & pids="$pids $!"
 $CXX $FLAGS -I"$HERE/../include" -c "$OUT/src/host/runtime.cpp" -o "$OUT/obj/runtime.o" & pids="$pids $!"
 gcc -O1 -fPIC -w -c "$HERE/hip_host/mfma_stubs.c" -o "$OUT/obj/mfma_stubs.o"
 # paged attention: the instantiations of mistral.rs_amd/build.py

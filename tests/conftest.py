@@ -42,6 +42,7 @@ def _enter_host_emulation():
 
     _from_numpy = torch.from_numpy
     torch.from_numpy = lambda a: _from_numpy(a).clone()  # `.to(cpu)` does not copy: keep the tests' numpy inputs out of reach of in-place kernels
+    torch.Tensor.is_cuda = property(lambda self: True)  # the wrappers' "must live on the GPU" guards: here the emulated device memory IS host memory
     torch.cuda.current_stream = lambda *a, **k: _NullStream()
     torch.cuda.synchronize = lambda *a, **k: None
 
