@@ -176,9 +176,61 @@ static void launch(const dim3 &grid, const dim3 &block, size_t lds, const std::f
 }  // namespace hiphost
 
 static inline void __syncthreads() { hiphost::block_barrier(); }
+// A wave executes in lockstep on the device, so LDS written by some lanes is visible to the others one instruction later WITHOUT a barrier; fibers are
+// not in lockstep.  build_hip_host.sh inserts this at the two places of the product sources that rely on it (paged_attention.cuh, decode_attn_wave_kernel).
+namespace hiphost { static inline void wave_sync() { wave_barrier(linear_tid() / WAVE, 0); } }
 template <class T> static inline T __shfl_xor(T v, int mask, int = 64) { return hiphost::exchange(v, (hiphost::linear_tid() & 63) ^ mask); }
 template <class T> static inline T __shfl(T v, int src, int = 64) { return hiphost::exchange(v, src); }
 static inline unsigned long long __ballot(int pred) { return hiphost::ballot(pred != 0); }
+
+
+// ---------------------------------------------------------------------------------------------- matrix cores (gfx950 v_mfma_f32_32x32x16_bf16)
+// D = A (32 x 16) * B (16 x 32) + C, one wave: lane l holds A[l % 32][8 * (l / 32) + j], B[8 * (l / 32) + j][l % 32] (j = 0..7) and the 16
+// accumulators C[8 * (i / 4) + 4 * (l / 32) + i % 4][l % 32] (i = 0..15).  Products are exact in f32; the sum over k is taken in ascending k
+// with plain f32 adds (the hardware's internal order / fusing is unspecified: tolerance-level agreement).  The layout is CALIBRATED, not assumed:
+// the GPU-green prefill GEMM / prefill attention tests pass on this model (`pytest --host-emulation`).
+typedef short hiphost_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float hiphost_f32x16 __attribute__((ext_vector_type(16)));
+namespace hiphost {
+inline uint16_t mfma_a[MAX_THREADS][8], mfma_b[MAX_THREADS][8];
+static inline float bf16_bits_f(uint16_t v) { uint32_t u = (uint32_t)v << 16; float f; memcpy(&f, &u, 4); return f; }
+static hiphost_f32x16 mfma_32x32x16_bf16(hiphost_bf16x8 a, hiphost_bf16x8 b, hiphost_f32x16 c) {
+  const int tid = linear_tid(), w = tid / WAVE, lane = tid & (WAVE - 1), base = w * WAVE;
+  for (int j = 0; j < 8; ++j) { mfma_a[tid][j] = (uint16_t)a[j]; mfma_b[tid][j] = (uint16_t)b[j]; }
+  wave_barrier(w, 0);
+  const int col = lane & 31, hi = lane >> 5;
+  hiphost_f32x16 d = c;
+  for (int i = 0; i < 16; ++i) {
+    const int row = 8 * (i / 4) + 4 * hi + (i % 4);
+    float acc = 0.0f;
+    for (int k = 0; k < 16; ++k) acc += bf16_bits_f(mfma_a[base + row + 32 * (k / 8)][k % 8]) * bf16_bits_f(mfma_b[base + col + 32 * (k / 8)][k % 8]);
+    d[i] = c[i] + acc;
+  }
+  wave_barrier(w, 0);
+  return d;
+}
+}  // namespace hiphost
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, CBSZ, ABID, BLGP) hiphost::mfma_32x32x16_bf16((A), (B), (C))
+// buffer resource: base + byte range; raw_buffer_load returns zeros out of range (as the hardware's bounds check does)
+struct __amdgpu_buffer_rsrc_t { const char *base; unsigned bytes; };
+static inline __amdgpu_buffer_rsrc_t hiphost_make_rsrc(void *p, int bytes) { return __amdgpu_buffer_rsrc_t{(const char *)p, (unsigned)bytes}; }
+#define __builtin_amdgcn_make_buffer_rsrc(P, STRIDE, NUM, FLAGS) hiphost_make_rsrc((P), (NUM))
+typedef unsigned hiphost_v4u __attribute__((ext_vector_type(4)));
+static inline hiphost_v4u hiphost_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  hiphost_v4u v = {0, 0, 0, 0};
+  const unsigned long long o = (unsigned long long)voff + soff;
+  if (o + 16 <= r.bytes) memcpy(&v, r.base + o, 16);
+  return v;
+}
+#define __builtin_amdgcn_raw_buffer_load_b128(R, VOFF, SOFF, AUX) hiphost_raw_buffer_load_b128((R), (VOFF), (SOFF))
+// f32 -> bf16 (RNE) for `__builtin_convertvector(float2, __bf16 x 2)`: x86 lowers it to this runtime call
+extern "C" inline __bf16 __truncsfbf2(float f) {
+  uint32_t x; memcpy(&x, &f, 4);
+  uint16_t h;
+  if ((x & 0x7fffffffu) > 0x7f800000u) h = (uint16_t)((x >> 16) | 0x40);
+  else { x += 0x7fffu + ((x >> 16) & 1u); h = (uint16_t)(x >> 16); }
+  __bf16 r; memcpy(&r, &h, 2); return r;
+}
 
 #define hipLaunchKernelGGL(K, G, B, LDS, STREAM, ...) hiphost::launch(dim3(G), dim3(B), (size_t)(LDS), [&] { K(__VA_ARGS__); })
 #define __builtin_amdgcn_update_dpp(OLD, SRC, CTRL, RMASK, BMASK, BOUND) hiphost::dpp((SRC), (CTRL))

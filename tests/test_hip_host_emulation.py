@@ -4,8 +4,14 @@ oracle/build_hip_host.sh -> oracle/_hiphost/libhiphost.so; test infrastructure) 
     give the same answers here -- bit-exact where the GPU test is bit-exact -- so the emulation models DPP / readlane / ballot / barriers
     the way the device executes them;
   * the MoE expert launchers added after the round's GPU minutes were spent run the bodies of tests/test_zz_moe_expert_abi.py here.
+  * a curated slice of the EXISTING `-m gpu` test files (MFMA prefill GEMM and flash attention, decode attention, RoPE / RMSNorm / GLU, paged attention)
+    is re-run unchanged in a child process with `--host-emulation` (tests/conftest.py), which keeps the matrix-core lane model and the
+    lockstep-LDS syncs of the emulation honest in every CPU run.
 Nothing in the product path uses this library."""
 import ctypes as C
+import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -126,3 +132,22 @@ def test_emulated_grouped_gemm(oracle, be, tname, mode):
 @pytest.mark.parametrize("sym,dt", [("launch_quantize_q8_1", "f32"), ("launch_quantize_q8_1_f16", "f16"), ("launch_quantize_q8_1_bf16", "bf16")])
 def test_emulated_moe_quantize_q8_1(oracle, be, sym, dt):
     M.check_quantize_q8_1(oracle, be, sym, dt)
+
+
+GPU_SUITE_SLICES = [
+    ("tests/test_gemm.py", "130-384-512-Q4_K or 1-128-256-Q6_K or (large_m and 256-128-512-False-Q8_0) or slab_producers"),   # MFMA GEMM, both kernels
+    ("tests/test_paged_attn.py", "(prefill_attention and 31-0-8-8) or (prefill_attention and 64-45-16-2) or (decode_attention and 8-4-64) "
+                                 "or (llama_shape and v2 and bf16) or reshape_and_cache_f32_into_bf16"),
+    ("tests/test_glue_ops.py", ""),
+]
+
+
+@pytest.mark.parametrize("path,expr", GPU_SUITE_SLICES, ids=[p.split("/")[-1] for p, _ in GPU_SUITE_SLICES])
+def test_gpu_suite_slice_on_host_emulation(path, expr):
+    """The unmodified GPU tests, CPU tensors, emulated kernels.  A child process: --host-emulation repoints the package's loader and patches torch."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "pytest", path, "-m", "gpu", "--host-emulation", "-q", "-x", "-p", "no:cacheprovider"] + (["-k", expr] if expr else [])
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900)
+    tail = "\n".join(r.stdout.splitlines()[-15:])
+    assert r.returncode == 0, tail
+    assert " passed" in tail and "failed" not in tail, tail
