@@ -406,11 +406,51 @@ class Llama {
     b += align(t * ff * 4) * 3;       // gate, up, act
     b += align((pad_to((int)d, MATRIX_ROW_PADDING) / 32) * 36);  // Q8_1 scratch of the last-token lm_head GEMV
     if (T > prefill_big_min()) b += align(t * std::max(std::max(d, nq), ff) * 2) + align(mrs_gemm_q_bf16_workspace_bytes(T));  // bf16 activations + split-K partials
+    if (c.num_experts > 0) {  // MoE FFN of the prompt: routes = T * top_k rows in expert-sorted order
+      const size_t tk = (size_t)std::max(1, (int)c.num_experts_per_tok), r = t * tk, E = (size_t)c.num_experts;
+      b += align(r * ff * 4) * 3;                                                    // gate, up, act per route (replace the dense t * ff buffers)
+      b += align(r * 4) * 3 + align((E + 1) * 4) + align(E * 4) * 2;                  // ids, weights, sorted routes; bounds, counts, cursors
+      b += align(t * (pad_to((int)d, MATRIX_ROW_PADDING) / 32) * 36);                // Q8_1 rows of the normed hidden states
+      b += align(r * (pad_to((int)ff, MATRIX_ROW_PADDING) / 32) * 36);               // Q8_1 rows of the routes' activations
+      b += align(t * d * 4);                                                         // sum of the weighted expert outputs
+    }
     return b + 4096;
+  }
+  // MoE FFN of a prompt (SparseMoeBlock::forward on [T, hidden], models/mixtral.rs:280-304; the reference's prompt route is
+  // FastExpertsWeights::forward_* -> moe_dispatch_build + grouped GEMM, moe/experts/backends.rs:969-1100, gguf/cuda.rs:590-640,1340-1420):
+  // router top-k on the device, stable dispatch by expert, grouped gate / up GEMMs over the expert-sorted routes (every expert's weights are
+  // read once per 8 of ITS routes instead of once per token), SiLU * up, grouped down GEMM that scales by the routing weight and sums the
+  // top-k routes of a token with f32 atomics into a zeroed buffer (top-k = 2: order-independent), residual add.  No host sync.
+  struct MoePrefillBufs { int32_t *ids, *sorted, *bounds, *counts, *cursors; float *w, *g, *u, *act, *sum; void *y_in, *y_act; };
+  typedef void (*moe_grouped_fn)(const void *, const void *, const int32_t *, const int32_t *, const float *, float *, int, int, int, int, int, int, void *);
+  static moe_grouped_fn grouped_gemm_for(int dtype) {
+    const DTypeInfo *ti = type_info(dtype);
+    if (!ti || !mmvq_supports(dtype)) return nullptr;
+    std::string tag = ti->tag;  // MoE symbols spell the K-quants without the underscore (q4k ...)
+    const size_t us = tag.find("_k");
+    if (us != std::string::npos) tag.erase(us, 1);
+    return (moe_grouped_fn)lookup("launch_moe_grouped_gemm_" + tag);
+  }
+  int moe_ffn_prefill(const Block &bl, float *h, float *xn, int T, const MoePrefillBufs &m, hipStream_t s) const {
+    const int d = cfg.hidden_size, ff = cfg.intermediate_size, E = cfg.num_experts, tk = cfg.num_experts_per_tok, routes = T * tk;
+    const int kp_d = pad_to(d, MATRIX_ROW_PADDING), kp_ff = pad_to(ff, MATRIX_ROW_PADDING);
+    if (cfg.world_size > 1) return fail("tensor-parallel MoE is not supported yet");
+    const moe_grouped_fn gate_up = grouped_gemm_for(bl.gate_exps.dtype), down = grouped_gemm_for(bl.down_exps.dtype);
+    if (!gate_up || !down || bl.up_exps.dtype != bl.gate_exps.dtype) return fail("prefill: no grouped MoE GEMM for expert dtypes %d / %d / %d", bl.gate_exps.dtype, bl.up_exps.dtype, bl.down_exps.dtype);
+    mrs_rms_norm_f32(h, bl.post_attention_layernorm, xn, T, d, cfg.rms_eps, (int64_t)(intptr_t)s);
+    if (mrs_moe_router_topk(xn, bl.router, T, E, d, tk, 1, m.ids, m.w, nullptr, s)) return fail("moe router refused (experts %d, top-k %d)", E, tk);
+    launch_moe_dispatch(m.ids, m.bounds, m.sorted, nullptr, routes, E, tk, m.counts, m.cursors, s);
+    launch_mmvq_gguf_quantize_q8_1_f32(xn, m.y_in, d, kp_d, T, s);
+    gate_up(bl.gate_exps.data, m.y_in, m.bounds, m.sorted, nullptr, m.g, ff, d, kp_d, E, tk, 1, s);  // input_dim1 = 1: the token's row; out[sorted position]
+    gate_up(bl.up_exps.data, m.y_in, m.bounds, m.sorted, nullptr, m.u, ff, d, kp_d, E, tk, 1, s);
+    fused_glu_f32(m.g, m.u, m.act, (uint32_t)routes, (uint32_t)ff, (uint32_t)ff, (uint32_t)ff, 0, s);
+    launch_mmvq_gguf_quantize_q8_1_f32(m.act, m.y_act, ff, kp_ff, routes, s);
+    if (hipMemsetAsync(m.sum, 0, (size_t)T * d * 4, s) != hipSuccess) return fail("prefill: hipMemsetAsync failed");
+    down(bl.down_exps.data, m.y_act, m.bounds, m.sorted, m.w, m.sum, d, ff, kp_ff, E, tk, 0, s);     // input_dim1 = 0: rows already in sorted order
+    return mrs_vec_add_f32(h, m.sum, (size_t)T * d, s) ? fail("prefill: residual add failed") : 0;
   }
   int prefill(const mrs_llama_prefill_args &pa, int T, hipStream_t s) const {
     if (T <= 0) return fail("prefill: T must be positive");
-    if (cfg.num_experts > 0) return fail("prefill: MoE models run their prompt through the decode kernels (prefill_chunked)");
     const int start_pos = pa.start_pos;
     if (!wte || !lm_head || !ln_f) return fail("model is missing token_embd / output / output_norm");
     if (pa.workspace_bytes < prefill_workspace_bytes(cfg, T)) return fail("prefill workspace too small");
@@ -422,6 +462,16 @@ class Llama {
     float *q = (float *)take(t * nq * 4), *attn = (float *)take(t * nq * 4);
     float *k = (float *)take(t * nkv * 4), *v = (float *)take(t * nkv * 4);
     float *g = (float *)take(t * ff * 4), *u = (float *)take(t * ff * 4), *act = (float *)take(t * ff * 4);
+    MoePrefillBufs moe{};
+    if (cfg.num_experts > 0) {
+      const size_t tk = (size_t)cfg.num_experts_per_tok, r = t * tk, E = (size_t)cfg.num_experts;
+      moe.g = (float *)take(r * ff * 4); moe.u = (float *)take(r * ff * 4); moe.act = (float *)take(r * ff * 4);
+      moe.ids = (int32_t *)take(r * 4); moe.w = (float *)take(r * 4); moe.sorted = (int32_t *)take(r * 4);
+      moe.bounds = (int32_t *)take((E + 1) * 4); moe.counts = (int32_t *)take(E * 4); moe.cursors = (int32_t *)take(E * 4);
+      moe.y_in = take(t * (pad_to(d, MATRIX_ROW_PADDING) / 32) * 36);
+      moe.y_act = take(r * (pad_to(ff, MATRIX_ROW_PADDING) / 32) * 36);
+      moe.sum = (float *)take(t * d * 4);
+    }
     const int64_t st = (int64_t)(intptr_t)s;
     // T > 128: the 256-row-tile kernel over bf16 activations (converted once per GEMM group), split-K partials in `part`
     const bool big = T > prefill_big_min() && !getenv("MRS_PREFILL_SMALL_TILES");
@@ -492,6 +542,11 @@ class Llama {
       if (cfg.world_size > 1) {  // row-parallel: partial -> all-reduce -> residual add (bias-free)
         if (gemm(*bl.o_proj, attn, nq, xn, d, 0) || all_reduce(xn, t * d, s) || mrs_vec_add_f32(h, xn, t * d, s)) return -1;
       } else if (gemm(*bl.o_proj, attn, nq, h, d, 1)) return -1;
+      if (cfg.num_experts > 0) {
+        if (!bl.router || !bl.gate_exps.data || !bl.up_exps.data || !bl.down_exps.data) return fail("layer %zu has no experts", li);
+        if (moe_ffn_prefill(bl, h, xn, T, moe, s)) return -1;
+        continue;
+      }
       if (big) { if (mrs_rms_norm_bf16_slabs(h, bl.post_attention_layernorm, T, d, cfg.rms_eps, xb, s)) return -1; xb_ready = xn; }
       else mrs_rms_norm_f32(h, bl.post_attention_layernorm, xn, T, d, cfg.rms_eps, st);
       if (gemm_multi({bl.gate_proj.get(), bl.up_proj.get()}, xn, d, {g, u}, {ff, ff})) return -1;
@@ -519,6 +574,8 @@ class Llama {
       for (const auto *m : {&bl.q_proj, &bl.k_proj, &bl.v_proj, &bl.o_proj, &bl.gate_proj, &bl.up_proj, &bl.down_proj})
         if (*m) w += (double)(*m)->get_qtensor()->rows * (double)(*m)->get_qtensor()->cols;
     double f = 2.0 * T * w;
+    if (cfg.num_experts > 0)  // every token visits top-k experts: gate, up, down of [ffn x hidden] each (the router's E x hidden GEMV is negligible)
+      f += 2.0 * T * (double)cfg.num_experts_per_tok * 3.0 * (double)cfg.intermediate_size * (double)cfg.hidden_size * (double)blocks.size();
     if (lm_head) f += 2.0 * (double)lm_head->get_qtensor()->rows * (double)lm_head->get_qtensor()->cols;
     f += 4.0 * cfg.num_layers * cfg.num_heads * cfg.head_dim * (double)T * (double)T / 2.0;  // QK^T + PV, causal
     return f;
