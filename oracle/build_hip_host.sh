@@ -5,7 +5,7 @@
 # instantiations, the MFMA prefill GEMM / attention, the C++ runner and KV manager) for the HOST on top of oracle/hip_host/hip/hip_runtime.h (wave64 fibers), so the C-ABI launchers can be executed and
 # compared with the oracle without a GPU (tests/test_hip_host_emulation.py).  Output: oracle/_hiphost/libhiphost.so (git-ignored).
 # v_mfma_f32_32x32x16_bf16 and the raw buffer loads of ext_gemm.hip / ext_attn_prefill.hip are modelled too (lane layout calibrated against the
-# GPU-green tests).  Not built: ext_comm.hip (RCCL).
+# GPU-green tests).  ext_comm.hip (RCCL) is replaced by hip_host/comm_shim.c: the all-reduce is a callback (gloo in tests/test_distributed.py).
 # The sources are copied into oracle/_hiphost/src with TWO textual changes (the second: two wave syncs in decode_attn_wave_kernel, see below); the first: `extern __shared__ ... name[];` (dynamic LDS) becomes a pointer to
 # the shim's LDS buffer.  Same flags that pin the arithmetic in the product build: -ffp-contract=off, no fast-math.
 set -e
@@ -34,12 +34,12 @@ for spec in q4_0:2:q4_0 q4_1:3:q4_1 q5_0:6:q5_0 q5_1:7:q5_1 q8_0:8:q8_0 q2_k:10:
 done
 for f in mmvq_quantize moe gemv quant_ops core_ops hqq ext_isq ext_decode ext_gemm ext_attn_prefill kv_cache_ops; do cc $f $f.hip; done
 # the C++ runner (plain host code: it finds the launchers with dlsym(RTLD_DEFAULT), so it only works in a process that loaded THIS library
-# RTLD_GLOBAL and not the product libraries -- `pytest --host-emulation`); the RCCL entry point is a refusing stub
+# RTLD_GLOBAL and not the product libraries -- `pytest --host-emulation`); the RCCL entry points are hip_host/comm_shim.c
 mkdir -p "$OUT/src/host"
 cp "$CSRC/host/runtime.cpp" "$CSRC/host/kv_cache_manager.cpp" "$OUT/src/host/"
 $CXX $FLAGS -c "$OUT/src/host/kv_cache_manager.cpp" -o "$OUT/obj/kv_cache_manager.o" & pids="$pids $!"
 $CXX $FLAGS -I"$HERE/../include" -c "$OUT/src/host/runtime.cpp" -o "$OUT/obj/runtime.o" & pids="$pids $!"
-gcc -O1 -fPIC -w -c "$HERE/hip_host/mfma_stubs.c" -o "$OUT/obj/mfma_stubs.o"
+gcc -O1 -fPIC -w -c "$HERE/hip_host/comm_shim.c" -o "$OUT/obj/comm_shim.o"
 # paged attention: the instantiations of mistral.rs_amd/build.py
 cc pa_f16 paged_attention.hip -DMRS_PA_TAG=f16 -DMRS_PA_T=mrs::f16_t -DMRS_PA_CT=mrs::f16_t -DMRS_PA_EXPORT_ABI
 cc pa_bf16 paged_attention.hip -DMRS_PA_TAG=bf16 -DMRS_PA_T=mrs::bf16_t -DMRS_PA_CT=mrs::bf16_t -DMRS_PA_EXPORT_ABI

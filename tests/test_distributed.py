@@ -125,6 +125,110 @@ def test_tensor_parallel_block_world2_gloo(oracle):
     assert err <= 2e-5 * scale, (err, scale)
 
 
+def _tp_runner_worker(rank, world, port, q):
+    """One tensor-parallel rank of the C++ runner on the host emulation: sharded weights, local head counts, fused decode kernels with the scaled
+    residual + ONE all-reduce per row-parallel projection, MFMA prefill with its all-reduces -- the collective is gloo instead of RCCL."""
+    sys.path.insert(0, ROOT)
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    from tests.conftest import _enter_host_emulation
+    _enter_host_emulation()
+    from tests.abi_backends import HostBackend
+    from mistralrs_amd import distributed as D
+    from mistralrs_amd.gguf import GgmlDType, QTensor
+    from mistralrs_amd.llama import Llama, LlamaConfig
+    from oracle import llama_ref
+    from oracle import oracle as O
+    O.build()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    lib = HostBackend.lib()
+
+    @C.CFUNCTYPE(C.c_int, C.POINTER(C.c_float), C.c_size_t)
+    def all_reduce(buf, count):  # what ncclAllReduce(sum) does for the real library
+        t = torch.as_tensor(np.ctypeslib.as_array(buf, shape=(count,)))  # a view of the runner's buffer
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return 0
+    lib.hiphost_set_all_reduce(all_reduce)
+    lib.mrs_comm_init.restype = C.c_void_p
+    lib.mrs_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int]
+
+    class Comm:
+        handle = lib.mrs_comm_init(None, rank, world)
+
+    heads, kvh, hd, hidden, ff, vocab = 4, 2, 128, 512, 1024, 256
+    types = dict(embd=O.Q4_K, q=O.Q4_K, k=O.Q4_K, v=O.Q6_K, o=O.Q4_K, gate=O.Q4_K, up=O.Q4_K, down=O.Q6_K, output=O.Q6_K)
+    full = LlamaConfig(hidden_size=hidden, intermediate_size=ff, num_layers=2, num_heads=heads, num_kv_heads=kvh, vocab_size=vocab, head_dim=hd,
+                       rope_theta=10000.0, max_position_embeddings=256, max_batch=2, max_context_len=64)
+    w = llama_ref.synth_weights(full, types, seed=3)  # the same full model on every rank
+    dev = torch.device("cpu")
+
+    def build(cfg, r, ws):
+        m = Llama(cfg, dev, max_new_tokens=8)
+        total = {"num_kv_heads": kvh, "head_dim": hd}
+        for name, val in w.items():
+            if isinstance(val, tuple):
+                dt = GgmlDType.from_id(val[0])
+                qt = QTensor.from_numpy(dt, (val[1].shape[0], val[1].shape[1] // dt.type_size * dt.block_size), val[1], dev)
+                sh = D.llama_tensor_shard(name, total, r, ws)
+                m.set_tensor(name, D.shard_qtensor(qt, sh) if sh is not None else qt)
+            else:
+                m.set_tensor(name, torch.from_numpy(val))
+        return m
+
+    lh, lkv, lff = D.local_dims(heads, kvh, ff, world)
+    tp_cfg = LlamaConfig(hidden_size=hidden, intermediate_size=lff, num_layers=2, num_heads=lh, num_kv_heads=lkv, vocab_size=vocab, head_dim=hd,
+                         rope_theta=10000.0, max_position_embeddings=256, max_batch=2, max_context_len=64, tp_world_size=world, tp_rank=rank)
+    mt = build(tp_cfg, rank, world)
+    mt.set_comm(Comm())
+    toks = [(1000 + i) % vocab for i in range(4)]
+    outs = []
+    for pos, t in enumerate(toks):      # fused decode path, one all-reduce per row-parallel projection
+        mt.set_state([t], [pos])
+        outs.append(mt.forward_logits(1)[0].clone())
+    prompt = [(7 * i + 3) % vocab for i in range(20)]
+    mp_ = build(tp_cfg, rank, world)     # MFMA prefill with TP (all-reduce of the GEMM partials), fresh pages
+    mp_.set_comm(Comm())
+    pl = mp_.prefill(prompt, 0).clone()
+    gathered = [torch.zeros_like(torch.stack(outs + [pl])) for _ in range(world)]
+    dist.all_gather(gathered, torch.stack(outs + [pl]))
+    if rank == 0:
+        m1 = build(full, 0, 1)           # the unsharded model, no collective
+        ref = []
+        for pos, t in enumerate(toks):
+            m1.set_state([t], [pos])
+            ref.append(m1.forward_logits(1)[0].clone())
+        m1p = build(full, 0, 1)
+        ref.append(m1p.prefill(prompt, 0).clone())
+        ref = torch.stack(ref)
+        same_on_all_ranks = all(bool(torch.equal(g, gathered[0])) for g in gathered)
+        rel = [float((gathered[0][i] - ref[i]).abs().max() / ref[i].abs().max()) for i in range(ref.shape[0])]
+        q.put((same_on_all_ranks, rel))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tensor_parallel_runner_world2_gloo_on_host_emulation(oracle):
+    """The C++ runner with TP = 2 in two CPU processes (host emulation of the kernels, gloo for the all-reduce) against the unsharded runner:
+    decode logits of 4 positions and the logits of a 20-token MFMA prefill.  Every rank must hold identical logits (the residual stream is
+    replicated after each all-reduce); sharded vs unsharded differ only by the f32 order of the partial sums (and the int8 / bf16 rounding
+    flips that can follow): same bar as the other runner tests."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_tp_runner_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    same, rel = q.get(timeout=1500)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert same, "ranks disagree on the logits"
+    assert max(rel) <= 3e-2, rel
+    assert np.mean(np.array(rel) <= 1e-3) >= 0.6, rel
+
+
 @pytest.mark.gpu
 def test_rccl_comm_world1_and_runner(oracle, dev):
     import torch
