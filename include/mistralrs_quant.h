@@ -139,6 +139,41 @@ void fused_glu_bf16(const void *a, const void *b, void *output, uint32_t rows, u
 void fused_glu_f32(const void *a, const void *b, void *output, uint32_t rows, uint32_t cols, uint32_t a_row_stride,
                    uint32_t b_row_stride, int activation, void *stream);
 
+/* ---- MMQ: prompt-sized quantized matmul behind fast_mmq.rs (shared_lhs / fused_qkv / fused_glu / fused_ffn, gguf/fast_mmq.rs:388-447,528-821).
+ *      Step 1, activations -> block_q8_1_mmq (144 B per 128 values: 16 header bytes + 128 x int8; block index (i0/128)*ne1 + i1; header
+ *      D4 = 4 x f32 d, DS4 = 4 x (half d, half sum x), D2S6 = 2 x half d (per 64) + 6 x half sum (per 16, first 96 values); kernels/mmq_gguf/
+ *      mmq_gguf.cuh:64-89).  x [ne1 rows][s01 stride] of type_x (0 = f32, 1 = f16, 30 = bf16), `ids` optional row gather, ne00 = K,
+ *      ne0 = padded K.  The _glu variants quantize activation(gate) * up (product formed in the input dtype).
+ *      replaces kernels/mmq_gguf/mmq_quantize.cu:104-198,236-325 (kernels), :386-476 (launchers); Rust: src/gguf/ffi.rs:1313-1408 */
+#define MRS_DECL_MMQ_QUANTIZE(L)                                                                                                               \
+  void launch_mmq_quantize_q8_1_##L(const void *x, const int32_t *ids, void *vy, int type_x, int64_t ne00, int64_t s01, int64_t s02, int64_t s03, \
+                                    int64_t ne0, int64_t ne1, int64_t ne2, int64_t ne3, void *stream);                                           \
+  void launch_mmq_quantize_glu_q8_1_##L##_f32(const float *gate, const float *up, const int32_t *ids, void *vy, int64_t ne00, int64_t s01,       \
+                                              int64_t ne0, int64_t ne1, int activation, void *stream);                                           \
+  void launch_mmq_quantize_glu_q8_1_##L(const void *gate, const void *up, const int32_t *ids, void *vy, int type_x, int64_t ne00, int64_t s01,   \
+                                        int64_t ne0, int64_t ne1, int activation, void *stream);
+MRS_DECL_MMQ_QUANTIZE(D4) MRS_DECL_MMQ_QUANTIZE(DS4) MRS_DECL_MMQ_QUANTIZE(D2S6)
+#undef MRS_DECL_MMQ_QUANTIZE
+/*      Step 2, dst[col * nrows_x + row] = W[row, :] . y_col  (type_dst 0 = f32, 1 = f16, 30 = bf16); the layout of y is fixed by <t>:
+ *      DS4 for q4_0 q4_1 q5_1 q4_k q5_k, D2S6 for q2_k, D4 for q5_0 q8_0 q3_k q6_k (mmq_gguf.cuh:100-135).  stride_row_x in blocks.
+ *      tmp_fixup / cc / nsm / smpbo / warp_size belong to the reference's stream-k tiling and are accepted and ignored.  _moe: y columns are
+ *      the routes in expert-sorted order, expert e owns [expert_bounds[e], expert_bounds[e+1]) and channel e of x, column j lands in dst
+ *      column ids_dst[j] (f32, column stride stride_col_dst).
+ *      replaces kernels/mmq_gguf/mmq_instance_<t>.cu:216-259 and DEFINE_MMQ_MOE_LAUNCHER (mmq_gguf.cuh:3968-4010); Rust: ffi.rs:1410-1452,
+ *      callers fast_mmq.rs:421-437 (dense), gguf/cuda.rs (grouped MoE prompt path).  MI355X note: the fast prompt path of this library is
+ *      the fused block-dequant -> bf16 MFMA GEMM (mrs_gemm_q_*, include/mrs_hip_ext.h); these entry points keep fast_mmq.rs linking and
+ *      numerically equivalent (integer dots, stored partial sums), at MMVQ-style throughput. */
+#define MRS_DECL_MMQ(t)                                                                                                                        \
+  void launch_mmq_gguf_##t(void *tmp_fixup, const void *x, const void *y, void *dst, int64_t ncols_x, int64_t nrows_x, int64_t ncols_y,          \
+                           int64_t stride_row_x, int64_t stride_col_dst, int cc, int nsm, int64_t smpbo, int warp_size, int type_dst,            \
+                           void *stream);                                                                                                        \
+  void launch_mmq_gguf_##t##_moe(void *tmp_fixup, const void *x, const void *y, const int32_t *ids_dst, const int32_t *expert_bounds, void *dst, \
+                                 int64_t ncols_x, int64_t nrows_x, int64_t ncols_dst, int64_t stride_row_x, int64_t stride_col_dst,              \
+                                 int64_t num_experts, int64_t ncols_max, int cc, int nsm, int64_t smpbo, int warp_size, void *stream);
+MRS_DECL_MMQ(q4_0) MRS_DECL_MMQ(q4_1) MRS_DECL_MMQ(q5_0) MRS_DECL_MMQ(q5_1) MRS_DECL_MMQ(q8_0)
+MRS_DECL_MMQ(q2_k) MRS_DECL_MMQ(q3_k) MRS_DECL_MMQ(q4_k) MRS_DECL_MMQ(q5_k) MRS_DECL_MMQ(q6_k)
+#undef MRS_DECL_MMQ
+
 /* ---- HQQ: unpack + dequantize (axis-0 groups).  Wq [h][w] packed (u8; i32 with ten 3-bit fields for 3 bit), scale / zero [w] of the
  *      output dtype, out [P*h][w], P = 1/2/4/8/10 values per packed element, most significant first:
  *          out[(c*h + r)*w + j] = (T(q_c(r, j)) - zero[j]) * scale[j]     evaluated in T

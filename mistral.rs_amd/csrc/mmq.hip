@@ -1,0 +1,285 @@
+// mmq.hip -- the reference's MMQ C ABI (prompt-sized quantized matmul) on gfx950:
+//   launch_mmq_quantize_q8_1_{D4,DS4,D2S6}(x, ids, vy, type_x, ne00, s01, s02, s03, ne0, ne1, ne2, ne3, stream)
+//   launch_mmq_quantize_glu_q8_1_{D4,DS4,D2S6}[_f32](gate, up, ids, vy, [type_x,] ne00, s01, ne0, ne1, activation, stream)
+//   launch_mmq_gguf_<t>(tmp_fixup, x, y, dst, ncols_x, nrows_x, ncols_y, stride_row_x, stride_col_dst, cc, nsm, smpbo, warp_size, type_dst, stream)
+//   launch_mmq_gguf_<t>_moe(tmp_fixup, x, y, ids_dst, expert_bounds, dst, ncols_x, nrows_x, ncols_dst, stride_row_x, stride_col_dst,
+//                           num_experts, ncols_max, cc, nsm, smpbo, warp_size, stream)
+// Reference: mistralrs-quant/src/gguf/ffi.rs:1313-1452 (declarations), src/gguf/fast_mmq.rs:388-447 (caller), kernels/mmq_gguf/mmq_quantize.cu
+// (quantizers), kernels/mmq_gguf/mmq_instance_<t>.cu + mmq_gguf.cuh:3960-4010 (launchers), mmq_vecdotq.cuh (arithmetic).
+//
+// What is kept from the reference: the ABI, the block_q8_1_mmq scratch format (so the caller's workspace sizes and the quantize -> matmul
+// hand-off are unchanged), and the arithmetic -- integer dots of the weight ints with the activation ints, weight offsets against the STORED
+// partial sums where the layout carries them (DS4: per 32 values; D2S6: per 16 values for the first 96 of 128) and d * SUM(u) elsewhere.
+// What is not: the tiling.  The reference's kernel is an int8 tensor-core (mma.sync) tile loop with stream-k fix-up; on MI355X the fast prompt
+// path is the fused block-dequant -> bf16 MFMA GEMM (ext_gemm.hip, mrs_gemm_q_*), which needs no activation quantizer at all.
+// These launchers exist so that fast_mmq.rs links and runs unmodified: one wave per weight row and 8 activation columns, lanes striding over
+// 32-weight slices (coalesced 16-byte weight loads, the same per-format decode as the MMVQ kernels: gguf_blocks.cuh load_slice), activations
+// read from the block_q8_1_mmq scratch through L2.  tmp_fixup / cc / nsm / smpbo / warp_size are accepted and unused (no stream-k here).
+// Scale products (d * sc, dmin * m) stay in f32; the reference's Q2_K tile loader rounds them to half.
+#include "common.cuh"
+#include "gguf_blocks.cuh"
+
+namespace mrs {
+
+enum : int { MMQ_D4 = 0, MMQ_DS4 = 1, MMQ_D2S6 = 2 };  // mmq_q8_1_ds_layout, mmq_gguf.cuh:64-68
+// which layout a weight type is paired with (mmq_gguf.cuh:100-135; Rust: fast_mmq.rs ds_layout_for)
+template <int TYPE> struct MmqLayout { static constexpr int value = MMQ_D4; };
+template <> struct MmqLayout<T_Q4_0> { static constexpr int value = MMQ_DS4; };
+template <> struct MmqLayout<T_Q4_1> { static constexpr int value = MMQ_DS4; };
+template <> struct MmqLayout<T_Q5_1> { static constexpr int value = MMQ_DS4; };
+template <> struct MmqLayout<T_Q4_K> { static constexpr int value = MMQ_DS4; };
+template <> struct MmqLayout<T_Q5_K> { static constexpr int value = MMQ_DS4; };
+template <> struct MmqLayout<T_Q2_K> { static constexpr int value = MMQ_D2S6; };
+
+constexpr int MMQ_BLOCK_BYTES = 144;  // 16 header bytes + 128 int8 (mmq_gguf.cuh:70-89)
+
+// ------------------------------------------------------------------------------------------------ quantizers
+// One thread = 4 consecutive values, 128 threads per workgroup = 512 values of one token (mmq_quantize.cu:104-198).  The exchanges stay inside
+// groups of <= 16 lanes, so the wave64 butterflies visit the partners in the reference's order (offsets n/8 .. 1).
+template <int LAYOUT>
+__device__ __forceinline__ void quantize4_store(float4 xi, uint8_t *__restrict__ y, int64_t ib, int iqs) {
+  constexpr int per_scale = LAYOUT == MMQ_D2S6 ? 64 : 32, per_sum = LAYOUT == MMQ_D2S6 ? 16 : 32;
+  float amax = fmaxf(fmaxf(fabsf(xi.x), fabsf(xi.y)), fmaxf(fabsf(xi.z), fabsf(xi.w)));
+#pragma unroll
+  for (int off = per_scale / 8; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+  float sum = 0.0f;
+  if constexpr (LAYOUT != MMQ_D4) {
+    sum = xi.x + xi.y + xi.z + xi.w;
+#pragma unroll
+    for (int off = per_sum / 8; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+  }
+  const bool zero = amax == 0.0f;  // the reference reaches 0 * inf = NaN -> int8 0 and d = 1 / inf = 0 here
+  const float d_inv = 127.0f / amax, d = zero ? 0.0f : 1.0f / d_inv;
+  uint8_t *blk = y + ib * MMQ_BLOCK_BYTES;
+  const uint32_t q = zero ? 0u
+                          : ((uint32_t)(uint8_t)(int8_t)roundf(xi.x * d_inv) | ((uint32_t)(uint8_t)(int8_t)roundf(xi.y * d_inv) << 8) |
+                             ((uint32_t)(uint8_t)(int8_t)roundf(xi.z * d_inv) << 16) | ((uint32_t)(uint8_t)(int8_t)roundf(xi.w * d_inv) << 24));
+  *(uint32_t *)(blk + 16 + iqs) = q;
+  if constexpr (LAYOUT == MMQ_D2S6) {
+    if (iqs % 16 != 0 || iqs >= 96) return;
+    *(uint16_t *)(blk + 4 + 2 * (iqs / 16)) = float_to_half_bits(sum);
+    if (iqs % 64 != 0) return;
+    *(uint16_t *)(blk + 2 * (iqs / 64)) = float_to_half_bits(d);
+  } else {
+    if (iqs % 32 != 0) return;
+    if constexpr (LAYOUT == MMQ_DS4) {
+      *(uint16_t *)(blk + 4 * (iqs / 32)) = float_to_half_bits(d);
+      *(uint16_t *)(blk + 4 * (iqs / 32) + 2) = float_to_half_bits(sum);
+    } else {
+      *(float *)(blk + 4 * (iqs / 32)) = d;
+    }
+  }
+}
+
+template <class T> __device__ __forceinline__ float4 load4(const T *__restrict__ x, int64_t base, int64_t i0, int64_t ne00) {
+  float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (i0 + 0 < ne00) v.x = to_f<T>(x[base + 0]);
+  if (i0 + 1 < ne00) v.y = to_f<T>(x[base + 1]);
+  if (i0 + 2 < ne00) v.z = to_f<T>(x[base + 2]);
+  if (i0 + 3 < ne00) v.w = to_f<T>(x[base + 3]);
+  return v;
+}
+
+template <class T, int LAYOUT>
+__global__ void __launch_bounds__(128) mmq_quantize_kernel(const T *__restrict__ x, const int32_t *__restrict__ ids, uint8_t *__restrict__ y, int64_t ne00,
+                                                           int64_t s01, int64_t s02, int64_t s03, int64_t ne0, int ne1, int ne2) {
+  const int64_t i0 = ((int64_t)blockDim.x * blockIdx.y + threadIdx.x) * 4;
+  if (i0 >= ne0) return;  // ne0 % 128 == 0 at every call site: whole exchange groups leave together
+  const int64_t i1 = blockIdx.x, i2 = blockIdx.z % ne2, i3 = blockIdx.z / ne2;
+  const int64_t i01 = ids ? ids[i1] : i1;
+  const int64_t ib0 = (int64_t)blockIdx.z * ((int64_t)gridDim.x * gridDim.y * blockDim.x / 32);  // first block of the channel
+  const int64_t ib = ib0 + (i0 / 128) * ne1 + i1;
+  const float4 xi = load4(x, i3 * s03 + i2 * s02 + i01 * s01 + i0, i0, ne00);
+  quantize4_store<LAYOUT>(xi, y, ib, (int)(i0 % 128));
+}
+
+// activation(gate) * up with the product formed in T (mmq_quantize.cu:229-234: `(input_t)act(gate) * (input_t)up`)
+template <class T> __device__ __forceinline__ float glu_product(float gate, float up, int act) {
+  return round_to<T>(round_to<T>(glu_act(gate, act)) * up);
+}
+
+template <class T, int LAYOUT>
+__global__ void __launch_bounds__(128) mmq_quantize_glu_kernel(const T *__restrict__ gate, const T *__restrict__ up, const int32_t *__restrict__ ids,
+                                                               uint8_t *__restrict__ y, int64_t ne00, int64_t s01, int64_t ne0, int ne1, int act) {
+  const int64_t i0 = ((int64_t)blockDim.x * blockIdx.y + threadIdx.x) * 4;
+  if (i0 >= ne0) return;
+  const int64_t i1 = blockIdx.x, i01 = ids ? ids[i1] : i1;
+  const int64_t ib = (i0 / 128) * ne1 + i1;
+  const float4 g = load4(gate, i01 * s01 + i0, i0, ne00), u = load4(up, i01 * s01 + i0, i0, ne00);
+  const float4 xi = make_float4(glu_product<T>(g.x, u.x, act), glu_product<T>(g.y, u.y, act), glu_product<T>(g.z, u.z, act), glu_product<T>(g.w, u.w, act));
+  quantize4_store<LAYOUT>(xi, y, ib, (int)(i0 % 128));
+}
+
+template <int LAYOUT>
+static void launch_quantize(const void *x, const int32_t *ids, void *vy, int type_x, int64_t ne00, int64_t s01, int64_t s02, int64_t s03, int64_t ne0,
+                            int64_t ne1, int64_t ne2, int64_t ne3, void *stream) {
+  if (ne0 <= 0 || ne1 <= 0 || ne2 <= 0 || ne3 <= 0) return;
+  const dim3 grid((unsigned)ne1, (unsigned)((ne0 + 511) / 512), (unsigned)(ne2 * ne3));
+  hipStream_t s = (hipStream_t)stream;
+  switch (type_x) {  // ggml type codes: 0 = f32, 1 = f16, 30 = bf16 (fast_mmq.rs:591-596); anything else: no launch, as the reference
+  case 0: hipLaunchKernelGGL((mmq_quantize_kernel<float, LAYOUT>), grid, dim3(128), 0, s, (const float *)x, ids, (uint8_t *)vy, ne00, s01, s02, s03, ne0, (int)ne1, (int)ne2); break;
+  case 1: hipLaunchKernelGGL((mmq_quantize_kernel<f16_t, LAYOUT>), grid, dim3(128), 0, s, (const f16_t *)x, ids, (uint8_t *)vy, ne00, s01, s02, s03, ne0, (int)ne1, (int)ne2); break;
+  case 30: hipLaunchKernelGGL((mmq_quantize_kernel<bf16_t, LAYOUT>), grid, dim3(128), 0, s, (const bf16_t *)x, ids, (uint8_t *)vy, ne00, s01, s02, s03, ne0, (int)ne1, (int)ne2); break;
+  default: break;
+  }
+}
+
+template <int LAYOUT>
+static void launch_quantize_glu(const void *gate, const void *up, const int32_t *ids, void *vy, int type_x, int64_t ne00, int64_t s01, int64_t ne0,
+                                int64_t ne1, int act, void *stream) {
+  if (ne0 <= 0 || ne1 <= 0) return;
+  const dim3 grid((unsigned)ne1, (unsigned)((ne0 + 511) / 512), 1);
+  hipStream_t s = (hipStream_t)stream;
+  switch (type_x) {
+  case 0: hipLaunchKernelGGL((mmq_quantize_glu_kernel<float, LAYOUT>), grid, dim3(128), 0, s, (const float *)gate, (const float *)up, ids, (uint8_t *)vy, ne00, s01, ne0, (int)ne1, act); break;
+  case 1: hipLaunchKernelGGL((mmq_quantize_glu_kernel<f16_t, LAYOUT>), grid, dim3(128), 0, s, (const f16_t *)gate, (const f16_t *)up, ids, (uint8_t *)vy, ne00, s01, ne0, (int)ne1, act); break;
+  case 30: hipLaunchKernelGGL((mmq_quantize_glu_kernel<bf16_t, LAYOUT>), grid, dim3(128), 0, s, (const bf16_t *)gate, (const bf16_t *)up, ids, (uint8_t *)vy, ne00, s01, ne0, (int)ne1, act); break;
+  default: break;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ matmul
+struct MmqArgs {
+  const uint8_t *x;            // weights: [channels][nrows_x] rows of stride_row_x blocks
+  const uint8_t *y;            // block_q8_1_mmq [k_padded / 128][ncols_y]
+  void *dst;                   // dst[col * nrows_dst + row]
+  const int32_t *ids_dst;      // MoE: destination column of y column j (else null)
+  const int32_t *expert_bounds; // MoE: y columns [bounds[e], bounds[e + 1]) belong to expert e (else null)
+  int64_t ncols_x, nrows_x, ncols_y, stride_row_x, nrows_dst, stride_channel_x;
+};
+
+// One 16-value activation run of column `col`: its ints, the scale of its 32- (64-) value group and the partner of the weight offset.
+template <int LAYOUT, bool HAS_OFFSET>
+__device__ __forceinline__ void act_run(const uint8_t *__restrict__ y, int64_t ncols_y, int64_t col, int run, int4 &u, float &d8, float &so) {
+  const int e = run * 16, r = e & 127;
+  const uint8_t *blk = y + ((int64_t)(e >> 7) * ncols_y + col) * MMQ_BLOCK_BYTES;
+  u = ld16_a16(blk + 16 + r);
+  if constexpr (LAYOUT == MMQ_D4) d8 = *(const float *)(blk + 4 * (r >> 5));
+  else if constexpr (LAYOUT == MMQ_DS4) d8 = half_bits_to_float(ld2(blk + 4 * (r >> 5)));
+  else d8 = half_bits_to_float(ld2(blk + 2 * (r >> 6)));
+  so = 0.0f;
+  if constexpr (HAS_OFFSET) {
+    const int4 ones = make_int4(0x01010101, 0x01010101, 0x01010101, 0x01010101);
+    if constexpr (LAYOUT == MMQ_DS4) so = 0.5f * half_bits_to_float(ld2(blk + 4 * (r >> 5) + 2));  // the two runs of a 32-block share its stored sum
+    else if constexpr (LAYOUT == MMQ_D2S6) so = r < 96 ? half_bits_to_float(ld2(blk + 4 + 2 * (r >> 4))) : d8 * (float)dot16(ones, u);
+    else so = d8 * (float)dot16(ones, u);
+  }
+}
+
+template <int TYPE, class OUT, int NC>
+__global__ void __launch_bounds__(256) mmq_kernel(MmqArgs a) {
+  constexpr int LAYOUT = MmqLayout<TYPE>::value;
+  constexpr bool OFF = Fmt<TYPE>::HAS_OFFSET;
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  if (row >= a.nrows_x) return;  // no workgroup barrier below
+  const int64_t col_low = a.expert_bounds ? a.expert_bounds[blockIdx.z] : 0;
+  const int64_t col_high = a.expert_bounds ? a.expert_bounds[blockIdx.z + 1] : a.ncols_y;
+  const int64_t c0 = col_low + (int64_t)blockIdx.y * NC;
+  if (c0 >= col_high) return;
+  const uint8_t *wrow = a.x + ((int64_t)blockIdx.z * a.stride_channel_x + row * a.stride_row_x) * Fmt<TYPE>::TS;
+  const int nslices = (int)(a.ncols_x / 32);
+  float acc[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) acc[c] = 0.0f;
+  for (int s = lane; s < nslices; s += 64) {
+    const Slice sl = load_slice<TYPE>(wrow, s);
+    int ra, rb;
+    slice_runs<TYPE>(s, ra, rb);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int64_t col = c0 + c < col_high ? c0 + c : col_high - 1;  // clamped: the surplus columns are computed and dropped
+      int4 ua, ub;
+      float da, db, soa, sob;
+      act_run<LAYOUT, OFF>(a.y, a.ncols_y, col, ra, ua, da, soa);
+      act_run<LAYOUT, OFF>(a.y, a.ncols_y, col, rb, ub, db, sob);
+      float p = (sl.sa * da) * (float)dot16(sl.qa, ua) + (sl.sb * db) * (float)dot16(sl.qb, ub);
+      if constexpr (OFF) p -= sl.oa * soa + sl.ob * sob;
+      acc[c] += p;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const float v = wave_sum(acc[c]);
+    if (lane == 0 && c0 + c < col_high) {
+      const int64_t dcol = a.ids_dst ? a.ids_dst[c0 + c] : c0 + c;
+      ((OUT *)a.dst)[dcol * a.nrows_dst + row] = from_f<OUT>(v);
+    }
+  }
+}
+
+template <int TYPE, class OUT> static void launch_mmq_t(const MmqArgs &a, int64_t channels, int64_t ncols_max, void *stream) {
+  constexpr int NC = 8;
+  if (a.nrows_x <= 0 || ncols_max <= 0 || channels <= 0) return;
+  const dim3 grid((unsigned)((a.nrows_x + 3) / 4), (unsigned)((ncols_max + NC - 1) / NC), (unsigned)channels);
+  hipLaunchKernelGGL((mmq_kernel<TYPE, OUT, NC>), grid, dim3(256), 0, (hipStream_t)stream, a);
+}
+
+// dense: dst column stride = nrows_x -- the reference's launcher puts nrows_x into mmq_args.nrows_dst and never reads its stride_col_dst
+// parameter (mmq_instance_<t>.cu:216-252; the caller passes nrows for both, fast_mmq.rs:426-430)
+template <int TYPE>
+static void launch_mmq_dense(const void *x, const void *y, void *dst, int64_t ncols_x, int64_t nrows_x, int64_t ncols_y, int64_t stride_row_x, int type_dst,
+                             void *stream) {
+  const MmqArgs a{(const uint8_t *)x, (const uint8_t *)y, dst, nullptr, nullptr, ncols_x, nrows_x, ncols_y, stride_row_x, nrows_x, 0};
+  switch (type_dst) {
+  case 0: launch_mmq_t<TYPE, float>(a, 1, ncols_y, stream); break;
+  case 1: launch_mmq_t<TYPE, f16_t>(a, 1, ncols_y, stream); break;
+  case 30: launch_mmq_t<TYPE, bf16_t>(a, 1, ncols_y, stream); break;
+  default: break;
+  }
+}
+
+// MoE: y holds the routes in expert-sorted order, expert e owns columns [bounds[e], bounds[e + 1]), its weights are channel e of x, the result
+// of column j goes to dst column ids_dst[j]; f32 output (DEFINE_MMQ_MOE_LAUNCHER, mmq_gguf.cuh:3968-4010)
+template <int TYPE>
+static void launch_mmq_moe(const void *x, const void *y, const int32_t *ids_dst, const int32_t *expert_bounds, void *dst, int64_t ncols_x, int64_t nrows_x,
+                           int64_t ncols_dst, int64_t stride_row_x, int64_t stride_col_dst, int64_t num_experts, int64_t ncols_max, void *stream) {
+  const MmqArgs a{(const uint8_t *)x, (const uint8_t *)y, dst, ids_dst, expert_bounds, ncols_x, nrows_x, ncols_dst, stride_row_x, stride_col_dst,
+                  nrows_x * stride_row_x};
+  launch_mmq_t<TYPE, float>(a, num_experts, ncols_max, stream);
+}
+
+}  // namespace mrs
+
+#define MRS_MMQ_QUANTIZE(NAME, LAYOUT)                                                                                                            \
+  extern "C" void launch_mmq_quantize_q8_1_##NAME(const void *x, const int32_t *ids, void *vy, int type_x, int64_t ne00, int64_t s01, int64_t s02, \
+                                                  int64_t s03, int64_t ne0, int64_t ne1, int64_t ne2, int64_t ne3, void *stream) {                 \
+    mrs::launch_quantize<LAYOUT>(x, ids, vy, type_x, ne00, s01, s02, s03, ne0, ne1, ne2, ne3, stream);                                             \
+  }                                                                                                                                                \
+  extern "C" void launch_mmq_quantize_glu_q8_1_##NAME##_f32(const float *gate, const float *up, const int32_t *ids, void *vy, int64_t ne00,        \
+                                                            int64_t s01, int64_t ne0, int64_t ne1, int activation, void *stream) {                 \
+    mrs::launch_quantize_glu<LAYOUT>(gate, up, ids, vy, 0, ne00, s01, ne0, ne1, activation, stream);                                               \
+  }                                                                                                                                                \
+  extern "C" void launch_mmq_quantize_glu_q8_1_##NAME(const void *gate, const void *up, const int32_t *ids, void *vy, int type_x, int64_t ne00,    \
+                                                      int64_t s01, int64_t ne0, int64_t ne1, int activation, void *stream) {                       \
+    mrs::launch_quantize_glu<LAYOUT>(gate, up, ids, vy, type_x, ne00, s01, ne0, ne1, activation, stream);                                          \
+  }
+MRS_MMQ_QUANTIZE(D4, mrs::MMQ_D4)
+MRS_MMQ_QUANTIZE(DS4, mrs::MMQ_DS4)
+MRS_MMQ_QUANTIZE(D2S6, mrs::MMQ_D2S6)
+
+#define MRS_MMQ_LAUNCHERS(TAG, TYPE)                                                                                                               \
+  extern "C" void launch_mmq_gguf_##TAG(void *tmp_fixup, const void *x, const void *y, void *dst, int64_t ncols_x, int64_t nrows_x, int64_t ncols_y, \
+                                        int64_t stride_row_x, int64_t stride_col_dst, int cc, int nsm, int64_t smpbo, int warp_size, int type_dst, \
+                                        void *stream) {                                                                                            \
+    (void)tmp_fixup; (void)stride_col_dst; (void)cc; (void)nsm; (void)smpbo; (void)warp_size;                                                      \
+    mrs::launch_mmq_dense<TYPE>(x, y, dst, ncols_x, nrows_x, ncols_y, stride_row_x, type_dst, stream);                                             \
+  }                                                                                                                                                \
+  extern "C" void launch_mmq_gguf_##TAG##_moe(void *tmp_fixup, const void *x, const void *y, const int32_t *ids_dst, const int32_t *expert_bounds, \
+                                              void *dst, int64_t ncols_x, int64_t nrows_x, int64_t ncols_dst, int64_t stride_row_x,               \
+                                              int64_t stride_col_dst, int64_t num_experts, int64_t ncols_max, int cc, int nsm, int64_t smpbo,      \
+                                              int warp_size, void *stream) {                                                                       \
+    (void)tmp_fixup; (void)cc; (void)nsm; (void)smpbo; (void)warp_size;                                                                            \
+    mrs::launch_mmq_moe<TYPE>(x, y, ids_dst, expert_bounds, dst, ncols_x, nrows_x, ncols_dst, stride_row_x, stride_col_dst, num_experts, ncols_max, \
+                              stream);                                                                                                             \
+  }
+MRS_MMQ_LAUNCHERS(q4_0, mrs::T_Q4_0)
+MRS_MMQ_LAUNCHERS(q4_1, mrs::T_Q4_1)
+MRS_MMQ_LAUNCHERS(q5_0, mrs::T_Q5_0)
+MRS_MMQ_LAUNCHERS(q5_1, mrs::T_Q5_1)
+MRS_MMQ_LAUNCHERS(q8_0, mrs::T_Q8_0)
+MRS_MMQ_LAUNCHERS(q2_k, mrs::T_Q2_K)
+MRS_MMQ_LAUNCHERS(q3_k, mrs::T_Q3_K)
+MRS_MMQ_LAUNCHERS(q4_k, mrs::T_Q4_K)
+MRS_MMQ_LAUNCHERS(q5_k, mrs::T_Q5_K)
+MRS_MMQ_LAUNCHERS(q6_k, mrs::T_Q6_K)

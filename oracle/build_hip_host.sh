@@ -1,7 +1,7 @@
 #!/bin/sh
 # oracle/build_hip_host.sh -- TEST INFRASTRUCTURE ONLY.
 # Compiles the PRODUCT kernel sources (mistral.rs_amd/csrc: the MMVQ core with every launcher of the 10 GGUF types, the Q8_1 quantizer,
-# moe.hip, gemv.hip, quant_ops / core_ops / hqq / ext_isq, the fused decode kernels of ext_decode.hip, kv_cache_ops and the paged-attention
+# mmq.hip, moe.hip, gemv.hip, quant_ops / core_ops / hqq / ext_isq, the fused decode kernels of ext_decode.hip, kv_cache_ops and the paged-attention
 # instantiations, the MFMA prefill GEMM / attention, the C++ runner and KV manager) for the HOST on top of oracle/hip_host/hip/hip_runtime.h (wave64 fibers), so the C-ABI launchers can be executed and
 # compared with the oracle without a GPU (tests/test_hip_host_emulation.py).  Output: oracle/_hiphost/libhiphost.so (git-ignored).
 # v_mfma_f32_32x32x16_bf16 and the raw buffer loads of ext_gemm.hip / ext_attn_prefill.hip are modelled too (lane layout calibrated against the
@@ -32,7 +32,7 @@ for spec in q4_0:2:q4_0 q4_1:3:q4_1 q5_0:6:q5_0 q5_1:7:q5_1 q8_0:8:q8_0 q2_k:10:
   tag=${spec%%:*}; rest=${spec#*:}; tid=${rest%%:*}; moe=${rest#*:}
   cc mmvq_$tag mmvq_inst.hip -DMRS_TAG=$tag -DMRS_TYPE=$tid -DMRS_MOE_TAG=$moe
 done
-for f in mmvq_quantize moe gemv quant_ops core_ops hqq ext_isq ext_decode ext_gemm ext_attn_prefill kv_cache_ops; do cc $f $f.hip; done
+for f in mmvq_quantize mmq moe gemv quant_ops core_ops hqq ext_isq ext_decode ext_gemm ext_attn_prefill kv_cache_ops; do cc $f $f.hip; done
 # the C++ runner (plain host code: it finds the launchers with dlsym(RTLD_DEFAULT), so it only works in a process that loaded THIS library
 # RTLD_GLOBAL and not the product libraries -- `pytest --host-emulation`); the RCCL entry points are hip_host/comm_shim.c
 mkdir -p "$OUT/src/host"

@@ -132,4 +132,17 @@ SORT="$REF/mistralrs-core/src/cuda/sort.cu"
   sed -n '148,318p' "$SORT" | awk '/^template <typename T>$/{t=$0; next} /^void launch_/{skip=1} !skip{if (t != "") print t; print} {t=""} skip && /^}$/{skip=0}'
   sed -n '351,428p' "$SORT"
   cat "$HERE/ref_shim/rms_driver.inc" ) | $CXX $FLAGS $FIB -o "$OUT/libref_rms.so" -
-echo "oracle/_ref: built libref_mmvq.so libref_affine.so libref_hqq.so libref_cache.so libref_pa.so libref_q8_1.so libref_rms.so libref_mmvq_kernel.so libref_glu.so libref_router.so libref_imoe.so libref_moe_decode.so libref_moe_grouped.so libref_gemv.so libref_half.so from $REF"
+# MMQ activation quantizer (mistralrs-quant/kernels/mmq_gguf/mmq_quantize.cu): block_q8_1_mmq + layout enum streamed from mmq_gguf.cuh, the two
+# kernels (plain, fused GLU) streamed from mmq_quantize.cu up to its launchers; f32 / f16 / bf16 inputs, D4 / DS4 / D2S6 layouts
+MMQ_DIR="$REF/mistralrs-quant/kernels/mmq_gguf"
+( cat "$HERE/ref_shim/cuda_shim.h" "$HERE/ref_shim/fiber_shim.h"
+  echo '#define QK8_1 32'
+  echo '#define MATRIX_ROW_PADDING 512'
+  echo 'struct char4 { signed char x, y, z, w; };'
+  echo 'struct __nv_bfloat162 { __nv_bfloat16 x, y; };'
+  echo 'static inline half2 make_half2(float a, float b) { half2 r; r.x = __half(a); r.y = __half(b); return r; }'
+  echo 'static inline float2 __bfloat1622float2(__nv_bfloat162 v) { return float2{(float)v.x, (float)v.y}; }'
+  awk '/^enum mmq_q8_1_ds_layout/{p=1} /^struct block_fp4_mmq/{exit} p{print}' "$MMQ_DIR/mmq_gguf.cuh"
+  awk '/^#define CUDA_QUANTIZE_BLOCK_SIZE_MMQ/{p=1} /^template <mmq_q8_1_ds_layout ds_layout>$/{exit} p{print}' "$MMQ_DIR/mmq_quantize.cu"
+  cat "$HERE/ref_shim/mmq_quantize_driver.inc" ) | $CXX $FLAGS $FIB -DSHIM_HALF_OPS -o "$OUT/libref_mmq_quantize.so" -
+echo "oracle/_ref: built libref_mmvq.so libref_affine.so libref_hqq.so libref_cache.so libref_pa.so libref_q8_1.so libref_rms.so libref_mmvq_kernel.so libref_glu.so libref_router.so libref_imoe.so libref_moe_decode.so libref_moe_grouped.so libref_gemv.so libref_half.so libref_mmq_quantize.so from $REF"

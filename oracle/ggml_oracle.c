@@ -554,6 +554,100 @@ void orc_quantize_q8_1(const float *x, void *vy, int kx, int kx_padded, int rows
     }
 }
 
+/* block_q8_1_mmq quantizer (reference: mistralrs-quant/kernels/mmq_gguf/mmq_quantize.cu:104-198 quantize_mmq_q8_1, launch geometry :328-357;
+ * block layout mmq_gguf.cuh:70-89).  144-byte blocks of 128 values: 16 header bytes + 128 int8; block index = (i0/128)*ne1 + i1 (k-block major,
+ * token minor).  layout 0 = D4 (4 x f32 d), 1 = DS4 (4 x (half d, half sum)), 2 = D2S6 (half d per 64 values, half sum per 16 values for the first 96).
+ * d_inv = 127/amax, q = roundf(x*d_inv), d = 1/d_inv; sums: 4 values per thread left to right, then the xor butterfly (offsets n/8 .. 1) over the
+ * threads of the group.  amax == 0: q = 0, d = 0 (the device's float->int conversion of NaN). */
+static float mmq_butterfly_sum(const float *t4, int nthreads) { /* t4: per-thread partial sums */
+  float t[8], u[8];
+  memcpy(t, t4, sizeof(float) * nthreads);
+  for (int off = nthreads / 2; off > 0; off >>= 1) { for (int l = 0; l < nthreads; ++l) u[l] = t[l] + t[l ^ off]; memcpy(t, u, sizeof(float) * nthreads); }
+  return t[0];
+}
+void orc_quantize_q8_1_mmq(const float *x, const int32_t *ids, void *vy, int layout, int64_t ne00, int64_t s01, int64_t ne0, int64_t ne1) {
+  uint8_t *y = vy;
+  const int per_scale = layout == 2 ? 64 : 32, per_sum = layout == 2 ? 16 : 32;
+  for (int64_t i1 = 0; i1 < ne1; ++i1) {
+    const int64_t row = ids ? ids[i1] : i1;
+    for (int64_t kb = 0; kb < (ne0 + 127) / 128; ++kb) {
+      uint8_t *blk = y + (size_t)(kb * ne1 + i1) * 144;
+      float v[128];
+      for (int j = 0; j < 128; ++j) { const int64_t i0 = kb * 128 + j; v[j] = (i0 < ne00 && i0 < ne0) ? x[row * s01 + i0] : 0.0f; }
+      for (int g = 0; g < 128 / per_scale; ++g) {
+        float amax = 0.0f;
+        for (int j = 0; j < per_scale; ++j) amax = fmaxf(amax, fabsf(v[g * per_scale + j]));
+        const float d_inv = 127.0f / amax, d = amax == 0.0f ? 0.0f : 1.0f / d_inv;
+        for (int j = 0; j < per_scale; ++j) ((int8_t *)(blk + 16))[g * per_scale + j] = amax == 0.0f ? 0 : (int8_t)roundf(v[g * per_scale + j] * d_inv);
+        if (layout == 0) memcpy(blk + 4 * g, &d, 4);
+        else st16(blk + (layout == 1 ? 4 * g : 2 * g), orc_fp32_to_fp16(d));
+      }
+      if (layout != 0)
+        for (int g = 0; g < (layout == 2 ? 6 : 4); ++g) {
+          float t4[8];
+          for (int t = 0; t < per_sum / 4; ++t) { const float *q = v + g * per_sum + 4 * t; t4[t] = q[0] + q[1] + q[2] + q[3]; }
+          const float sum = mmq_butterfly_sum(t4, per_sum / 4);
+          st16(blk + (layout == 1 ? 4 * g + 2 : 4 + 2 * g), orc_fp32_to_fp16(sum));
+        }
+    }
+  }
+}
+
+/* MMQ maths (reference: mmq_vecdotq.cuh vec_dot_*_q8_1_impl_mmq / _dp4a, tile loaders of mmq_gguf.cuh): integer dots of the weight ints with the
+ * block_q8_1_mmq ints, scaled by (weight scale * activation d); the weight offsets meet the STORED partial sums where the layout carries one
+ * (DS4: half(sum x) of the 32-block; D2S6: half(sum x) of the 16-value run for the first 96 values of a 128-block) and d*SUM(u) otherwise.
+ * f64 combination: order-free reference for any f32 summation order.  out[col*N + row]. */
+static int mmq_layout_of(int type) {
+  switch (type) {
+  case ORC_Q4_0: case ORC_Q4_1: case ORC_Q5_1: case ORC_Q4_K: case ORC_Q5_K: return 1;
+  case ORC_Q2_K: return 2;
+  default: return 0;
+  }
+}
+int orc_mmq_layout(int type) { return mmq_layout_of(type); }
+static double row_dot_q8_1_mmq(int type, const uint8_t *wrow, int K, const uint8_t *y, int64_t ncols_y, int64_t col, double *mag) {
+  const int blk = orc_block_size(type), ts = orc_type_size(type), layout = mmq_layout_of(type);
+  int q[256]; float sc[16], off[16];
+  double acc = 0, m = 0;
+  for (int ib = 0; ib < K / blk; ++ib) {
+    const uint8_t *b = wrow + (size_t)ib * ts;
+    block_ints(type, b, q);
+    const int gs = block_affine(type, b, sc, off);
+    const int step = gs < 16 ? gs : 16; /* 16-value runs: the finest granularity any layout stores a sum at */
+    for (int s = 0; s < blk / step; ++s) {
+      const int e0 = s * step, g = e0 / gs;
+      const int64_t e = (int64_t)ib * blk + e0;
+      const uint8_t *yb = y + (size_t)((e / 128) * ncols_y + col) * 144;
+      const int r = (int)(e % 128);
+      const int8_t *u = (const int8_t *)(yb + 16) + r;
+      float d8;
+      if (layout == 0) d8 = ldf32(yb + 4 * (r / 32));
+      else d8 = orc_fp16_to_fp32(ld16(yb + (layout == 1 ? 4 * (r / 32) : 2 * (r / 64))));
+      int dot = 0, su = 0;
+      for (int j = 0; j < step; ++j) { dot += q[e0 + j] * u[j]; su += u[j]; }
+      double so; /* the offset's partner */
+      if (layout == 1) so = 0.5 * (double)orc_fp16_to_fp32(ld16(yb + 4 * (r / 32) + 2)); /* two 16-runs share the 32-block's stored sum */
+      else if (layout == 2 && r < 96) so = (double)orc_fp16_to_fp32(ld16(yb + 4 + 2 * (r / 16)));
+      else so = (double)d8 * su;
+      const double a = (double)sc[g] * (double)d8 * dot, o = (double)off[g] * so;
+      acc += a - o;
+      m += fabs(a) + fabs(o);
+    }
+  }
+  if (mag) *mag = m;
+  return acc;
+}
+void orc_matmul_q8_1_mmq(int type, const void *W, int N, int K, int64_t stride_row_x, const void *y, int64_t ncols_y, float *out, float *mag) {
+  const size_t row_bytes = (size_t)stride_row_x * orc_type_size(type);
+#pragma omp parallel for schedule(static)
+  for (int n = 0; n < N; ++n)
+    for (int64_t c = 0; c < ncols_y; ++c) {
+      double m;
+      out[(size_t)c * N + n] = (float)row_dot_q8_1_mmq(type, (const uint8_t *)W + n * row_bytes, K, y, ncols_y, c, &m);
+      if (mag) mag[(size_t)c * N + n] = (float)m;
+    }
+}
+
 void orc_quantize_q8_K(const float *x, void *vy, int64_t k) {
   uint8_t *y = vy;
   for (int64_t i = 0; i < k / QK_K; ++i, x += QK_K, y += 292) {

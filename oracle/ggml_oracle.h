@@ -50,6 +50,11 @@ void orc_random_blocks(int type, void *blocks, int64_t n_blocks, uint64_t seed, 
  * q=roundf(x/d), ds = (half d, half sum(x)) */
 void orc_quantize_q8_1(const float *x, void *y, int kx, int kx_padded, int rows);
 void orc_quantize_q8_K(const float *x, void *y, int64_t k); /* candle BlockQ8K::from_float */
+/* block_q8_1_mmq (144 B / 128 values; mmq_quantize.cu:104-198): layout 0 = D4, 1 = DS4, 2 = D2S6; block (i0/128)*ne1 + i1 */
+void orc_quantize_q8_1_mmq(const float *x, const int32_t *ids, void *vy, int layout, int64_t ne00, int64_t s01, int64_t ne0, int64_t ne1);
+int  orc_mmq_layout(int type); /* the layout the reference pairs with a weight type (mmq_gguf.cuh:100-135) */
+/* D: GPU-MMQ semantics: integer dots against block_q8_1_mmq, stored partial sums where the layout has them; out / mag [ncols_y, N] */
+void orc_matmul_q8_1_mmq(int type, const void *W, int N, int K, int64_t stride_row_x, const void *y_mmq, int64_t ncols_y, float *out, float *mag);
 
 /* matmul oracles: W [N, K] packed row-major, X [B, K] f32, out [B, N] */
 /* A: exact: dequantize W to f32, accumulate in f64 */

@@ -124,6 +124,38 @@ def quantize_q8_1(x: np.ndarray, k_padded: int | None = None) -> np.ndarray:
     return out
 
 
+MMQ_D4, MMQ_DS4, MMQ_D2S6 = 0, 1, 2  # mmq_q8_1_ds_layout (mmq_gguf.cuh:64-68)
+
+
+def mmq_layout(t: int) -> int:
+    """The block_q8_1_mmq layout the reference pairs with weight type t (mmq_gguf.cuh:100-135, fast_mmq.rs ds_layout_for)."""
+    return int(lib().orc_mmq_layout(t))
+
+
+def quantize_q8_1_mmq(x: np.ndarray, layout: int, ne0: int | None = None, ids=None, ne1: int | None = None) -> np.ndarray:
+    """x [rows, K] f32 -> uint8 [ne0/128, ne1, 144] block_q8_1_mmq (mmq_quantize.cu:104-198); ne0 = padded K (multiple of 512 as the callers
+    pass it), ids = optional row gather (token ne1 reads row ids[i1])."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    rows, k = x.shape
+    kp = pad512(k) if ne0 is None else ne0
+    n1 = (len(ids) if ids is not None else rows) if ne1 is None else ne1
+    out = np.zeros(((kp + 127) // 128, n1, 144), dtype=np.uint8)
+    idp = None if ids is None else _p(np.ascontiguousarray(ids, dtype=np.int32))
+    lib().orc_quantize_q8_1_mmq(_p(x), idp, _p(out), layout, C.c_int64(k), C.c_int64(k), C.c_int64(kp), C.c_int64(n1))
+    return out
+
+
+def matmul_q8_1_mmq(t: int, w: np.ndarray, n: int, k: int, y: np.ndarray, stride_row_x: int | None = None):
+    """(out, mag) [ncols_y, n]: MMQ maths of weight type t against block_q8_1_mmq y [k_padded/128, ncols_y, 144] in the layout mmq_layout(t)."""
+    y = np.ascontiguousarray(y, dtype=np.uint8)
+    ncols = y.shape[1]
+    out = np.empty((ncols, n), dtype=np.float32)
+    mag = np.empty((ncols, n), dtype=np.float32)
+    srx = k // block_size(t) if stride_row_x is None else stride_row_x
+    lib().orc_matmul_q8_1_mmq(t, _p(w), n, k, C.c_int64(srx), _p(y), C.c_int64(ncols), _p(out), _p(mag))
+    return out, mag
+
+
 def quantize_q8_K(x: np.ndarray) -> np.ndarray:
     x = np.ascontiguousarray(x, dtype=np.float32)
     b, k = x.shape
