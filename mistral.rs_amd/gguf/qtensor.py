@@ -66,7 +66,10 @@ class QTensor:
     data: torch.Tensor  # uint8, N * row_bytes(K)
 
     def __post_init__(self):
-        n, k = self.shape
+        *lead, k = self.shape  # (N, K), or (experts, N, K) for stacked MoE experts (fast_mmq.grouped)
+        n = 1
+        for d in lead:
+            n *= d
         want = n * self.dtype.row_bytes(k)
         if self.data.dtype != torch.uint8 or self.data.numel() != want:
             raise ValueError(f"QTensor: expected {want} packed bytes for {self.dtype.name} {self.shape}, "
