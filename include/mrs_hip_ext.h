@@ -178,6 +178,10 @@ int mrs_isq_quantize_q8_0(const void *src, int src_dtype, void *dst, long long n
  * ggml_type 2 Q4_0, 3 Q4_1, 6 Q5_0, 7 Q5_1, 8 Q8_0, 12 Q4_K, 13 Q5_K, 14 Q6_K (one lane per sub-block, 8 / 16 lanes per K-quant superblock).
  * Returns 0, -1 for an unknown dtype / type or n_elements not a multiple of the block size (32 / 256). */
 int mrs_isq_quantize(const void *src, int src_dtype, void *dst, long long n_elements, int ggml_type, void *stream);
+/* QuantMethod::dequantize_w for GGUF blocks (mistralrs-quant/src/gguf/mod.rs:430-432 -> candle QTensor::dequantize): packed [nrows][K/blk]
+ * of ggml_type 2,3,6,7,8,10..14 -> dense [nrows][K] of out_dtype 0 f32 / 1 f16 / 30 bf16; w = scale*q - offset in f32 (the format spec of
+ * kernels/gguf_affine_packed/marlin_gguf_affine_repack.cu:141-278), one rounding to the output dtype.  Returns 0 / -1. */
+int mrs_dequantize(const void *w, int ggml_type, long long nrows, int K, void *out, int out_dtype, void *stream);
 
 /* ---------------------------------------------------------------- paged KV cache manager (host/kv_cache_manager.cpp; host code only)
  * Block pool with prefix caching + per-request block tracking: the C++ counterpart of mistralrs-core/src/paged_attention/

@@ -5,6 +5,7 @@
 // result side by side, so there is no host round trip.  Output = standard Q8_0 bytes [N][K/32][34] consumed by the same GEMV /
 // GEMM kernels as GGUF Q8_0 files.  `K % 32 != 0` is refused (the reference falls back to another dtype: isq.rs:249-287).
 #include "common.cuh"
+#include "gguf_blocks.cuh"
 
 namespace mrs {
 
@@ -349,6 +350,42 @@ template <class T> static int isq_dispatch(const T *src, uint8_t *dst, size_t n,
   }
 }
 
+// ------------------------------------------------------------------------------------------------ dequantize (QuantMethod::dequantize_w)
+// One lane per 32-weight slice (gguf_blocks.cuh: two 16-weight runs, w = s*q - o in f32, the arithmetic of the in-tree format spec
+// marlin_gguf_affine_repack.cu:218-278 get_affine_params); a wave reads consecutive 16-byte pieces of the packed row and writes two 64-byte
+// spans per lane.  HBM-bound: type_size/blk bytes in, sizeof(OUT) bytes out per weight.
+__device__ __forceinline__ int byte_of(int4 v, int i) { return (int)(int8_t)(((const uint32_t *)&v)[i >> 2] >> (8 * (i & 3))); }
+
+template <int TYPE, class OUT>
+__global__ void __launch_bounds__(256) dequantize_kernel(const uint8_t *__restrict__ w, OUT *__restrict__ out, int64_t nrows, int K) {
+  const int nslices = K / 32;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= nrows * nslices) return;
+  const int64_t row = gid / nslices;
+  const int s = (int)(gid % nslices);
+  const Slice sl = load_slice<TYPE>(w + row * (int64_t)(K / Fmt<TYPE>::BLK) * Fmt<TYPE>::TS, s);
+  int ra, rb;
+  slice_runs<TYPE>(s, ra, rb);
+  OUT *oa = out + row * K + (int64_t)ra * 16, *ob = out + row * K + (int64_t)rb * 16;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    oa[i] = from_f<OUT>(sl.sa * (float)byte_of(sl.qa, i) - sl.oa);
+    ob[i] = from_f<OUT>(sl.sb * (float)byte_of(sl.qb, i) - sl.ob);
+  }
+}
+
+template <class OUT> static int dequantize_dispatch(const uint8_t *w, OUT *out, int64_t nrows, int K, int type, hipStream_t s) {
+  const int64_t total = nrows * (K / 32);
+  if (total <= 0) return 0;
+  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+#define MRS_DQ(T) case T: hipLaunchKernelGGL((dequantize_kernel<T, OUT>), grid, block, 0, s, w, out, nrows, K); return 0;
+  switch (type) {
+    MRS_DQ(T_Q4_0) MRS_DQ(T_Q4_1) MRS_DQ(T_Q5_0) MRS_DQ(T_Q5_1) MRS_DQ(T_Q8_0) MRS_DQ(T_Q2_K) MRS_DQ(T_Q3_K) MRS_DQ(T_Q4_K) MRS_DQ(T_Q5_K) MRS_DQ(T_Q6_K)
+  default: return -1;
+  }
+#undef MRS_DQ
+}
+
 }  // namespace mrs
 
 // src: dense [N*K] elements, dtype 0 = f32, 1 = f16, 30 = bf16 (ggml ids); dst: N*K/32*34 bytes.  Returns 0 / -1.
@@ -378,6 +415,22 @@ extern "C" int mrs_isq_quantize(const void *src, int src_dtype, void *dst, long 
   case 0: return mrs::isq_dispatch<float>((const float *)src, (uint8_t *)dst, (size_t)n_elements, ggml_type, s);
   case 1: return mrs::isq_dispatch<mrs::f16_t>((const mrs::f16_t *)src, (uint8_t *)dst, (size_t)n_elements, ggml_type, s);
   case 30: return mrs::isq_dispatch<mrs::bf16_t>((const mrs::bf16_t *)src, (uint8_t *)dst, (size_t)n_elements, ggml_type, s);
+  default: return -1;
+  }
+}
+
+// QuantMethod::dequantize_w for GGUF blocks (gguf/mod.rs:430-432 -> QTensor::dequantize): packed [nrows][K/blk] -> dense [nrows][K] of
+// out_dtype 0 = f32, 1 = f16, 30 = bf16 (values computed in f32, one rounding).  Returns 0, -1 for an unknown type / dtype or K not a
+// multiple of the block size.
+extern "C" int mrs_dequantize(const void *w, int ggml_type, long long nrows, int K, void *out, int out_dtype, void *stream) {
+  if (nrows <= 0 || K <= 0) return 0;
+  const int blk = (ggml_type >= 10 && ggml_type <= 14) ? 256 : 32;
+  if (K % blk) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  switch (out_dtype) {
+  case 0: return mrs::dequantize_dispatch<float>((const uint8_t *)w, (float *)out, nrows, K, ggml_type, s);
+  case 1: return mrs::dequantize_dispatch<mrs::f16_t>((const uint8_t *)w, (mrs::f16_t *)out, nrows, K, ggml_type, s);
+  case 30: return mrs::dequantize_dispatch<mrs::bf16_t>((const uint8_t *)w, (mrs::bf16_t *)out, nrows, K, ggml_type, s);
   default: return -1;
   }
 }
