@@ -57,10 +57,12 @@ def libraries():
         "libmrs_hip_ext.so": ["ext_decode.hip", "ext_gemm.hip", "ext_attn_prefill.hip", "ext_comm.hip", "ext_isq.hip",
                               "host/runtime.cpp", "host/kv_cache_manager.cpp"],
     }
+    # experiment knob (default off): MRS_DECODE_MIN_WAVES=4 caps the decode GEMV kernels at 128 VGPRs (csrc/ext_decode.hip); use with --force
+    decode_defs = {"ext_decode.hip": (f"-DMRS_DECODE_MIN_WAVES={os.environ['MRS_DECODE_MIN_WAVES']}",)} if os.environ.get("MRS_DECODE_MIN_WAVES") else {}
     for lib, srcs in optional.items():
         for s in srcs:
             if os.path.exists(os.path.join(CSRC, s)):
-                libs.setdefault(lib, []).append(_tu(s, os.path.basename(os.path.splitext(s)[0]) + ".o"))
+                libs.setdefault(lib, []).append(_tu(s, os.path.basename(os.path.splitext(s)[0]) + ".o", decode_defs.get(s, ())))
     return libs
 
 

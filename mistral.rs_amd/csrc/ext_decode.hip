@@ -145,8 +145,16 @@ __device__ __forceinline__ size_t hot_row_bytes(int t, int K) {
   }
 }
 
+// MRS_DECODE_MIN_WAVES (build-time experiment knob, default off = the measured round-1 object code): the minimum number of waves per SIMD the
+// register allocator must leave room for.  4 caps the kernel at 128 VGPRs so that TWO 512-thread workgroups share a CU (16 waves per CU instead
+// of 8); pair it with MRS_PROJ_WGS=512 / MRS_GLU_PER=32 / MRS_QKV_PPW at run time.  profiles/round1_decode_kernel_resources.md has the numbers.
+#ifdef MRS_DECODE_MIN_WAVES
+#define MRS_DECODE_BOUNDS(NT) __launch_bounds__(NT, MRS_DECODE_MIN_WAVES)
+#else
+#define MRS_DECODE_BOUNDS(NT) __launch_bounds__(NT)
+#endif
 template <int NCOLS, int PRO, int EPI, int NT>
-__global__ void __launch_bounds__(NT) decode_gemv_kernel(const DecodeGemvArgs a) {
+__global__ void MRS_DECODE_BOUNDS(NT) decode_gemv_kernel(const DecodeGemvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NW = NT / 64;
   const int K = a.K;
