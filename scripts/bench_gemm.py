@@ -10,10 +10,11 @@ def main():
     ap.add_argument("--t", type=int, default=512)
     ap.add_argument("--types", default="q4_k,q6_k")
     ap.add_argument("--big", action="store_true", help="256-row-tile kernel over bf16 activations (mrs_gemm_q_bf16_multi)")
+    ap.add_argument("--mmq", action="store_true", help="the reference-ABI route instead: launch_mmq_quantize_q8_1_* + launch_mmq_gguf_<t> (fast_mmq.plain)")
     a = ap.parse_args()
     import torch
     import mistralrs_amd  # noqa: F401
-    from mistralrs_amd.gguf import GgmlDType, fast_gemm
+    from mistralrs_amd.gguf import GgmlDType, fast_gemm, fast_mmq
     from mistralrs_amd.llama import random_qtensor
     dev = torch.device("cuda:0")
     tags = {d.tag: d for d in GgmlDType}
@@ -24,7 +25,12 @@ def main():
             out = torch.empty(a.t, n, device=dev)
             ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
             xb = fast_gemm.to_slabs(x) if a.big else None
-            run = (lambda: fast_gemm.plain_bf16(w, xb, out=out, workspace=ws)) if a.big else (lambda: fast_gemm.plain(w, x, out=out))
+            if a.mmq:
+                run = lambda: fast_mmq.plain(w, x)
+            elif a.big:
+                run = lambda: fast_gemm.plain_bf16(w, xb, out=out, workspace=ws)
+            else:
+                run = lambda: fast_gemm.plain(w, x, out=out)
             run()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
