@@ -12,7 +12,7 @@
 // partial sums where the layout carries them (DS4: per 32 values; D2S6: per 16 values for the first 96 of 128) and d * SUM(u) elsewhere.
 // What is not: the tiling.  The reference's kernel is an int8 tensor-core (mma.sync) tile loop with stream-k fix-up; on MI355X the fast prompt
 // path is the fused block-dequant -> bf16 MFMA GEMM (ext_gemm.hip, mrs_gemm_q_*), which needs no activation quantizer at all.
-// These launchers exist so that fast_mmq.rs links and runs unmodified: one wave per weight row and 8 activation columns, lanes striding over
+// These launchers exist so that fast_mmq.rs links and runs unmodified: one wave per 1 or 4 weight rows x 8 activation columns, lanes striding over
 // 32-weight slices (coalesced 16-byte weight loads, the same per-format decode as the MMVQ kernels: gguf_blocks.cuh load_slice), activations
 // read from the block_q8_1_mmq scratch through L2.  tmp_fixup / cc / nsm / smpbo / warp_size are accepted and unused (no stream-k here).
 // Scale products (d * sc, dmin * m) stay in f32; the reference's Q2_K tile loader rounds them to half.
@@ -166,53 +166,73 @@ __device__ __forceinline__ void act_run(const uint8_t *__restrict__ y, int64_t n
   }
 }
 
-template <int TYPE, class OUT, int NC>
+// R weight rows x NC activation columns per wave: one activation run (ints, scale, stored sum) is loaded once and meets R decoded weight
+// slices, one weight slice meets NC columns -- R*NC products per (R weight + NC activation) loads.  The per-(row, column) arithmetic and its
+// order (lane partial sums over s = lane, lane + 64, ..., then the wave reduction) do not depend on R, so every R gives bit-identical results.
+template <int TYPE, class OUT, int NC, int R>
 __global__ void __launch_bounds__(256) mmq_kernel(MmqArgs a) {
   constexpr int LAYOUT = MmqLayout<TYPE>::value;
   constexpr bool OFF = Fmt<TYPE>::HAS_OFFSET;
   const int lane = lane_id(), wave = threadIdx.x >> 6;
-  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
-  if (row >= a.nrows_x) return;  // no workgroup barrier below
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * R;
+  if (row0 >= a.nrows_x) return;  // no workgroup barrier below
   const int64_t col_low = a.expert_bounds ? a.expert_bounds[blockIdx.z] : 0;
   const int64_t col_high = a.expert_bounds ? a.expert_bounds[blockIdx.z + 1] : a.ncols_y;
   const int64_t c0 = col_low + (int64_t)blockIdx.y * NC;
   if (c0 >= col_high) return;
-  const uint8_t *wrow = a.x + ((int64_t)blockIdx.z * a.stride_channel_x + row * a.stride_row_x) * Fmt<TYPE>::TS;
+  const uint8_t *wbase = a.x + (int64_t)blockIdx.z * a.stride_channel_x * Fmt<TYPE>::TS;
   const int nslices = (int)(a.ncols_x / 32);
-  float acc[NC];
+  float acc[R][NC];
 #pragma unroll
-  for (int c = 0; c < NC; ++c) acc[c] = 0.0f;
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[r][c] = 0.0f;
   for (int s = lane; s < nslices; s += 64) {
-    const Slice sl = load_slice<TYPE>(wrow, s);
+    Slice sl[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t row = row0 + r < a.nrows_x ? row0 + r : a.nrows_x - 1;  // clamped: the surplus rows are computed and dropped
+      sl[r] = load_slice<TYPE>(wbase + row * a.stride_row_x * Fmt<TYPE>::TS, s);
+    }
     int ra, rb;
     slice_runs<TYPE>(s, ra, rb);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      const int64_t col = c0 + c < col_high ? c0 + c : col_high - 1;  // clamped: the surplus columns are computed and dropped
+      const int64_t col = c0 + c < col_high ? c0 + c : col_high - 1;  // clamped likewise
       int4 ua, ub;
       float da, db, soa, sob;
       act_run<LAYOUT, OFF>(a.y, a.ncols_y, col, ra, ua, da, soa);
       act_run<LAYOUT, OFF>(a.y, a.ncols_y, col, rb, ub, db, sob);
-      float p = (sl.sa * da) * (float)dot16(sl.qa, ua) + (sl.sb * db) * (float)dot16(sl.qb, ub);
-      if constexpr (OFF) p -= sl.oa * soa + sl.ob * sob;
-      acc[c] += p;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float p = (sl[r].sa * da) * (float)dot16(sl[r].qa, ua) + (sl[r].sb * db) * (float)dot16(sl[r].qb, ub);
+        if constexpr (OFF) p -= sl[r].oa * soa + sl[r].ob * sob;
+        acc[r][c] += p;
+      }
     }
   }
 #pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    const float v = wave_sum(acc[c]);
-    if (lane == 0 && c0 + c < col_high) {
-      const int64_t dcol = a.ids_dst ? a.ids_dst[c0 + c] : c0 + c;
-      ((OUT *)a.dst)[dcol * a.nrows_dst + row] = from_f<OUT>(v);
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const float v = wave_sum(acc[r][c]);
+      if (lane == 0 && row0 + r < a.nrows_x && c0 + c < col_high) {
+        const int64_t dcol = a.ids_dst ? a.ids_dst[c0 + c] : c0 + c;
+        ((OUT *)a.dst)[dcol * a.nrows_dst + row0 + r] = from_f<OUT>(v);
+      }
     }
-  }
 }
 
 template <int TYPE, class OUT> static void launch_mmq_t(const MmqArgs &a, int64_t channels, int64_t ncols_max, void *stream) {
   constexpr int NC = 8;
   if (a.nrows_x <= 0 || ncols_max <= 0 || channels <= 0) return;
-  const dim3 grid((unsigned)((a.nrows_x + 3) / 4), (unsigned)((ncols_max + NC - 1) / NC), (unsigned)channels);
-  hipLaunchKernelGGL((mmq_kernel<TYPE, OUT, NC>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  const unsigned gy = (unsigned)((ncols_max + NC - 1) / NC), gz = (unsigned)channels;
+  // 4 rows per wave once that still leaves >= 2 workgroups per CU (256 CUs); small launches keep one row per wave to fill the chip
+  if (((a.nrows_x + 15) / 16) * (int64_t)gy * gz >= 512) {
+    hipLaunchKernelGGL((mmq_kernel<TYPE, OUT, NC, 4>), dim3((unsigned)((a.nrows_x + 15) / 16), gy, gz), dim3(256), 0, (hipStream_t)stream, a);
+  } else {
+    hipLaunchKernelGGL((mmq_kernel<TYPE, OUT, NC, 1>), dim3((unsigned)((a.nrows_x + 3) / 4), gy, gz), dim3(256), 0, (hipStream_t)stream, a);
+  }
 }
 
 // dense: dst column stride = nrows_x -- the reference's launcher puts nrows_x into mmq_args.nrows_dst and never reads its stride_col_dst

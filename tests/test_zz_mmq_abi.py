@@ -182,6 +182,29 @@ def test_mmq_host_emulation(oracle, tname):
     check_mmq(oracle, HostBackend(), t, "bf16", 5, 256, 3)
 
 
+def check_mmq_row_paths(oracle, be, t, n, k, cols):
+    """Launches with >= 512 (16-row x 8-column) tiles take the 4-rows-per-wave kernel, smaller ones the 1-row kernel (csrc/mmq.hip launch_mmq_t);
+    the per-output arithmetic does not depend on the path: the big launch (ragged against 16 rows) is within budget of the oracle AND its
+    first rows are bit-identical to a small launch over the same weights."""
+    assert ((n + 15) // 16) * ((cols + 7) // 8) >= 512 and n % 16
+    w, y = _mmq_inputs(oracle, t, n, k, cols, seed=t + 1)
+    want, mag = oracle.matmul_q8_1_mmq(t, w, n, k, y)
+    W, Y = be.buf(w), be.buf(y)
+    D, D7 = be.buf(np.full((cols, n), 7.0, np.float32)), be.buf(np.full((cols, 7), 7.0, np.float32))
+    fn = be.sym(f"launch_mmq_gguf_{oracle.TYPE_NAMES[t]}", [P, P, P, P] + [L] * 5 + [I, I, L, I, I, P])
+    fn(None, W.ptr, Y.ptr, D.ptr, k, n, cols, k // oracle.block_size(t), n, 0, 256, 160 << 10, 64, 0, be.stream)
+    fn(None, W.ptr, Y.ptr, D7.ptr, k, 7, cols, k // oracle.block_size(t), 7, 0, 256, 160 << 10, 64, 0, be.stream)
+    got = D.numpy().astype(np.float64)
+    assert (np.abs(got - want) <= _tol(k, mag, want, "f32")).all()
+    assert np.array_equal(D.numpy()[:, :7], D7.numpy())
+
+
+@pytest.mark.parametrize("tname", ["q4_k", "q6_k"])
+def test_mmq_row_paths_host_emulation(oracle, tname):
+    t = {v: k for k, v in oracle.TYPE_NAMES.items()}[tname]
+    check_mmq_row_paths(oracle, HostBackend(), t, 1030, 256, 64)
+
+
 @pytest.mark.parametrize("tname", ["q4_k", "q6_k", "q8_0", "q2_k"])
 def test_mmq_moe_host_emulation(oracle, tname):
     t = {v: k for k, v in oracle.TYPE_NAMES.items()}[tname]
@@ -209,6 +232,14 @@ def test_mmq_abi_gpu(oracle, dev, tname, dt):
     be = GpuBackend(dev)
     check_mmq(oracle, be, t, dt, 7, 512, 11)
     check_mmq(oracle, be, t, dt, 130, 4096, 33)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tname", ["q4_0", "q4_1", "q5_0", "q5_1", "q8_0", "q2_k", "q3_k", "q4_k", "q5_k", "q6_k"])
+def test_mmq_row_paths_abi_gpu(oracle, dev, tname):
+    t = {v: k for k, v in oracle.TYPE_NAMES.items()}[tname]
+    check_mmq_row_paths(oracle, GpuBackend(dev), t, 1030, 512, 64)
+    check_mmq_row_paths(oracle, GpuBackend(dev), t, 4100, 1024, 40)
 
 
 @pytest.mark.gpu
