@@ -14,7 +14,7 @@
 //
 // Numerics are those of the reference CPU path's dataflow (f32 residual stream, f32 norm / RoPE / SiLU,
 // SURVEY 3.4) combined with the reference GPU path's Q8_1 activation quantisation (mmvq_gguf.cu), and are
-// bit-identical to running the unfused C-ABI kernels in sequence (tests/test_ext_decode.py).
+// bit-identical to running the unfused C-ABI kernels in sequence (tests/test_llama_runner.py::test_fused_equals_reference_sequence_and_oracle).
 #include "mmvq_core.cuh"
 #include <stdio.h>
 #include <stdlib.h>

@@ -1,9 +1,9 @@
 """Do parallel branches of a captured HIP graph run concurrently?  Two independent long streaming kernels on forked streams."""
 import ctypes as C, os, subprocess, torch
 here = os.path.dirname(os.path.abspath(__file__))
-so = os.path.join(here, "stream_test.so")
+so = os.path.join(here, "stream_probe.so")
 if not os.path.exists(so):
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", os.path.join(here, "stream_test.hip"), "-o", so])
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", os.path.join(here, "stream_probe.hip"), "-o", so])
 lib = C.CDLL(so)
 lib.stream_launch.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]
 dev = torch.device("cuda:0")

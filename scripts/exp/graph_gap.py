@@ -1,6 +1,6 @@
 import ctypes as C, os, torch
 here = os.path.dirname(os.path.abspath(__file__))
-lib = C.CDLL(os.path.join(here, "stream_test.so"))
+lib = C.CDLL(os.path.join(here, "stream_probe.so"))
 lib.stream_launch.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]
 dev = torch.device("cuda:0")
 sink = torch.zeros(8 + 4096 * 64, dtype=torch.int32, device=dev)

@@ -1,6 +1,6 @@
 import ctypes as C, os, subprocess, sys, torch
 here = os.path.dirname(os.path.abspath(__file__))
-so = os.path.join(here, "stream_test.so")
+so = os.path.join(here, "stream_probe.so")
 lib = C.CDLL(so)
 lib.stream_launch.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]
 dev = torch.device("cuda:0")

@@ -83,7 +83,11 @@ class GpuBackend:
 
     def sym(self, name, argtypes, restype=None):
         from mistralrs_amd import _lib
-        return _lib.sym("quant", name, argtypes, restype)
+        # the launchers live in four libraries (quant / paged_attn / core / ext): resolve the symbol in whichever exports it
+        for key in ("quant", "ext", "paged_attn", "core"):
+            if hasattr(_lib.load(key), name):
+                return _lib.sym(key, name, argtypes, restype)
+        raise AttributeError(f"{name}: exported by none of {list(_lib.NAMES.values())}")
 
     def buf(self, a, dtype=None):
         import torch
