@@ -38,6 +38,25 @@ int mrs_decode_proj_scaled(const void *w, int type, int n, int K, const void *y_
 int mrs_vec_add_f32(float *a, const float *b, size_t n, void *stream); /* a += b */
 int mrs_decode_norm_proj(const void *w, int type, int n, int K, const float *h, const float *norm_w, float eps, float *out,
                          int out_stride, int b, void *stream);
+/* ---------------------------------------------------------------- decode engine (ext_dec.hip, dec_core.cuh)
+ * The batch <= 8 decode step in the arithmetic of the reference CPU path (GgufMatMul::forward_raw -> candle QMatMul with f32
+ * activations, mistralrs-quant/src/gguf/mod.rs:465-478): activations are quantized to Q8_K (K-quants) / Q8_0 (Q8_0 weights) inside
+ * the kernels, integer block dots, f32 combination -- north_star's parity target.  Weights are read from a DECODE LAYOUT made once at
+ * load time from the unmodified GGUF blocks (same bits, row-major planes; Q4_K / Q5_K sub-block scales expanded from 6 to 8 bits). */
+typedef struct { const void *planes; int type; long long n, k; } mrs_dec_mat; /* planes: mrs_dec_repack output for a [n][k] tensor */
+int mrs_dec_supported(int ggml_type);                         /* q4_k q5_k q6_k q8_0 */
+size_t mrs_dec_repack_bytes(int ggml_type, long long n, long long k); /* 0 = unsupported type / shape */
+int mrs_dec_repack(const void *gguf_blocks, int ggml_type, long long n, long long k, void *planes, void *stream);
+/* RmsNorm + q/k/v projections + interleaved RoPE + KV-cache write (kv_dtype: 1 = bf16, 0 = f16 pages); q_out f32 [b][nq] */
+int mrs_dec_qkv(const mrs_dec_mat *wq, const mrs_dec_mat *wk, const mrs_dec_mat *wv, const float *h, int ldh, const float *norm_w, float eps,
+                float *q_out, void *k_cache, void *v_cache, const int64_t *slot_mapping, const int32_t *positions, const float *cos_t,
+                const float *sin_t, int head_dim, int rot_pairs, int num_kv_heads, int block_size, int kv_dtype, int b, void *stream);
+/* RmsNorm + act(W_g x) * (W_u x) -> act_out f32 [b][ld_out]; n = rows per expert, expert_sel = device pointer to the expert id (NULL: dense) */
+int mrs_dec_gate_up(const mrs_dec_mat *wg, const mrs_dec_mat *wu, int n, const int32_t *expert_sel, const float *h, int ldh, const float *norm_w,
+                    float eps, int activation, float *act_out, int ld_out, int b, void *stream);
+/* (RmsNorm when norm_w) + GEMV; mode 0: out = W x; mode 1: out = out * resid_scale + s * W x with s = *acc_scale (NULL: 1) */
+int mrs_dec_proj(const mrs_dec_mat *w, int n, const int32_t *expert_sel, const float *x, int ldx, const float *norm_w, float eps, float *out,
+                 int ld_out, int mode, float resid_scale, const float *acc_scale, int b, void *stream);
 /* quantized (or f32/f16/bf16) embedding rows -> f32; role of QuantMethod::embedding_forward (lib.rs:1561, gguf/mod.rs:436) */
 int mrs_embedding(const void *table, int type, const int32_t *ids, float *out, int K, int tokens, void *stream);
 /* f32 rows -> Q8_1 blocks: same bytes as launch_mmvq_gguf_quantize_q8_1_f32 with kx_padded = 32*stride_blocks */

@@ -1,0 +1,450 @@
+// dec_core.cuh -- MI355X decode engine ("dec"): the GEMV core of the batch<=8 decode step in the arithmetic of the reference CPU path.
+//
+// What the reference does on this path: GgufMatMul::forward_raw -> candle QMatMul::forward with f32 activations
+// (mistralrs-quant/src/gguf/mod.rs:465-478): every activation row is quantized to the vec_dot partner of the weight format -- Q8_K
+// (one f32 scale per 256 values, int8 quants, per-16 sums) for the K-quants, Q8_0 (f16 scale per 32) for Q8_0 -- and every output is
+// sum over blocks of (d_w * d_x) * <integer dot> (- (dmin * d_x) * <integer min term>).  north_star pins THIS arithmetic (logits within
+// 1e-3 of the CPU path, same greedy ids), so the engine computes exactly these integers and combines them in f32; only the f32 summation
+// order over the superblocks of a row differs from a sequential CPU loop (oracle: oracle/ggml_oracle.c dot_kquant_q8K / dot_legacy_q8).
+//
+// MI355X design:
+//   * weights live in a DECODE LAYOUT made once at load time (mrs_dec_repack): per tensor four planes -- quant bytes, extra bits, 8-bit
+//     pre-decoded sub-block scales, f16 super-scales -- each row-major, so a wave's 64 lanes read 64 consecutive 16-byte pieces (1 KiB per
+//     instruction, 16-byte aligned also for Q6_K / Q8_0 whose GGUF blocks are only 2-byte aligned) and no lane decodes 6-bit scales;
+//   * a wave owns whole rows; lane l takes unit t*64+l of a row (unit = 32 weights for Q4_K / Q5_K, 64 for Q6_K, 16 for Q8_0);
+//   * loads are raw buffer loads (one descriptor per tensor): positions past the end of the wave's work or of a ragged row are sent out of
+//     range, return zeros and cost no memory traffic, so the prefetch ring needs no branches (hipcc keeps exact vmcnt waits) and ragged
+//     tails need no masks;
+//   * a ring of DEPTH tiles per wave is in flight before the activation prologue starts and stays full across rows and tensors;
+//   * activations: int8 in LDS in an XOR piece swizzle that is bank-conflict-free for the three access patterns, f32 block scales, int32
+//     per-16 sums; integer dots with v_dot4_i32_i8, integer scale / min combination, two f32 FMAs per unit, DPP wave reduction per row.
+#pragma once
+#include "gguf_blocks.cuh"
+
+#ifndef MRS_WAVE_SYNC
+#define MRS_WAVE_SYNC() __builtin_amdgcn_wave_barrier() /* lanes of a wave exchange through LDS in lockstep; the host emulation maps this to a fiber sync */
+#endif
+
+namespace mrs {
+namespace dec {
+
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+constexpr int NT = 512, NW = NT / 64;
+constexpr unsigned OOB = 0xFFFFFF00u;  // buffer offset that is out of range for every tensor: the load returns zeros
+
+// ------------------------------------------------------------------------------------------------ decode layout
+// Plane offsets (bytes) inside one tensor's repacked buffer.  S = K / 256 superblocks per row.
+//   Q4_K: q  [n][S][128] nibbles as in the GGUF block            hs [n][S][4][sc(2c) sc(2c+1) m(2c) m(2c+1)]   hd [n][S][d dmin] f16
+//   Q5_K: q  as Q4_K; x [n][S][8 slices][u32 hi-bits, see repack] hs, hd as Q4_K
+//   Q6_K: q  [n][S][128] = ql; x [n][S][4 units][16 B 2-bit fields]; hs [n][S][4 units][4 x int8 scale]; hd [n][S] f16 d
+//   Q8_0: q  [n][K] int8;                                         hd [n][K/32] f16 d
+struct Planes { size_t q, x, hs, hd, total; };
+__host__ __device__ inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+__host__ __device__ inline Planes plane_layout(int type, long long n, long long k) {
+  Planes p{};
+  const size_t S = (size_t)(k / 256), N = (size_t)n;
+  size_t o = 0;
+  switch (type) {
+  case T_Q4_K: o = align256(N * S * 128); p.hs = o; o += align256(N * S * 16); p.hd = o; o += align256(N * S * 4); break;
+  case T_Q5_K: o = align256(N * S * 128); p.x = o; o += align256(N * S * 32); p.hs = o; o += align256(N * S * 16); p.hd = o; o += align256(N * S * 4); break;
+  case T_Q6_K: o = align256(N * S * 128); p.x = o; o += align256(N * S * 64); p.hs = o; o += align256(N * S * 16); p.hd = o; o += align256(N * S * 2); break;
+  case T_Q8_0: o = align256(N * (size_t)k); p.hd = o; o += align256(N * (size_t)(k / 32) * 2); break;
+  default: break;
+  }
+  p.total = o;
+  return p;
+}
+__host__ __device__ inline bool dec_type(int t) { return t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_Q8_0; }
+
+// one tensor in decode layout, as the kernels see it
+struct Mat {
+  const uint8_t *base;
+  unsigned off_x, off_hs, off_hd, bytes;  // the q plane starts at 0
+  int type, n, k;
+};
+
+// ------------------------------------------------------------------------------------------------ activations in LDS
+// per column:  q [K] int8 (16-byte pieces, piece p of superblock sb stored at p ^ m(sb));  d [K/32] f32 (Q8_K mode: entry sb = d of the
+// superblock; Q8_0 mode: entry b = f32(f16(d)) of block b);  bs [K/16] int32 sums of each 16-run (Q8_K mode)
+// m(sb) = (sb & 1) * 3 | ((sb >> 1) & 1) * 4: the 16 lanes of one ds_read_b128 group then touch 16 different 16-byte bank groups for
+//   Q4_K / Q5_K (lane -> run sb*16 + 4c + hp [+2]),  Q6_K (lane -> runs sb*16 + 8h + 2j [+1, +4, +5])  and  Q8_0 (lane -> piece).
+enum : int { ACT_Q8K = 0, ACT_Q80 = 1 };
+__host__ __device__ inline int act_mode_for(int type) { return type == T_Q8_0 ? ACT_Q80 : ACT_Q8K; }
+__host__ __device__ inline size_t act_bytes(int K, int ncols) { return (size_t)ncols * ((size_t)K + (size_t)(K / 32) * 4 + (size_t)(K / 16) * 4); }
+struct Act {
+  const char *q;    // [ncols][K]
+  const float *d;   // [ncols][K/32]
+  const int *bs;    // [ncols][K/16]
+  int K;
+};
+__device__ __forceinline__ int sb_mask(int sb) { return (sb & 1) * 3 | ((sb >> 1) & 1) * 4; }
+__device__ __forceinline__ int swz_piece(int p) { return p ^ sb_mask(p >> 4); }
+
+template <int CTRL> __device__ __forceinline__ float dppf(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL> __device__ __forceinline__ int dppi(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+
+// f32 activations [NCOLS][ldx] (optionally RMSNorm(x) * w first: RmsNorm::forward, mistralrs-core/src/layers.rs:403-414) -> the LDS image
+// above.  Quantizers: candle BlockQ8K::from_float (amax with its sign, iscale = -128 / max, q = min(127, round(iscale * x)), d = 1 / iscale,
+// first maximum wins) and quantize_row_q8_0 (d = amax / 127, q = round(x / d), d kept as f16) -- restated in oracle/ggml_oracle.c
+// orc_quantize_q8_K / quantize_legacy.
+// Two steps so that the activation loads sit IN FRONT of the weight ring in the wave's (in-order) load queue: act_issue() puts the first
+// column's values (and the norm weights) into registers with buffer loads -- thread t takes the float4 at t*4 + j*2048, i.e. wave w owns the
+// 256-blocks w, w+8, ... -- then the caller fills the ring, then act_finish() normalises / quantizes while the weights are in flight.
+// Rows longer than 16384 values (or 8192 with a norm) take the remaining pieces after the ring (correct, just later).
+constexpr int ACT_MAXV = 8, ACT_MAXW = 4;
+struct ActPre { v4u xv[ACT_MAXV]; v4u wv[ACT_MAXW]; };
+__device__ __forceinline__ float4 as_f4(v4u v) { return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)); }
+
+// SC1: loads at agent scope (bypass the CU's L1) -- the persistent step kernel reads vectors that other CUs wrote a moment ago
+template <bool SC1> __device__ __forceinline__ v4u ld_act(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  if constexpr (SC1) return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16);
+  else return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+}
+template <bool SC1> __device__ __forceinline__ ActPre act_issue(const float *x, const float *nw, int K) {
+  ActPre p;
+  const unsigned off = threadIdx.x * 16u;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)x, (short)0, K * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)(nw ? nw : x), (short)0, nw ? K * 4 : 0, 0x00020000);
+#pragma unroll
+  for (int j = 0; j < ACT_MAXV; ++j) p.xv[j] = ld_act<SC1>(rx, off + (unsigned)j * 8192u);  // beyond K: out of range, zeros, no traffic
+#pragma unroll
+  for (int j = 0; j < ACT_MAXW; ++j) p.wv[j] = ld_act<false>(rw, off + (unsigned)j * 8192u);
+  return p;
+}
+
+__device__ __forceinline__ float wave_max_all(float v) {
+  v = fmaxf(v, dppf<0xB1>(v)); v = fmaxf(v, dppf<0x4E>(v)); v = fmaxf(v, dppf<0x141>(v)); v = fmaxf(v, dppf<0x140>(v));
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+__device__ __forceinline__ int wave_min_all(int v) {
+  v = min(v, dppi<0xB1>(v)); v = min(v, dppi<0x4E>(v)); v = min(v, dppi<0x141>(v)); v = min(v, dppi<0x140>(v));
+  return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+// sum over the wave, every lane gets it (DPP inside rows of 16, readlane across)
+__device__ __forceinline__ float wave_sum_all(float v) {
+  v += dppf<0xB1>(v);
+  v += dppf<0x4E>(v);
+  v += dppf<0x141>(v);
+  v += dppf<0x140>(v);
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return (r0 + r1) + (r2 + r3);
+}
+
+
+// quantize the 4 values a lane holds at element e (all lanes of the wave together: one 256-block in Q8_K mode, 8 blocks of 32 in Q8_0 mode)
+__device__ __forceinline__ void quantize4(float4 v, int e, bool in, int mode, char *qc, float *dc, int *bsc) {
+  const int lane = lane_id();
+  if (mode == ACT_Q8K) {
+    const float ax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    const float amax = wave_max_all(ax);
+    const int cand = fabsf(v.x) == amax ? 0 : (fabsf(v.y) == amax ? 1 : (fabsf(v.z) == amax ? 2 : (fabsf(v.w) == amax ? 3 : 1 << 20)));
+    const int first = wave_min_all(lane * 4 + cand);  // first element of the block with |x| == amax (candle keeps the first maximum)
+    const int sl = (first >> 2) & 63, comp = first & 3;
+    const float mx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, comp == 0 ? v.x : (comp == 1 ? v.y : (comp == 2 ? v.z : v.w))), sl));
+    int q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+    float dd = 0.f;
+    if (amax != 0.f) {
+      const float iscale = -128.f / mx;
+      q0 = (int)fminf(127.f, roundf(iscale * v.x)); q1 = (int)fminf(127.f, roundf(iscale * v.y));
+      q2 = (int)fminf(127.f, roundf(iscale * v.z)); q3 = (int)fminf(127.f, roundf(iscale * v.w));
+      dd = 1.0f / iscale;
+    }
+    int s = (q0 + q1) + (q2 + q3);
+    s += dppi<0xB1>(s);
+    s += dppi<0x4E>(s);  // 4 lanes = one 16-run
+    if (in) {
+      const int piece = e >> 4;
+      *(int *)(qc + (size_t)swz_piece(piece) * 16 + (e & 15)) = (q0 & 0xff) | ((q1 & 0xff) << 8) | ((q2 & 0xff) << 16) | ((q3 & 0xff) << 24);
+      if ((lane & 3) == 0) bsc[piece] = s;
+      if (lane == 0) dc[e >> 8] = dd;
+    }
+  } else {
+    float amax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    amax = fmaxf(amax, dppf<0xB1>(amax));
+    amax = fmaxf(amax, dppf<0x4E>(amax));
+    amax = fmaxf(amax, dppf<0x141>(amax));  // 8 lanes = one 32-block
+    const float dq = amax / 127.0f, id = dq != 0.f ? 1.0f / dq : 0.0f;
+    const int q0 = (int)roundf(v.x * id), q1 = (int)roundf(v.y * id), q2 = (int)roundf(v.z * id), q3 = (int)roundf(v.w * id);
+    if (in) {
+      *(int *)(qc + (size_t)swz_piece(e >> 4) * 16 + (e & 15)) = (q0 & 0xff) | ((q1 & 0xff) << 8) | ((q2 & 0xff) << 16) | ((q3 & 0xff) << 24);
+      if ((e & 31) == 0) dc[e >> 5] = half_bits_to_float(float_to_half_bits(dq));
+    }
+  }
+}
+
+// Whole workgroup, ends with a barrier.  `red` = 8 floats of LDS scratch.  pre = act_issue() of column 0.
+template <int NCOLS, bool SC1>
+__device__ __forceinline__ Act act_finish(char *smem, float *red, const ActPre &pre, const float *__restrict__ x, int ldx, const float *__restrict__ nw, float eps,
+                                          int K, int mode) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char *q = smem;
+  float *d = (float *)(smem + (size_t)NCOLS * K);
+  int *bs = (int *)(d + (size_t)NCOLS * (K / 32));
+  const int nv = (K + 2047) >> 11;  // float4 pieces per thread
+#pragma unroll 1
+  for (int c = 0; c < NCOLS; ++c) {
+    const float *xr = x + (size_t)c * ldx;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)xr, (short)0, K * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)(nw ? nw : xr), (short)0, nw ? K * 4 : 0, 0x00020000);
+    // pieces j < ACT_MAXV (ACT_MAXW) of column 0 come from the registers act_issue() filled: static indices only
+    auto xload = [&](int j) -> float4 { return as_f4(ld_act<SC1>(rx, (unsigned)tid * 16u + (unsigned)j * 8192u)); };
+    auto wload = [&](int j) -> float4 { return as_f4(ld_act<false>(rw, (unsigned)tid * 16u + (unsigned)j * 8192u)); };
+    float inv = 1.0f;
+    if (nw) {  // sum of squares: per-thread partials in element order, DPP wave sums, the 8 wave sums in wave order
+      float ss = 0.f;
+      auto sq = [&](float4 v4) { ss = fmaf(v4.x, v4.x, ss); ss = fmaf(v4.y, v4.y, ss); ss = fmaf(v4.z, v4.z, ss); ss = fmaf(v4.w, v4.w, ss); };
+#pragma unroll
+      for (int j = 0; j < ACT_MAXV; ++j) if (j < nv) sq(c == 0 ? as_f4(pre.xv[j]) : xload(j));
+      for (int j = ACT_MAXV; j < nv; ++j) sq(xload(j));
+      ss = wave_sum_all(ss);
+      if (lane == 0) red[wave] = ss;
+      __syncthreads();
+      inv = 1.0f / sqrtf((((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]))) / (float)K + eps);
+      __syncthreads();  // red is reused by the next column
+    }
+    char *qc = q + (size_t)c * K;
+    float *dc = d + (size_t)c * (K / 32);
+    int *bsc = bs + (size_t)c * (K / 16);
+    auto one = [&](int j, float4 v, float4 w4) {  // uniform trip count: every lane takes part in the cross-lane steps
+      const int e = tid * 4 + j * 2048;
+      if (nw) { v.x = v.x * inv * w4.x; v.y = v.y * inv * w4.y; v.z = v.z * inv * w4.z; v.w = v.w * inv * w4.w; }
+      quantize4(v, e, e < K, mode, qc, dc, bsc);
+    };
+#pragma unroll
+    for (int j = 0; j < ACT_MAXV; ++j)
+      if (j < nv) one(j, c == 0 ? as_f4(pre.xv[j]) : xload(j), j < ACT_MAXW ? as_f4(pre.wv[j < ACT_MAXW ? j : 0]) : (nw ? wload(j) : make_float4(1.f, 1.f, 1.f, 1.f)));
+    for (int j = ACT_MAXV; j < nv; ++j) one(j, xload(j), nw ? wload(j) : make_float4(1.f, 1.f, 1.f, 1.f));
+  }
+  __syncthreads();
+  return Act{q, d, bs, K};
+}
+
+// ------------------------------------------------------------------------------------------------ per-format tiles
+// A tile = what the 64 lanes of a wave take from one row in one step.  Raw = the registers a lane holds for it (filled by buffer loads);
+// LaneC = lane constants (LDS offsets for tile 0 of a row); accumulate() adds the lane's share of <row, activation column> to acc[].
+__device__ __forceinline__ v4u ldb128(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 2); }  // aux 2 = nt: weights are read once per token
+__device__ __forceinline__ unsigned ldb32(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0); }
+__device__ __forceinline__ unsigned ldb16(__amdgpu_buffer_rsrc_t r, unsigned off) { return (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0); }
+__device__ __forceinline__ int dot16u(v4u q, int4 u) { return dot4((int)q.w, u.w, dot4((int)q.z, u.z, dot4((int)q.y, u.y, dot4((int)q.x, u.x, 0)))); }
+__device__ __forceinline__ int mul24i(int a, int b) { return __mul24(a, b); }
+
+template <int TYPE> struct Tile;
+
+template <> struct Tile<T_Q4_K> {
+  static constexpr int DEPTH = 8, UNIT = 32;
+  struct Raw { v4u q; unsigned hs, hd; };
+  struct LaneC { int pa, pb, ra, sbl; };
+  static __device__ __forceinline__ LaneC lanec(int lane) {
+    const int sbl = lane >> 3, c = (lane >> 1) & 3, hp = lane & 1, m = sb_mask(sbl), r = 4 * c + hp;
+    return LaneC{(sbl * 16 + (r ^ m)) * 16, (sbl * 16 + ((r + 2) ^ m)) * 16, sbl * 16 + r, sbl};
+  }
+  // unit index u = t*64 + lane of row `row` (S superblocks per row); off = OOB when the unit does not exist
+  static __device__ __forceinline__ Raw load(__amdgpu_buffer_rsrc_t rs, const Mat &m, unsigned row, int u, int S, bool ok) {
+    const unsigned sbg = row * (unsigned)S + (unsigned)(u >> 3);
+    Raw r;
+    r.q = ldb128(rs, ok ? (row * (unsigned)S * 8u + (unsigned)u) * 16u : OOB);
+    r.hs = ldb32(rs, ok ? m.off_hs + sbg * 16u + (unsigned)((u >> 1) & 3) * 4u : OOB);
+    r.hd = ldb32(rs, ok ? m.off_hd + sbg * 4u : OOB);
+    return r;
+  }
+  template <int NCOLS> static __device__ __forceinline__ void accumulate(const Raw &w, const LaneC &lc, int t, int S, const Act &act, float (&acc)[NCOLS]) {
+    const v4u lo = w.q & 0x0F0F0F0Fu, hi = (w.q >> 4) & 0x0F0F0F0Fu;
+    const int sca = (int)(w.hs & 0xff), scb = (int)((w.hs >> 8) & 0xff), ma = (int)((w.hs >> 16) & 0xff), mb = (int)(w.hs >> 24);
+    const float d = half_bits_to_float((uint16_t)(w.hd & 0xffff)), dmin = half_bits_to_float((uint16_t)(w.hd >> 16));
+    const int K = act.K;
+    const int sb = min(t * 8 + lc.sbl, S - 1);  // lanes without a unit hold zeros; keep their scale read inside the row
+#pragma unroll
+    for (int c = 0; c < NCOLS; ++c) {
+      const char *qc = act.q + (size_t)c * K + t * 2048;
+      const int4 ua = *(const int4 *)(qc + lc.pa), ub = *(const int4 *)(qc + lc.pb);
+      const int *bsc = act.bs + (size_t)c * (K / 16) + t * 128 + lc.ra;
+      const int isum = mul24i(scb, dot16u(hi, ub)) + mul24i(sca, dot16u(lo, ua));
+      const int msum = mul24i(mb, bsc[2]) + mul24i(ma, bsc[0]);
+      const float yd = act.d[(size_t)c * (K / 32) + sb];
+      acc[c] = fmaf(d * yd, (float)isum, acc[c]);
+      acc[c] = fmaf(-(dmin * yd), (float)msum, acc[c]);
+    }
+  }
+};
+
+template <> struct Tile<T_Q5_K> {
+  static constexpr int DEPTH = 8, UNIT = 32;
+  struct Raw { v4u q; unsigned xh, hs, hd; };
+  using LaneC = Tile<T_Q4_K>::LaneC;
+  static __device__ __forceinline__ LaneC lanec(int lane) { return Tile<T_Q4_K>::lanec(lane); }
+  static __device__ __forceinline__ Raw load(__amdgpu_buffer_rsrc_t rs, const Mat &m, unsigned row, int u, int S, bool ok) {
+    const unsigned sbg = row * (unsigned)S + (unsigned)(u >> 3), ug = row * (unsigned)S * 8u + (unsigned)u;
+    Raw r;
+    r.q = ldb128(rs, ok ? ug * 16u : OOB);
+    r.xh = ldb32(rs, ok ? m.off_x + ug * 4u : OOB);
+    r.hs = ldb32(rs, ok ? m.off_hs + sbg * 16u + (unsigned)((u >> 1) & 3) * 4u : OOB);
+    r.hd = ldb32(rs, ok ? m.off_hd + sbg * 4u : OOB);
+    return r;
+  }
+  template <int NCOLS> static __device__ __forceinline__ void accumulate(const Raw &w, const LaneC &lc, int t, int S, const Act &act, float (&acc)[NCOLS]) {
+    // xh bit 8j+k = fifth bit of low-nibble weight 4k+j, bit 8j+4+k = of high-nibble weight 4k+j (k = dword, j = byte)
+    v4u lo = w.q & 0x0F0F0F0Fu, hi = (w.q >> 4) & 0x0F0F0F0Fu;
+    lo.x |= (w.xh & 0x01010101u) << 4; lo.y |= ((w.xh >> 1) & 0x01010101u) << 4; lo.z |= ((w.xh >> 2) & 0x01010101u) << 4; lo.w |= ((w.xh >> 3) & 0x01010101u) << 4;
+    hi.x |= ((w.xh >> 4) & 0x01010101u) << 4; hi.y |= ((w.xh >> 5) & 0x01010101u) << 4; hi.z |= ((w.xh >> 6) & 0x01010101u) << 4; hi.w |= ((w.xh >> 7) & 0x01010101u) << 4;
+    const int sca = (int)(w.hs & 0xff), scb = (int)((w.hs >> 8) & 0xff), ma = (int)((w.hs >> 16) & 0xff), mb = (int)(w.hs >> 24);
+    const float d = half_bits_to_float((uint16_t)(w.hd & 0xffff)), dmin = half_bits_to_float((uint16_t)(w.hd >> 16));
+    const int K = act.K;
+    const int sb = min(t * 8 + lc.sbl, S - 1);
+#pragma unroll
+    for (int c = 0; c < NCOLS; ++c) {
+      const char *qc = act.q + (size_t)c * K + t * 2048;
+      const int4 ua = *(const int4 *)(qc + lc.pa), ub = *(const int4 *)(qc + lc.pb);
+      const int *bsc = act.bs + (size_t)c * (K / 16) + t * 128 + lc.ra;
+      const int isum = mul24i(scb, dot16u(hi, ub)) + mul24i(sca, dot16u(lo, ua));
+      const int msum = mul24i(mb, bsc[2]) + mul24i(ma, bsc[0]);
+      const float yd = act.d[(size_t)c * (K / 32) + sb];
+      acc[c] = fmaf(d * yd, (float)isum, acc[c]);
+      acc[c] = fmaf(-(dmin * yd), (float)msum, acc[c]);
+    }
+  }
+};
+
+template <> struct Tile<T_Q6_K> {
+  static constexpr int DEPTH = 4, UNIT = 64;
+  struct Raw { v4u l0, l1, x; unsigned hs, hd; };
+  struct LaneC { int pa0, pa1, pb0, pb1, ra, sbl; };
+  static __device__ __forceinline__ LaneC lanec(int lane) {
+    const int sbl = lane >> 2, u = lane & 3, h = u >> 1, j = u & 1, m = sb_mask(sbl), r = 8 * h + 2 * j;
+    return LaneC{(sbl * 16 + (r ^ m)) * 16, (sbl * 16 + ((r + 1) ^ m)) * 16, (sbl * 16 + ((r + 4) ^ m)) * 16, (sbl * 16 + ((r + 5) ^ m)) * 16, sbl * 16 + r, sbl};
+  }
+  static __device__ __forceinline__ Raw load(__amdgpu_buffer_rsrc_t rs, const Mat &m, unsigned row, int u, int S, bool ok) {
+    const unsigned sbg = row * (unsigned)S + (unsigned)(u >> 2), ug = row * (unsigned)S * 4u + (unsigned)u;
+    Raw r;
+    r.l0 = ldb128(rs, ok ? ug * 32u : OOB);
+    r.l1 = ldb128(rs, ok ? ug * 32u + 16u : OOB);
+    r.x = ldb128(rs, ok ? m.off_x + ug * 16u : OOB);
+    r.hs = ldb32(rs, ok ? m.off_hs + sbg * 16u + (unsigned)(u & 3) * 4u : OOB);
+    r.hd = ldb16(rs, ok ? m.off_hd + sbg * 2u : OOB);
+    return r;
+  }
+  template <int NCOLS> static __device__ __forceinline__ void accumulate(const Raw &w, const LaneC &lc, int t, int S, const Act &act, float (&acc)[NCOLS]) {
+    // x byte b: bits 1:0 -> weight b (A0), 3:2 -> 16+b (A1), 5:4 -> 32+b (B0), 7:6 -> 48+b (B1) of the unit; low nibbles of l0/l1 = A, high = B
+    const v4u a0 = (w.l0 & 0x0F0F0F0Fu) | ((w.x << 4) & 0x30303030u);
+    const v4u a1 = (w.l1 & 0x0F0F0F0Fu) | ((w.x << 2) & 0x30303030u);
+    const v4u b0 = ((w.l0 >> 4) & 0x0F0F0F0Fu) | (w.x & 0x30303030u);
+    const v4u b1 = ((w.l1 >> 4) & 0x0F0F0F0Fu) | ((w.x >> 2) & 0x30303030u);
+    const int s0 = (int)(int8_t)(w.hs & 0xff), s1 = (int)(int8_t)((w.hs >> 8) & 0xff), s2 = (int)(int8_t)((w.hs >> 16) & 0xff), s3 = (int)(int8_t)(w.hs >> 24);
+    const float d = half_bits_to_float((uint16_t)w.hd);
+    const int K = act.K;
+    const int sb = min(t * 16 + lc.sbl, S - 1);
+#pragma unroll
+    for (int c = 0; c < NCOLS; ++c) {
+      const char *qc = act.q + (size_t)c * K + t * 4096;
+      const int4 u0 = *(const int4 *)(qc + lc.pa0), u1 = *(const int4 *)(qc + lc.pa1), u2 = *(const int4 *)(qc + lc.pb0), u3 = *(const int4 *)(qc + lc.pb1);
+      const int *bsc = act.bs + (size_t)c * (K / 16) + t * 256 + lc.ra;
+      // sum sc * <q - 32, u> = sum sc * (<q, u> - 32 * sum u), all integer
+      int isum = mul24i(s0, dot16u(a0, u0)) + mul24i(s1, dot16u(a1, u1));
+      isum += mul24i(s2, dot16u(b0, u2)) + mul24i(s3, dot16u(b1, u3));
+      const int osum = (mul24i(s0, bsc[0]) + mul24i(s1, bsc[1])) + (mul24i(s2, bsc[4]) + mul24i(s3, bsc[5]));
+      const float yd = act.d[(size_t)c * (K / 32) + sb];
+      acc[c] = fmaf(d * yd, (float)(isum - 32 * osum), acc[c]);
+    }
+  }
+};
+
+template <> struct Tile<T_Q8_0> {
+  static constexpr int DEPTH = 8, UNIT = 16;
+  struct Raw { v4u q; unsigned hd; };
+  struct LaneC { int pa, odd; };
+  static __device__ __forceinline__ LaneC lanec(int lane) { return LaneC{(lane ^ sb_mask(lane >> 4)) * 16, lane & 1}; }
+  static __device__ __forceinline__ Raw load(__amdgpu_buffer_rsrc_t rs, const Mat &m, unsigned row, int u, int S /* = K/16 units per row */, bool ok) {
+    Raw r;
+    r.q = ldb128(rs, ok ? (row * (unsigned)S + (unsigned)u) * 16u : OOB);
+    r.hd = ldb16(rs, ok ? m.off_hd + (row * (unsigned)(S >> 1) + (unsigned)(u >> 1)) * 2u : OOB);
+    return r;
+  }
+  template <int NCOLS> static __device__ __forceinline__ void accumulate(const Raw &w, const LaneC &lc, int t, int S, const Act &act, float (&acc)[NCOLS]) {
+    const float dw = half_bits_to_float((uint16_t)w.hd);
+    const int K = act.K;
+    const int blk = min(t * 32 + (lane_id() >> 1), (S >> 1) - 1);
+#pragma unroll
+    for (int c = 0; c < NCOLS; ++c) {
+      const int4 u = *(const int4 *)(act.q + (size_t)c * K + t * 1024 + lc.pa);
+      int isum = dot16u(w.q, u);
+      isum += dppi<0xB1>(isum);  // the two halves of the 32-block sit on lanes 2b, 2b+1: block dot in integers, as vec_dot_q8_0_q8_0
+      const float dx = act.d[(size_t)c * (K / 32) + blk];
+      const float p = (float)isum * dw * dx;
+      acc[c] += lc.odd ? 0.0f : p;
+    }
+  }
+};
+
+template <int TYPE> __host__ __device__ constexpr int unit_weights() { return TYPE == T_Q6_K ? 64 : TYPE == T_Q8_0 ? 16 : 32; }
+// "S" argument of Tile::load / accumulate: superblocks per row for the K-quants, 16-weight units per row for Q8_0
+template <int TYPE> __host__ __device__ inline int row_param(int K) { return TYPE == T_Q8_0 ? K / 16 : K / 256; }
+
+// ------------------------------------------------------------------------------------------------ the streaming core
+// One wave streams up to two row segments of the SAME format: segment i = rows [row0[i], row0[i] + nrows[i]) of tensor mat[i].
+// The ring is filled before `pro()` (the activation prologue, which contains the workgroup barriers and, in the persistent step kernel, the
+// wait for the producer phase) and never drains across rows or segments.  epi(seg, row, acc) is called once per finished row with
+// wave-uniform sums.
+struct Segs {
+  Mat mat[2];
+  int row0[2], nrows[2];
+  int nseg;
+};
+
+template <int TYPE, int NCOLS, class Pre, class Pro, class Epi>
+__device__ __forceinline__ void stream(const Segs &sg, int K, Pre pre, Pro pro, Epi epi) {
+  using TL = Tile<TYPE>;
+  constexpr int D = TL::DEPTH;
+  const int lane = lane_id();
+  const int upr = K / unit_weights<TYPE>();  // units per row
+  const int tpr = (upr + 63) >> 6;            // tiles per row
+  const int S = row_param<TYPE>(K);
+  const int rows0 = sg.nrows[0], rows1 = sg.nseg > 1 ? sg.nrows[1] : 0;
+  const int total = (rows0 + rows1) * tpr;
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void *)sg.mat[0].base, (short)0, (int)sg.mat[0].bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void *)sg.mat[sg.nseg > 1 ? 1 : 0].base, (short)0, (int)sg.mat[sg.nseg > 1 ? 1 : 0].bytes, 0x00020000);
+  typename TL::Raw ring[D];
+  int lr = 0, lt = 0, lseg = 0;  // loader cursor: row inside the segment, tile inside the row, segment
+  auto issue = [&](typename TL::Raw &slot) {
+    const bool live = lseg == 0 ? lr < rows0 : (lseg == 1 && lr < rows1);
+    const int u = lt * 64 + lane;
+    const bool ok = live && u < upr;
+    const unsigned row = (unsigned)((lseg == 0 ? sg.row0[0] : sg.row0[1]) + lr);
+    slot = lseg == 0 ? TL::load(rs0, sg.mat[0], row, u, S, ok) : TL::load(rs1, sg.mat[1], row, u, S, ok);
+    if (++lt == tpr) { lt = 0; if (++lr == (lseg == 0 ? rows0 : rows1) && lseg == 0 && rows1 > 0) { lr = 0; lseg = 1; } }
+  };
+  const auto pr = pre();  // activation loads first: they are small and must not wait behind the ring in the in-order return queue
+#pragma unroll
+  for (int i = 0; i < D; ++i) issue(ring[i]);
+  const Act act = pro(pr);
+  const typename TL::LaneC lc = TL::lanec(lane);
+  float acc[NCOLS];
+#pragma unroll
+  for (int c = 0; c < NCOLS; ++c) acc[c] = 0.0f;
+  int cr = 0, ct = 0, cseg = 0;
+  for (int g = 0; g < total; g += D) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      if (g + i < total) {  // wave-uniform
+        TL::template accumulate<NCOLS>(ring[i], lc, ct, S, act, acc);
+        if (++ct == tpr) {
+          float sum[NCOLS];
+#pragma unroll
+          for (int c = 0; c < NCOLS; ++c) { sum[c] = wave_sum_all(acc[c]); acc[c] = 0.0f; }
+          epi(cseg, (cseg == 0 ? sg.row0[0] : sg.row0[1]) + cr, sum);
+          ct = 0;
+          if (++cr == (cseg == 0 ? rows0 : rows1) && cseg == 0) { cr = 0; cseg = 1; }
+        }
+      }
+      issue(ring[i]);
+    }
+  }
+}
+
+}  // namespace dec
+}  // namespace mrs

@@ -1,0 +1,346 @@
+// ext_dec.hip -- MI355X decode engine: the GEMV phases of a decode step on the core of dec_core.cuh, the decode-layout repack, and the
+// C entry points (include/mrs_hip_ext.h, mrs_dec_*).
+//
+// A decode step of one Llama layer is five phases (reference call sequence: mistralrs-core/src/models/llama.rs:68-157, 243-260):
+//   qkv      RMSNorm(h) -> Q8_K/Q8_0 activations in LDS -> q, k, v GEMV rows -> RoPE -> q (f32), k / v into the paged cache
+//   attn     decode attention over the cache (paged_attention.cuh) -> f32
+//   o_proj   quantize(attn) -> GEMV -> h = h * s + W_o . attn
+//   gate/up  RMSNorm(h) -> quantize -> gate and up rows -> act(gate) * up (f32)
+//   down     quantize(act) -> GEMV -> h = h * s + W_d . act
+// Every phase is the same kernel body: fill the weight ring, run the activation prologue (norm + quantize: ONE pass over <= 57 KB of f32),
+// stream the wave's rows, apply the phase's epilogue per finished row.  Arithmetic: header of dec_core.cuh.
+#include "dec_core.cuh"
+#include <stdio.h>
+#include <stdlib.h>
+
+namespace mrs {
+namespace dec {
+
+enum : int { EPI_STORE = 0, EPI_RESID = 1, EPI_GLU = 2, EPI_QKV = 3 };
+
+struct GemvArgs {
+  Mat m[3];
+  int nrows[3];  // logical rows of the phase per tensor (== m[i].n except for stacked experts)
+  int K;
+  const float *x; int ldx; const float *norm_w; float eps;
+  float *out; int out_stride; float resid_scale;
+  int activation;
+  float *q_out; void *k_cache, *v_cache; const int64_t *slot_mapping; const int32_t *positions; const float *cos_t, *sin_t;
+  int head_dim, rot_pairs, num_kv_heads, block_size, cache_x, kv_f16;
+  int units, units_per_wave;
+  int wstart[4];  // EPI_QKV: first wave of q, k, v and the total
+  const int32_t *expert_sel;  // stacked experts [E * nrows][K]: rows of expert e start at e * nrows (nullptr = dense)
+  const float *acc_scale;     // RESID: out = out * resid_scale + (*acc_scale) * W.x  (routing weight)
+};
+
+#define MRS_DEC_TYPE_SWITCH(t, ...)                              \
+  switch (t) {                                                   \
+  case T_Q4_K: { constexpr int TT = T_Q4_K; __VA_ARGS__ } break; \
+  case T_Q5_K: { constexpr int TT = T_Q5_K; __VA_ARGS__ } break; \
+  case T_Q6_K: { constexpr int TT = T_Q6_K; __VA_ARGS__ } break; \
+  case T_Q8_0: { constexpr int TT = T_Q8_0; __VA_ARGS__ } break; \
+  default: break;                                                \
+  }
+
+__device__ __forceinline__ float rl(float v, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane)); }
+
+template <int NCOLS, int EPI>
+__device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float *red) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // readfirstlane: lets hipcc keep everything derived from the wave index in SGPRs
+  const int gw = blockIdx.x * NW + wave;
+  const int K = a.K;
+  // the activation image is staged once per workgroup
+  auto pre = [&]() -> ActPre { return act_issue<false>(a.x, a.norm_w, K); };
+  auto pro = [&](const ActPre &p) -> Act { return act_finish<NCOLS, false>(smem, red, p, a.x, a.ldx, a.norm_w, a.eps, K, act_mode_for(a.m[0].type)); };
+  const int u0 = min(gw * a.units_per_wave, a.units), u1 = min(u0 + a.units_per_wave, a.units);
+  const int eoff = a.expert_sel ? *a.expert_sel * a.nrows[0] : 0;
+
+  if constexpr (EPI == EPI_STORE || EPI == EPI_RESID) {
+    Segs sg{};
+    sg.nseg = 1; sg.mat[0] = a.m[0]; sg.row0[0] = eoff + u0; sg.nrows[0] = u1 - u0;
+    const float ascale = a.acc_scale ? *a.acc_scale : 1.0f;
+    float hold[NCOLS];
+#pragma unroll
+    for (int c = 0; c < NCOLS; ++c) hold[c] = 0.0f;
+    if constexpr (EPI == EPI_RESID) {  // residual values up front (lane i <-> the wave's row i): no dependent load between a row's sum and its store
+      if (lane < u1 - u0) {
+#pragma unroll
+        for (int c = 0; c < NCOLS; ++c) hold[c] = a.out[(size_t)c * a.out_stride + u0 + lane];
+      }
+    }
+    auto epi = [&](int, int row, const float(&sum)[NCOLS]) {
+      const int r = row - eoff;
+#pragma unroll
+      for (int c = 0; c < NCOLS; ++c) {
+        float *o = a.out + (size_t)c * a.out_stride + r;
+        if constexpr (EPI == EPI_RESID) {
+          const float old = rl(hold[c], r - u0);
+          if (lane == 0) *o = old * a.resid_scale + sum[c] * ascale;
+        } else {
+          if (lane == 0) *o = sum[c];
+        }
+      }
+    };
+    MRS_DEC_TYPE_SWITCH(a.m[0].type, (stream<TT, NCOLS>(sg, K, pre, pro, epi));)
+  } else if constexpr (EPI == EPI_GLU) {
+    Segs sg{};
+    sg.nseg = 2; sg.mat[0] = a.m[0]; sg.mat[1] = a.m[1];
+    sg.row0[0] = sg.row0[1] = eoff + u0; sg.nrows[0] = sg.nrows[1] = u1 - u0;
+    float gsave[NCOLS];  // lane i keeps gate row i of the wave until the matching up row arrives
+#pragma unroll
+    for (int c = 0; c < NCOLS; ++c) gsave[c] = 0.0f;
+    auto epi = [&](int seg, int row, const float(&sum)[NCOLS]) {
+      const int i = row - eoff - u0;
+#pragma unroll
+      for (int c = 0; c < NCOLS; ++c) {
+        if (seg == 0) {
+          gsave[c] = lane == i ? sum[c] : gsave[c];
+        } else {
+          const float g = rl(gsave[c], i);
+          if (lane == 0) a.out[(size_t)c * a.out_stride + (row - eoff)] = glu_act(g, a.activation) * sum[c];
+        }
+      }
+    };
+    MRS_DEC_TYPE_SWITCH(a.m[0].type, (stream<TT, NCOLS>(sg, K, pre, pro, epi));)
+  } else {  // EPI_QKV: units are RoPE pairs (2i, 2i+1); waves [wstart[i], wstart[i+1]) take tensor i (q, k, v), so a wave never straddles two tensors
+    const int mi = gw >= a.wstart[2] ? 2 : (gw >= a.wstart[1] ? 1 : 0);
+    const int npairs = a.nrows[mi] >> 1;
+    const int p0 = min((gw - a.wstart[mi]) * a.units_per_wave, npairs), p1 = min(p0 + a.units_per_wave, npairs);
+    const int r0 = 2 * p0;
+    // epilogue operands up front: lane i <-> pair i of the wave
+    float pcs[NCOLS], psn[NCOLS];
+    int64_t slots[NCOLS];
+    {
+      const int pair_i = ((r0 + 2 * min(lane, max(p1 - p0 - 1, 0))) % a.head_dim) >> 1;
+      const bool rot = mi < 2 && pair_i < a.rot_pairs;
+#pragma unroll
+      for (int c = 0; c < NCOLS; ++c) {
+        const size_t ti = (size_t)a.positions[c] * a.rot_pairs + (rot ? pair_i : 0);
+        const float cs = a.cos_t[ti], sn = a.sin_t[ti];
+        pcs[c] = rot ? cs : 1.0f;  // identity rotation for v and unrotated dims (x*1 - y*0 = x exactly)
+        psn[c] = rot ? sn : 0.0f;
+        slots[c] = mi == 0 ? 0 : a.slot_mapping[c];
+      }
+    }
+    float prev[NCOLS];
+#pragma unroll
+    for (int c = 0; c < NCOLS; ++c) prev[c] = 0.0f;
+    auto epi = [&](int, int row, const float(&sum)[NCOLS]) {  // row = local row of tensor mi
+      if ((row & 1) == 0) {
+#pragma unroll
+        for (int c = 0; c < NCOLS; ++c) prev[c] = sum[c];
+        return;
+      }
+      const int lr = row - 1;          // even row of the pair
+      const int pi = (lr - r0) >> 1;   // pair index inside the wave
+      const int head = lr / a.head_dim, dd = lr % a.head_dim;
+#pragma unroll
+      for (int c = 0; c < NCOLS; ++c) {
+        const float cs = rl(pcs[c], pi), sn = rl(psn[c], pi);
+        float x, y;
+        rope_pair<float>(prev[c], sum[c], cs, sn, x, y);
+        if (lane == 0) {
+          if (mi == 0) {
+            a.q_out[(size_t)c * a.nrows[0] + lr] = x;
+            a.q_out[(size_t)c * a.nrows[0] + lr + 1] = y;
+          } else {
+            const int64_t slot = slots[c];
+            if (slot >= 0) {
+              const int64_t blk = slot / a.block_size, off = slot % a.block_size;
+              uint16_t *kc = (uint16_t *)a.k_cache, *vc = (uint16_t *)a.v_cache;
+              const uint16_t xb = a.kv_f16 ? float_to_half_bits(x) : float_to_bf16_bits(x), yb = a.kv_f16 ? float_to_half_bits(y) : float_to_bf16_bits(y);
+              if (mi == 1) {
+                const int X = a.cache_x;
+                const int64_t o = ((blk * a.num_kv_heads + head) * (a.head_dim / X) + dd / X) * a.block_size * X + off * X + dd % X;
+                kc[o] = xb;
+                kc[o + 1] = yb;  // dd is even and X is even: same 16-byte group
+              } else {
+                const int64_t o = ((blk * a.num_kv_heads + head) * a.head_dim + dd) * a.block_size + off;
+                vc[o] = xb;
+                vc[o + a.block_size] = yb;
+              }
+            }
+          }
+        }
+      }
+    };
+    Segs sg{};
+    sg.nseg = 1; sg.mat[0] = a.m[mi]; sg.row0[0] = r0; sg.nrows[0] = 2 * (p1 - p0);
+    MRS_DEC_TYPE_SWITCH(sg.mat[0].type, (stream<TT, NCOLS>(sg, K, pre, pro, epi));)
+  }
+}
+
+template <int NCOLS, int EPI>
+__global__ void __launch_bounds__(NT) dec_gemv_kernel(const GemvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ float red[8];
+  gemv_phase<NCOLS, EPI>(a, smem, red);
+}
+
+// ------------------------------------------------------------------------------------------------ repack GGUF blocks -> decode layout
+// one thread per block (superblock, or 32-block for Q8_0); block i of the row-major GGUF tensor = (row, sb)
+template <int TYPE>
+__global__ void __launch_bounds__(256) repack_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, const Planes p, long long nblocks) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nblocks) return;
+  if constexpr (TYPE == T_Q4_K || TYPE == T_Q5_K) {
+    const uint8_t *b = src + i * Fmt<TYPE>::TS;
+    *(uint32_t *)(dst + p.hd + i * 4) = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
+    const uint8_t *sc12 = b + 4;
+    uint8_t sc[8], mn[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {  // get_scale_min_k4 (marlin_gguf_affine_repack.cu:200-210)
+      if (g < 4) { sc[g] = sc12[g] & 63; mn[g] = sc12[g + 4] & 63; }
+      else { sc[g] = (sc12[g + 4] & 15) | ((sc12[g - 4] >> 6) << 4); mn[g] = (sc12[g + 4] >> 4) | ((sc12[g] >> 6) << 4); }
+    }
+    for (int c = 0; c < 4; ++c) {
+      uint8_t *h = dst + p.hs + i * 16 + c * 4;
+      h[0] = sc[2 * c]; h[1] = sc[2 * c + 1]; h[2] = mn[2 * c]; h[3] = mn[2 * c + 1];
+    }
+    const uint8_t *qs = b + (TYPE == T_Q5_K ? 48 : 16);
+    for (int j = 0; j < 128; j += 4) *(uint32_t *)(dst + p.q + i * 128 + j) = (uint32_t)qs[j] | ((uint32_t)qs[j + 1] << 8) | ((uint32_t)qs[j + 2] << 16) | ((uint32_t)qs[j + 3] << 24);
+    if constexpr (TYPE == T_Q5_K) {
+      const uint8_t *qh = b + 16;
+      for (int s = 0; s < 8; ++s) {  // slice s = (quarter c, half hp): low nibbles = weights c*64 + hp*16 + a, high = + 32; fifth bits = qh[hp*16 + a] bits 2c, 2c+1
+        const int c = s >> 1, hp = s & 1;
+        uint32_t w = 0;
+        for (int k = 0; k < 4; ++k)
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t v = qh[hp * 16 + 4 * k + j];
+            w |= ((v >> (2 * c)) & 1u) << (8 * j + k);
+            w |= ((v >> (2 * c + 1)) & 1u) << (8 * j + 4 + k);
+          }
+        *(uint32_t *)(dst + p.x + i * 32 + s * 4) = w;
+      }
+    }
+  } else if constexpr (TYPE == T_Q6_K) {
+    const uint8_t *b = src + i * 210;
+    for (int j = 0; j < 128; j += 2) *(uint16_t *)(dst + p.q + i * 128 + j) = (uint16_t)(b[j] | (b[j + 1] << 8));
+    const uint8_t *qh = b + 128;
+    const int8_t *scs = (const int8_t *)(b + 192);
+    for (int u = 0; u < 4; ++u) {
+      const int h = u >> 1, j = u & 1;
+      for (int e = 0; e < 16; ++e) {
+        const uint32_t v0 = qh[h * 32 + e], v1 = qh[h * 32 + 16 + e];
+        dst[p.x + i * 64 + u * 16 + e] = (uint8_t)(((v0 >> (2 * j)) & 3) | (((v1 >> (2 * j)) & 3) << 2) | (((v0 >> (2 * j + 4)) & 3) << 4) | (((v1 >> (2 * j + 4)) & 3) << 6));
+      }
+      const int r = 8 * h + 2 * j;
+      uint8_t *hs = dst + p.hs + i * 16 + u * 4;
+      hs[0] = (uint8_t)scs[r]; hs[1] = (uint8_t)scs[r + 1]; hs[2] = (uint8_t)scs[r + 4]; hs[3] = (uint8_t)scs[r + 5];
+    }
+    *(uint16_t *)(dst + p.hd + i * 2) = (uint16_t)(b[208] | (b[209] << 8));
+  } else {  // Q8_0
+    const uint8_t *b = src + i * 34;
+    *(uint16_t *)(dst + p.hd + i * 2) = (uint16_t)(b[0] | (b[1] << 8));
+    for (int j = 0; j < 32; j += 2) *(uint16_t *)(dst + p.q + i * 32 + j) = (uint16_t)(b[2 + j] | (b[3 + j] << 8));
+  }
+}
+
+static bool make_mat(Mat &m, const void *planes, int type, long long n, long long k) {
+  if (!planes || !dec_type(type) || n <= 0 || k <= 0 || k % 32 || (type != T_Q8_0 && k % 256)) return false;
+  const Planes p = plane_layout(type, n, k);
+  if (p.total >= 0x7fffff00ull) return false;  // one 31-bit buffer descriptor per tensor
+  m.base = (const uint8_t *)planes; m.off_x = (unsigned)p.x; m.off_hs = (unsigned)p.hs; m.off_hd = (unsigned)p.hd; m.bytes = (unsigned)p.total;
+  m.type = type; m.n = (int)n; m.k = (int)k;
+  return true;
+}
+
+template <int EPI> struct Launch {
+  template <int NCOLS> static int go(GemvArgs a, hipStream_t s) {
+    int upw = (a.units + 256 * NW - 1) / (256 * NW);
+    if (upw < 1) upw = 1;
+    if (upw > 64) upw = 64;  // epilogue operands are prefetched one unit per lane
+    { static int ov = -1; if (ov < 0) { const char *e = getenv("MRS_DEC_UPW"); ov = e ? atoi(e) : 0; } if (ov > 0 && ov <= 64) upw = ov; }
+    a.units_per_wave = upw;
+    int grid = (a.units + upw * NW - 1) / (upw * NW);
+    if (EPI == EPI_QKV) {
+      a.wstart[0] = 0;
+      for (int i = 0; i < 3; ++i) a.wstart[i + 1] = a.wstart[i] + ((a.nrows[i] >> 1) + upw - 1) / upw;
+      grid = (a.wstart[3] + NW - 1) / NW;
+    }
+    const size_t lds = (act_bytes(a.K, NCOLS) + 15) & ~(size_t)15;
+    if (lds > 158 * 1024) return -2;
+    auto kern = dec_gemv_kernel<NCOLS, EPI>;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024); attr = true; }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, s, a);
+    return 0;
+  }
+  static int run(const GemvArgs &a, int b, hipStream_t s) {
+    switch (b) {
+    case 1: return go<1>(a, s); case 2: return go<2>(a, s); case 3: return go<3>(a, s); case 4: return go<4>(a, s);
+    case 5: return go<5>(a, s); case 6: return go<6>(a, s); case 7: return go<7>(a, s); case 8: return go<8>(a, s);
+    default: return -1;
+    }
+  }
+};
+
+}  // namespace dec
+}  // namespace mrs
+
+using namespace mrs;
+using namespace mrs::dec;
+
+struct mrs_dec_mat_c { const void *planes; int type; long long n, k; };  // == mrs_dec_mat (include/mrs_hip_ext.h)
+
+extern "C" int mrs_dec_supported(int ggml_type) { return dec_type(ggml_type) ? 1 : 0; }
+extern "C" size_t mrs_dec_repack_bytes(int type, long long n, long long k) {
+  if (!dec_type(type) || k % 32 || (type != T_Q8_0 && k % 256)) return 0;
+  return plane_layout(type, n, k).total;
+}
+extern "C" int mrs_dec_repack(const void *gguf_blocks, int type, long long n, long long k, void *planes, void *stream) {
+  if (!mrs_dec_repack_bytes(type, n, k) || !gguf_blocks || !planes) return -1;
+  const Planes p = plane_layout(type, n, k);
+  const long long nb = n * (k / (type == T_Q8_0 ? 32 : 256));
+  const dim3 grid((unsigned)((nb + 255) / 256));
+  hipStream_t s = (hipStream_t)stream;
+  switch (type) {
+  case T_Q4_K: hipLaunchKernelGGL(repack_kernel<T_Q4_K>, grid, dim3(256), 0, s, (const uint8_t *)gguf_blocks, (uint8_t *)planes, p, nb); break;
+  case T_Q5_K: hipLaunchKernelGGL(repack_kernel<T_Q5_K>, grid, dim3(256), 0, s, (const uint8_t *)gguf_blocks, (uint8_t *)planes, p, nb); break;
+  case T_Q6_K: hipLaunchKernelGGL(repack_kernel<T_Q6_K>, grid, dim3(256), 0, s, (const uint8_t *)gguf_blocks, (uint8_t *)planes, p, nb); break;
+  default: hipLaunchKernelGGL(repack_kernel<T_Q8_0>, grid, dim3(256), 0, s, (const uint8_t *)gguf_blocks, (uint8_t *)planes, p, nb); break;
+  }
+  return 0;
+}
+
+// q, k, v projections of the decode step: h [b][ldh] f32 -> RMSNorm -> quantize -> GEMV -> RoPE (interleaved pairs) -> q_out f32 [b][nq],
+// k / v into the paged cache (kv_dtype 1 = bf16, 0 = f16).  All three tensors must share the activation format (K-quants or Q8_0).
+extern "C" int mrs_dec_qkv(const mrs_dec_mat_c *wq, const mrs_dec_mat_c *wk, const mrs_dec_mat_c *wv, const float *h, int ldh, const float *norm_w, float eps,
+                           float *q_out, void *k_cache, void *v_cache, const int64_t *slot_mapping, const int32_t *positions, const float *cos_t,
+                           const float *sin_t, int head_dim, int rot_pairs, int num_kv_heads, int block_size, int kv_dtype, int b, void *stream) {
+  GemvArgs a{};
+  if (!wq || !wk || !wv || !make_mat(a.m[0], wq->planes, wq->type, wq->n, wq->k) || !make_mat(a.m[1], wk->planes, wk->type, wk->n, wk->k) ||
+      !make_mat(a.m[2], wv->planes, wv->type, wv->n, wv->k)) return -1;
+  if (wq->k != wk->k || wq->k != wv->k || ((wq->n | wk->n | wv->n | head_dim) & 1)) return -1;
+  if (act_mode_for(wq->type) != act_mode_for(wk->type) || act_mode_for(wq->type) != act_mode_for(wv->type)) return -1;
+  if (kv_dtype != 0 && kv_dtype != 1) return -1;
+  a.nrows[0] = (int)wq->n; a.nrows[1] = (int)wk->n; a.nrows[2] = (int)wv->n; a.K = (int)wq->k;
+  a.x = h; a.ldx = ldh; a.norm_w = norm_w; a.eps = eps; a.q_out = q_out; a.k_cache = k_cache; a.v_cache = v_cache; a.slot_mapping = slot_mapping;
+  a.positions = positions; a.cos_t = cos_t; a.sin_t = sin_t; a.head_dim = head_dim; a.rot_pairs = rot_pairs; a.num_kv_heads = num_kv_heads;
+  a.block_size = block_size; a.cache_x = 8; a.kv_f16 = kv_dtype == 0;
+  a.units = (a.nrows[0] + a.nrows[1] + a.nrows[2]) / 2;
+  return Launch<EPI_QKV>::run(a, b, (hipStream_t)stream);
+}
+
+// gate / up: h -> RMSNorm -> quantize -> act(W_g . x) * (W_u . x) -> act_out f32 [b][ld_out].  expert_sel != nullptr: stacked experts
+// [E * n][K], the expert index is read on the device (graph-capturable routing).
+extern "C" int mrs_dec_gate_up(const mrs_dec_mat_c *wg, const mrs_dec_mat_c *wu, int n, const int32_t *expert_sel, const float *h, int ldh, const float *norm_w,
+                               float eps, int activation, float *act_out, int ld_out, int b, void *stream) {
+  GemvArgs a{};
+  if (!wg || !wu || !make_mat(a.m[0], wg->planes, wg->type, wg->n, wg->k) || !make_mat(a.m[1], wu->planes, wu->type, wu->n, wu->k)) return -1;
+  if (wg->type != wu->type || wg->n != wu->n || wg->k != wu->k || n <= 0 || wg->n % n || (!expert_sel && wg->n != n)) return -1;
+  a.nrows[0] = a.nrows[1] = n; a.K = (int)wg->k; a.x = h; a.ldx = ldh; a.norm_w = norm_w; a.eps = eps; a.activation = activation;
+  a.out = act_out; a.out_stride = ld_out; a.units = n; a.expert_sel = expert_sel;
+  return Launch<EPI_GLU>::run(a, b, (hipStream_t)stream);
+}
+
+// plain projection: x [b][ldx] f32 (-> RMSNorm when norm_w) -> quantize -> GEMV.  mode 0: out = W.x;  mode 1: out = out * resid_scale + s * W.x
+// (s = *acc_scale or 1; resid_scale = 1 / world_size under tensor parallelism, distributed/layers.rs:965-975)
+extern "C" int mrs_dec_proj(const mrs_dec_mat_c *w, int n, const int32_t *expert_sel, const float *x, int ldx, const float *norm_w, float eps, float *out,
+                            int ld_out, int mode, float resid_scale, const float *acc_scale, int b, void *stream) {
+  GemvArgs a{};
+  if (!w || !make_mat(a.m[0], w->planes, w->type, w->n, w->k) || n <= 0 || w->n % n || (!expert_sel && w->n != n)) return -1;
+  a.nrows[0] = n; a.K = (int)w->k; a.x = x; a.ldx = ldx; a.norm_w = norm_w; a.eps = eps; a.out = out; a.out_stride = ld_out;
+  a.resid_scale = resid_scale; a.acc_scale = acc_scale; a.units = n; a.expert_sel = expert_sel;
+  return mode ? Launch<EPI_RESID>::run(a, b, (hipStream_t)stream) : Launch<EPI_STORE>::run(a, b, (hipStream_t)stream);
+}

@@ -303,7 +303,9 @@ __global__ void __launch_bounds__(256) isq_legacy_kernel(const T *__restrict__ s
     float amax = 0, mx = 0;
 #pragma unroll
     for (int i = 0; i < 32; ++i) if (fabsf(x[i]) > amax) { amax = fabsf(x[i]); mx = x[i]; }
-    const float d = mx / -(float)HR, id = d ? 1.f / d : 0.f;
+    // an all-zero block gives d = 0 / -HR = -0 in GGML (sign bit set in the stored f16); spelled out because hipcc folds the division
+    // by a constant into a multiplication sequence that loses the sign of zero
+    const float d = mx == 0.f ? -0.0f : mx / -(float)HR, id = d ? 1.f / d : 0.f;
     *(uint16_t *)y = float_to_half_bits(d);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {

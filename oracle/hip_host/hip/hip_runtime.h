@@ -223,6 +223,20 @@ static inline hiphost_v4u hiphost_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r,
   return v;
 }
 #define __builtin_amdgcn_raw_buffer_load_b128(R, VOFF, SOFF, AUX) hiphost_raw_buffer_load_b128((R), (VOFF), (SOFF))
+static inline unsigned hiphost_raw_buffer_load_b32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  unsigned v = 0;
+  const unsigned long long o = (unsigned long long)voff + soff;
+  if (o + 4 <= r.bytes) memcpy(&v, r.base + o, 4);
+  return v;
+}
+static inline short hiphost_raw_buffer_load_b16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  short v = 0;
+  const unsigned long long o = (unsigned long long)voff + soff;
+  if (o + 2 <= r.bytes) memcpy(&v, r.base + o, 2);
+  return v;
+}
+#define __builtin_amdgcn_raw_buffer_load_b32(R, VOFF, SOFF, AUX) hiphost_raw_buffer_load_b32((R), (VOFF), (SOFF))
+#define __builtin_amdgcn_raw_buffer_load_b16(R, VOFF, SOFF, AUX) hiphost_raw_buffer_load_b16((R), (VOFF), (SOFF))
 // f32 -> bf16 (RNE) for `__builtin_convertvector(float2, __bf16 x 2)`: x86 lowers it to this runtime call
 extern "C" inline __bf16 __truncsfbf2(float f) {
   uint32_t x; memcpy(&x, &f, 4);
@@ -235,6 +249,8 @@ extern "C" inline __bf16 __truncsfbf2(float f) {
 #define hipLaunchKernelGGL(K, G, B, LDS, STREAM, ...) hiphost::launch(dim3(G), dim3(B), (size_t)(LDS), [&] { K(__VA_ARGS__); })
 #define __builtin_amdgcn_update_dpp(OLD, SRC, CTRL, RMASK, BMASK, BOUND) hiphost::dpp((SRC), (CTRL))
 #define __builtin_amdgcn_readlane(V, L) hiphost::exchange((int)(V), (L))
+#define __builtin_amdgcn_readfirstlane(V) hiphost::exchange((int)(V), 0) /* kernels use it on wave-uniform values only */
+#define MRS_WAVE_SYNC() hiphost::wave_sync()                           /* product code: a compiler-level wave barrier (lockstep lanes) */
 #define __builtin_amdgcn_sdot4(A, B, C, CLAMP) hiphost_sdot4((A), (B), (C))
 static inline int hiphost_sdot4(int a, int b, int c) {
   for (int i = 0; i < 4; ++i) c += (int)(int8_t)((uint32_t)a >> (8 * i)) * (int)(int8_t)((uint32_t)b >> (8 * i));

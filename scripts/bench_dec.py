@@ -1,0 +1,127 @@
+#!/usr/bin/env python
+"""Decode-engine phase microbenchmark (mrs_dec_*): us per launch and TB/s of GGUF weight bytes at Llama-3-8B shapes, weights rotated over
+>= 1.2 GB so nothing is Infinity-Cache resident.  `--old` times the round-1 fused kernels (mrs_decode_*) on the same tensors."""
+import argparse, ctypes as C, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+class Mat(C.Structure):
+    _fields_ = [("planes", C.c_void_p), ("type", C.c_int), ("n", C.c_longlong), ("k", C.c_longlong)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--b", type=int, default=1)
+    ap.add_argument("--reps", type=int, default=4)
+    ap.add_argument("--old", action="store_true")
+    ap.add_argument("--phases", default="qkv,o,gate_up,down4,down6,lm_head")
+    a = ap.parse_args()
+    import torch
+    import mistralrs_amd  # noqa: F401
+    from mistralrs_amd import _lib
+    from mistralrs_amd.gguf import GgmlDType
+    from mistralrs_amd.llama import random_qtensor
+    dev = torch.device("cuda:0")
+    L = _lib.load("ext")
+    _lib.load("quant")
+    L.mrs_dec_repack_bytes.restype = C.c_size_t
+    L.mrs_dec_repack_bytes.argtypes = [C.c_int, C.c_longlong, C.c_longlong]
+    L.mrs_dec_repack.argtypes = [C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p]
+    st = torch.cuda.current_stream().cuda_stream
+    b = a.b
+
+    def make(dt, n, k, seed):
+        w = random_qtensor(dt, n, k, dev, seed)
+        nb = L.mrs_dec_repack_bytes(dt.id, n, k)
+        p = torch.empty(nb, dtype=torch.uint8, device=dev)
+        assert L.mrs_dec_repack(w.data.data_ptr(), dt.id, n, k, p.data_ptr(), st) == 0
+        return w, p, Mat(p.data_ptr(), dt.id, n, k)
+
+    d, ff, nq, nkv, hd = 4096, 14336, 4096, 1024, 128
+    h = torch.randn(b, d, device=dev)
+    nw = torch.ones(d, device=dev)
+    act = torch.randn(b, ff, device=dev)
+    attn = torch.randn(b, nq, device=dev)
+    q_out = torch.empty(b, nq, device=dev)
+    kc = torch.zeros(8, 8, hd // 8, 32, 8, dtype=torch.bfloat16, device=dev)
+    vc = torch.zeros(8, 8, hd, 32, dtype=torch.bfloat16, device=dev)
+    slots = torch.arange(b, dtype=torch.int64, device=dev)
+    pos = torch.arange(b, dtype=torch.int32, device=dev)
+    cos = torch.ones(64, hd // 2, device=dev); sin = torch.zeros(64, hd // 2, device=dev)
+    logits = torch.empty(b, 128256, device=dev)
+    ya = torch.zeros(b * (4096 // 32) * 36, dtype=torch.uint8, device=dev)
+    yb = torch.zeros(b * (14336 // 32) * 36, dtype=torch.uint8, device=dev)
+    Q4, Q6 = GgmlDType.Q4K, GgmlDType.Q6K
+    MP = C.POINTER(Mat)
+    L.mrs_dec_qkv.argtypes = [MP, MP, MP, C.c_void_p, C.c_int, C.c_void_p, C.c_float] + [C.c_void_p] * 7 + [C.c_int] * 6 + [C.c_void_p]
+    L.mrs_dec_gate_up.argtypes = [MP, MP, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.mrs_dec_proj.argtypes = [MP, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p]
+    L.mrs_decode_qkv.argtypes = [C.c_void_p] * 3 + [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_float] + [C.c_void_p] * 7 + [C.c_int] * 5 + [C.c_void_p]
+    L.mrs_decode_gate_up.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.mrs_decode_proj.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.mrs_decode_norm_proj.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+
+    def nbytes(*ws):
+        return sum(w.data.numel() for w in ws)
+
+    phases = {}
+
+    def ph_qkv(i):
+        ws = (make(Q4, nq, d, 3 * i), make(Q4, nkv, d, 3 * i + 1), make(Q6, nkv, d, 3 * i + 2))
+        new = lambda: L.mrs_dec_qkv(C.byref(ws[0][2]), C.byref(ws[1][2]), C.byref(ws[2][2]), h.data_ptr(), d, nw.data_ptr(), 1e-5, q_out.data_ptr(), kc.data_ptr(), vc.data_ptr(),
+                                    slots.data_ptr(), pos.data_ptr(), cos.data_ptr(), sin.data_ptr(), hd, hd // 2, 8, 32, 1, b, st)
+        old = lambda: L.mrs_decode_qkv(ws[0][0].data.data_ptr(), ws[1][0].data.data_ptr(), ws[2][0].data.data_ptr(), 12, 12, 14, nq, nkv, nkv, d, h.data_ptr(), nw.data_ptr(), 1e-5,
+                                       q_out.data_ptr(), kc.data_ptr(), vc.data_ptr(), slots.data_ptr(), pos.data_ptr(), cos.data_ptr(), sin.data_ptr(), hd, hd // 2, 8, 32, b, st)
+        return ws, new, old, nbytes(*[w[0] for w in ws])
+
+    def ph_proj(dt, n, k, x, ldx, ybuf, stride):
+        def f(i):
+            ws = (make(dt, n, k, 100 + i),)
+            new = lambda: L.mrs_dec_proj(C.byref(ws[0][2]), n, None, x.data_ptr(), ldx, None, 0.0, h.data_ptr(), d, 1, 1.0, None, b, st)
+            old = lambda: L.mrs_decode_proj(ws[0][0].data.data_ptr(), dt.id, n, k, ybuf.data_ptr(), stride, h.data_ptr(), d, 1, b, st)
+            return ws, new, old, nbytes(ws[0][0])
+        return f
+
+    def ph_gate_up(i):
+        ws = (make(Q4, ff, d, 200 + 2 * i), make(Q4, ff, d, 201 + 2 * i))
+        new = lambda: L.mrs_dec_gate_up(C.byref(ws[0][2]), C.byref(ws[1][2]), ff, None, h.data_ptr(), d, nw.data_ptr(), 1e-5, 0, act.data_ptr(), ff, b, st)
+        old = lambda: L.mrs_decode_gate_up(ws[0][0].data.data_ptr(), ws[1][0].data.data_ptr(), 12, ff, d, h.data_ptr(), nw.data_ptr(), 1e-5, 0, yb.data_ptr(), 14336 // 32, b, st)
+        return ws, new, old, nbytes(ws[0][0], ws[1][0])
+
+    def ph_lm(i):
+        ws = (make(Q6, 128256, d, 300 + i),)
+        new = lambda: L.mrs_dec_proj(C.byref(ws[0][2]), 128256, None, h.data_ptr(), d, nw.data_ptr(), 1e-5, logits.data_ptr(), 128256, 0, 1.0, None, b, st)
+        old = lambda: L.mrs_decode_norm_proj(ws[0][0].data.data_ptr(), 14, 128256, d, h.data_ptr(), nw.data_ptr(), 1e-5, logits.data_ptr(), 128256, b, st)
+        return ws, new, old, nbytes(ws[0][0])
+
+    table = {"qkv": ph_qkv, "o": ph_proj(Q4, d, nq, attn, nq, ya, 4096 // 32), "gate_up": ph_gate_up, "down4": ph_proj(Q4, d, ff, act, ff, yb, 14336 // 32),
+             "down6": ph_proj(Q6, d, ff, act, ff, yb, 14336 // 32), "lm_head": ph_lm}
+    for name in a.phases.split(","):
+        mk = table[name]
+        insts, total = [], 0
+        while total < 1.2e9 and len(insts) < 64:
+            inst = mk(len(insts))
+            insts.append(inst)
+            total += inst[3]
+        for which in (("new", 1),) + ((("old", 2),) if a.old else ()):
+            fns = [inst[which[1]] for inst in insts]
+            for f in fns:
+                assert f() == 0
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.reps):
+                for f in fns:
+                    f()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / (a.reps * len(fns))
+            print(json.dumps({"phase": name, "impl": which[0], "b": b, "MB": round(insts[0][3] / 1e6, 2), "us": round(us, 2), "TBps": round(insts[0][3] / us / 1e6, 3),
+                              "frac_8TBps": round(insts[0][3] / us / 1e6 / 8.0, 3), "buffers": len(insts)}), flush=True)
+        del insts
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()

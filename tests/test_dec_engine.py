@@ -1,0 +1,199 @@
+"""Decode engine (csrc/dec_core.cuh, ext_dec.hip): GEMV phases in the arithmetic of the reference CPU path
+(GgufMatMul::forward_raw -> candle QMatMul on f32 activations, mistralrs-quant/src/gguf/mod.rs:465-478): Q8_K / Q8_0 activation quantization,
+integer block dots, f32 combination.  Checked against oracle B (oracle/ggml_oracle.c orc_matmul_cpu: dot_kquant_q8K / dot_legacy_q8).
+Same test bodies on the wave64 host emulation (CPU suite) and on the MI355X (`-m gpu`).
+
+Tolerance: with identical activations the integer parts are exact, so only the f32 summation order over the blocks of a row differs:
+|got - want| <= 4 * 2^-23 * sqrt(blocks) * sum|terms| is generous; the tests use 2e-5 * max|want| + that bound's typical size."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.abi_backends import GpuBackend, HostBackend
+
+
+class Mat(C.Structure):
+    _fields_ = [("planes", C.c_void_p), ("type", C.c_int), ("n", C.c_longlong), ("k", C.c_longlong)]
+
+
+def repack(be, O, t, packed, n, k):
+    nbytes = be.sym("mrs_dec_repack_bytes", [C.c_int, C.c_longlong, C.c_longlong], C.c_size_t)(t, n, k)
+    assert nbytes > 0
+    src = be.buf(np.ascontiguousarray(packed).reshape(-1))
+    dst = be.buf(np.zeros(nbytes, dtype=np.uint8))
+    assert be.sym("mrs_dec_repack", [C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p], C.c_int)(src.ptr, t, n, k, dst.ptr, be.stream) == 0
+    return dst, Mat(dst.ptr, t, n, k)
+
+
+def _weights(O, t, n, k, seed):
+    rng = np.random.default_rng(seed)
+    w = (rng.standard_normal((n, k)) * 0.05).astype(np.float32)
+    return O.quantize(t, w).reshape(n, -1)
+
+
+PROJ = [C.POINTER(Mat), C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p]
+
+
+def check_proj(O, be, tname, n, k, b, mode, seed=0):
+    t = getattr(O, tname)
+    packed = _weights(O, t, n, k, seed)
+    keep, m = repack(be, O, t, packed, n, k)
+    rng = np.random.default_rng(seed + 1)
+    x = rng.standard_normal((b, k)).astype(np.float32)
+    x[0, : min(256, k)] *= 0.0 if seed % 2 else 1.0  # an all-zero activation block now and then
+    want = O.matmul_cpu(t, packed, n, k, x)
+    base = rng.standard_normal((b, n)).astype(np.float32)
+    xb, ob = be.buf(x), be.buf(base.copy())
+    fn = be.sym("mrs_dec_proj", PROJ, C.c_int)
+    rs = 0.5
+    assert fn(C.byref(m), n, None, xb.ptr, k, None, 0.0, ob.ptr, n, mode, rs, None, b, be.stream) == 0
+    got = ob.numpy()
+    if mode:
+        want = base * np.float32(rs) + want
+    tol = 2e-5 * np.abs(want).max()
+    assert np.abs(got - want).max() <= tol, (tname, n, k, b, float(np.abs(got - want).max()), tol)
+
+
+CASES = [("Q4_K", 70, 512, 1, 0), ("Q4_K", 33, 1024, 2, 1), ("Q4_K", 16, 4096, 1, 1), ("Q4_K", 9, 768, 3, 0), ("Q4_K", 24, 3584, 1, 0),
+         ("Q5_K", 40, 512, 1, 0), ("Q5_K", 12, 2048, 2, 1),
+         ("Q6_K", 50, 512, 1, 0), ("Q6_K", 20, 4096, 1, 1), ("Q6_K", 7, 768, 8, 0), ("Q6_K", 10, 3584, 2, 0),
+         ("Q8_0", 40, 512, 1, 0), ("Q8_0", 18, 1056, 2, 1), ("Q8_0", 8, 4096, 1, 0)]
+
+
+@pytest.mark.parametrize("tname,n,k,b,mode", CASES)
+def test_proj_host_emulation(oracle, tname, n, k, b, mode):
+    check_proj(oracle, HostBackend(), tname, n, k, b, mode, seed=n + k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tname,n,k,b,mode", CASES + [("Q4_K", 4096, 4096, 1, 1), ("Q4_K", 4096, 14336, 1, 1), ("Q6_K", 4096, 14336, 1, 1), ("Q6_K", 1024, 4096, 4, 0),
+                                                     ("Q8_0", 4096, 4096, 2, 1), ("Q5_K", 2048, 4096, 1, 0), ("Q6_K", 32064, 4096, 1, 0)])
+def test_proj_gpu(oracle, dev, tname, n, k, b, mode):
+    check_proj(oracle, GpuBackend(dev), tname, n, k, b, mode, seed=n + k)
+
+
+def check_norm_proj(O, be, tname, n, k, b):
+    """RMSNorm fused into the prologue: the normed row feeds the quantizer; a 1-ulp difference of the norm can move single quants by one
+    step, so the bar here is the quantization step, not the f32 order."""
+    t = getattr(O, tname)
+    packed = _weights(O, t, n, k, 3)
+    keep, m = repack(be, O, t, packed, n, k)
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((b, k)).astype(np.float32)
+    nw = (1.0 + 0.1 * rng.standard_normal(k)).astype(np.float32)
+    want = O.matmul_cpu(t, packed, n, k, O.rms_norm(x, nw, 1e-5))
+    xb, nb, ob = be.buf(x), be.buf(nw), be.buf(np.zeros((b, n), dtype=np.float32))
+    assert be.sym("mrs_dec_proj", PROJ, C.c_int)(C.byref(m), n, None, xb.ptr, k, nb.ptr, 1e-5, ob.ptr, n, 0, 1.0, None, b, be.stream) == 0
+    got = ob.numpy()
+    assert np.abs(got - want).max() <= 2e-3 * np.abs(want).max()
+    assert np.median(np.abs(got - want)) <= 2e-5 * np.abs(want).max()  # most outputs see identical quants
+
+
+@pytest.mark.parametrize("tname,n,k,b", [("Q4_K", 24, 1024, 2), ("Q6_K", 16, 512, 1), ("Q8_0", 16, 512, 1)])
+def test_norm_proj_host_emulation(oracle, tname, n, k, b):
+    check_norm_proj(oracle, HostBackend(), tname, n, k, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tname,n,k,b", [("Q4_K", 1024, 4096, 2), ("Q6_K", 2048, 4096, 1), ("Q8_0", 512, 4096, 3)])
+def test_norm_proj_gpu(oracle, dev, tname, n, k, b):
+    check_norm_proj(oracle, GpuBackend(dev), tname, n, k, b)
+
+
+GLU = [C.POINTER(Mat), C.POINTER(Mat), C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+
+
+def check_gate_up(O, be, tname, n, k, b, experts=0, sel=0):
+    t = getattr(O, tname)
+    E = max(experts, 1)
+    pg, pu = _weights(O, t, E * n, k, 11), _weights(O, t, E * n, k, 12)
+    kg, mg = repack(be, O, t, pg, E * n, k)
+    ku, mu = repack(be, O, t, pu, E * n, k)
+    rng = np.random.default_rng(13)
+    x = rng.standard_normal((b, k)).astype(np.float32)
+    g = O.matmul_cpu(t, pg[sel * n:(sel + 1) * n], n, k, x)
+    u = O.matmul_cpu(t, pu[sel * n:(sel + 1) * n], n, k, x)
+    want = O.fused_glu(g, u, 0)
+    xb, ob = be.buf(x), be.buf(np.zeros((b, n), dtype=np.float32))
+    selb = be.buf(np.array([sel], dtype=np.int32)) if experts else None
+    fn = be.sym("mrs_dec_gate_up", GLU, C.c_int)
+    assert fn(C.byref(mg), C.byref(mu), n, selb.ptr if selb else None, xb.ptr, k, None, 0.0, 0, ob.ptr, n, b, be.stream) == 0
+    got = ob.numpy()
+    assert np.abs(got - want).max() <= 3e-5 * np.abs(want).max() + 1e-7
+
+
+@pytest.mark.parametrize("tname,n,k,b,experts,sel", [("Q4_K", 64, 512, 1, 0, 0), ("Q6_K", 20, 768, 2, 0, 0), ("Q8_0", 36, 512, 1, 0, 0), ("Q4_K", 40, 512, 1, 3, 2)])
+def test_gate_up_host_emulation(oracle, tname, n, k, b, experts, sel):
+    check_gate_up(oracle, HostBackend(), tname, n, k, b, experts, sel)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tname,n,k,b,experts,sel", [("Q4_K", 14336, 4096, 1, 0, 0), ("Q6_K", 1000, 4096, 2, 0, 0), ("Q8_0", 2048, 4096, 1, 0, 0), ("Q4_K", 1024, 4096, 1, 4, 3),
+                                                     ("Q5_K", 512, 2048, 8, 0, 0)])
+def test_gate_up_gpu(oracle, dev, tname, n, k, b, experts, sel):
+    check_gate_up(oracle, GpuBackend(dev), tname, n, k, b, experts, sel)
+
+
+QKV = [C.POINTER(Mat)] * 3 + [C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+
+
+def check_qkv(O, be, tq, tv, heads, kvh, hd, k, b, kv_dtype=1):
+    """q/k/v + interleaved RoPE + paged cache write vs the oracle: rope(matmul_cpu(...)), cache pages through kv_cache_gather."""
+    nq, nkv, bs = heads * hd, kvh * hd, 32
+    pq, pk, pv = _weights(O, getattr(O, tq), nq, k, 21), _weights(O, getattr(O, tq), nkv, k, 22), _weights(O, getattr(O, tv), nkv, k, 23)
+    kq, mq = repack(be, O, getattr(O, tq), pq, nq, k)
+    kk, mk = repack(be, O, getattr(O, tq), pk, nkv, k)
+    kv, mv = repack(be, O, getattr(O, tv), pv, nkv, k)
+    rng = np.random.default_rng(24)
+    x = rng.standard_normal((b, k)).astype(np.float32)
+    nw = (1.0 + 0.05 * rng.standard_normal(k)).astype(np.float32)
+    maxpos = 64
+    inv = 1.0 / (10000.0 ** (np.arange(0, hd, 2, dtype=np.float32) / hd))
+    fr = np.arange(maxpos, dtype=np.float32)[:, None] * inv[None, :]
+    cos, sin = np.cos(fr).astype(np.float32), np.sin(fr).astype(np.float32)
+    pos = np.array([5 + 7 * i for i in range(b)], dtype=np.int32)
+    nblocks = 2 * b
+    slots = np.array([(2 * i) * bs + int(pos[i]) % bs for i in range(b)], dtype=np.int64)
+    xn = O.rms_norm(x, nw, 1e-5)
+    q = O.rope(O.matmul_cpu(getattr(O, tq), pq, nq, k, xn).reshape(b, heads, hd), cos, sin, pos, False).reshape(b, nq)
+    kk_ = O.rope(O.matmul_cpu(getattr(O, tq), pk, nkv, k, xn).reshape(b, kvh, hd), cos, sin, pos, False).reshape(b, nkv)
+    vv = O.matmul_cpu(getattr(O, tv), pv, nkv, k, xn)
+    cache_np = np.float16 if kv_dtype == 0 else None
+    kc = be.buf(np.zeros((nblocks, kvh, hd // 8, bs, 8), dtype=np.uint16))
+    vc = be.buf(np.zeros((nblocks, kvh, hd, bs), dtype=np.uint16))
+    xb, nb, qb = be.buf(x), be.buf(nw), be.buf(np.zeros((b, nq), dtype=np.float32))
+    sb, pb, cb, snb = be.buf(slots), be.buf(pos), be.buf(cos), be.buf(sin)
+    fn = be.sym("mrs_dec_qkv", QKV, C.c_int)
+    assert fn(C.byref(mq), C.byref(mk), C.byref(mv), xb.ptr, k, nb.ptr, 1e-5, qb.ptr, kc.ptr, vc.ptr, sb.ptr, pb.ptr, cb.ptr, snb.ptr, hd, hd // 2, kvh, bs, kv_dtype, b,
+              be.stream) == 0
+    got_q = qb.numpy()
+    tol = 2e-3 * max(np.abs(q).max(), np.abs(kk_).max(), np.abs(vv).max())
+    assert np.abs(got_q - q).max() <= tol
+
+    def dec(a16):
+        a16 = np.asarray(a16).astype(np.uint16)
+        return a16.view(np.float16).astype(np.float32) if kv_dtype == 0 else O.from_bf16_bits(a16)
+    kcn, vcn = dec(kc.numpy().reshape(nblocks, kvh, hd // 8, bs, 8)), dec(vc.numpy().reshape(nblocks, kvh, hd, bs))
+    for i in range(b):
+        blk, off = int(slots[i]) // bs, int(slots[i]) % bs
+        gk = kcn[blk, :, :, off, :].reshape(kvh * hd)
+        gv = vcn[blk, :, :, off].reshape(kvh * hd)
+        rel = 2.0 ** -8 if kv_dtype == 1 else 2.0 ** -11
+        assert np.abs(gk - kk_[i]).max() <= tol + rel * np.abs(kk_[i]).max()
+        assert np.abs(gv - vv[i]).max() <= tol + rel * np.abs(vv[i]).max()
+    # untouched slots stay zero
+    assert np.count_nonzero(kcn) <= b * kvh * hd and np.count_nonzero(vcn) <= b * kvh * hd
+
+
+@pytest.mark.parametrize("tq,tv,heads,kvh,hd,k,b,kvd", [("Q4_K", "Q6_K", 4, 2, 64, 512, 1, 1), ("Q4_K", "Q4_K", 2, 1, 128, 512, 2, 0), ("Q8_0", "Q8_0", 2, 2, 64, 256, 1, 1)])
+def test_qkv_host_emulation(oracle, tq, tv, heads, kvh, hd, k, b, kvd):
+    check_qkv(oracle, HostBackend(), tq, tv, heads, kvh, hd, k, b, kvd)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tq,tv,heads,kvh,hd,k,b,kvd", [("Q4_K", "Q6_K", 32, 8, 128, 4096, 1, 1), ("Q4_K", "Q4_K", 32, 8, 128, 4096, 3, 0), ("Q8_0", "Q8_0", 8, 2, 128, 2048, 2, 1),
+                                                        ("Q6_K", "Q6_K", 8, 1, 128, 1024, 1, 1)])
+def test_qkv_gpu(oracle, dev, tq, tv, heads, kvh, hd, k, b, kvd):
+    check_qkv(oracle, GpuBackend(dev), tq, tv, heads, kvh, hd, k, b, kvd)
