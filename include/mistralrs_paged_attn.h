@@ -86,6 +86,12 @@ int mrs_decode_attention_q8_1_f32_bf16(void *y_q8_1, int y_stride_blocks, float 
                                        int max_context_len, int num_seqs, int num_heads, int head_size,
                                        int max_num_blocks_per_seq, int q_stride, int kv_block_stride, int kv_head_stride,
                                        void *stream);
+/* decode engine: the same split-KV kernel with f32 probabilities (reference CPU path) and an f32 result out [seqs][heads * 128];
+ * kv_dtype 1 = bf16 pages, 0 = f16 pages; head_size 128, block_size 32 */
+int mrs_decode_attention_f32_f32_bf16(float *out, float *exp_sums, float *max_logits, void *tmp_out, const void *query, const void *key_cache,
+                                      const void *value_cache, int num_kv_heads, float scale, const uint32_t *block_tables,
+                                      const uint32_t *context_lens, int block_size, int max_context_len, int num_seqs, int num_heads, int head_size,
+                                      int max_num_blocks_per_seq, int q_stride, int kv_block_stride, int kv_head_stride, int kv_dtype, void *stream);
 /* ffi.rs:484-510 ; update_kvscales.cu:46-150: *k_scales = max(*k_scales, absmax(k) / 240), same for v (fp8 KV-cache scale tracking,
  * backend/scale_update.rs:81-105); k, v: num_elements values of the named dtype */
 void update_kv_scales_f32(void *k, void *v, const long num_elements, float *k_scales, float *v_scales, int64_t stream);

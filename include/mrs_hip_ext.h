@@ -128,10 +128,12 @@ typedef struct {
   int32_t max_blocks_per_seq;
   int32_t max_batch;          /* decode batch capacity (<= 8) */
   int32_t max_context_len;
-  int32_t use_fused;          /* 1: ext_decode fused kernels when the weight types allow; 0: reference launch sequence */
+  int32_t use_fused;          /* 2: decode engine (ext_dec.hip: reference CPU-path arithmetic, needs mrs_llama_set_dec_tensor for every linear);
+                                 1: round-1 fused kernels (Q8_1 activations, bit-identical to the drop-in launch sequence); 0: reference launch sequence */
   int32_t world_size, rank;   /* tensor parallel (1, 0 = single GPU) */
   int32_t num_experts;        /* 0 = dense FFN; > 0: Mixtral-style sparse MoE FFN in every layer (models/mixtral.rs:236-304) */
   int32_t num_experts_per_tok; /* top-k of the router (softmax over all experts -> top-k -> renormalise) */
+  int32_t kv_f16;             /* decode engine only: 1 = f16 KV pages (the reference CPU path's default KV dtype, kv_cache/mod.rs:66-89), 0 = bf16 */
 } mrs_llama_config;
 
 typedef struct {  /* all device pointers, owned by the caller */
@@ -151,6 +153,9 @@ typedef struct {  /* all device pointers, owned by the caller */
 } mrs_llama_buffers;
 
 size_t mrs_llama_workspace_bytes(const mrs_llama_config *cfg);
+/* decode-layout copy (mrs_dec_repack output, caller-owned) of a linear tensor already registered with mrs_llama_set_tensor */
+int mrs_llama_set_dec_tensor(void *model, const char *name, const void *planes);
+int mrs_llama_set_mode(void *model, int use_fused); /* switch the decode path (values of mrs_llama_config.use_fused) */
 void *mrs_llama_create(const mrs_llama_config *cfg);
 void mrs_llama_destroy(void *model);
 /* name = GGUF tensor name ("token_embd.weight", "blk.3.attn_q.weight", "output_norm.weight", ...: the binding table of

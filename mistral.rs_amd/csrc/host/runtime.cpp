@@ -159,6 +159,8 @@ static int try_fused_quantized_gate_up(const QuantMethod &g, const QuantMethod &
 // ---------------------------------------------------------------------------------------------- model
 struct Block {
   std::unique_ptr<GgufMatMul> q_proj, k_proj, v_proj, o_proj, gate_proj, up_proj, down_proj;
+  // decode-layout copies (mrs_dec_repack) for the decode engine; planes == nullptr until mrs_llama_set_dec_tensor
+  mrs_dec_mat dq{}, dk{}, dv{}, dout{}, dgate{}, dup{}, ddown{}, dgate_exps{}, dup_exps{}, ddown_exps{};
   // sparse MoE FFN (cfg.num_experts > 0): router [E][hidden] f32 + experts stacked along the row axis, [E * n][k] packed blocks
   const float *router = nullptr;
   QTensor gate_exps, up_exps, down_exps;
@@ -176,6 +178,7 @@ struct Workspace {  // carve-up of the caller's scratch
   int32_t *moe_ids;         // [B][top_k]
   float *moe_w;             // [B][top_k]
   void *moe_y;              // [top_k] Q8_1 rows of the selected experts' activations
+  float *moe_act;           // decode engine: [top_k][intermediate] f32 activations of the selected experts
 };
 
 class Llama {
@@ -184,6 +187,7 @@ class Llama {
   mrs_llama_config cfg;
   std::vector<Block> blocks;
   std::unique_ptr<GgufMatMul> wte, lm_head;
+  mrs_dec_mat dlm_head{};
   const float *ln_f = nullptr;
   mrs_llama_buffers bufs{};
   Workspace ws{};
@@ -214,6 +218,7 @@ class Llama {
     if (c.num_experts > 0) {
       const size_t k = std::max(1, (int)c.num_experts_per_tok);
       t += align(B * k * 4) * 2 + align(k * (pad_to(c.intermediate_size, MATRIX_ROW_PADDING) / 32) * 36);
+      t += align(k * (size_t)c.intermediate_size * 4);
     }
     return t + 4096;
   }
@@ -240,6 +245,7 @@ class Llama {
       const size_t k = std::max(1, (int)cfg.num_experts_per_tok);
       ws.moe_ids = (int32_t *)take(B * k * 4); ws.moe_w = (float *)take(B * k * 4);
       ws.moe_y = take(k * (pad_to(cfg.intermediate_size, MATRIX_ROW_PADDING) / 32) * 36);
+      ws.moe_act = (float *)take(k * (size_t)cfg.intermediate_size * 4);
     }
     // zero once: Q8_1 padding blocks beyond K are never written by the fused epilogues; sample scratch must start at 0
     if (hipMemset(b.workspace, 0, b.workspace_bytes) != hipSuccess) return fail("hipMemset(workspace) failed");
@@ -263,7 +269,7 @@ class Llama {
   }
 
   bool fused_ok() const {
-    if (!cfg.use_fused || !cfg.rope_interleaved) return false;
+    if (cfg.use_fused != 1 || !cfg.rope_interleaved) return false;
     auto hot = [](const std::unique_ptr<GgufMatMul> &m) { return mrs_decode_gemv_supported(m->get_qtensor()->dtype) != 0; };
     if (!hot(lm_head)) return false;
     for (const Block &bl : blocks) {
@@ -388,6 +394,66 @@ class Llama {
     const QTensor *lm = lm_head->get_qtensor();
     if (!(ab & 32) && mrs_decode_norm_proj(lm->data, lm->dtype, cfg.vocab_size, d, ws.h, ln_f, cfg.rms_eps, bufs.logits, cfg.vocab_size, b, s))
       return fail("mrs_decode_norm_proj refused");
+    return 0;
+  }
+
+  // ---- decode engine (ext_dec.hip): the reference CPU path's arithmetic -- f32 activations quantized to Q8_K / Q8_0 inside the GEMV
+  //      kernels (candle QMatMul::forward, gguf/mod.rs:465-478), f32 norm / RoPE / SiLU / softmax -- over decode-layout weights
+  bool engine_ok() const {
+    if (cfg.use_fused != 2 || !cfg.rope_interleaved || cfg.head_dim != 128 || cfg.block_size != 32 || (cfg.head_dim & 1)) return false;
+    const int g = cfg.num_heads / cfg.num_kv_heads;
+    if (g != 1 && g != 2 && g != 4 && g != 8) return false;
+    if (!dlm_head.planes) return false;
+    for (const Block &bl : blocks) {
+      if (!bl.dq.planes || !bl.dk.planes || !bl.dv.planes || !bl.dout.planes) return false;
+      if ((bl.dq.type == Q8_0) != (bl.dk.type == Q8_0) || (bl.dq.type == Q8_0) != (bl.dv.type == Q8_0)) return false;  // one activation format per phase
+      if (cfg.num_experts > 0) {
+        if (!bl.dgate_exps.planes || !bl.dup_exps.planes || !bl.ddown_exps.planes || bl.dgate_exps.type != bl.dup_exps.type) return false;
+      } else if (!bl.dgate.planes || !bl.dup.planes || !bl.ddown.planes || bl.dgate.type != bl.dup.type) return false;
+    }
+    return true;
+  }
+  int forward_engine(int b, hipStream_t s) const {
+    const float rs = 1.0f / (float)std::max(1, (int)cfg.world_size);
+    const int d = cfg.hidden_size, hd = cfg.head_dim, nq = cfg.num_heads * hd, ff = cfg.intermediate_size, kvd = cfg.kv_f16 ? 0 : 1;
+    const int bs = cfg.block_size, kvh = cfg.num_kv_heads;
+    const int eff_max = std::min(cfg.max_blocks_per_seq * bs, cfg.max_context_len);
+    if (wte->embedding_forward_raw(bufs.input_ids, b, ws.h, s)) return -1;
+    for (const Block &bl : blocks) {
+      if (mrs_dec_qkv(&bl.dq, &bl.dk, &bl.dv, ws.h, d, bl.input_layernorm, cfg.rms_eps, ws.q, bl.key_cache, bl.value_cache, bufs.slot_mapping, bufs.positions,
+                      bufs.cos_table, bufs.sin_table, hd, cfg.rot_dim / 2, kvh, bs, kvd, b, s))
+        return fail("mrs_dec_qkv refused the layer");
+      if (mrs_decode_attention_f32_f32_bf16(ws.attn, ws.exp_sums, ws.max_logits, ws.attn_ws, ws.q, bl.key_cache, bl.value_cache, kvh, 1.0f / sqrtf((float)hd),
+                                            bufs.block_tables, bufs.context_lens, bs, eff_max, b, cfg.num_heads, hd, cfg.max_blocks_per_seq, nq, kvh * hd * bs,
+                                            hd * bs, kvd, s))
+        return fail("mrs_decode_attention_f32 refused the shape");
+      // TP: h <- h / world + W_o . attn on every rank, then ONE sum all-reduce of h (the residual add stays fused, as in forward_fused)
+      if (mrs_dec_proj(&bl.dout, d, nullptr, ws.attn, nq, nullptr, 0.f, ws.h, d, 1, rs, nullptr, b, s) || all_reduce(ws.h, (size_t)b * d, s))
+        return fail("o_proj failed: %s", g_last_error.c_str());
+      if (cfg.num_experts > 0) {
+        // SparseMoeBlock::forward (models/mixtral.rs:280-304): router on the normed hidden state; per token the top-k experts' gate/up then down,
+        // accumulated into h with the renormalised routing weights; expert ids / weights stay on the device
+        if (cfg.world_size > 1) return fail("tensor-parallel MoE is not supported yet");
+        const int E = cfg.num_experts, tk = cfg.num_experts_per_tok;
+        mrs_rms_norm_f32(ws.h, bl.post_attention_layernorm, ws.xn, b, d, cfg.rms_eps, (int64_t)(intptr_t)s);
+        if (mrs_moe_router_topk(ws.xn, bl.router, b, E, d, tk, 1, ws.moe_ids, ws.moe_w, nullptr, s)) return fail("moe router refused (experts %d, top-k %d)", E, tk);
+        for (int t = 0; t < b; ++t) {
+          float *ht = ws.h + (size_t)t * d;
+          for (int sl = 0; sl < tk; ++sl)  // all of a token's expert activations are computed before h changes
+            if (mrs_dec_gate_up(&bl.dgate_exps, &bl.dup_exps, ff, ws.moe_ids + t * tk + sl, ht, d, bl.post_attention_layernorm, cfg.rms_eps, 0,
+                                ws.moe_act + (size_t)sl * ff, ff, 1, s))
+              return fail("moe gate/up refused");
+          for (int sl = 0; sl < tk; ++sl)
+            if (mrs_dec_proj(&bl.ddown_exps, d, ws.moe_ids + t * tk + sl, ws.moe_act + (size_t)sl * ff, ff, nullptr, 0.f, ht, d, 1, 1.0f, ws.moe_w + t * tk + sl, 1, s))
+              return fail("moe down refused");
+        }
+        continue;
+      }
+      if (mrs_dec_gate_up(&bl.dgate, &bl.dup, ff, nullptr, ws.h, d, bl.post_attention_layernorm, cfg.rms_eps, 0, ws.act, ff, b, s)) return fail("mrs_dec_gate_up refused");
+      if (mrs_dec_proj(&bl.ddown, d, nullptr, ws.act, ff, nullptr, 0.f, ws.h, d, 1, rs, nullptr, b, s) || all_reduce(ws.h, (size_t)b * d, s))
+        return fail("down_proj failed: %s", g_last_error.c_str());
+    }
+    if (mrs_dec_proj(&dlm_head, cfg.vocab_size, nullptr, ws.h, d, ln_f, cfg.rms_eps, bufs.logits, cfg.vocab_size, 0, 1.0f, nullptr, b, s)) return fail("lm_head refused");
     return 0;
   }
 
@@ -583,6 +649,10 @@ class Llama {
 
   int forward_logits(int b, hipStream_t s) const {
     if (check_ready(b)) return -1;
+    if (cfg.use_fused == 2) {  // the engine never falls back silently: its arithmetic (Q8_K activations) differs from the Q8_1 paths
+      if (!engine_ok()) return fail("decode engine: needs interleaved RoPE, head_dim 128, block 32, q4_k/q5_k/q6_k/q8_0 linears and a decode-layout copy of every linear");
+      return forward_engine(b, s);
+    }
     if (cfg.num_experts > 0 && !fused_ok()) return fail("MoE layers need the fused decode path (interleaved RoPE, q4_k/q5_k/q6_k/q8_0 weights, use_fused)");
     return fused_ok() ? forward_fused(b, s) : forward_unfused(b, s);
   }
@@ -681,6 +751,39 @@ extern "C" void *mrs_llama_create(const mrs_llama_config *cfg) {
 extern "C" void mrs_llama_destroy(void *m) { delete (Llama *)m; }
 extern "C" int mrs_llama_set_tensor(void *m, const char *name, const void *p, int type, int64_t rows, int64_t cols) {
   return mrs_host::bind_tensor(*(Llama *)m, name, p, type, rows, cols);
+}
+extern "C" int mrs_llama_set_dec_tensor(void *mm, const char *cname, const void *planes) {
+  Llama &m = *(Llama *)mm;
+  const std::string name = cname;
+  auto bind = [&](mrs_dec_mat &slot, const mrs_host::QTensor *t) {
+    if (!t || !t->data) return mrs_host::fail("decode layout for %s: register the tensor with mrs_llama_set_tensor first", cname);
+    if (!mrs_dec_repack_bytes(t->dtype, t->rows, t->cols)) return mrs_host::fail("decode layout for %s: ggml dtype %d / shape not supported", cname, t->dtype);
+    slot = mrs_dec_mat{planes, t->dtype, (long long)t->rows, (long long)t->cols};
+    return 0;
+  };
+  auto lin = [&](mrs_dec_mat &slot, const std::unique_ptr<mrs_host::GgufMatMul> &l) { return bind(slot, l ? l->get_qtensor() : nullptr); };
+  if (name == "output.weight") return lin(m.dlm_head, m.lm_head);
+  int layer = -1, consumed = 0;
+  if (sscanf(cname, "blk.%d.%n", &layer, &consumed) == 1 && consumed > 0 && layer >= 0 && layer < m.cfg.num_layers) {
+    mrs_host::Block &b = m.blocks[layer];
+    const std::string rest = name.substr(consumed);
+    if (rest == "attn_q.weight") return lin(b.dq, b.q_proj);
+    if (rest == "attn_k.weight") return lin(b.dk, b.k_proj);
+    if (rest == "attn_v.weight") return lin(b.dv, b.v_proj);
+    if (rest == "attn_output.weight") return lin(b.dout, b.o_proj);
+    if (rest == "ffn_gate.weight") return lin(b.dgate, b.gate_proj);
+    if (rest == "ffn_up.weight") return lin(b.dup, b.up_proj);
+    if (rest == "ffn_down.weight") return lin(b.ddown, b.down_proj);
+    if (rest == "ffn_gate_exps.weight") return bind(b.dgate_exps, &b.gate_exps);
+    if (rest == "ffn_up_exps.weight") return bind(b.dup_exps, &b.up_exps);
+    if (rest == "ffn_down_exps.weight") return bind(b.ddown_exps, &b.down_exps);
+  }
+  return mrs_host::fail("decode layout: tensor %s has no decode-engine role", cname);
+}
+extern "C" int mrs_llama_set_mode(void *m, int use_fused) {
+  if (use_fused < 0 || use_fused > 2) return mrs_host::fail("mrs_llama_set_mode: 0, 1 or 2");
+  ((Llama *)m)->cfg.use_fused = use_fused;
+  return 0;
 }
 extern "C" int mrs_llama_set_kv_cache(void *m, int layer, void *k, void *v) {
   Llama &l = *(Llama *)m;

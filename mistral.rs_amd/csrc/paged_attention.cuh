@@ -352,7 +352,9 @@ __global__ void __launch_bounds__(HD) paged_attention_reduce_q8_1_kernel(uint8_t
 //   * K and V loads of a block are issued together, before any arithmetic;
 //   * output: un-normalised partial o[g][d], running max m[g] and sum l[g] per (seq, head, split) for the merge kernel.
 // Semantics = pagedattention.cuh:110-486 with f32 probabilities rounded to the KV dtype before P.V (ROUND_P).
-template <int G>
+// CT: element type of the pages (bf16_t / f16_t); ROUND_P: probabilities rounded to CT before P.V (the reference GPU kernels, pagedattention.cuh:381-384)
+// or kept in f32 (the reference CPU path, attention/backends/cpu/single_q.rs -- the decode engine's arithmetic)
+template <int G, class CT = bf16_t, bool ROUND_P = true>
 __global__ void __launch_bounds__(256) decode_attn_wave_kernel(const float *__restrict__ q, const uint16_t *__restrict__ k_cache,
                                                                const uint16_t *__restrict__ v_cache, const uint32_t *__restrict__ block_tables,
                                                                const uint32_t *__restrict__ context_lens, float *__restrict__ part_o,
@@ -396,7 +398,7 @@ __global__ void __launch_bounds__(256) decode_attn_wave_kernel(const float *__re
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       float kf[8];
-      unpack16<bf16_t>(kr[c], kf);
+      unpack16<CT>(kr[c], kf);
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         const float4 qa = *(const float4 *)(q_s[wave] + g * HD + (half * 8 + c) * 8);
@@ -416,7 +418,7 @@ __global__ void __launch_bounds__(256) decode_attn_wave_kernel(const float *__re
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       const float mn = fmaxf(m[g], mx);
       const float p = valid ? __expf(v - mn) : 0.f;
-      const float pr = bf16_bits_to_float(float_to_bf16_bits(p));  // reference: probabilities cast to the KV dtype before P.V
+      const float pr = ROUND_P ? round_to<CT>(p) : p;  // reference GPU kernels: probabilities cast to the KV dtype before P.V
       float ps = p;
       ps += dpp_f<0xB1>(ps); ps += dpp_f<0x4E>(ps); ps += dpp_f<0x141>(ps); ps += dpp_f<0x140>(ps);
       ps += __shfl_xor(ps, 16, 64);
@@ -432,7 +434,7 @@ __global__ void __launch_bounds__(256) decode_attn_wave_kernel(const float *__re
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         float vf[8];
-        unpack16<bf16_t>(vr[r * 4 + c], vf);
+        unpack16<CT>(vr[r * 4 + c], vf);
 #pragma unroll
         for (int j = 0; j < 8; ++j) vf[j] = (b * BS + c * 8 + j < ctx) ? vf[j] : 0.f;  // stale slots may hold NaNs
 #pragma unroll
@@ -458,7 +460,8 @@ __global__ void __launch_bounds__(256) decode_attn_wave_kernel(const float *__re
 
 // merge of the per-split partials + Q8_1 quantisation of the attention output (o_proj's activation format).
 // grid (heads, seqs), 128 threads (thread = head dim)
-template <int HD>
+// F32OUT: y = float [seqs][heads * HD] (decode engine: the o_proj prologue quantizes); else Q8_1 blocks
+template <int HD, bool F32OUT = false>
 __global__ void __launch_bounds__(HD) decode_attn_merge_q8_1_kernel(uint8_t *__restrict__ y, int stride_blocks, const float *__restrict__ part_o,
                                                                      const float *__restrict__ part_m, const float *__restrict__ part_l,
                                                                      const uint32_t *__restrict__ context_lens, int bpw, int max_splits) {
@@ -491,6 +494,10 @@ __global__ void __launch_bounds__(HD) decode_attn_merge_q8_1_kernel(uint8_t *__r
   for (; j < ns; ++j) a0 = fmaf(po[(size_t)j * HD], r_s[j], a0);
   const float acc = (a0 + a1) + (a2 + a3);
   const float v = acc * (1.0f / (gs + 1e-6f));
+  if constexpr (F32OUT) {
+    ((float *)y)[((size_t)seq * num_heads + head) * HD + i] = v;
+    return;
+  }
   float amax = fabsf(v), sum = v;
 #pragma unroll
   for (int mk = 16; mk > 0; mk >>= 1) { amax = fmaxf(amax, __shfl_xor(amax, mk, 64)); sum += __shfl_xor(sum, mk, 64); }

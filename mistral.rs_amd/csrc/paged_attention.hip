@@ -215,6 +215,33 @@ extern "C" int PA_CAT(mrs_decode_attention_q8_1_, MRS_PA_TAG)(
   pa_check("mrs_decode_attention_q8_1");
   return 0;
 }
+// Decode engine: same split-KV kernel with f32 probabilities (the reference CPU path keeps them in f32) and an f32 result
+// out [seqs][heads * head_size]; kv_dtype 1 = bf16 pages, 0 = f16 pages.  head_size 128, block 32, GQA group 1 / 2 / 4 / 8.
+extern "C" int PA_CAT(mrs_decode_attention_f32_, MRS_PA_TAG)(
+    float *out, float *exp_sums, float *max_logits, void *tmp_out, const void *query, const void *key_cache, const void *value_cache, int num_kv_heads,
+    float scale, const uint32_t *block_tables, const uint32_t *context_lens, int block_size, int max_context_len, int num_seqs, int num_heads,
+    int head_size, int max_num_blocks_per_seq, int q_stride, int kv_block_stride, int kv_head_stride, int kv_dtype, void *stream) {
+  using namespace mrs;
+  if (block_size != 32 || head_size != 128 || num_seqs <= 0 || num_heads % num_kv_heads || (kv_dtype != 0 && kv_dtype != 1)) return -1;
+  const int qpk = num_heads / num_kv_heads;
+  if (qpk != 1 && qpk != 2 && qpk != 4 && qpk != 8) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  const int max_splits = mrs_decode_attention_max_splits(max_context_len);
+  const int bpw = dec_bpw(max_context_len);
+  const int nsplit = ((max_context_len + 31) / 32 + bpw - 1) / bpw;
+  const dim3 grid(num_kv_heads, num_seqs, (nsplit + 3) / 4);
+#define DEC(G, CT) hipLaunchKernelGGL((decode_attn_wave_kernel<G, CT, false>), grid, dim3(256), 0, s, (const float *)query, (const uint16_t *)key_cache,   \
+                                      (const uint16_t *)value_cache, block_tables, context_lens, (float *)tmp_out, max_logits, exp_sums, num_heads,        \
+                                      num_kv_heads, max_num_blocks_per_seq, q_stride, kv_block_stride, kv_head_stride, bpw, max_splits, scale)
+#define DECG(CT) switch (qpk) { case 1: DEC(1, CT); break; case 2: DEC(2, CT); break; case 4: DEC(4, CT); break; default: DEC(8, CT); break; }
+  if (kv_dtype == 1) { DECG(bf16_t) } else { DECG(f16_t) }
+#undef DECG
+#undef DEC
+  hipLaunchKernelGGL((decode_attn_merge_q8_1_kernel<128, true>), dim3(num_heads, num_seqs), dim3(128), 0, s, (uint8_t *)out, 0, (const float *)tmp_out,
+                     max_logits, exp_sums, context_lens, bpw, max_splits);
+  pa_check("mrs_decode_attention_f32");
+  return 0;
+}
 #endif
 
 #ifdef MRS_PA_EXPORT_ABI

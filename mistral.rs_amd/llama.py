@@ -43,6 +43,10 @@ class LlamaConfig:
     max_batch: int = 1
     max_context_len: int = 1024
     use_fused: bool = True
+    # decode engine (csrc/ext_dec.hip: the reference CPU path's arithmetic, Q8_K / Q8_0 activations).  None = whenever the model allows it
+    # (use_fused, interleaved RoPE, head_dim 128, block 32, q4_k / q5_k / q6_k / q8_0 linears); False = the round-1 fused kernels (Q8_1)
+    decode_engine: bool | None = None
+    kv_dtype: str = "bf16"  # "f16": the reference CPU path's default KV dtype (decode engine only; the MFMA prefill needs bf16 pages)
     tp_world_size: int = 1  # tensor parallel: num_heads / num_kv_heads / intermediate_size are the LOCAL (per-rank) sizes
     tp_rank: int = 0
     num_experts: int = 0           # > 0: Mixtral-style sparse MoE FFN in every layer (models/mixtral.rs:236-304)
@@ -101,7 +105,7 @@ class _Cfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("hidden_size", "intermediate_size", "num_layers", "num_heads", "num_kv_heads", "head_dim",
                                          "vocab_size", "rot_dim", "rope_interleaved")] + [("rms_eps", C.c_float)] + \
                [(n, C.c_int32) for n in ("block_size", "max_blocks_per_seq", "max_batch", "max_context_len", "use_fused", "world_size", "rank",
-                                         "num_experts", "num_experts_per_tok")]
+                                         "num_experts", "num_experts_per_tok", "kv_f16")]
 
 
 class _PrefillArgs(C.Structure):
@@ -143,23 +147,40 @@ class Llama:
         L.mrs_llama_prefill_flops.restype = C.c_double
         L.mrs_llama_prefill_flops.argtypes = [C.c_void_p, C.c_int]
         L.mrs_llama_set_comm.argtypes = [C.c_void_p, C.c_void_p]
+        L.mrs_llama_set_dec_tensor.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
+        L.mrs_llama_set_mode.argtypes = [C.c_void_p, C.c_int]
+        L.mrs_dec_repack_bytes.restype = C.c_size_t
+        L.mrs_dec_repack_bytes.argtypes = [C.c_int, C.c_longlong, C.c_longlong]
+        L.mrs_dec_repack.argtypes = [C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p]
         L.mrs_last_error.restype = C.c_char_p
         c = _Cfg(cfg.hidden_size, cfg.intermediate_size, cfg.num_layers, cfg.num_heads, cfg.num_kv_heads, cfg.head_dim,
                  cfg.vocab_size, cfg.head_dim, int(cfg.rope_interleaved), cfg.rms_eps, cfg.block_size, cfg.max_blocks_per_seq,
                  cfg.max_batch, cfg.max_context_len, int(cfg.use_fused), cfg.tp_world_size, cfg.tp_rank, cfg.num_experts,
-                 cfg.num_experts_per_tok if cfg.num_experts else 0)
+                 cfg.num_experts_per_tok if cfg.num_experts else 0, int(cfg.kv_dtype == "f16"))
         self._c = c
         self._h = L.mrs_llama_create(C.byref(c))
         if not self._h:
             raise ValueError(self._err())
         self._keep: dict = {}
+        if cfg.kv_dtype not in ("bf16", "f16"):
+            raise ValueError("kv_dtype must be bf16 or f16")
+        # decode engine: wanted unless switched off; possible while every linear registered so far has a decode layout
+        self._engine_wanted = cfg.decode_engine is not False and cfg.use_fused and cfg.rope_interleaved and cfg.head_dim == 128 and cfg.block_size == 32 \
+            and cfg.num_heads // cfg.num_kv_heads in (1, 2, 4, 8)
+        if cfg.decode_engine and not self._engine_wanted:
+            raise ValueError("decode_engine needs use_fused, interleaved RoPE, head_dim 128, block_size 32 and a GQA group of 1 / 2 / 4 / 8")
+        if cfg.kv_dtype == "f16" and not self._engine_wanted:
+            raise ValueError("f16 KV pages are a decode-engine feature")
+        self._engine_ok = self._engine_wanted
+        self._mode_set = None
         B, dev = cfg.max_batch, device
         # paged KV cache, bf16, reference layout (cache_engine.rs:458-484); blocks for max_batch full sequences
         self.num_blocks = B * cfg.max_blocks_per_seq
         x = 8
-        self.key_caches = [torch.zeros(self.num_blocks, cfg.num_kv_heads, cfg.head_dim // x, cfg.block_size, x, dtype=torch.bfloat16, device=dev)
+        kvt = torch.float16 if cfg.kv_dtype == "f16" else torch.bfloat16
+        self.key_caches = [torch.zeros(self.num_blocks, cfg.num_kv_heads, cfg.head_dim // x, cfg.block_size, x, dtype=kvt, device=dev)
                            for _ in range(cfg.num_layers)]
-        self.value_caches = [torch.zeros(self.num_blocks, cfg.num_kv_heads, cfg.head_dim, cfg.block_size, dtype=torch.bfloat16, device=dev)
+        self.value_caches = [torch.zeros(self.num_blocks, cfg.num_kv_heads, cfg.head_dim, cfg.block_size, dtype=kvt, device=dev)
                              for _ in range(cfg.num_layers)]
         for i, (k, v) in enumerate(zip(self.key_caches, self.value_caches)):
             self._chk(L.mrs_llama_set_kv_cache(self._h, i, k.data_ptr(), v.data_ptr()))
@@ -207,6 +228,18 @@ class Llama:
         if isinstance(t, QTensor):
             self._keep[name] = t
             self._chk(self._L.mrs_llama_set_tensor(self._h, name.encode(), t.data.data_ptr(), t.dtype.id, t.shape[0], t.shape[1]))
+            if self._engine_wanted and name != "token_embd.weight":
+                # decode layout (mrs_dec_repack): same bits in row-major planes, made once; the GGUF blocks stay for the prefill GEMMs
+                nb = self._L.mrs_dec_repack_bytes(t.dtype.id, t.shape[0], t.shape[1])
+                if nb == 0:
+                    if self.cfg.decode_engine:
+                        raise ValueError(f"decode engine: {name} has ggml dtype {t.dtype.name}; supported: Q4K Q5K Q6K Q8_0")
+                    self._engine_ok = False
+                else:
+                    planes = torch.empty(nb, dtype=torch.uint8, device=self.device)
+                    self._chk(self._L.mrs_dec_repack(t.data.data_ptr(), t.dtype.id, t.shape[0], t.shape[1], planes.data_ptr(), self._stream()))
+                    self._keep[name + "#dec"] = planes
+                    self._chk(self._L.mrs_llama_set_dec_tensor(self._h, name.encode(), planes.data_ptr()))
         else:
             t = t.to(self.device, torch.float32).contiguous()
             self._keep[name] = t
@@ -233,11 +266,26 @@ class Llama:
         self.context_lens[:b] = torch.tensor((pos + 1).astype(np.int32), device=self.device)
         self.slot_mapping[:b] = torch.tensor(slots, device=self.device)
 
+    @property
+    def decode_path(self) -> str:
+        """'engine' (ext_dec.hip, reference CPU-path arithmetic), 'fused' (round-1 kernels, Q8_1) or 'reference-sequence'."""
+        return "engine" if (self._engine_wanted and self._engine_ok) else ("fused" if self.cfg.use_fused else "reference-sequence")
+
+    def _set_mode(self) -> None:
+        mode = 2 if (self._engine_wanted and self._engine_ok) else int(bool(self.cfg.use_fused))
+        if mode != self._mode_set:
+            if self.cfg.kv_dtype == "f16" and mode != 2:
+                raise ValueError("f16 KV pages need the decode engine (a linear has a dtype it does not support)")
+            self._chk(self._L.mrs_llama_set_mode(self._h, mode))
+            self._mode_set = mode
+
     def forward_logits(self, b: int) -> torch.Tensor:
+        self._set_mode()
         self._chk(self._L.mrs_llama_forward_logits(self._h, b, self._stream()))
         return self.logits[:b]
 
     def decode_step(self, b: int = 1) -> None:
+        self._set_mode()
         self._chk(self._L.mrs_llama_decode_step(self._h, b, self._stream()))
 
     def capture_decode_graph(self, b: int = 1) -> None:
@@ -267,6 +315,8 @@ class Llama:
         (PagedAttention::forward try_regular_prompt + reshape_and_cache, paged_attention.rs:1413-1475)."""
         cfg, dev = self.cfg, self.device
         T = len(tokens)
+        if cfg.kv_dtype != "bf16":
+            raise ValueError("the MFMA prefill reads and writes bf16 KV pages; use prefill_chunked() with f16 pages")
         if start_pos + T > cfg.max_context_len:
             raise ValueError("prompt does not fit max_context_len")
         pos = torch.arange(start_pos, start_pos + T, dtype=torch.int32, device=dev)

@@ -69,30 +69,30 @@ def main():
 
     def ph_qkv(i):
         ws = (make(Q4, nq, d, 3 * i), make(Q4, nkv, d, 3 * i + 1), make(Q6, nkv, d, 3 * i + 2))
-        new = lambda: L.mrs_dec_qkv(C.byref(ws[0][2]), C.byref(ws[1][2]), C.byref(ws[2][2]), h.data_ptr(), d, nw.data_ptr(), 1e-5, q_out.data_ptr(), kc.data_ptr(), vc.data_ptr(),
+        new = lambda st: L.mrs_dec_qkv(C.byref(ws[0][2]), C.byref(ws[1][2]), C.byref(ws[2][2]), h.data_ptr(), d, nw.data_ptr(), 1e-5, q_out.data_ptr(), kc.data_ptr(), vc.data_ptr(),
                                     slots.data_ptr(), pos.data_ptr(), cos.data_ptr(), sin.data_ptr(), hd, hd // 2, 8, 32, 1, b, st)
-        old = lambda: L.mrs_decode_qkv(ws[0][0].data.data_ptr(), ws[1][0].data.data_ptr(), ws[2][0].data.data_ptr(), 12, 12, 14, nq, nkv, nkv, d, h.data_ptr(), nw.data_ptr(), 1e-5,
+        old = lambda st: L.mrs_decode_qkv(ws[0][0].data.data_ptr(), ws[1][0].data.data_ptr(), ws[2][0].data.data_ptr(), 12, 12, 14, nq, nkv, nkv, d, h.data_ptr(), nw.data_ptr(), 1e-5,
                                        q_out.data_ptr(), kc.data_ptr(), vc.data_ptr(), slots.data_ptr(), pos.data_ptr(), cos.data_ptr(), sin.data_ptr(), hd, hd // 2, 8, 32, b, st)
         return ws, new, old, nbytes(*[w[0] for w in ws])
 
     def ph_proj(dt, n, k, x, ldx, ybuf, stride):
         def f(i):
             ws = (make(dt, n, k, 100 + i),)
-            new = lambda: L.mrs_dec_proj(C.byref(ws[0][2]), n, None, x.data_ptr(), ldx, None, 0.0, h.data_ptr(), d, 1, 1.0, None, b, st)
-            old = lambda: L.mrs_decode_proj(ws[0][0].data.data_ptr(), dt.id, n, k, ybuf.data_ptr(), stride, h.data_ptr(), d, 1, b, st)
+            new = lambda st: L.mrs_dec_proj(C.byref(ws[0][2]), n, None, x.data_ptr(), ldx, None, 0.0, h.data_ptr(), d, 1, 1.0, None, b, st)
+            old = lambda st: L.mrs_decode_proj(ws[0][0].data.data_ptr(), dt.id, n, k, ybuf.data_ptr(), stride, h.data_ptr(), d, 1, b, st)
             return ws, new, old, nbytes(ws[0][0])
         return f
 
     def ph_gate_up(i):
         ws = (make(Q4, ff, d, 200 + 2 * i), make(Q4, ff, d, 201 + 2 * i))
-        new = lambda: L.mrs_dec_gate_up(C.byref(ws[0][2]), C.byref(ws[1][2]), ff, None, h.data_ptr(), d, nw.data_ptr(), 1e-5, 0, act.data_ptr(), ff, b, st)
-        old = lambda: L.mrs_decode_gate_up(ws[0][0].data.data_ptr(), ws[1][0].data.data_ptr(), 12, ff, d, h.data_ptr(), nw.data_ptr(), 1e-5, 0, yb.data_ptr(), 14336 // 32, b, st)
+        new = lambda st: L.mrs_dec_gate_up(C.byref(ws[0][2]), C.byref(ws[1][2]), ff, None, h.data_ptr(), d, nw.data_ptr(), 1e-5, 0, act.data_ptr(), ff, b, st)
+        old = lambda st: L.mrs_decode_gate_up(ws[0][0].data.data_ptr(), ws[1][0].data.data_ptr(), 12, ff, d, h.data_ptr(), nw.data_ptr(), 1e-5, 0, yb.data_ptr(), 14336 // 32, b, st)
         return ws, new, old, nbytes(ws[0][0], ws[1][0])
 
     def ph_lm(i):
         ws = (make(Q6, 128256, d, 300 + i),)
-        new = lambda: L.mrs_dec_proj(C.byref(ws[0][2]), 128256, None, h.data_ptr(), d, nw.data_ptr(), 1e-5, logits.data_ptr(), 128256, 0, 1.0, None, b, st)
-        old = lambda: L.mrs_decode_norm_proj(ws[0][0].data.data_ptr(), 14, 128256, d, h.data_ptr(), nw.data_ptr(), 1e-5, logits.data_ptr(), 128256, b, st)
+        new = lambda st: L.mrs_dec_proj(C.byref(ws[0][2]), 128256, None, h.data_ptr(), d, nw.data_ptr(), 1e-5, logits.data_ptr(), 128256, 0, 1.0, None, b, st)
+        old = lambda st: L.mrs_decode_norm_proj(ws[0][0].data.data_ptr(), 14, 128256, d, h.data_ptr(), nw.data_ptr(), 1e-5, logits.data_ptr(), 128256, b, st)
         return ws, new, old, nbytes(ws[0][0])
 
     table = {"qkv": ph_qkv, "o": ph_proj(Q4, d, nq, attn, nq, ya, 4096 // 32), "gate_up": ph_gate_up, "down4": ph_proj(Q4, d, ff, act, ff, yb, 14336 // 32),
@@ -107,13 +107,26 @@ def main():
         for which in (("new", 1),) + ((("old", 2),) if a.old else ()):
             fns = [inst[which[1]] for inst in insts]
             for f in fns:
-                assert f() == 0
+                assert f(torch.cuda.current_stream().cuda_stream) == 0
+            torch.cuda.synchronize()
+            # one HIP graph over all buffers: the figure is GPU time (kernel + boundary), not the host's launch rate
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for f in fns:
+                    f(side.cuda_stream)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for f in fns:
+                    f(torch.cuda.current_stream().cuda_stream)
+            g.replay()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(a.reps):
-                for f in fns:
-                    f()
+                g.replay()
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / (a.reps * len(fns))

@@ -26,7 +26,8 @@ def _mk(oracle, dev, use_fused, types, hd=64, heads=4, kvh=2, layers=2, hidden=2
     from oracle import llama_ref
     cfg = LlamaConfig(hidden_size=hidden, intermediate_size=ff, num_layers=layers, num_heads=heads, num_kv_heads=kvh,
                       vocab_size=vocab, head_dim=hd, rope_theta=10000.0, max_position_embeddings=256, max_batch=max_batch,
-                      max_context_len=192, use_fused=use_fused, num_experts=experts, num_experts_per_tok=top_k)
+                      max_context_len=192, use_fused=use_fused, decode_engine=False,  # this file covers the round-1 fused kernels (Q8_1); the decode engine: tests/test_dec_model.py
+                      num_experts=experts, num_experts_per_tok=top_k)
     w = llama_ref.synth_weights(cfg, types, seed=seed)
     m = Llama(cfg, dev, max_new_tokens=64)
     for name, val in w.items():
