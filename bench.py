@@ -79,6 +79,8 @@ def cpu_baseline(model, cfg, budget_s=12.0):
     O.build()
     w = {}
     for name, t in model._keep.items():
+        if "#" in name:  # decode-layout copies of the same tensors
+            continue
         if hasattr(t, "dtype") and hasattr(t, "shape") and not hasattr(t, "data_ptr"):  # QTensor
             w[name] = (t.dtype.id, t.data.cpu().numpy().reshape(t.shape[0], -1))
         else:

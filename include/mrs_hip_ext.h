@@ -57,6 +57,29 @@ int mrs_dec_gate_up(const mrs_dec_mat *wg, const mrs_dec_mat *wu, int n, const i
 /* (RmsNorm when norm_w) + GEMV; mode 0: out = W x; mode 1: out = out * resid_scale + s * W x with s = *acc_scale (NULL: 1) */
 int mrs_dec_proj(const mrs_dec_mat *w, int n, const int32_t *expert_sel, const float *x, int ldx, const float *norm_w, float eps, float *out,
                  int ld_out, int mode, float resid_scale, const float *acc_scale, int b, void *stream);
+/* Persistent decode step: ONE launch runs phases [phase_begin, phase_end) of a decode step for one sequence (b = 1) on a grid of resident
+ * workgroups (one per CU) with device-side phase barriers; the weight stream of a phase starts before the barrier in front of it completes.
+ * Phase ids: 0 = embedding, 1 + 6 l + {0 qkv, 1 attention splits, 2 attention merge, 3 o_proj, 4 gate/up, 5 down}, 1 + 6 L = final norm + lm_head.
+ * Same arithmetic and bits as the launch-per-phase calls above (mrs_dec_qkv, mrs_decode_attention_f32_*, mrs_dec_proj, mrs_dec_gate_up).
+ * Returns 0; -3 = shape / batch outside the persistent kernel (use the per-phase calls); -1 = bad arguments. */
+typedef struct { mrs_dec_mat q, k, v, o, gate, up, down; const float *attn_norm, *ffn_norm; void *k_cache, *v_cache; } mrs_dec_layer;
+typedef struct {
+  int num_layers;
+  mrs_dec_mat lm_head; const float *final_norm;
+  const void *embd; int embd_type;              /* token_embd.weight as registered (GGUF blocks or f32 / f16 / bf16) */
+  const int32_t *input_ids;
+  float *h, *q, *attn, *act, *logits, *part_o, *part_m, *part_l; /* h [hidden], q / attn [heads * 128], act [ffn], logits [vocab]; attention partials as mrs_decode_attention_* */
+  const uint32_t *block_tables, *context_lens; const int32_t *positions; const int64_t *slot_mapping; const float *cos_t, *sin_t;
+  int hidden, num_heads, num_kv_heads, head_dim, rot_pairs, ff, vocab, block_size, max_blocks_per_seq, max_context_len;
+  float eps, resid_scale;
+  int kv_dtype;                                 /* 1 = bf16 pages, 0 = f16 */
+} mrs_dec_step_args;
+size_t mrs_dec_step_table_bytes(int num_layers);
+int mrs_dec_step_num_phases(int num_layers);
+/* host -> device phase table of a model (blocking copy, load-time); all pointers must outlive the table */
+int mrs_dec_build_step_table(const mrs_dec_step_args *args, const mrs_dec_layer *layers, void *device_table);
+/* sync: 8 bytes of device memory (arrival counter, error flag: non-zero after a launch = the grid was not resident); max_k = longest GEMV row */
+int mrs_dec_step(const void *device_table, int num_layers, int max_k, void *sync, int phase_begin, int phase_end, void *stream);
 /* quantized (or f32/f16/bf16) embedding rows -> f32; role of QuantMethod::embedding_forward (lib.rs:1561, gguf/mod.rs:436) */
 int mrs_embedding(const void *table, int type, const int32_t *ids, float *out, int K, int tokens, void *stream);
 /* f32 rows -> Q8_1 blocks: same bytes as launch_mmvq_gguf_quantize_q8_1_f32 with kx_padded = 32*stride_blocks */
@@ -155,6 +178,7 @@ typedef struct {  /* all device pointers, owned by the caller */
 size_t mrs_llama_workspace_bytes(const mrs_llama_config *cfg);
 /* decode-layout copy (mrs_dec_repack output, caller-owned) of a linear tensor already registered with mrs_llama_set_tensor */
 int mrs_llama_set_dec_tensor(void *model, const char *name, const void *planes);
+int mrs_llama_set_dec_persist(void *model, int mode); /* decode engine, b = 1: 1 = one persistent launch per step (default), 2 = same kernel phase by phase, 0 = per-phase kernels */
 int mrs_llama_set_mode(void *model, int use_fused); /* switch the decode path (values of mrs_llama_config.use_fused) */
 void *mrs_llama_create(const mrs_llama_config *cfg);
 void mrs_llama_destroy(void *model);

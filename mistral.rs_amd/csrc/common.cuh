@@ -5,6 +5,9 @@
 #include <stdint.h>
 
 #define MRS_WAVE 64
+#ifndef MRS_WAVE_SYNC
+#define MRS_WAVE_SYNC() __builtin_amdgcn_wave_barrier() /* lanes of a wave exchange through LDS in lockstep; the host emulation maps this to a fiber sync */
+#endif
 
 namespace mrs {
 
@@ -70,6 +73,13 @@ __device__ __forceinline__ uint16_t float_to_half_bits(float f) {
 
 // ---------------------------------------------------------------------------------- wave ops
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// Thread id the optimiser cannot look through: the persistent decode step runs ~20 phase bodies inside one loop; with a plain threadIdx.x
+// hipcc hoists every phase's lane-constant address arithmetic out of that loop and keeps it live in VGPRs across all phases (spills).
+#ifndef MRS_OPAQUE_TID
+#define MRS_OPAQUE_TID(t) asm volatile("" : "+v"(t))
+#endif
+__device__ __forceinline__ int tid_opaque() { int t = (int)threadIdx.x; MRS_OPAQUE_TID(t); return t; }
+__device__ __forceinline__ int lane_opaque() { return tid_opaque() & 63; }
 
 template <class T> __device__ __forceinline__ T wave_sum(T x) {
 #pragma unroll

@@ -104,7 +104,7 @@ template <bool SC1> __device__ __forceinline__ v4u ld_act(__amdgpu_buffer_rsrc_t
 }
 template <bool SC1> __device__ __forceinline__ ActPre act_issue(const float *x, const float *nw, int K) {
   ActPre p;
-  const unsigned off = threadIdx.x * 16u;
+  const unsigned off = (unsigned)tid_opaque() * 16u;
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)x, (short)0, K * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)(nw ? nw : x), (short)0, nw ? K * 4 : 0, 0x00020000);
 #pragma unroll
@@ -140,7 +140,7 @@ __device__ __forceinline__ float wave_sum_all(float v) {
 
 // quantize the 4 values a lane holds at element e (all lanes of the wave together: one 256-block in Q8_K mode, 8 blocks of 32 in Q8_0 mode)
 __device__ __forceinline__ void quantize4(float4 v, int e, bool in, int mode, char *qc, float *dc, int *bsc) {
-  const int lane = lane_id();
+  const int lane = lane_opaque();
   if (mode == ACT_Q8K) {
     const float ax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
     const float amax = wave_max_all(ax);
@@ -183,7 +183,7 @@ __device__ __forceinline__ void quantize4(float4 v, int e, bool in, int mode, ch
 template <int NCOLS, bool SC1>
 __device__ __forceinline__ Act act_finish(char *smem, float *red, const ActPre &pre, const float *__restrict__ x, int ldx, const float *__restrict__ nw, float eps,
                                           int K, int mode) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid = tid_opaque(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   char *q = smem;
   float *d = (float *)(smem + (size_t)NCOLS * K);
   int *bs = (int *)(d + (size_t)NCOLS * (K / 32));
@@ -237,8 +237,14 @@ __device__ __forceinline__ int mul24i(int a, int b) { return __mul24(a, b); }
 
 template <int TYPE> struct Tile;
 
+#ifndef MRS_DEC_DEPTH_Q4K
+#define MRS_DEC_DEPTH_Q4K 8
+#endif
+#ifndef MRS_DEC_DEPTH_Q6K
+#define MRS_DEC_DEPTH_Q6K 4
+#endif
 template <> struct Tile<T_Q4_K> {
-  static constexpr int DEPTH = 8, UNIT = 32;
+  static constexpr int DEPTH = MRS_DEC_DEPTH_Q4K, UNIT = 32;
   struct Raw { v4u q; unsigned hs, hd; };
   struct LaneC { int pa, pb, ra, sbl; };
   static __device__ __forceinline__ LaneC lanec(int lane) {
@@ -312,7 +318,7 @@ template <> struct Tile<T_Q5_K> {
 };
 
 template <> struct Tile<T_Q6_K> {
-  static constexpr int DEPTH = 4, UNIT = 64;
+  static constexpr int DEPTH = MRS_DEC_DEPTH_Q6K, UNIT = 64;
   struct Raw { v4u l0, l1, x; unsigned hs, hd; };
   struct LaneC { int pa0, pa1, pb0, pb1, ra, sbl; };
   static __device__ __forceinline__ LaneC lanec(int lane) {
@@ -357,8 +363,8 @@ template <> struct Tile<T_Q6_K> {
 template <> struct Tile<T_Q8_0> {
   static constexpr int DEPTH = 8, UNIT = 16;
   struct Raw { v4u q; unsigned hd; };
-  struct LaneC { int pa, odd; };
-  static __device__ __forceinline__ LaneC lanec(int lane) { return LaneC{(lane ^ sb_mask(lane >> 4)) * 16, lane & 1}; }
+  struct LaneC { int pa, odd, blk; };
+  static __device__ __forceinline__ LaneC lanec(int lane) { return LaneC{(lane ^ sb_mask(lane >> 4)) * 16, lane & 1, lane >> 1}; }
   static __device__ __forceinline__ Raw load(__amdgpu_buffer_rsrc_t rs, const Mat &m, unsigned row, int u, int S /* = K/16 units per row */, bool ok) {
     Raw r;
     r.q = ldb128(rs, ok ? (row * (unsigned)S + (unsigned)u) * 16u : OOB);
@@ -368,7 +374,7 @@ template <> struct Tile<T_Q8_0> {
   template <int NCOLS> static __device__ __forceinline__ void accumulate(const Raw &w, const LaneC &lc, int t, int S, const Act &act, float (&acc)[NCOLS]) {
     const float dw = half_bits_to_float((uint16_t)w.hd);
     const int K = act.K;
-    const int blk = min(t * 32 + (lane_id() >> 1), (S >> 1) - 1);
+    const int blk = min(t * 32 + lc.blk, (S >> 1) - 1);
 #pragma unroll
     for (int c = 0; c < NCOLS; ++c) {
       const int4 u = *(const int4 *)(act.q + (size_t)c * K + t * 1024 + lc.pa);
@@ -400,14 +406,15 @@ template <int TYPE, int NCOLS, class Pre, class Pro, class Epi>
 __device__ __forceinline__ void stream(const Segs &sg, int K, Pre pre, Pro pro, Epi epi) {
   using TL = Tile<TYPE>;
   constexpr int D = TL::DEPTH;
-  const int lane = lane_id();
+  const int lane = lane_opaque();
   const int upr = K / unit_weights<TYPE>();  // units per row
   const int tpr = (upr + 63) >> 6;            // tiles per row
   const int S = row_param<TYPE>(K);
   const int rows0 = sg.nrows[0], rows1 = sg.nseg > 1 ? sg.nrows[1] : 0;
   const int total = (rows0 + rows1) * tpr;
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void *)sg.mat[0].base, (short)0, (int)sg.mat[0].bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void *)sg.mat[sg.nseg > 1 ? 1 : 0].base, (short)0, (int)sg.mat[sg.nseg > 1 ? 1 : 0].bytes, 0x00020000);
+  const bool two = sg.nseg > 1;
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void *)(two ? sg.mat[1].base : sg.mat[0].base), (short)0, (int)(two ? sg.mat[1].bytes : sg.mat[0].bytes), 0x00020000);
   typename TL::Raw ring[D];
   int lr = 0, lt = 0, lseg = 0;  // loader cursor: row inside the segment, tile inside the row, segment
   auto issue = [&](typename TL::Raw &slot) {

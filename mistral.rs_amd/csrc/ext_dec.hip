@@ -9,12 +9,20 @@
 //   down     quantize(act) -> GEMV -> h = h * s + W_d . act
 // Every phase is the same kernel body: fill the weight ring, run the activation prologue (norm + quantize: ONE pass over <= 57 KB of f32),
 // stream the wave's rows, apply the phase's epilogue per finished row.  Arithmetic: header of dec_core.cuh.
+#include "dec_attn.cuh"
 #include "dec_core.cuh"
 #include <stdio.h>
 #include <stdlib.h>
+#include <math.h>
+#include <algorithm>
+#include "../../include/mistralrs_paged_attn.h"
 
 namespace mrs {
 namespace dec {
+
+#ifndef MRS_WAIT_VMCNT0
+#define MRS_WAIT_VMCNT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
 
 enum : int { EPI_STORE = 0, EPI_RESID = 1, EPI_GLU = 2, EPI_QKV = 3 };
 
@@ -42,16 +50,45 @@ struct GemvArgs {
   default: break;                                                \
   }
 
+// MRS_DEC_AGENT_IO (build experiment, off): in the persistent step, write the vectors handed to other CUs through at agent scope (sc1) and read them at
+// agent scope, with MRS_DEC_NOFENCE dropping the release / acquire fences of the phase barrier.  Measured: no faster, attention not covered.
+#ifndef MRS_DEC_AGENT_IO
+#define MRS_DEC_AGENT_IO 0
+#endif
+template <bool AGENT> __device__ __forceinline__ void st_out(float *p, float v) {
+  if constexpr (AGENT && MRS_DEC_AGENT_IO) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+template <bool AGENT> __device__ __forceinline__ float ld_out(const float *p) {
+  if constexpr (AGENT && MRS_DEC_AGENT_IO) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
 __device__ __forceinline__ float rl(float v, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane)); }
 
-template <int NCOLS, int EPI>
-__device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float *red) {
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // readfirstlane: lets hipcc keep everything derived from the wave index in SGPRs
+// LATE / sync: the persistent step kernel cannot read the activations before the producer phase has finished on every CU: the ring is filled
+// first, then sync() waits for the grid, then the activations are loaded at agent scope and quantized.  Launch-per-phase: LATE = false, the
+// activation loads go out before the ring (they are at the head of the wave's in-order load queue) and sync() is empty.
+struct NoSync { __device__ __forceinline__ void operator()() const {} };
+template <int NCOLS, int EPI, bool LATE = false, class Sync = NoSync>
+__device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float *red, Sync sync = Sync()) {
+  const int tid0 = tid_opaque();
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6), lane = tid0 & 63;  // readfirstlane: lets hipcc keep everything derived from the wave index in SGPRs
   const int gw = blockIdx.x * NW + wave;
   const int K = a.K;
   // the activation image is staged once per workgroup
-  auto pre = [&]() -> ActPre { return act_issue<false>(a.x, a.norm_w, K); };
-  auto pro = [&](const ActPre &p) -> Act { return act_finish<NCOLS, false>(smem, red, p, a.x, a.ldx, a.norm_w, a.eps, K, act_mode_for(a.m[0].type)); };
+  auto pre = [&]() -> ActPre {
+    if constexpr (LATE) return ActPre{};
+    else return act_issue<false>(a.x, a.norm_w, K);
+  };
+  auto pro = [&](const ActPre &p) -> Act {
+    if constexpr (LATE) {
+      sync();
+      const ActPre late = act_issue<MRS_DEC_AGENT_IO != 0>(a.x, a.norm_w, K);
+      return act_finish<NCOLS, MRS_DEC_AGENT_IO != 0>(smem, red, late, a.x, a.ldx, a.norm_w, a.eps, K, act_mode_for(a.m[0].type));
+    } else {
+      return act_finish<NCOLS, false>(smem, red, p, a.x, a.ldx, a.norm_w, a.eps, K, act_mode_for(a.m[0].type));
+    }
+  };
   const int u0 = min(gw * a.units_per_wave, a.units), u1 = min(u0 + a.units_per_wave, a.units);
   const int eoff = a.expert_sel ? *a.expert_sel * a.nrows[0] : 0;
 
@@ -65,7 +102,7 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
     if constexpr (EPI == EPI_RESID) {  // residual values up front (lane i <-> the wave's row i): no dependent load between a row's sum and its store
       if (lane < u1 - u0) {
 #pragma unroll
-        for (int c = 0; c < NCOLS; ++c) hold[c] = a.out[(size_t)c * a.out_stride + u0 + lane];
+        for (int c = 0; c < NCOLS; ++c) hold[c] = ld_out<LATE>(a.out + (size_t)c * a.out_stride + u0 + lane);
       }
     }
     auto epi = [&](int, int row, const float(&sum)[NCOLS]) {
@@ -75,9 +112,9 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
         float *o = a.out + (size_t)c * a.out_stride + r;
         if constexpr (EPI == EPI_RESID) {
           const float old = rl(hold[c], r - u0);
-          if (lane == 0) *o = old * a.resid_scale + sum[c] * ascale;
+          if (lane == 0) st_out<LATE>(o, old * a.resid_scale + sum[c] * ascale);
         } else {
-          if (lane == 0) *o = sum[c];
+          if (lane == 0) st_out<LATE>(o, sum[c]);
         }
       }
     };
@@ -97,15 +134,17 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
           gsave[c] = lane == i ? sum[c] : gsave[c];
         } else {
           const float g = rl(gsave[c], i);
-          if (lane == 0) a.out[(size_t)c * a.out_stride + (row - eoff)] = glu_act(g, a.activation) * sum[c];
+          if (lane == 0) st_out<LATE>(a.out + (size_t)c * a.out_stride + (row - eoff), glu_act(g, a.activation) * sum[c]);
         }
       }
     };
     MRS_DEC_TYPE_SWITCH(a.m[0].type, (stream<TT, NCOLS>(sg, K, pre, pro, epi));)
   } else {  // EPI_QKV: units are RoPE pairs (2i, 2i+1); waves [wstart[i], wstart[i+1]) take tensor i (q, k, v), so a wave never straddles two tensors
+    // (selects, not a.m[mi]: in the persistent kernel the arguments are a local struct and a dynamic index would push it into scratch memory)
     const int mi = gw >= a.wstart[2] ? 2 : (gw >= a.wstart[1] ? 1 : 0);
-    const int npairs = a.nrows[mi] >> 1;
-    const int p0 = min((gw - a.wstart[mi]) * a.units_per_wave, npairs), p1 = min(p0 + a.units_per_wave, npairs);
+    const int npairs = (mi == 0 ? a.nrows[0] : (mi == 1 ? a.nrows[1] : a.nrows[2])) >> 1;
+    const int w0 = mi == 0 ? a.wstart[0] : (mi == 1 ? a.wstart[1] : a.wstart[2]);
+    const int p0 = min((gw - w0) * a.units_per_wave, npairs), p1 = min(p0 + a.units_per_wave, npairs);
     const int r0 = 2 * p0;
     // epilogue operands up front: lane i <-> pair i of the wave
     float pcs[NCOLS], psn[NCOLS];
@@ -141,8 +180,8 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
         rope_pair<float>(prev[c], sum[c], cs, sn, x, y);
         if (lane == 0) {
           if (mi == 0) {
-            a.q_out[(size_t)c * a.nrows[0] + lr] = x;
-            a.q_out[(size_t)c * a.nrows[0] + lr + 1] = y;
+            st_out<LATE>(a.q_out + (size_t)c * a.nrows[0] + lr, x);
+            st_out<LATE>(a.q_out + (size_t)c * a.nrows[0] + lr + 1, y);
           } else {
             const int64_t slot = slots[c];
             if (slot >= 0) {
@@ -165,7 +204,7 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
       }
     };
     Segs sg{};
-    sg.nseg = 1; sg.mat[0] = a.m[mi]; sg.row0[0] = r0; sg.nrows[0] = 2 * (p1 - p0);
+    sg.nseg = 1; sg.mat[0] = mi == 0 ? a.m[0] : (mi == 1 ? a.m[1] : a.m[2]); sg.row0[0] = r0; sg.nrows[0] = 2 * (p1 - p0);
     MRS_DEC_TYPE_SWITCH(sg.mat[0].type, (stream<TT, NCOLS>(sg, K, pre, pro, epi));)
   }
 }
@@ -176,6 +215,141 @@ __global__ void __launch_bounds__(NT) dec_gemv_kernel(const GemvArgs a) {
   __shared__ float red[8];
   gemv_phase<NCOLS, EPI>(a, smem, red);
 }
+
+// ------------------------------------------------------------------------------------------------ persistent decode step
+// ONE launch runs a range of phases of the decode step on a grid of resident workgroups (one per CU): embedding, then per layer
+// qkv / attention splits / attention merge / o_proj / gate-up / down, then final norm + lm_head.  Between phases every workgroup arrives on a
+// monotonic device-scope counter and the next phase's prologue waits for it -- but the next phase's WEIGHT RING is filled before the wait, so
+// HBM keeps streaming across the seam (what a kernel boundary cannot do: DESIGN.md section 4.5).  Cross-CU visibility: agent-scope release
+// (after the phase's stores) -> relaxed counter -> agent-scope acquire (guide: MI355X_MICROARCH "Workgroup dispatch ... visibility").
+// Every spin is bounded: a grid that is not fully resident gives up, flags sync[1] and lets the launch finish (garbage out, no hang).
+// Every phase reads its arguments from a table in device memory that the host fills once (mrs_dec_build_step_table): the kernel bodies then
+// see them exactly as a stand-alone kernel sees its kernarg segment (scalar loads, dynamic indices allowed) -- a struct assembled inside the
+// kernel would live in scratch memory and put scratch loads into the weight stream's in-order queue.
+enum : int { PH_EMBED = 0, PH_QKV = 1, PH_ATTN = 2, PH_MERGE = 3, PH_RESID = 4, PH_GLU = 5, PH_STORE = 6 };
+struct PhaseDesc {
+  int kind, group, kv_f16, embd_type;
+  GemvArgs g;
+  AttnArgs t;
+  const uint8_t *embd; const int32_t *input_ids;  // PH_EMBED: g.out = h, g.K = hidden
+};
+struct StepArgs {
+  const PhaseDesc *table;
+  unsigned *sync;  // [0] arrivals, [1] error flag; [0] is zeroed before every launch
+  int phase_begin, phase_end;  // phase ids: 0 = embedding, 1 + 6 l + {0 qkv, 1 attention splits, 2 attention merge, 3 o_proj, 4 gate/up, 5 down}, 1 + 6 L = lm_head
+};
+
+__device__ __forceinline__ void grid_arrive(unsigned *ctr) {
+  MRS_WAIT_VMCNT0();  // this wave's stores have left the CU
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#ifndef MRS_DEC_NOFENCE
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
+    MRS_WAIT_VMCNT0();  // the write-back must be complete before the arrival becomes visible (hipcc may drop its own wait)
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+__device__ __forceinline__ void grid_wait(unsigned *sync, unsigned target) {
+  if (threadIdx.x == 0) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1u << 22) || __hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {  // not all workgroups resident (or a peer gave up)
+        __hip_atomic_store(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+#ifndef MRS_DEC_NOFENCE
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+  }
+  __syncthreads();
+}
+
+struct GridSync {
+  unsigned *sync; unsigned target; bool wait;
+  __device__ __forceinline__ void operator()() const { if (wait) grid_wait(sync, target); }
+};
+// HG = query heads per work item (a GQA group of G runs as G / HG items: the K/V chunk is read G / HG times, the wave keeps HG heads of state)
+template <int NCOLS, int HG, class CT>
+__device__ __forceinline__ void attn_phase(const AttnArgs &t, int G, char *smem, bool merge) {
+  const int wave = __builtin_amdgcn_readfirstlane(tid_opaque() >> 6);
+  // item i -> workgroup i % grid, wave i / grid: the first `grid` items land on different CUs
+  const int nwg = gridDim.x;
+  if (!merge) {
+    float *q_s = (float *)smem + wave * (HG * 128 + HG * 32), *p_s = q_s + HG * 128;
+    const int sub = G / HG;  // items per kv head and split
+    const int items = NCOLS * t.num_kv_heads * sub * t.max_splits;
+    for (int i = wave * nwg + blockIdx.x; i < items; i += NW * nwg) {
+      const int split = i % t.max_splits, r = i / t.max_splits, sb = r % sub, kvh = (r / sub) % t.num_kv_heads, seq = r / (sub * t.num_kv_heads);
+      attn_split_item<HG, CT>(t, kvh, kvh * G + sb * HG, seq, split, q_s, p_s);
+    }
+  } else {
+    const int items = NCOLS * t.num_heads;
+    for (int i = wave * nwg + blockIdx.x; i < items; i += NW * nwg) attn_merge_item(t, i % t.num_heads, i / t.num_heads);
+  }
+}
+
+template <int TYPE> __device__ __forceinline__ void dequant_units(const uint8_t *row, int K, float *o) {
+  for (int s = tid_opaque(); s < K / 32; s += NT) {
+    const Slice sl = load_slice<TYPE>(row, s);
+    int ra, rb;
+    slice_runs<TYPE>(s, ra, rb);
+    const int8_t *qa = (const int8_t *)&sl.qa, *qb = (const int8_t *)&sl.qb;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { o[ra * 16 + j] = sl.sa * (float)qa[j] - sl.oa; o[rb * 16 + j] = sl.sb * (float)qb[j] - sl.ob; }
+  }
+}
+
+#ifndef MRS_DEC_NO_STEP
+template <int NCOLS>
+__global__ void __launch_bounds__(NT) dec_step_kernel(const StepArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ float red[8];
+  const int nwg = gridDim.x;
+  for (int p = a.phase_begin; p < a.phase_end; ++p) {
+    const GridSync sync{a.sync, (unsigned)(p - a.phase_begin) * (unsigned)nwg, p > a.phase_begin};
+    const PhaseDesc &d = a.table[p];
+    switch (d.kind) {
+    case PH_EMBED: {  // embedding rows -> h (QuantMethod::embedding_forward): workgroup c takes token c
+      if ((int)blockIdx.x < NCOLS) {
+        const int K = d.g.K;
+        const int64_t id = d.input_ids[blockIdx.x];
+        float *o = d.g.out + (size_t)blockIdx.x * K;
+        const int t0 = tid_opaque();
+        if (d.embd_type == 0) { const float *src = (const float *)d.embd + id * K; for (int i = t0; i < K; i += NT) o[i] = src[i]; }
+        else if (d.embd_type == 1) { const uint16_t *src = (const uint16_t *)d.embd + id * K; for (int i = t0; i < K; i += NT) o[i] = half_bits_to_float(src[i]); }
+        else if (d.embd_type == 30) { const uint16_t *src = (const uint16_t *)d.embd + id * K; for (int i = t0; i < K; i += NT) o[i] = bf16_bits_to_float(src[i]); }
+        else {
+          switch (d.embd_type) {
+          case T_Q4_K: dequant_units<T_Q4_K>(d.embd + (size_t)id * (K / 256) * 144, K, o); break;
+          case T_Q5_K: dequant_units<T_Q5_K>(d.embd + (size_t)id * (K / 256) * 176, K, o); break;
+          case T_Q6_K: dequant_units<T_Q6_K>(d.embd + (size_t)id * (K / 256) * 210, K, o); break;
+          default: dequant_units<T_Q8_0>(d.embd + (size_t)id * (K / 32) * 34, K, o); break;
+          }
+        }
+      }
+    } break;
+    case PH_QKV: gemv_phase<NCOLS, EPI_QKV, true, GridSync>(d.g, smem, red, sync); break;
+    case PH_RESID: gemv_phase<NCOLS, EPI_RESID, true, GridSync>(d.g, smem, red, sync); break;
+    case PH_GLU: gemv_phase<NCOLS, EPI_GLU, true, GridSync>(d.g, smem, red, sync); break;
+    case PH_STORE: gemv_phase<NCOLS, EPI_STORE, true, GridSync>(d.g, smem, red, sync); break;
+    case PH_ATTN:
+      sync();
+      if (d.group == 1) { if (d.kv_f16) attn_phase<NCOLS, 1, f16_t>(d.t, 1, smem, false); else attn_phase<NCOLS, 1, bf16_t>(d.t, 1, smem, false); }
+      else { if (d.kv_f16) attn_phase<NCOLS, 2, f16_t>(d.t, d.group, smem, false); else attn_phase<NCOLS, 2, bf16_t>(d.t, d.group, smem, false); }
+      break;
+    default:  // PH_MERGE
+      sync();
+      attn_phase<NCOLS, 1, bf16_t>(d.t, d.group, smem, true);
+      break;
+    }
+    if (p + 1 < a.phase_end) grid_arrive(a.sync);
+  }
+}
+
+#endif  // MRS_DEC_NO_STEP
 
 // ------------------------------------------------------------------------------------------------ repack GGUF blocks -> decode layout
 // one thread per block (superblock, or 32-block for Q8_0); block i of the row-major GGUF tensor = (row, sb)
@@ -258,8 +432,9 @@ template <int EPI> struct Launch {
       for (int i = 0; i < 3; ++i) a.wstart[i + 1] = a.wstart[i] + ((a.nrows[i] >> 1) + upw - 1) / upw;
       grid = (a.wstart[3] + NW - 1) / NW;
     }
-    const size_t lds = (act_bytes(a.K, NCOLS) + 15) & ~(size_t)15;
+    size_t lds = (act_bytes(a.K, NCOLS) + 15) & ~(size_t)15;
     if (lds > 158 * 1024) return -2;
+    { static long pad = -1; if (pad < 0) { const char *e = getenv("MRS_DEC_LDS_PAD"); pad = e ? atol(e) : 0; } if ((size_t)pad > lds && pad <= 158 * 1024) lds = (size_t)pad; }  // experiment: > 80 KiB forces one workgroup per CU
     auto kern = dec_gemv_kernel<NCOLS, EPI>;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024); attr = true; }
@@ -343,4 +518,136 @@ extern "C" int mrs_dec_proj(const mrs_dec_mat_c *w, int n, const int32_t *expert
   a.nrows[0] = n; a.K = (int)w->k; a.x = x; a.ldx = ldx; a.norm_w = norm_w; a.eps = eps; a.out = out; a.out_stride = ld_out;
   a.resid_scale = resid_scale; a.acc_scale = acc_scale; a.units = n; a.expert_sel = expert_sel;
   return mode ? Launch<EPI_RESID>::run(a, b, (hipStream_t)stream) : Launch<EPI_STORE>::run(a, b, (hipStream_t)stream);
+}
+
+// ---- persistent decode step (one launch for a range of phases; b = 1)
+struct mrs_dec_layer_c { mrs_dec_mat_c q, k, v, o, gate, up, down; const float *attn_norm, *ffn_norm; void *k_cache, *v_cache; };
+struct mrs_dec_step_args_c {
+  int num_layers;
+  mrs_dec_mat_c lm_head; const float *final_norm;
+  const void *embd; int embd_type;
+  const int32_t *input_ids;
+  float *h, *q, *attn, *act, *logits, *part_o, *part_m, *part_l;
+  const uint32_t *block_tables, *context_lens; const int32_t *positions; const int64_t *slot_mapping; const float *cos_t, *sin_t;
+  int hidden, num_heads, num_kv_heads, head_dim, rot_pairs, ff, vocab, block_size, max_blocks_per_seq, max_context_len;
+  float eps, resid_scale;
+  int kv_dtype;
+};
+static int dec_step_grid() {
+  static int g = 0;
+  if (!g) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    const char *e = getenv("MRS_DEC_STEP_WGS");
+    g = e && atoi(e) > 0 ? atoi(e) : cus;  // one resident workgroup per CU
+  }
+  return g;
+}
+extern "C" size_t mrs_dec_step_table_bytes(int num_layers) { return (size_t)(2 + 6 * num_layers) * sizeof(PhaseDesc); }
+extern "C" int mrs_dec_step_num_phases(int num_layers) { return 2 + 6 * num_layers; }
+// Builds the phase table of a model on the host and copies it to `device_table` (blocking copy: load-time set-up; every pointer in `c` and
+// `layers` must stay valid while the table is used).  Returns -3 when a shape needs the launch-per-phase route, -1 on bad arguments.
+extern "C" int mrs_dec_build_step_table(const mrs_dec_step_args_c *c, const mrs_dec_layer_c *layers, void *device_table) {
+  if (!c || !layers || !device_table || c->num_layers <= 0) return -1;
+  if (c->head_dim != 128 || c->block_size != 32 || (c->kv_dtype != 0 && c->kv_dtype != 1)) return -3;
+  const int G = c->num_heads / c->num_kv_heads;
+  if (c->num_heads % c->num_kv_heads || (G != 1 && G != 2 && G != 4 && G != 8)) return -3;
+  const int grid = dec_step_grid(), waves = grid * NW;
+  const int nq = c->num_heads * c->head_dim, nkv = c->num_kv_heads * c->head_dim, d = c->hidden;
+  auto upw_of = [&](int units) { return (units + waves - 1) / waves; };
+  if (upw_of(c->vocab) > 64 || upw_of(c->ff) > 64 || upw_of(d) > 64) return -3;
+  const int np = 2 + 6 * c->num_layers;
+  PhaseDesc *tab = (PhaseDesc *)calloc((size_t)np, sizeof(PhaseDesc));
+  if (!tab) return -1;
+  int rc = 0;
+  const int eff_max = std::min(c->max_blocks_per_seq * c->block_size, c->max_context_len);
+  const int nblk = (eff_max + 31) / 32;
+  AttnArgs t{};
+  t.q = c->q; t.block_tables = c->block_tables; t.context_lens = c->context_lens; t.part_o = c->part_o; t.part_m = c->part_m; t.part_l = c->part_l;
+  t.out = c->attn; t.num_heads = c->num_heads; t.num_kv_heads = c->num_kv_heads; t.max_blocks_per_seq = c->max_blocks_per_seq; t.q_stride = nq;
+  t.kv_block_stride = c->num_kv_heads * c->head_dim * c->block_size; t.kv_head_stride = c->head_dim * c->block_size;
+  t.bpw = nblk <= 64 ? 1 : (nblk + 63) / 64;                 // == dec_bpw() of paged_attention.hip
+  t.max_splits = mrs_decode_attention_max_splits(eff_max);   // stride of the partials, as in the launch-per-phase route
+  t.num_seqs = 1; t.scale = 1.0f / sqrtf((float)c->head_dim);
+  {
+    PhaseDesc &e = tab[0];
+    e.kind = PH_EMBED; e.embd = (const uint8_t *)c->embd; e.embd_type = c->embd_type; e.input_ids = c->input_ids; e.g.out = c->h; e.g.K = d;
+  }
+  for (int l = 0; l < c->num_layers && !rc; ++l) {
+    const mrs_dec_layer_c &L = layers[l];
+    PhaseDesc *ph = tab + 1 + 6 * l;
+    {  // qkv
+      GemvArgs &g = ph[0].g;
+      ph[0].kind = PH_QKV;
+      if (!make_mat(g.m[0], L.q.planes, L.q.type, L.q.n, L.q.k) || !make_mat(g.m[1], L.k.planes, L.k.type, L.k.n, L.k.k) || !make_mat(g.m[2], L.v.planes, L.v.type, L.v.n, L.v.k)) rc = -1;
+      if (act_mode_for(L.q.type) != act_mode_for(L.k.type) || act_mode_for(L.q.type) != act_mode_for(L.v.type) || L.q.n != nq || L.k.n != nkv || L.v.n != nkv || L.q.k != d) rc = -1;
+      g.nrows[0] = nq; g.nrows[1] = nkv; g.nrows[2] = nkv; g.K = d; g.x = c->h; g.ldx = d; g.norm_w = L.attn_norm; g.eps = c->eps; g.q_out = c->q;
+      g.k_cache = L.k_cache; g.v_cache = L.v_cache; g.slot_mapping = c->slot_mapping; g.positions = c->positions; g.cos_t = c->cos_t; g.sin_t = c->sin_t;
+      g.head_dim = c->head_dim; g.rot_pairs = c->rot_pairs; g.num_kv_heads = c->num_kv_heads; g.block_size = c->block_size; g.cache_x = 8; g.kv_f16 = c->kv_dtype == 0;
+      g.units = (nq + 2 * nkv) / 2;
+      int upw = upw_of(g.units);
+      for (;; ++upw) {  // one tensor per wave: grow the pairs per wave until q, k and v fit the grid's waves
+        g.wstart[0] = 0;
+        for (int i = 0; i < 3; ++i) g.wstart[i + 1] = g.wstart[i] + ((g.nrows[i] >> 1) + upw - 1) / upw;
+        if (g.wstart[3] <= waves) break;
+      }
+      if (upw > 64) rc = -3;
+      g.units_per_wave = upw;
+    }
+    for (int j = 1; j <= 2; ++j) {  // attention splits, merge
+      ph[j].kind = j == 1 ? PH_ATTN : PH_MERGE; ph[j].group = G; ph[j].kv_f16 = c->kv_dtype == 0; ph[j].t = t;
+      ph[j].t.k_cache = (const uint16_t *)L.k_cache; ph[j].t.v_cache = (const uint16_t *)L.v_cache;
+    }
+    for (int j = 3; j <= 5; j += 2) {  // o_proj, down: h = h * s + W x
+      GemvArgs &g = ph[j].g;
+      const mrs_dec_mat_c &w = j == 3 ? L.o : L.down;
+      ph[j].kind = PH_RESID;
+      if (!make_mat(g.m[0], w.planes, w.type, w.n, w.k) || w.n != d || w.k != (j == 3 ? nq : c->ff)) rc = -1;
+      g.nrows[0] = d; g.K = (int)w.k; g.x = j == 3 ? c->attn : c->act; g.ldx = g.K; g.eps = c->eps; g.out = c->h; g.out_stride = d; g.resid_scale = c->resid_scale;
+      g.units = d; g.units_per_wave = upw_of(d);
+    }
+    {  // gate / up
+      GemvArgs &g = ph[4].g;
+      ph[4].kind = PH_GLU;
+      if (!make_mat(g.m[0], L.gate.planes, L.gate.type, L.gate.n, L.gate.k) || !make_mat(g.m[1], L.up.planes, L.up.type, L.up.n, L.up.k)) rc = -1;
+      if (L.gate.type != L.up.type || L.gate.n != c->ff || L.up.n != c->ff || L.gate.k != d || L.up.k != d) rc = -1;
+      g.nrows[0] = g.nrows[1] = c->ff; g.K = d; g.x = c->h; g.ldx = d; g.norm_w = L.ffn_norm; g.eps = c->eps; g.out = c->act; g.out_stride = c->ff;
+      g.units = c->ff; g.units_per_wave = upw_of(c->ff);
+    }
+  }
+  {  // final norm + lm_head
+    PhaseDesc &e = tab[np - 1];
+    GemvArgs &g = e.g;
+    e.kind = PH_STORE;
+    if (!make_mat(g.m[0], c->lm_head.planes, c->lm_head.type, c->lm_head.n, c->lm_head.k) || c->lm_head.n != c->vocab || c->lm_head.k != d) rc = -1;
+    g.nrows[0] = c->vocab; g.K = d; g.x = c->h; g.ldx = d; g.norm_w = c->final_norm; g.eps = c->eps; g.out = c->logits; g.out_stride = c->vocab;
+    g.units = c->vocab; g.units_per_wave = upw_of(c->vocab);
+  }
+  size_t lds = act_bytes(std::max(std::max(d, c->ff), nq), 1);
+  if (std::max(lds, (size_t)NW * 2 * 160 * 4) > 158 * 1024) rc = rc ? rc : -3;
+  if (!rc && hipMemcpy(device_table, tab, (size_t)np * sizeof(PhaseDesc), hipMemcpyHostToDevice) != hipSuccess) rc = -1;
+  free(tab);
+  return rc;
+}
+// Phases [phase_begin, phase_end) of one decode step for ONE sequence in a single launch.  max_k = the longest GEMV row of the model
+// (max(hidden, ffn, heads * 128)): sizes the activation image in LDS.
+extern "C" int mrs_dec_step(const void *device_table, int num_layers, int max_k, void *sync, int phase_begin, int phase_end, void *stream) {
+  const int np = 2 + 6 * num_layers;
+  if (!device_table || !sync || phase_begin < 0 || phase_end > np || phase_begin >= phase_end) return -1;
+  StepArgs a{(const PhaseDesc *)device_table, (unsigned *)sync, phase_begin, phase_end};
+  size_t lds = std::max(act_bytes(max_k, 1), (size_t)NW * 2 * 160 * 4);
+  lds = (lds + 15) & ~(size_t)15;
+  if (lds > 158 * 1024) return -3;
+#ifdef MRS_DEC_NO_STEP
+  (void)a; (void)stream;
+  return -3;
+#else
+  hipStream_t s = (hipStream_t)stream;
+  auto kern = dec_step_kernel<1>;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024); attr = true; }
+  if (phase_end - phase_begin > 1 && hipMemsetAsync(sync, 0, 8, s) != hipSuccess) return -1;
+  hipLaunchKernelGGL(kern, dim3(dec_step_grid()), dim3(NT), lds, s, a);
+  return 0;
+#endif
 }

@@ -149,6 +149,7 @@ class Llama:
         L.mrs_llama_set_comm.argtypes = [C.c_void_p, C.c_void_p]
         L.mrs_llama_set_dec_tensor.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
         L.mrs_llama_set_mode.argtypes = [C.c_void_p, C.c_int]
+        L.mrs_llama_set_dec_persist.argtypes = [C.c_void_p, C.c_int]
         L.mrs_dec_repack_bytes.restype = C.c_size_t
         L.mrs_dec_repack_bytes.argtypes = [C.c_int, C.c_longlong, C.c_longlong]
         L.mrs_dec_repack.argtypes = [C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p]
@@ -270,6 +271,11 @@ class Llama:
     def decode_path(self) -> str:
         """'engine' (ext_dec.hip, reference CPU-path arithmetic), 'fused' (round-1 kernels, Q8_1) or 'reference-sequence'."""
         return "engine" if (self._engine_wanted and self._engine_ok) else ("fused" if self.cfg.use_fused else "reference-sequence")
+
+    def set_decode_persist(self, mode: int) -> None:
+        """Decode engine at b = 1: 1 = one persistent launch per step (default), 2 = the same kernel one phase per launch, 0 = per-phase kernels."""
+        self._chk(self._L.mrs_llama_set_dec_persist(self._h, mode))
+        self._graph = None
 
     def _set_mode(self) -> None:
         mode = 2 if (self._engine_wanted and self._engine_ok) else int(bool(self.cfg.use_fused))

@@ -250,6 +250,18 @@ extern "C" inline __bf16 __truncsfbf2(float f) {
 #define __builtin_amdgcn_update_dpp(OLD, SRC, CTRL, RMASK, BMASK, BOUND) hiphost::dpp((SRC), (CTRL))
 #define __builtin_amdgcn_readlane(V, L) hiphost::exchange((int)(V), (L))
 #define __builtin_amdgcn_readfirstlane(V) hiphost::exchange((int)(V), 0) /* kernels use it on wave-uniform values only */
+#define MRS_OPAQUE_TID(t) ((void)0)
+#define MRS_WAIT_VMCNT0() ((void)0)                                     /* product code: s_waitcnt vmcnt(0) */
+#define __builtin_amdgcn_fence(ORDER, SCOPE) ((void)0)                  /* one workgroup runs at a time: nothing to order */
+#define __builtin_amdgcn_s_sleep(N) ((void)0)
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_fetch_add(P, V, ORDER, SCOPE) atomicAdd((P), (V))
+#define __hip_atomic_load(P, ORDER, SCOPE) (*(P))
+#define __hip_atomic_store(P, V, ORDER, SCOPE) (*(P) = (V))
+enum { hipMemcpyHostToDevice = 1, hipDeviceAttributeMultiprocessorCount = 63 };
+static inline hipError_t hipMemcpy(void *d, const void *s_, size_t n, int) { memcpy(d, s_, n); return hipSuccess; }
+static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipDeviceGetAttribute(int *v, int, int) { *v = 4; return hipSuccess; }  /* the emulated "chip": 4 CUs (persistent step: 4 workgroups) */
 #define MRS_WAVE_SYNC() hiphost::wave_sync()                           /* product code: a compiler-level wave barrier (lockstep lanes) */
 #define __builtin_amdgcn_sdot4(A, B, C, CLAMP) hiphost_sdot4((A), (B), (C))
 static inline int hiphost_sdot4(int a, int b, int c) {

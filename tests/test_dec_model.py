@@ -190,6 +190,28 @@ def test_engine_graph_loop_batch_and_chunked_prefill(oracle, dev, request):
         assert torch.equal(both[0], alone), f"batched != single at position {pos}"
 
 
+def test_persistent_step_equals_phase_launches(oracle, dev, request):
+    """The persistent step kernel (one launch, device-side phase barriers, weight stream running across the seams) == the same kernel launched
+    phase by phase == the per-phase kernels, bit for bit, over a prompt and a few generated tokens -- at a context long enough for several
+    attention splits.  A stale read across a phase barrier (visibility bug) would show up here as a difference."""
+    import torch
+    emu = request.config.getoption("--host-emulation")
+    outs = {}
+    for mode in ((2, 0) if emu else (1, 2, 0)):
+        cfg, w, m, cos, sin = _mk(oracle, dev, Q4KM(oracle), "bf16")
+        m.set_decode_persist(mode)
+        toks, seq = [(1000 + 7 * i) % cfg.vocab_size for i in range(3 if emu else 70)], []
+        for pos, t in enumerate(toks):
+            m.set_state([t], [pos])
+            seq.append(m.forward_logits(1)[0].clone())
+        if not emu:
+            torch.cuda.synchronize()
+        outs[mode] = torch.stack(seq)
+    ref = outs[0]
+    for mode, o in outs.items():
+        assert torch.equal(o, ref), f"decode_persist mode {mode} differs from the per-phase kernels: {float((o - ref).abs().max())}"
+
+
 def test_engine_mixtral_moe_vs_cpu_path_oracle(oracle, dev, request):
     steps = 3 if request.config.getoption("--host-emulation") else 24
     types = dict(embd=oracle.Q4_K, q=oracle.Q4_K, k=oracle.Q4_K, v=oracle.Q6_K, o=oracle.Q4_K, gate=oracle.Q4_K, up=oracle.Q4_K, down=oracle.Q6_K, output=oracle.Q6_K)
