@@ -10,7 +10,10 @@ barrier + torch.cuda.synchronize(); `value` = decoded tokens/s over all ranks (m
 Method mirrors `mistralrs bench` (mistralrs-cli/src/commands/bench.rs:52-55,253-305): synthetic prompt tokens
 1000 + (start+i) % 2048, EOS disabled, greedy; prefill tok/s = prompt_len / TTFT is reported next to it.
 Weights are synthetic (no network): random valid GGUF blocks with the llama.cpp Q4_K_M tensor-type map; inputs are
-resident in HBM when the timed region starts.  Multi-GPU (round 1): N independent replicas (weak scaling), see DESIGN.md.
+resident in HBM when the timed region starts.
+Multi-GPU: `--gpus N` with N > 1 runs ONE model tensor-parallel over the N GPUs (one process per GPU, RCCL all-reduce after every
+row-parallel projection; "scaling": "strong"); launched by torch.distributed.run, or self-spawned when WORLD_SIZE is not set.
+`--model auto` = Llama-3-8B (BASELINE configs[1]) for N < 8 and Llama-3-70B, 2048 prefill (configs[3]) for N = 8; `--replicas` = N independent copies.
 """
 from __future__ import annotations
 
@@ -47,7 +50,11 @@ def q4_k_m_types(n_layers: int):
     return out
 
 
-def build_model(cfg, device, seed=0, max_new_tokens=4096):
+def build_model(cfg, device, seed=0, max_new_tokens=4096, tp=None):
+    """Synthetic model of `cfg`'s (per-rank) dims.  tp = (rank, world): the column / row-parallel shards (q / k / v / gate / up rows, o / down
+    columns: distributed/layers.rs:695-975,1160-1616) get rank-specific random blocks of the SHARD's shape -- the bytes and the arithmetic of a
+    real shard without materialising the unsharded 40 GB tensor on every GPU -- while the replicated tensors (embedding, norms, lm_head) use
+    the same seed on every rank, so all ranks compute the same logits and sample the same token."""
     import torch
     from mistralrs_amd.llama import Llama, random_qtensor
     m = Llama(cfg, device, max_new_tokens=max_new_tokens)
@@ -58,11 +65,9 @@ def build_model(cfg, device, seed=0, max_new_tokens=4096):
     types = q4_k_m_types(cfg.num_layers)
     g = torch.Generator(device="cpu").manual_seed(seed)
     for i, (name, t) in enumerate(types.items()):
-        if name in ("token_embd.weight", "output.weight"):
-            n, k = cfg.vocab_size, d
-        else:
-            n, k = shapes[name.split(".")[2]]
-        m.set_tensor(name, random_qtensor(t, n, k, device, seed * 1000 + i))
+        sharded = name not in ("token_embd.weight", "output.weight")
+        n, k = shapes[name.split(".")[2]] if sharded else (cfg.vocab_size, d)
+        m.set_tensor(name, random_qtensor(t, n, k, device, seed * 1000 + i + (7919 * (tp[0] + 1) if tp and sharded else 0)))
     for i in range(cfg.num_layers):
         for nm in ("attn_norm", "ffn_norm"):
             m.set_tensor(f"blk.{i}.{nm}.weight", 1.0 + 0.01 * torch.randn(d, generator=g))
@@ -102,32 +107,35 @@ def cpu_baseline(model, cfg, budget_s=12.0):
         if dt < best[0]:
             best = (dt, thr)
     O.set_threads(best[1])
-    ref = llama_ref.LlamaRef(cfg, w, cos, sin, mode="cpu_fast", kv_dtype="f32")
-    tok, n, t0 = 1000, 0, time.perf_counter()
+    ref = llama_ref.LlamaRef(cfg, w, cos, sin, mode="cpu_fast", kv_dtype="bf16")
+    # same token rule as the GPU run, from an empty context; the GPU side repeats exactly this (token by token through the decode engine)
+    # for the greedy_match check, so the two token lists are comparable
+    tok, n, toks, t0 = 1000 % cfg.vocab_size, 0, [], time.perf_counter()
     while True:
         lg = ref.step(tok, n)
         tok, n = int(lg.argmax()), n + 1
+        toks.append(tok)
         el = time.perf_counter() - t0
         if el > budget_s or n >= 16:
             break
     return {"value": round(n / el, 3), "unit": "tokens/s", "cores": best[1], "kind": "port",
-            "sample": f"{n} greedy decode tokens from an empty context, same synthetic Llama-3-8B Q4_K_M weights, "
+            "sample": f"{n} greedy decode tokens from an empty context, same synthetic {cfg.num_layers}-layer Q4_K_M weights, "
                       f"oracle-B restatement of the candle CPU path (Q8_K activations, OpenMP rows, gcc -O3 -march=native); "
-                      f"host reports {os.cpu_count()} logical CPUs"}
+                      f"host reports {os.cpu_count()} logical CPUs"}, toks
 
 
 def measured_traffic(model_name):
     """HBM bytes per launch of the dominant kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE on this same command,
     x2 gfx950 correction; scripts/profile_round.sh -> profiles/round1_hbm_traffic.json).  Counters cannot be read from inside the
     timed process, so the figure is the last profiled one for this kernel and workload; null for any other workload."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_hbm_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round2_hbm_traffic.json")
     try:
-        k = json.load(open(path))["kernels"]["void mrs::decode_gemv_kernel<1, 1, 2, 512>(mrs::DecodeGemvArgs)"]
+        k = json.load(open(path))["kernels"]["dec_gemv_kernel<1, EPI_GLU>"]
     except (OSError, KeyError, ValueError):
         return {"traffic": None}
     if "8B" not in model_name:
         return {"traffic": None}
-    return {"traffic": int(k["read_bytes_per_launch"] + k["write_bytes_per_launch"]), "traffic_source": "profiles/round1_hbm_traffic.json"}
+    return {"traffic": int(k["read_bytes_per_launch"] + k["write_bytes_per_launch"]), "traffic_source": "profiles/round2_hbm_traffic.json"}
 
 
 def main():
@@ -138,14 +146,46 @@ def main():
     ap.add_argument("--prompt-len", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--small", action="store_true", help="tiny config (smoke / CI), not the benchmark")
-    ap.add_argument("--tp", action="store_true", help="N > 1: ONE model sharded tensor-parallel over the N GPUs (RCCL all-reduce) instead of N replicas")
+    ap.add_argument("--tp", action="store_true", help="(default for N > 1) ONE model sharded tensor-parallel over the N GPUs")
+    ap.add_argument("--replicas", action="store_true", help="N > 1: N independent replicas (weak scaling) instead of tensor parallelism")
+    ap.add_argument("--model", choices=["auto", "8b", "70b"], default="auto", help="auto: 70b (configs[3]) when N == 8, else 8b (configs[1])")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # driver contract: `python bench.py --gpus N` must use N GPUs -- re-launch ourselves as one process per GPU (mistralrs-core/src/distributed.rs:569-795
+        # spawns its ranks the same way)
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.call(cmd, env=env))
 
     import torch
     import torch.distributed as dist
+    if os.environ.get("MRS_BENCH_DRY_RUN"):
+        # launcher check without GPUs (tests/test_distributed.py): every rank joins a gloo group, rank 0 prints the line's identity fields
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world > 1:
+            dist.init_process_group("gloo")
+            dist.barrier()
+        tp = world > 1 and not a.replicas
+        big = a.model == "70b" or (a.model == "auto" and world == 8 and not a.replicas)
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps({"metric": "decode_tokens_per_sec", "dry_run": True, "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                              "scaling": "strong" if tp else "weak",
+                              "config": {"workload": ("Llama-3-70B" if big else "Llama-3-8B") + " GGUF Q4_K_M", "parallelism": "tp1" if world == 1 else (f"tp{world}" if tp else f"replicas x{world}")}}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and rank == 0:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: measuring {world} rank(s)", file=sys.stderr)
     if world > 1:
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -154,25 +194,34 @@ def main():
 
     import mistralrs_amd  # noqa: F401
     from mistralrs_amd.llama import LlamaConfig
+    big = a.model == "70b" or (a.model == "auto" and world == 8 and not a.replicas)
+    if big and a.prompt_len == 512:
+        a.prompt_len = 2048  # configs[3]: 2048 prefill / 256 decode
     ctx_needed = a.prompt_len + a.warmup + a.steps + 2
     max_ctx = (ctx_needed + 63) // 64 * 64
     if a.small:
         cfg = LlamaConfig(hidden_size=512, intermediate_size=1024, num_layers=2, num_heads=8, num_kv_heads=2, vocab_size=2048,
                           head_dim=64, max_batch=8, max_context_len=max_ctx, max_position_embeddings=max(8192, max_ctx))
         name = "tiny-llama (smoke)"
+    elif big:
+        cfg = LlamaConfig.llama3_70b(max_batch=8, max_context_len=max_ctx, max_position_embeddings=max(8192, max_ctx))
+        name = "Llama-3-70B"
     else:
         cfg = LlamaConfig.llama3_8b(max_batch=8, max_context_len=max_ctx, max_position_embeddings=max(8192, max_ctx))
         name = "Llama-3-8B"
-    tp = a.tp and world > 1
+    tp = world > 1 and not a.replicas
     if tp:  # column / row parallel shards (mistralrs-quant/src/distributed/layers.rs): local heads, kv heads, ffn
         from mistralrs_amd import distributed as D
         cfg.head_dim = cfg.head_dim  # keep the global head_dim
         cfg.num_heads, cfg.num_kv_heads, cfg.intermediate_size = D.local_dims(cfg.num_heads, cfg.num_kv_heads, cfg.intermediate_size, world)
         cfg.tp_world_size, cfg.tp_rank = world, rank
-    model = build_model(cfg, dev, seed=rank, max_new_tokens=a.warmup + a.steps + 8)
+    model = build_model(cfg, dev, seed=0 if tp else rank, max_new_tokens=a.warmup + a.steps + 8, tp=(rank, world) if tp else None)
+    comm = None
     if tp:
         from mistralrs_amd import distributed as D
-        model.set_comm(D.RcclComm(rank, world, dev))
+        comm = D.RcclComm(rank, world, dev)
+        assert comm.nranks() == world, f"RCCL communicator has {comm.nranks()} ranks, expected {world}"
+        model.set_comm(comm)
     torch.cuda.synchronize()
 
     def sync():
@@ -213,22 +262,32 @@ def main():
     toks = model.tokens_out[0, : a.warmup + a.steps].cpu().numpy()
     assert int(model.positions[0]) == a.prompt_len + a.warmup + a.steps, "decode state did not advance as expected"
 
-    # ---------------- roofline of the dominant kernel: the fused gate/up GEMV (2 x [ffn, d] weights per launch)
+    # ---------------- roofline of the dominant kernel: the decode engine's gate/up phase (RMSNorm + Q8_K quantize + 2 x [ffn, d] GEMV + SiLU*up),
+    # timed with HIP events on the launch stream over every layer's weights (>= 1 GB: nothing Infinity-Cache resident)
     import ctypes as C
     from mistralrs_amd import _lib
     ext = _lib.load("ext")
-    ext.mrs_decode_gate_up.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_int,
-                                       C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+
+    class Mat(C.Structure):
+        _fields_ = [("planes", C.c_void_p), ("type", C.c_int), ("n", C.c_longlong), ("k", C.c_longlong)]
+    MP = C.POINTER(Mat)
+    ext.mrs_dec_gate_up.argtypes = [MP, MP, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     h = torch.randn(1, cfg.hidden_size, device=dev)
-    y = torch.zeros(((cfg.intermediate_size + 511) // 512 * 512) // 32 * 36, dtype=torch.uint8, device=dev)
+    act = torch.empty(1, cfg.intermediate_size, device=dev)
     st = torch.cuda.current_stream().cuda_stream
-    layers = [(model._keep[f"blk.{i}.ffn_gate.weight"], model._keep[f"blk.{i}.ffn_up.weight"], model._keep[f"blk.{i}.ffn_norm.weight"])
-              for i in range(cfg.num_layers)]
+    assert model.decode_path == "engine", model.decode_path
+    layers = []
+    for i in range(cfg.num_layers):
+        g, u = model._keep[f"blk.{i}.ffn_gate.weight"], model._keep[f"blk.{i}.ffn_up.weight"]
+        layers.append((Mat(model._keep[f"blk.{i}.ffn_gate.weight#dec"].data_ptr(), g.dtype.id, g.shape[0], g.shape[1]),
+                       Mat(model._keep[f"blk.{i}.ffn_up.weight#dec"].data_ptr(), u.dtype.id, u.shape[0], u.shape[1]),
+                       model._keep[f"blk.{i}.ffn_norm.weight"], g.nbytes() + u.nbytes()))
 
     def gate_up_pass():
-        for g, u, nw in layers:
-            ext.mrs_decode_gate_up(g.data.data_ptr(), u.data.data_ptr(), g.dtype.id, cfg.intermediate_size, cfg.hidden_size,
-                                   h.data_ptr(), nw.data_ptr(), cfg.rms_eps, 0, y.data_ptr(), y.numel() // 36, 1, st)
+        for mg, mu, nw, _ in layers:
+            rc = ext.mrs_dec_gate_up(C.byref(mg), C.byref(mu), cfg.intermediate_size, None, h.data_ptr(), cfg.hidden_size, nw.data_ptr(), cfg.rms_eps, 0,
+                                     act.data_ptr(), cfg.intermediate_size, 1, st)
+            assert rc == 0
     gate_up_pass()
     torch.cuda.synchronize()
     reps = 8
@@ -239,8 +298,25 @@ def main():
     k1.record()
     torch.cuda.synchronize()
     kern_s = k0.elapsed_time(k1) / 1e3 / (reps * len(layers))
-    kern_bytes = layers[0][0].nbytes() + layers[0][1].nbytes()  # algorithmic bytes per launch: the two packed weight tensors
+    kern_bytes = layers[0][3]  # algorithmic bytes per launch: the two GGUF weight tensors (the decode layout holds the same bits + 2.8 % for 8-bit scales)
     achieved = kern_bytes / kern_s
+
+    # ---------------- tensor parallel: cost of the decode all-reduces (2 per layer, [1, hidden] f32) measured on the same communicator
+    ar = None
+    if tp:
+        buf = torch.zeros(cfg.hidden_size, device=dev)
+        for _ in range(10):
+            comm.all_reduce_(buf)
+        sync()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(200):
+            comm.all_reduce_(buf)
+        e1.record()
+        sync()
+        us = e0.elapsed_time(e1) * 1e3 / 200
+        ar = {"us_per_call": round(us, 2), "calls_per_step": 2 * cfg.num_layers, "bytes": cfg.hidden_size * 4,
+              "frac_of_step": round(us * 2 * cfg.num_layers / (1e6 * t_all / a.steps), 4), "impl": "rccl ncclAllReduce f32 (back-to-back launches; in the step they sit inside the captured graph)"}
 
     avg_ctx = a.prompt_len + a.warmup + a.steps / 2
     step_bytes = model.decode_bytes(1, int(avg_ctx))
@@ -248,8 +324,8 @@ def main():
     out = {
         "metric": "decode_tokens_per_sec", "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(1e3 * t_all / a.steps, 4), "higher_is_better": True, "scaling": "strong" if tp else "weak",
-        "vs_baseline": None, "dtype": "q4_k/q6_k weights x q8_1 activations (int8 dot, f32 accumulate)", "data": "synthetic",
-        "config": {"workload": f"{name} GGUF Q4_K_M, TP=1, {a.prompt_len} prefill / {a.steps} decode, batch 1, paged KV bf16 (block 32)",
+        "vs_baseline": None, "dtype": "q4_k/q6_k weights x q8_k activations (int8 dot, f32 accumulate: the reference CPU path's arithmetic)", "data": "synthetic",
+        "config": {"workload": f"{name} GGUF Q4_K_M, TP={world if tp else 1}, {a.prompt_len} prefill / {a.steps} decode, batch 1, paged KV bf16 (block 32)",
                    "parallelism": "tp1" if world == 1 else (f"tp{world}" if tp else f"replicas x{world}")},
         "prefill_tokens_per_sec": round(a.prompt_len / ttft, 1), "ttft_ms": round(1e3 * ttft, 2),
         "prefill_roofline": {"bound": "mfma", "achieved": round(prefill_flops / ttft / 1e12, 1), "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s",
@@ -257,14 +333,25 @@ def main():
                              "note": "fused block-dequant -> bf16 MFMA GEMMs (mrs_gemm_q_bf16_multi) + MFMA flash attention over the paged cache; whole prompt incl. the host read-back of the first token"},
         "device_ms_per_step": round(1e3 * dev_s / a.steps, 4),
         "step_bytes": int(step_bytes), "step_roofline_frac": round(step_bytes * (a.steps / t_all) / HBM_PEAK, 4),
-        "roofline": {"bound": "hbm", "kernel": "decode_gemv_kernel<1, PRO_NORM, EPI_GLU_Q8_1> (fused RMSNorm+Q8_1+gate/up GEMV+SiLU*mul+Q8_1)",
+        "roofline": {"bound": "hbm", "kernel": "dec_gemv_kernel<1, EPI_GLU> (decode engine gate/up phase: RMSNorm + Q8_K quantize + gate/up GEMV + SiLU*up)",
                      "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4),
                      "bytes_per_launch": int(kern_bytes), "us_per_launch": round(kern_s * 1e6, 2), **measured_traffic(name)},
         "greedy_tokens_head": [int(t) for t in toks[a.warmup: a.warmup + 8]],
     }
+    if ar is not None:
+        out["allreduce"] = ar
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(model, cfg)
+            out["cpu_baseline"], cpu_toks = cpu_baseline(model, cfg)
+            # greedy_match: the same 16 greedy tokens from an empty context on the GPU (decode engine, token by token) vs the CPU-path restatement
+            tok, gpu_toks = 1000 % cfg.vocab_size, []
+            for pos in range(len(cpu_toks)):
+                model.set_state([tok], [pos])
+                tok = int(model.forward_logits(1)[0].argmax())
+                gpu_toks.append(tok)
+            out["greedy_match"] = gpu_toks == cpu_toks
+            out["greedy_match_detail"] = {"tokens": len(cpu_toks), "first_difference": next((i for i, (x, y) in enumerate(zip(gpu_toks, cpu_toks)) if x != y), None),
+                                          "note": "two f32 summation orders of the same int8-activation arithmetic can pick different tokens at a near-tie (tests/test_dec_model.py measures the spread)"}
         except Exception as e:  # the baseline is a reported extra, never fatal
             out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
     if rank == 0:

@@ -297,6 +297,7 @@ void mrs_kv_pool_set_ref_cnt_for_test(void *pool, int64_t block_id, uint32_t val
 int mrs_comm_unique_id(void *out128);                            /* rank 0: ncclGetUniqueId -> 128 bytes */
 void *mrs_comm_init(const void *id128, int rank, int world);     /* ncclCommInitRank on the current device; NULL on error */
 int mrs_comm_all_reduce_sum_f32(void *comm, float *buf, size_t count, void *stream); /* in place, asynchronous on stream */
+int mrs_comm_nranks(void *comm); /* ncclCommCount */
 void mrs_comm_destroy(void *comm);
 int mrs_llama_set_comm(void *model, void *comm);                 /* required when cfg.world_size > 1 */
 const char *mrs_last_error(void);

@@ -18,7 +18,8 @@ typedef int (*init_rank_fn)(void **, int, nccl_uid, int);
 typedef int (*all_reduce_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);
 typedef int (*destroy_fn)(void *);
 typedef const char *(*errstr_fn)(int);
-struct Rccl { void *h = nullptr; get_uid_fn uid; init_rank_fn init; all_reduce_fn ar; destroy_fn destroy; errstr_fn err; };
+typedef int (*count_fn)(void *, int *);
+struct Rccl { void *h = nullptr; get_uid_fn uid; init_rank_fn init; all_reduce_fn ar; destroy_fn destroy; errstr_fn err; count_fn count; };
 Rccl *rccl() {
   static Rccl r;
   if (r.h) return &r;
@@ -28,7 +29,7 @@ Rccl *rccl() {
   if (!r.h) { mrs_host::fail("RCCL: cannot dlopen librccl.so (%s)", dlerror()); return nullptr; }
   r.uid = (get_uid_fn)dlsym(r.h, "ncclGetUniqueId"); r.init = (init_rank_fn)dlsym(r.h, "ncclCommInitRank");
   r.ar = (all_reduce_fn)dlsym(r.h, "ncclAllReduce"); r.destroy = (destroy_fn)dlsym(r.h, "ncclCommDestroy");
-  r.err = (errstr_fn)dlsym(r.h, "ncclGetErrorString");
+  r.err = (errstr_fn)dlsym(r.h, "ncclGetErrorString"); r.count = (count_fn)dlsym(r.h, "ncclCommCount");
   if (!r.uid || !r.init || !r.ar || !r.destroy) { mrs_host::fail("RCCL: missing symbols in librccl"); r.h = nullptr; return nullptr; }
   return &r;
 }
@@ -57,6 +58,13 @@ extern "C" int mrs_comm_all_reduce_sum_f32(void *comm, float *buf, size_t count,
   Rccl *r = rccl();
   if (!r || !comm) return mrs_host::fail("RCCL communicator not initialised");
   return check(r, r->ar(buf, buf, count, 7, 0, comm, (hipStream_t)stream), "ncclAllReduce");
+}
+// ranks of the communicator as RCCL sees them (ncclCommCount); -1 on error
+extern "C" int mrs_comm_nranks(void *comm) {
+  Rccl *r = rccl();
+  int n = -1;
+  if (!r || !comm || !r->count || r->count(comm, &n) != 0) return -1;
+  return n;
 }
 extern "C" void mrs_comm_destroy(void *comm) {
   Rccl *r = rccl();

@@ -430,11 +430,14 @@ __global__ void __launch_bounds__(64) sample_advance_kernel(const SampleArgs a) 
   a.scratch[c] = 0;
   a.next_ids[c] = idx;
   const int step = *a.step_counter;
-  if (a.tokens_out) a.tokens_out[(size_t)c * a.tokens_out_stride + step] = idx;
+  // a graph replayed past the buffers it was captured for must not write outside them: tokens beyond tokens_out are dropped, and a position
+  // beyond the block table gets the pad slot (-1: reshape_and_cache / the fused epilogues skip it) instead of another sequence's page
+  if (a.tokens_out && step < a.tokens_out_stride) a.tokens_out[(size_t)c * a.tokens_out_stride + step] = idx;
   const int pos = a.positions[c] + 1;
   a.positions[c] = pos;
   a.context_lens[c] = (uint32_t)pos + 1;
-  a.slot_mapping[c] = (int64_t)a.block_tables[(size_t)c * a.max_blocks + pos / a.block_size] * a.block_size + pos % a.block_size;
+  const int blk = pos / a.block_size;
+  a.slot_mapping[c] = blk < a.max_blocks ? (int64_t)a.block_tables[(size_t)c * a.max_blocks + blk] * a.block_size + pos % a.block_size : (int64_t)-1;
   __syncthreads();
   if (c == 0) *a.step_counter = step + 1;
 }

@@ -626,8 +626,7 @@ class Llama {
     const int bs = cfg.block_size, kvh = cfg.num_kv_heads;
     const int eff_max = std::min(cfg.max_blocks_per_seq * bs, cfg.max_context_len);
     const int parts = (eff_max + 511) / 512;
-    const bool use_v1 = (parts == 1 || (long)T * cfg.num_heads > 512);  // paged_attention.rs:302-307
-    if (!use_v1) return fail("prefill: context too long for the v1 attention path of this round");
+    const bool use_v1 = (parts == 1 || (long)T * cfg.num_heads > 512);  // paged_attention.rs:302-307 (only consulted when the MFMA flash kernel refuses the shape)
     for (size_t li = 0; li < blocks.size(); ++li) {
       const Block &bl = blocks[li];
       if (!bl.q_proj || !bl.key_cache) return fail("layer %zu is incomplete", li);
@@ -640,10 +639,20 @@ class Llama {
       // causal attention over the pages just written: MFMA flash kernel (head_dim 128 / block 32), else prompt token t = "sequence" t
       // of the decode-style kernel with context_lens[t] = pos + 1
       if (mrs_prefill_attention_f32_bf16(q, bl.key_cache, bl.value_cache, pa.block_tables, attn, T, start_pos, cfg.num_heads, kvh, hd, bs, nq, nq,
-                                         kvh * hd * bs, hd * bs, 1.0f / sqrtf((float)hd), s) != 0)
-      mrs_paged_attention_f32_bf16(0, attn, nullptr, nullptr, nullptr, q, bl.key_cache, bl.value_cache, nullptr, kvh, 1.0f / sqrtf((float)hd), 1.0f,
-                                   pa.block_tables, pa.context_lens, bs, eff_max, T, cfg.num_heads, hd, cfg.max_blocks_per_seq, nq, kvh * hd * bs,
-                                   hd * bs, s, nullptr);
+                                         kvh * hd * bs, hd * bs, 1.0f / sqrtf((float)hd), s) != 0) {
+        // fallback for head / block sizes outside the flash kernel: prompt token t = "sequence" t of the decode-style kernel.  v1 keeps all logits of
+        // a sequence in LDS, so long contexts with few (token, head) pairs take v2 over 512-token partitions with the runner's partial buffers
+        if (use_v1) {
+          mrs_paged_attention_f32_bf16(0, attn, nullptr, nullptr, nullptr, q, bl.key_cache, bl.value_cache, nullptr, kvh, 1.0f / sqrtf((float)hd), 1.0f,
+                                       pa.block_tables, pa.context_lens, bs, eff_max, T, cfg.num_heads, hd, cfg.max_blocks_per_seq, nq, kvh * hd * bs,
+                                       hd * bs, s, nullptr);
+        } else {
+          if (T > cfg.max_batch) return fail("prefill: %d prompt tokens at max_context_len %d need the v2 attention workspace of %d sequences; use prompts of <= %d tokens or the flash-attention shapes (head_dim 128, block 32)", T, cfg.max_context_len, T, cfg.max_batch);
+          mrs_paged_attention_f32_bf16(1, attn, ws.exp_sums, ws.max_logits, ws.attn_ws, q, bl.key_cache, bl.value_cache, nullptr, kvh, 1.0f / sqrtf((float)hd), 1.0f,
+                                       pa.block_tables, pa.context_lens, bs, eff_max, T, cfg.num_heads, hd, cfg.max_blocks_per_seq, nq, kvh * hd * bs,
+                                       hd * bs, s, nullptr);
+        }
+      }
       if (cfg.world_size > 1) {  // row-parallel: partial -> all-reduce -> residual add (bias-free)
         if (gemm(*bl.o_proj, attn, nq, xn, d, 0) || all_reduce(xn, t * d, s) || mrs_vec_add_f32(h, xn, t * d, s)) return -1;
       } else if (gemm(*bl.o_proj, attn, nq, h, d, 1)) return -1;

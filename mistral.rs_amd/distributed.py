@@ -165,6 +165,11 @@ class RcclComm:
         if not self.handle:
             raise RuntimeError((L.mrs_last_error() or b"").decode())
 
+    def nranks(self) -> int:
+        """Ranks of the communicator as RCCL counts them (ncclCommCount)."""
+        self._L.mrs_comm_nranks.argtypes = [C.c_void_p]
+        return int(self._L.mrs_comm_nranks(self.handle))
+
     def all_reduce_(self, t: torch.Tensor) -> torch.Tensor:
         assert t.dtype == torch.float32 and t.is_contiguous()
         if self._L.mrs_comm_all_reduce_sum_f32(self.handle, t.data_ptr(), t.numel(), torch.cuda.current_stream().cuda_stream) != 0:

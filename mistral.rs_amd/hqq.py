@@ -56,6 +56,9 @@ def pack(bits: int, wq: torch.Tensor) -> torch.Tensor:
     st = torch.cuda.current_stream().cuda_stream
     if bits == 3:
         src = wq.to(torch.int32).contiguous()  # the reference feeds u32
+        if rows % p:  # the reference zero-pads the rows to a multiple of 10 before packing (hqq/mod.rs:401-410); dequantize() trims
+            src = torch.cat([src, torch.zeros(p - rows % p, width, dtype=torch.int32, device=wq.device)], 0).contiguous()
+            rows = src.shape[0]
         out = torch.empty(rows // p, width, dtype=torch.int32, device=wq.device)
     else:
         src = wq.to(torch.uint8).contiguous()

@@ -66,6 +66,11 @@ class LlamaConfig:
                    rope_theta=1e6, num_experts=8, num_experts_per_tok=2, **kw)
 
     @classmethod
+    def llama3_70b(cls, **kw):  # BASELINE.json configs[3]
+        return cls(hidden_size=8192, intermediate_size=28672, num_layers=80, num_heads=64, num_kv_heads=8, vocab_size=128256,
+                   rope_theta=500000.0, rope_scaling=RopeScaling("llama3", 8.0, 1.0, 4.0, 8192), **kw)
+
+    @classmethod
     def llama3_8b(cls, **kw):
         return cls(hidden_size=4096, intermediate_size=14336, num_layers=32, num_heads=32, num_kv_heads=8, vocab_size=128256,
                    rope_theta=500000.0, rope_scaling=RopeScaling("llama3", 8.0, 1.0, 4.0, 8192), **kw)
@@ -163,6 +168,8 @@ class Llama:
         if not self._h:
             raise ValueError(self._err())
         self._keep: dict = {}
+        if cfg.max_context_len > cfg.max_position_embeddings:
+            raise ValueError(f"max_context_len {cfg.max_context_len} exceeds max_position_embeddings {cfg.max_position_embeddings} (the RoPE tables)")
         if cfg.kv_dtype not in ("bf16", "f16"):
             raise ValueError("kv_dtype must be bf16 or f16")
         # decode engine: wanted unless switched off; possible while every linear registered so far has a decode layout
@@ -202,6 +209,7 @@ class Llama:
                   self.cos.data_ptr(), self.sin.data_ptr(), self.logits.data_ptr(), self.workspace.data_ptr(), self.workspace.numel())
         self._chk(L.mrs_llama_set_buffers(self._h, C.byref(b)))
         self._graph = None
+        self._replays_left = None
 
     # -------------------------------------------------------------------------------------------------
     def _err(self) -> str:
@@ -266,6 +274,7 @@ class Llama:
         self.positions[:b] = torch.tensor(pos.astype(np.int32), device=self.device)
         self.context_lens[:b] = torch.tensor((pos + 1).astype(np.int32), device=self.device)
         self.slot_mapping[:b] = torch.tensor(slots, device=self.device)
+        self._replays_left = None  # recomputed from the device state at the next replay()
 
     @property
     def decode_path(self) -> str:
@@ -313,6 +322,12 @@ class Llama:
             t.copy_(v)
 
     def replay(self) -> None:
+        # the captured step advances device-side state; refuse to run it past the buffers it indexes (tokens_out, block table, RoPE tables)
+        if self._replays_left is None:  # one read-back per set_state(): replays that stay inside the context window and the token buffer
+            self._replays_left = int(min(self.cfg.max_context_len - 1 - int(self.positions.max().item()), self.tokens_out.shape[1] - int(self.step_counter.item())))
+        if self._replays_left <= 0:
+            raise ValueError("replay(): the decode graph would run past max_new_tokens / max_context_len; set_state() to a new position first")
+        self._replays_left -= 1
         self._graph.replay()
 
     def prefill(self, tokens, start_pos: int = 0, seq: int = 0) -> torch.Tensor:

@@ -21,4 +21,5 @@ int mrs_comm_all_reduce_sum_f32(void *comm, float *buf, size_t count, void *stre
   if (!comm || !g_all_reduce) return -1;
   return g_all_reduce(buf, count);
 }
+int mrs_comm_nranks(void *comm) { return comm ? ((struct hiphost_comm *)comm)->world : -1; }
 void mrs_comm_destroy(void *comm) { free(comm); }

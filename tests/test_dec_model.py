@@ -14,13 +14,13 @@ Q8 = lambda O: dict(embd=O.Q8_0, q=O.Q8_0, k=O.Q8_0, v=O.Q8_0, o=O.Q8_0, gate=O.
 Q5 = lambda O: dict(embd=O.Q5_K, q=O.Q5_K, k=O.Q5_K, v=O.Q5_K, o=O.Q5_K, gate=O.Q5_K, up=O.Q5_K, down=O.Q6_K, output=O.Q6_K)
 
 
-def _mk(oracle, dev, types, kv_dtype="bf16", heads=4, kvh=2, layers=2, hidden=512, ff=1024, vocab=512, max_batch=4, seed=0, experts=0, max_new=160):
+def _mk(oracle, dev, types, kv_dtype="bf16", heads=4, kvh=2, layers=2, hidden=512, ff=1024, vocab=512, max_batch=4, seed=0, experts=0, max_new=160, max_ctx=192):
     import torch
     from mistralrs_amd.gguf import GgmlDType, QTensor
     from mistralrs_amd.llama import Llama, LlamaConfig, rope_tables
     from oracle import llama_ref
     cfg = LlamaConfig(hidden_size=hidden, intermediate_size=ff, num_layers=layers, num_heads=heads, num_kv_heads=kvh, vocab_size=vocab, head_dim=128,
-                      rope_theta=10000.0, max_position_embeddings=256, max_batch=max_batch, max_context_len=192, decode_engine=True, kv_dtype=kv_dtype,
+                      rope_theta=10000.0, max_position_embeddings=max(256, max_ctx), max_batch=max_batch, max_context_len=max_ctx, decode_engine=True, kv_dtype=kv_dtype,
                       num_experts=experts, num_experts_per_tok=2)
     w = llama_ref.synth_weights(cfg, types, seed=seed)
     m = Llama(cfg, dev, max_new_tokens=max_new)
@@ -210,6 +210,35 @@ def test_persistent_step_equals_phase_launches(oracle, dev, request):
     ref = outs[0]
     for mode, o in outs.items():
         assert torch.equal(o, ref), f"decode_persist mode {mode} differs from the per-phase kernels: {float((o - ref).abs().max())}"
+
+
+def test_short_prompt_in_long_context_and_replay_guard(oracle, dev, request):
+    """(advisor, round 1) a prompt of <= 16 tokens must prefill when max_context_len > 512 (the v1 / v2 rule of the fallback attention used to refuse
+    before the MFMA flash kernel was even tried), and a captured decode graph must not be replayed past max_new_tokens / max_context_len."""
+    import torch
+    if request.config.getoption("--host-emulation"):
+        pytest.skip("graph capture needs the device")
+    cfg, w, m, cos, sin = _mk(oracle, dev, Q4KM(oracle), "bf16", max_ctx=1024, max_new=6, max_batch=1)
+    prompt = [(1000 + i) % cfg.vocab_size for i in range(9)]
+    lp = m.prefill(prompt, 0)
+    ref = []
+    cfg2, w2, m2, _, _ = _mk(oracle, dev, Q4KM(oracle), "bf16", max_ctx=1024, max_new=6, max_batch=1)
+    for pos, t in enumerate(prompt):
+        m2.set_state([t], [pos])
+        ld = m2.forward_logits(1)[0].clone()
+    assert float((lp - ld).abs().max()) <= 5e-2 * float(ld.abs().max())  # bf16 MFMA prefill vs int8-activation decode: two documented approximations
+    m.set_state([int(lp.argmax())], [len(prompt)])
+    m.step_counter.zero_()
+    m.capture_decode_graph(1)
+    for _ in range(6):
+        m.replay()
+    torch.cuda.synchronize()
+    with pytest.raises(ValueError, match="past max_new_tokens"):
+        m.replay()
+    from mistralrs_amd.llama import Llama, LlamaConfig
+    with pytest.raises(ValueError, match="max_position_embeddings"):
+        Llama(LlamaConfig(hidden_size=256, intermediate_size=512, num_layers=1, num_heads=2, num_kv_heads=1, vocab_size=64, head_dim=128, max_position_embeddings=128,
+                          max_context_len=256), dev)
 
 
 def test_engine_mixtral_moe_vs_cpu_path_oracle(oracle, dev, request):

@@ -283,3 +283,23 @@ def test_llama3_70b_tp8_placement_shapes():
         assert D.llama_tensor_shard(name, total, 3, world) is None  # replicated
     with pytest.raises(ValueError):
         D.local_dims(heads, kvh, ff, 7)
+
+
+def test_bench_launcher_spawns_one_rank_per_gpu():
+    """Driver contract: `python bench.py --gpus N` must measure N GPUs.  Without WORLD_SIZE the script re-launches itself under
+    torch.distributed.run (one process per GPU, tensor parallel by default); MRS_BENCH_DRY_RUN keeps the ranks off the GPU so the launcher
+    itself can be checked here: the line must carry n_gpus == N and the tensor-parallel labels."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MRS_BENCH_DRY_RUN="1")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["parallelism"] == "tp2", j
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--replicas"], env=env, capture_output=True, text=True, timeout=300)
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["parallelism"] == "replicas x2", j

@@ -173,3 +173,22 @@ def test_hqq_layer_quantize_and_forward(dev, bits):
     assert (np.abs(got - want) <= 2.0 ** -18 * mag).all()
     half = layer.to_dtype(torch.bfloat16)
     assert half.dequantize().dtype == torch.bfloat16
+
+
+@pytest.mark.gpu
+def test_hqq_3bit_default_group_size_round_trip(dev):
+    """3 bit with the default group size 64: 64 rows are not a multiple of the 10 values per i32, the reference zero-pads the rows before packing
+    (hqq/mod.rs:401-410) and trims after the dequantize; quantize -> dequantize must give back a [n, k] tensor close to the input."""
+    import torch
+    from mistralrs_amd.hqq import HqqConfig, HqqLayer, pack
+    rng = np.random.default_rng(7)
+    n, k = 128, 64
+    w = (rng.standard_normal((n, k)) * 0.05).astype(np.float32)
+    layer = HqqLayer.quantize(_t(dev, w), HqqConfig(bits=3, group_size=64))
+    assert layer.w_q.shape[0] == 7  # ceil(64 / 10) packed rows per group column
+    back = layer.dequantize().cpu().numpy()
+    assert back.shape == (n, k)
+    assert np.abs(back - w).max() <= 0.25 * np.abs(w).max()  # 8 levels per group
+    # pack() itself: a [64, w] block packs to 7 rows, the padding rows read back as zeros
+    q = torch.from_numpy(rng.integers(0, 8, (64, 16)).astype(np.int32)).to(dev)
+    assert pack(3, q).shape == (7, 16)
