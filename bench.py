@@ -216,12 +216,32 @@ def main():
         cfg.num_heads, cfg.num_kv_heads, cfg.intermediate_size = D.local_dims(cfg.num_heads, cfg.num_kv_heads, cfg.intermediate_size, world)
         cfg.tp_world_size, cfg.tp_rank = world, rank
     model = build_model(cfg, dev, seed=0 if tp else rank, max_new_tokens=a.warmup + a.steps + 8, tp=(rank, world) if tp else None)
-    comm = None
+    comm, p2p = None, None
     if tp:
         from mistralrs_amd import distributed as D
         comm = D.RcclComm(rank, world, dev)
         assert comm.nranks() == world, f"RCCL communicator has {comm.nranks()} ranks, expected {world}"
         model.set_comm(comm)
+        # decode-sized all-reduces: one-shot peer-mailbox route (csrc/ext_p2p.hip) when it is available AND agrees with RCCL on a probe vector on
+        # every rank; otherwise RCCL carries everything
+        p2p, p2p_note = None, "rccl only"
+        if not os.environ.get("MRS_NO_P2P"):
+            try:
+                p2p = D.P2PAllReduce(rank, world, dev)
+                probe = (torch.arange(4096, device=dev, dtype=torch.float32) % 97) * (rank + 1)
+                a1, a2 = probe.clone(), probe.clone()
+                p2p.all_reduce_(a1)
+                comm.all_reduce_(a2)
+                torch.cuda.synchronize()
+                good = torch.tensor([int(torch.equal(a1, a2) and p2p.error() == 0)], device=dev)
+            except Exception as e:  # IPC not available on this box
+                good, p2p_note = torch.tensor([0], device=dev), f"rccl only (p2p unavailable: {type(e).__name__})"
+            dist.all_reduce(good, op=dist.ReduceOp.MIN)
+            if int(good.item()) == 1:
+                model.set_p2p(p2p)
+                p2p_note = "one-shot peer-mailbox all-reduce over xGMI (ext_p2p.hip) for [1, hidden]; RCCL for the prefill messages"
+            else:
+                p2p = None
     torch.cuda.synchronize()
 
     def sync():
@@ -315,8 +335,19 @@ def main():
         e1.record()
         sync()
         us = e0.elapsed_time(e1) * 1e3 / 200
-        ar = {"us_per_call": round(us, 2), "calls_per_step": 2 * cfg.num_layers, "bytes": cfg.hidden_size * 4,
-              "frac_of_step": round(us * 2 * cfg.num_layers / (1e6 * t_all / a.steps), 4), "impl": "rccl ncclAllReduce f32 (back-to-back launches; in the step they sit inside the captured graph)"}
+        ar = {"rccl_us_per_call": round(us, 2), "calls_per_step": 2 * cfg.num_layers, "bytes": cfg.hidden_size * 4, "decode_route": p2p_note}
+        if p2p is not None:
+            for _ in range(10):
+                p2p.all_reduce_(buf)
+            sync()
+            e0.record()
+            for _ in range(200):
+                p2p.all_reduce_(buf)
+            e1.record()
+            sync()
+            ar["p2p_us_per_call"] = round(e0.elapsed_time(e1) * 1e3 / 200, 2)
+        used = ar.get("p2p_us_per_call", ar["rccl_us_per_call"])
+        ar["frac_of_step"] = round(used * 2 * cfg.num_layers / (1e6 * t_all / a.steps), 4)  # back-to-back launches; in the step they sit inside the captured graph
 
     avg_ctx = a.prompt_len + a.warmup + a.steps / 2
     step_bytes = model.decode_bytes(1, int(avg_ctx))

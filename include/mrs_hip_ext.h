@@ -298,6 +298,21 @@ int mrs_comm_unique_id(void *out128);                            /* rank 0: nccl
 void *mrs_comm_init(const void *id128, int rank, int world);     /* ncclCommInitRank on the current device; NULL on error */
 int mrs_comm_all_reduce_sum_f32(void *comm, float *buf, size_t count, void *stream); /* in place, asynchronous on stream */
 int mrs_comm_nranks(void *comm); /* ncclCommCount */
+/* ---- one-shot all-reduce over peer-mapped mailboxes (ext_p2p.hip) for decode-sized messages: every rank writes its vector into every peer's
+ * mailbox over xGMI (one hop), polls its own mailbox and sums in rank order (bit-identical on all ranks); graph-capturable; messages larger than
+ * max_elems return -2 (keep RCCL for those).  Replaces ncclAllReduce at distributed/mod.rs:584-587 for [b, hidden] messages. */
+size_t mrs_p2p_mailbox_bytes(int world, size_t max_elems);
+int mrs_ipc_get_handle(void *dev_ptr, void *out64);      /* hipIpcGetMemHandle */
+void *mrs_ipc_open_handle(const void *in64);             /* hipIpcOpenMemHandle */
+int mrs_ipc_close_handle(void *ptr);
+void *mrs_p2p_create(int rank, int world, void *const *mailboxes, size_t max_elems); /* mailboxes: zeroed, mrs_p2p_mailbox_bytes each */
+void mrs_p2p_destroy(void *comm);
+size_t mrs_p2p_max_elems(void *comm);
+int mrs_p2p_all_reduce_sum_f32(void *comm, float *buf, size_t count, void *stream);
+int mrs_p2p_post(void *comm, const float *buf, size_t count, void *stream);   /* the two halves as separate launches (tests) */
+int mrs_p2p_reduce(void *comm, float *buf, size_t count, void *stream);
+int mrs_p2p_error(void *comm);                            /* 1: a peer never posted (blocking read of the error word) */
+int mrs_llama_set_p2p(void *model, void *p2p_comm);      /* row-parallel all-reduces of <= max_elems values take this route, larger ones RCCL */
 void mrs_comm_destroy(void *comm);
 int mrs_llama_set_comm(void *model, void *comm);                 /* required when cfg.world_size > 1 */
 const char *mrs_last_error(void);

@@ -1,0 +1,149 @@
+// ext_p2p.hip -- one-shot all-reduce over peer-mapped mailboxes for the decode-sized messages of tensor parallelism.
+//
+// Role: SumAllReduce after every row-parallel projection (mistralrs-quant/src/distributed/layers.rs:965-975 -> ncclAllReduce,
+// distributed/mod.rs:584-587).  In decode the message is [b, hidden] f32 = 16-256 KiB, 2 x layers times per token: a ring all-reduce is
+// latency-bound there (2 (N-1) hops), while xGMI is a full point-to-point mesh (7 links per GPU), so every rank can write its whole vector
+// straight into every peer's HBM in ONE hop and sum locally:
+//   post:    rank r stores its values as 8-byte granules {f32 bits, sequence number} into slot r of EVERY rank's mailbox (its own included)
+//            -- one naturally aligned 8-byte store per value, so a reader can never see a value without its tag (no flag, no fence, no
+//            ordering assumption about the fabric);
+//   reduce:  each rank polls the `world` slots of its own mailbox until every granule carries the current sequence number and adds them in
+//            rank order -- every rank computes bit-identical sums (the reference's NCCL ring does not guarantee that).
+// Two mailbox halves alternate (sequence parity): a rank that is already posting all-reduce n+1 cannot overwrite granules a slower peer still
+// reads for n, and nobody can start n+2 before every peer has posted n+1, i.e. finished reading n.
+// One workgroup per call (the message is a few thousand values; latency, not bandwidth), no host work: the sequence number lives in device
+// memory and is advanced by the kernel, so the call is graph-capturable like ncclAllReduce.  Messages above `max_elems` are refused (-2):
+// the caller keeps RCCL for those (prefill: [T, hidden]).  Mailboxes are plain device allocations shared with hipIpcGetMemHandle /
+// hipIpcOpenMemHandle (one process per GPU); a spin that sees no progress gives up and raises the error word instead of hanging.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+namespace mrs_host { int fail(const char *fmt, ...); }
+
+namespace mrs {
+namespace p2p {
+
+constexpr int MAX_WORLD = 16, NT = 1024;
+struct Comm {
+  int rank, world;
+  unsigned long long *mail[MAX_WORLD];  // mail[r]: base of rank r's mailbox, [2 parity][world src][max_elems] granules
+  unsigned *state;                      // own device memory: [0] sequence number of the last finished call, [1] error flag
+  size_t max_elems;
+};
+
+#ifndef MRS_P2P_SYSTEM_IO
+#define MRS_P2P_STORE(P, V) __hip_atomic_store((P), (V), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+#define MRS_P2P_LOAD(P) __hip_atomic_load((P), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+#endif
+
+__device__ __forceinline__ void post(const Comm &c, const float *buf, size_t count, unsigned seq) {
+  const size_t half = (size_t)(seq & 1) * c.world * c.max_elems;
+  for (size_t i = threadIdx.x; i < count; i += NT) {
+    const unsigned long long g = (unsigned long long)__float_as_uint(buf[i]) | ((unsigned long long)seq << 32);
+    for (int r = 0; r < c.world; ++r) MRS_P2P_STORE(c.mail[r] + half + (size_t)c.rank * c.max_elems + i, g);
+  }
+}
+// returns false if a granule never arrived (bounded spin)
+__device__ __forceinline__ bool reduce(const Comm &c, float *buf, size_t count, unsigned seq) {
+  const size_t half = (size_t)(seq & 1) * c.world * c.max_elems;
+  bool ok = true;
+  for (size_t i = threadIdx.x; i < count; i += NT) {
+    float sum = 0.f;
+    for (int r = 0; r < c.world; ++r) {
+      const unsigned long long *p = c.mail[c.rank] + half + (size_t)r * c.max_elems + i;
+      unsigned long long g = MRS_P2P_LOAD(p);
+      for (unsigned spins = 0; (unsigned)(g >> 32) != seq; ++spins) {
+        if (spins > (1u << 24)) { ok = false; break; }
+        __builtin_amdgcn_s_sleep(1);
+        g = MRS_P2P_LOAD(p);
+      }
+      sum += __uint_as_float((unsigned)g);  // rank order: identical bits on every rank
+    }
+    buf[i] = sum;
+  }
+  return ok;
+}
+
+__global__ void __launch_bounds__(NT) all_reduce_kernel(const Comm c, float *buf, size_t count) {
+  const unsigned seq = c.state[0] + 1;
+  post(c, buf, count, seq);
+  const bool ok = reduce(c, buf, count, seq);
+  if (!ok) c.state[1] = 1;
+  __syncthreads();  // every thread has read state[0]
+  if (threadIdx.x == 0) c.state[0] = seq;
+}
+// the two halves as separate launches (tests on a sequential schedule: post on every rank, then reduce on every rank)
+__global__ void __launch_bounds__(NT) post_kernel(const Comm c, const float *buf, size_t count) { post(c, buf, count, c.state[0] + 1); }
+__global__ void __launch_bounds__(NT) reduce_kernel(const Comm c, float *buf, size_t count) {
+  const unsigned seq = c.state[0] + 1;
+  if (!reduce(c, buf, count, seq)) c.state[1] = 1;
+  __syncthreads();
+  if (threadIdx.x == 0) c.state[0] = seq;
+}
+
+}  // namespace p2p
+}  // namespace mrs
+
+using mrs::p2p::Comm;
+
+extern "C" size_t mrs_p2p_mailbox_bytes(int world, size_t max_elems) { return world > 0 ? (size_t)2 * world * max_elems * 8 + 256 : 0; }
+// hipIpcGetMemHandle / hipIpcOpenMemHandle of a mailbox (64-byte handles, exchanged by the host framework); HSA_ENABLE_IPC_MODE_LEGACY=0 on this stack
+extern "C" int mrs_ipc_get_handle(void *dev_ptr, void *out64) {
+  hipIpcMemHandle_t h;
+  if (hipIpcGetMemHandle(&h, dev_ptr) != hipSuccess) return mrs_host::fail("hipIpcGetMemHandle failed (HSA_ENABLE_IPC_MODE_LEGACY=0 set?)");
+  memcpy(out64, &h, sizeof h);
+  return 0;
+}
+extern "C" void *mrs_ipc_open_handle(const void *in64) {
+  hipIpcMemHandle_t h;
+  memcpy(&h, in64, sizeof h);
+  void *p = nullptr;
+  if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { mrs_host::fail("hipIpcOpenMemHandle failed"); return nullptr; }
+  return p;
+}
+extern "C" int mrs_ipc_close_handle(void *p) { return hipIpcCloseMemHandle(p) == hipSuccess ? 0 : -1; }
+
+// mailboxes[r] = rank r's mailbox as addressable from THIS process (own allocation for r == rank, an opened IPC handle otherwise), each
+// mrs_p2p_mailbox_bytes(world, max_elems) bytes and zeroed before the first call on any rank
+extern "C" void *mrs_p2p_create(int rank, int world, void *const *mailboxes, size_t max_elems) {
+  if (world < 1 || world > mrs::p2p::MAX_WORLD || rank < 0 || rank >= world || !mailboxes || !max_elems) { mrs_host::fail("mrs_p2p_create: bad arguments"); return nullptr; }
+  Comm *c = (Comm *)calloc(1, sizeof(Comm));
+  if (!c) return nullptr;
+  c->rank = rank; c->world = world; c->max_elems = max_elems;
+  for (int r = 0; r < world; ++r) {
+    if (!mailboxes[r]) { free(c); mrs_host::fail("mrs_p2p_create: mailbox %d missing", r); return nullptr; }
+    c->mail[r] = (unsigned long long *)mailboxes[r];
+  }
+  c->state = (unsigned *)((char *)mailboxes[rank] + (size_t)2 * world * max_elems * 8);  // the tail of the own mailbox
+  return c;
+}
+extern "C" void mrs_p2p_destroy(void *comm) { free(comm); }
+extern "C" size_t mrs_p2p_max_elems(void *comm) { return comm ? ((Comm *)comm)->max_elems : 0; }
+// in-place sum all-reduce of buf[count] f32 on `stream`; -2: message larger than the mailboxes (use RCCL)
+extern "C" int mrs_p2p_all_reduce_sum_f32(void *comm, float *buf, size_t count, void *stream) {
+  if (!comm) return mrs_host::fail("p2p all-reduce: no communicator");
+  const Comm &c = *(Comm *)comm;
+  if (count > c.max_elems) return -2;
+  if (!count) return 0;
+  hipLaunchKernelGGL(mrs::p2p::all_reduce_kernel, dim3(1), dim3(mrs::p2p::NT), 0, (hipStream_t)stream, c, buf, count);
+  return 0;
+}
+extern "C" int mrs_p2p_post(void *comm, const float *buf, size_t count, void *stream) {
+  if (!comm || count > ((Comm *)comm)->max_elems) return -2;
+  hipLaunchKernelGGL(mrs::p2p::post_kernel, dim3(1), dim3(mrs::p2p::NT), 0, (hipStream_t)stream, *(Comm *)comm, buf, count);
+  return 0;
+}
+extern "C" int mrs_p2p_reduce(void *comm, float *buf, size_t count, void *stream) {
+  if (!comm || count > ((Comm *)comm)->max_elems) return -2;
+  hipLaunchKernelGGL(mrs::p2p::reduce_kernel, dim3(1), dim3(mrs::p2p::NT), 0, (hipStream_t)stream, *(Comm *)comm, buf, count);
+  return 0;
+}
+// error word of the last calls (1: a granule never arrived -- a peer is not running the same sequence of all-reduces); blocking read
+extern "C" int mrs_p2p_error(void *comm) {
+  if (!comm) return -1;
+  unsigned st[2] = {0, 0};
+  if (hipMemcpy(st, ((Comm *)comm)->state, 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (int)st[1];
+}

@@ -196,10 +196,15 @@ class Llama {
   mutable bool dec_table_ready = false, dec_table_unfit = false;
   int dec_persist = [] { const char *e = getenv("MRS_DEC_PERSIST"); return e ? atoi(e) : 0; }();  // default 0: measured slower than per-phase kernels on MI355X
   void *comm = nullptr;  // RCCL communicator (ext_comm.hip) when cfg.world_size > 1
+  void *p2p = nullptr;   // one-shot peer-mailbox all-reduce (ext_p2p.hip) for decode-sized messages
 
   // SumAllReduce of a row-parallel output (distributed/layers.rs:965-975), in place on the runner's stream
   int all_reduce(float *buf, size_t count, hipStream_t s) const {
     if (cfg.world_size <= 1) return 0;
+    if (p2p) {  // decode-sized messages: one-shot write-to-all-peers all-reduce (ext_p2p.hip); -2 = too large for the mailboxes
+      const int rc = mrs_p2p_all_reduce_sum_f32(p2p, buf, count, s);
+      if (rc != -2) return rc;
+    }
     if (!comm) return fail("tensor parallel world_size %d but no communicator was set (mrs_llama_set_comm)", cfg.world_size);
     return mrs_comm_all_reduce_sum_f32(comm, buf, count, s);
   }
@@ -858,3 +863,4 @@ extern "C" int mrs_llama_prefill(void *m, const mrs_llama_prefill_args *a, int T
 }
 extern "C" double mrs_llama_prefill_flops(void *m, int T) { return ((Llama *)m)->prefill_flops(T); }
 extern "C" int mrs_llama_set_comm(void *m, void *comm) { ((Llama *)m)->comm = comm; return 0; }
+extern "C" int mrs_llama_set_p2p(void *m, void *p2p) { ((Llama *)m)->p2p = p2p; return 0; }

@@ -175,3 +175,57 @@ class RcclComm:
         if self._L.mrs_comm_all_reduce_sum_f32(self.handle, t.data_ptr(), t.numel(), torch.cuda.current_stream().cuda_stream) != 0:
             raise RuntimeError((self._L.mrs_last_error() or b"").decode())
         return t
+
+
+class P2PAllReduce:
+    """One-shot all-reduce over peer-mapped mailboxes (csrc/ext_p2p.hip) for the decode-sized messages of tensor parallelism: every rank
+    allocates a mailbox, the 64-byte IPC handles travel through torch.distributed (all_gather_object), every rank opens its peers' mailboxes
+    (hipIpcOpenMemHandle; the processes need HSA_ENABLE_IPC_MODE_LEGACY=0 on this stack).  Replaces ncclAllReduce
+    (mistralrs-quant/src/distributed/mod.rs:584-587) for messages of <= max_elems f32; larger ones stay on RCCL (Llama.set_comm)."""
+
+    def __init__(self, rank: int, world_size: int, device: torch.device, max_elems: int = 8 * 8192):
+        import torch.distributed as dist
+        from . import _lib
+        L = _lib.load("ext")
+        L.mrs_p2p_mailbox_bytes.restype = C.c_size_t
+        L.mrs_p2p_mailbox_bytes.argtypes = [C.c_int, C.c_size_t]
+        L.mrs_ipc_get_handle.argtypes = [C.c_void_p, C.c_void_p]
+        L.mrs_ipc_open_handle.restype = C.c_void_p
+        L.mrs_ipc_open_handle.argtypes = [C.c_void_p]
+        L.mrs_p2p_create.restype = C.c_void_p
+        L.mrs_p2p_create.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_size_t]
+        L.mrs_p2p_all_reduce_sum_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.mrs_p2p_error.argtypes = [C.c_void_p]
+        L.mrs_last_error.restype = C.c_char_p
+        self._L, self.rank, self.world_size, self.max_elems = L, rank, world_size, max_elems
+        torch.cuda.set_device(device)
+        self.mailbox = torch.zeros(L.mrs_p2p_mailbox_bytes(world_size, max_elems), dtype=torch.uint8, device=device)
+        torch.cuda.synchronize()
+        mine = (C.c_char * 64)()
+        if L.mrs_ipc_get_handle(self.mailbox.data_ptr(), mine) != 0:
+            raise RuntimeError((L.mrs_last_error() or b"").decode())
+        handles = [None] * world_size
+        dist.all_gather_object(handles, bytes(mine))
+        ptrs = (C.c_void_p * world_size)()
+        for r, hb in enumerate(handles):
+            if r == rank:
+                ptrs[r] = self.mailbox.data_ptr()
+            else:
+                p = L.mrs_ipc_open_handle(C.create_string_buffer(hb, 64))
+                if not p:
+                    raise RuntimeError((L.mrs_last_error() or b"").decode())
+                ptrs[r] = p
+        dist.barrier()  # every mailbox is zeroed and mapped before the first granule is written
+        self.handle = L.mrs_p2p_create(rank, world_size, ptrs, max_elems)
+        if not self.handle:
+            raise RuntimeError((L.mrs_last_error() or b"").decode())
+
+    def all_reduce_(self, t: torch.Tensor) -> torch.Tensor:
+        assert t.dtype == torch.float32 and t.is_contiguous()
+        rc = self._L.mrs_p2p_all_reduce_sum_f32(self.handle, t.data_ptr(), t.numel(), torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise RuntimeError("message larger than the mailboxes: use RCCL" if rc == -2 else (self._L.mrs_last_error() or b"").decode())
+        return t
+
+    def error(self) -> int:
+        return int(self._L.mrs_p2p_error(self.handle))

@@ -232,6 +232,12 @@ class Llama:
         self._comm = comm
         self._chk(self._L.mrs_llama_set_comm(self._h, comm.handle))
 
+    def set_p2p(self, p2p) -> None:
+        """Attach the one-shot peer-mailbox all-reduce (distributed.P2PAllReduce): decode-sized row-parallel all-reduces take it, larger ones RCCL."""
+        self._p2p = p2p
+        self._L.mrs_llama_set_p2p.argtypes = [C.c_void_p, C.c_void_p]
+        self._chk(self._L.mrs_llama_set_p2p(self._h, p2p.handle))
+
     def set_tensor(self, name: str, t) -> None:
         """t: QTensor (packed GGUF blocks) or an f32 torch tensor (norm weights)."""
         if isinstance(t, QTensor):

@@ -258,7 +258,12 @@ extern "C" inline __bf16 __truncsfbf2(float f) {
 #define __hip_atomic_fetch_add(P, V, ORDER, SCOPE) atomicAdd((P), (V))
 #define __hip_atomic_load(P, ORDER, SCOPE) (*(P))
 #define __hip_atomic_store(P, V, ORDER, SCOPE) (*(P) = (V))
-enum { hipMemcpyHostToDevice = 1, hipDeviceAttributeMultiprocessorCount = 63 };
+enum { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipDeviceAttributeMultiprocessorCount = 63, hipIpcMemLazyEnablePeerAccess = 1 };
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
+struct hipIpcMemHandle_t { char reserved[64]; };
+static inline hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t *h, void *p) { memset(h, 0, sizeof *h); memcpy(h, &p, sizeof p); return hipSuccess; }  /* one address space */
+static inline hipError_t hipIpcOpenMemHandle(void **p, hipIpcMemHandle_t h, unsigned) { memcpy(p, &h, sizeof *p); return hipSuccess; }
+static inline hipError_t hipIpcCloseMemHandle(void *) { return hipSuccess; }
 static inline hipError_t hipMemcpy(void *d, const void *s_, size_t n, int) { memcpy(d, s_, n); return hipSuccess; }
 static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipDeviceGetAttribute(int *v, int, int) { *v = 4; return hipSuccess; }  /* the emulated "chip": 4 CUs (persistent step: 4 workgroups) */

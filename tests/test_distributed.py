@@ -303,3 +303,75 @@ def test_bench_launcher_spawns_one_rank_per_gpu():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--replicas"], env=env, capture_output=True, text=True, timeout=300)
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["parallelism"] == "replicas x2", j
+
+
+def _p2p_world(be, world, max_elems):
+    """`world` communicators in ONE address space (plain pointers instead of IPC handles): the kernels cannot tell the difference."""
+    import ctypes as C
+    nbytes = be.sym("mrs_p2p_mailbox_bytes", [C.c_int, C.c_size_t], C.c_size_t)(world, max_elems)
+    boxes = [be.buf(np.zeros(nbytes, dtype=np.uint8)) for _ in range(world)]
+    ptrs = (C.c_void_p * world)(*[b.ptr for b in boxes])
+    create = be.sym("mrs_p2p_create", [C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_size_t], C.c_void_p)
+    return boxes, [create(r, world, ptrs, max_elems) for r in range(world)]
+
+
+def check_p2p_all_reduce_split_launches(be, world, count, rounds=5):
+    """post on every rank, then reduce on every rank (the schedule a sequential emulation can run): sums in rank order, identical bits on every
+    rank, the two mailbox halves alternate over the rounds, oversized messages are refused (-2: RCCL keeps those)."""
+    import ctypes as C
+    max_elems = 4096
+    boxes, comms = _p2p_world(be, world, max_elems)
+    post = be.sym("mrs_p2p_post", [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p], C.c_int)
+    red = be.sym("mrs_p2p_reduce", [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p], C.c_int)
+    rng = np.random.default_rng(world)
+    for it in range(rounds):
+        xs = [rng.standard_normal(count).astype(np.float32) for _ in range(world)]
+        bufs = [be.buf(x) for x in xs]
+        for r in range(world):
+            assert post(comms[r], bufs[r].ptr, count, be.stream) == 0
+        for r in range(world):
+            assert red(comms[r], bufs[r].ptr, count, be.stream) == 0
+        want = np.zeros(count, dtype=np.float32)
+        for x in xs:  # rank order, f32
+            want = (want + x).astype(np.float32)
+        for r in range(world):
+            np.testing.assert_array_equal(bufs[r].numpy().view(np.uint32), want.view(np.uint32))
+    assert be.sym("mrs_p2p_all_reduce_sum_f32", [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p], C.c_int)(comms[0], bufs[0].ptr, max_elems + 1, be.stream) == -2
+    err = be.sym("mrs_p2p_error", [C.c_void_p], C.c_int)
+    assert all(err(c) == 0 for c in comms)
+    for c in comms:
+        be.sym("mrs_p2p_destroy", [C.c_void_p], None)(c)
+
+
+@pytest.mark.parametrize("world,count", [(2, 300), (8, 4096), (3, 1)])
+def test_p2p_all_reduce_host_emulation(world, count):
+    from tests.abi_backends import HostBackend
+    check_p2p_all_reduce_split_launches(HostBackend(), world, count)
+
+
+@pytest.mark.gpu
+def test_p2p_all_reduce_gpu_split_and_concurrent(dev):
+    """On one MI355X: (i) the split launches; (ii) the REAL one-kernel all-reduce of 4 "ranks" launched on 4 streams of the same device -- the
+    kernels poll each other's granules while running concurrently, exactly as 4 GPUs would (mailboxes in one address space instead of IPC)."""
+    import ctypes as C
+    import torch
+    from tests.abi_backends import GpuBackend
+    be = GpuBackend(dev)
+    check_p2p_all_reduce_split_launches(be, 4, 4096)
+    world, count = 4, 8192
+    boxes, comms = _p2p_world(be, world, 16384)
+    ar = be.sym("mrs_p2p_all_reduce_sum_f32", [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p], C.c_int)
+    streams = [torch.cuda.Stream() for _ in range(world)]
+    torch.cuda.synchronize()
+    for it in range(6):
+        xs = [torch.randn(count, device=dev) for _ in range(world)]
+        want = torch.zeros(count, device=dev)
+        for x in xs:
+            want = want + x
+        torch.cuda.synchronize()
+        for r in range(world):
+            assert ar(comms[r], xs[r].data_ptr(), count, streams[r].cuda_stream) == 0
+        torch.cuda.synchronize()
+        for r in range(world):
+            assert torch.equal(xs[r], want), (it, r)
+    assert all(be.sym("mrs_p2p_error", [C.c_void_p], C.c_int)(c) == 0 for c in comms)
