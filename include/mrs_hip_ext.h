@@ -311,6 +311,7 @@ size_t mrs_p2p_max_elems(void *comm);
 int mrs_p2p_all_reduce_sum_f32(void *comm, float *buf, size_t count, void *stream);
 int mrs_p2p_post(void *comm, const float *buf, size_t count, void *stream);   /* the two halves as separate launches (tests) */
 int mrs_p2p_reduce(void *comm, float *buf, size_t count, void *stream);
+int mrs_p2p_all_reduce_group(void *const *comms, float *const *bufs, int n, size_t count, void *stream); /* test: n ranks of one address space as one grid */
 int mrs_p2p_error(void *comm);                            /* 1: a peer never posted (blocking read of the error word) */
 int mrs_llama_set_p2p(void *model, void *p2p_comm);      /* row-parallel all-reduces of <= max_elems values take this route, larger ones RCCL */
 void mrs_comm_destroy(void *comm);

@@ -138,31 +138,44 @@ __device__ __forceinline__ float wave_sum_all(float v) {
 }
 
 
-// quantize the 4 values a lane holds at element e (all lanes of the wave together: one 256-block in Q8_K mode, 8 blocks of 32 in Q8_0 mode)
-__device__ __forceinline__ void quantize4(float4 v, int e, bool in, int mode, char *qc, float *dc, int *bsc) {
+// round half away from zero (C roundf / Rust f32::round) for |x| < 2^23, exact: trunc + a compare on the exact fraction
+__device__ __forceinline__ float round_away(float x) {
+  const float t = truncf(x);
+  return fabsf(x - t) >= 0.5f ? t + copysignf(1.0f, x) : t;
+}
+
+// quantize the 4 values a lane holds at element e (all lanes of the wave together: one 256-block in Q8_K mode, 8 blocks of 32 in Q8_0 mode).
+// qoff = byte offset of the lane's 4 quants inside the column's (swizzled) int8 image.
+__device__ __forceinline__ void quantize4(float4 v, int e, int qoff, bool in, int mode, char *qc, float *dc, int *bsc) {
   const int lane = lane_opaque();
   if (mode == ACT_Q8K) {
     const float ax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
     const float amax = wave_max_all(ax);
-    const int cand = fabsf(v.x) == amax ? 0 : (fabsf(v.y) == amax ? 1 : (fabsf(v.z) == amax ? 2 : (fabsf(v.w) == amax ? 3 : 1 << 20)));
-    const int first = wave_min_all(lane * 4 + cand);  // first element of the block with |x| == amax (candle keeps the first maximum)
-    const int sl = (first >> 2) & 63, comp = first & 3;
-    const float mx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, comp == 0 ? v.x : (comp == 1 ? v.y : (comp == 2 ? v.z : v.w))), sl));
+    // candle keeps the FIRST element with the largest magnitude and its sign decides iscale.  Only when +amax and -amax both occur in the block
+    // does the order matter: two ballots settle the common case, the exact first-index search runs for such ties only (wave-uniform branch).
+    const unsigned long long bp = __ballot(v.x == amax || v.y == amax || v.z == amax || v.w == amax);
+    const unsigned long long bn = __ballot(v.x == -amax || v.y == -amax || v.z == -amax || v.w == -amax);
+    float mx = bn == 0 ? amax : -amax;
+    if (bp != 0 && bn != 0 && amax != 0.f) {
+      const int cand = fabsf(v.x) == amax ? 0 : (fabsf(v.y) == amax ? 1 : (fabsf(v.z) == amax ? 2 : (fabsf(v.w) == amax ? 3 : 1 << 20)));
+      const int first = wave_min_all(lane * 4 + cand);
+      const int sl = (first >> 2) & 63, comp = first & 3;
+      mx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, comp == 0 ? v.x : (comp == 1 ? v.y : (comp == 2 ? v.z : v.w))), sl));
+    }
     int q0 = 0, q1 = 0, q2 = 0, q3 = 0;
     float dd = 0.f;
-    if (amax != 0.f) {
+    if (amax != 0.f) {  // wave-uniform
       const float iscale = -128.f / mx;
-      q0 = (int)fminf(127.f, roundf(iscale * v.x)); q1 = (int)fminf(127.f, roundf(iscale * v.y));
-      q2 = (int)fminf(127.f, roundf(iscale * v.z)); q3 = (int)fminf(127.f, roundf(iscale * v.w));
+      q0 = (int)fminf(127.f, round_away(iscale * v.x)); q1 = (int)fminf(127.f, round_away(iscale * v.y));
+      q2 = (int)fminf(127.f, round_away(iscale * v.z)); q3 = (int)fminf(127.f, round_away(iscale * v.w));
       dd = 1.0f / iscale;
     }
     int s = (q0 + q1) + (q2 + q3);
     s += dppi<0xB1>(s);
     s += dppi<0x4E>(s);  // 4 lanes = one 16-run
     if (in) {
-      const int piece = e >> 4;
-      *(int *)(qc + (size_t)swz_piece(piece) * 16 + (e & 15)) = (q0 & 0xff) | ((q1 & 0xff) << 8) | ((q2 & 0xff) << 16) | ((q3 & 0xff) << 24);
-      if ((lane & 3) == 0) bsc[piece] = s;
+      *(int *)(qc + qoff) = (q0 & 0xff) | ((q1 & 0xff) << 8) | ((q2 & 0xff) << 16) | ((q3 & 0xff) << 24);
+      if ((lane & 3) == 0) bsc[e >> 4] = s;
       if (lane == 0) dc[e >> 8] = dd;
     }
   } else {
@@ -171,9 +184,9 @@ __device__ __forceinline__ void quantize4(float4 v, int e, bool in, int mode, ch
     amax = fmaxf(amax, dppf<0x4E>(amax));
     amax = fmaxf(amax, dppf<0x141>(amax));  // 8 lanes = one 32-block
     const float dq = amax / 127.0f, id = dq != 0.f ? 1.0f / dq : 0.0f;
-    const int q0 = (int)roundf(v.x * id), q1 = (int)roundf(v.y * id), q2 = (int)roundf(v.z * id), q3 = (int)roundf(v.w * id);
+    const int q0 = (int)round_away(v.x * id), q1 = (int)round_away(v.y * id), q2 = (int)round_away(v.z * id), q3 = (int)round_away(v.w * id);
     if (in) {
-      *(int *)(qc + (size_t)swz_piece(e >> 4) * 16 + (e & 15)) = (q0 & 0xff) | ((q1 & 0xff) << 8) | ((q2 & 0xff) << 16) | ((q3 & 0xff) << 24);
+      *(int *)(qc + qoff) = (q0 & 0xff) | ((q1 & 0xff) << 8) | ((q2 & 0xff) << 16) | ((q3 & 0xff) << 24);
       if ((e & 31) == 0) dc[e >> 5] = half_bits_to_float(float_to_half_bits(dq));
     }
   }
@@ -212,10 +225,13 @@ __device__ __forceinline__ Act act_finish(char *smem, float *red, const ActPre &
     char *qc = q + (size_t)c * K;
     float *dc = d + (size_t)c * (K / 32);
     int *bsc = bs + (size_t)c * (K / 16);
+    // byte offset of the lane's 4 quants in the swizzled image: piece = e >> 4 = tid / 4 + 128 j, superblock = piece >> 4 = wave + 8 j, so the XOR
+    // mask m(superblock) depends on the wave only and the offset is a lane constant + 2048 j
+    const int qoff0 = (((tid >> 2) ^ sb_mask(wave)) << 4) | ((tid & 3) << 2);
     auto one = [&](int j, float4 v, float4 w4) {  // uniform trip count: every lane takes part in the cross-lane steps
       const int e = tid * 4 + j * 2048;
       if (nw) { v.x = v.x * inv * w4.x; v.y = v.y * inv * w4.y; v.z = v.z * inv * w4.z; v.w = v.w * inv * w4.w; }
-      quantize4(v, e, e < K, mode, qc, dc, bsc);
+      quantize4(v, e, qoff0 + j * 2048, e < K, mode, qc, dc, bsc);
     };
 #pragma unroll
     for (int j = 0; j < ACT_MAXV; ++j)
@@ -403,7 +419,7 @@ struct Segs {
 };
 
 template <int TYPE, int NCOLS, class Pre, class Pro, class Epi>
-__device__ __forceinline__ void stream(const Segs &sg, int K, Pre pre, Pro pro, Epi epi) {
+__device__ __forceinline__ void stream(const Segs &sg, int K, Pre pre, Pro pro, Epi epi, bool skip_acc = false) {
   using TL = Tile<TYPE>;
   constexpr int D = TL::DEPTH;
   const int lane = lane_opaque();
@@ -438,7 +454,8 @@ __device__ __forceinline__ void stream(const Segs &sg, int K, Pre pre, Pro pro, 
 #pragma unroll
     for (int i = 0; i < D; ++i) {
       if (g + i < total) {  // wave-uniform
-        TL::template accumulate<NCOLS>(ring[i], lc, ct, S, act, acc);
+        if (!skip_acc) TL::template accumulate<NCOLS>(ring[i], lc, ct, S, act, acc);
+        else acc[0] += __uint_as_float(ring[i].hd & 1u);  // experiment: keep the loads alive (in-order return: the last load of the slot), drop the arithmetic
         if (++ct == tpr) {
           float sum[NCOLS];
 #pragma unroll

@@ -39,6 +39,7 @@ struct GemvArgs {
   int wstart[4];  // EPI_QKV: first wave of q, k, v and the total
   const int32_t *expert_sel;  // stacked experts [E * nrows][K]: rows of expert e start at e * nrows (nullptr = dense)
   const float *acc_scale;     // RESID: out = out * resid_scale + (*acc_scale) * W.x  (routing weight)
+  int ablate;                 // experiments (MRS_DEC_ABLATE): 1 = skip the activation prologue's arithmetic, 2 = skip the accumulate (loads only)
 };
 
 #define MRS_DEC_TYPE_SWITCH(t, ...)                              \
@@ -86,6 +87,7 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
       const ActPre late = act_issue<MRS_DEC_AGENT_IO != 0>(a.x, a.norm_w, K);
       return act_finish<NCOLS, MRS_DEC_AGENT_IO != 0>(smem, red, late, a.x, a.ldx, a.norm_w, a.eps, K, act_mode_for(a.m[0].type));
     } else {
+      if (a.ablate & 1) { __syncthreads(); return Act{smem, (const float *)(smem + (size_t)NCOLS * K), (const int *)(smem + (size_t)NCOLS * K + (size_t)NCOLS * (K / 32) * 4), K}; }
       return act_finish<NCOLS, false>(smem, red, p, a.x, a.ldx, a.norm_w, a.eps, K, act_mode_for(a.m[0].type));
     }
   };
@@ -118,7 +120,7 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
         }
       }
     };
-    MRS_DEC_TYPE_SWITCH(a.m[0].type, (stream<TT, NCOLS>(sg, K, pre, pro, epi));)
+    MRS_DEC_TYPE_SWITCH(a.m[0].type, (stream<TT, NCOLS>(sg, K, pre, pro, epi, (a.ablate & 2) != 0));)
   } else if constexpr (EPI == EPI_GLU) {
     Segs sg{};
     sg.nseg = 2; sg.mat[0] = a.m[0]; sg.mat[1] = a.m[1];
@@ -138,7 +140,7 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
         }
       }
     };
-    MRS_DEC_TYPE_SWITCH(a.m[0].type, (stream<TT, NCOLS>(sg, K, pre, pro, epi));)
+    MRS_DEC_TYPE_SWITCH(a.m[0].type, (stream<TT, NCOLS>(sg, K, pre, pro, epi, (a.ablate & 2) != 0));)
   } else {  // EPI_QKV: units are RoPE pairs (2i, 2i+1); waves [wstart[i], wstart[i+1]) take tensor i (q, k, v), so a wave never straddles two tensors
     // (selects, not a.m[mi]: in the persistent kernel the arguments are a local struct and a dynamic index would push it into scratch memory)
     const int mi = gw >= a.wstart[2] ? 2 : (gw >= a.wstart[1] ? 1 : 0);
@@ -205,7 +207,7 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
     };
     Segs sg{};
     sg.nseg = 1; sg.mat[0] = mi == 0 ? a.m[0] : (mi == 1 ? a.m[1] : a.m[2]); sg.row0[0] = r0; sg.nrows[0] = 2 * (p1 - p0);
-    MRS_DEC_TYPE_SWITCH(sg.mat[0].type, (stream<TT, NCOLS>(sg, K, pre, pro, epi));)
+    MRS_DEC_TYPE_SWITCH(sg.mat[0].type, (stream<TT, NCOLS>(sg, K, pre, pro, epi, (a.ablate & 2) != 0));)
   }
 }
 
@@ -425,6 +427,7 @@ template <int EPI> struct Launch {
     if (upw < 1) upw = 1;
     if (upw > 64) upw = 64;  // epilogue operands are prefetched one unit per lane
     { static int ov = -1; if (ov < 0) { const char *e = getenv("MRS_DEC_UPW"); ov = e ? atoi(e) : 0; } if (ov > 0 && ov <= 64) upw = ov; }
+    { static int ab = -1; if (ab < 0) { const char *e = getenv("MRS_DEC_ABLATE"); ab = e ? atoi(e) : 0; } a.ablate = ab; }
     a.units_per_wave = upw;
     int grid = (a.units + upw * NW - 1) / (upw * NW);
     if (EPI == EPI_QKV) {

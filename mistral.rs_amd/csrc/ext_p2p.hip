@@ -83,6 +83,19 @@ __global__ void __launch_bounds__(NT) reduce_kernel(const Comm c, float *buf, si
   if (threadIdx.x == 0) c.state[0] = seq;
 }
 
+// several ranks of one address space as the workgroups of ONE grid (single-GPU test of the real polling path: the workgroups of a grid are
+// co-resident, kernels on different streams of one device need not be)
+struct Group { Comm c[MAX_WORLD]; float *buf[MAX_WORLD]; };
+__global__ void __launch_bounds__(NT) all_reduce_group_kernel(const Group g, size_t count) {
+  const Comm &c = g.c[blockIdx.x];
+  float *buf = g.buf[blockIdx.x];
+  const unsigned seq = c.state[0] + 1;
+  post(c, buf, count, seq);
+  if (!reduce(c, buf, count, seq)) c.state[1] = 1;
+  __syncthreads();
+  if (threadIdx.x == 0) c.state[0] = seq;
+}
+
 }  // namespace p2p
 }  // namespace mrs
 
@@ -146,4 +159,16 @@ extern "C" int mrs_p2p_error(void *comm) {
   unsigned st[2] = {0, 0};
   if (hipMemcpy(st, ((Comm *)comm)->state, 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
   return (int)st[1];
+}
+// test entry: n communicators of one address space run the one-kernel all-reduce concurrently as the n workgroups of a single grid
+extern "C" int mrs_p2p_all_reduce_group(void *const *comms, float *const *bufs, int n, size_t count, void *stream) {
+  if (!comms || !bufs || n < 1 || n > mrs::p2p::MAX_WORLD) return -1;
+  mrs::p2p::Group g{};
+  for (int i = 0; i < n; ++i) {
+    if (!comms[i] || count > ((Comm *)comms[i])->max_elems) return -2;
+    g.c[i] = *(Comm *)comms[i];
+    g.buf[i] = bufs[i];
+  }
+  hipLaunchKernelGGL(mrs::p2p::all_reduce_group_kernel, dim3(n), dim3(mrs::p2p::NT), 0, (hipStream_t)stream, g, count);
+  return 0;
 }

@@ -1,0 +1,12 @@
+mkdir -p gpurun_out/r2c17
+timeout 300 python -m pytest tests/test_distributed.py -m gpu -q -p no:cacheprovider -k "p2p" 2>&1 | grep -E "Error|assert|error|passed|failed" | head -20
+export MRS_EXT_LIB=libmrs_hip_ext_ab.so
+(echo "== full"; timeout 200 python scripts/bench_dec.py --reps 8
+echo "== no prologue arithmetic (ABLATE=1)"; MRS_DEC_ABLATE=1 timeout 200 python scripts/bench_dec.py --reps 8 --phases o,down4) 2>&1 | grep -v amdgpu.ids | python -c "
+import sys, json
+for l in sys.stdin:
+    l=l.strip()
+    if l.startswith('{'):
+        j=json.loads(l); print('  %-8s %6.2f us  %5.3f TB/s' % (j['phase'], j['us'], j['TBps']))
+    else: print(l)
+" | tee gpurun_out/r2c17/ablate.log

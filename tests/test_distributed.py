@@ -351,26 +351,25 @@ def test_p2p_all_reduce_host_emulation(world, count):
 
 @pytest.mark.gpu
 def test_p2p_all_reduce_gpu_split_and_concurrent(dev):
-    """On one MI355X: (i) the split launches; (ii) the REAL one-kernel all-reduce of 4 "ranks" launched on 4 streams of the same device -- the
-    kernels poll each other's granules while running concurrently, exactly as 4 GPUs would (mailboxes in one address space instead of IPC)."""
+    """On one MI355X: (i) the split launches; (ii) the one-kernel path (post, poll the tagged granules, rank-order sum, advance the sequence) of 8
+    "ranks" running CONCURRENTLY as the 8 workgroups of one grid -- they poll each other's granules through memory exactly as 8 GPUs would
+    (mailboxes in one address space instead of IPC; kernels on different streams of one device are not guaranteed to overlap, workgroups are)."""
     import ctypes as C
     import torch
     from tests.abi_backends import GpuBackend
     be = GpuBackend(dev)
     check_p2p_all_reduce_split_launches(be, 4, 4096)
-    world, count = 4, 8192
+    world, count = 8, 8192
     boxes, comms = _p2p_world(be, world, 16384)
-    ar = be.sym("mrs_p2p_all_reduce_sum_f32", [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p], C.c_int)
-    streams = [torch.cuda.Stream() for _ in range(world)]
-    torch.cuda.synchronize()
+    grp = be.sym("mrs_p2p_all_reduce_group", [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_size_t, C.c_void_p], C.c_int)
+    cs = (C.c_void_p * world)(*comms)
     for it in range(6):
         xs = [torch.randn(count, device=dev) for _ in range(world)]
         want = torch.zeros(count, device=dev)
         for x in xs:
             want = want + x
-        torch.cuda.synchronize()
-        for r in range(world):
-            assert ar(comms[r], xs[r].data_ptr(), count, streams[r].cuda_stream) == 0
+        bs = (C.c_void_p * world)(*[x.data_ptr() for x in xs])
+        assert grp(cs, bs, world, count, be.stream) == 0
         torch.cuda.synchronize()
         for r in range(world):
             assert torch.equal(xs[r], want), (it, r)
