@@ -80,6 +80,11 @@ int mrs_dec_step_num_phases(int num_layers);
 int mrs_dec_build_step_table(const mrs_dec_step_args *args, const mrs_dec_layer *layers, void *device_table);
 /* sync: 8 bytes of device memory (arrival counter, error flag: non-zero after a launch = the grid was not resident); max_k = longest GEMV row */
 int mrs_dec_step(const void *device_table, int num_layers, int max_k, void *sync, int phase_begin, int phase_end, void *stream);
+/* Fused HQQ dequant-GEMV for decode (ext_hqq_gemv.hip): out [b][ldo] = x [b][ldx] . W^T (+ bias) straight from the packed 4-bit / 8-bit HQQ tensor (group 64, axis 0),
+ * b <= 8; dtype 0 = f32, 1 = f16, 2 = bf16 for x / scale / zero / bias / out.  Role: HqqLayer::forward_raw (hqq/mod.rs:1092-1100,1163-1171) without materialising
+ * dequantize_w(); the dequantized values are bit-identical to dequantize_{4,8}bit_u8_kernel_*.  -1 = outside the fused kernel (keep dequantize + dense matmul). */
+int mrs_hqq_gemv(int bits, int dtype, const void *wq, const void *scale, const void *zero, const void *bias, const void *x, int ldx, void *out, int ldo,
+                 int N, int K, int b, void *stream);
 /* quantized (or f32/f16/bf16) embedding rows -> f32; role of QuantMethod::embedding_forward (lib.rs:1561, gguf/mod.rs:436) */
 int mrs_embedding(const void *table, int type, const int32_t *ids, float *out, int K, int tokens, void *stream);
 /* f32 rows -> Q8_1 blocks: same bytes as launch_mmvq_gguf_quantize_q8_1_f32 with kx_padded = 32*stride_blocks */

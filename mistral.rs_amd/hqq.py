@@ -158,7 +158,22 @@ class HqqLayer:
         return out.reshape(-1)[:n].reshape(self.w_shape)  # 3 bit: ten values per i32 may over-cover the group rows
 
     def forward(self, xs: torch.Tensor) -> torch.Tensor:
-        """dequantize_matmul (mod.rs:1092-1100): x @ W^T (+ bias) through the dense linear."""
+        """HqqLayer::forward_raw (mod.rs:1092-1100,1163-1171): x @ W^T (+ bias).  Decode-sized inputs (<= 8 rows, 4 / 8 bit, group 64) take the fused
+        dequant-GEMV of csrc/ext_hqq_gemv.hip (the packed bytes are read once, dequantize_w() is never materialised); everything else dequantizes and
+        uses the dense matmul like the reference."""
+        dt = self.scales.dtype
+        if (self.cfg.bits in (4, 8) and self.cfg.group_size == 64 and self.cfg.axis == 0 and xs.dim() == 2 and 1 <= xs.shape[0] <= 8 and len(self.w_shape) == 2
+                and self.w_shape[0] % 64 == 0 and self.w_shape[1] % 4 == 0 and dt in _TAG and self.zeros.dtype == dt):
+            _need_gpu(xs)
+            n, k = self.w_shape
+            x = xs.to(dt).contiguous()
+            out = torch.empty(x.shape[0], n, dtype=dt, device=x.device)
+            bias = self.bias.to(dt).contiguous() if self.bias is not None else None
+            fn = _lib.sym("ext", "mrs_hqq_gemv", [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p], C.c_int)
+            rc = fn(self.cfg.bits, {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}[dt], self.w_q.data_ptr(), self.scales.data_ptr(), self.zeros.data_ptr(),
+                    bias.data_ptr() if bias is not None else None, x.data_ptr(), k, out.data_ptr(), n, n, k, x.shape[0], torch.cuda.current_stream().cuda_stream)
+            if rc == 0:
+                return out
         w = self.dequantize()
         y = xs.to(w.dtype) @ w.t()
         return y + self.bias.to(y.dtype) if self.bias is not None else y

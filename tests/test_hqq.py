@@ -192,3 +192,53 @@ def test_hqq_3bit_default_group_size_round_trip(dev):
     # pack() itself: a [64, w] block packs to 7 rows, the padding rows read back as zeros
     q = torch.from_numpy(rng.integers(0, 8, (64, 16)).astype(np.int32)).to(dev)
     assert pack(3, q).shape == (7, 16)
+
+
+def _check_fused_gemv(be_kind, dev, bits, dtype, n, k, b):
+    """mrs_hqq_gemv vs dequantize_w() @ x: the dequantized values are the reference's bit for bit, so the only freedom is the f32 summation order."""
+    import torch
+    from mistralrs_amd.hqq import HqqConfig, HqqLayer
+    rng = np.random.default_rng(bits * 100 + n)
+    w = (rng.standard_normal((n, k)) * 0.05).astype(np.float32)
+    layer = HqqLayer.quantize(_t(dev, w), HqqConfig(bits=bits, group_size=64))
+    if dtype != torch.float32:
+        layer = layer.to_dtype(dtype)
+    bias = _t(dev, rng.standard_normal(n).astype(np.float32)).to(dtype)
+    x = _t(dev, rng.standard_normal((b, k)).astype(np.float32)).to(dtype)
+    got = layer.with_bias(bias).forward(x).float().cpu().numpy()
+    wd = layer.dequantize().float().cpu().numpy().astype(np.float64)
+    xf = x.float().cpu().numpy().astype(np.float64)
+    want = xf @ wd.T + bias.float().cpu().numpy()
+    mag = np.abs(xf) @ np.abs(wd).T + np.abs(bias.float().cpu().numpy())
+    tol = 2.0 ** -18 * mag if dtype == torch.float32 else 2.0 ** -8 * np.abs(want) + 2.0 ** -18 * mag  # 16-bit outputs: one rounding of the result
+    assert (np.abs(got - want) <= tol).all(), float((np.abs(got - want) / mag).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits,n,k,b", [(4, 128, 64, 1), (4, 256, 1024, 3), (8, 128, 512, 2), (4, 4096, 4096, 1), (8, 1024, 4096, 8), (4, 1024, 14336, 1)])
+def test_fused_hqq_gemv_vs_dequantize_matmul(dev, bits, n, k, b):
+    import torch
+    for dtype in (torch.float32, torch.bfloat16):
+        _check_fused_gemv("gpu", dev, bits, dtype, n, k, b)
+
+
+@pytest.mark.parametrize("bits,n,k,b", [(4, 128, 64, 1), (4, 64, 1028, 2), (8, 128, 96, 3)])
+def test_fused_hqq_gemv_host_emulation(bits, n, k, b):
+    """The fused kernel on the wave64 host emulation (f32) vs the oracle's dequantize @ x."""
+    from tests.abi_backends import HostBackend
+    be = HostBackend()
+    rng = np.random.default_rng(bits + n + k)
+    w = (rng.standard_normal((n, k)) * 0.05).astype(np.float32)
+    wq, scale, zero = H.quantize(w, bits, 64)
+    inv = scale.reshape(-1).astype(np.float32)  # H.quantize already returns 1 / scale, the dequantizer's multiplier
+    wd = H.dequantize(bits, wq, inv, zero.reshape(-1).astype(np.float32)).reshape(-1)[: n * k].reshape(n, k)
+    x = rng.standard_normal((b, k)).astype(np.float32)
+    bias = rng.standard_normal(n).astype(np.float32)
+    fn = be.sym("mrs_hqq_gemv", [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p], C.c_int)
+    bw, bs, bz, bb, bx, bo = be.buf(wq), be.buf(inv), be.buf(zero.reshape(-1).astype(np.float32)), be.buf(bias), be.buf(x), be.buf(np.zeros((b, n), dtype=np.float32))
+    assert fn(bits, 0, bw.ptr, bs.ptr, bz.ptr, bb.ptr, bx.ptr, k, bo.ptr, n, n, k, b, None) == 0
+    want = x.astype(np.float64) @ wd.astype(np.float64).T + bias
+    mag = np.abs(x).astype(np.float64) @ np.abs(wd).astype(np.float64).T + np.abs(bias)
+    assert (np.abs(bo.numpy() - want) <= 2.0 ** -18 * mag).all()
+    assert fn(3, 0, bw.ptr, bs.ptr, bz.ptr, None, bx.ptr, k, bo.ptr, n, n, k, b, None) == -1  # other bit widths: dequantize + dense matmul
+    assert fn(bits, 0, bw.ptr, bs.ptr, bz.ptr, None, bx.ptr, k, bo.ptr, n, n, k, 9, None) == -1
