@@ -50,7 +50,7 @@ def q4_k_m_types(n_layers: int):
     return out
 
 
-def build_model(cfg, device, seed=0, max_new_tokens=4096, tp=None):
+def build_model(cfg, device, seed=0, max_new_tokens=4096, tp=None, quant="q4_k_m"):
     """Synthetic model of `cfg`'s (per-rank) dims.  tp = (rank, world): the column / row-parallel shards (q / k / v / gate / up rows, o / down
     columns: distributed/layers.rs:695-975,1160-1616) get rank-specific random blocks of the SHARD's shape -- the bytes and the arithmetic of a
     real shard without materialising the unsharded 40 GB tensor on every GPU -- while the replicated tensors (embedding, norms, lm_head) use
@@ -67,7 +67,14 @@ def build_model(cfg, device, seed=0, max_new_tokens=4096, tp=None):
     for i, (name, t) in enumerate(types.items()):
         sharded = name not in ("token_embd.weight", "output.weight")
         n, k = shapes[name.split(".")[2]] if sharded else (cfg.vocab_size, d)
-        m.set_tensor(name, random_qtensor(t, n, k, device, seed * 1000 + i + (7919 * (tp[0] + 1) if tp and sharded else 0)))
+        tseed = seed * 1000 + i + (7919 * (tp[0] + 1) if tp and sharded else 0)
+        if quant == "q8_0_isq":  # in-situ quantisation: bf16 weights -> Q8_0 blocks on the device (utils/isq.rs:323-361 does this on the host cores)
+            from mistralrs_amd import isq
+            from mistralrs_amd.gguf import GgmlDType
+            gw = torch.Generator(device=device).manual_seed(tseed)
+            m.set_tensor(name, isq.quantize((torch.randn(n, k, device=device, generator=gw) * 0.02).to(torch.bfloat16), GgmlDType.Q8_0))
+        else:
+            m.set_tensor(name, random_qtensor(t, n, k, device, tseed))
     for i in range(cfg.num_layers):
         for nm in ("attn_norm", "ffn_norm"):
             m.set_tensor(f"blk.{i}.{nm}.weight", 1.0 + 0.01 * torch.randn(d, generator=g))
@@ -150,6 +157,8 @@ def main():
     ap.add_argument("--tp", action="store_true", help="(default for N > 1) ONE model sharded tensor-parallel over the N GPUs")
     ap.add_argument("--replicas", action="store_true", help="N > 1: N independent replicas (weak scaling) instead of tensor parallelism")
     ap.add_argument("--model", choices=["auto", "8b", "70b"], default="auto", help="auto: 70b (configs[3]) when N == 8, else 8b (configs[1])")
+    ap.add_argument("--quant", choices=["q4_k_m", "q8_0_isq"], default="q4_k_m",
+                    help="q8_0_isq = BASELINE configs[2]: every linear quantized in situ from bf16 weights to Q8_0 on the GPU (mistralrs_amd.isq, role of generate_isq!)")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -216,7 +225,7 @@ def main():
         cfg.head_dim = cfg.head_dim  # keep the global head_dim
         cfg.num_heads, cfg.num_kv_heads, cfg.intermediate_size = D.local_dims(cfg.num_heads, cfg.num_kv_heads, cfg.intermediate_size, world)
         cfg.tp_world_size, cfg.tp_rank = world, rank
-    model = build_model(cfg, dev, seed=0 if tp else rank, max_new_tokens=a.warmup + a.steps + 8, tp=(rank, world) if tp else None)
+    model = build_model(cfg, dev, seed=0 if tp else rank, max_new_tokens=a.warmup + a.steps + 8, tp=(rank, world) if tp else None, quant=a.quant)
     comm, p2p = None, None
     if tp:
         from mistralrs_amd import distributed as D
@@ -356,8 +365,8 @@ def main():
     out = {
         "metric": "decode_tokens_per_sec", "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(1e3 * t_all / a.steps, 4), "higher_is_better": True, "scaling": "strong" if tp else "weak",
-        "vs_baseline": None, "dtype": "q4_k/q6_k weights x q8_k activations (int8 dot, f32 accumulate: the reference CPU path's arithmetic)", "data": "synthetic",
-        "config": {"workload": f"{name} GGUF Q4_K_M, TP={world if tp else 1}, {a.prompt_len} prefill / {a.steps} decode, batch 1, paged KV bf16 (block 32)",
+        "vs_baseline": None, "dtype": ("q4_k/q6_k weights x q8_k activations" if a.quant == "q4_k_m" else "q8_0 weights x q8_0 activations") + " (int8 dot, f32 accumulate: the reference CPU path's arithmetic)", "data": "synthetic",
+        "config": {"workload": f"{name} " + ("GGUF Q4_K_M" if a.quant == "q4_k_m" else "ISQ Q8_0 (in situ from bf16, on the GPU)") + f", TP={world if tp else 1}, {a.prompt_len} prefill / {a.steps} decode, batch 1, paged KV bf16 (block 32)",
                    "parallelism": "tp1" if world == 1 else (f"tp{world}" if tp else f"replicas x{world}")},
         "prefill_tokens_per_sec": round(a.prompt_len / ttft, 1), "ttft_ms": round(1e3 * ttft, 2),
         "prefill_roofline": {"bound": "mfma", "achieved": round(prefill_flops / ttft / 1e12, 1), "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s",

@@ -29,7 +29,11 @@ namespace mrs {
 namespace dec {
 
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
-constexpr int NT = 512, NW = NT / 64;
+#ifndef MRS_DEC_NT
+#define MRS_DEC_NT 512
+#endif
+constexpr int NT = MRS_DEC_NT, NW = NT / 64;  // threads / waves per workgroup (one workgroup per CU): 512 or 1024
+constexpr int ACT_STRIDE = NT * 4;           // values between a thread's consecutive float4 pieces of the activation row
 constexpr unsigned OOB = 0xFFFFFF00u;  // buffer offset that is out of range for every tensor: the load returns zeros
 
 // ------------------------------------------------------------------------------------------------ decode layout
@@ -93,7 +97,7 @@ template <int CTRL> __device__ __forceinline__ int dppi(int v) { return __builti
 // column's values (and the norm weights) into registers with buffer loads -- thread t takes the float4 at t*4 + j*2048, i.e. wave w owns the
 // 256-blocks w, w+8, ... -- then the caller fills the ring, then act_finish() normalises / quantizes while the weights are in flight.
 // Rows longer than 16384 values (or 8192 with a norm) take the remaining pieces after the ring (correct, just later).
-constexpr int ACT_MAXV = 8, ACT_MAXW = 4;
+constexpr int ACT_MAXV = 16384 / (MRS_DEC_NT * 4), ACT_MAXW = 8192 / (MRS_DEC_NT * 4);  // register-resident pieces: rows of <= 16384 values (8192 with a norm)
 struct ActPre { v4u xv[ACT_MAXV]; v4u wv[ACT_MAXW]; };
 __device__ __forceinline__ float4 as_f4(v4u v) { return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)); }
 
@@ -108,9 +112,9 @@ template <bool SC1> __device__ __forceinline__ ActPre act_issue(const float *x, 
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)x, (short)0, K * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)(nw ? nw : x), (short)0, nw ? K * 4 : 0, 0x00020000);
 #pragma unroll
-  for (int j = 0; j < ACT_MAXV; ++j) p.xv[j] = ld_act<SC1>(rx, off + (unsigned)j * 8192u);  // beyond K: out of range, zeros, no traffic
+  for (int j = 0; j < ACT_MAXV; ++j) p.xv[j] = ld_act<SC1>(rx, off + (unsigned)j * (unsigned)(ACT_STRIDE * 4));  // beyond K: out of range, zeros, no traffic
 #pragma unroll
-  for (int j = 0; j < ACT_MAXW; ++j) p.wv[j] = ld_act<false>(rw, off + (unsigned)j * 8192u);
+  for (int j = 0; j < ACT_MAXW; ++j) p.wv[j] = ld_act<false>(rw, off + (unsigned)j * (unsigned)(ACT_STRIDE * 4));
   return p;
 }
 
@@ -200,15 +204,15 @@ __device__ __forceinline__ Act act_finish(char *smem, float *red, const ActPre &
   char *q = smem;
   float *d = (float *)(smem + (size_t)NCOLS * K);
   int *bs = (int *)(d + (size_t)NCOLS * (K / 32));
-  const int nv = (K + 2047) >> 11;  // float4 pieces per thread
+  const int nv = (K + ACT_STRIDE - 1) / ACT_STRIDE;  // float4 pieces per thread
 #pragma unroll 1
   for (int c = 0; c < NCOLS; ++c) {
     const float *xr = x + (size_t)c * ldx;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)xr, (short)0, K * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)(nw ? nw : xr), (short)0, nw ? K * 4 : 0, 0x00020000);
     // pieces j < ACT_MAXV (ACT_MAXW) of column 0 come from the registers act_issue() filled: static indices only
-    auto xload = [&](int j) -> float4 { return as_f4(ld_act<SC1>(rx, (unsigned)tid * 16u + (unsigned)j * 8192u)); };
-    auto wload = [&](int j) -> float4 { return as_f4(ld_act<false>(rw, (unsigned)tid * 16u + (unsigned)j * 8192u)); };
+    auto xload = [&](int j) -> float4 { return as_f4(ld_act<SC1>(rx, (unsigned)tid * 16u + (unsigned)j * (unsigned)(ACT_STRIDE * 4))); };
+    auto wload = [&](int j) -> float4 { return as_f4(ld_act<false>(rw, (unsigned)tid * 16u + (unsigned)j * (unsigned)(ACT_STRIDE * 4))); };
     float inv = 1.0f;
     if (nw) {  // sum of squares: per-thread partials in element order, DPP wave sums, the 8 wave sums in wave order
       float ss = 0.f;
@@ -219,7 +223,9 @@ __device__ __forceinline__ Act act_finish(char *smem, float *red, const ActPre &
       ss = wave_sum_all(ss);
       if (lane == 0) red[wave] = ss;
       __syncthreads();
-      inv = 1.0f / sqrtf((((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]))) / (float)K + eps);
+      float tot = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+      if constexpr (NW == 16) tot += ((red[8] + red[9]) + (red[10] + red[11])) + ((red[12] + red[13]) + (red[14] + red[15]));
+      inv = 1.0f / sqrtf(tot / (float)K + eps);
       __syncthreads();  // red is reused by the next column
     }
     char *qc = q + (size_t)c * K;
@@ -229,9 +235,9 @@ __device__ __forceinline__ Act act_finish(char *smem, float *red, const ActPre &
     // mask m(superblock) depends on the wave only and the offset is a lane constant + 2048 j
     const int qoff0 = (((tid >> 2) ^ sb_mask(wave)) << 4) | ((tid & 3) << 2);
     auto one = [&](int j, float4 v, float4 w4) {  // uniform trip count: every lane takes part in the cross-lane steps
-      const int e = tid * 4 + j * 2048;
+      const int e = tid * 4 + j * ACT_STRIDE;
       if (nw) { v.x = v.x * inv * w4.x; v.y = v.y * inv * w4.y; v.z = v.z * inv * w4.z; v.w = v.w * inv * w4.w; }
-      quantize4(v, e, qoff0 + j * 2048, e < K, mode, qc, dc, bsc);
+      quantize4(v, e, qoff0 + j * ACT_STRIDE, e < K, mode, qc, dc, bsc);
     };
 #pragma unroll
     for (int j = 0; j < ACT_MAXV; ++j)
