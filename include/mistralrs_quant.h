@@ -59,12 +59,13 @@ MRS_DECL_MMVQ_T(q2_k) MRS_DECL_MMVQ_T(q3_k) MRS_DECL_MMVQ_T(q4_k) MRS_DECL_MMVQ_
 /* ---- indexed MoE forward: out[task][row] = W[indices[task]][row] . y[input_dim1 == 1 ? task / topk : task], task = token * topk + slot.
  *      all_weights: E stacked packed matrices [n][k / blk]; all_inputs: Q8_1 rows of k_padded / 32 blocks; all_outputs f32 [batch*topk][n].
  *      replaces kernels/indexed_moe/indexed_moe.cu:806-1157 ; Rust: src/gguf/ffi.rs:100-260 ; caller gguf/cuda.rs:514-588
- *      (qmatmul_indexed_moe_forward <- GgufMatMul::gather_forward_raw, gguf/mod.rs:485-516).  The q8_1-weight variant is not built. */
+ *      (qmatmul_indexed_moe_forward <- GgufMatMul::gather_forward_raw, gguf/mod.rs:485-516).  q8_1 here is Q8_1 as a WEIGHT format (ffi.rs:268): per block
+ *      d_w d_x <q,u> + 4 s_w s_x, the literal result of the reference's four vec_dot_q8_1_q8_1 calls per block (indexed_moe.cu:483-502). */
 #define MRS_DECL_IMOE(t)                                                                                                          \
   void launch_indexed_moe_forward_##t##_q8_1(const void *all_weights, const void *all_inputs, const unsigned int *indices,         \
                                              float *all_outputs, int n, int k, int batch, int topk, int k_padded, int input_dim1, \
                                              void *stream);
-MRS_DECL_IMOE(q4_0) MRS_DECL_IMOE(q4_1) MRS_DECL_IMOE(q5_0) MRS_DECL_IMOE(q5_1) MRS_DECL_IMOE(q8_0)
+MRS_DECL_IMOE(q4_0) MRS_DECL_IMOE(q4_1) MRS_DECL_IMOE(q5_0) MRS_DECL_IMOE(q5_1) MRS_DECL_IMOE(q8_0) MRS_DECL_IMOE(q8_1)
 MRS_DECL_IMOE(q2k) MRS_DECL_IMOE(q3k) MRS_DECL_IMOE(q4k) MRS_DECL_IMOE(q5k) MRS_DECL_IMOE(q6k)
 #undef MRS_DECL_IMOE
 
@@ -80,7 +81,7 @@ MRS_DECL_IMOE(q2k) MRS_DECL_IMOE(q3k) MRS_DECL_IMOE(q4k) MRS_DECL_IMOE(q5k) MRS_
   void launch_moe_gemv_down_aggregate_##t##_q8_1(const void *all_weights, const void *all_inputs, const unsigned int *indices,       \
                                                  const float *topk_weights, float *all_outputs, int n, int k, int batch, int topk,   \
                                                  int k_padded, void *stream);
-MRS_DECL_MOE_DECODE(q4_0) MRS_DECL_MOE_DECODE(q4_1) MRS_DECL_MOE_DECODE(q5_0) MRS_DECL_MOE_DECODE(q5_1) MRS_DECL_MOE_DECODE(q8_0)
+MRS_DECL_MOE_DECODE(q4_0) MRS_DECL_MOE_DECODE(q4_1) MRS_DECL_MOE_DECODE(q5_0) MRS_DECL_MOE_DECODE(q5_1) MRS_DECL_MOE_DECODE(q8_0) MRS_DECL_MOE_DECODE(q8_1)
 MRS_DECL_MOE_DECODE(q2k) MRS_DECL_MOE_DECODE(q3k) MRS_DECL_MOE_DECODE(q4k) MRS_DECL_MOE_DECODE(q5k) MRS_DECL_MOE_DECODE(q6k)
 #undef MRS_DECL_MOE_DECODE
 
@@ -101,7 +102,7 @@ void launch_moe_dispatch(const int32_t *topk_ids, int32_t *expert_bounds, int32_
   void launch_moe_grouped_gemm_##t(const void *all_weights, const void *all_inputs, const int32_t *expert_bounds,                    \
                                    const int32_t *sorted_token_ids, const float *topk_weights, float *all_outputs, int N, int K,     \
                                    int K_padded, int num_experts, int topk, int input_dim1, void *stream);
-MRS_DECL_MOE_GROUPED(q4_0) MRS_DECL_MOE_GROUPED(q4_1) MRS_DECL_MOE_GROUPED(q5_0) MRS_DECL_MOE_GROUPED(q5_1) MRS_DECL_MOE_GROUPED(q8_0)
+MRS_DECL_MOE_GROUPED(q4_0) MRS_DECL_MOE_GROUPED(q4_1) MRS_DECL_MOE_GROUPED(q5_0) MRS_DECL_MOE_GROUPED(q5_1) MRS_DECL_MOE_GROUPED(q8_0) MRS_DECL_MOE_GROUPED(q8_1)
 MRS_DECL_MOE_GROUPED(q2k) MRS_DECL_MOE_GROUPED(q3k) MRS_DECL_MOE_GROUPED(q4k) MRS_DECL_MOE_GROUPED(q5k) MRS_DECL_MOE_GROUPED(q6k)
 #undef MRS_DECL_MOE_GROUPED
 int launch_moe_weighted_reduce_flat(const void *inputs, const float *topk_weights, void *outputs, int num_tokens, int hidden, int topk,

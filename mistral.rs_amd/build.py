@@ -40,6 +40,8 @@ def libraries():
     quant += [_tu("mmvq_inst.hip", f"mmvq_{tag}.o", (f"-DMRS_TAG={tag}", f"-DMRS_TYPE={tid}",
                                                       "-DMRS_MOE_TAG=" + (tag.replace("_k", "k") if tag.endswith("_k") else tag)))
               for tag, tid in MMVQ_TYPES.items()]
+    # Q8_1 as a weight format: MoE launchers only (gguf/ffi.rs:268,424,601,800)
+    quant.append(_tu("mmvq_inst.hip", "mmvq_q8_1.o", ("-DMRS_TAG=q8_1", "-DMRS_TYPE=9", "-DMRS_MOE_TAG=q8_1", "-DMRS_MOE_ONLY")))
     libs = {"libmistralrsquant.so": quant}
     pa = [_tu("kv_cache_ops.hip")]
     for tag, t, ct, abi in (("f16", "mrs::f16_t", "mrs::f16_t", True), ("bf16", "mrs::bf16_t", "mrs::bf16_t", True),

@@ -18,7 +18,7 @@
 namespace mrs {
 
 // ggml type ids (reference: mistralrs-quant/src/gguf/archive.rs:73-160)
-enum : int { T_Q4_0 = 2, T_Q4_1 = 3, T_Q5_0 = 6, T_Q5_1 = 7, T_Q8_0 = 8, T_Q2_K = 10, T_Q3_K = 11,
+enum : int { T_Q4_0 = 2, T_Q4_1 = 3, T_Q5_0 = 6, T_Q5_1 = 7, T_Q8_0 = 8, T_Q8_1 = 9, T_Q2_K = 10, T_Q3_K = 11,
              T_Q4_K = 12, T_Q5_K = 13, T_Q6_K = 14 };
 
 struct Slice {
@@ -37,6 +37,9 @@ template <> struct Fmt<T_Q4_1> { static constexpr int BLK = 32, TS = 20; static 
 template <> struct Fmt<T_Q5_0> { static constexpr int BLK = 32, TS = 22; static constexpr bool HAS_OFFSET = true; static constexpr int SUM_MODE = 1; };
 template <> struct Fmt<T_Q5_1> { static constexpr int BLK = 32, TS = 24; static constexpr bool HAS_OFFSET = true; static constexpr int SUM_MODE = 1; };
 template <> struct Fmt<T_Q8_0> { static constexpr int BLK = 32, TS = 34; static constexpr bool HAS_OFFSET = false; static constexpr int SUM_MODE = 0; };
+// Q8_1 as a WEIGHT format (MoE launchers only: indexed_moe.cu:483-502, moe_grouped.cu:471-490): every vec_dot call returns
+// d_w d_x sumi + s_w s_x and a block takes QI8_1 / VDR = 4 calls, i.e. per block d_w d_x <q,u> + 4 s_w s_x -> offset o = -4 s_w against the stored s_x
+template <> struct Fmt<T_Q8_1> { static constexpr int BLK = 32, TS = 36; static constexpr bool HAS_OFFSET = true; static constexpr int SUM_MODE = 1; };
 template <> struct Fmt<T_Q2_K> { static constexpr int BLK = 256, TS = 84; static constexpr bool HAS_OFFSET = true; static constexpr int SUM_MODE = 0; };
 template <> struct Fmt<T_Q3_K> { static constexpr int BLK = 256, TS = 110; static constexpr bool HAS_OFFSET = true; static constexpr int SUM_MODE = 0; };
 template <> struct Fmt<T_Q4_K> { static constexpr int BLK = 256, TS = 144; static constexpr bool HAS_OFFSET = true; static constexpr int SUM_MODE = 0; };
@@ -119,6 +122,12 @@ template <int TYPE> __device__ __forceinline__ Slice load_slice(const uint8_t *_
     const float d = half_bits_to_float(ld2(blk));
     r.qa = ld16_a2(blk + 2); r.qb = ld16_a2(blk + 18);
     r.sa = r.sb = d; r.oa = r.ob = 0.0f;
+  } else if constexpr (TYPE == T_Q8_1) {
+    const uint8_t *blk = row + (size_t)s * 36;  // [half d][half s][32 x int8], 4-byte aligned
+    const unsigned ds = *(const unsigned *)blk;
+    r.qa = ld16_a4(blk + 4); r.qb = ld16_a4(blk + 20);
+    r.sa = r.sb = half_bits_to_float((uint16_t)(ds & 0xffff));
+    r.oa = r.ob = -4.0f * half_bits_to_float((uint16_t)(ds >> 16));
   } else if constexpr (TYPE == T_Q4_0 || TYPE == T_Q4_1) {
     const uint8_t *blk = row + (size_t)s * Fmt<TYPE>::TS;
     const float d = half_bits_to_float(ld2(blk));

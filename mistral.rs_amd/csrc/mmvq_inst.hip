@@ -5,7 +5,9 @@
 #ifndef MRS_TAG
 #error "compile with -DMRS_TAG=<type tag> -DMRS_TYPE=<ggml type id>"
 #endif
+#ifndef MRS_MOE_ONLY  // Q8_1 weights exist only behind the MoE launchers (gguf/ffi.rs:268,424,601,800)
 MRS_MMVQ_LAUNCHERS(MRS_TAG, MRS_TYPE)
+#endif
 #ifdef MRS_MOE_TAG
 MRS_INDEXED_MOE_LAUNCHER(MRS_MOE_TAG, MRS_TYPE)
 #endif

@@ -518,6 +518,9 @@ void orc_random_blocks(int type, void *blocks, int64_t n_blocks, uint64_t seed, 
     switch (type) {
     case ORC_Q4_0: case ORC_Q5_0: case ORC_Q8_0: st16(b, orc_fp32_to_fp16(d)); break;
     case ORC_Q4_1: case ORC_Q5_1: st16(b, orc_fp32_to_fp16(fabsf(d))); st16(b + 2, orc_fp32_to_fp16(-8.f * m)); break;
+    case ORC_Q8_1: { /* a consistent block: s = d * sum(q), as the quantizer writes it */
+      int sm = 0; for (int j = 0; j < 32; ++j) sm += (int8_t)b[4 + j];
+      st16(b, orc_fp32_to_fp16(d)); st16(b + 2, orc_fp32_to_fp16(d * (float)sm)); } break;
     case ORC_Q2_K: st16(b + 80, orc_fp32_to_fp16(fabsf(d))); st16(b + 82, orc_fp32_to_fp16(m)); break;
     case ORC_Q3_K: st16(b + 108, orc_fp32_to_fp16(d / 16.f)); break;
     case ORC_Q4_K: case ORC_Q5_K: st16(b, orc_fp32_to_fp16(fabsf(d) / 32.f)); st16(b + 2, orc_fp32_to_fp16(m / 4.f)); break;
@@ -702,7 +705,10 @@ void orc_matmul_exact(int type, const void *W, int N, int K, const float *X, int
  *   sum = SUM_g,j sc_g*d8_j*<q,u>_{g∩j}  -  off_g*d8_j*SUM(u)_{g∩j}
  * which is algebraically what every vec_dot_*_q8_1 computes (mmvq_gguf.cu:240-700), except
  * that Q4_0/Q4_1/Q5_0/Q5_1 fold the offset through the stored s = half(sum x) term instead of
- * d8*SUM(u) (vec_dot_q4_0_q8_1_impl, :244-258): handled explicitly below. */
+ * d8*SUM(u) (vec_dot_q4_0_q8_1_impl, :244-258): handled explicitly below.
+ * Q8_1 as a weight format exists only in the MoE kernels (indexed_moe.cu:483-502, moe_grouped.cu:471-490): each of the QI8_1 / VDR = 4
+ * vec_dot calls of a block returns d_w d_x sumi + s_w s_x, so a block contributes d_w d_x <q,u> + 4 s_w s_x (the stored sums multiplied,
+ * four times over -- the reference's literal arithmetic, restated as offset -4 s_w against the stored s_x). */
 static double row_dot_q8_1(int type, const uint8_t *wrow, int K, const uint8_t *y, double *mag) {
   const int blk = orc_block_size(type), ts = orc_type_size(type);
   int q[256]; float sc[16], off[16];
@@ -720,7 +726,8 @@ static double row_dot_q8_1(int type, const uint8_t *wrow, int K, const uint8_t *
       const int8_t *u = (const int8_t *)(yb + 4) + (e0 % 32);
       int dot = 0, su = 0;
       for (int e = 0; e < step; ++e) { dot += q[e0 + e] * u[e]; su += u[e]; }
-      if (type == ORC_Q4_0 || type == ORC_Q5_0 || type == ORC_Q4_1 || type == ORC_Q5_1) {
+      if (type == ORC_Q8_1) off[g] = -4.0f * orc_fp16_to_fp32(ld16(b + 2)); /* Q8_1 WEIGHTS (MoE kernels only): see the note above */
+      if (type == ORC_Q4_0 || type == ORC_Q5_0 || type == ORC_Q4_1 || type == ORC_Q5_1 || type == ORC_Q8_1) {
         const float s8 = orc_fp16_to_fp32(ld16(yb + 2));
         acc += (double)sc[g] * (double)d8 * dot - (double)off[g] * (double)s8;
         m += fabs((double)sc[g] * (double)d8 * dot) + fabs((double)off[g] * (double)s8);

@@ -27,6 +27,8 @@ Q2_K, Q3_K, Q4_K, Q5_K, Q6_K, Q8_K, BF16 = 10, 11, 12, 13, 14, 15, 30
 TYPE_NAMES = {Q4_0: "q4_0", Q4_1: "q4_1", Q5_0: "q5_0", Q5_1: "q5_1", Q8_0: "q8_0",
               Q2_K: "q2_k", Q3_K: "q3_k", Q4_K: "q4_k", Q5_K: "q5_k", Q6_K: "q6_k"}
 MMVQ_TYPES = tuple(TYPE_NAMES)
+# the MoE launchers also take Q8_1 as a WEIGHT format (gguf/ffi.rs:268,424,601,800)
+MOE_TYPE_NAMES = {**TYPE_NAMES, Q8_1: "q8_1"}
 
 
 def build(force: bool = False) -> str:

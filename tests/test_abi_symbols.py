@@ -54,3 +54,8 @@ def test_header_symbols_exported(built, header):
 def test_quant_header_counts():
     syms = declared_symbols("mistralrs_quant.h")
     assert sum(s.startswith("launch_mmvq_gguf_") for s in syms) >= 93
+    # the MoE launchers exist for the 10 MMVQ formats and for Q8_1 weights (gguf/ffi.rs:268,424,601,800)
+    for t in ("q4_0", "q4_1", "q5_0", "q5_1", "q8_0", "q8_1", "q2k", "q3k", "q4k", "q5k", "q6k"):
+        for name in (f"launch_indexed_moe_forward_{t}_q8_1", f"launch_moe_grouped_gemm_{t}", f"launch_moe_gemv_fused_gate_up_{t}_q8_1",
+                     f"launch_moe_gemv_down_aggregate_{t}_q8_1"):
+            assert name in syms, name

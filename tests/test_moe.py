@@ -77,7 +77,7 @@ def test_moe_router_topk_abi_vs_oracle(oracle, dev, dt):
         ops.moe_router_topk(torch.zeros(2, 12, device=dev), 2)
 
 
-@pytest.mark.parametrize("tname", ["Q4_0", "Q4_1", "Q5_0", "Q5_1", "Q8_0", "Q2_K", "Q3_K", "Q4_K", "Q5_K", "Q6_K"])
+@pytest.mark.parametrize("tname", ["Q4_0", "Q4_1", "Q5_0", "Q5_1", "Q8_0", "Q8_1", "Q2_K", "Q3_K", "Q4_K", "Q5_K", "Q6_K"])
 @pytest.mark.parametrize("input_dim1", [1, 2])
 def test_indexed_moe_forward_abi(oracle, dev, tname, input_dim1):
     """Drop-in `launch_indexed_moe_forward_<t>_q8_1` (gguf/ffi.rs:100-260): per task the plain MMVQ result of the selected expert, within the
@@ -95,7 +95,7 @@ def test_indexed_moe_forward_abi(oracle, dev, tname, input_dim1):
     kp = oracle.pad512(k)
     wt, yt, it = torch.from_numpy(w).to(dev), torch.from_numpy(y).to(dev), torch.from_numpy(idx.astype(np.int32)).to(dev)
     out = torch.zeros(batch * topk, n, device=dev)
-    tag = oracle.TYPE_NAMES[t].replace("_k", "k")
+    tag = oracle.MOE_TYPE_NAMES[t].replace("_k", "k")
     fn = _lib.sym("quant", f"launch_indexed_moe_forward_{tag}_q8_1", [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_void_p])
     fn(wt.data_ptr(), yt.data_ptr(), it.data_ptr(), out.data_ptr(), n, k, batch, topk, kp, input_dim1, torch.cuda.current_stream().cuda_stream)
     got = out.cpu().numpy().astype(np.float64)

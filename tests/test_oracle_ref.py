@@ -351,7 +351,7 @@ def _imoe_case(oracle, t, seed=0):
     return E, n, k, batch, topk, w, idx, rng
 
 
-@pytest.mark.parametrize("t", TYPES)
+@pytest.mark.parametrize("t", TYPES + [9])  # 9: Q8_1 weights (indexed_moe.cu:483-502)
 @pytest.mark.parametrize("input_dim1", [1, 2])
 def test_indexed_moe_forward_matches_reference_kernel(oracle, t, input_dim1):
     """indexed_moe_forward_<t>_q8_1 (kernels/indexed_moe/indexed_moe.cu:806-1013) on host fibers == per task the Q8_1 matvec oracle with the

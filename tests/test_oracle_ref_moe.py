@@ -9,7 +9,9 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from tests.test_oracle_ref import TYPES, _ref
+from tests.test_oracle_ref import TYPES as _MMVQ_TYPES, _ref
+
+TYPES = _MMVQ_TYPES + [9]  # the MoE kernels are also instantiated for Q8_1 weights
 from tests.util import round_through
 
 

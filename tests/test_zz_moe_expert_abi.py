@@ -17,7 +17,7 @@ import pytest
 from tests.abi_backends import GpuBackend
 from tests.util import round_through
 
-TNAMES = ["Q4_0", "Q4_1", "Q5_0", "Q5_1", "Q8_0", "Q2_K", "Q3_K", "Q4_K", "Q5_K", "Q6_K"]
+TNAMES = ["Q4_0", "Q4_1", "Q5_0", "Q5_1", "Q8_0", "Q8_1", "Q2_K", "Q3_K", "Q4_K", "Q5_K", "Q6_K"]
 P, I = C.c_void_p, C.c_int
 
 
@@ -26,7 +26,7 @@ def _f32_tol(k, mag, want):
 
 
 def _tag(oracle, t):
-    return oracle.TYPE_NAMES[t].replace("_k", "k")
+    return oracle.MOE_TYPE_NAMES[t].replace("_k", "k")
 
 
 def _stack(oracle, t, E, n, k, seed):
