@@ -129,6 +129,9 @@ int mrs_gemm_q_f32_multi(int nseg, const void *const *w, const int *N, float *co
 int mrs_gemm_q_bf16_multi(int nseg, const void *const *w, const int *N, float *const *out, const int *ldo, int ggml_type, int K,
                           const void *x_slabs, int M, int accumulate, void *workspace, size_t workspace_bytes, void *stream);
 size_t mrs_gemm_q_bf16_workspace_bytes(int M);
+/* kernel behind mrs_gemm_q_bf16_multi: 1 = producer / consumer wave specialisation, 0 = every wave stages and multiplies (round 1), -1 = by weight type (default: Q4_K -> 1);
+ * identical results, kept selectable for A/B measurements (also MRS_GEMM_VARIANT) */
+void mrs_gemm_set_variant(int variant);
 /* x f32 [M][ldx] -> bf16 (round to nearest even) slabs y[K/64][M][64]; K % 64 == 0, ldx % 4 == 0 */
 int mrs_convert_f32_bf16_slabs(const float *x, int ldx, int M, int K, void *y, void *stream);
 /* producers that write the slabs directly: act(g) * u (role of fused_glu, utils/ops.rs:2953; activation codes of mistralrs_quant.h) and

@@ -522,6 +522,183 @@ __global__ void __launch_bounds__(HT) gemm_qb_kernel(const GemmBArgs a) {
     }
 }
 
+// Wave-specialised variant of the 256 x 128 x 64 tile (same operands, same MFMA order, identical bits): waves 0-3 are CONSUMERS (one per
+// SIMD, 128 x 64 each = 4 x 2 MFMA tiles, 128 accumulator registers): ds_read_b128 fragments + MFMA and nothing else; waves 4-7 are
+// PRODUCERS (one per SIMD): global loads two k-steps ahead, block decode to bf16, LDS writes.  The two kinds share each SIMD, so the decode
+// VALU of a k-step runs under the MFMAs of the previous one by hardware wave interleaving instead of by compiler scheduling inside one
+// instruction stream (gemm_qb_kernel: every wave alternates both phases and the SIMD partners fall into lockstep between the barriers).
+// LDS per k-step: 48 KiB written + 96 KiB read (a 128 x 64 wave tile reads 24 KiB per 32 MFMAs instead of 16 KiB per 16).
+// One barrier per k-step, hit by both kinds (s_barrier counts waves, not call sites).
+#ifndef MRS_GEMM_ABLATE
+#define MRS_GEMM_ABLATE 0  // experiment builds only (scripts/exp/build_gemm_ablate.sh): 1 no decode arithmetic, 2 producers idle, 4 no MFMA, 8 no fragment reads, 16 no A copies
+#endif
+template <int TYPE>
+__global__ void __launch_bounds__(HT) gemm_qc_kernel(const GemmBArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A 256 x 64 bf16 | B 128 x 64 bf16] = 96 KiB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int seg = 0;
+  if (a.nseg > 2 && (int)blockIdx.x >= a.tile0[2]) seg = 2;
+  else if (a.nseg > 1 && (int)blockIdx.x >= a.tile0[1]) seg = 1;
+  const int segN = a.N[seg];
+  const int m0 = blockIdx.y * HM, n0 = ((int)blockIdx.x - a.tile0[seg]) * HN;
+  const int nk_all = a.K / HK;
+  const int k_lo = (int)((long)nk_all * blockIdx.z / a.splits), k_hi = (int)((long)nk_all * (blockIdx.z + 1) / a.splits);
+  const int nk = k_hi - k_lo;
+  char *buf0 = smem, *buf1 = smem + (HM + HN) * HK * 2;
+
+  if (wave >= 4) {  // ---------------- producers
+    // B: one 32-weight sub-block per thread and k-step (block header decoded once per 32 weights instead of once per 16; rows 2 apart
+    // on neighbouring lanes so that the 8 lanes of a ds_write_b128 group carry 8 distinct swizzle keys); A: 8 x 16 B per thread.  The
+    // VALU budget beside the consumers' 32 MFMAs per k-step is ~5 single-issue instructions per MFMA and SIMD (MI355X_MICROARCH): PMC
+    // showed 2 x 137 (gemm_qb_kernel) / 234 (16-weight units) VALU per SIMD and k-step against that ~160.
+    const int p = tid - 256;
+    const int half = p >> 7, q7 = p & 127, ar = ((q7 & 63) << 1) | (q7 >> 6);
+    const int xc = p & 7, xr0 = p >> 3;  // A: 16-byte chunk, rows xr0 + 32 i
+    const uint8_t *wrow = a.w[seg] + (size_t)min(n0 + ar, segN - 1) * a.row_bytes;
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, (short)0, (int)((size_t)a.M * a.K * 2), 0x00020000);
+    unsigned xoff[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xoff[i] = (unsigned)((min(m0 + xr0 + 32 * i, a.M - 1) * HK + xc * 8) * 2);
+    const int slab_bytes = a.M * HK * 2;
+    v4u xa[2][8];
+    RawG<TYPE> wb[2];
+    auto issue = [&](int set, int kb_raw) {  // unconditional, k index clamped
+      const int kb = k_lo + min(kb_raw, nk - 1);
+      if constexpr (MRS_GEMM_ABLATE & 2) return;
+      if constexpr (!(MRS_GEMM_ABLATE & 16)) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xa[set][i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xoff[i], kb * slab_bytes, 16);  // slab offset in an SGPR
+      }
+      wb[set] = gemm_load_w<TYPE>(wrow, kb, half);
+    };
+    auto commit = [&](int set, int kb_raw, char *buf) {
+      const int kb = k_lo + min(kb_raw, nk - 1);
+      char *A = buf, *B = buf + HM * HK * 2;
+      if constexpr (MRS_GEMM_ABLATE & 2) return;
+      if constexpr (!(MRS_GEMM_ABLATE & 16)) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *(v4u *)(A + tile_off(xr0 + 32 * i, xc)) = xa[set][i];
+      }
+      unsigned o[16];
+      if constexpr (MRS_GEMM_ABLATE & 1) {
+        const int *r = (const int *)&wb[set];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) o[c] = (unsigned)r[c % (int)(sizeof(wb[set]) / 4)];
+      } else {
+        gemm_decode_w<TYPE>(wb[set], kb, half, o);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) *(int4 *)(B + tile_off(ar, half * 4 + c)) = make_int4((int)o[4 * c], (int)o[4 * c + 1], (int)o[4 * c + 2], (int)o[4 * c + 3]);
+    };
+    issue(0, 0);
+    issue(1, 1);
+    commit(0, 0, buf0);
+    __syncthreads();
+    for (int kb = 0; kb < nk; kb += 2) {
+      issue(0, kb + 2);
+      commit(1, kb + 1, buf1);
+      __syncthreads();
+      if (kb + 1 >= nk) break;
+      issue(1, kb + 3);
+      commit(0, kb + 2, buf0);
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ---------------- consumers
+  const int wm = (wave & 1) * 128, wn = (wave >> 1) * 64;
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int frow = lane & 31, fk = lane >> 5;
+  // fragment addresses: tile_off(row, chunk) with row = 32 * t + frow (+ wm / wn, multiples of 32): the swizzle key (row >> 1) & 7 depends on frow
+  // only, so a stage needs one base per operand + one 16-byte-chunk offset per k-slab; the tile index is an immediate offset of the ds_read
+  const int key = (frow >> 1) & 7;
+  const int abase = (wm + frow) * 128, bbase = HM * HK * 2 + (wn + frow) * 128;
+  int ko[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) ko[ks] = ((ks * 2 + fk) ^ key) << 4;
+  // Software pipeline over the four 16-k slabs of a stage: the 6 fragment reads of slab s + 1 are threaded between the 8 MFMAs of slab s
+  // (hipcc otherwise sinks every read to just before its first use and the matrix pipe idles on LDS latency); the barrier sits in front
+  // of the LAST slab's MFMAs (they only need registers), and the reads of the next stage's slab 0 go under them.
+  bf16x8 af[2][4], bfr[2][2];
+  auto rd = [&](int set, const char *buf, int ks) {
+    if constexpr (MRS_GEMM_ABLATE & 8) { if (nk > 0) return; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[set][i] = *(const bf16x8 *)(buf + abase + ko[ks] + i * 4096);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bfr[set][j] = *(const bf16x8 *)(buf + bbase + ko[ks] + j * 4096);
+  };
+  auto mm = [&](int set) {
+    if constexpr (MRS_GEMM_ABLATE & 4) {  // keep the fragment reads alive without the matrix pipe
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j][0] += __builtin_bit_cast(float, (int)af[set][i][0] ^ (int)bfr[set][j][0]);
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[set][i], bfr[set][j], acc[i][j], 0, 0, 0);
+  };
+  constexpr int STAGE = (HM + HN) * HK * 2;
+  int st = 0;
+  __syncthreads();
+  rd(0, smem, 0);
+  for (int kb = 0; kb < nk; ++kb) {
+    const char *buf = smem + st;
+    rd(1, buf, 1); mm(0);
+    rd(0, buf, 2); mm(1);
+    rd(1, buf, 3); mm(0);
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    }
+    __syncthreads();
+    st ^= STAGE;
+    rd(0, smem + st, 0);  // after the last stage: a harmless read of stale LDS
+    mm(1);
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 1);
+  }
+  float *obase;
+  int ldo, ncol0;
+  if (a.splits > 1) { obase = a.partial + (size_t)blockIdx.z * a.M * a.ldp; ldo = a.ldp; ncol0 = (int)blockIdx.x * HN - n0; }
+  else { obase = a.out[seg]; ldo = a.ldo[seg]; ncol0 = 0; }
+  const bool accum = a.accumulate && a.splits == 1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < a.M && n < segN) {
+          float *p = obase + (size_t)m * ldo + ncol0 + n;
+          *p = accum ? *p + acc[i][j][r] : acc[i][j][r];
+        }
+      }
+    }
+}
+
 // out[seg][m][n] (+)= sum_z partial[z][m][tile0[seg]*128 + n], z ascending (fixed order)
 __global__ void __launch_bounds__(256) gemm_splitk_reduce_kernel(const GemmBArgs a) {
   const int total_cols = a.ldp;
@@ -595,6 +772,10 @@ __global__ void __launch_bounds__(256) rms_norm_bf16_slabs_kernel(const float *_
   }
 }
 
+// 1 = wave-specialised gemm_qc_kernel, 0 = gemm_qb_kernel, -1 (default) = by weight type: measured on the MI355X (profiles/round2_prefill_gemm.md) the
+// producer / consumer split wins for Q4_K (gate/up 692 -> 631 us, down 312 -> 288 us at T = 2048), is neutral for Q5_K / Q8_0 and loses for Q6_K
+// (its 32-weight unit loads four 2-byte-aligned 16-B pieces).  MRS_GEMM_VARIANT / mrs_gemm_set_variant: tests compare the two bit for bit.
+static int &gemm_variant() { static int v = [] { const char *e = getenv("MRS_GEMM_VARIANT"); return e ? atoi(e) : -1; }(); return v; }
 template <int TYPE, int NI> static void gemm_b_launch_ni(GemmBArgs a, size_t ws_bytes, hipStream_t s) {
   constexpr int TN = HN * NI;
   int tiles = 0;
@@ -612,8 +793,12 @@ template <int TYPE, int NI> static void gemm_b_launch_ni(GemmBArgs a, size_t ws_
   a.splits = splits;
   constexpr size_t lds = 2 * (HM + TN) * HK * 2;
   static bool attr = false;
-  auto kern = gemm_qb_kernel<TYPE, NI>;
-  if (!attr) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  auto kern = NI == 1 && (gemm_variant() == 1 || (gemm_variant() < 0 && TYPE == T_Q4_K)) ? gemm_qc_kernel<TYPE> : gemm_qb_kernel<TYPE, NI>;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void *)gemm_qb_kernel<TYPE, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void *)gemm_qc_kernel<TYPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
   hipLaunchKernelGGL(kern, dim3(tiles, mt, splits), dim3(HT), lds, s, a);
   if (splits > 1) {
     const size_t n4s = (size_t)a.M * a.ldp / 4;
@@ -658,6 +843,7 @@ extern "C" int mrs_rms_norm_bf16_slabs(const float *x, const float *w, int M, in
 
 // Large-M GEMM over bf16 activations in k-slab-major layout x[K/64][M][64] (mrs_convert_f32_bf16_slabs): out_s[m*ldo_s + n] (+)= sum_k x[m][k] * bf16(W_s[n][k]).
 // workspace (may be NULL): split-K partials for shapes with fewer tiles than CUs; mrs_gemm_q_bf16_workspace_bytes() always suffices.
+extern "C" void mrs_gemm_set_variant(int v) { mrs::gemm_variant() = v; }
 extern "C" size_t mrs_gemm_q_bf16_workspace_bytes(int M) { return (size_t)M * 65536 * 4 / (size_t)((M + HM - 1) / HM) + 65536; }
 extern "C" int mrs_gemm_q_bf16_multi(int nseg, const void *const *w, const int *N, float *const *out, const int *ldo, int ggml_type, int K,
                                      const void *x_slabs, int M, int accumulate, void *workspace, size_t workspace_bytes, void *stream) {

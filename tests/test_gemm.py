@@ -76,6 +76,32 @@ def test_prefill_gemm_large_m_vs_oracle(oracle, dev, tname, m, n, k, split):
     assert torch.equal(fast_gemm.plain_bf16(wt, xt, split_k=split), torch.from_numpy(got.astype(np.float32)).to(dev))  # deterministic
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("tname", ["Q4_K", "Q5_K", "Q6_K", "Q8_0"])
+@pytest.mark.parametrize("m,n,k,split", [(512, 384, 1024, False), (300, 200, 2048, True), (257, 128, 512, False)])
+def test_wave_specialised_gemm_equals_ping_pong_kernel(oracle, dev, tname, m, n, k, split):
+    """gemm_qc_kernel (producer / consumer waves, the default) and gemm_qb_kernel feed the same MFMAs the same operands in the same k
+    order: identical bits (ragged M / N tiles, split-K)."""
+    import ctypes as C
+    import torch
+    from mistralrs_amd import _lib
+    from mistralrs_amd.gguf import GgmlDType, QTensor, fast_gemm
+    t = getattr(oracle, tname)
+    rng = np.random.default_rng(m + n + k)
+    w = oracle.random_blocks(t, n, k, seed=3 + n + k, d_scale=0.02)
+    wt = QTensor.from_numpy(GgmlDType.from_id(t), (n, k), w, dev)
+    xt = torch.from_numpy((rng.standard_normal((m, k)) * rng.uniform(0.2, 3.0, (m, 1))).astype(np.float32)).to(dev)
+    setv = _lib.sym("ext", "mrs_gemm_set_variant", [C.c_int], None)
+    try:
+        setv(0)
+        old = fast_gemm.plain_bf16(wt, xt, split_k=split).clone()
+        setv(1)
+        new = fast_gemm.plain_bf16(wt, xt, split_k=split)
+    finally:
+        setv(-1)
+    assert torch.equal(old, new)
+
+
 def test_slab_producers(dev):
     """to_slabs is the layout [K/64][M][64] of the bf16-rounded matrix; the fused producers equal the unfused op + to_slabs bit for bit."""
     import torch
