@@ -57,6 +57,16 @@ int mrs_dec_gate_up(const mrs_dec_mat *wg, const mrs_dec_mat *wu, int n, const i
 /* (RmsNorm when norm_w) + GEMV; mode 0: out = W x; mode 1: out = out * resid_scale + s * W x with s = *acc_scale (NULL: 1) */
 int mrs_dec_proj(const mrs_dec_mat *w, int n, const int32_t *expert_sel, const float *x, int ldx, const float *norm_w, float eps, float *out,
                  int ld_out, int mode, float resid_scale, const float *acc_scale, int b, void *stream);
+/* Short-context decode attention in one launch (max_context_len <= 1024, head size 128, block 32, even GQA group): split-KV attention with the
+ * partials in LDS, merge, and the Q8_K quantization o_proj's prologue would do; img_out = activation image of b columns x num_heads * 128 values
+ * (mrs_dec_act_image_bytes) for mrs_dec_proj_img, out_f32 (may be NULL) = the f32 result.  Same bits as mrs_decode_attention_f32_* followed by
+ * mrs_dec_proj.  Returns -3 when the shape is outside the kernel (caller falls back), -1 on bad arguments. */
+size_t mrs_dec_act_image_bytes(int k, int b);
+int mrs_dec_attention_q8k(void *img_out, float *out_f32, const float *q, const void *k_cache, const void *v_cache, int num_kv_heads, float scale,
+                          const uint32_t *block_tables, const uint32_t *context_lens, int block_size, int max_context_len, int num_seqs, int num_heads,
+                          int head_size, int max_blocks_per_seq, int q_stride, int kv_block_stride, int kv_head_stride, int kv_dtype, void *stream);
+/* GEMV on a pre-quantized activation image (K-quant weights only; -3: image larger than the prologue's staging registers) */
+int mrs_dec_proj_img(const mrs_dec_mat *w, int n, const void *x_img, float *out, int ld_out, int mode, float resid_scale, int b, void *stream);
 /* Persistent decode step: ONE launch runs phases [phase_begin, phase_end) of a decode step for one sequence (b = 1) on a grid of resident
  * workgroups (one per CU) with device-side phase barriers; the weight stream of a phase starts before the barrier in front of it completes.
  * Phase ids: 0 = embedding, 1 + 6 l + {0 qkv, 1 attention splits, 2 attention merge, 3 o_proj, 4 gate/up, 5 down}, 1 + 6 L = final norm + lm_head.
@@ -186,6 +196,7 @@ typedef struct {  /* all device pointers, owned by the caller */
 size_t mrs_llama_workspace_bytes(const mrs_llama_config *cfg);
 /* decode-layout copy (mrs_dec_repack output, caller-owned) of a linear tensor already registered with mrs_llama_set_tensor */
 int mrs_llama_set_dec_tensor(void *model, const char *name, const void *planes);
+int mrs_llama_set_fused_attention(void *model, int on); /* decode engine: 1 = one-launch attention + Q8_K image for contexts <= 1024 (mrs_dec_attention_q8k), 0 (default: measured faster) = split + merge kernels */
 int mrs_llama_set_dec_persist(void *model, int mode); /* decode engine, b = 1: 1 = one persistent launch per step (default), 2 = same kernel phase by phase, 0 = per-phase kernels */
 int mrs_llama_set_mode(void *model, int use_fused); /* switch the decode path (values of mrs_llama_config.use_fused) */
 void *mrs_llama_create(const mrs_llama_config *cfg);

@@ -21,14 +21,13 @@ struct AttnArgs {
 };
 
 // q_s: G * 128 floats, p_s: G * 32 floats of wave-private LDS; the item covers query heads [head0, head0 + G) of kv head kvh
-template <int G, class CT>
-__device__ __forceinline__ void attn_split_item(const AttnArgs &a, int kvh, int head0, int seq, int split, float *q_s, float *p_s) {
+// blocks [b0, b1) of the sequence; sink(g, o0, o1, m, l) receives the un-normalised partial of query head head0 + g (o0 / o1: dims lane / lane + 64)
+template <int G, class CT, class Sink>
+__device__ __forceinline__ void attn_split_core(const AttnArgs &a, int kvh, int head0, int seq, int b0, int b1, float *q_s, float *p_s, Sink sink) {
   constexpr int HD = 128, BS = 32;
   const int lane = lane_opaque();
   const int ctx = (int)a.context_lens[seq];
-  const int nblk = (ctx + BS - 1) / BS;
-  const int b0 = split * a.bpw, b1 = min(b0 + a.bpw, nblk);
-  if (b0 >= nblk) return;  // wave-uniform
+  if (b0 >= b1) return;  // wave-uniform
   const float *qg = a.q + (size_t)seq * a.q_stride + (size_t)head0 * HD;
   for (int i = lane * 4; i < G * HD; i += 256) *(float4 *)(q_s + i) = *(const float4 *)(qg + i);
   MRS_WAVE_SYNC();
@@ -105,29 +104,33 @@ __device__ __forceinline__ void attn_split_item(const AttnArgs &a, int kvh, int 
     MRS_WAVE_SYNC();
   }
 #pragma unroll
-  for (int g = 0; g < G; ++g) {
+  for (int g = 0; g < G; ++g) sink(g, o0[g], o1[g], m[g], l[g]);
+}
+template <int G, class CT>
+__device__ __forceinline__ void attn_split_item(const AttnArgs &a, int kvh, int head0, int seq, int split, float *q_s, float *p_s) {
+  const int lane = lane_opaque();
+  const int nblk = ((int)a.context_lens[seq] + 31) / 32;
+  const int b0 = split * a.bpw, b1 = min(b0 + a.bpw, nblk);
+  attn_split_core<G, CT>(a, kvh, head0, seq, b0, b1, q_s, p_s, [&](int g, float o0, float o1, float m, float l) {
     const size_t pi = ((size_t)seq * a.num_heads + head0 + g) * a.max_splits + split;
-    a.part_o[pi * HD + lane] = o0[g];
-    a.part_o[pi * HD + lane + 64] = o1[g];
-    if (lane == 0) { a.part_m[pi] = m[g]; a.part_l[pi] = l[g]; }
-  }
+    a.part_o[pi * 128 + lane] = o0;
+    a.part_o[pi * 128 + lane + 64] = o1;
+    if (lane == 0) { a.part_m[pi] = m; a.part_l[pi] = l; }
+  });
 }
 
 // one wave merges the splits of (seq, head): lane j <-> split j for the weights, lane d / d + 64 for the output dims
-__device__ __forceinline__ void attn_merge_item(const AttnArgs &a, int head, int seq) {
+// ns (<= 64) partials of one head: pm / pl [ns], po [ns][128]; returns the head's output at dims lane (v0) and lane + 64 (v1)
+__device__ __forceinline__ void attn_merge_core(int ns, const float *pm, const float *pl, const float *po, float &v0, float &v1) {
   constexpr int HD = 128;
   const int lane = lane_opaque();
-  const int nblk = ((int)a.context_lens[seq] + 31) / 32;
-  const int ns = (nblk + a.bpw - 1) / a.bpw;  // <= 64
-  const size_t p0 = ((size_t)seq * a.num_heads + head) * a.max_splits;
-  const float mj = lane < ns ? a.part_m[p0 + lane] : -FLT_MAX;
-  const float lj = lane < ns ? a.part_l[p0 + lane] : 0.f;
+  const float mj = lane < ns ? pm[lane] : -FLT_MAX;
+  const float lj = lane < ns ? pl[lane] : 0.f;
   const float mx = wave_max(mj);
   const float r = lane < ns ? __expf(mj - mx) : 0.f;
   const float gs = wave_sum(lj * r);
   // the standalone merge kernel sums four interleaved chains over the splits: same order here
   float a0[2] = {0.f, 0.f}, a1[2] = {0.f, 0.f}, a2[2] = {0.f, 0.f}, a3[2] = {0.f, 0.f};
-  const float *po = a.part_o + p0 * HD;
   int j = 0;
   for (; j + 4 <= ns; j += 4) {
     const float r0 = __shfl(r, j, 64), r1 = __shfl(r, j + 1, 64), r2 = __shfl(r, j + 2, 64), r3 = __shfl(r, j + 3, 64);
@@ -144,8 +147,18 @@ __device__ __forceinline__ void attn_merge_item(const AttnArgs &a, int head, int
     for (int h = 0; h < 2; ++h) a0[h] = fmaf(po[(size_t)j * HD + lane + 64 * h], rj, a0[h]);
   }
   const float inv = 1.0f / (gs + 1e-6f);
-#pragma unroll
-  for (int h = 0; h < 2; ++h) a.out[((size_t)seq * a.num_heads + head) * HD + lane + 64 * h] = ((a0[h] + a1[h]) + (a2[h] + a3[h])) * inv;
+  v0 = ((a0[0] + a1[0]) + (a2[0] + a3[0])) * inv;
+  v1 = ((a0[1] + a1[1]) + (a2[1] + a3[1])) * inv;
+}
+__device__ __forceinline__ void attn_merge_item(const AttnArgs &a, int head, int seq) {
+  const int lane = lane_opaque();
+  const int nblk = ((int)a.context_lens[seq] + 31) / 32;
+  const int ns = (nblk + a.bpw - 1) / a.bpw;  // <= 64
+  const size_t p0 = ((size_t)seq * a.num_heads + head) * a.max_splits;
+  float v0, v1;
+  attn_merge_core(ns, a.part_m + p0, a.part_l + p0, a.part_o + p0 * 128, v0, v1);
+  a.out[((size_t)seq * a.num_heads + head) * 128 + lane] = v0;
+  a.out[((size_t)seq * a.num_heads + head) * 128 + lane + 64] = v1;
 }
 
 }  // namespace dec

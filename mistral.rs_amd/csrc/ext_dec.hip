@@ -40,6 +40,7 @@ struct GemvArgs {
   const int32_t *expert_sel;  // stacked experts [E * nrows][K]: rows of expert e start at e * nrows (nullptr = dense)
   const float *acc_scale;     // RESID: out = out * resid_scale + (*acc_scale) * W.x  (routing weight)
   int ablate;                 // experiments (MRS_DEC_ABLATE): 1 = skip the activation prologue's arithmetic, 2 = skip the accumulate (loads only)
+  const void *x_img;          // activations already quantized by the producer (decode_attn_fused_kernel): the LDS image of NCOLS columns, byte for byte
 };
 
 #define MRS_DEC_TYPE_SWITCH(t, ...)                              \
@@ -79,7 +80,8 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
   // the activation image is staged once per workgroup
   auto pre = [&]() -> ActPre {
     if constexpr (LATE) return ActPre{};
-    else return act_issue<false>(a.x, a.norm_w, K);
+    // a pre-quantized image goes through the same registers: its 16-byte pieces sit at tid * 16 + j * NT * 16, like the f32 vector's
+    else return act_issue<false>(a.x_img ? (const float *)a.x_img : a.x, a.x_img ? nullptr : a.norm_w, a.x_img ? (int)(act_bytes(K, NCOLS) / 4) : K);
   };
   auto pro = [&](const ActPre &p) -> Act {
     if constexpr (LATE) {
@@ -87,6 +89,13 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
       const ActPre late = act_issue<MRS_DEC_AGENT_IO != 0>(a.x, a.norm_w, K);
       return act_finish<NCOLS, MRS_DEC_AGENT_IO != 0>(smem, red, late, a.x, a.ldx, a.norm_w, a.eps, K, act_mode_for(a.m[0].type));
     } else {
+      if (a.x_img) {
+#pragma unroll
+        for (int j = 0; j < ACT_MAXV; ++j)
+          if ((size_t)(tid0 * 16 + j * NT * 16) < act_bytes(K, NCOLS)) *(v4u *)(smem + tid0 * 16 + j * NT * 16) = p.xv[j];
+        __syncthreads();
+        return Act{smem, (const float *)(smem + (size_t)NCOLS * K), (const int *)(smem + (size_t)NCOLS * K + (size_t)NCOLS * (K / 32) * 4), K};
+      }
       if (a.ablate & 1) { __syncthreads(); return Act{smem, (const float *)(smem + (size_t)NCOLS * K), (const int *)(smem + (size_t)NCOLS * K + (size_t)NCOLS * (K / 32) * 4), K}; }
       return act_finish<NCOLS, false>(smem, red, p, a.x, a.ldx, a.norm_w, a.eps, K, act_mode_for(a.m[0].type));
     }
@@ -421,6 +430,50 @@ static bool make_mat(Mat &m, const void *planes, int type, long long n, long lon
   return true;
 }
 
+// ------------------------------------------------------------------------------------------------ short-context decode attention, one launch
+// Split-KV attention + merge + Q8_K quantization of the result in ONE kernel for contexts of <= FUSED_MAX_CTX tokens (the launch-per-phase path
+// otherwise spends 6.8 + 4.8 us per layer in two latency-bound kernels, and o_proj re-quantizes the f32 result in every workgroup):
+// a workgroup = HG = 2 query heads of one kv head (256 output values = exactly one Q8_K superblock of the attention vector), 12 waves (168 VGPRs: 16 waves spill); wave w
+// takes the 32-token blocks w, w + 12, ... one at a time (attn_split_core with the same per-block arithmetic as the split kernel at bpw = 1),
+// partials go to LDS instead of HBM; waves 0 / 1 merge the two heads (attn_merge_core: the merge kernel's order), wave 0 quantizes the 256
+// values exactly as o_proj's prologue would (quantize4: same lane <-> element mapping) and writes the activation IMAGE (q | d | bsums in the
+// LDS layout of dec_core.cuh) that dec_gemv_kernel copies into LDS.  Bits: identical to decode_attn_wave_kernel<.., false> + merge + prologue.
+constexpr int FUSED_MAX_CTX = 1024;
+template <int HG, class CT, int FUSED_NW>
+__global__ void __launch_bounds__(FUSED_NW * 64) decode_attn_fused_kernel(const AttnArgs a, uint8_t *img, float *out_f32, int G, int ns_cap) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *po = (float *)smem;                              // [HG][ns_cap][128]
+  float *pm = po + (size_t)HG * ns_cap * 128, *pl = pm + HG * ns_cap;  // [HG][ns_cap]
+  float *merged = pl + HG * ns_cap;                       // [HG * 128]
+  const int tid = tid_opaque(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float *q_s = merged + HG * 128 + wave * (HG * 128 + HG * 32), *p_s = q_s + HG * 128;
+  const int sub = G / HG, kvh = (int)blockIdx.x / sub, head0 = kvh * G + ((int)blockIdx.x % sub) * HG, seq = blockIdx.y;
+  const int nblk = min(((int)a.context_lens[seq] + 31) / 32, ns_cap);
+  for (int b = wave; b < nblk; b += FUSED_NW)
+    attn_split_core<HG, CT>(a, kvh, head0, seq, b, b + 1, q_s, p_s, [&](int g, float o0, float o1, float m, float l) {
+      float *o = po + ((size_t)g * ns_cap + b) * 128;
+      o[lane] = o0; o[lane + 64] = o1;
+      if (lane == 0) { pm[g * ns_cap + b] = m; pl[g * ns_cap + b] = l; }
+    });
+  __syncthreads();
+  if (wave < HG) {
+    float v0, v1;
+    attn_merge_core(nblk, pm + wave * ns_cap, pl + wave * ns_cap, po + (size_t)wave * ns_cap * 128, v0, v1);
+    merged[wave * 128 + lane] = v0; merged[wave * 128 + lane + 64] = v1;
+    if (out_f32) { float *o = out_f32 + ((size_t)seq * a.num_heads + head0 + wave) * 128; o[lane] = v0; o[lane + 64] = v1; }
+  }
+  __syncthreads();
+  if (wave == 0) {  // HG * 128 = 256 values = superblock head0 / 2 of column seq
+    const int K = a.num_heads * 128, ncols = gridDim.y, sb = head0 >> 1;
+    const float4 v = *(const float4 *)(merged + lane * 4);
+    char *qc = (char *)img + (size_t)seq * K;
+    float *dc = (float *)(img + (size_t)ncols * K) + (size_t)seq * (K / 32);
+    int *bsc = (int *)(img + (size_t)ncols * K + (size_t)ncols * (K / 32) * 4) + (size_t)seq * (K / 16);
+    const int e = sb * 256 + lane * 4, piece = e >> 4;
+    quantize4(v, e, ((piece ^ sb_mask(sb)) << 4) | ((lane & 3) << 2), true, ACT_Q8K, qc, dc, bsc);
+  }
+}
+
 template <int EPI> struct Launch {
   template <int NCOLS> static int go(GemvArgs a, hipStream_t s) {
     int upw = (a.units + 256 * NW - 1) / (256 * NW);
@@ -521,6 +574,44 @@ extern "C" int mrs_dec_proj(const mrs_dec_mat_c *w, int n, const int32_t *expert
   a.nrows[0] = n; a.K = (int)w->k; a.x = x; a.ldx = ldx; a.norm_w = norm_w; a.eps = eps; a.out = out; a.out_stride = ld_out;
   a.resid_scale = resid_scale; a.acc_scale = acc_scale; a.units = n; a.expert_sel = expert_sel;
   return mode ? Launch<EPI_RESID>::run(a, b, (hipStream_t)stream) : Launch<EPI_STORE>::run(a, b, (hipStream_t)stream);
+}
+
+// o_proj & friends on activations the producer already quantized (mrs_dec_attention_q8k): x_img = the LDS image of b columns of k values
+extern "C" int mrs_dec_proj_img(const mrs_dec_mat_c *w, int n, const void *x_img, float *out, int ld_out, int mode, float resid_scale, int b, void *stream) {
+  GemvArgs a{};
+  if (!w || !x_img || !make_mat(a.m[0], w->planes, w->type, w->n, w->k) || n <= 0 || w->n != n || act_mode_for(w->type) != ACT_Q8K) return -1;
+  if (act_bytes((int)w->k, b) > (size_t)ACT_MAXV * NT * 16) return -3;  // the image is staged through the prologue's registers
+  a.nrows[0] = n; a.K = (int)w->k; a.x_img = x_img; a.out = out; a.out_stride = ld_out; a.resid_scale = resid_scale; a.units = n;
+  return mode ? Launch<EPI_RESID>::run(a, b, (hipStream_t)stream) : Launch<EPI_STORE>::run(a, b, (hipStream_t)stream);
+}
+extern "C" size_t mrs_dec_act_image_bytes(int k, int b) { return act_bytes(k, b); }
+// Decode attention for short contexts in one launch: img_out = Q8_K activation image [b columns][num_heads * 128] for mrs_dec_proj_img, out_f32
+// (may be NULL) = the f32 result [b][num_heads * 128].  Returns -3 when the shape is outside the kernel (max_context_len > 1024, GQA group
+// not a multiple of 2, head size != 128, block size != 32): the caller uses mrs_decode_attention_f32_* + mrs_dec_proj.
+extern "C" int mrs_dec_attention_q8k(void *img_out, float *out_f32, const float *q, const void *k_cache, const void *v_cache, int num_kv_heads, float scale,
+                                     const uint32_t *block_tables, const uint32_t *context_lens, int block_size, int max_context_len, int num_seqs,
+                                     int num_heads, int head_size, int max_blocks_per_seq, int q_stride, int kv_block_stride, int kv_head_stride,
+                                     int kv_dtype, void *stream) {
+  if (!img_out || block_size != 32 || head_size != 128 || num_seqs <= 0 || num_seqs > 8 || num_kv_heads <= 0 || num_heads % num_kv_heads ||
+      (kv_dtype != 0 && kv_dtype != 1)) return -1;
+  const int G = num_heads / num_kv_heads;
+  if (G % 2 || max_context_len > FUSED_MAX_CTX || max_context_len <= 0) return -3;
+  AttnArgs t{};
+  t.q = q; t.k_cache = (const uint16_t *)k_cache; t.v_cache = (const uint16_t *)v_cache; t.block_tables = block_tables; t.context_lens = context_lens;
+  t.num_heads = num_heads; t.num_kv_heads = num_kv_heads; t.max_blocks_per_seq = max_blocks_per_seq; t.q_stride = q_stride;
+  t.kv_block_stride = kv_block_stride; t.kv_head_stride = kv_head_stride; t.bpw = 1; t.num_seqs = num_seqs; t.scale = scale;
+  const int ns_cap = (max_context_len + 31) / 32;
+  t.max_splits = ns_cap;
+  static const int nw = [] { const char *e = getenv("MRS_DEC_ATTN_WAVES"); const int v = e ? atoi(e) : 8; return v == 12 ? 12 : 8; }();
+  const size_t lds = ((size_t)2 * ns_cap * 128 + 2 * 2 * ns_cap + 2 * 128 + (size_t)nw * (2 * 128 + 2 * 32)) * 4;
+  const dim3 grid(num_kv_heads * (G / 2), num_seqs);
+  auto go = [&](auto kern) {
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+    hipLaunchKernelGGL(kern, grid, dim3(nw * 64), lds, (hipStream_t)stream, t, (uint8_t *)img_out, out_f32, G, ns_cap);
+  };
+  if (kv_dtype == 1) { if (nw == 8) go(decode_attn_fused_kernel<2, bf16_t, 8>); else go(decode_attn_fused_kernel<2, bf16_t, 12>); }
+  else { if (nw == 8) go(decode_attn_fused_kernel<2, f16_t, 8>); else go(decode_attn_fused_kernel<2, f16_t, 12>); }
+  return 0;
 }
 
 // ---- persistent decode step (one launch for a range of phases; b = 1)

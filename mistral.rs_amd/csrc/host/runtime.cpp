@@ -180,6 +180,7 @@ struct Workspace {  // carve-up of the caller's scratch
   void *moe_y;              // [top_k] Q8_1 rows of the selected experts' activations
   void *dec_table, *dec_sync;  // persistent decode step: device table of layers, 2 x u32 sync words
   float *moe_act;           // decode engine: [top_k][intermediate] f32 activations of the selected experts
+  void *attn_img;           // decode engine: Q8_K activation image of the attention result (mrs_dec_attention_q8k -> mrs_dec_proj_img)
 };
 
 class Llama {
@@ -195,6 +196,7 @@ class Llama {
   bool have_bufs = false;
   mutable bool dec_table_ready = false, dec_table_unfit = false;
   int dec_persist = [] { const char *e = getenv("MRS_DEC_PERSIST"); return e ? atoi(e) : 0; }();  // default 0: measured slower than per-phase kernels on MI355X
+  int fused_attn = [] { const char *e = getenv("MRS_DEC_FUSED_ATTN"); return e ? atoi(e) : 0; }();  // decode engine: one-launch attention for contexts <= 1024; measured 1-5 % SLOWER per token than split + merge (profiles/round2_decode_experiments.md 5): off
   void *comm = nullptr;  // RCCL communicator (ext_comm.hip) when cfg.world_size > 1
   void *p2p = nullptr;   // one-shot peer-mailbox all-reduce (ext_p2p.hip) for decode-sized messages
 
@@ -224,6 +226,7 @@ class Llama {
     t += align(B * c.num_heads * parts * c.head_dim * 4) + 2 * align(B * c.num_heads * parts * 4);
     t += align(B * 8);
     t += align(mrs_dec_step_table_bytes(c.num_layers)) + align(64);  // persistent decode step: layer table, sync words
+    t += align(mrs_dec_act_image_bytes((int)nq, (int)B));
     if (c.num_experts > 0) {
       const size_t k = std::max(1, (int)c.num_experts_per_tok);
       t += align(B * k * 4) * 2 + align(k * (pad_to(c.intermediate_size, MATRIX_ROW_PADDING) / 32) * 36);
@@ -251,6 +254,7 @@ class Llama {
     ws.max_logits = (float *)take(B * cfg.num_heads * parts * 4);
     ws.sample_scratch = take(B * 8);
     ws.dec_table = take(mrs_dec_step_table_bytes(cfg.num_layers)); ws.dec_sync = take(64);
+    ws.attn_img = take(mrs_dec_act_image_bytes((int)nq, (int)B));
     dec_table_ready = false; dec_table_unfit = false;
     if (cfg.num_experts > 0) {
       const size_t k = std::max(1, (int)cfg.num_experts_per_tok);
@@ -467,13 +471,23 @@ class Llama {
       if (mrs_dec_qkv(&bl.dq, &bl.dk, &bl.dv, ws.h, d, bl.input_layernorm, cfg.rms_eps, ws.q, bl.key_cache, bl.value_cache, bufs.slot_mapping, bufs.positions,
                       bufs.cos_table, bufs.sin_table, hd, cfg.rot_dim / 2, kvh, bs, kvd, b, s))
         return fail("mrs_dec_qkv refused the layer");
-      if (mrs_decode_attention_f32_f32_bf16(ws.attn, ws.exp_sums, ws.max_logits, ws.attn_ws, ws.q, bl.key_cache, bl.value_cache, kvh, 1.0f / sqrtf((float)hd),
-                                            bufs.block_tables, bufs.context_lens, bs, eff_max, b, cfg.num_heads, hd, cfg.max_blocks_per_seq, nq, kvh * hd * bs,
-                                            hd * bs, kvd, s))
-        return fail("mrs_decode_attention_f32 refused the shape");
-      // TP: h <- h / world + W_o . attn on every rank, then ONE sum all-reduce of h (the residual add stays fused, as in forward_fused)
-      if (mrs_dec_proj(&bl.dout, d, nullptr, ws.attn, nq, nullptr, 0.f, ws.h, d, 1, rs, nullptr, b, s) || all_reduce(ws.h, (size_t)b * d, s))
-        return fail("o_proj failed: %s", g_last_error.c_str());
+      // short contexts: attention + merge + Q8_K quantization in one launch, o_proj copies the activation image (-3: shape outside that kernel)
+      int arc = fused_attn && bl.dout.type != 8 /* Q8_0 weights take Q8_0 activations */ ? mrs_dec_attention_q8k(ws.attn_img, nullptr, ws.q, bl.key_cache, bl.value_cache, kvh, 1.0f / sqrtf((float)hd), bufs.block_tables,
+                                                    bufs.context_lens, bs, eff_max, b, cfg.num_heads, hd, cfg.max_blocks_per_seq, nq, kvh * hd * bs, hd * bs, kvd, s)
+                           : -3;
+      if (arc == 0) arc = mrs_dec_proj_img(&bl.dout, d, ws.attn_img, ws.h, d, 1, rs, b, s);
+      if (arc != 0 && arc != -3) return fail("fused decode attention / o_proj failed (%d)", arc);
+      if (arc == 0) {
+        if (all_reduce(ws.h, (size_t)b * d, s)) return fail("o_proj all-reduce failed: %s", g_last_error.c_str());
+      } else {
+        if (mrs_decode_attention_f32_f32_bf16(ws.attn, ws.exp_sums, ws.max_logits, ws.attn_ws, ws.q, bl.key_cache, bl.value_cache, kvh, 1.0f / sqrtf((float)hd),
+                                              bufs.block_tables, bufs.context_lens, bs, eff_max, b, cfg.num_heads, hd, cfg.max_blocks_per_seq, nq, kvh * hd * bs,
+                                              hd * bs, kvd, s))
+          return fail("mrs_decode_attention_f32 refused the shape");
+        // TP: h <- h / world + W_o . attn on every rank, then ONE sum all-reduce of h (the residual add stays fused, as in forward_fused)
+        if (mrs_dec_proj(&bl.dout, d, nullptr, ws.attn, nq, nullptr, 0.f, ws.h, d, 1, rs, nullptr, b, s) || all_reduce(ws.h, (size_t)b * d, s))
+          return fail("o_proj failed: %s", g_last_error.c_str());
+      }
       if (cfg.num_experts > 0) {
         // SparseMoeBlock::forward (models/mixtral.rs:280-304): router on the normed hidden state; per token the top-k experts' gate/up then down,
         // accumulated into h with the renormalised routing weights; expert ids / weights stay on the device
@@ -844,6 +858,7 @@ extern "C" int mrs_llama_set_dec_persist(void *m, int mode) {
   ((Llama *)m)->dec_persist = mode;
   return 0;
 }
+extern "C" int mrs_llama_set_fused_attention(void *m, int on) { ((Llama *)m)->fused_attn = on ? 1 : 0; return 0; }
 extern "C" int mrs_llama_set_kv_cache(void *m, int layer, void *k, void *v) {
   Llama &l = *(Llama *)m;
   if (layer < 0 || layer >= l.cfg.num_layers) return mrs_host::fail("kv cache: layer %d out of range", layer);

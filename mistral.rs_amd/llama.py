@@ -292,6 +292,12 @@ class Llama:
         self._chk(self._L.mrs_llama_set_dec_persist(self._h, mode))
         self._graph = None
 
+    def set_fused_attention(self, on: bool) -> None:
+        """Decode engine: one-launch attention + Q8_K image for contexts <= 1024 vs the split + merge kernels (default: measured faster); same bits."""
+        self._L.mrs_llama_set_fused_attention.argtypes = [C.c_void_p, C.c_int]
+        self._chk(self._L.mrs_llama_set_fused_attention(self._h, int(on)))
+        self._graph = None
+
     def _set_mode(self) -> None:
         mode = 2 if (self._engine_wanted and self._engine_ok) else int(bool(self.cfg.use_fused))
         if mode != self._mode_set:

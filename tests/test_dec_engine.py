@@ -197,3 +197,70 @@ def test_qkv_host_emulation(oracle, tq, tv, heads, kvh, hd, k, b, kvd):
                                                         ("Q6_K", "Q6_K", 8, 1, 128, 1024, 1, 1)])
 def test_qkv_gpu(oracle, dev, tq, tv, heads, kvh, hd, k, b, kvd):
     check_qkv(oracle, GpuBackend(dev), tq, tv, heads, kvh, hd, k, b, kvd)
+
+
+ATTN_F32 = [C.c_void_p] * 7 + [C.c_int, C.c_float, C.c_void_p, C.c_void_p] + [C.c_int] * 10 + [C.c_void_p]
+ATTN_Q8K = [C.c_void_p] * 5 + [C.c_int, C.c_float, C.c_void_p, C.c_void_p] + [C.c_int] * 10 + [C.c_void_p]
+PROJ_IMG = [C.POINTER(Mat), C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]
+
+
+def check_fused_attention(O, be, heads, kvh, ctxs, max_ctx, kv_dtype=1, n_out=24, waves=None):
+    """mrs_dec_attention_q8k (one launch: split attention in LDS + merge + Q8_K image) followed by mrs_dec_proj_img == the split / merge kernels
+    (mrs_decode_attention_f32_*) followed by mrs_dec_proj, bit for bit: f32 attention result, and the o_proj output."""
+    hd, bs, b = 128, 32, len(ctxs)
+    nq = heads * hd
+    rng = np.random.default_rng(heads + kvh + sum(ctxs))
+    mbs = (max_ctx + bs - 1) // bs
+    nblocks = b * mbs + 1
+    to16 = (lambda a: a.astype(np.float16).view(np.uint16)) if kv_dtype == 0 else O.to_bf16_bits
+    kc = be.buf(to16((rng.standard_normal((nblocks, kvh, hd // 8, bs, 8)) * 0.7).astype(np.float32)))
+    vc = be.buf(to16(rng.standard_normal((nblocks, kvh, hd, bs)).astype(np.float32)))
+    bt = be.buf(rng.permutation(nblocks - 1)[: b * mbs].reshape(b, mbs).astype(np.uint32) + 1)
+    cl = be.buf(np.asarray(ctxs, dtype=np.uint32))
+    q = be.buf((rng.standard_normal((b, nq)) * 0.5).astype(np.float32))
+    splits = be.sym("mrs_decode_attention_max_splits", [C.c_int], C.c_int)(max_ctx)
+    po, pm, pl = be.buf(np.zeros((b, heads, splits, hd), np.float32)), be.buf(np.zeros((b, heads, splits), np.float32)), be.buf(np.zeros((b, heads, splits), np.float32))
+    ref = be.buf(np.zeros((b, nq), np.float32))
+    scale = 1.0 / np.sqrt(hd)
+    f32 = be.sym("mrs_decode_attention_f32_f32_bf16", ATTN_F32, C.c_int)
+    assert f32(ref.ptr, pl.ptr, pm.ptr, po.ptr, q.ptr, kc.ptr, vc.ptr, kvh, scale, bt.ptr, cl.ptr, bs, max_ctx, b, heads, hd, mbs, nq, kvh * hd * bs, hd * bs, kv_dtype,
+               be.stream) == 0
+    nimg = be.sym("mrs_dec_act_image_bytes", [C.c_int, C.c_int], C.c_size_t)(nq, b)
+    assert nimg == b * (nq + nq // 32 * 4 + nq // 16 * 4)
+    img, got = be.buf(np.zeros(nimg, np.uint8)), be.buf(np.full((b, nq), np.nan, np.float32))
+    fused = be.sym("mrs_dec_attention_q8k", ATTN_Q8K, C.c_int)
+    rc = fused(img.ptr, got.ptr, q.ptr, kc.ptr, vc.ptr, kvh, scale, bt.ptr, cl.ptr, bs, max_ctx, b, heads, hd, mbs, nq, kvh * hd * bs, hd * bs, kv_dtype, be.stream)
+    assert rc == 0
+    np.testing.assert_array_equal(got.numpy(), ref.numpy())
+    # o_proj on the image == o_proj on the f32 vector (the same quantizer ran in a different kernel)
+    t = O.Q4_K
+    packed = _weights(O, t, n_out, nq, 7)
+    keep, m = repack(be, O, t, packed, n_out, nq)
+    base = rng.standard_normal((b, n_out)).astype(np.float32)
+    o_ref, o_img = be.buf(base.copy()), be.buf(base.copy())
+    assert be.sym("mrs_dec_proj", PROJ, C.c_int)(C.byref(m), n_out, None, ref.ptr, nq, None, 0.0, o_ref.ptr, n_out, 1, 0.5, None, b, be.stream) == 0
+    assert be.sym("mrs_dec_proj_img", PROJ_IMG, C.c_int)(C.byref(m), n_out, img.ptr, o_img.ptr, n_out, 1, 0.5, b, be.stream) == 0
+    np.testing.assert_array_equal(o_img.numpy(), o_ref.numpy())
+    # and the image is the oracle's Q8_K quantization of the f32 result
+    want = O.matmul_cpu(t, packed, n_out, nq, ref.numpy())
+    assert np.abs(o_img.numpy() - (base * np.float32(0.5) + want)).max() <= 2e-5 * max(1.0, np.abs(want).max())
+
+
+def test_fused_attention_refuses_long_contexts_and_odd_groups(oracle):
+    be = HostBackend()
+    fused = be.sym("mrs_dec_attention_q8k", ATTN_Q8K, C.c_int)
+    d = be.buf(np.zeros(64, np.uint8))
+    args = lambda heads, kvh, max_ctx: (d.ptr, None, d.ptr, d.ptr, d.ptr, kvh, 1.0, d.ptr, d.ptr, 32, max_ctx, 1, heads, 128, 64, heads * 128, kvh * 128 * 32, 128 * 32, 1, be.stream)
+    assert fused(*args(4, 2, 2048)) == -3   # > 1024 tokens: the split / merge kernels spread the KV over more CUs
+    assert fused(*args(3, 3, 512)) == -3    # one query head per kv head is half a Q8_K superblock
+
+
+@pytest.mark.parametrize("heads,kvh,ctxs,max_ctx,kvd", [(4, 2, [70], 128, 1), (4, 1, [33, 200], 224, 1), (2, 1, [1], 64, 0), (8, 2, [500, 17, 96], 512, 1)])
+def test_fused_attention_host_emulation(oracle, heads, kvh, ctxs, max_ctx, kvd):
+    check_fused_attention(oracle, HostBackend(), heads, kvh, ctxs, max_ctx, kvd)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("heads,kvh,ctxs,max_ctx,kvd", [(32, 8, [700], 832, 1), (32, 8, [1024, 3, 515], 1024, 1), (8, 4, [129], 160, 0), (64, 8, [333, 1000], 1024, 1)])
+def test_fused_attention_gpu(oracle, dev, heads, kvh, ctxs, max_ctx, kvd):
+    check_fused_attention(oracle, GpuBackend(dev), heads, kvh, ctxs, max_ctx, kvd, n_out=256)

@@ -212,6 +212,26 @@ def test_persistent_step_equals_phase_launches(oracle, dev, request):
         assert torch.equal(o, ref), f"decode_persist mode {mode} differs from the per-phase kernels: {float((o - ref).abs().max())}"
 
 
+def test_fused_attention_path_equals_split_merge_path(oracle, dev, request):
+    """Per-phase engine with the one-launch attention (split partials in LDS + merge + Q8_K image, o_proj on the image) == the same engine with
+    the split and merge kernels and o_proj's own quantizer: identical logits over a sequence (single and batched)."""
+    import torch
+    emu = request.config.getoption("--host-emulation")
+    outs = {}
+    for fused in (True, False):
+        cfg, w, m, cos, sin = _mk(oracle, dev, Q4KM(oracle), "bf16", max_batch=2)
+        m.set_decode_persist(0)
+        m.set_fused_attention(fused)
+        toks, seq = [(1000 + 7 * i) % cfg.vocab_size for i in range(3 if emu else 70)], []
+        for pos, t in enumerate(toks):
+            m.set_state([t, (t + 5) % cfg.vocab_size], [pos, pos])
+            seq.append(m.forward_logits(2).clone())
+        if not emu:
+            torch.cuda.synchronize()
+        outs[fused] = torch.stack(seq)
+    assert torch.equal(outs[True], outs[False]), float((outs[True] - outs[False]).abs().max())
+
+
 def test_short_prompt_in_long_context_and_replay_guard(oracle, dev, request):
     """(advisor, round 1) a prompt of <= 16 tokens must prefill when max_context_len > 512 (the v1 / v2 rule of the fallback attention used to refuse
     before the MFMA flash kernel was even tried), and a captured decode graph must not be replayed past max_new_tokens / max_context_len."""
