@@ -141,7 +141,7 @@ def measured_traffic(model_name):
         k = next(v for name, v in ks.items() if "dec_gemv_kernel<1, 2>" in name)  # NCOLS = 1, EPI_GLU
     except (OSError, KeyError, ValueError, StopIteration):
         return {"traffic": None}
-    if "8B" not in model_name:
+    if "8B" not in model_name or "Q4_K_M" not in model_name:  # the profiled workload is the Q4_K_M model; ISQ Q8_0 streams twice the bytes
         return {"traffic": None}
     return {"traffic": int(k["read_bytes_per_launch"] + k["write_bytes_per_launch"]), "traffic_source": "profiles/round2_hbm_traffic.json"}
 

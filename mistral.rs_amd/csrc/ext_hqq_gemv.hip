@@ -7,8 +7,8 @@
 // Layout facts used (hqq/quantize.rs:7-70): the [N, K] weight is viewed as [64, w] with w = N K / 64; element (n, k) sits in group row
 // n / (N / 64) and column j = (n % (N / 64)) * K + k, so the 64 output rows n_lo + r * (N / 64) share one K-vector of (scale, zero); 4-bit packing puts group rows r
 // (high nibble) and r + 32 (low nibble) in byte [r][j].  One workgroup = one n_lo (and a slice of the packed rows): it streams 32 (16, 8) contiguous K-byte rows.
-// Arithmetic = the reference's: the dequantized VALUE is bit-identical to dequantize_{4,8}bit (per column only 16 values exist in 4-bit: a 16 x 512 lookup table
-// per K-chunk in LDS, laid out so that the 64 lanes of a read hit 64 banks); products and sums in f32 like a dense f32-accumulate matmul.
+// Arithmetic = the reference's: the dequantized VALUE is bit-identical to dequantize_{4,8}bit (the two T-roundings are applied explicitly); products and
+// sums in f32 like a dense f32-accumulate matmul.
 #include "common.cuh"
 #include <hip/hip_runtime.h>
 
@@ -17,76 +17,93 @@ namespace mrs_host { int fail(const char *fmt, ...); }
 namespace mrs {
 namespace hqqv {
 
-constexpr int NT = 512, NW = 8, CH = 512;  // threads, waves, columns per lookup-table chunk
+constexpr int NT = 512, NW = 8, CH = 2048;  // threads, waves, columns per staged chunk of the (zero, scale) K-vectors
 
-template <class T> __device__ __forceinline__ float deq(unsigned q, float z, float s) { return to_f<T>(from_f<T>(round_to<T>((float)q - z) * s)); }
+// round to T and back: the reference's dequantize kernels compute in T (hqq.cu:24-34: T(q) - zero, then * scale, each rounded to T)
+template <class T> __device__ __forceinline__ float rt(float x);
+template <> __device__ __forceinline__ float rt<float>(float x) { return x; }
+template <> __device__ __forceinline__ float rt<f16_t>(float x) { return (float)(f16_t)x; }
+typedef __bf16 hq_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float hq_f32x2 __attribute__((ext_vector_type(2)));
+template <> __device__ __forceinline__ float rt<bf16_t>(float x) {  // one v_cvt_pk_bf16_f32 (RNE) + a shift
+  const hq_f32x2 v = {x, 0.f};
+  return __uint_as_float(__builtin_bit_cast(unsigned, __builtin_convertvector(v, hq_bf16x2)) << 16);
+}
+// (q - z) is exact in f32 (q <= 255, z has <= 11 significant bits), rounding it to T is the reference's T-subtraction; the product of two T values
+// is exact in f32, rounding it is the reference's T-multiplication: bit-identical to dequantize_{4,8}bit
+template <class T> __device__ __forceinline__ float deq(unsigned q, float z, float s) { return rt<T>(rt<T>((float)q - z) * s); }
 
 struct Args {
   const uint8_t *wq; const void *scale, *zero, *x, *bias; void *out;
   int N, K, ldx, ldo, rsplit;
 };
 
-// grid (N / 64, rsplit); LDS: xs [NCOLS][K] f32 | lut [16][CH] f32 (4-bit)
+// grid (N / 64, rsplit); LDS: xs [NCOLS][K] f32 | zs [2][CH] f32 (zero, scale of the current chunk)
+// A wave owns `rpw` packed rows; per chunk it first issues every 16-byte load of its rows (bytes in flight), then decodes: 16 bytes = 16 columns x
+// (high nibble = group row r, low nibble = group row r + 32), ~7 VALU per weight (extract, convert, subtract, 2 roundings, multiply, fma) against a
+// 16-entry lookup table per column before (LDS-bound at 0.3-0.9 TB/s: 32 KiB of table writes per 8 KiB of packed weights).
 template <int BITS, class T, int NCOLS>
 __global__ void __launch_bounds__(NT) hqq_gemv_kernel(const Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int PACKED_ROWS = BITS == 4 ? 32 : 64;
+  constexpr int PACKED_ROWS = BITS == 4 ? 32 : 64, MAXR = 8;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int K = a.K, R = a.N / 64;          // R = output rows per group row
   const int n_lo = blockIdx.x;
   const size_t w = (size_t)R * K, j0 = (size_t)n_lo * K;
   const int pr_per_wg = PACKED_ROWS / a.rsplit, pr0 = blockIdx.y * pr_per_wg, rpw = pr_per_wg / NW;  // packed rows of this workgroup / per wave (1..8)
-  float *xs = (float *)smem, *lut = xs + (size_t)NCOLS * K;
+  float *xs = (float *)smem, *zs = xs + (size_t)NCOLS * K;
   const T *x = (const T *)a.x, *scale = (const T *)a.scale + j0, *zero = (const T *)a.zero + j0;
   for (int c = 0; c < NCOLS; ++c)
     for (int k = tid; k < K; k += NT) xs[(size_t)c * K + k] = to_f<T>(x[(size_t)c * a.ldx + k]);
-  constexpr int MAXR = 8;
   float acc_hi[MAXR][NCOLS], acc_lo[MAXR][NCOLS];
 #pragma unroll
   for (int r = 0; r < MAXR; ++r)
 #pragma unroll
     for (int c = 0; c < NCOLS; ++c) { acc_hi[r][c] = 0.f; acc_lo[r][c] = 0.f; }
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
   for (int c0 = 0; c0 < K; c0 += CH) {
-    __syncthreads();  // xs staged / the previous chunk's table no longer read
-    if constexpr (BITS == 4) {
-      // column kk = c0 + tid of the chunk -> table position (tid % 4) * 128 + tid / 4: lane l of a reader (columns 4l' + e) then reads position e * 128 + l'
-      if (c0 + tid < K) {
-        const float z = to_f<T>(zero[c0 + tid]), s = to_f<T>(scale[c0 + tid]);
-        const int pos = (tid & 3) * 128 + (tid >> 2);
+    __syncthreads();  // xs staged / the previous chunk's (zero, scale) no longer read
+    for (int k = tid; k < CH && c0 + k < K; k += NT) { zs[k] = to_f<T>(zero[c0 + k]); zs[CH + k] = to_f<T>(scale[c0 + k]); }
+    // the wave's packed bytes of this chunk: 16 B per lane and piece, two pieces of 1024 columns
+    v4u raw[MAXR][2];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) lut[q * CH + pos] = deq<T>((unsigned)q, z, s);
+    for (int r = 0; r < MAXR; ++r)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int kk = c0 + (h * 64 + lane) * 16;
+        raw[r][h] = (r < rpw && kk < K) ? __builtin_nontemporal_load((const v4u *)(a.wq + (size_t)(pr0 + wave * rpw + r) * w + j0 + kk)) : v4u{0, 0, 0, 0};
       }
-      __syncthreads();
-    }
+    __syncthreads();
 #pragma unroll
-    for (int r = 0; r < MAXR; ++r) {
-      if (r < rpw) {  // wave-uniform
-        const uint8_t *row = a.wq + (size_t)(pr0 + wave * rpw + r) * w + j0 + c0;
+    for (int h = 0; h < 2; ++h) {
+      const int kl = (h * 64 + lane) * 16;  // first column of the piece inside the chunk
+      if (c0 + kl < K) {
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {  // 512 columns = 2 dwords per lane
-          const int d = half * 64 + lane, kk = 4 * d;  // dword index inside the chunk, its first column
-          if (c0 + kk < K) {
-            const unsigned v = *(const unsigned *)(row + kk);
-            float wh[4], wl[4];
-            if constexpr (BITS == 4) {
+        for (int d = 0; d < 4; ++d) {  // dword d = 4 columns
+          const float4 z4 = *(const float4 *)(zs + kl + 4 * d), s4 = *(const float4 *)(zs + CH + kl + 4 * d);
+          const float zz[4] = {z4.x, z4.y, z4.z, z4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
+          float xv[NCOLS][4];
+#pragma unroll
+          for (int c = 0; c < NCOLS; ++c) {
+            const float4 t = *(const float4 *)(xs + (size_t)c * K + c0 + kl + 4 * d);
+            xv[c][0] = t.x; xv[c][1] = t.y; xv[c][2] = t.z; xv[c][3] = t.w;
+          }
+#pragma unroll
+          for (int r = 0; r < MAXR; ++r) {
+            if (r < rpw) {  // wave-uniform
+              const unsigned v = raw[r][h][d];
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
-                const unsigned b = (v >> (8 * e)) & 0xff;
-                wh[e] = lut[(b >> 4) * CH + e * 128 + d];
-                wl[e] = lut[(b & 15) * CH + e * 128 + d];
-              }
-            } else {
+                const unsigned bq = (v >> (8 * e)) & 0xff;
+                if constexpr (BITS == 4) {
+                  const float wh = deq<T>(bq >> 4, zz[e], ss[e]), wl = deq<T>(bq & 15, zz[e], ss[e]);
 #pragma unroll
-              for (int e = 0; e < 4; ++e) wh[e] = deq<T>((v >> (8 * e)) & 0xff, to_f<T>(zero[c0 + kk + e]), to_f<T>(scale[c0 + kk + e]));
-            }
+                  for (int c = 0; c < NCOLS; ++c) { acc_hi[r][c] = fmaf(wh, xv[c][e], acc_hi[r][c]); acc_lo[r][c] = fmaf(wl, xv[c][e], acc_lo[r][c]); }
+                } else {
+                  const float wh = deq<T>(bq, zz[e], ss[e]);
 #pragma unroll
-            for (int c = 0; c < NCOLS; ++c) {
-              const float4 xv = *(const float4 *)(xs + (size_t)c * K + c0 + kk);
-              acc_hi[r][c] = fmaf(wh[0], xv.x, acc_hi[r][c]); acc_hi[r][c] = fmaf(wh[1], xv.y, acc_hi[r][c]);
-              acc_hi[r][c] = fmaf(wh[2], xv.z, acc_hi[r][c]); acc_hi[r][c] = fmaf(wh[3], xv.w, acc_hi[r][c]);
-              if constexpr (BITS == 4) {
-                acc_lo[r][c] = fmaf(wl[0], xv.x, acc_lo[r][c]); acc_lo[r][c] = fmaf(wl[1], xv.y, acc_lo[r][c]);
-                acc_lo[r][c] = fmaf(wl[2], xv.z, acc_lo[r][c]); acc_lo[r][c] = fmaf(wl[3], xv.w, acc_lo[r][c]);
+                  for (int c = 0; c < NCOLS; ++c) acc_hi[r][c] = fmaf(wh, xv[c][e], acc_hi[r][c]);
+                }
               }
             }
           }
@@ -118,9 +135,10 @@ __global__ void __launch_bounds__(NT) hqq_gemv_kernel(const Args a) {
 template <int BITS, class T> static int launch(const Args &a, int b, hipStream_t s) {
   const dim3 grid(a.N / 64, a.rsplit), block(NT);
   auto go = [&](auto kern, int ncols) {
-    const size_t lds = (size_t)ncols * a.K * 4 + (BITS == 4 ? 16 * CH * 4 : 0);
+    const size_t lds = (size_t)ncols * a.K * 4 + 2 * CH * 4;
     if (lds > 158 * 1024) return -2;
-    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+    static bool attr = false;  // per instantiation; not an operation a stream capture tolerates on every call
+    if (!attr) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024); attr = true; }
     hipLaunchKernelGGL(kern, grid, block, lds, s, a);
     return 0;
   };
@@ -138,11 +156,11 @@ template <int BITS, class T> static int launch(const Args &a, int b, hipStream_t
 
 // x [b][ldx], out [b][ldo], scale / zero [N K / 64], bias [N] or NULL, all of dtype 0 = f32, 1 = f16, 2 = bf16; wq = the packed tensor of HqqLayer
 // ([32, N K / 64] bytes for 4 bit, [64, N K / 64] for 8 bit; group size 64, axis 0).  Returns 0; -1 = arguments outside the fused kernel (other bit widths,
-// N % 64, K % 4, b > 8: the caller keeps dequantize + dense matmul); -2 = activation rows too long for LDS.
+// N % 64, K % 16, b > 8: the caller keeps dequantize + dense matmul); -2 = activation rows too long for LDS.
 extern "C" int mrs_hqq_gemv(int bits, int dtype, const void *wq, const void *scale, const void *zero, const void *bias, const void *x, int ldx, void *out, int ldo,
                             int N, int K, int b, void *stream) {
   using namespace mrs::hqqv;
-  if ((bits != 4 && bits != 8) || N <= 0 || K <= 0 || N % 64 || K % 4 || b < 1 || b > 8 || !wq || !scale || !zero || !x || !out) return -1;
+  if ((bits != 4 && bits != 8) || N <= 0 || K <= 0 || N % 64 || K % 16 || b < 1 || b > 8 || !wq || !scale || !zero || !x || !out) return -1;
   Args a{(const uint8_t *)wq, scale, zero, x, bias, out, N, K, ldx, ldo, 1};
   // split the packed rows of a group over more workgroups until the chip is covered (each split re-reads the K-vectors of x / scale / zero from L2)
   const int packed_rows = bits == 4 ? 32 : 64;

@@ -222,7 +222,7 @@ def test_fused_hqq_gemv_vs_dequantize_matmul(dev, bits, n, k, b):
         _check_fused_gemv("gpu", dev, bits, dtype, n, k, b)
 
 
-@pytest.mark.parametrize("bits,n,k,b", [(4, 128, 64, 1), (4, 64, 1028, 2), (8, 128, 96, 3)])
+@pytest.mark.parametrize("bits,n,k,b", [(4, 128, 64, 1), (4, 64, 1040, 2), (8, 128, 96, 3), (4, 64, 2096, 1)])
 def test_fused_hqq_gemv_host_emulation(bits, n, k, b):
     """The fused kernel on the wave64 host emulation (f32) vs the oracle's dequantize @ x."""
     from tests.abi_backends import HostBackend
@@ -242,3 +242,12 @@ def test_fused_hqq_gemv_host_emulation(bits, n, k, b):
     assert (np.abs(bo.numpy() - want) <= 2.0 ** -18 * mag).all()
     assert fn(3, 0, bw.ptr, bs.ptr, bz.ptr, None, bx.ptr, k, bo.ptr, n, n, k, b, None) == -1  # other bit widths: dequantize + dense matmul
     assert fn(bits, 0, bw.ptr, bs.ptr, bz.ptr, None, bx.ptr, k, bo.ptr, n, n, k, 9, None) == -1
+
+
+def test_fused_hqq_gemv_refuses_rows_that_are_not_16_byte_multiples():
+    """K % 16 != 0: the 16-byte weight loads would be misaligned -> -1, HqqLayer.forward keeps dequantize + matmul for such layers."""
+    from tests.abi_backends import HostBackend
+    be = HostBackend()
+    d = be.buf(np.zeros(1 << 16, np.uint8))
+    fn = be.sym("mrs_hqq_gemv", [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p], C.c_int)
+    assert fn(4, 0, d.ptr, d.ptr, d.ptr, None, d.ptr, 1028, d.ptr, 64, 64, 1028, 1, be.stream) == -1
