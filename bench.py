@@ -131,7 +131,7 @@ def cpu_baseline(model, cfg, budget_s=12.0):
                       f"host reports {os.cpu_count()} logical CPUs"}, toks
 
 
-def measured_traffic(model_name):
+def measured_traffic(model_name, quant="q4_k_m"):
     """HBM bytes per launch of the dominant kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE on this same command,
     x2 gfx950 correction; scripts/profile_round.sh -> profiles/round1_hbm_traffic.json).  Counters cannot be read from inside the
     timed process, so the figure is the last profiled one for this kernel and workload; null for any other workload."""
@@ -141,7 +141,7 @@ def measured_traffic(model_name):
         k = next(v for name, v in ks.items() if "dec_gemv_kernel<1, 2>" in name)  # NCOLS = 1, EPI_GLU
     except (OSError, KeyError, ValueError, StopIteration):
         return {"traffic": None}
-    if "8B" not in model_name or "Q4_K_M" not in model_name:  # the profiled workload is the Q4_K_M model; ISQ Q8_0 streams twice the bytes
+    if "8B" not in model_name or quant != "q4_k_m":  # the profiled workload is the Q4_K_M model; ISQ Q8_0 streams twice the bytes
         return {"traffic": None}
     return {"traffic": int(k["read_bytes_per_launch"] + k["write_bytes_per_launch"]), "traffic_source": "profiles/round2_hbm_traffic.json"}
 
@@ -376,7 +376,7 @@ def main():
         "step_bytes": int(step_bytes), "step_roofline_frac": round(step_bytes * (a.steps / t_all) / HBM_PEAK, 4),
         "roofline": {"bound": "hbm", "kernel": "dec_gemv_kernel<1, EPI_GLU> (decode engine gate/up phase: RMSNorm + Q8_K quantize + gate/up GEMV + SiLU*up)",
                      "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4),
-                     "bytes_per_launch": int(kern_bytes), "us_per_launch": round(kern_s * 1e6, 2), **measured_traffic(name)},
+                     "bytes_per_launch": int(kern_bytes), "us_per_launch": round(kern_s * 1e6, 2), **measured_traffic(name, a.quant)},
         "greedy_tokens_head": [int(t) for t in toks[a.warmup: a.warmup + 8]],
     }
     if ar is not None:

@@ -139,6 +139,12 @@ int mrs_gemm_q_f32_multi(int nseg, const void *const *w, const int *N, float *co
 int mrs_gemm_q_bf16_multi(int nseg, const void *const *w, const int *N, float *const *out, const int *ldo, int ggml_type, int K,
                           const void *x_slabs, int M, int accumulate, void *workspace, size_t workspace_bytes, void *stream);
 size_t mrs_gemm_q_bf16_workspace_bytes(int M);
+/* Grouped MoE GEMM of a prompt on the matrix cores (same dispatch tables as launch_moe_dispatch / launch_moe_grouped_gemm_<t>, mistralrs_quant.h):
+ * for expert e and sorted position pos in [bounds[e], bounds[e+1]): acc = W_e . x[row], row = gather ? sorted[pos] / topk : pos;
+ * route_w ? atomicAdd(out[sorted[pos] / topk], route_w[sorted[pos]] * acc) : out[pos] = acc.  x_slabs: bf16 slabs [K/64][x_rows][64]; w: [E * N][K] blocks.
+ * Per expert bit-identical to mrs_gemm_q_bf16_multi on that expert's rows. */
+int mrs_moe_gemm_q_bf16(const void *w, int ggml_type, int N, int K, int num_experts, const void *x_slabs, int x_rows, const int32_t *bounds,
+                        const int32_t *sorted, int topk, int gather, const float *route_w, float *out, int ldo, int routes, void *stream);
 /* kernel behind mrs_gemm_q_bf16_multi: 1 = producer / consumer wave specialisation, 0 = every wave stages and multiplies (round 1), -1 = by weight type (default: Q4_K -> 1);
  * identical results, kept selectable for A/B measurements (also MRS_GEMM_VARIANT) */
 void mrs_gemm_set_variant(int variant);

@@ -390,11 +390,17 @@ struct GemmBArgs {
   int M, K, accumulate, splits, ldp, tn;
   float *partial;     // [splits][M][ldp] when splits > 1 (column = global n-tile * tn + n)
   size_t row_bytes;
+  // grouped MoE mode (gemm_qb_kernel<.., MOE = true>, blockIdx.z = expert): rows of expert e are the sorted positions [bounds[e], bounds[e + 1]);
+  // w[0] = experts stacked along the row axis, expert_stride bytes apart; xrows = rows of the slab layout (tokens when gathering, routes otherwise)
+  const int32_t *bounds, *sorted;  // launch_moe_dispatch outputs: sorted[pos] = flat route index (token * topk + slot)
+  const float *route_w;            // down projection: out[token][n] += route_w[flat] * acc (f32 atomics); NULL: out[pos][n] = acc
+  int topk, gather, xrows;         // gather: the A row of position pos is token sorted[pos] / topk (gate / up); else pos itself (down)
+  size_t expert_stride;
 };
 
 // NI = 128-column blocks per workgroup tile: 1 -> 256 x 128 (waves 4 x 2, 64 x 64 each), 2 -> 256 x 256 (waves 2 x 4, 128 x 64 each:
 // half the A traffic, LDS bytes and decode work per FLOP; needs >= ~200 column tiles of 256 to fill the chip without split-K).
-template <int TYPE, int NI>
+template <int TYPE, int NI, bool MOE = false>
 __global__ void __launch_bounds__(HT) gemm_qb_kernel(const GemmBArgs a) {
   constexpr int TN = HN * NI, MI = 2 * NI, PF = NI == 1 ? 2 : 1;  // PF: staging register sets (prefetch distance in k-steps)
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A 256 x 64 bf16 | B TN x 64 bf16] = 96 / 128 KiB
@@ -404,14 +410,23 @@ __global__ void __launch_bounds__(HT) gemm_qb_kernel(const GemmBArgs a) {
   else if (a.nseg > 1 && (int)blockIdx.x >= a.tile0[1]) seg = 1;
   const int segN = a.N[seg];
   const int m0 = blockIdx.y * HM, n0 = ((int)blockIdx.x - a.tile0[seg]) * TN;
+  int cnt = a.M, pos0 = 0;  // valid rows of this row tile's matrix, its first sorted position
+  const uint8_t *wbase = a.w[seg];
+  if constexpr (MOE) {
+    pos0 = a.bounds[blockIdx.z];
+    cnt = a.bounds[blockIdx.z + 1] - pos0;
+    if (m0 >= cnt) return;  // workgroup-uniform: most (expert, row tile) pairs of the worst-case grid are empty
+    wbase += (size_t)blockIdx.z * a.expert_stride;
+  }
   const int wm = NI == 1 ? (wave & 3) * 64 : (wave & 1) * 128, wn = NI == 1 ? (wave >> 2) * 64 : (wave >> 1) * 64;
   const int ar = tid >> 2, aq = tid & 3;     // B: rows ar + 128 j, 16-weight quarter of the 64-k slab
   const int xc = tid & 7, xr0 = tid >> 3;    // A: 16-byte chunk, rows xr0 + 64 i
   const uint8_t *wrow[NI];
 #pragma unroll
-  for (int jn = 0; jn < NI; ++jn) wrow[jn] = a.w[seg] + (size_t)min(n0 + ar + 128 * jn, segN - 1) * a.row_bytes;
+  for (int jn = 0; jn < NI; ++jn) wrow[jn] = wbase + (size_t)min(n0 + ar + 128 * jn, segN - 1) * a.row_bytes;
   const int nk_all = a.K / HK;
-  const int k_lo = (int)((long)nk_all * blockIdx.z / a.splits), k_hi = (int)((long)nk_all * (blockIdx.z + 1) / a.splits);
+  const int kz = MOE ? 0 : (int)blockIdx.z;
+  const int k_lo = (int)((long)nk_all * kz / a.splits), k_hi = (int)((long)nk_all * (kz + 1) / a.splits);
   const int nk = k_hi - k_lo;
 
   f32x16 acc[MI][2];
@@ -426,16 +441,21 @@ __global__ void __launch_bounds__(HT) gemm_qb_kernel(const GemmBArgs a) {
   // workgroup: with default loads its 32 KB per k-step flush the weight-block lines (re-used over 4 k-steps) out of L1 -- measured
   // 2x on the whole kernel; nontemporal loads fix L1 but also drop the lines from L2, which every other column tile re-reads (-15 %).
   typedef unsigned v4u __attribute__((ext_vector_type(4)));
-  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, (short)0, (int)((size_t)a.M * a.K * 2), 0x00020000);
+  const int xrows = MOE ? a.xrows : a.M;
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, (short)0, (int)((size_t)xrows * a.K * 2), 0x00020000);
   unsigned xoff[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) xoff[i] = (unsigned)((min(m0 + xr0 + 64 * i, a.M - 1) * HK + xc * 8) * 2);
+  for (int i = 0; i < 4; ++i) {
+    int row = min(m0 + xr0 + 64 * i, cnt - 1);
+    if constexpr (MOE) { row += pos0; if (a.gather) row = a.sorted[row] / a.topk; }
+    xoff[i] = (unsigned)((row * HK + xc * 8) * 2);
+  }
   v4u xa[PF][4];
   RawH<TYPE> wb[PF][NI];
   auto issue = [&](int set, int kb_raw) {  // unconditional, k index clamped (a load under a branch makes hipcc drain vmcnt)
     const int kb = k_lo + min(kb_raw, nk - 1);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xa[set][i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xoff[i] + (unsigned)kb * (unsigned)(a.M * HK * 2), 0, 16);
+    for (int i = 0; i < 4; ++i) xa[set][i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xoff[i] + (unsigned)kb * (unsigned)(xrows * HK * 2), 0, 16);
 #pragma unroll
     for (int jn = 0; jn < NI; ++jn) wb[set][jn] = gemm_load_w16<TYPE>(wrow[jn], kb, aq);
   };
@@ -514,9 +534,18 @@ __global__ void __launch_bounds__(HT) gemm_qb_kernel(const GemmBArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m < a.M && n < segN) {
-          float *p = obase + (size_t)m * ldo + ncol0 + n;
-          *p = accum ? *p + acc[i][j][r] : acc[i][j][r];
+        if (m < cnt && n < segN) {
+          if constexpr (MOE) {
+            if (a.route_w) {
+              const int flat = a.sorted[pos0 + m];
+              atomicAdd(obase + (size_t)(flat / a.topk) * ldo + n, a.route_w[flat] * acc[i][j][r]);
+            } else {
+              obase[(size_t)(pos0 + m) * ldo + n] = acc[i][j][r];
+            }
+          } else {
+            float *p = obase + (size_t)m * ldo + ncol0 + n;
+            *p = accum ? *p + acc[i][j][r] : acc[i][j][r];
+          }
         }
       }
     }
@@ -843,6 +872,37 @@ extern "C" int mrs_rms_norm_bf16_slabs(const float *x, const float *w, int M, in
 
 // Large-M GEMM over bf16 activations in k-slab-major layout x[K/64][M][64] (mrs_convert_f32_bf16_slabs): out_s[m*ldo_s + n] (+)= sum_k x[m][k] * bf16(W_s[n][k]).
 // workspace (may be NULL): split-K partials for shapes with fewer tiles than CUs; mrs_gemm_q_bf16_workspace_bytes() always suffices.
+// Grouped MoE GEMM of a prompt on the matrix cores (role of launch_moe_grouped_gemm_<t> / moe_grouped.cu:1180-1235 for long prompts, same
+// dispatch tables): for every expert e and sorted position pos in [bounds[e], bounds[e + 1]): acc[n] = sum_k bf16(x[row][k]) * bf16(dequant(W_e)[n][k]),
+// row = gather ? sorted[pos] / topk : pos;  route_w ? atomicAdd(out[sorted[pos] / topk][n], route_w[sorted[pos]] * acc) : out[pos][n] = acc.
+// x_slabs = bf16 slabs [K/64][x_rows][64]; w = [E * N][K] blocks; routes = number of sorted positions (grid covers the worst case: all on one expert).
+// Arithmetic and k order of mrs_gemm_q_bf16_multi: per expert bit-identical to that GEMM on the expert's rows.
+extern "C" int mrs_moe_gemm_q_bf16(const void *w, int ggml_type, int N, int K, int num_experts, const void *x_slabs, int x_rows, const int32_t *bounds,
+                                   const int32_t *sorted, int topk, int gather, const float *route_w, float *out, int ldo, int routes, void *stream) {
+  if (!w || !x_slabs || !bounds || !sorted || !out || N <= 0 || num_experts <= 0 || topk <= 0 || x_rows <= 0) return -1;
+  if (routes <= 0) return 0;
+  if (K <= 0 || K % 64 || ((ggml_type == T_Q4_K || ggml_type == T_Q5_K || ggml_type == T_Q6_K) && K % 256)) return -1;
+  GemmBArgs a{};
+  a.nseg = 1; a.w[0] = (const uint8_t *)w; a.out[0] = out; a.N[0] = N; a.ldo[0] = ldo; a.tile0[0] = 0;
+  a.x = (const uint16_t *)x_slabs; a.M = routes; a.K = K; a.splits = 1; a.tn = HN;
+  a.bounds = bounds; a.sorted = sorted; a.route_w = route_w; a.topk = topk; a.gather = gather; a.xrows = x_rows;
+  const dim3 grid((N + HN - 1) / HN, (routes + HM - 1) / HM, num_experts);
+  constexpr size_t lds = 2 * (HM + HN) * HK * 2;
+  auto go = [&](auto kern, size_t row_bytes) {
+    a.row_bytes = row_bytes; a.expert_stride = (size_t)N * row_bytes;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    hipLaunchKernelGGL(kern, grid, dim3(HT), lds, (hipStream_t)stream, a);
+    return 0;
+  };
+  switch (ggml_type) {
+  case T_Q4_K: return go(gemm_qb_kernel<T_Q4_K, 1, true>, (size_t)(K / 256) * 144);
+  case T_Q5_K: return go(gemm_qb_kernel<T_Q5_K, 1, true>, (size_t)(K / 256) * 176);
+  case T_Q6_K: return go(gemm_qb_kernel<T_Q6_K, 1, true>, (size_t)(K / 256) * 210);
+  case T_Q8_0: return go(gemm_qb_kernel<T_Q8_0, 1, true>, (size_t)(K / 32) * 34);
+  default: return -1;
+  }
+}
 extern "C" void mrs_gemm_set_variant(int v) { mrs::gemm_variant() = v; }
 extern "C" size_t mrs_gemm_q_bf16_workspace_bytes(int M) { return (size_t)M * 65536 * 4 / (size_t)((M + HM - 1) / HM) + 65536; }
 extern "C" int mrs_gemm_q_bf16_multi(int nseg, const void *const *w, const int *N, float *const *out, const int *ldo, int ggml_type, int K,

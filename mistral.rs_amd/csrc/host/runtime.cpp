@@ -537,6 +537,7 @@ class Llama {
       b += align(t * (pad_to((int)d, MATRIX_ROW_PADDING) / 32) * 36);                // Q8_1 rows of the normed hidden states
       b += align(r * (pad_to((int)ff, MATRIX_ROW_PADDING) / 32) * 36);               // Q8_1 rows of the routes' activations
       b += align(t * d * 4);                                                         // sum of the weighted expert outputs
+      if (T > prefill_big_min()) b += align(t * d * 2) + align(r * ff * 2);         // bf16 slabs of the normed tokens and of the routes' activations
     }
     return b + 4096;
   }
@@ -545,7 +546,7 @@ class Llama {
   // router top-k on the device, stable dispatch by expert, grouped gate / up GEMMs over the expert-sorted routes (every expert's weights are
   // read once per 8 of ITS routes instead of once per token), SiLU * up, grouped down GEMM that scales by the routing weight and sums the
   // top-k routes of a token with f32 atomics into a zeroed buffer (top-k = 2: order-independent), residual add.  No host sync.
-  struct MoePrefillBufs { int32_t *ids, *sorted, *bounds, *counts, *cursors; float *w, *g, *u, *act, *sum; void *y_in, *y_act; };
+  struct MoePrefillBufs { int32_t *ids, *sorted, *bounds, *counts, *cursors; float *w, *g, *u, *act, *sum; void *y_in, *y_act; void *xb, *yb; };  // xb / yb: bf16 slabs of the normed tokens / of the routes' activations (matrix-core route)
   typedef void (*moe_grouped_fn)(const void *, const void *, const int32_t *, const int32_t *, const float *, float *, int, int, int, int, int, int, void *);
   static moe_grouped_fn grouped_gemm_for(int dtype) {
     const DTypeInfo *ti = type_info(dtype);
@@ -564,6 +565,19 @@ class Llama {
     mrs_rms_norm_f32(h, bl.post_attention_layernorm, xn, T, d, cfg.rms_eps, (int64_t)(intptr_t)s);
     if (mrs_moe_router_topk(xn, bl.router, T, E, d, tk, 1, m.ids, m.w, nullptr, s)) return fail("moe router refused (experts %d, top-k %d)", E, tk);
     launch_moe_dispatch(m.ids, m.bounds, m.sorted, nullptr, routes, E, tk, m.counts, m.cursors, s);
+    // long prompts: the grouped GEMMs on the matrix cores (block dequant -> bf16 MFMA, the dense prompt GEMM's arithmetic) over the same dispatch
+    // tables -- every expert's weights are decoded once per 256 of ITS routes.  MRS_MOE_PREFILL_MFMA=0 keeps the int8-dot grouped GEMV route.
+    static const bool mfma_on = [] { const char *e = getenv("MRS_MOE_PREFILL_MFMA"); return !e || atoi(e) != 0; }();
+    if (mfma_on && m.xb && m.yb && d % 64 == 0 && ff % 64 == 0 && bl.up_exps.dtype == bl.gate_exps.dtype) {
+      int rc = mrs_convert_f32_bf16_slabs(xn, d, T, d, m.xb, s);
+      if (!rc) rc = mrs_moe_gemm_q_bf16(bl.gate_exps.data, bl.gate_exps.dtype, ff, d, E, m.xb, T, m.bounds, m.sorted, tk, 1, nullptr, m.g, ff, routes, s);
+      if (!rc) rc = mrs_moe_gemm_q_bf16(bl.up_exps.data, bl.up_exps.dtype, ff, d, E, m.xb, T, m.bounds, m.sorted, tk, 1, nullptr, m.u, ff, routes, s);
+      if (!rc) rc = mrs_glu_bf16_slabs(m.g, m.u, ff, routes, ff, 0, m.yb, s);
+      if (!rc && hipMemsetAsync(m.sum, 0, (size_t)T * d * 4, s) != hipSuccess) return fail("prefill: hipMemsetAsync failed");
+      if (!rc) rc = mrs_moe_gemm_q_bf16(bl.down_exps.data, bl.down_exps.dtype, d, ff, E, m.yb, routes, m.bounds, m.sorted, tk, 0, m.w, m.sum, d, routes, s);
+      if (!rc) return mrs_vec_add_f32(h, m.sum, (size_t)T * d, s) ? fail("prefill: residual add failed") : 0;
+      if (rc != -1) return fail("prefill: grouped MoE GEMM on the matrix cores failed (%d)", rc);  // -1: a dtype outside that kernel -> the route below
+    }
     launch_mmvq_gguf_quantize_q8_1_f32(xn, m.y_in, d, kp_d, T, s);
     gate_up(bl.gate_exps.data, m.y_in, m.bounds, m.sorted, nullptr, m.g, ff, d, kp_d, E, tk, 1, s);  // input_dim1 = 1: the token's row; out[sorted position]
     gate_up(bl.up_exps.data, m.y_in, m.bounds, m.sorted, nullptr, m.u, ff, d, kp_d, E, tk, 1, s);
@@ -595,6 +609,7 @@ class Llama {
       moe.y_in = take(t * (pad_to(d, MATRIX_ROW_PADDING) / 32) * 36);
       moe.y_act = take(r * (pad_to(ff, MATRIX_ROW_PADDING) / 32) * 36);
       moe.sum = (float *)take(t * d * 4);
+      if (T > prefill_big_min()) { moe.xb = take(t * d * 2); moe.yb = take(r * ff * 2); }
     }
     const int64_t st = (int64_t)(intptr_t)s;
     // T > 128: the 256-row-tile kernel over bf16 activations (converted once per GEMM group), split-K partials in `part`

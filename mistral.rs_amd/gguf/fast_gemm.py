@@ -112,3 +112,25 @@ def glu_slabs(g: torch.Tensor, u: torch.Tensor, activation: int = 0) -> torch.Te
     if fn(g.data_ptr(), u.data_ptr(), g.stride(0), m, n, int(activation), y.data_ptr(), torch.cuda.current_stream().cuda_stream):
         raise ValueError("fast_gemm.glu_slabs: N must be a multiple of 64 and the row stride a multiple of 4")
     return y
+
+
+def moe_grouped_bf16(w: QTensor, num_experts: int, slabs: torch.Tensor, bounds: torch.Tensor, sorted_ids: torch.Tensor, topk: int, gather: bool,
+                     out: torch.Tensor, route_w: torch.Tensor | None = None) -> torch.Tensor:
+    """Grouped MoE GEMM of a prompt on the matrix cores (mrs_moe_gemm_q_bf16): w = experts stacked along the rows [E * N, K]; slabs = bf16 slabs of the
+    tokens (gather: row of sorted position pos is token sorted_ids[pos] // topk) or of the routes in sorted order; bounds / sorted_ids = launch_moe_dispatch
+    tables (int32).  route_w None: out[pos] = W_e . x[row] (f32 [routes, N]); else out[token] += route_w[flat] * (W_e . x[pos]) with f32 atomics."""
+    if not supports(w.dtype):
+        raise ValueError(f"fast_gemm: unsupported quant dtype {w.dtype!r}")
+    rows, k = w.shape
+    if rows % num_experts or slabs.dtype != torch.bfloat16 or slabs.dim() != 3 or slabs.shape[0] * 64 != k or not slabs.is_contiguous():
+        raise ValueError("fast_gemm.moe_grouped_bf16: stacked experts [E * N, K] and bf16 slabs [K / 64, rows, 64]")
+    if bounds.dtype != torch.int32 or sorted_ids.dtype != torch.int32 or bounds.numel() != num_experts + 1 or out.dtype != torch.float32 or out.stride(-1) != 1:
+        raise ValueError("fast_gemm.moe_grouped_bf16: int32 dispatch tables and an f32 output")
+    n = rows // num_experts
+    fn = _lib.sym("ext", "mrs_moe_gemm_q_bf16", [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                                 C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p], C.c_int)
+    rc = fn(w.data.data_ptr(), w.dtype.id, n, k, num_experts, slabs.data_ptr(), slabs.shape[1], bounds.data_ptr(), sorted_ids.data_ptr(), topk, int(gather),
+            route_w.data_ptr() if route_w is not None else None, out.data_ptr(), out.stride(0), sorted_ids.numel(), torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        raise ValueError(f"fast_gemm.moe_grouped_bf16: unsupported shape K={k} for {w.dtype.name}")
+    return out

@@ -102,6 +102,56 @@ def test_wave_specialised_gemm_equals_ping_pong_kernel(oracle, dev, tname, m, n,
     assert torch.equal(old, new)
 
 
+@pytest.mark.parametrize("tname", ["Q4_K", "Q6_K", "Q8_0"])
+@pytest.mark.parametrize("E,tokens,topk,n,k", [(4, 70, 2, 200, 512), (3, 300, 2, 128, 1024), (8, 9, 3, 130, 256)])
+def test_moe_grouped_gemm_on_matrix_cores(oracle, dev, tname, E, tokens, topk, n, k):
+    """mrs_moe_gemm_q_bf16 (grouped MoE GEMM of a prompt, dispatch tables of launch_moe_dispatch): per expert bit-identical to the dense bf16 MFMA
+    GEMM on that expert's gathered rows; the down form (rows in sorted order, routing weights, f32 atomics into a zeroed buffer) == the sum of the
+    weighted per-route results (top-k 2: order-free; top-k 3: f32 order tolerance).  Includes an expert without routes and ragged row tiles."""
+    import ctypes as C
+    import torch
+    from mistralrs_amd import _lib
+    from mistralrs_amd.gguf import GgmlDType, QTensor, fast_gemm
+    t = getattr(oracle, tname)
+    rng = np.random.default_rng(E + tokens + n)
+    w = np.concatenate([oracle.random_blocks(t, n, k, seed=11 + e + n, d_scale=0.02) for e in range(E)], axis=0)
+    wt = QTensor.from_numpy(GgmlDType.from_id(t), (E * n, k), w, dev)
+    ids = np.stack([rng.permutation(E - 1)[:topk] if E > topk else rng.permutation(E)[:topk] for _ in range(tokens)]).astype(np.int32)  # expert E - 1 stays empty when E > topk
+    routes = tokens * topk
+    idt = torch.from_numpy(ids.reshape(-1)).to(dev)
+    bounds, sorted_ids = torch.zeros(E + 1, dtype=torch.int32, device=dev), torch.zeros(routes, dtype=torch.int32, device=dev)
+    counts, cursors = torch.zeros(E, dtype=torch.int32, device=dev), torch.zeros(E, dtype=torch.int32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.sym("quant", "launch_moe_dispatch", [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p] * 3)(idt.data_ptr(), bounds.data_ptr(), sorted_ids.data_ptr(), None, routes, E, topk,
+                                                                                                   counts.data_ptr(), cursors.data_ptr(), st)
+    x = torch.from_numpy((rng.standard_normal((tokens, k)) * rng.uniform(0.2, 3.0, (tokens, 1))).astype(np.float32)).to(dev)
+    xs = fast_gemm.to_slabs(x)
+    out = torch.full((routes, n), float("nan"), device=dev)
+    fast_gemm.moe_grouped_bf16(wt, E, xs, bounds, sorted_ids, topk, True, out)
+    b, so = bounds.cpu().numpy(), sorted_ids.cpu().numpy()
+    assert b[-1] == routes
+    per_route = torch.empty(routes, n, device=dev)  # by flat route index
+    for e in range(E):
+        pos = np.arange(b[e], b[e + 1])
+        if len(pos) == 0:
+            continue
+        we = QTensor.from_numpy(GgmlDType.from_id(t), (n, k), w[e * n:(e + 1) * n], dev)
+        rows = torch.from_numpy(so[pos] // topk).to(dev)
+        want = fast_gemm.plain_bf16(we, x[rows].contiguous(), split_k=False)
+        assert torch.equal(out[torch.from_numpy(pos).to(dev)], want), e
+        per_route[torch.from_numpy(so[pos]).to(dev).long()] = want
+    # down form: the routes' activations in sorted order, scaled by the routing weights, summed per token
+    rw = torch.from_numpy(rng.uniform(0.1, 0.9, routes).astype(np.float32)).to(dev)
+    xr = x[torch.from_numpy(so // topk).to(dev).long()].contiguous()  # row pos = the token of sorted position pos
+    acc = torch.zeros(tokens, n, device=dev)
+    fast_gemm.moe_grouped_bf16(wt, E, fast_gemm.to_slabs(xr), bounds, sorted_ids, topk, False, acc, route_w=rw)
+    ref = (per_route * rw[:, None]).reshape(tokens, topk, n)
+    if topk == 2:
+        assert torch.equal(acc, ref[:, 0] + ref[:, 1])
+    else:
+        assert float((acc - ref.sum(1)).abs().max()) <= 1e-5 * float(ref.abs().sum(1).max())
+
+
 def test_slab_producers(dev):
     """to_slabs is the layout [K/64][M][64] of the bf16-rounded matrix; the fused producers equal the unfused op + to_slabs bit for bit."""
     import torch
