@@ -382,7 +382,7 @@ class Llama {
         // SparseMoeBlock::forward (models/mixtral.rs:280-304): router on the normed hidden state, then per token the top-k experts'
         // fused gate/up (+SiLU*up -> Q8_1) and down GEMVs, accumulated into h with the renormalised routing weights.  Expert ids and
         // weights stay on the device (the kernels read them), so the step is graph-capturable.
-        if (cfg.world_size > 1) return fail("tensor-parallel MoE is not supported yet");
+        if (cfg.world_size > 1) return fail("tensor-parallel MoE runs on the decode engine (decode_engine / use_fused = 2), not on the round-1 fused kernels");
         const int E = cfg.num_experts, tk = cfg.num_experts_per_tok;
         const size_t g_stride = bl.gate_exps.nbytes() / E, d_stride = bl.down_exps.nbytes() / E;
         const size_t y_row = (size_t)stride_f * 36;
@@ -491,7 +491,8 @@ class Llama {
       if (cfg.num_experts > 0) {
         // SparseMoeBlock::forward (models/mixtral.rs:280-304): router on the normed hidden state; per token the top-k experts' gate/up then down,
         // accumulated into h with the renormalised routing weights; expert ids / weights stay on the device
-        if (cfg.world_size > 1) return fail("tensor-parallel MoE is not supported yet");
+        // TP (moe/experts/mod.rs:332-339): every expert is sharded on the ffn dimension like a dense FFN; h <- h / world + sum of the local experts' partial
+        // outputs, then ONE all-reduce per MoE block (the router is replicated: every rank picks the same experts)
         const int E = cfg.num_experts, tk = cfg.num_experts_per_tok;
         mrs_rms_norm_f32(ws.h, bl.post_attention_layernorm, ws.xn, b, d, cfg.rms_eps, (int64_t)(intptr_t)s);
         if (mrs_moe_router_topk(ws.xn, bl.router, b, E, d, tk, 1, ws.moe_ids, ws.moe_w, nullptr, s)) return fail("moe router refused (experts %d, top-k %d)", E, tk);
@@ -502,9 +503,10 @@ class Llama {
                                 ws.moe_act + (size_t)sl * ff, ff, 1, s))
               return fail("moe gate/up refused");
           for (int sl = 0; sl < tk; ++sl)
-            if (mrs_dec_proj(&bl.ddown_exps, d, ws.moe_ids + t * tk + sl, ws.moe_act + (size_t)sl * ff, ff, nullptr, 0.f, ht, d, 1, 1.0f, ws.moe_w + t * tk + sl, 1, s))
+            if (mrs_dec_proj(&bl.ddown_exps, d, ws.moe_ids + t * tk + sl, ws.moe_act + (size_t)sl * ff, ff, nullptr, 0.f, ht, d, 1, sl == 0 ? rs : 1.0f, ws.moe_w + t * tk + sl, 1, s))
               return fail("moe down refused");
         }
+        if (all_reduce(ws.h, (size_t)b * d, s)) return fail("moe all-reduce failed: %s", g_last_error.c_str());
         continue;
       }
       if (mrs_dec_gate_up(&bl.dgate, &bl.dup, ff, nullptr, ws.h, d, bl.post_attention_layernorm, cfg.rms_eps, 0, ws.act, ff, b, s)) return fail("mrs_dec_gate_up refused");
@@ -559,7 +561,6 @@ class Llama {
   int moe_ffn_prefill(const Block &bl, float *h, float *xn, int T, const MoePrefillBufs &m, hipStream_t s) const {
     const int d = cfg.hidden_size, ff = cfg.intermediate_size, E = cfg.num_experts, tk = cfg.num_experts_per_tok, routes = T * tk;
     const int kp_d = pad_to(d, MATRIX_ROW_PADDING), kp_ff = pad_to(ff, MATRIX_ROW_PADDING);
-    if (cfg.world_size > 1) return fail("tensor-parallel MoE is not supported yet");
     const moe_grouped_fn gate_up = grouped_gemm_for(bl.gate_exps.dtype), down = grouped_gemm_for(bl.down_exps.dtype);
     if (!gate_up || !down || bl.up_exps.dtype != bl.gate_exps.dtype) return fail("prefill: no grouped MoE GEMM for expert dtypes %d / %d / %d", bl.gate_exps.dtype, bl.up_exps.dtype, bl.down_exps.dtype);
     mrs_rms_norm_f32(h, bl.post_attention_layernorm, xn, T, d, cfg.rms_eps, (int64_t)(intptr_t)s);
@@ -575,6 +576,7 @@ class Llama {
       if (!rc) rc = mrs_glu_bf16_slabs(m.g, m.u, ff, routes, ff, 0, m.yb, s);
       if (!rc && hipMemsetAsync(m.sum, 0, (size_t)T * d * 4, s) != hipSuccess) return fail("prefill: hipMemsetAsync failed");
       if (!rc) rc = mrs_moe_gemm_q_bf16(bl.down_exps.data, bl.down_exps.dtype, d, ff, E, m.yb, routes, m.bounds, m.sorted, tk, 0, m.w, m.sum, d, routes, s);
+      if (!rc && all_reduce(m.sum, (size_t)T * d, s)) return fail("prefill: moe all-reduce failed: %s", g_last_error.c_str());  // TP: experts sharded on ffn
       if (!rc) return mrs_vec_add_f32(h, m.sum, (size_t)T * d, s) ? fail("prefill: residual add failed") : 0;
       if (rc != -1) return fail("prefill: grouped MoE GEMM on the matrix cores failed (%d)", rc);  // -1: a dtype outside that kernel -> the route below
     }
@@ -585,6 +587,7 @@ class Llama {
     launch_mmvq_gguf_quantize_q8_1_f32(m.act, m.y_act, ff, kp_ff, routes, s);
     if (hipMemsetAsync(m.sum, 0, (size_t)T * d * 4, s) != hipSuccess) return fail("prefill: hipMemsetAsync failed");
     down(bl.down_exps.data, m.y_act, m.bounds, m.sorted, m.w, m.sum, d, ff, kp_ff, E, tk, 0, s);     // input_dim1 = 0: rows already in sorted order
+    if (all_reduce(m.sum, (size_t)T * d, s)) return fail("prefill: moe all-reduce failed: %s", g_last_error.c_str());
     return mrs_vec_add_f32(h, m.sum, (size_t)T * d, s) ? fail("prefill: residual add failed") : 0;
   }
   int prefill(const mrs_llama_prefill_args &pa, int T, hipStream_t s) const {

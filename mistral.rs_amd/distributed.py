@@ -101,17 +101,33 @@ def shard_qtensor(w: QTensor, shard: Shard) -> QTensor:
     raise ValueError("quantized weights shard along dim 0 or 1")
 
 
+def shard_stacked_experts(w: QTensor, num_experts: int, shard: Shard) -> QTensor:
+    """Shard of experts stacked along the row axis [E * n, k] (Mixtral `ffn_{gate,up,down}_exps`): every expert is cut like a dense FFN matrix
+    (moe/experts/mod.rs:332-339: experts sharded on the ffn dimension, one all-reduce per MoE block) -- dim 0: rows [lo, hi) of EACH expert;
+    dim 1: the same column blocks of every row."""
+    rows, k = w.shape
+    if rows % num_experts:
+        raise ValueError(f"stacked experts: {rows} rows are not a multiple of {num_experts} experts")
+    if shard.dim == 1:
+        return shard_qtensor(w, shard)
+    n = rows // num_experts
+    rb = w.dtype.row_bytes(k)
+    lo, hi = shard.bounds(n)
+    data = w.data.view(num_experts, n, rb)[:, lo:hi].contiguous()
+    return QTensor(w.dtype, (num_experts * (hi - lo), k), data.view(-1))
+
+
 def llama_tensor_shard(name: str, cfg_total: dict, rank: int, world_size: int) -> Shard | None:
     """Placement of a GGUF tensor under TP (models/llama.rs:320-470): q/k/v/gate/up column-parallel (dim 0), attn_output /
     ffn_down row-parallel (dim 1), embeddings / norms / lm_head replicated (None)."""
     if world_size == 1:
         return None
     leaf = name.split(".")[-2] if name.startswith("blk.") else name
-    if leaf in ("attn_q", "ffn_gate", "ffn_up"):
+    if leaf in ("attn_q", "ffn_gate", "ffn_up", "ffn_gate_exps", "ffn_up_exps"):  # stacked experts: per expert (shard_stacked_experts)
         return Shard(0, rank, world_size)
     if leaf in ("attn_k", "attn_v"):
         return compute_kv_shard(cfg_total["num_kv_heads"], cfg_total["head_dim"], rank, world_size)
-    if leaf in ("attn_output", "ffn_down"):
+    if leaf in ("attn_output", "ffn_down", "ffn_down_exps"):
         return Shard(1, rank, world_size)
     return None
 

@@ -39,6 +39,25 @@ def test_kv_shard_rules():
         D.validate_tp_kv_heads(0, 2)
 
 
+def test_shard_stacked_experts(oracle):
+    from mistralrs_amd import distributed as D
+    """ffn_{gate,up}_exps: rows [lo, hi) of EACH expert; ffn_down_exps: the same column blocks of every row."""
+    import torch
+    from mistralrs_amd.gguf import GgmlDType, QTensor
+    E, n, k = 3, 8, 512
+    packed = np.concatenate([oracle.random_blocks(oracle.Q4_K, n, k, seed=e) for e in range(E)], axis=0)
+    qt = QTensor.from_numpy(GgmlDType.from_id(oracle.Q4_K), (E * n, k), packed, torch.device("cpu"))
+    rb = packed.shape[1]
+    up = D.shard_stacked_experts(qt, E, D.Shard(0, 1, 2))
+    assert up.shape == (E * n // 2, k)
+    np.testing.assert_array_equal(up.data.view(E, n // 2, rb).numpy(), packed.reshape(E, n, rb)[:, n // 2:])
+    dn = D.shard_stacked_experts(qt, E, D.Shard(1, 0, 2))
+    assert dn.shape == (E * n, k // 2)
+    np.testing.assert_array_equal(dn.data.view(E * n, rb // 2).numpy(), packed[:, : rb // 2])
+    assert D.llama_tensor_shard("blk.0.ffn_gate_exps.weight", {}, 1, 2) == D.Shard(0, 1, 2) and D.llama_tensor_shard("blk.0.ffn_down_exps.weight", {}, 1, 2) == D.Shard(1, 1, 2)
+    assert D.llama_tensor_shard("blk.0.ffn_gate_inp.weight", {}, 1, 2) is None  # the router is replicated
+
+
 def test_shard_qtensor_blocks(oracle):
     import torch
     import mistralrs_amd  # noqa: F401
@@ -125,7 +144,7 @@ def test_tensor_parallel_block_world2_gloo(oracle):
     assert err <= 2e-5 * scale, (err, scale)
 
 
-def _tp_runner_worker(rank, world, port, q):
+def _tp_runner_worker(rank, world, port, q, experts=0):
     """One tensor-parallel rank of the C++ runner on the host emulation: sharded weights, local head counts, fused decode kernels with the scaled
     residual + ONE all-reduce per row-parallel projection, MFMA prefill with its all-reduces -- the collective is gloo instead of RCCL."""
     sys.path.insert(0, ROOT)
@@ -158,8 +177,9 @@ def _tp_runner_worker(rank, world, port, q):
 
     heads, kvh, hd, hidden, ff, vocab = 4, 2, 128, 512, 1024, 256
     types = dict(embd=O.Q4_K, q=O.Q4_K, k=O.Q4_K, v=O.Q6_K, o=O.Q4_K, gate=O.Q4_K, up=O.Q4_K, down=O.Q6_K, output=O.Q6_K)
+    moe = dict(num_experts=experts, num_experts_per_tok=2, decode_engine=True) if experts else {}
     full = LlamaConfig(hidden_size=hidden, intermediate_size=ff, num_layers=2, num_heads=heads, num_kv_heads=kvh, vocab_size=vocab, head_dim=hd,
-                       rope_theta=10000.0, max_position_embeddings=256, max_batch=2, max_context_len=64)
+                       rope_theta=10000.0, max_position_embeddings=256, max_batch=2, max_context_len=64, **moe)
     w = llama_ref.synth_weights(full, types, seed=3)  # the same full model on every rank
     dev = torch.device("cpu")
 
@@ -171,14 +191,18 @@ def _tp_runner_worker(rank, world, port, q):
                 dt = GgmlDType.from_id(val[0])
                 qt = QTensor.from_numpy(dt, (val[1].shape[0], val[1].shape[1] // dt.type_size * dt.block_size), val[1], dev)
                 sh = D.llama_tensor_shard(name, total, r, ws)
-                m.set_tensor(name, D.shard_qtensor(qt, sh) if sh is not None else qt)
+                if sh is not None and "_exps" in name:
+                    qt = D.shard_stacked_experts(qt, experts, sh)  # every expert cut like a dense FFN matrix
+                elif sh is not None:
+                    qt = D.shard_qtensor(qt, sh)
+                m.set_tensor(name, qt)
             else:
                 m.set_tensor(name, torch.from_numpy(val))
         return m
 
     lh, lkv, lff = D.local_dims(heads, kvh, ff, world)
     tp_cfg = LlamaConfig(hidden_size=hidden, intermediate_size=lff, num_layers=2, num_heads=lh, num_kv_heads=lkv, vocab_size=vocab, head_dim=hd,
-                         rope_theta=10000.0, max_position_embeddings=256, max_batch=2, max_context_len=64, tp_world_size=world, tp_rank=rank)
+                         rope_theta=10000.0, max_position_embeddings=256, max_batch=2, max_context_len=64, tp_world_size=world, tp_rank=rank, **moe)
     mt = build(tp_cfg, rank, world)
     mt.set_comm(Comm())
     toks = [(1000 + i) % vocab for i in range(4)]
@@ -227,6 +251,25 @@ def test_tensor_parallel_runner_world2_gloo_on_host_emulation(oracle):
     assert same, "ranks disagree on the logits"
     assert max(rel) <= 3e-2, rel
     assert np.mean(np.array(rel) <= 1e-3) >= 0.6, rel
+
+
+def test_tensor_parallel_moe_runner_world2_gloo_on_host_emulation(oracle):
+    """Mixtral-style sparse MoE under TP = 2 (BASELINE configs[4]; moe/experts/mod.rs:332-339): every expert sharded on the ffn dimension, replicated
+    router, ONE all-reduce per MoE block -- decode through the decode engine (scaled residual on the first expert's accumulate) and a 20-token prompt
+    through the matrix-core grouped GEMMs (all-reduce of the weighted expert sums) against the unsharded runner."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_tp_runner_worker, args=(r, 2, port, q, 4)) for r in range(2)]
+    for p in procs:
+        p.start()
+    same, rel = q.get(timeout=1500)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert same, "ranks disagree on the logits"
+    assert max(rel) <= 3e-2, rel
 
 
 @pytest.mark.gpu
