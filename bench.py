@@ -157,6 +157,8 @@ def main():
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--prompt-len", type=int, default=512)
+    ap.add_argument("--batch", type=int, default=1, help="sequences decoded concurrently (1..8; BASELINE configs use 1): value = batch * steps / time")
+    ap.add_argument("--shard-shapes", type=int, default=0, help="single GPU, no collectives: run ONE rank's shard shapes of a TP = N model (shape smoke test for --gpus N)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--small", action="store_true", help="tiny config (smoke / CI), not the benchmark")
     ap.add_argument("--tp", action="store_true", help="(default for N > 1) ONE model sharded tensor-parallel over the N GPUs")
@@ -224,6 +226,10 @@ def main():
     else:
         cfg = LlamaConfig.llama3_8b(max_batch=8, max_context_len=max_ctx, max_position_embeddings=max(8192, max_ctx))
         name = "Llama-3-8B"
+    if a.shard_shapes > 1 and world == 1:
+        from mistralrs_amd import distributed as D
+        cfg.num_heads, cfg.num_kv_heads, cfg.intermediate_size = D.local_dims(cfg.num_heads, cfg.num_kv_heads, cfg.intermediate_size, a.shard_shapes)
+        name += f" (shapes of one rank of TP={a.shard_shapes}, no collectives)"
     tp = world > 1 and not a.replicas
     if tp:  # column / row parallel shards (mistralrs-quant/src/distributed/layers.rs): local heads, kv heads, ffn
         from mistralrs_amd import distributed as D
@@ -273,11 +279,14 @@ def main():
     first_tok = int(last.argmax())  # device -> host read-back of the first token: end of TTFT
     ttft = time.perf_counter() - t0
     prefill_flops = model.prefill_flops(a.prompt_len)
+    B = max(1, min(8, a.batch))
+    for sq in range(1, B):  # the other sequences of a batched run: same prompt into their own pages (untimed)
+        model.prefill(prompt, 0, seq=sq)
 
     # ---------------- decode: HIP graph of one step, replayed
-    model.set_state([first_tok], [a.prompt_len])
+    model.set_state([first_tok] * B, [a.prompt_len] * B)
     model.step_counter.zero_()
-    model.capture_decode_graph(1)
+    model.capture_decode_graph(B)
     for _ in range(a.warmup):
         model.replay()
     sync()
@@ -365,13 +374,13 @@ def main():
         ar["frac_of_step"] = round(used * 2 * cfg.num_layers / (1e6 * t_all / a.steps), 4)  # back-to-back launches; in the step they sit inside the captured graph
 
     avg_ctx = a.prompt_len + a.warmup + a.steps / 2
-    step_bytes = model.decode_bytes(1, int(avg_ctx))
-    tok_s = (1 if tp else world) * a.steps / t_all  # TP: the N GPUs decode ONE sequence
+    step_bytes = model.decode_bytes(B, int(avg_ctx))
+    tok_s = (1 if tp else world) * B * a.steps / t_all  # TP: the N GPUs decode ONE sequence (B sequences with --batch)
     out = {
         "metric": "decode_tokens_per_sec", "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(1e3 * t_all / a.steps, 4), "higher_is_better": True, "scaling": "strong" if tp else "weak",
         "vs_baseline": None, "dtype": ("q4_k/q6_k weights x q8_k activations" if a.quant == "q4_k_m" else "q8_0 weights x q8_0 activations") + " (int8 dot, f32 accumulate: the reference CPU path's arithmetic)", "data": "synthetic",
-        "config": {"workload": f"{name} " + ("GGUF Q4_K_M" if a.quant == "q4_k_m" else "ISQ Q8_0 (in situ from bf16, on the GPU)") + f", TP={world if tp else 1}, {a.prompt_len} prefill / {a.steps} decode, batch 1, paged KV bf16 (block 32)",
+        "config": {"workload": f"{name} " + ("GGUF Q4_K_M" if a.quant == "q4_k_m" else "ISQ Q8_0 (in situ from bf16, on the GPU)") + f", TP={world if tp else 1}, {a.prompt_len} prefill / {a.steps} decode, batch {B}, paged KV bf16 (block 32)",
                    "parallelism": "tp1" if world == 1 else (f"tp{world}" if tp else f"replicas x{world}")},
         "prefill_tokens_per_sec": round(a.prompt_len / ttft, 1), "ttft_ms": round(1e3 * ttft, 2),
         "prefill_roofline": {"bound": "mfma", "achieved": round(prefill_flops / ttft / 1e12, 1), "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s",

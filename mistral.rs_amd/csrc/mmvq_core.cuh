@@ -289,8 +289,12 @@ __device__ __forceinline__ void stream_rows(int first_row, int nrows, int row_st
   // wave already has in flight).  A load inside ANY conditional block (divergent or uniform) makes hipcc lose its
   // exact vmcnt bookkeeping and wait for everything outstanding, which would serialise the pipeline; callers pick
   // U so that 2*U does not exceed the steps a wave actually has (pick_unroll()).
+  // a wave without rows (the tail of the last workgroup) must not touch memory at all: its first_row lies past the tensor -- up to rows_per_wave rows,
+  // i.e. megabytes for lm_head-sized launches (found on the MI355X as a page fault with a [128256, 8192] Q6_K head whose allocation had 48 KiB of slack;
+  // smaller tensors sit inside larger allocator blocks and the stray read went unnoticed).  It still runs the prologue: that holds the workgroup barriers.
+  if (nrows <= 0) { (void)pro(); return; }
   const int total = nrows * ipr;
-  const int last_row = nrows > 0 ? nrows - 1 : 0;
+  const int last_row = nrows - 1;
   auto issue = [&](Unit(&b)[U][NM]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
