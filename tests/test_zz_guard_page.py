@@ -20,15 +20,22 @@ be = HostBackend()
 libc = C.CDLL(None, use_errno=True)
 libc.mprotect.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
 n, K, sym = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
-t = O.Q6_K if sym == "norm_proj" else O.Q4_K
+t = O.Q6_K if sym in ("norm_proj", "gemm_q6") else O.Q4_K
 w = O.random_blocks(t, n, K, seed=1, d_scale=0.02).reshape(-1)
 page = mmap.PAGESIZE
-size = (w.size + page - 1) // page * page + page
-mm = mmap.mmap(-1, size)
-base = C.addressof(C.c_char.from_buffer(mm))
-assert libc.mprotect(base + size - page, page, 0) == 0  # PROT_NONE guard page right behind the tensor
-dst = base + size - page - w.size
-C.memmove(dst, w.ctypes.data, w.size)
+keep = []
+def guarded(a):
+    """Copy of the bytes of `a` that ENDS at a PROT_NONE page (16-byte aligned start when the size allows it)."""
+    a = np.ascontiguousarray(a).reshape(-1).view(np.uint8)
+    size = (a.size + page - 1) // page * page + page
+    mm = mmap.mmap(-1, size)
+    keep.append(mm)
+    base = C.addressof(C.c_char.from_buffer(mm))
+    assert libc.mprotect(base + size - page, page, 0) == 0
+    p = base + size - page - a.size
+    C.memmove(p, a.ctypes.data, a.size)
+    return p
+dst = guarded(w)
 x = np.random.default_rng(0).standard_normal((1, K)).astype(np.float32)
 nw = np.ones(K, np.float32)
 xb, nb, ob = be.buf(x), be.buf(nw), be.buf(np.full((1, n), np.nan, np.float32))
@@ -36,6 +43,39 @@ if sym == "norm_proj":
     fn = be.sym("mrs_decode_norm_proj", [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_void_p], C.c_int)
     assert fn(dst, t, n, K, xb.ptr, nb.ptr, 1e-5, ob.ptr, n, 1, be.stream) == 0
     want = O.matmul_q8_1(t, w.reshape(n, -1), n, K, O.quantize_q8_1(O.rms_norm(x, nw, 1e-5)))
+elif sym in ("gemm", "gemm_q6"):
+    # prompt GEMM (both kernels behind mrs_gemm_q_bf16_multi): weights AND the bf16 activation slabs end at guard pages; ragged N and M tiles
+    import torch
+    M = 70
+    xm = np.random.default_rng(1).standard_normal((M, K)).astype(np.float32)
+    slabs = be.buf(np.zeros((K // 64, M, 64), np.uint16))
+    xmb = be.buf(xm)
+    assert be.sym("mrs_convert_f32_bf16_slabs", [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p], C.c_int)(xmb.ptr, K, M, K, slabs.ptr, be.stream) == 0
+    sp = guarded(slabs.numpy())
+    out = be.buf(np.full((M, n), np.nan, np.float32))
+    wp, np_, op, ld = (C.c_void_p * 1)(dst), (C.c_int * 1)(n), (C.c_void_p * 1)(out.ptr), (C.c_int * 1)(n)
+    fn = be.sym("mrs_gemm_q_bf16_multi", [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p], C.c_int)
+    assert fn(1, wp, np_, op, ld, t, K, sp, M, 0, None, 0, be.stream) == 0
+    from tests.util import round_through
+    want = round_through(xm, "bf16").astype(np.float64) @ round_through(O.dequantize(t, w.reshape(n, -1), K), "bf16").astype(np.float64).T
+    got = out.numpy()
+    assert np.isfinite(got).all() and np.abs(got - want).max() <= 1e-3 * np.abs(want).max()
+    print("guard page intact"); sys.exit(0)
+elif sym == "dec_proj":
+    # decode engine: the repacked planes end at the guard page (buffer loads: out-of-range lanes must stay out of range)
+    class Mat(C.Structure):
+        _fields_ = [("planes", C.c_void_p), ("type", C.c_int), ("n", C.c_longlong), ("k", C.c_longlong)]
+    nbytes = be.sym("mrs_dec_repack_bytes", [C.c_int, C.c_longlong, C.c_longlong], C.c_size_t)(t, n, K)
+    planes = be.buf(np.zeros(nbytes, np.uint8))
+    src = be.buf(w)
+    assert be.sym("mrs_dec_repack", [C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p], C.c_int)(src.ptr, t, n, K, planes.ptr, be.stream) == 0
+    m = Mat(guarded(planes.numpy()), t, n, K)
+    PROJ = [C.POINTER(Mat), C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p]
+    assert be.sym("mrs_dec_proj", PROJ, C.c_int)(C.byref(m), n, None, xb.ptr, K, None, 0.0, ob.ptr, n, 0, 1.0, None, 1, be.stream) == 0
+    want = O.matmul_cpu(t, w.reshape(n, -1), n, K, x)
+    got = ob.numpy()
+    assert np.isfinite(got).all() and np.abs(got - want).max() <= 1e-4 * np.abs(want).max()
+    print("guard page intact"); sys.exit(0)
 else:
     kp = O.pad512(K)
     y = be.buf(O.quantize_q8_1(x))
@@ -48,7 +88,9 @@ print("guard page intact")
 '''
 
 
-@pytest.mark.parametrize("n,k,sym,env", [(600, 512, "norm_proj", {"MRS_PROJ_WGS": "2"}), (129, 1024, "mmvq", {}), (2049, 256, "mmvq", {})])
+@pytest.mark.parametrize("n,k,sym,env", [(600, 512, "norm_proj", {"MRS_PROJ_WGS": "2"}), (129, 1024, "mmvq", {}), (2049, 256, "mmvq", {}),
+                                         (200, 512, "gemm", {"MRS_GEMM_VARIANT": "1"}), (200, 512, "gemm", {"MRS_GEMM_VARIANT": "0"}), (130, 256, "gemm_q6", {}),
+                                         (70, 512, "dec_proj", {}), (2049, 256, "dec_proj", {})])
 def test_row_less_waves_do_not_read_past_the_tensor(n, k, sym, env):
     r = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT}, str(n), str(k), sym], capture_output=True, text=True, timeout=600,
                        env={**os.environ, **env})
