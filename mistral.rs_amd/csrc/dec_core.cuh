@@ -196,7 +196,9 @@ __device__ __forceinline__ void quantize4(float4 v, int e, int qoff, bool in, in
   }
 }
 
-// Whole workgroup, ends with a barrier.  `red` = 8 floats of LDS scratch.  pre = act_issue() of column 0.
+// Whole workgroup, ends with a barrier.  `red` = NCOLS * NW floats of LDS scratch.  pre = act_issue() of column 0.
+// All columns' sums of squares go through ONE barrier (per column: the same per-thread / wave / workgroup summation order as a single-column call, so a
+// batched step stays bit-identical to single sequences), then every column is quantized: 2 barriers per launch instead of 2 per column.
 template <int NCOLS, bool SC1>
 __device__ __forceinline__ Act act_finish(char *smem, float *red, const ActPre &pre, const float *__restrict__ x, int ldx, const float *__restrict__ nw, float eps,
                                           int K, int mode) {
@@ -205,38 +207,48 @@ __device__ __forceinline__ Act act_finish(char *smem, float *red, const ActPre &
   float *d = (float *)(smem + (size_t)NCOLS * K);
   int *bs = (int *)(d + (size_t)NCOLS * (K / 32));
   const int nv = (K + ACT_STRIDE - 1) / ACT_STRIDE;  // float4 pieces per thread
-#pragma unroll 1
-  for (int c = 0; c < NCOLS; ++c) {
-    const float *xr = x + (size_t)c * ldx;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)xr, (short)0, K * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)(nw ? nw : xr), (short)0, nw ? K * 4 : 0, 0x00020000);
-    // pieces j < ACT_MAXV (ACT_MAXW) of column 0 come from the registers act_issue() filled: static indices only
-    auto xload = [&](int j) -> float4 { return as_f4(ld_act<SC1>(rx, (unsigned)tid * 16u + (unsigned)j * (unsigned)(ACT_STRIDE * 4))); };
-    auto wload = [&](int j) -> float4 { return as_f4(ld_act<false>(rw, (unsigned)tid * 16u + (unsigned)j * (unsigned)(ACT_STRIDE * 4))); };
-    float inv = 1.0f;
-    if (nw) {  // sum of squares: per-thread partials in element order, DPP wave sums, the 8 wave sums in wave order
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)(nw ? nw : x), (short)0, nw ? K * 4 : 0, 0x00020000);
+  auto wload = [&](int j) -> float4 { return as_f4(ld_act<false>(rw, (unsigned)tid * 16u + (unsigned)j * (unsigned)(ACT_STRIDE * 4))); };
+  auto col_rsrc = [&](int c) { return __builtin_amdgcn_make_buffer_rsrc((void *)(x + (size_t)c * ldx), (short)0, K * 4, 0x00020000); };
+  float inv[NCOLS];
+#pragma unroll
+  for (int c = 0; c < NCOLS; ++c) inv[c] = 1.0f;
+  if (nw) {  // sum of squares: per-thread partials in element order, DPP wave sums, the wave sums in wave order
+#pragma unroll
+    for (int c = 0; c < NCOLS; ++c) {
+      const __amdgpu_buffer_rsrc_t rx = col_rsrc(c);
+      auto xload = [&](int j) -> float4 { return as_f4(ld_act<SC1>(rx, (unsigned)tid * 16u + (unsigned)j * (unsigned)(ACT_STRIDE * 4))); };
       float ss = 0.f;
       auto sq = [&](float4 v4) { ss = fmaf(v4.x, v4.x, ss); ss = fmaf(v4.y, v4.y, ss); ss = fmaf(v4.z, v4.z, ss); ss = fmaf(v4.w, v4.w, ss); };
 #pragma unroll
       for (int j = 0; j < ACT_MAXV; ++j) if (j < nv) sq(c == 0 ? as_f4(pre.xv[j]) : xload(j));
       for (int j = ACT_MAXV; j < nv; ++j) sq(xload(j));
       ss = wave_sum_all(ss);
-      if (lane == 0) red[wave] = ss;
-      __syncthreads();
-      float tot = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
-      if constexpr (NW == 16) tot += ((red[8] + red[9]) + (red[10] + red[11])) + ((red[12] + red[13]) + (red[14] + red[15]));
-      inv = 1.0f / sqrtf(tot / (float)K + eps);
-      __syncthreads();  // red is reused by the next column
+      if (lane == 0) red[c * NW + wave] = ss;
     }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NCOLS; ++c) {
+      const float *r = red + c * NW;
+      float tot = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+      if constexpr (NW == 16) tot += ((r[8] + r[9]) + (r[10] + r[11])) + ((r[12] + r[13]) + (r[14] + r[15]));
+      inv[c] = 1.0f / sqrtf(tot / (float)K + eps);
+    }
+  }
+  // byte offset of the lane's 4 quants in the swizzled image: piece = e >> 4 = tid / 4 + 128 j, superblock = piece >> 4 = wave + 8 j, so the XOR
+  // mask m(superblock) depends on the wave only and the offset is a lane constant + 2048 j
+  const int qoff0 = (((tid >> 2) ^ sb_mask(wave)) << 4) | ((tid & 3) << 2);
+#pragma unroll
+  for (int c = 0; c < NCOLS; ++c) {
+    const __amdgpu_buffer_rsrc_t rx = col_rsrc(c);
+    auto xload = [&](int j) -> float4 { return as_f4(ld_act<SC1>(rx, (unsigned)tid * 16u + (unsigned)j * (unsigned)(ACT_STRIDE * 4))); };
     char *qc = q + (size_t)c * K;
     float *dc = d + (size_t)c * (K / 32);
     int *bsc = bs + (size_t)c * (K / 16);
-    // byte offset of the lane's 4 quants in the swizzled image: piece = e >> 4 = tid / 4 + 128 j, superblock = piece >> 4 = wave + 8 j, so the XOR
-    // mask m(superblock) depends on the wave only and the offset is a lane constant + 2048 j
-    const int qoff0 = (((tid >> 2) ^ sb_mask(wave)) << 4) | ((tid & 3) << 2);
+    const float ic = inv[c];
     auto one = [&](int j, float4 v, float4 w4) {  // uniform trip count: every lane takes part in the cross-lane steps
       const int e = tid * 4 + j * ACT_STRIDE;
-      if (nw) { v.x = v.x * inv * w4.x; v.y = v.y * inv * w4.y; v.z = v.z * inv * w4.z; v.w = v.w * inv * w4.w; }
+      if (nw) { v.x = v.x * ic * w4.x; v.y = v.y * ic * w4.y; v.z = v.z * ic * w4.z; v.w = v.w * ic * w4.w; }
       quantize4(v, e, qoff0 + j * ACT_STRIDE, e < K, mode, qc, dc, bsc);
     };
 #pragma unroll

@@ -223,7 +223,7 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
 template <int NCOLS, int EPI>
 __global__ void __launch_bounds__(NT) dec_gemv_kernel(const GemvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ float red[NW];
+  __shared__ float red[8 * NW];  // RMSNorm partials: [column][wave]
   gemv_phase<NCOLS, EPI>(a, smem, red);
 }
 
@@ -317,7 +317,7 @@ template <int TYPE> __device__ __forceinline__ void dequant_units(const uint8_t 
 template <int NCOLS>
 __global__ void __launch_bounds__(NT) dec_step_kernel(const StepArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ float red[NW];
+  __shared__ float red[8 * NW];  // RMSNorm partials: [column][wave]
   const int nwg = gridDim.x;
   for (int p = a.phase_begin; p < a.phase_end; ++p) {
     const GridSync sync{a.sync, (unsigned)(p - a.phase_begin) * (unsigned)nwg, p > a.phase_begin};
