@@ -21,7 +21,7 @@ libc = C.CDLL(None, use_errno=True)
 libc.mprotect.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
 n, K, sym = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
 t = O.Q6_K if sym in ("norm_proj", "gemm_q6") else O.Q4_K
-w = O.random_blocks(t, n, K, seed=1, d_scale=0.02).reshape(-1)
+w = O.random_blocks(t, n, K if sym != "hqq" else 256, seed=1, d_scale=0.02).reshape(-1)
 page = mmap.PAGESIZE
 keep = []
 def guarded(a):
@@ -61,6 +61,51 @@ elif sym in ("gemm", "gemm_q6"):
     got = out.numpy()
     assert np.isfinite(got).all() and np.abs(got - want).max() <= 1e-3 * np.abs(want).max()
     print("guard page intact"); sys.exit(0)
+elif sym == "mmq":
+    # prompt-sized drop-in launcher (launch_mmq_gguf_q4_k): weights and the block_q8_1_mmq activations end at guard pages
+    cols = 37
+    xm = np.random.default_rng(2).standard_normal((cols, K)).astype(np.float32)
+    y = O.quantize_q8_1_mmq(xm, O.mmq_layout(t))
+    yp = guarded(y)
+    D = be.buf(np.full((cols, n), 7.0, np.float32))
+    P, L, I = C.c_void_p, C.c_int64, C.c_int
+    fn = be.sym("launch_mmq_gguf_q4_k", [P, P, P, P] + [L] * 5 + [I, I, L, I, I, P])
+    fn(None, dst, yp, D.ptr, K, n, cols, K // 256, n, 0, 256, 160 << 10, 64, 0, be.stream)
+    want, mag = O.matmul_q8_1_mmq(t, w.reshape(n, -1), n, K, y)
+    got = D.numpy().astype(np.float64)
+    assert np.isfinite(got).all() and (np.abs(got - want) <= 1e-4 * (mag + 1e-30) + 1e-6).all()
+    print("guard page intact"); sys.exit(0)
+elif sym == "imoe":
+    # expert-indexed GEMV (launch_indexed_moe_forward_q4k_q8_1): the stacked experts end at the guard page, the last task picks the last expert
+    E, batch, topk = 3, 2, 2
+    we = np.concatenate([O.random_blocks(t, n, K, seed=5 + e, d_scale=0.02) for e in range(E)], axis=0)
+    wp = guarded(we)
+    idx = np.array([0, 2, 1, 2], dtype=np.uint32)
+    xm = np.random.default_rng(3).standard_normal((batch, K)).astype(np.float32)
+    y = O.quantize_q8_1(xm)
+    yb, ib = be.buf(y), be.buf(idx)
+    out = be.buf(np.full((batch * topk, n), np.nan, np.float32))
+    fn = be.sym("launch_indexed_moe_forward_q4k_q8_1", [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_void_p])
+    fn(wp, yb.ptr, ib.ptr, out.ptr, n, K, batch, topk, O.pad512(K), 1, be.stream)
+    got = out.numpy()
+    for task in range(batch * topk):
+        e = int(idx[task])
+        want = O.matmul_q8_1(t, we[e * n:(e + 1) * n], n, K, y[task // topk: task // topk + 1])
+        assert np.abs(got[task] - want[0]).max() <= 1e-4 * np.abs(want).max()
+    print("guard page intact"); sys.exit(0)
+elif sym == "hqq":
+    # fused HQQ GEMV: packed weights, scales and zeros end at guard pages
+    from oracle import hqq_oracle as H
+    wf = (np.random.default_rng(4).standard_normal((n, K)) * 0.05).astype(np.float32)
+    wq, scale, zero = H.quantize(wf, 4, 64)
+    inv, zr = scale.reshape(-1).astype(np.float32), zero.reshape(-1).astype(np.float32)
+    wd = H.dequantize(4, wq, inv, zr).reshape(-1)[: n * K].reshape(n, K)
+    fn = be.sym("mrs_hqq_gemv", [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p], C.c_int)
+    assert fn(4, 0, guarded(wq), guarded(inv), guarded(zr), None, xb.ptr, K, ob.ptr, n, n, K, 1, be.stream) == 0
+    want = x @ wd.T
+    got = ob.numpy()
+    assert np.isfinite(got).all() and np.abs(got - want).max() <= 1e-4 * np.abs(want).max()
+    print("guard page intact"); sys.exit(0)
 elif sym == "dec_proj":
     # decode engine: the repacked planes end at the guard page (buffer loads: out-of-range lanes must stay out of range)
     class Mat(C.Structure):
@@ -90,7 +135,8 @@ print("guard page intact")
 
 @pytest.mark.parametrize("n,k,sym,env", [(600, 512, "norm_proj", {"MRS_PROJ_WGS": "2"}), (129, 1024, "mmvq", {}), (2049, 256, "mmvq", {}),
                                          (200, 512, "gemm", {"MRS_GEMM_VARIANT": "1"}), (200, 512, "gemm", {"MRS_GEMM_VARIANT": "0"}), (130, 256, "gemm_q6", {}),
-                                         (70, 512, "dec_proj", {}), (2049, 256, "dec_proj", {})])
+                                         (70, 512, "dec_proj", {}), (2049, 256, "dec_proj", {}),
+                                         (70, 512, "mmq", {}), (129, 256, "mmq", {}), (50, 512, "imoe", {}), (128, 256, "hqq", {}), (64, 2064, "hqq", {})])
 def test_row_less_waves_do_not_read_past_the_tensor(n, k, sym, env):
     r = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT}, str(n), str(k), sym], capture_output=True, text=True, timeout=600,
                        env={**os.environ, **env})
