@@ -145,6 +145,9 @@ size_t mrs_gemm_q_bf16_workspace_bytes(int M);
  * Per expert bit-identical to mrs_gemm_q_bf16_multi on that expert's rows. */
 int mrs_moe_gemm_q_bf16(const void *w, int ggml_type, int N, int K, int num_experts, const void *x_slabs, int x_rows, const int32_t *bounds,
                         const int32_t *sorted, int topk, int gather, const float *route_w, float *out, int ldo, int routes, void *stream);
+/* Fused gate / up of a prompt: y = act(W_g x) * (W_u x) as bf16 slabs y[N/64][M][64] in ONE launch (role of fast_mmq::fused_glu, gguf/fast_mmq.rs:762-821);
+ * same bits as two mrs_gemm_q_bf16_multi launches + mrs_glu_bf16_slabs.  N % 64 == 0; y_slabs must not alias x_slabs. */
+int mrs_gemm_q_bf16_glu(const void *w_gate, const void *w_up, int ggml_type, int N, int K, const void *x_slabs, int M, int activation, void *y_slabs, void *stream);
 /* kernel behind mrs_gemm_q_bf16_multi: 1 = producer / consumer wave specialisation, 0 = every wave stages and multiplies (round 1), -1 = by weight type (default: Q4_K -> 1);
  * identical results, kept selectable for A/B measurements (also MRS_GEMM_VARIANT) */
 void mrs_gemm_set_variant(int variant);

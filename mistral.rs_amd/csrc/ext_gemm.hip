@@ -396,11 +396,15 @@ struct GemmBArgs {
   const float *route_w;            // down projection: out[token][n] += route_w[flat] * acc (f32 atomics); NULL: out[pos][n] = acc
   int topk, gather, xrows;         // gather: the A row of position pos is token sorted[pos] / topk (gate / up); else pos itself (down)
   size_t expert_stride;
+  // fused gate / up mode (GLU = true): w[0] = gate, w[1] = up ([N[0]][K] each); a 128-row B tile = 64 output columns: rows [0,32) gate cols 0-31, [32,64) up
+  // cols 0-31, [64,96) gate cols 32-63, [96,128) up cols 32-63, so a wave's two 32-column MFMA tiles are (gate, up) of the SAME columns and the epilogue
+  // writes act(gate) * up as bf16 slabs glu_out[N/64][M][64] (the down GEMM's activation layout) -- no f32 round trip, no GLU kernel
+  uint16_t *glu_out; int activation;
 };
 
 // NI = 128-column blocks per workgroup tile: 1 -> 256 x 128 (waves 4 x 2, 64 x 64 each), 2 -> 256 x 256 (waves 2 x 4, 128 x 64 each:
 // half the A traffic, LDS bytes and decode work per FLOP; needs >= ~200 column tiles of 256 to fill the chip without split-K).
-template <int TYPE, int NI, bool MOE = false>
+template <int TYPE, int NI, bool MOE = false, bool GLU = false>
 __global__ void __launch_bounds__(HT) gemm_qb_kernel(const GemmBArgs a) {
   constexpr int TN = HN * NI, MI = 2 * NI, PF = NI == 1 ? 2 : 1;  // PF: staging register sets (prefetch distance in k-steps)
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A 256 x 64 bf16 | B TN x 64 bf16] = 96 / 128 KiB
@@ -409,7 +413,7 @@ __global__ void __launch_bounds__(HT) gemm_qb_kernel(const GemmBArgs a) {
   if (a.nseg > 2 && (int)blockIdx.x >= a.tile0[2]) seg = 2;
   else if (a.nseg > 1 && (int)blockIdx.x >= a.tile0[1]) seg = 1;
   const int segN = a.N[seg];
-  const int m0 = blockIdx.y * HM, n0 = ((int)blockIdx.x - a.tile0[seg]) * TN;
+  const int m0 = blockIdx.y * HM, n0 = GLU ? (int)blockIdx.x * 64 : ((int)blockIdx.x - a.tile0[seg]) * TN;
   int cnt = a.M, pos0 = 0;  // valid rows of this row tile's matrix, its first sorted position
   const uint8_t *wbase = a.w[seg];
   if constexpr (MOE) {
@@ -423,7 +427,10 @@ __global__ void __launch_bounds__(HT) gemm_qb_kernel(const GemmBArgs a) {
   const int xc = tid & 7, xr0 = tid >> 3;    // A: 16-byte chunk, rows xr0 + 64 i
   const uint8_t *wrow[NI];
 #pragma unroll
-  for (int jn = 0; jn < NI; ++jn) wrow[jn] = wbase + (size_t)min(n0 + ar + 128 * jn, segN - 1) * a.row_bytes;
+  for (int jn = 0; jn < NI; ++jn) {
+    if constexpr (GLU) wrow[jn] = a.w[(ar >> 5) & 1] + (size_t)min(n0 + (ar >> 6) * 32 + (ar & 31), segN - 1) * a.row_bytes;
+    else wrow[jn] = wbase + (size_t)min(n0 + ar + 128 * jn, segN - 1) * a.row_bytes;
+  }
   const int nk_all = a.K / HK;
   const int kz = MOE ? 0 : (int)blockIdx.z;
   const int k_lo = (int)((long)nk_all * kz / a.splits), k_hi = (int)((long)nk_all * (kz + 1) / a.splits);
@@ -521,6 +528,18 @@ __global__ void __launch_bounds__(HT) gemm_qb_kernel(const GemmBArgs a) {
       __syncthreads();
     }
   }
+  if constexpr (GLU) {
+    const int n = n0 + (wn >> 6) * 32 + (lane & 31);
+    uint16_t *y = a.glu_out + (size_t)(n >> 6) * a.M * 64 + (n & 63);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < a.M && n < segN) y[(size_t)m * 64] = (uint16_t)(pack_bf16(glu_act(acc[i][0][r], a.activation) * acc[i][1][r], 0.f) & 0xffffu);
+      }
+    return;
+  }
   float *obase;
   int ldo, ncol0;
   if (a.splits > 1) { obase = a.partial + (size_t)blockIdx.z * a.M * a.ldp; ldo = a.ldp; ncol0 = (int)blockIdx.x * TN - n0; }
@@ -561,7 +580,7 @@ __global__ void __launch_bounds__(HT) gemm_qb_kernel(const GemmBArgs a) {
 #ifndef MRS_GEMM_ABLATE
 #define MRS_GEMM_ABLATE 0  // experiment builds only (scripts/exp/build_gemm_ablate.sh): 1 no decode arithmetic, 2 producers idle, 4 no MFMA, 8 no fragment reads, 16 no A copies
 #endif
-template <int TYPE>
+template <int TYPE, bool GLU = false>
 __global__ void __launch_bounds__(HT) gemm_qc_kernel(const GemmBArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A 256 x 64 bf16 | B 128 x 64 bf16] = 96 KiB
   const int tid = threadIdx.x, lane = tid & 63;
@@ -570,7 +589,7 @@ __global__ void __launch_bounds__(HT) gemm_qc_kernel(const GemmBArgs a) {
   if (a.nseg > 2 && (int)blockIdx.x >= a.tile0[2]) seg = 2;
   else if (a.nseg > 1 && (int)blockIdx.x >= a.tile0[1]) seg = 1;
   const int segN = a.N[seg];
-  const int m0 = blockIdx.y * HM, n0 = ((int)blockIdx.x - a.tile0[seg]) * HN;
+  const int m0 = blockIdx.y * HM, n0 = GLU ? (int)blockIdx.x * 64 : ((int)blockIdx.x - a.tile0[seg]) * HN;
   const int nk_all = a.K / HK;
   const int k_lo = (int)((long)nk_all * blockIdx.z / a.splits), k_hi = (int)((long)nk_all * (blockIdx.z + 1) / a.splits);
   const int nk = k_hi - k_lo;
@@ -584,7 +603,8 @@ __global__ void __launch_bounds__(HT) gemm_qc_kernel(const GemmBArgs a) {
     const int p = tid - 256;
     const int half = p >> 7, q7 = p & 127, ar = ((q7 & 63) << 1) | (q7 >> 6);
     const int xc = p & 7, xr0 = p >> 3;  // A: 16-byte chunk, rows xr0 + 32 i
-    const uint8_t *wrow = a.w[seg] + (size_t)min(n0 + ar, segN - 1) * a.row_bytes;
+    const uint8_t *wrow = GLU ? a.w[(ar >> 5) & 1] + (size_t)min(n0 + (ar >> 6) * 32 + (ar & 31), segN - 1) * a.row_bytes
+                              : a.w[seg] + (size_t)min(n0 + ar, segN - 1) * a.row_bytes;
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, (short)0, (int)((size_t)a.M * a.K * 2), 0x00020000);
     unsigned xoff[8];
@@ -706,6 +726,18 @@ __global__ void __launch_bounds__(HT) gemm_qc_kernel(const GemmBArgs a) {
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
     }
     __builtin_amdgcn_sched_group_barrier(0x008, 2, 1);
+  }
+  if constexpr (GLU) {
+    const int n = n0 + (wn >> 6) * 32 + (lane & 31);
+    uint16_t *y = a.glu_out + (size_t)(n >> 6) * a.M * 64 + (n & 63);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < a.M && n < segN) y[(size_t)m * 64] = (uint16_t)(pack_bf16(glu_act(acc[i][0][r], a.activation) * acc[i][1][r], 0.f) & 0xffffu);
+      }
+    return;
   }
   float *obase;
   int ldo, ncol0;
@@ -900,6 +932,35 @@ extern "C" int mrs_moe_gemm_q_bf16(const void *w, int ggml_type, int N, int K, i
   case T_Q5_K: return go(gemm_qb_kernel<T_Q5_K, 1, true>, (size_t)(K / 256) * 176);
   case T_Q6_K: return go(gemm_qb_kernel<T_Q6_K, 1, true>, (size_t)(K / 256) * 210);
   case T_Q8_0: return go(gemm_qb_kernel<T_Q8_0, 1, true>, (size_t)(K / 32) * 34);
+  default: return -1;
+  }
+}
+// Fused gate / up GEMM of a prompt: y = act(W_g x) * (W_u x) as bf16 slabs y[N/64][M][64] (the down GEMM's activation layout) -- the role of
+// fast_mmq::fused_glu / fused_ffn's first half (gguf/fast_mmq.rs:762-821).  Same MFMA arithmetic as two mrs_gemm_q_bf16_multi launches followed by
+// mrs_glu_bf16_slabs: identical bits.  y must not alias x_slabs.  N % 64 == 0.
+extern "C" int mrs_gemm_q_bf16_glu(const void *w_gate, const void *w_up, int ggml_type, int N, int K, const void *x_slabs, int M, int activation, void *y_slabs,
+                                   void *stream) {
+  if (!w_gate || !w_up || !x_slabs || !y_slabs || y_slabs == x_slabs || N <= 0 || N % 64) return -1;
+  if (M <= 0) return 0;
+  if (K <= 0 || K % 64 || ((ggml_type == T_Q4_K || ggml_type == T_Q5_K || ggml_type == T_Q6_K) && K % 256)) return -1;
+  GemmBArgs a{};
+  a.nseg = 1; a.w[0] = (const uint8_t *)w_gate; a.w[1] = (const uint8_t *)w_up; a.N[0] = N; a.tile0[0] = 0;
+  a.x = (const uint16_t *)x_slabs; a.M = M; a.K = K; a.splits = 1; a.tn = HN; a.glu_out = (uint16_t *)y_slabs; a.activation = activation;
+  const dim3 grid(N / 64, (M + HM - 1) / HM, 1);
+  constexpr size_t lds = 2 * (HM + HN) * HK * 2;
+  auto go = [&](auto kern, size_t row_bytes) {
+    a.row_bytes = row_bytes;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    hipLaunchKernelGGL(kern, grid, dim3(HT), lds, (hipStream_t)stream, a);
+    return 0;
+  };
+  const bool qc = gemm_variant() == 1 || (gemm_variant() < 0 && ggml_type == T_Q4_K);
+  switch (ggml_type) {
+  case T_Q4_K: return qc ? go(gemm_qc_kernel<T_Q4_K, true>, (size_t)(K / 256) * 144) : go(gemm_qb_kernel<T_Q4_K, 1, false, true>, (size_t)(K / 256) * 144);
+  case T_Q5_K: return qc ? go(gemm_qc_kernel<T_Q5_K, true>, (size_t)(K / 256) * 176) : go(gemm_qb_kernel<T_Q5_K, 1, false, true>, (size_t)(K / 256) * 176);
+  case T_Q6_K: return qc ? go(gemm_qc_kernel<T_Q6_K, true>, (size_t)(K / 256) * 210) : go(gemm_qb_kernel<T_Q6_K, 1, false, true>, (size_t)(K / 256) * 210);
+  case T_Q8_0: return qc ? go(gemm_qc_kernel<T_Q8_0, true>, (size_t)(K / 32) * 34) : go(gemm_qb_kernel<T_Q8_0, 1, false, true>, (size_t)(K / 32) * 34);
   default: return -1;
   }
 }

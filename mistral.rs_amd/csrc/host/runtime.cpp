@@ -531,7 +531,7 @@ class Llama {
     b += align(t * nkv * 4) * 2;      // k, v
     b += align(t * ff * 4) * 3;       // gate, up, act
     b += align((pad_to((int)d, MATRIX_ROW_PADDING) / 32) * 36);  // Q8_1 scratch of the last-token lm_head GEMV
-    if (T > prefill_big_min()) b += align(t * std::max(std::max(d, nq), ff) * 2) + align(mrs_gemm_q_bf16_workspace_bytes(T));  // bf16 activations + split-K partials
+    if (T > prefill_big_min()) b += align(t * std::max(std::max(d, nq), ff) * 2) + align(mrs_gemm_q_bf16_workspace_bytes(T)) + align(t * ff * 2);  // bf16 activations + split-K partials + act(gate)*up slabs of the fused gate/up GEMM
     if (c.num_experts > 0) {  // MoE FFN of the prompt: routes = T * top_k rows in expert-sorted order
       const size_t tk = (size_t)std::max(1, (int)c.num_experts_per_tok), r = t * tk, E = (size_t)c.num_experts;
       b += align(r * ff * 4) * 3;                                                    // gate, up, act per route (replace the dense t * ff buffers)
@@ -619,6 +619,7 @@ class Llama {
     const bool big = T > prefill_big_min() && !getenv("MRS_PREFILL_SMALL_TILES");
     const size_t part_bytes = big ? mrs_gemm_q_bf16_workspace_bytes(T) : 0;
     void *xb = big ? take(t * std::max(std::max(d, nq), ff) * 2) : nullptr, *part = big ? take(part_bytes) : nullptr;
+    void *xg = big ? take(t * ff * 2) : nullptr;  // output slabs of the fused gate / up GEMM (it reads xb while it writes)
     const float *xb_src = nullptr;    // which f32 buffer xb currently mirrors (within one GEMM group)
     const float *xb_ready = nullptr;  // set by a producer that wrote the slabs of that (never materialised) f32 buffer directly
     auto to_bf16 = [&](const float *x, int K) -> int {
@@ -700,6 +701,20 @@ class Llama {
       }
       if (big) { if (mrs_rms_norm_bf16_slabs(h, bl.post_attention_layernorm, T, d, cfg.rms_eps, xb, s)) return -1; xb_ready = xn; }
       else mrs_rms_norm_f32(h, bl.post_attention_layernorm, xn, T, d, cfg.rms_eps, st);
+      // gate / up / SiLU*up in ONE launch (act(gate) * up leaves the epilogue as the down GEMM's bf16 slabs): bit-identical, but measured 1.5-2.5 % SLOWER per
+      // prompt on the MI355X than two GEMM segments + the 12.7 us GLU pass (TTFT 14.15 vs 13.82 ms at 512 tokens, 47.5 vs 46.9 ms at 2048: the epilogue's expf and
+      // 2-byte half-line stores sit in the un-overlapped tail of every workgroup) -> opt-in (MRS_PREFILL_FUSED_GLU=1)
+      static const bool glu_fused = [] { const char *e = getenv("MRS_PREFILL_FUSED_GLU"); return e && atoi(e) != 0; }();
+      const QTensor *qg = bl.gate_proj->get_qtensor(), *qu = bl.up_proj->get_qtensor(), *qd = bl.down_proj->get_qtensor();
+      if (big && glu_fused && ff % 64 == 0 && qg->dtype == qu->dtype && xb_ready == xn &&
+          mrs_gemm_q_bf16_glu(qg->data, qu->data, qg->dtype, ff, d, xb, T, 0, xg, s) == 0) {
+        xb_ready = nullptr; xb_src = nullptr;
+        float *dst = cfg.world_size > 1 ? xn : h;
+        if (mrs_gemm_q_bf16_multi(1, &qd->data, &d, &dst, &d, qd->dtype, ff, xg, T, cfg.world_size > 1 ? 0 : 1, part, part_bytes, s))
+          return fail("prefill: no GEMM for ggml dtype %d (K=%d)", qd->dtype, ff);
+        if (cfg.world_size > 1 && (all_reduce(xn, t * d, s) || mrs_vec_add_f32(h, xn, t * d, s))) return -1;
+        continue;
+      }
       if (gemm_multi({bl.gate_proj.get(), bl.up_proj.get()}, xn, d, {g, u}, {ff, ff})) return -1;
       if (big && ff % 64 == 0) { if (mrs_glu_bf16_slabs(g, u, ff, T, ff, 0, xb, s)) return -1; xb_ready = act; }
       else fused_glu_f32(g, u, act, (uint32_t)T, (uint32_t)ff, (uint32_t)ff, (uint32_t)ff, 0, s);

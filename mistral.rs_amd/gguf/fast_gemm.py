@@ -134,3 +134,19 @@ def moe_grouped_bf16(w: QTensor, num_experts: int, slabs: torch.Tensor, bounds: 
     if rc != 0:
         raise ValueError(f"fast_gemm.moe_grouped_bf16: unsupported shape K={k} for {w.dtype.name}")
     return out
+
+
+def fused_glu_bf16(w_gate: QTensor, w_up: QTensor, slabs: torch.Tensor, activation: int = 0) -> torch.Tensor:
+    """act(W_g x) * (W_u x) of a prompt in ONE launch (mrs_gemm_q_bf16_glu; role of fast_mmq::fused_glu, gguf/fast_mmq.rs:762-821): bf16 slabs in, bf16 slabs
+    [N / 64, M, 64] out -- the down GEMM's activation layout.  Same bits as plain_bf16(gate), plain_bf16(up), glu_slabs."""
+    if not supports(w_gate.dtype) or w_gate.dtype != w_up.dtype or w_gate.shape != w_up.shape:
+        raise ValueError("fast_gemm.fused_glu_bf16: gate and up must share a supported quant dtype and shape")
+    n, k = w_gate.shape
+    if slabs.dtype != torch.bfloat16 or slabs.dim() != 3 or slabs.shape[2] != 64 or slabs.shape[0] * 64 != k or not slabs.is_contiguous() or n % 64:
+        raise ValueError(f"fast_gemm.fused_glu_bf16: weight [{n}, {k}] (N % 64 == 0) vs slabs {tuple(slabs.shape)}")
+    m = slabs.shape[1]
+    y = torch.empty(n // 64, m, 64, dtype=torch.bfloat16, device=slabs.device)
+    fn = _lib.sym("ext", "mrs_gemm_q_bf16_glu", [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p], C.c_int)
+    if fn(w_gate.data.data_ptr(), w_up.data.data_ptr(), w_gate.dtype.id, n, k, slabs.data_ptr(), m, int(activation), y.data_ptr(), torch.cuda.current_stream().cuda_stream):
+        raise ValueError(f"fast_gemm.fused_glu_bf16: unsupported shape K={k} for {w_gate.dtype.name}")
+    return y

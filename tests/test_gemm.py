@@ -152,6 +152,31 @@ def test_moe_grouped_gemm_on_matrix_cores(oracle, dev, tname, E, tokens, topk, n
         assert float((acc - ref.sum(1)).abs().max()) <= 1e-5 * float(ref.abs().sum(1).max())
 
 
+@pytest.mark.parametrize("tname", ["Q4_K", "Q5_K", "Q6_K", "Q8_0"])
+@pytest.mark.parametrize("m,n,k,act", [(300, 192, 512, 0), (70, 64, 1024, 1), (512, 448, 256, 0)])
+def test_fused_gate_up_glu_gemm(oracle, dev, tname, m, n, k, act):
+    """mrs_gemm_q_bf16_glu (gate and up rows interleaved in one B tile, act(gate) * up -> bf16 slabs in the epilogue) == the two GEMMs followed by the
+    GLU-to-slabs kernel, bit for bit, through both GEMM kernels."""
+    import ctypes as C
+    import torch
+    from mistralrs_amd import _lib
+    from mistralrs_amd.gguf import GgmlDType, QTensor, fast_gemm
+    t = getattr(oracle, tname)
+    rng = np.random.default_rng(m + n + k)
+    wg = QTensor.from_numpy(GgmlDType.from_id(t), (n, k), oracle.random_blocks(t, n, k, seed=1 + n, d_scale=0.02), dev)
+    wu = QTensor.from_numpy(GgmlDType.from_id(t), (n, k), oracle.random_blocks(t, n, k, seed=2 + n, d_scale=0.02), dev)
+    xs = fast_gemm.to_slabs(torch.from_numpy((rng.standard_normal((m, k)) * rng.uniform(0.2, 3.0, (m, 1))).astype(np.float32)).to(dev))
+    want = fast_gemm.glu_slabs(fast_gemm.plain_bf16(wg, xs, split_k=False), fast_gemm.plain_bf16(wu, xs, split_k=False), act)
+    setv = _lib.sym("ext", "mrs_gemm_set_variant", [C.c_int], None)
+    try:
+        for v in (0, 1):
+            setv(v)
+            got = fast_gemm.fused_glu_bf16(wg, wu, xs, act)
+            assert torch.equal(got.view(torch.int16), want.view(torch.int16)), v
+    finally:
+        setv(-1)
+
+
 def test_slab_producers(dev):
     """to_slabs is the layout [K/64][M][64] of the bf16-rounded matrix; the fused producers equal the unfused op + to_slabs bit for bit."""
     import torch
