@@ -106,6 +106,31 @@ elif sym == "hqq":
     got = ob.numpy()
     assert np.isfinite(got).all() and np.abs(got - want).max() <= 1e-4 * np.abs(want).max()
     print("guard page intact"); sys.exit(0)
+elif sym == "attn":
+    # decode attention (split + merge kernels and the one-launch variant): K / V pages end at guard pages and the sequence's last block IS the last page
+    heads, kvh, hd, bs, ctx = 4, 2, 128, 32, n
+    mbs = (ctx + bs - 1) // bs
+    nblocks = mbs + 1
+    rng = np.random.default_rng(5)
+    kc = O.to_bf16_bits((rng.standard_normal((nblocks, kvh, hd // 8, bs, 8)) * 0.7).astype(np.float32))
+    vc = O.to_bf16_bits(rng.standard_normal((nblocks, kvh, hd, bs)).astype(np.float32))
+    kp, vp = guarded(kc), guarded(vc)
+    bt = be.buf(np.arange(nblocks - mbs, nblocks, dtype=np.uint32)[::-1].copy().reshape(1, mbs))  # includes block nblocks - 1
+    cl = be.buf(np.array([ctx], np.uint32))
+    q = be.buf((rng.standard_normal((1, heads * hd)) * 0.5).astype(np.float32))
+    splits = be.sym("mrs_decode_attention_max_splits", [C.c_int], C.c_int)(mbs * bs)
+    po, pm, pl = be.buf(np.zeros((1, heads, splits, hd), np.float32)), be.buf(np.zeros((1, heads, splits), np.float32)), be.buf(np.zeros((1, heads, splits), np.float32))
+    ref, got = be.buf(np.zeros((1, heads * hd), np.float32)), be.buf(np.zeros((1, heads * hd), np.float32))
+    A = [C.c_void_p] * 7 + [C.c_int, C.c_float, C.c_void_p, C.c_void_p] + [C.c_int] * 10 + [C.c_void_p]
+    B = [C.c_void_p] * 5 + [C.c_int, C.c_float, C.c_void_p, C.c_void_p] + [C.c_int] * 10 + [C.c_void_p]
+    sc = 1.0 / np.sqrt(hd)
+    assert be.sym("mrs_decode_attention_f32_f32_bf16", A, C.c_int)(ref.ptr, pl.ptr, pm.ptr, po.ptr, q.ptr, kp, vp, kvh, sc, bt.ptr, cl.ptr, bs, mbs * bs, 1, heads, hd, mbs, heads * hd,
+                                                                   kvh * hd * bs, hd * bs, 1, be.stream) == 0
+    img = be.buf(np.zeros(heads * hd * 2, np.uint8))
+    assert be.sym("mrs_dec_attention_q8k", B, C.c_int)(img.ptr, got.ptr, q.ptr, kp, vp, kvh, sc, bt.ptr, cl.ptr, bs, mbs * bs, 1, heads, hd, mbs, heads * hd, kvh * hd * bs, hd * bs, 1,
+                                                       be.stream) == 0
+    assert np.isfinite(ref.numpy()).all() and np.array_equal(ref.numpy(), got.numpy())
+    print("guard page intact"); sys.exit(0)
 elif sym == "dec_proj":
     # decode engine: the repacked planes end at the guard page (buffer loads: out-of-range lanes must stay out of range)
     class Mat(C.Structure):
@@ -136,7 +161,8 @@ print("guard page intact")
 @pytest.mark.parametrize("n,k,sym,env", [(600, 512, "norm_proj", {"MRS_PROJ_WGS": "2"}), (129, 1024, "mmvq", {}), (2049, 256, "mmvq", {}),
                                          (200, 512, "gemm", {"MRS_GEMM_VARIANT": "1"}), (200, 512, "gemm", {"MRS_GEMM_VARIANT": "0"}), (130, 256, "gemm_q6", {}),
                                          (70, 512, "dec_proj", {}), (2049, 256, "dec_proj", {}),
-                                         (70, 512, "mmq", {}), (129, 256, "mmq", {}), (50, 512, "imoe", {}), (128, 256, "hqq", {}), (64, 2064, "hqq", {})])
+                                         (70, 512, "mmq", {}), (129, 256, "mmq", {}), (50, 512, "imoe", {}), (128, 256, "hqq", {}), (64, 2064, "hqq", {}),
+                                         (96, 256, "attn", {}), (33, 256, "attn", {})])
 def test_row_less_waves_do_not_read_past_the_tensor(n, k, sym, env):
     r = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT}, str(n), str(k), sym], capture_output=True, text=True, timeout=600,
                        env={**os.environ, **env})
