@@ -54,6 +54,11 @@ int mrs_dec_qkv(const mrs_dec_mat *wq, const mrs_dec_mat *wk, const mrs_dec_mat 
 /* RmsNorm + act(W_g x) * (W_u x) -> act_out f32 [b][ld_out]; n = rows per expert, expert_sel = device pointer to the expert id (NULL: dense) */
 int mrs_dec_gate_up(const mrs_dec_mat *wg, const mrs_dec_mat *wu, int n, const int32_t *expert_sel, const float *h, int ldh, const float *norm_w,
                     float eps, int activation, float *act_out, int ld_out, int b, void *stream);
+/* MoE decode: gate / up of ALL top-k experts of one token in one launch (expert_sel [topk] on the device, act_out [topk][ld_out]); -3: caller loops over mrs_dec_gate_up */
+int mrs_dec_gate_up_topk(const mrs_dec_mat *wg, const mrs_dec_mat *wu, int n, const int32_t *expert_sel, int topk, const float *h, const float *norm_w, float eps,
+                         int activation, float *act_out, int ld_out, void *stream);
+/* MoE decode, top-2: out = (out * resid_scale + w[0] W_{sel[0]} x[0]) + w[1] W_{sel[1]} x[1] in one launch (x [2][ldx]); same bits as two mrs_dec_proj launches */
+int mrs_dec_proj_top2(const mrs_dec_mat *w, int n, const int32_t *expert_sel, const float *x, int ldx, float *out, float resid_scale, const float *acc_scale, void *stream);
 /* (RmsNorm when norm_w) + GEMV; mode 0: out = W x; mode 1: out = out * resid_scale + s * W x with s = *acc_scale (NULL: 1) */
 int mrs_dec_proj(const mrs_dec_mat *w, int n, const int32_t *expert_sel, const float *x, int ldx, const float *norm_w, float eps, float *out,
                  int ld_out, int mode, float resid_scale, const float *acc_scale, int b, void *stream);

@@ -436,7 +436,8 @@ struct Segs {
   int nseg;
 };
 
-template <int TYPE, int NCOLS, class Pre, class Pro, class Epi>
+// SEGCOL (NCOLS must be 1): segment s multiplies by activation column s of a 2-column image (MoE down: two experts' rows against their own activations)
+template <int TYPE, int NCOLS, bool SEGCOL = false, class Pre, class Pro, class Epi>
 __device__ __forceinline__ void stream(const Segs &sg, int K, Pre pre, Pro pro, Epi epi, bool skip_acc = false) {
   using TL = Tile<TYPE>;
   constexpr int D = TL::DEPTH;
@@ -463,6 +464,7 @@ __device__ __forceinline__ void stream(const Segs &sg, int K, Pre pre, Pro pro, 
 #pragma unroll
   for (int i = 0; i < D; ++i) issue(ring[i]);
   const Act act = pro(pr);
+  const Act act1 = Act{act.q + K, act.d + K / 32, act.bs + K / 16, K};  // column 1 (SEGCOL)
   const typename TL::LaneC lc = TL::lanec(lane);
   float acc[NCOLS];
 #pragma unroll
@@ -472,7 +474,8 @@ __device__ __forceinline__ void stream(const Segs &sg, int K, Pre pre, Pro pro, 
 #pragma unroll
     for (int i = 0; i < D; ++i) {
       if (g + i < total) {  // wave-uniform
-        if (!skip_acc) TL::template accumulate<NCOLS>(ring[i], lc, ct, S, act, acc);
+        if constexpr (SEGCOL) { if (cseg == 0) TL::template accumulate<NCOLS>(ring[i], lc, ct, S, act, acc); else TL::template accumulate<NCOLS>(ring[i], lc, ct, S, act1, acc); }
+        else if (!skip_acc) TL::template accumulate<NCOLS>(ring[i], lc, ct, S, act, acc);
         else acc[0] += __uint_as_float(ring[i].hd & 1u);  // experiment: keep the loads alive (in-order return: the last load of the slot), drop the arithmetic
         if (++ct == tpr) {
           float sum[NCOLS];

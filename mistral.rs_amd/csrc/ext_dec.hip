@@ -24,7 +24,7 @@ namespace dec {
 #define MRS_WAIT_VMCNT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #endif
 
-enum : int { EPI_STORE = 0, EPI_RESID = 1, EPI_GLU = 2, EPI_QKV = 3 };
+enum : int { EPI_STORE = 0, EPI_RESID = 1, EPI_GLU = 2, EPI_QKV = 3, EPI_RESID2 = 4 };
 
 struct GemvArgs {
   Mat m[3];
@@ -40,6 +40,7 @@ struct GemvArgs {
   const int32_t *expert_sel;  // stacked experts [E * nrows][K]: rows of expert e start at e * nrows (nullptr = dense)
   const float *acc_scale;     // RESID: out = out * resid_scale + (*acc_scale) * W.x  (routing weight)
   int ablate;                 // experiments (MRS_DEC_ABLATE): 1 = skip the activation prologue's arithmetic, 2 = skip the accumulate (loads only)
+  int slots, slot_out_stride;  // GLU with several experts of ONE token in a launch (MoE top-k): unit u -> slot u / nrows[0], expert expert_sel[slot], output out + slot * slot_out_stride
   const void *x_img;          // activations already quantized by the producer (decode_attn_fused_kernel): the LDS image of NCOLS columns, byte for byte
 };
 
@@ -100,8 +101,13 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
       return act_finish<NCOLS, false>(smem, red, p, a.x, a.ldx, a.norm_w, a.eps, K, act_mode_for(a.m[0].type));
     }
   };
-  const int u0 = min(gw * a.units_per_wave, a.units), u1 = min(u0 + a.units_per_wave, a.units);
-  const int eoff = a.expert_sel ? *a.expert_sel * a.nrows[0] : 0;
+  int u0 = min(gw * a.units_per_wave, a.units), u1 = min(u0 + a.units_per_wave, a.units);
+  int slot = 0;
+  if (a.slots > 1) {  // the launcher made units_per_wave a divisor of nrows: a wave never straddles two experts
+    slot = u0 / a.nrows[0];
+    u0 -= slot * a.nrows[0]; u1 -= slot * a.nrows[0];
+  }
+  const int eoff = a.expert_sel ? a.expert_sel[slot] * a.nrows[0] : 0;
 
   if constexpr (EPI == EPI_STORE || EPI == EPI_RESID) {
     Segs sg{};
@@ -130,6 +136,28 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
       }
     };
     MRS_DEC_TYPE_SWITCH(a.m[0].type, (stream<TT, NCOLS>(sg, K, pre, pro, epi, (a.ablate & 2) != 0));)
+  } else if constexpr (EPI == EPI_RESID2) {
+    // MoE down of the two experts of one token in one launch (NCOLS == 2 = the two experts' activation vectors): a wave streams rows [u0, u1) of expert
+    // sel[0] against column 0, then the same rows of expert sel[1] against column 1, and writes (out * resid_scale + w0 s0) * 1 + w1 s1 -- the two
+    // roundings of two consecutive EPI_RESID launches, bit for bit
+    static_assert(EPI != EPI_RESID2 || NCOLS == 2, "two experts = two activation columns");
+    Segs sg{};
+    sg.nseg = 2; sg.mat[0] = sg.mat[1] = a.m[0];
+    sg.row0[0] = a.expert_sel[0] * a.nrows[0] + u0; sg.row0[1] = a.expert_sel[1] * a.nrows[0] + u0; sg.nrows[0] = sg.nrows[1] = u1 - u0;
+    const float w0 = a.acc_scale[0], w1 = a.acc_scale[1];
+    float hold = 0.0f, s0save = 0.0f;
+    if (lane < u1 - u0) hold = ld_out<LATE>(a.out + u0 + lane);
+    auto epi = [&](int seg, int row, const float(&sum)[1]) {
+      const int i = row - (seg == 0 ? sg.row0[0] : sg.row0[1]);
+      if (seg == 0) {
+        s0save = lane == i ? sum[0] : s0save;
+      } else {
+        const float s0 = rl(s0save, i), old = rl(hold, i);
+        const float h1 = old * a.resid_scale + s0 * w0;
+        if (lane == 0) st_out<LATE>(a.out + u0 + i, h1 * 1.0f + sum[0] * w1);
+      }
+    };
+    MRS_DEC_TYPE_SWITCH(a.m[0].type, (stream<TT, 1, true>(sg, K, pre, pro, epi, false));)
   } else if constexpr (EPI == EPI_GLU) {
     Segs sg{};
     sg.nseg = 2; sg.mat[0] = a.m[0]; sg.mat[1] = a.m[1];
@@ -145,7 +173,7 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
           gsave[c] = lane == i ? sum[c] : gsave[c];
         } else {
           const float g = rl(gsave[c], i);
-          if (lane == 0) st_out<LATE>(a.out + (size_t)c * a.out_stride + (row - eoff), glu_act(g, a.activation) * sum[c]);
+          if (lane == 0) st_out<LATE>(a.out + (size_t)slot * a.slot_out_stride + (size_t)c * a.out_stride + (row - eoff), glu_act(g, a.activation) * sum[c]);
         }
       }
     };
@@ -481,6 +509,10 @@ template <int EPI> struct Launch {
     if (upw > 64) upw = 64;  // epilogue operands are prefetched one unit per lane
     { static int ov = -1; if (ov < 0) { const char *e = getenv("MRS_DEC_UPW"); ov = e ? atoi(e) : 0; } if (ov > 0 && ov <= 64) upw = ov; }
     { static int ab = -1; if (ab < 0) { const char *e = getenv("MRS_DEC_ABLATE"); ab = e ? atoi(e) : 0; } a.ablate = ab; }
+    if (a.slots > 1) {  // units = slots * nrows: waves must not straddle experts
+      while (upw > 1 && a.nrows[0] % upw) --upw;
+      if (a.nrows[0] % upw) return -3;
+    }
     a.units_per_wave = upw;
     int grid = (a.units + upw * NW - 1) / (upw * NW);
     if (EPI == EPI_QKV) {
@@ -563,6 +595,29 @@ extern "C" int mrs_dec_gate_up(const mrs_dec_mat_c *wg, const mrs_dec_mat_c *wu,
   a.nrows[0] = a.nrows[1] = n; a.K = (int)wg->k; a.x = h; a.ldx = ldh; a.norm_w = norm_w; a.eps = eps; a.activation = activation;
   a.out = act_out; a.out_stride = ld_out; a.units = n; a.expert_sel = expert_sel;
   return Launch<EPI_GLU>::run(a, b, (hipStream_t)stream);
+}
+
+// MoE decode: the gate / up phase of ALL top-k experts of one token in one launch (one activation prologue, one dispatch, 2 x top-k x n rows streamed):
+// expert_sel [topk] on the device, act_out [topk][ld_out].  -3: the row count does not split into whole waves per expert (caller loops over mrs_dec_gate_up).
+extern "C" int mrs_dec_gate_up_topk(const mrs_dec_mat_c *wg, const mrs_dec_mat_c *wu, int n, const int32_t *expert_sel, int topk, const float *h, const float *norm_w,
+                                    float eps, int activation, float *act_out, int ld_out, void *stream) {
+  GemvArgs a{};
+  if (!wg || !wu || !expert_sel || topk < 1 || topk > 8 || !make_mat(a.m[0], wg->planes, wg->type, wg->n, wg->k) || !make_mat(a.m[1], wu->planes, wu->type, wu->n, wu->k)) return -1;
+  if (wg->type != wu->type || wg->n != wu->n || wg->k != wu->k || n <= 0 || wg->n % n) return -1;
+  a.nrows[0] = a.nrows[1] = n; a.K = (int)wg->k; a.x = h; a.ldx = (int)wg->k; a.norm_w = norm_w; a.eps = eps; a.activation = activation;
+  a.out = act_out; a.out_stride = ld_out; a.units = n * topk; a.expert_sel = expert_sel; a.slots = topk; a.slot_out_stride = ld_out;
+  return Launch<EPI_GLU>::run(a, 1, (hipStream_t)stream);
+}
+
+// MoE decode, top-2: out = (out * resid_scale + w[0] W_{sel[0]} . x[0]) + w[1] W_{sel[1]} . x[1] in one launch; x [2][ldx] = the two experts' activations,
+// expert_sel / acc_scale [2] on the device.  Same bits as two mrs_dec_proj launches (mode 1: resid_scale, then 1).
+extern "C" int mrs_dec_proj_top2(const mrs_dec_mat_c *w, int n, const int32_t *expert_sel, const float *x, int ldx, float *out, float resid_scale,
+                                 const float *acc_scale, void *stream) {
+  GemvArgs a{};
+  if (!w || !expert_sel || !acc_scale || !make_mat(a.m[0], w->planes, w->type, w->n, w->k) || n <= 0 || w->n % n) return -1;
+  a.nrows[0] = n; a.K = (int)w->k; a.x = x; a.ldx = ldx; a.out = out; a.out_stride = n; a.resid_scale = resid_scale; a.acc_scale = acc_scale; a.units = n;
+  a.expert_sel = expert_sel;
+  return Launch<EPI_RESID2>::go<2>(a, (hipStream_t)stream);
 }
 
 // plain projection: x [b][ldx] f32 (-> RMSNorm when norm_w) -> quantize -> GEMV.  mode 0: out = W.x;  mode 1: out = out * resid_scale + s * W.x

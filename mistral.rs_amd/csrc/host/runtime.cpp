@@ -498,10 +498,15 @@ class Llama {
         if (mrs_moe_router_topk(ws.xn, bl.router, b, E, d, tk, 1, ws.moe_ids, ws.moe_w, nullptr, s)) return fail("moe router refused (experts %d, top-k %d)", E, tk);
         for (int t = 0; t < b; ++t) {
           float *ht = ws.h + (size_t)t * d;
-          for (int sl = 0; sl < tk; ++sl)  // all of a token's expert activations are computed before h changes
+          // all of a token's expert activations are computed before h changes: one launch for the top-k experts (-3: shapes that do not split -> one per expert)
+          const int grc = mrs_dec_gate_up_topk(&bl.dgate_exps, &bl.dup_exps, ff, ws.moe_ids + t * tk, tk, ht, bl.post_attention_layernorm, cfg.rms_eps, 0, ws.moe_act, ff, s);
+          if (grc != 0 && grc != -3) return fail("moe gate/up refused (%d)", grc);
+          for (int sl = 0; grc == -3 && sl < tk; ++sl)
             if (mrs_dec_gate_up(&bl.dgate_exps, &bl.dup_exps, ff, ws.moe_ids + t * tk + sl, ht, d, bl.post_attention_layernorm, cfg.rms_eps, 0,
                                 ws.moe_act + (size_t)sl * ff, ff, 1, s))
               return fail("moe gate/up refused");
+          // top-2 (Mixtral): both experts' down projections in one launch, same roundings as two accumulating launches
+          if (tk == 2 && grc == 0 && mrs_dec_proj_top2(&bl.ddown_exps, d, ws.moe_ids + t * tk, ws.moe_act, ff, ht, rs, ws.moe_w + t * tk, s) == 0) continue;
           for (int sl = 0; sl < tk; ++sl)
             if (mrs_dec_proj(&bl.ddown_exps, d, ws.moe_ids + t * tk + sl, ws.moe_act + (size_t)sl * ff, ff, nullptr, 0.f, ht, d, 1, sl == 0 ? rs : 1.0f, ws.moe_w + t * tk + sl, 1, s))
               return fail("moe down refused");

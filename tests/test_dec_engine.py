@@ -264,3 +264,68 @@ def test_fused_attention_host_emulation(oracle, heads, kvh, ctxs, max_ctx, kvd):
 @pytest.mark.parametrize("heads,kvh,ctxs,max_ctx,kvd", [(32, 8, [700], 832, 1), (32, 8, [1024, 3, 515], 1024, 1), (8, 4, [129], 160, 0), (64, 8, [333, 1000], 1024, 1)])
 def test_fused_attention_gpu(oracle, dev, heads, kvh, ctxs, max_ctx, kvd):
     check_fused_attention(oracle, GpuBackend(dev), heads, kvh, ctxs, max_ctx, kvd, n_out=256)
+
+
+GLU_TOPK = [C.POINTER(Mat), C.POINTER(Mat), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+
+
+def check_gate_up_topk(O, be, tname, n, k, experts, sels):
+    """mrs_dec_gate_up_topk (all top-k experts of a token in one launch) == one mrs_dec_gate_up launch per expert, bit for bit."""
+    t = getattr(O, tname)
+    pg, pu = _weights(O, t, experts * n, k, 31), _weights(O, t, experts * n, k, 32)
+    kg, mg = repack(be, O, t, pg, experts * n, k)
+    ku, mu = repack(be, O, t, pu, experts * n, k)
+    rng = np.random.default_rng(33)
+    x = rng.standard_normal((1, k)).astype(np.float32)
+    nw = (1.0 + 0.05 * rng.standard_normal(k)).astype(np.float32)
+    xb, nb = be.buf(x), be.buf(nw)
+    selb = be.buf(np.array(sels, dtype=np.int32))
+    one = be.buf(np.zeros((len(sels), n), dtype=np.float32))
+    fn = be.sym("mrs_dec_gate_up", GLU, C.c_int)
+    for i in range(len(sels)):
+        assert fn(C.byref(mg), C.byref(mu), n, selb.ptr + 4 * i, xb.ptr, k, nb.ptr, 1e-5, 0, one.ptr + 4 * n * i, n, 1, be.stream) == 0
+    allk = be.buf(np.full((len(sels), n), np.nan, dtype=np.float32))
+    rc = be.sym("mrs_dec_gate_up_topk", GLU_TOPK, C.c_int)(C.byref(mg), C.byref(mu), n, selb.ptr, len(sels), xb.ptr, nb.ptr, 1e-5, 0, allk.ptr, n, be.stream)
+    assert rc == 0
+    np.testing.assert_array_equal(allk.numpy(), one.numpy())
+
+
+@pytest.mark.parametrize("tname,n,k,experts,sels", [("Q4_K", 64, 512, 4, [3, 1]), ("Q6_K", 48, 768, 3, [0, 2, 1]), ("Q4_K", 37, 512, 2, [1, 0])])
+def test_gate_up_topk_host_emulation(oracle, tname, n, k, experts, sels):
+    check_gate_up_topk(oracle, HostBackend(), tname, n, k, experts, sels)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tname,n,k,experts,sels", [("Q4_K", 14336, 4096, 8, [5, 2]), ("Q6_K", 1000, 4096, 4, [3, 0]), ("Q4_K", 2048, 4096, 4, [1, 2, 3])])
+def test_gate_up_topk_gpu(oracle, dev, tname, n, k, experts, sels):
+    check_gate_up_topk(oracle, GpuBackend(dev), tname, n, k, experts, sels)
+
+
+def check_proj_top2(O, be, tname, n, k, experts, sels):
+    """mrs_dec_proj_top2 (both experts' down projections of a token in one launch) == two accumulating mrs_dec_proj launches, bit for bit."""
+    t = getattr(O, tname)
+    pw = _weights(O, t, experts * n, k, 41)
+    keep, m = repack(be, O, t, pw, experts * n, k)
+    rng = np.random.default_rng(42)
+    x = rng.standard_normal((2, k)).astype(np.float32)
+    base = rng.standard_normal((1, n)).astype(np.float32)
+    rw = rng.uniform(0.2, 0.8, 2).astype(np.float32)
+    xb, selb, wb = be.buf(x), be.buf(np.array(sels, dtype=np.int32)), be.buf(rw)
+    two, one = be.buf(base.copy()), be.buf(base.copy())
+    fn = be.sym("mrs_dec_proj", PROJ, C.c_int)
+    for i in range(2):
+        assert fn(C.byref(m), n, selb.ptr + 4 * i, xb.ptr + 4 * k * i, k, None, 0.0, two.ptr, n, 1, 0.5 if i == 0 else 1.0, wb.ptr + 4 * i, 1, be.stream) == 0
+    T2 = [C.POINTER(Mat), C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
+    assert be.sym("mrs_dec_proj_top2", T2, C.c_int)(C.byref(m), n, selb.ptr, xb.ptr, k, one.ptr, 0.5, wb.ptr, be.stream) == 0
+    np.testing.assert_array_equal(one.numpy(), two.numpy())
+
+
+@pytest.mark.parametrize("tname,n,k,experts,sels", [("Q4_K", 70, 512, 4, [3, 1]), ("Q6_K", 33, 768, 3, [0, 2]), ("Q4_K", 16, 1024, 2, [1, 1])])
+def test_proj_top2_host_emulation(oracle, tname, n, k, experts, sels):
+    check_proj_top2(oracle, HostBackend(), tname, n, k, experts, sels)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tname,n,k,experts,sels", [("Q4_K", 4096, 14336, 8, [5, 2]), ("Q6_K", 4096, 14336, 4, [3, 0]), ("Q4_K", 1000, 4096, 4, [1, 2])])
+def test_proj_top2_gpu(oracle, dev, tname, n, k, experts, sels):
+    check_proj_top2(oracle, GpuBackend(dev), tname, n, k, experts, sels)
