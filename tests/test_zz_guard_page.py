@@ -131,6 +131,23 @@ elif sym == "attn":
                                                        be.stream) == 0
     assert np.isfinite(ref.numpy()).all() and np.array_equal(ref.numpy(), got.numpy())
     print("guard page intact"); sys.exit(0)
+elif sym == "prefill_attn":
+    # prompt attention (MFMA flash kernel reading the paged cache with 16-byte loads): pages end at guard pages, the prompt's last block is the last page,
+    # the block table itself ends at a guard page too; T = n tokens (ragged last block)
+    heads, kvh, hd, bs, T = 4, 2, 128, 32, n
+    mbs = (T + bs - 1) // bs
+    nblocks = mbs + 1
+    rng = np.random.default_rng(6)
+    kc = O.to_bf16_bits((rng.standard_normal((nblocks, kvh, hd // 8, bs, 8)) * 0.7).astype(np.float32))
+    vc = O.to_bf16_bits(rng.standard_normal((nblocks, kvh, hd, bs)).astype(np.float32))
+    btab = np.arange(nblocks - mbs, nblocks, dtype=np.uint32)[::-1].copy()
+    q = (rng.standard_normal((T, heads * hd)) * 0.5).astype(np.float32)
+    out = be.buf(np.full((T, heads * hd), np.nan, np.float32))
+    fn = be.sym("mrs_prefill_attention_f32_bf16", [C.c_void_p] * 5 + [C.c_int] * 10 + [C.c_float, C.c_void_p], C.c_int)
+    assert fn(guarded(q), guarded(kc), guarded(vc), guarded(btab), out.ptr, T, 0, heads, kvh, hd, bs, heads * hd, heads * hd, kvh * hd * bs, hd * bs, 1.0 / np.sqrt(hd),
+              be.stream) == 0
+    assert np.isfinite(out.numpy()).all()
+    print("guard page intact"); sys.exit(0)
 elif sym == "dec_proj":
     # decode engine: the repacked planes end at the guard page (buffer loads: out-of-range lanes must stay out of range)
     class Mat(C.Structure):
@@ -162,7 +179,7 @@ print("guard page intact")
                                          (200, 512, "gemm", {"MRS_GEMM_VARIANT": "1"}), (200, 512, "gemm", {"MRS_GEMM_VARIANT": "0"}), (130, 256, "gemm_q6", {}),
                                          (70, 512, "dec_proj", {}), (2049, 256, "dec_proj", {}),
                                          (70, 512, "mmq", {}), (129, 256, "mmq", {}), (50, 512, "imoe", {}), (128, 256, "hqq", {}), (64, 2064, "hqq", {}),
-                                         (96, 256, "attn", {}), (33, 256, "attn", {})])
+                                         (96, 256, "attn", {}), (33, 256, "attn", {}), (70, 256, "prefill_attn", {}), (33, 256, "prefill_attn", {})])
 def test_row_less_waves_do_not_read_past_the_tensor(n, k, sym, env):
     r = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT}, str(n), str(k), sym], capture_output=True, text=True, timeout=600,
                        env={**os.environ, **env})
