@@ -120,6 +120,9 @@ int mrs_sample_greedy_advance(const float *logits, int vocab, int b, int32_t *ne
 int mrs_moe_router_topk(const float *x_normed, const float *gate_w /* f32 [E][K] */, int tokens, int n_experts, int K, int top_k,
                         int renormalize, int32_t *ids /* [tokens][top_k] */, float *weights /* [tokens][top_k] */,
                         float *logits_out /* optional [tokens][E] */, void *stream);
+/* router on the un-normed hidden state: RmsNorm(h) * norm_w (bit-identical to mrs_rms_norm_f32) inside the router's workgroup; -3: K * 4 bytes > 64 KiB of LDS */
+int mrs_moe_router_topk_norm(const float *h, const float *norm_w, float eps, const float *gate_w, int tokens, int n_experts, int K, int top_k, int renormalize,
+                             int32_t *ids, float *weights, void *stream);
 int mrs_moe_decode_gate_up(const void *wg, const void *wu, size_t expert_stride_bytes, const int32_t *expert_sel, int type, int n, int K,
                            const float *h, const float *norm_w, float eps, int activation, void *y_out, int y_out_stride, void *stream);
 int mrs_moe_decode_down(const void *w, size_t expert_stride_bytes, const int32_t *expert_sel, const float *topk_weight, int type, int n, int K,

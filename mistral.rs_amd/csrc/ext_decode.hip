@@ -537,11 +537,37 @@ namespace mrs {
 // One wave per expert (up to 16 waves), the loop unrolled so that a lane's loads of a row are all in flight before its first fma: the 4-wave version
 // with one dependent load pair per iteration took 17-18 us per decode token (16 serialized memory round trips), 10 % of a Mixtral step.  The per-lane
 // summation order (element order, then the wave sum) is unchanged.
+// NORM: x is the un-normed hidden state; the first 256 threads compute RmsNorm(x) * norm_w into LDS with the arithmetic of rms_norm_kernel<float, 0, true>
+// (core_ops.hip: float4 v = tid + 256 j, fmaf chain, wave sums, red[0..3] in order, x * inv * w) -- same values, one launch less per MoE layer and token.
+template <bool NORM>
 __global__ void __launch_bounds__(1024) moe_router_kernel(const float *__restrict__ x, const float *__restrict__ gate_w, int E, int K, int top_k,
-                                                          int renormalize, int32_t *__restrict__ ids, float *__restrict__ weights, float *__restrict__ logits_out) {
+                                                          int renormalize, int32_t *__restrict__ ids, float *__restrict__ weights, float *__restrict__ logits_out,
+                                                          const float *__restrict__ norm_w, float eps) {
   __shared__ float lg[512];
+  __shared__ float red[4];
+  extern __shared__ __attribute__((aligned(16))) char xn_s[];
   const int tok = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
   const float *xr = x + (size_t)tok * K;
+  if constexpr (NORM) {
+    float *xn = (float *)xn_s;
+    const int tid = threadIdx.x, nvec = K / 4;
+    float sum = 0.f;
+    if (tid < 256)
+      for (int v = tid; v < nvec; v += 256) {
+        const float4 t = *(const float4 *)(xr + 4 * v);
+        sum = fmaf(t.x, t.x, sum); sum = fmaf(t.y, t.y, sum); sum = fmaf(t.z, t.z, sum); sum = fmaf(t.w, t.w, sum);
+      }
+    sum = wave_sum(sum);
+    if (tid < 256 && lane == 0) red[wave] = sum;
+    __syncthreads();
+    const float inv = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)K + eps);
+    for (int v = tid; v < nvec; v += blockDim.x) {
+      const float4 t = *(const float4 *)(xr + 4 * v), w = *(const float4 *)(norm_w + 4 * v);
+      *(float4 *)(xn + 4 * v) = make_float4(t.x * inv * w.x, t.y * inv * w.y, t.z * inv * w.z, t.w * inv * w.w);
+    }
+    __syncthreads();
+    xr = xn;
+  }
   for (int e = wave; e < E; e += nwaves) {
     float s = 0.f;
     const float *wr = gate_w + (size_t)e * K;
@@ -580,7 +606,19 @@ extern "C" int mrs_moe_router_topk(const float *x, const float *gate_w, int toke
   if (tokens <= 0) return 0;
   if (n_experts < 1 || n_experts > 64 || top_k < 1 || top_k > n_experts || (K & 3)) return -1;
   const int waves = n_experts < 4 ? 4 : (n_experts > 16 ? 16 : n_experts);
-  hipLaunchKernelGGL(mrs::moe_router_kernel, dim3(tokens), dim3(64 * waves), 0, (hipStream_t)stream, x, gate_w, n_experts, K, top_k, renormalize, ids, weights, logits_out);
+  hipLaunchKernelGGL(mrs::moe_router_kernel<false>, dim3(tokens), dim3(64 * waves), 0, (hipStream_t)stream, x, gate_w, n_experts, K, top_k, renormalize, ids, weights,
+                     logits_out, (const float *)nullptr, 0.f);
+  return 0;
+}
+// the same on the un-normed hidden state: RmsNorm(h) * norm_w (the values mrs_rms_norm_f32 writes) computed inside the router's workgroup; -3: row too long for LDS
+extern "C" int mrs_moe_router_topk_norm(const float *h, const float *norm_w, float eps, const float *gate_w, int tokens, int n_experts, int K, int top_k, int renormalize,
+                                        int32_t *ids, float *weights, void *stream) {
+  if (tokens <= 0) return 0;
+  if (n_experts < 1 || n_experts > 64 || top_k < 1 || top_k > n_experts || (K & 3) || !norm_w) return -1;
+  if ((size_t)K * 4 > 64 * 1024) return -3;
+  const int waves = n_experts < 4 ? 4 : (n_experts > 16 ? 16 : n_experts);
+  hipLaunchKernelGGL(mrs::moe_router_kernel<true>, dim3(tokens), dim3(64 * waves), (size_t)K * 4, (hipStream_t)stream, h, gate_w, n_experts, K, top_k, renormalize, ids,
+                     weights, (float *)nullptr, norm_w, eps);
   return 0;
 }
 

@@ -494,8 +494,11 @@ class Llama {
         // TP (moe/experts/mod.rs:332-339): every expert is sharded on the ffn dimension like a dense FFN; h <- h / world + sum of the local experts' partial
         // outputs, then ONE all-reduce per MoE block (the router is replicated: every rank picks the same experts)
         const int E = cfg.num_experts, tk = cfg.num_experts_per_tok;
-        mrs_rms_norm_f32(ws.h, bl.post_attention_layernorm, ws.xn, b, d, cfg.rms_eps, (int64_t)(intptr_t)s);
-        if (mrs_moe_router_topk(ws.xn, bl.router, b, E, d, tk, 1, ws.moe_ids, ws.moe_w, nullptr, s)) return fail("moe router refused (experts %d, top-k %d)", E, tk);
+        const int rrc = mrs_moe_router_topk_norm(ws.h, bl.post_attention_layernorm, cfg.rms_eps, bl.router, b, E, d, tk, 1, ws.moe_ids, ws.moe_w, s);  // norm inside the router
+        if (rrc == -3) {
+          mrs_rms_norm_f32(ws.h, bl.post_attention_layernorm, ws.xn, b, d, cfg.rms_eps, (int64_t)(intptr_t)s);
+          if (mrs_moe_router_topk(ws.xn, bl.router, b, E, d, tk, 1, ws.moe_ids, ws.moe_w, nullptr, s)) return fail("moe router refused (experts %d, top-k %d)", E, tk);
+        } else if (rrc) return fail("moe router refused (experts %d, top-k %d)", E, tk);
         for (int t = 0; t < b; ++t) {
           float *ht = ws.h + (size_t)t * d;
           // all of a token's expert activations are computed before h changes: one launch for the top-k experts (-3: shapes that do not split -> one per expert)

@@ -329,3 +329,33 @@ def test_proj_top2_host_emulation(oracle, tname, n, k, experts, sels):
 @pytest.mark.parametrize("tname,n,k,experts,sels", [("Q4_K", 4096, 14336, 8, [5, 2]), ("Q6_K", 4096, 14336, 4, [3, 0]), ("Q4_K", 1000, 4096, 4, [1, 2])])
 def test_proj_top2_gpu(oracle, dev, tname, n, k, experts, sels):
     check_proj_top2(oracle, GpuBackend(dev), tname, n, k, experts, sels)
+
+
+def _check_router_norm(be, tokens, E, K, topk):
+    """mrs_moe_router_topk_norm (RmsNorm inside the router's workgroup) == mrs_rms_norm_f32 followed by mrs_moe_router_topk: same ids, same weights bit for bit."""
+    rng = np.random.default_rng(E + K + tokens)
+    h = (rng.standard_normal((tokens, K)) * 1.7).astype(np.float32)
+    nw = (1.0 + 0.05 * rng.standard_normal(K)).astype(np.float32)
+    gw = (rng.standard_normal((E, K)) * 0.05).astype(np.float32)
+    hb, nb, gb = be.buf(h), be.buf(nw), be.buf(gw)
+    xn = be.buf(np.zeros((tokens, K), np.float32))
+    ids_a, w_a = be.buf(np.full((tokens, topk), -1, np.int32)), be.buf(np.zeros((tokens, topk), np.float32))
+    ids_b, w_b = be.buf(np.full((tokens, topk), -1, np.int32)), be.buf(np.zeros((tokens, topk), np.float32))
+    be.sym("mrs_rms_norm_f32", [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_float, C.c_int64])(hb.ptr, nb.ptr, xn.ptr, tokens, K, 1e-5, 0)
+    R = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert be.sym("mrs_moe_router_topk", R, C.c_int)(xn.ptr, gb.ptr, tokens, E, K, topk, 1, ids_a.ptr, w_a.ptr, None, be.stream) == 0
+    RN = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert be.sym("mrs_moe_router_topk_norm", RN, C.c_int)(hb.ptr, nb.ptr, 1e-5, gb.ptr, tokens, E, K, topk, 1, ids_b.ptr, w_b.ptr, be.stream) == 0
+    np.testing.assert_array_equal(ids_b.numpy(), ids_a.numpy())
+    np.testing.assert_array_equal(w_b.numpy(), w_a.numpy())
+
+
+@pytest.mark.parametrize("tokens,E,K,topk", [(1, 8, 4096, 2), (3, 4, 512, 2), (2, 16, 1024, 3), (1, 3, 256, 1)])
+def test_router_with_fused_norm_host_emulation(tokens, E, K, topk):
+    _check_router_norm(HostBackend(), tokens, E, K, topk)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tokens,E,K,topk", [(1, 8, 4096, 2), (8, 8, 4096, 2), (2, 64, 2048, 6)])
+def test_router_with_fused_norm_gpu(dev, tokens, E, K, topk):
+    _check_router_norm(GpuBackend(dev), tokens, E, K, topk)

@@ -105,3 +105,4 @@ def test_indexed_moe_forward_abi(oracle, dev, tname, input_dim1):
         want, mag = oracle.matmul_q8_1_mag(t, w[e * n:(e + 1) * n], n, k, y[row:row + 1])
         tol = 8 * 2.0 ** -23 * np.sqrt(k / 16) * mag[0].astype(np.float64) + 2.0 ** -23 * np.abs(want[0]) + 1e-30
         assert (np.abs(got[task] - want[0]) <= tol).all(), task
+
