@@ -72,7 +72,7 @@ def main():
     dt = time.perf_counter() - t0
     step_bytes = m.decode_bytes(1, a.prompt_len + a.warmup + a.steps // 2)
     print(json.dumps({"metric": "decode_tokens_per_sec", "value": round(a.steps / dt, 2), "unit": "tokens/s", "n_gpus": 1, "steps": a.steps,
-                      "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 4), "dtype": "q4_k/q6_k weights x q8_1 activations",
+                      "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 4), "dtype": ("q4_k/q6_k weights x q8_k activations (decode engine: the reference CPU path's arithmetic)" if m.decode_path == "engine" else "q4_k/q6_k weights x q8_1 activations"), "decode_path": m.decode_path,
                       "data": "synthetic", "config": {"workload": f"Mixtral-8x7B-shaped GGUF Q4_K_M ({cfg.num_layers} layers, 8 experts top-2), TP=1, "
                                                                   f"{a.prompt_len}-token prompt ({a.prompt_path} prompt path) / {a.steps} decode, batch 1"},
                       "step_bytes": int(step_bytes), "step_roofline_frac": round(step_bytes * a.steps / dt / 8e12, 4),
