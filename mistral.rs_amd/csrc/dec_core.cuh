@@ -20,6 +20,7 @@
 //     per-16 sums; integer dots with v_dot4_i32_i8, integer scale / min combination, two f32 FMAs per unit, DPP wave reduction per row.
 #pragma once
 #include "gguf_blocks.cuh"
+#include <type_traits>
 
 #ifndef MRS_WAVE_SYNC
 #define MRS_WAVE_SYNC() __builtin_amdgcn_wave_barrier() /* lanes of a wave exchange through LDS in lockstep; the host emulation maps this to a fiber sync */
@@ -97,7 +98,13 @@ template <int CTRL> __device__ __forceinline__ int dppi(int v) { return __builti
 // column's values (and the norm weights) into registers with buffer loads -- thread t takes the float4 at t*4 + j*2048, i.e. wave w owns the
 // 256-blocks w, w+8, ... -- then the caller fills the ring, then act_finish() normalises / quantizes while the weights are in flight.
 // Rows longer than 16384 values (or 8192 with a norm) take the remaining pieces after the ring (correct, just later).
-constexpr int ACT_MAXV = 16384 / (MRS_DEC_NT * 4), ACT_MAXW = 8192 / (MRS_DEC_NT * 4);  // register-resident pieces: rows of <= 16384 values (8192 with a norm)
+#ifndef MRS_ACT_MAXV
+#define MRS_ACT_MAXV (16384 / (MRS_DEC_NT * 4))
+#endif
+#ifndef MRS_ACT_MAXW
+#define MRS_ACT_MAXW (8192 / (MRS_DEC_NT * 4))
+#endif
+constexpr int ACT_MAXV = MRS_ACT_MAXV, ACT_MAXW = MRS_ACT_MAXW;  // register-resident pieces: rows of <= 16384 values (8192 with a norm)
 struct ActPre { v4u xv[ACT_MAXV]; v4u wv[ACT_MAXW]; };
 __device__ __forceinline__ float4 as_f4(v4u v) { return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)); }
 
@@ -201,8 +208,13 @@ __device__ __forceinline__ void quantize4(float4 v, int e, int qoff, bool in, in
 // batched step stays bit-identical to single sequences), then every column is quantized: 2 barriers per launch instead of 2 per column.
 template <int NCOLS, bool SC1>
 __device__ __forceinline__ Act act_finish(char *smem, float *red, const ActPre &pre, const float *__restrict__ x, int ldx, const float *__restrict__ nw, float eps,
-                                          int K, int mode) {
+                                          int K, int mode, unsigned long long *tlp = nullptr) {
   const int tid = tid_opaque(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef MRS_DEC_TIMELINE
+#define MRS_TLP(i) do { if (tlp && tid == 0) tlp[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MRS_TLP(i) do { } while (0)
+#endif
   char *q = smem;
   float *d = (float *)(smem + (size_t)NCOLS * K);
   int *bs = (int *)(d + (size_t)NCOLS * (K / 32));
@@ -226,7 +238,9 @@ __device__ __forceinline__ Act act_finish(char *smem, float *red, const ActPre &
       ss = wave_sum_all(ss);
       if (lane == 0) red[c * NW + wave] = ss;
     }
+    MRS_TLP(19);  // wave 0: activations arrived, squares summed
     __syncthreads();
+    MRS_TLP(9);   // after the norm barrier
 #pragma unroll
     for (int c = 0; c < NCOLS; ++c) {
       const float *r = red + c * NW;
@@ -256,9 +270,73 @@ __device__ __forceinline__ Act act_finish(char *smem, float *red, const ActPre &
       if (j < nv) one(j, c == 0 ? as_f4(pre.xv[j]) : xload(j), j < ACT_MAXW ? as_f4(pre.wv[j < ACT_MAXW ? j : 0]) : (nw ? wload(j) : make_float4(1.f, 1.f, 1.f, 1.f)));
     for (int j = ACT_MAXV; j < nv; ++j) one(j, xload(j), nw ? wload(j) : make_float4(1.f, 1.f, 1.f, 1.f));
   }
+  MRS_TLP(20);  // wave 0 quantized its share
   __syncthreads();
   return Act{q, d, bs, K};
 }
+
+// The same prologue for ONE column, cut into stages that stream() interleaves with the issue of the weight ring (round 3).  Measured with the
+// timeline build (profiles/round3_decode_timeline.md): a wave spends the first ~3 us of a launch blocked on the ISSUE of its ring loads (every CU asks
+// for 64-80 KiB at once and the memory system accepts requests at HBM rate), then ~2-7 us in the prologue's VALU work while nothing new is
+// requested.  The activation vector arrives long before the ring is accepted (it is first in the queue), so its arithmetic can run in the issue
+// slots between two ring loads: stage 1 = squares + partial sums, stage 2 = norm barrier + inverse, stages 3.. = one quantize pass each
+// (without a norm the passes start at stage 1).  Same instructions on the same values in the same order per element: bit-identical to act_finish.
+template <int D> struct ActStager {
+  char *smem; float *red; const float *x; const float *nw; float eps; int K, mode;
+  unsigned long long *tlp;  // timeline builds
+  bool staged;  // wave-uniform; false: finish() runs the whole prologue (act_finish)
+  float inv;
+  __device__ __forceinline__ int first_q() const { return nw ? 3 : 1; }
+  __device__ __forceinline__ void quant(int j, const ActPre &pre) {
+    const int tid = tid_opaque(), wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qoff0 = (((tid >> 2) ^ sb_mask(wave)) << 4) | ((tid & 3) << 2);
+    char *q = smem;
+    float *d = (float *)(smem + (size_t)K);
+    int *bs = (int *)(d + (size_t)(K / 32));
+    const int e = tid * 4 + j * ACT_STRIDE;
+    float4 v = as_f4(pre.xv[j]);
+    if (nw) { const float4 w4 = as_f4(pre.wv[j < ACT_MAXW ? j : 0]); v.x = v.x * inv * w4.x; v.y = v.y * inv * w4.y; v.z = v.z * inv * w4.z; v.w = v.w * inv * w4.w; }
+    quantize4(v, e, qoff0 + j * ACT_STRIDE, e < K, mode, q, d, bs);
+  }
+  template <int I> __device__ __forceinline__ void stage(const ActPre &pre) {
+    if (!staged) return;
+    const int tid = tid_opaque(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nv = (K + ACT_STRIDE - 1) / ACT_STRIDE;
+    if (nw) {
+      if constexpr (I == 1) {
+        float ss = 0.f;
+        auto sq = [&](float4 v4) { ss = fmaf(v4.x, v4.x, ss); ss = fmaf(v4.y, v4.y, ss); ss = fmaf(v4.z, v4.z, ss); ss = fmaf(v4.w, v4.w, ss); };
+#pragma unroll
+        for (int j = 0; j < ACT_MAXV; ++j) if (j < nv) sq(as_f4(pre.xv[j]));
+        ss = wave_sum_all(ss);
+        if (lane == 0) red[wave] = ss;
+      } else if constexpr (I == 2) {
+        __syncthreads();
+        const float *r = red;
+        float tot = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        if constexpr (NW == 16) tot += ((r[8] + r[9]) + (r[10] + r[11])) + ((r[12] + r[13]) + (r[14] + r[15]));
+        inv = 1.0f / sqrtf(tot / (float)K + eps);
+      } else if constexpr (I >= 3 && I - 3 < ACT_MAXV) {
+        if (I - 3 < nv) quant(I - 3, pre);
+      }
+    } else {
+      if constexpr (I >= 1 && I - 1 < ACT_MAXV) {
+        if (I - 1 < nv) quant(I - 1, pre);
+      }
+    }
+  }
+  // passes the stages did not reach + the closing barrier (staged), or the whole prologue
+  __device__ __forceinline__ Act finish(const ActPre &pre) {
+    const int nv = (K + ACT_STRIDE - 1) / ACT_STRIDE;
+    const int done = D - first_q();
+#pragma unroll
+    for (int j = 0; j < ACT_MAXV; ++j) if (j >= done && j < nv) quant(j, pre);
+    __syncthreads();
+    return Act{smem, (const float *)(smem + (size_t)K), (const int *)(smem + (size_t)K + (size_t)(K / 32) * 4), K};
+  }
+  // rows the register-resident pieces cover, a norm whose weights fit the registers
+  static __device__ __forceinline__ bool fits(int K, bool norm) { return K <= ACT_MAXV * ACT_STRIDE && (!norm || K <= ACT_MAXW * ACT_STRIDE); }
+};
 
 // ------------------------------------------------------------------------------------------------ per-format tiles
 // A tile = what the 64 lanes of a wave take from one row in one step.  Raw = the registers a lane holds for it (filled by buffer loads);
@@ -437,8 +515,9 @@ struct Segs {
 };
 
 // SEGCOL (NCOLS must be 1): segment s multiplies by activation column s of a 2-column image (MoE down: two experts' rows against their own activations)
-template <int TYPE, int NCOLS, bool SEGCOL = false, class Pre, class Pro, class Epi>
-__device__ __forceinline__ void stream(const Segs &sg, int K, Pre pre, Pro pro, Epi epi, bool skip_acc = false) {
+struct NoStager {};
+template <int TYPE, int NCOLS, bool SEGCOL = false, class Pre, class Pro, class Epi, class Stg = NoStager>
+__device__ __forceinline__ void stream(const Segs &sg, int K, Pre pre, Pro pro, Epi epi, bool skip_acc = false, Stg *stg = nullptr) {
   using TL = Tile<TYPE>;
   constexpr int D = TL::DEPTH;
   const int lane = lane_opaque();
@@ -461,8 +540,24 @@ __device__ __forceinline__ void stream(const Segs &sg, int K, Pre pre, Pro pro, 
     if (++lt == tpr) { lt = 0; if (++lr == (lseg == 0 ? rows0 : rows1) && lseg == 0 && rows1 > 0) { lr = 0; lseg = 1; } }
   };
   const auto pr = pre();  // activation loads first: they are small and must not wait behind the ring in the in-order return queue
+  if constexpr (std::is_same<Stg, NoStager>::value) {
 #pragma unroll
-  for (int i = 0; i < D; ++i) issue(ring[i]);
+    for (int i = 0; i < D; ++i) issue(ring[i]);
+  } else {  // prologue stages in the issue slots between the ring loads (ActStager)
+    static_assert(D == 4 || D == 8 || D == 12 || D == 16, "ring depth");
+#ifdef MRS_DEC_TIMELINE
+#define MRS_TLS(i) do { if (stg->tlp && tid_opaque() == 0) stg->tlp[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MRS_TLS(i) do { } while (0)
+#endif
+#define MRS_ISSUE_STAGE(i) __builtin_amdgcn_sched_barrier(0); issue(ring[i]); MRS_TLS(21 + i); __builtin_amdgcn_sched_barrier(0); stg->template stage<i>(pr)
+    issue(ring[0]); MRS_TLS(21);
+    MRS_ISSUE_STAGE(1); MRS_ISSUE_STAGE(2); MRS_ISSUE_STAGE(3);
+    if constexpr (D >= 8) { MRS_ISSUE_STAGE(4); MRS_ISSUE_STAGE(5); MRS_ISSUE_STAGE(6); MRS_ISSUE_STAGE(7); }
+    if constexpr (D >= 12) { MRS_ISSUE_STAGE(8); MRS_ISSUE_STAGE(9); MRS_ISSUE_STAGE(10); MRS_ISSUE_STAGE(11); }
+    if constexpr (D >= 16) { MRS_ISSUE_STAGE(12); MRS_ISSUE_STAGE(13); MRS_ISSUE_STAGE(14); MRS_ISSUE_STAGE(15); }
+    __builtin_amdgcn_sched_barrier(0);
+  }
   const Act act = pro(pr);
   const Act act1 = Act{act.q + K, act.d + K / 32, act.bs + K / 16, K};  // column 1 (SEGCOL)
   const typename TL::LaneC lc = TL::lanec(lane);

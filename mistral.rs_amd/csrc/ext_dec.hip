@@ -42,7 +42,18 @@ struct GemvArgs {
   int ablate;                 // experiments (MRS_DEC_ABLATE): 1 = skip the activation prologue's arithmetic, 2 = skip the accumulate (loads only)
   int slots, slot_out_stride;  // GLU with several experts of ONE token in a launch (MoE top-k): unit u -> slot u / nrows[0], expert expert_sel[slot], output out + slot * slot_out_stride
   const void *x_img;          // activations already quantized by the producer (decode_attn_fused_kernel): the LDS image of NCOLS columns, byte for byte
+  int staged;                 // 1: the one-column prologue runs in stages between the ring loads (dec_core.cuh ActStager); set by the launcher
+  unsigned long long *tl;     // experiment builds (-DMRS_DEC_TIMELINE): 8 s_memrealtime stamps per workgroup of this launch (scripts/exp/timeline.py)
 };
+
+// -DMRS_DEC_TIMELINE: lane 0 of wave `w` writes the 100 MHz constant clock into slot i of its workgroup's record
+#ifdef MRS_DEC_TIMELINE
+#define MRS_TL(a, w, i) do { if ((a).tl && tid_opaque() == (w) * 64) (a).tl[blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define MRS_TLW(a, i) do { if ((a).tl && (tid_opaque() & 63) == 0) (a).tl[blockIdx.x * 32 + (i) + (tid_opaque() >> 6)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MRS_TL(a, w, i) do { } while (0)
+#define MRS_TLW(a, i) do { } while (0)
+#endif
 
 #define MRS_DEC_TYPE_SWITCH(t, ...)                              \
   switch (t) {                                                   \
@@ -52,6 +63,20 @@ struct GemvArgs {
   case T_Q8_0: { constexpr int TT = T_Q8_0; __VA_ARGS__ } break; \
   default: break;                                                \
   }
+
+// one stream() call of gemv_phase: the staged prologue (one column, launch-per-phase, f32 activations) or the plain one
+#define MRS_DEC_STREAM(TYPE_EXPR, NC, SEGCOL, sg, epi, skip)                                                                         \
+  MRS_DEC_TYPE_SWITCH(TYPE_EXPR, {                                                                                                   \
+    ActStager<Tile<TT>::DEPTH> stg_{smem, red, a.x, a.norm_w, a.eps, K, act_mode_for(TT), a.tl ? a.tl + blockIdx.x * 32 : nullptr, can_stage, 1.0f};                          \
+    auto pro2 = [&](const ActPre &p_) -> Act {                                                                                       \
+      if (!stg_.staged) return pro(p_);                                                                                              \
+      MRS_TLW(a, 1);                                                                                                                 \
+      const Act r_ = stg_.finish(p_);                                                                                                \
+      MRS_TL(a, 0, 10);                                                                                                              \
+      return r_;                                                                                                                     \
+    };                                                                                                                               \
+    stream<TT, NC, SEGCOL>(sg, K, pre, pro2, epi, skip, &stg_);                                                                      \
+  })
 
 // MRS_DEC_AGENT_IO (build experiment, off): in the persistent step, write the vectors handed to other CUs through at agent scope (sc1) and read them at
 // agent scope, with MRS_DEC_NOFENCE dropping the release / acquire fences of the phase barrier.  Measured: no faster, attention not covered.
@@ -78,6 +103,7 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6), lane = tid0 & 63;  // readfirstlane: lets hipcc keep everything derived from the wave index in SGPRs
   const int gw = blockIdx.x * NW + wave;
   const int K = a.K;
+  MRS_TL(a, 0, 0);
   // the activation image is staged once per workgroup
   auto pre = [&]() -> ActPre {
     if constexpr (LATE) return ActPre{};
@@ -98,9 +124,13 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
         return Act{smem, (const float *)(smem + (size_t)NCOLS * K), (const int *)(smem + (size_t)NCOLS * K + (size_t)NCOLS * (K / 32) * 4), K};
       }
       if (a.ablate & 1) { __syncthreads(); return Act{smem, (const float *)(smem + (size_t)NCOLS * K), (const int *)(smem + (size_t)NCOLS * K + (size_t)NCOLS * (K / 32) * 4), K}; }
-      return act_finish<NCOLS, false>(smem, red, p, a.x, a.ldx, a.norm_w, a.eps, K, act_mode_for(a.m[0].type));
+      MRS_TLW(a, 1);  // ring issued (per wave: slots 1..8)
+      const Act r = act_finish<NCOLS, false>(smem, red, p, a.x, a.ldx, a.norm_w, a.eps, K, act_mode_for(a.m[0].type), a.tl ? a.tl + blockIdx.x * 32 : nullptr);
+      MRS_TL(a, 0, 10);  // prologue done (after its last barrier)
+      return r;
     }
   };
+  const bool can_stage = NCOLS == 1 && !LATE && a.staged != 0 && !a.x_img && !(a.ablate & 1);
   int u0 = min(gw * a.units_per_wave, a.units), u1 = min(u0 + a.units_per_wave, a.units);
   int slot = 0;
   if (a.slots > 1) {  // the launcher made units_per_wave a divisor of nrows: a wave never straddles two experts
@@ -135,7 +165,7 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
         }
       }
     };
-    MRS_DEC_TYPE_SWITCH(a.m[0].type, (stream<TT, NCOLS>(sg, K, pre, pro, epi, (a.ablate & 2) != 0));)
+    MRS_DEC_STREAM(a.m[0].type, NCOLS, false, sg, epi, (a.ablate & 2) != 0)
   } else if constexpr (EPI == EPI_RESID2) {
     // MoE down of the two experts of one token in one launch (NCOLS == 2 = the two experts' activation vectors): a wave streams rows [u0, u1) of expert
     // sel[0] against column 0, then the same rows of expert sel[1] against column 1, and writes (out * resid_scale + w0 s0) * 1 + w1 s1 -- the two
@@ -157,7 +187,7 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
         if (lane == 0) st_out<LATE>(a.out + u0 + i, h1 * 1.0f + sum[0] * w1);
       }
     };
-    MRS_DEC_TYPE_SWITCH(a.m[0].type, (stream<TT, 1, true>(sg, K, pre, pro, epi, false));)
+    MRS_DEC_STREAM(a.m[0].type, 1, true, sg, epi, false)
   } else if constexpr (EPI == EPI_GLU) {
     Segs sg{};
     sg.nseg = 2; sg.mat[0] = a.m[0]; sg.mat[1] = a.m[1];
@@ -177,7 +207,7 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
         }
       }
     };
-    MRS_DEC_TYPE_SWITCH(a.m[0].type, (stream<TT, NCOLS>(sg, K, pre, pro, epi, (a.ablate & 2) != 0));)
+    MRS_DEC_STREAM(a.m[0].type, NCOLS, false, sg, epi, (a.ablate & 2) != 0)
   } else {  // EPI_QKV: units are RoPE pairs (2i, 2i+1); waves [wstart[i], wstart[i+1]) take tensor i (q, k, v), so a wave never straddles two tensors
     // (selects, not a.m[mi]: in the persistent kernel the arguments are a local struct and a dynamic index would push it into scratch memory)
     const int mi = gw >= a.wstart[2] ? 2 : (gw >= a.wstart[1] ? 1 : 0);
@@ -244,7 +274,7 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
     };
     Segs sg{};
     sg.nseg = 1; sg.mat[0] = mi == 0 ? a.m[0] : (mi == 1 ? a.m[1] : a.m[2]); sg.row0[0] = r0; sg.nrows[0] = 2 * (p1 - p0);
-    MRS_DEC_TYPE_SWITCH(sg.mat[0].type, (stream<TT, NCOLS>(sg, K, pre, pro, epi, (a.ablate & 2) != 0));)
+    MRS_DEC_STREAM(sg.mat[0].type, NCOLS, false, sg, epi, (a.ablate & 2) != 0)
   }
 }
 
@@ -253,6 +283,7 @@ __global__ void __launch_bounds__(NT) dec_gemv_kernel(const GemvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ float red[8 * NW];  // RMSNorm partials: [column][wave]
   gemv_phase<NCOLS, EPI>(a, smem, red);
+  MRS_TLW(a, 11);  // per-wave end: slots 11..18
 }
 
 // ------------------------------------------------------------------------------------------------ persistent decode step
@@ -502,6 +533,18 @@ __global__ void __launch_bounds__(FUSED_NW * 64) decode_attn_fused_kernel(const 
   }
 }
 
+// experiment support (-DMRS_DEC_TIMELINE builds): mrs_dec_timeline(buf, cap) hands the launchers a device buffer of cap records of 256 x 32 stamps;
+// launch i of the process writes record i % cap, its epilogue kind goes to the host-side log read back with mrs_dec_timeline_log
+static unsigned long long *g_tl_buf = nullptr;
+static int g_tl_cap = 0, g_tl_next = 0;
+static int g_tl_kind[4096];
+static unsigned long long *timeline_slot(int kind) {
+  if (!g_tl_buf || g_tl_cap <= 0) return nullptr;
+  const int i = g_tl_next++ % g_tl_cap;
+  g_tl_kind[i % 4096] = kind;
+  return g_tl_buf + (size_t)i * 256 * 32;
+}
+
 template <int EPI> struct Launch {
   template <int NCOLS> static int go(GemvArgs a, hipStream_t s) {
     int upw = (a.units + 256 * NW - 1) / (256 * NW);
@@ -509,6 +552,9 @@ template <int EPI> struct Launch {
     if (upw > 64) upw = 64;  // epilogue operands are prefetched one unit per lane
     { static int ov = -1; if (ov < 0) { const char *e = getenv("MRS_DEC_UPW"); ov = e ? atoi(e) : 0; } if (ov > 0 && ov <= 64) upw = ov; }
     { static int ab = -1; if (ab < 0) { const char *e = getenv("MRS_DEC_ABLATE"); ab = e ? atoi(e) : 0; } a.ablate = ab; }
+    a.tl = timeline_slot(EPI);
+    { static int stg = -1; if (stg < 0) { const char *e = getenv("MRS_DEC_STAGED"); stg = e ? atoi(e) : 1; }
+      a.staged = stg && NCOLS == 1 && EPI != EPI_RESID2 && !a.x_img && a.K <= ACT_MAXV * ACT_STRIDE && (!a.norm_w || a.K <= ACT_MAXW * ACT_STRIDE); }
     if (a.slots > 1) {  // units = slots * nrows: waves must not straddle experts
       while (upw > 1 && a.nrows[0] % upw) --upw;
       if (a.nrows[0] % upw) return -3;
@@ -530,6 +576,9 @@ template <int EPI> struct Launch {
     return 0;
   }
   static int run(const GemvArgs &a, int b, hipStream_t s) {
+#ifdef MRS_DEC_EXP_B1  // experiment builds: batch 1 only (an eighth of the compile time)
+    return b == 1 ? go<1>(a, s) : -1;
+#endif
     switch (b) {
     case 1: return go<1>(a, s); case 2: return go<2>(a, s); case 3: return go<3>(a, s); case 4: return go<4>(a, s);
     case 5: return go<5>(a, s); case 6: return go<6>(a, s); case 7: return go<7>(a, s); case 8: return go<8>(a, s);
@@ -546,6 +595,8 @@ using namespace mrs::dec;
 
 struct mrs_dec_mat_c { const void *planes; int type; long long n, k; };  // == mrs_dec_mat (include/mrs_hip_ext.h)
 
+extern "C" void mrs_dec_timeline(void *buf, int cap) { g_tl_buf = (unsigned long long *)buf; g_tl_cap = cap > 4096 ? 4096 : cap; g_tl_next = 0; }
+extern "C" int mrs_dec_timeline_log(int *kinds, int n) { const int m = g_tl_next < g_tl_cap ? g_tl_next : g_tl_cap; for (int i = 0; i < n && i < m; ++i) kinds[i] = g_tl_kind[i]; return g_tl_next; }
 extern "C" int mrs_dec_supported(int ggml_type) { return dec_type(ggml_type) ? 1 : 0; }
 extern "C" size_t mrs_dec_repack_bytes(int type, long long n, long long k) {
   if (!dec_type(type) || k % 32 || (type != T_Q8_0 && k % 256)) return 0;

@@ -251,6 +251,7 @@ extern "C" inline __bf16 __truncsfbf2(float f) {
 #define __builtin_amdgcn_readlane(V, L) hiphost::exchange((int)(V), (L))
 #define __builtin_amdgcn_readfirstlane(V) hiphost::exchange((int)(V), 0) /* kernels use it on wave-uniform values only */
 #define __builtin_amdgcn_sched_group_barrier(MASK, SIZE, SYNC) ((void)0) /* instruction-order hint only */
+#define __builtin_amdgcn_sched_barrier(MASK) ((void)0)                  /* instruction-order hint only */
 #define MRS_OPAQUE_TID(t) ((void)0)
 #define MRS_WAIT_VMCNT0() ((void)0)                                     /* product code: s_waitcnt vmcnt(0) */
 #define __builtin_amdgcn_fence(ORDER, SCOPE) ((void)0)                  /* one workgroup runs at a time: nothing to order */
