@@ -70,6 +70,17 @@ size_t mrs_dec_act_image_bytes(int k, int b);
 int mrs_dec_attention_q8k(void *img_out, float *out_f32, const float *q, const void *k_cache, const void *v_cache, int num_kv_heads, float scale,
                           const uint32_t *block_tables, const uint32_t *context_lens, int block_size, int max_context_len, int num_seqs, int num_heads,
                           int head_size, int max_blocks_per_seq, int q_stride, int kv_block_stride, int kv_head_stride, int kv_dtype, void *stream);
+/* Decode attention of the engine in ONE launch (round 3 default): split-KV waves (32-token blocks, f32 online softmax through the reference's
+ * fast_exp, attention/backends/cpu/elem.rs:417-433) publish their partials; the last workgroup to arrive on the (sequence, kv head) ticket merges them
+ * in the order of single_q.rs run_barrier and writes out_f32 [b][num_heads * 128] (may be NULL when an image is requested) and, for even GQA groups
+ * and b <= 8, the Q8_K activation image img_out (may be NULL) for mrs_dec_proj_img.  ticket: [b * num_kv_heads] u32, zero before the first call
+ * (left zero); part_o / part_m / part_l: b * num_heads * mrs_decode_attention_max_splits(max_context_len) x {128, 1, 1} floats.
+ * Returns 1 when the image was written, 0 when only out_f32 was, -1 for shapes outside the kernel (head size 128, block 32, GQA 1 / 2 / 4 / 8). */
+int mrs_dec_attention(float *out_f32, void *img_out, unsigned *ticket, float *part_o, float *part_m, float *part_l, const float *q, const void *k_cache,
+                      const void *v_cache, int num_kv_heads, float scale, const uint32_t *block_tables, const uint32_t *context_lens, int block_size,
+                      int max_context_len, int num_seqs, int num_heads, int head_size, int max_blocks_per_seq, int q_stride, int kv_block_stride,
+                      int kv_head_stride, int kv_dtype, void *stream);
+size_t mrs_dec_proj_img_max_bytes(void); /* largest activation image mrs_dec_proj_img stages */
 /* GEMV on a pre-quantized activation image (K-quant weights only; -3: image larger than the prologue's staging registers) */
 int mrs_dec_proj_img(const mrs_dec_mat *w, int n, const void *x_img, float *out, int ld_out, int mode, float resid_scale, int b, void *stream);
 /* Persistent decode step: ONE launch runs phases [phase_begin, phase_end) of a decode step for one sequence (b = 1) on a grid of resident

@@ -135,4 +135,22 @@ __device__ __forceinline__ float glu_act(float x, int act) {
   }
 }
 
+// The reference's Cephes-style exp of its CPU attention (mistralrs-core/src/attention/backends/cpu/elem.rs:417-433), operation for operation
+// (the build pins -ffp-contract=off): the decode engine takes every exponential through it, so that a CPU evaluates the same bits
+// (oracle/cpu_path_oracle.c orc_fast_exp).  f32::round = half away from zero.
+__device__ __forceinline__ float fast_exp_ref(float x) {
+  const float LOG2E = 1.44269504088896340736f, C0 = 0.6933594f, C1 = -2.1219444e-4f;
+  x = fminf(fmaxf(x, -87.0f), 87.0f);
+  const float zx = x * LOG2E;
+  const float zt = truncf(zx);
+  const float z = fabsf(zx - zt) >= 0.5f ? zt + copysignf(1.0f, zx) : zt;
+  const float r = x - z * C0 - z * C1;
+  const float r2 = r * r;
+  const float p = r + r2 * (0.5f + r * (0.16666546f + r * (0.041665795f + r * (0.00833345f + r * 0.0013920345f))));
+  const float e = __uint_as_float((unsigned)(((int)z + 127) << 23));
+  return e * (1.0f + p);
+}
+// SiLU of the decode engine: x / (1 + exp(-x)) (mistralrs-quant/src/utils/ops.rs:2601-2612) with the exponential above
+__device__ __forceinline__ float silu_engine(float x) { return x / (1.0f + fast_exp_ref(-x)); }
+
 }  // namespace mrs

@@ -1,9 +1,11 @@
-// dec_attn.cuh -- decode attention of the decode engine as wave-level device functions (used by the persistent step kernel of ext_dec.hip).
-// Same arithmetic, in the same order, as decode_attn_wave_kernel<G, CT, false> + decode_attn_merge_q8_1_kernel<128, true> of
-// paged_attention.cuh (so the persistent step and the launch-per-phase step produce identical bits): one wave per 32-token KV chunk range of
-// one (sequence, kv head): online softmax in f32 for the G query heads of the GQA group, probabilities kept in f32 (the reference CPU path,
-// attention/backends/cpu/single_q.rs), partial (m, l, o) per split; then one wave per (sequence, head) merges the splits.
-// Semantics of the split / merge: pagedattention.cuh:110-486 (v2 partitions + reduce), 1 / (sum + 1e-6).
+// dec_attn.cuh -- decode attention of the decode engine as wave-level device functions: the split kernel with the last-arriver merge
+// (ext_dec.hip dec_attn2_kernel, the default), the persistent step kernel and the one-launch short-context kernel all call these, so every
+// engine path produces the same bits.  One wave per range of 32-token KV blocks of one (sequence, kv head): online softmax in f32 for the G query
+// heads of the GQA group, probabilities kept in f32, partial (m, l, o) per split; then the splits are merged per head.
+// Arithmetic = the reference CPU attention (mistralrs-core/src/attention/backends/cpu/single_q.rs): tile max, correction and probabilities
+// through the reference's fast_exp (elem.rs:417-433, common.cuh fast_exp_ref), merge as run_barrier (:108-157: weights exp(m_c - m_all), sums and
+// outputs accumulated chunk by chunk with separate multiply and add, out = acc * (1 / s_all), no epsilon); the f32 summation ORDER inside a
+// block is the kernel's own and is written down in oracle/cpu_path_oracle.c orc_attention_engine, which the kernels equal bit for bit.
 #pragma once
 #include "paged_attention.cuh"
 
@@ -71,11 +73,11 @@ __device__ __forceinline__ void attn_split_core(const AttnArgs &a, int kvh, int 
       mx = fmaxf(mx, dpp_f<0xB1>(mx)); mx = fmaxf(mx, dpp_f<0x4E>(mx)); mx = fmaxf(mx, dpp_f<0x141>(mx)); mx = fmaxf(mx, dpp_f<0x140>(mx));
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       const float mn = fmaxf(m[g], mx);
-      const float p = valid ? __expf(v - mn) : 0.f;
+      const float p = valid ? fast_exp_ref(v - mn) : 0.f;
       float ps = p;
       ps += dpp_f<0xB1>(ps); ps += dpp_f<0x4E>(ps); ps += dpp_f<0x141>(ps); ps += dpp_f<0x140>(ps);
       ps += __shfl_xor(ps, 16, 64);
-      const float alpha = __expf(m[g] - mn);
+      const float alpha = fast_exp_ref(m[g] - mn);
       l[g] = l[g] * alpha + ps;
       o0[g] *= alpha; o1[g] *= alpha;
       m[g] = mn;
@@ -120,35 +122,26 @@ __device__ __forceinline__ void attn_split_item(const AttnArgs &a, int kvh, int 
 }
 
 // one wave merges the splits of (seq, head): lane j <-> split j for the weights, lane d / d + 64 for the output dims
-// ns (<= 64) partials of one head: pm / pl [ns], po [ns][128]; returns the head's output at dims lane (v0) and lane + 64 (v1)
+// ns (<= 64) partials of one head: pm / pl [ns], po [ns][128]; returns the head's output at dims lane (v0) and lane + 64 (v1).
+// Order (single_q.rs:108-157): w_j = fast_exp(m_j - max m); s += l_j * w_j and acc += o_j * w_j for j ascending, multiply and add separate.
 __device__ __forceinline__ void attn_merge_core(int ns, const float *pm, const float *pl, const float *po, float &v0, float &v1) {
   constexpr int HD = 128;
   const int lane = lane_opaque();
   const float mj = lane < ns ? pm[lane] : -FLT_MAX;
   const float lj = lane < ns ? pl[lane] : 0.f;
   const float mx = wave_max(mj);
-  const float r = lane < ns ? __expf(mj - mx) : 0.f;
-  const float gs = wave_sum(lj * r);
-  // the standalone merge kernel sums four interleaved chains over the splits: same order here
-  float a0[2] = {0.f, 0.f}, a1[2] = {0.f, 0.f}, a2[2] = {0.f, 0.f}, a3[2] = {0.f, 0.f};
-  int j = 0;
-  for (; j + 4 <= ns; j += 4) {
-    const float r0 = __shfl(r, j, 64), r1 = __shfl(r, j + 1, 64), r2 = __shfl(r, j + 2, 64), r3 = __shfl(r, j + 3, 64);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const float *pp = po + lane + 64 * h;
-      a0[h] = fmaf(pp[(size_t)(j + 0) * HD], r0, a0[h]); a1[h] = fmaf(pp[(size_t)(j + 1) * HD], r1, a1[h]);
-      a2[h] = fmaf(pp[(size_t)(j + 2) * HD], r2, a2[h]); a3[h] = fmaf(pp[(size_t)(j + 3) * HD], r3, a3[h]);
-    }
+  const float w = fast_exp_ref(mj - mx);
+  float s_all = 0.f, a0 = 0.f, a1 = 0.f;
+  for (int j = 0; j < ns; ++j) {
+    const float wj = __shfl(w, j, 64), lw = __shfl(lj, j, 64) * wj;
+    s_all = s_all + lw;
+    const float t0 = po[(size_t)j * HD + lane] * wj, t1 = po[(size_t)j * HD + lane + 64] * wj;
+    a0 = a0 + t0;
+    a1 = a1 + t1;
   }
-  for (; j < ns; ++j) {
-    const float rj = __shfl(r, j, 64);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) a0[h] = fmaf(po[(size_t)j * HD + lane + 64 * h], rj, a0[h]);
-  }
-  const float inv = 1.0f / (gs + 1e-6f);
-  v0 = ((a0[0] + a1[0]) + (a2[0] + a3[0])) * inv;
-  v1 = ((a0[1] + a1[1]) + (a2[1] + a3[1])) * inv;
+  const float inv = 1.0f / s_all;
+  v0 = a0 * inv;
+  v1 = a1 * inv;
 }
 __device__ __forceinline__ void attn_merge_item(const AttnArgs &a, int head, int seq) {
   const int lane = lane_opaque();

@@ -155,6 +155,14 @@ __device__ __forceinline__ float round_away(float x) {
   return fabsf(x - t) >= 0.5f ? t + copysignf(1.0f, x) : t;
 }
 
+// x / m for the RmsNorm (candle: x / sqrt(mean + eps) * w): y = 1 / m correctly rounded (computed once per column), then Markstein's final step
+// q0 = x y, r = x - m q0 (exact in the fma), q = q0 + r y -- the correctly rounded quotient (checked against `/`: tests/test_dec_engine.py)
+__device__ __forceinline__ float div_by(float x, float m, float y) {
+  const float q0 = x * y;
+  const float r = fmaf(-m, q0, x);
+  return fmaf(r, y, q0);
+}
+
 // quantize the 4 values a lane holds at element e (all lanes of the wave together: one 256-block in Q8_K mode, 8 blocks of 32 in Q8_0 mode).
 // qoff = byte offset of the lane's 4 quants inside the column's (swizzled) int8 image.
 __device__ __forceinline__ void quantize4(float4 v, int e, int qoff, bool in, int mode, char *qc, float *dc, int *bsc) {
@@ -222,9 +230,9 @@ __device__ __forceinline__ Act act_finish(char *smem, float *red, const ActPre &
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)(nw ? nw : x), (short)0, nw ? K * 4 : 0, 0x00020000);
   auto wload = [&](int j) -> float4 { return as_f4(ld_act<false>(rw, (unsigned)tid * 16u + (unsigned)j * (unsigned)(ACT_STRIDE * 4))); };
   auto col_rsrc = [&](int c) { return __builtin_amdgcn_make_buffer_rsrc((void *)(x + (size_t)c * ldx), (short)0, K * 4, 0x00020000); };
-  float inv[NCOLS];
+  float nm[NCOLS], inv[NCOLS];  // m = sqrt(mean + eps) and 1 / m
 #pragma unroll
-  for (int c = 0; c < NCOLS; ++c) inv[c] = 1.0f;
+  for (int c = 0; c < NCOLS; ++c) { nm[c] = 1.0f; inv[c] = 1.0f; }
   if (nw) {  // sum of squares: per-thread partials in element order, DPP wave sums, the wave sums in wave order
 #pragma unroll
     for (int c = 0; c < NCOLS; ++c) {
@@ -246,7 +254,8 @@ __device__ __forceinline__ Act act_finish(char *smem, float *red, const ActPre &
       const float *r = red + c * NW;
       float tot = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
       if constexpr (NW == 16) tot += ((r[8] + r[9]) + (r[10] + r[11])) + ((r[12] + r[13]) + (r[14] + r[15]));
-      inv[c] = 1.0f / sqrtf(tot / (float)K + eps);
+      nm[c] = sqrtf(tot / (float)K + eps);
+      inv[c] = 1.0f / nm[c];
     }
   }
   // byte offset of the lane's 4 quants in the swizzled image: piece = e >> 4 = tid / 4 + 128 j, superblock = piece >> 4 = wave + 8 j, so the XOR
@@ -259,10 +268,10 @@ __device__ __forceinline__ Act act_finish(char *smem, float *red, const ActPre &
     char *qc = q + (size_t)c * K;
     float *dc = d + (size_t)c * (K / 32);
     int *bsc = bs + (size_t)c * (K / 16);
-    const float ic = inv[c];
+    const float ic = inv[c], mc = nm[c];
     auto one = [&](int j, float4 v, float4 w4) {  // uniform trip count: every lane takes part in the cross-lane steps
       const int e = tid * 4 + j * ACT_STRIDE;
-      if (nw) { v.x = v.x * ic * w4.x; v.y = v.y * ic * w4.y; v.z = v.z * ic * w4.z; v.w = v.w * ic * w4.w; }
+      if (nw) { v.x = div_by(v.x, mc, ic) * w4.x; v.y = div_by(v.y, mc, ic) * w4.y; v.z = div_by(v.z, mc, ic) * w4.z; v.w = div_by(v.w, mc, ic) * w4.w; }
       quantize4(v, e, qoff0 + j * ACT_STRIDE, e < K, mode, qc, dc, bsc);
     };
 #pragma unroll
@@ -285,7 +294,7 @@ template <int D> struct ActStager {
   char *smem; float *red; const float *x; const float *nw; float eps; int K, mode;
   unsigned long long *tlp;  // timeline builds
   bool staged;  // wave-uniform; false: finish() runs the whole prologue (act_finish)
-  float inv;
+  float inv, nm;
   __device__ __forceinline__ int first_q() const { return nw ? 3 : 1; }
   __device__ __forceinline__ void quant(int j, const ActPre &pre) {
     const int tid = tid_opaque(), wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -295,7 +304,10 @@ template <int D> struct ActStager {
     int *bs = (int *)(d + (size_t)(K / 32));
     const int e = tid * 4 + j * ACT_STRIDE;
     float4 v = as_f4(pre.xv[j]);
-    if (nw) { const float4 w4 = as_f4(pre.wv[j < ACT_MAXW ? j : 0]); v.x = v.x * inv * w4.x; v.y = v.y * inv * w4.y; v.z = v.z * inv * w4.z; v.w = v.w * inv * w4.w; }
+    if (nw) {
+      const float4 w4 = as_f4(pre.wv[j < ACT_MAXW ? j : 0]);
+      v.x = div_by(v.x, nm, inv) * w4.x; v.y = div_by(v.y, nm, inv) * w4.y; v.z = div_by(v.z, nm, inv) * w4.z; v.w = div_by(v.w, nm, inv) * w4.w;
+    }
     quantize4(v, e, qoff0 + j * ACT_STRIDE, e < K, mode, q, d, bs);
   }
   template <int I> __device__ __forceinline__ void stage(const ActPre &pre) {
@@ -315,7 +327,8 @@ template <int D> struct ActStager {
         const float *r = red;
         float tot = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
         if constexpr (NW == 16) tot += ((r[8] + r[9]) + (r[10] + r[11])) + ((r[12] + r[13]) + (r[14] + r[15]));
-        inv = 1.0f / sqrtf(tot / (float)K + eps);
+        nm = sqrtf(tot / (float)K + eps);
+        inv = 1.0f / nm;
       } else if constexpr (I >= 3 && I - 3 < ACT_MAXV) {
         if (I - 3 < nv) quant(I - 3, pre);
       }

@@ -67,7 +67,7 @@ struct GemvArgs {
 // one stream() call of gemv_phase: the staged prologue (one column, launch-per-phase, f32 activations) or the plain one
 #define MRS_DEC_STREAM(TYPE_EXPR, NC, SEGCOL, sg, epi, skip)                                                                         \
   MRS_DEC_TYPE_SWITCH(TYPE_EXPR, {                                                                                                   \
-    ActStager<Tile<TT>::DEPTH> stg_{smem, red, a.x, a.norm_w, a.eps, K, act_mode_for(TT), a.tl ? a.tl + blockIdx.x * 32 : nullptr, can_stage, 1.0f};                          \
+    ActStager<Tile<TT>::DEPTH> stg_{smem, red, a.x, a.norm_w, a.eps, K, act_mode_for(TT), a.tl ? a.tl + blockIdx.x * 32 : nullptr, can_stage, 1.0f, 1.0f};                          \
     auto pro2 = [&](const ActPre &p_) -> Act {                                                                                       \
       if (!stg_.staged) return pro(p_);                                                                                              \
       MRS_TLW(a, 1);                                                                                                                 \
@@ -203,7 +203,7 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
           gsave[c] = lane == i ? sum[c] : gsave[c];
         } else {
           const float g = rl(gsave[c], i);
-          if (lane == 0) st_out<LATE>(a.out + (size_t)slot * a.slot_out_stride + (size_t)c * a.out_stride + (row - eoff), glu_act(g, a.activation) * sum[c]);
+          if (lane == 0) st_out<LATE>(a.out + (size_t)slot * a.slot_out_stride + (size_t)c * a.out_stride + (row - eoff), (a.activation == 0 ? silu_engine(g) : glu_act(g, a.activation)) * sum[c]);
         }
       }
     };
@@ -533,6 +533,96 @@ __global__ void __launch_bounds__(FUSED_NW * 64) decode_attn_fused_kernel(const 
   }
 }
 
+// ------------------------------------------------------------------------------------------------ decode attention, split + last-arriver merge
+// Round 3 default.  Grid (kv heads, sequences, ceil(max splits / 4)), 4 waves = 4 splits per workgroup, no barrier in the split phase (as
+// decode_attn_wave_kernel).  Instead of a second launch for the merge (4.9 us + a kernel boundary per layer), every workgroup publishes its
+// partials write-through at agent scope, drains its stores and takes a ticket on the (sequence, kv head) counter; the workgroup that draws the
+// last ticket merges all G heads of the kv head: wave w = query heads 2w, 2w + 1 (256 output values = ONE Q8_K superblock of the attention
+// vector), lane = 4 consecutive dims, sequential over the splits (attn_merge_core's order).  It writes the f32 result and -- what o_proj's
+// prologue would otherwise recompute in all 256 workgroups -- the Q8_K activation image that dec_gemv_kernel copies into LDS (quantize4: same
+// lane <-> element mapping as the prologue, so the same bits).  The counter resets itself; hand-off recipe: MI355X guide, "handoff-flag"
+// (sc1 payload -> vmcnt(0) -> agent atomic; consumer: returned atomic -> sc1 loads).
+struct Attn2Args {
+  AttnArgs t;
+  unsigned *ticket;  // [seqs][kv heads], zero at rest
+  uint8_t *img;      // Q8_K image of [seqs] columns of num_heads * 128 values, or nullptr (odd GQA groups: the caller's o_proj quantizes)
+};
+template <int G, class CT>
+__global__ void __launch_bounds__(256) dec_attn2_kernel(const Attn2Args a) {
+  constexpr int HD = 128;
+  __shared__ __attribute__((aligned(16))) float q_s[4][G * HD + G * 32];
+  __shared__ int last_s;
+  const AttnArgs &t = a.t;
+  const int tid = tid_opaque(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kvh = blockIdx.x, seq = blockIdx.y;
+  const int nblk = ((int)t.context_lens[seq] + 31) / 32;
+  const int ns = (nblk + t.bpw - 1) / t.bpw, nwg = (ns + 3) / 4;
+  if ((int)blockIdx.z >= nwg) return;  // workgroup-uniform: no split of this sequence lands here
+  const int split = blockIdx.z * 4 + wave, head0 = kvh * G;
+  if (split < ns) {
+    const int b0 = split * t.bpw, b1 = min(b0 + t.bpw, nblk);
+    attn_split_core<G, CT>(t, kvh, head0, seq, b0, b1, q_s[wave], q_s[wave] + G * HD, [&](int g, float o0, float o1, float m, float l) {
+      const size_t pi = ((size_t)seq * t.num_heads + head0 + g) * t.max_splits + split;
+      __hip_atomic_store(t.part_o + pi * HD + lane, o0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(t.part_o + pi * HD + lane + 64, o1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) {
+        __hip_atomic_store(t.part_m + pi, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(t.part_l + pi, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    });
+  }
+  MRS_WAIT_VMCNT0();  // this wave's partials have left the CU
+  __syncthreads();
+  unsigned *tk = a.ticket + (size_t)seq * t.num_kv_heads + kvh;
+  if (tid == 0) last_s = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nwg - 1);
+  __syncthreads();
+  if (!last_s) return;
+  if (tid == 0) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every other workgroup of this (seq, kv head) has already drawn
+  // ---- merge: wave w <-> heads (2w, 2w + 1) of the group (G == 1: wave 0, one head in lanes 0..31)
+  constexpr int NP = (G + 1) / 2;
+  if (wave >= NP) return;
+  const int hsel = lane >> 5, head = head0 + 2 * wave + hsel;
+  const bool live = 2 * wave + hsel < G;
+  const size_t pA = ((size_t)seq * t.num_heads + head0 + 2 * wave) * t.max_splits;                 // partials of head A (lanes 0..31)
+  const size_t pB = ((size_t)seq * t.num_heads + head0 + min(2 * wave + 1, G - 1)) * t.max_splits;  // head B (lanes 32..63)
+  auto ldw = [&](const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  const float mA = lane < ns ? ldw(t.part_m + pA + lane) : -FLT_MAX, lA = lane < ns ? ldw(t.part_l + pA + lane) : 0.f;
+  const float mB = lane < ns ? ldw(t.part_m + pB + lane) : -FLT_MAX, lB = lane < ns ? ldw(t.part_l + pB + lane) : 0.f;
+  const float wA = fast_exp_ref(mA - wave_max(mA)), wB = fast_exp_ref(mB - wave_max(mB));
+  // one descriptor for both heads' partials (wave-uniform); the lanes of head B add its distance
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)(t.part_o + pA * HD), (short)0, (int)((pB - pA + ns) * HD * 4), 0x00020000);
+  const unsigned off0 = (unsigned)(lane & 31) * 16u + (hsel ? (unsigned)((pB - pA) * HD * 4) : 0u);
+  float s_all = 0.f;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto step = [&](int j, v4u raw) {
+    const float wAj = __shfl(wA, j, 64), wBj = __shfl(wB, j, 64), lAj = __shfl(lA, j, 64), lBj = __shfl(lB, j, 64);  // all lanes take part in every exchange
+    const float wj = hsel ? wBj : wAj, lj = hsel ? lBj : lAj;
+    const float lw = lj * wj;
+    s_all = s_all + lw;
+    const float4 o = as_f4(raw);
+    const float t0 = o.x * wj, t1 = o.y * wj, t2 = o.z * wj, t3 = o.w * wj;
+    acc.x = acc.x + t0; acc.y = acc.y + t1; acc.z = acc.z + t2; acc.w = acc.w + t3;
+  };
+  int j = 0;
+  for (; j + 4 <= ns; j += 4) {  // four agent-scope (sc1) loads in flight per lane
+    const v4u r0 = __builtin_amdgcn_raw_buffer_load_b128(ro, off0 + (unsigned)(j + 0) * 512u, 0, 16), r1 = __builtin_amdgcn_raw_buffer_load_b128(ro, off0 + (unsigned)(j + 1) * 512u, 0, 16);
+    const v4u r2 = __builtin_amdgcn_raw_buffer_load_b128(ro, off0 + (unsigned)(j + 2) * 512u, 0, 16), r3 = __builtin_amdgcn_raw_buffer_load_b128(ro, off0 + (unsigned)(j + 3) * 512u, 0, 16);
+    step(j, r0); step(j + 1, r1); step(j + 2, r2); step(j + 3, r3);
+  }
+  for (; j < ns; ++j) step(j, __builtin_amdgcn_raw_buffer_load_b128(ro, off0 + (unsigned)j * 512u, 0, 16));
+  const float inv = 1.0f / s_all;
+  const float4 v = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+  if (t.out && live) *(float4 *)(t.out + ((size_t)seq * t.num_heads + head) * HD + (lane & 31) * 4) = v;
+  if (a.img) {  // G even: the wave's 256 values = superblock (head0 + 2 wave) / 2 of column seq
+    const int K = t.num_heads * HD, ncols = gridDim.y, sb = (head0 + 2 * wave) >> 1;
+    char *qc = (char *)a.img + (size_t)seq * K;
+    float *dc = (float *)(a.img + (size_t)ncols * K) + (size_t)seq * (K / 32);
+    int *bsc = (int *)(a.img + (size_t)ncols * K + (size_t)ncols * (K / 32) * 4) + (size_t)seq * (K / 16);
+    const int e = sb * 256 + lane * 4, piece = e >> 4;
+    quantize4(v, e, ((piece ^ sb_mask(sb)) << 4) | ((lane & 3) << 2), true, ACT_Q8K, qc, dc, bsc);
+  }
+}
+
 // experiment support (-DMRS_DEC_TIMELINE builds): mrs_dec_timeline(buf, cap) hands the launchers a device buffer of cap records of 256 x 32 stamps;
 // launch i of the process writes record i % cap, its epilogue kind goes to the host-side log read back with mrs_dec_timeline_log
 static unsigned long long *g_tl_buf = nullptr;
@@ -691,6 +781,7 @@ extern "C" int mrs_dec_proj_img(const mrs_dec_mat_c *w, int n, const void *x_img
   return mode ? Launch<EPI_RESID>::run(a, b, (hipStream_t)stream) : Launch<EPI_STORE>::run(a, b, (hipStream_t)stream);
 }
 extern "C" size_t mrs_dec_act_image_bytes(int k, int b) { return act_bytes(k, b); }
+extern "C" size_t mrs_dec_proj_img_max_bytes(void) { return (size_t)ACT_MAXV * NT * 16; }
 // Decode attention for short contexts in one launch: img_out = Q8_K activation image [b columns][num_heads * 128] for mrs_dec_proj_img, out_f32
 // (may be NULL) = the f32 result [b][num_heads * 128].  Returns -3 when the shape is outside the kernel (max_context_len > 1024, GQA group
 // not a multiple of 2, head size != 128, block size != 32): the caller uses mrs_decode_attention_f32_* + mrs_dec_proj.
@@ -719,6 +810,41 @@ extern "C" int mrs_dec_attention_q8k(void *img_out, float *out_f32, const float 
   if (kv_dtype == 1) { if (nw == 8) go(decode_attn_fused_kernel<2, bf16_t, 8>); else go(decode_attn_fused_kernel<2, bf16_t, 12>); }
   else { if (nw == 8) go(decode_attn_fused_kernel<2, f16_t, 8>); else go(decode_attn_fused_kernel<2, f16_t, 12>); }
   return 0;
+}
+
+// Decode attention of the engine, one launch (dec_attn2_kernel).  out_f32 [b][num_heads * 128] (may be NULL when an image is written);
+// img_out: Q8_K activation image for mrs_dec_proj_img (written when the GQA group is even; may be NULL); ticket: [b * num_kv_heads] u32, zero
+// before the first call (the kernel leaves it zero); part_*: the partials workspace of mrs_decode_attention_f32_*.  Returns 1 when the image
+// was written, 0 when only out_f32 was, < 0 on a shape outside the kernel (head size 128, 32-token pages, GQA group 1 / 2 / 4 / 8).
+extern "C" int mrs_dec_attention(float *out_f32, void *img_out, unsigned *ticket, float *part_o, float *part_m, float *part_l, const float *q, const void *k_cache,
+                                 const void *v_cache, int num_kv_heads, float scale, const uint32_t *block_tables, const uint32_t *context_lens, int block_size,
+                                 int max_context_len, int num_seqs, int num_heads, int head_size, int max_blocks_per_seq, int q_stride, int kv_block_stride,
+                                 int kv_head_stride, int kv_dtype, void *stream) {
+  if (!ticket || !part_o || !part_m || !part_l || block_size != 32 || head_size != 128 || num_seqs <= 0 || num_kv_heads <= 0 || num_heads % num_kv_heads ||
+      (kv_dtype != 0 && kv_dtype != 1) || max_context_len <= 0) return -1;
+  const int G = num_heads / num_kv_heads;
+  if (G != 1 && G != 2 && G != 4 && G != 8) return -1;
+  const bool with_img = img_out && (G % 2 == 0) && num_seqs <= 8;
+  if (!with_img && !out_f32) return -1;
+  Attn2Args a{};
+  AttnArgs &t = a.t;
+  t.q = q; t.k_cache = (const uint16_t *)k_cache; t.v_cache = (const uint16_t *)v_cache; t.block_tables = block_tables; t.context_lens = context_lens;
+  t.part_o = part_o; t.part_m = part_m; t.part_l = part_l; t.out = out_f32;
+  t.num_heads = num_heads; t.num_kv_heads = num_kv_heads; t.max_blocks_per_seq = max_blocks_per_seq; t.q_stride = q_stride;
+  t.kv_block_stride = kv_block_stride; t.kv_head_stride = kv_head_stride; t.num_seqs = num_seqs; t.scale = scale;
+  const int nblk = (max_context_len + 31) / 32;
+  t.bpw = nblk <= 64 ? 1 : (nblk + 63) / 64;                        // == dec_bpw() of paged_attention.hip: at most 64 splits
+  t.max_splits = mrs_decode_attention_max_splits(max_context_len);  // stride of the partials, as in the two-launch route
+  a.ticket = ticket; a.img = with_img ? (uint8_t *)img_out : nullptr;
+  const int nsplit = (nblk + t.bpw - 1) / t.bpw;
+  const dim3 grid(num_kv_heads, num_seqs, (nsplit + 3) / 4);
+  hipStream_t s = (hipStream_t)stream;
+#define MRS_A2(GG, CT) hipLaunchKernelGGL((dec_attn2_kernel<GG, CT>), grid, dim3(256), 0, s, a)
+#define MRS_A2G(CT) switch (G) { case 1: MRS_A2(1, CT); break; case 2: MRS_A2(2, CT); break; case 4: MRS_A2(4, CT); break; default: MRS_A2(8, CT); break; }
+  if (kv_dtype == 1) { MRS_A2G(bf16_t) } else { MRS_A2G(f16_t) }
+#undef MRS_A2G
+#undef MRS_A2
+  return with_img ? 1 : 0;
 }
 
 // ---- persistent decode step (one launch for a range of phases; b = 1)

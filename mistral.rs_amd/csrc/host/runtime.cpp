@@ -180,7 +180,8 @@ struct Workspace {  // carve-up of the caller's scratch
   void *moe_y;              // [top_k] Q8_1 rows of the selected experts' activations
   void *dec_table, *dec_sync;  // persistent decode step: device table of layers, 2 x u32 sync words
   float *moe_act;           // decode engine: [top_k][intermediate] f32 activations of the selected experts
-  void *attn_img;           // decode engine: Q8_K activation image of the attention result (mrs_dec_attention_q8k -> mrs_dec_proj_img)
+  void *attn_img;           // decode engine: Q8_K activation image of the attention result (mrs_dec_attention / mrs_dec_attention_q8k -> mrs_dec_proj_img)
+  unsigned *attn_ticket;    // decode engine: [max_batch][kv heads] arrival counters of mrs_dec_attention (zero at rest)
 };
 
 class Llama {
@@ -196,6 +197,7 @@ class Llama {
   bool have_bufs = false;
   mutable bool dec_table_ready = false, dec_table_unfit = false;
   int dec_persist = [] { const char *e = getenv("MRS_DEC_PERSIST"); return e ? atoi(e) : 0; }();  // default 0: measured slower than per-phase kernels on MI355X
+  int attn2 = [] { const char *e = getenv("MRS_DEC_ATTN2"); return e ? atoi(e) : 1; }();  // decode engine attention: 1 = split kernel with the last-arriver merge + Q8_K image for o_proj (round 3, one launch), 0 = split + merge launches
   int fused_attn = [] { const char *e = getenv("MRS_DEC_FUSED_ATTN"); return e ? atoi(e) : 0; }();  // decode engine: one-launch attention for contexts <= 1024; measured 1-5 % SLOWER per token than split + merge (profiles/round2_decode_experiments.md 5): off
   void *comm = nullptr;  // RCCL communicator (ext_comm.hip) when cfg.world_size > 1
   void *p2p = nullptr;   // one-shot peer-mailbox all-reduce (ext_p2p.hip) for decode-sized messages
@@ -226,7 +228,7 @@ class Llama {
     t += align(B * c.num_heads * parts * c.head_dim * 4) + 2 * align(B * c.num_heads * parts * 4);
     t += align(B * 8);
     t += align(mrs_dec_step_table_bytes(c.num_layers)) + align(64);  // persistent decode step: layer table, sync words
-    t += align(mrs_dec_act_image_bytes((int)nq, (int)B));
+    t += align(mrs_dec_act_image_bytes((int)nq, (int)B)) + align(B * (size_t)c.num_kv_heads * 4);
     if (c.num_experts > 0) {
       const size_t k = std::max(1, (int)c.num_experts_per_tok);
       t += align(B * k * 4) * 2 + align(k * (pad_to(c.intermediate_size, MATRIX_ROW_PADDING) / 32) * 36);
@@ -255,6 +257,7 @@ class Llama {
     ws.sample_scratch = take(B * 8);
     ws.dec_table = take(mrs_dec_step_table_bytes(cfg.num_layers)); ws.dec_sync = take(64);
     ws.attn_img = take(mrs_dec_act_image_bytes((int)nq, (int)B));
+    ws.attn_ticket = (unsigned *)take(B * (size_t)cfg.num_kv_heads * 4);
     dec_table_ready = false; dec_table_unfit = false;
     if (cfg.num_experts > 0) {
       const size_t k = std::max(1, (int)cfg.num_experts_per_tok);
@@ -479,6 +482,16 @@ class Llama {
       if (arc != 0 && arc != -3) return fail("fused decode attention / o_proj failed (%d)", arc);
       if (arc == 0) {
         if (all_reduce(ws.h, (size_t)b * d, s)) return fail("o_proj all-reduce failed: %s", g_last_error.c_str());
+      } else if (attn2) {
+        // one launch: splits + last-arriver merge; even GQA groups hand o_proj the Q8_K image of the result (Q8_0 weights take Q8_0 activations: f32 result)
+        const bool want_img = bl.dout.type != 8 && (cfg.num_heads / kvh) % 2 == 0 && mrs_dec_act_image_bytes(nq, b) <= mrs_dec_proj_img_max_bytes();
+        const int rc2 = mrs_dec_attention(want_img ? nullptr : ws.attn, want_img ? ws.attn_img : nullptr, ws.attn_ticket, (float *)ws.attn_ws, ws.max_logits, ws.exp_sums, ws.q,
+                                          bl.key_cache, bl.value_cache, kvh, 1.0f / sqrtf((float)hd), bufs.block_tables, bufs.context_lens, bs, eff_max, b, cfg.num_heads, hd,
+                                          cfg.max_blocks_per_seq, nq, kvh * hd * bs, hd * bs, kvd, s);
+        if (rc2 < 0) return fail("mrs_dec_attention refused the shape");
+        const int prc = rc2 == 1 ? mrs_dec_proj_img(&bl.dout, d, ws.attn_img, ws.h, d, 1, rs, b, s)
+                                 : mrs_dec_proj(&bl.dout, d, nullptr, ws.attn, nq, nullptr, 0.f, ws.h, d, 1, rs, nullptr, b, s);
+        if (prc || all_reduce(ws.h, (size_t)b * d, s)) return fail("o_proj failed (%d): %s", prc, g_last_error.c_str());
       } else {
         if (mrs_decode_attention_f32_f32_bf16(ws.attn, ws.exp_sums, ws.max_logits, ws.attn_ws, ws.q, bl.key_cache, bl.value_cache, kvh, 1.0f / sqrtf((float)hd),
                                               bufs.block_tables, bufs.context_lens, bs, eff_max, b, cfg.num_heads, hd, cfg.max_blocks_per_seq, nq, kvh * hd * bs,

@@ -82,6 +82,22 @@ void orc_fused_glu(const float *a, const float *b, float *out, int64_t n, int ac
 void orc_attention(const float *q, const float *k, const float *v, float *out, int T, int S,
                    int H, int KVH, int hd, float scale, float softcap);
 
+/* ---- oracle/cpu_path_oracle.c (round 3): the in-tree CPU decode path restated, and the engine's own f32 orders ---- */
+float orc_fast_exp(float x);   /* attention/backends/cpu/elem.rs:417-433 */
+/* single_q.rs run_barrier / compute_group_range, portable elem.rs bodies: q [H][hd], k / v [kv_len][KVH][hd], out [H][hd] */
+void orc_attention_single_q_cpu(const float *q, const float *k, const float *v, float *out, int kv_len, int H, int KVH, int hd,
+                                float scale, int n_kv_chunks);
+void orc_rms_norm_candle(const float *x, const float *w, float *out, int rows, int d, float eps); /* x / sqrt(mean + eps) * w, f32 sums in order */
+void orc_rms_norm_engine(const float *x, const float *w, float *out, int rows, int d, float eps); /* same expression, the engine's summation tree */
+int64_t orc_div_by_mismatches(const float *x, const float *m, int64_t n);                                   /* dec_core.cuh div_by vs `/` */
+float orc_silu_engine(float x);                                                                   /* x / (1 + fast_exp(-x)) */
+void orc_fused_glu_engine(const float *a, const float *b, float *out, int64_t n);
+void orc_attention_engine(const float *q, const float *k, const float *v, float *out, int kv_len, int H, int KVH, float scale, int bpw);
+/* llama_oracle.c: the reference CPU matvec with ONE f32 term per superblock, added in superblock order (a second CPU summation order) */
+int orc_gemv_cpu_fast(int type, const void *W, int N, int K, const float *x, float *out);
+/* cpu_path_oracle.c: the same integers and products in the decode engine's summation order (64 per-lane chains + butterfly) */
+int orc_gemv_engine(int type, const void *W, int N, int K, const float *x, float *out);
+
 void orc_set_threads(int n);
 int  orc_get_threads(void);
 

@@ -2,13 +2,19 @@
 
 CPU restatement of the Llama / Mistral decoder graph as the reference drives it
 (mistralrs-core/src/models/llama.rs:68-157 CausalSelfAttention, :243-260 Block, :487-518 forward_embeds),
-token by token with an eager KV cache.  `mode` selects the matmul arithmetic:
-  "q8_1"  the GPU path's dataflow: activations quantized to Q8_1 (mmvq_gguf.cu), integer dots (oracle C)
-  "cpu"   the reference CPU path: candle QMatMul = Q8_K / Q8_0 activations (oracle B; parity unpinned)
-  "cpu_fast"  as "cpu" with vectorisable dot loops + OpenMP rows (b = 1 only; used as cpu_baseline)
-  "exact" dequantized weights, f64 accumulation (oracle A)
-Everything else is f32 like the CPU path: RMSNorm, interleaved/neox RoPE, SiLU-GLU, softmax attention.
-`kv_dtype` in {"f32", "bf16", "f16"} rounds K/V on the way into the cache.
+token by token with an eager KV cache.  `mode` selects the arithmetic:
+  "q8_1"  the GPU path's dataflow: activations quantized to Q8_1 (mmvq_gguf.cu), integer dots (oracle C); f64 glue ops
+  "exact" dequantized weights, f64 accumulation (oracle A); f64 glue ops
+  "cpu"   the reference CPU path: candle QMatMul = Q8_K / Q8_0 activations with ggml's generic 8-lane f32 order (oracle B; parity unpinned),
+          candle's rms_norm (f32 sums in order, x / sqrt(mean + eps) * w), the in-tree CPU attention (single_q.rs + fast_exp,
+          cpu_path_oracle.c), SiLU with libm exp
+  "cpu_fast"  as "cpu", but every GEMV row = one f32 term per superblock added in superblock order (llama_oracle.c; OpenMP rows: the
+          cpu_baseline kernel) -- a second CPU evaluation of the same path, used to measure what f32 summation order alone does
+  "engine"    the decode engine's orders: GEMV = the same integers and products in the kernel's summation order (orc_gemv_engine), and the SAME rms_norm / attention / SiLU expressions with the summation trees of
+          the HIP kernels and the reference's fast_exp wherever an exponential is taken (cpu_path_oracle.c orc_*_engine): the HIP engine must
+          equal this mode bit for bit
+Everything else is f32 like the CPU path: interleaved/neox RoPE, residual adds.
+`kv_dtype` in {"f32", "bf16", "f16"} rounds K/V on the way into the cache; `attn_bpw` = 32-token blocks per attention split ("engine").
 """
 from __future__ import annotations
 
@@ -26,10 +32,12 @@ def _round(x, dt):
 
 
 class LlamaRef:
-    def __init__(self, cfg, weights: dict, cos: np.ndarray, sin: np.ndarray, mode: str = "q8_1", kv_dtype: str = "bf16"):
+    def __init__(self, cfg, weights: dict, cos: np.ndarray, sin: np.ndarray, mode: str = "q8_1", kv_dtype: str = "bf16", attn_bpw: int = 1,
+                 n_kv_chunks: int = 1):
         """cfg: object with hidden_size, intermediate_size, num_layers, num_heads, num_kv_heads, head_dim, vocab_size,
         rms_eps, rope_interleaved.  weights: GGUF name -> (ggml_type, packed uint8 [N, row_bytes]) or f32 array."""
         self.cfg, self.w, self.cos, self.sin, self.mode, self.kv_dtype = cfg, weights, cos, sin, mode, kv_dtype
+        self.attn_bpw, self.n_kv_chunks = attn_bpw, n_kv_chunks
         self.k = [[] for _ in range(cfg.num_layers)]
         self.v = [[] for _ in range(cfg.num_layers)]
 
@@ -41,9 +49,30 @@ class LlamaRef:
             return O.matmul_q8_1(t, packed, n, k, O.quantize_q8_1(x.reshape(-1, k)))
         if self.mode == "cpu":
             return O.matmul_cpu(t, packed, n, k, x.reshape(-1, k))
-        if self.mode == "cpu_fast":  # same arithmetic, throughput-oriented (bench.py cpu_baseline)
+        if self.mode == "cpu_fast":  # one f32 term per superblock, superblock order (bench.py cpu_baseline)
             return O.gemv_cpu_fast(t, packed, n, k, x.reshape(-1, k))
+        if self.mode == "engine":  # the decode engine's summation order
+            return np.concatenate([O.gemv_engine(t, packed, n, k, r) for r in x.reshape(-1, k)], axis=0)
         return O.matmul_exact(t, packed, n, k, x.reshape(-1, k))
+
+    # ---- glue ops by mode
+    def norm(self, x, w):
+        if self.mode == "engine":
+            return O.rms_norm_engine(x, w, self.cfg.rms_eps)
+        if self.mode in ("cpu", "cpu_fast"):
+            return O.rms_norm_candle(x, w, self.cfg.rms_eps)
+        return O.rms_norm(x, w, self.cfg.rms_eps)
+
+    def attend(self, q, k, v, scale):
+        """q [1, H, hd]; k, v [S, KVH, hd]"""
+        if self.mode == "engine":
+            return O.attention_engine(q[0], k, v, scale, self.attn_bpw)[None]
+        if self.mode in ("cpu", "cpu_fast"):
+            return O.attention_single_q_cpu(q[0], k, v, scale, self.n_kv_chunks)[None]
+        return O.attention(q, k, v, scale)
+
+    def glu(self, g, u):
+        return O.fused_glu_engine(g, u) if self.mode == "engine" else O.fused_glu(g, u, 0)
 
     def embed(self, ids) -> np.ndarray:
         t, packed = self.w["token_embd.weight"]
@@ -56,7 +85,7 @@ class LlamaRef:
         h = self.embed([token]).astype(np.float32)  # [1, d]
         for l in range(c.num_layers):
             p = f"blk.{l}."
-            xn = O.rms_norm(h, self.w[p + "attn_norm.weight"], c.rms_eps)
+            xn = self.norm(h, self.w[p + "attn_norm.weight"])
             q = self.linear(p + "attn_q.weight", xn).reshape(1, H, hd)
             k = self.linear(p + "attn_k.weight", xn).reshape(1, KVH, hd)
             v = self.linear(p + "attn_v.weight", xn).reshape(1, KVH, hd)
@@ -66,16 +95,16 @@ class LlamaRef:
             assert len(self.k[l]) == pos, "cache out of sync with position"
             self.k[l].append(_round(k[0], self.kv_dtype))
             self.v[l].append(_round(v[0], self.kv_dtype))
-            att = O.attention(q, np.stack(self.k[l]), np.stack(self.v[l]), 1.0 / np.sqrt(hd))
+            att = self.attend(q, np.stack(self.k[l]), np.stack(self.v[l]), np.float32(1.0 / np.sqrt(np.float32(hd))))
             h = h + self.linear(p + "attn_output.weight", att.reshape(1, H * hd))
-            xn = O.rms_norm(h, self.w[p + "ffn_norm.weight"], c.rms_eps)
+            xn = self.norm(h, self.w[p + "ffn_norm.weight"])
             if p + "ffn_gate_inp.weight" in self.w:
                 h = h + self.moe(p, xn)
                 continue
             g = self.linear(p + "ffn_gate.weight", xn)
             u = self.linear(p + "ffn_up.weight", xn)
-            h = h + self.linear(p + "ffn_down.weight", O.fused_glu(g, u, 0))
-        xn = O.rms_norm(h, self.w["output_norm.weight"], c.rms_eps)
+            h = h + self.linear(p + "ffn_down.weight", self.glu(g, u))
+        xn = self.norm(h, self.w["output_norm.weight"])
         return self.linear("output.weight", xn)[0]
 
     def moe(self, p: str, xn: np.ndarray) -> np.ndarray:
@@ -95,7 +124,7 @@ class LlamaRef:
             tu, pu = self.w[p + "ffn_up_exps.weight"]
             td, pd = self.w[p + "ffn_down_exps.weight"]
             self.w["_g"], self.w["_u"], self.w["_d"] = (tg, pg[e * ff:(e + 1) * ff]), (tu, pu[e * ff:(e + 1) * ff]), (td, pd[e * c.hidden_size:(e + 1) * c.hidden_size])
-            act = O.fused_glu(self.linear("_g", xn), self.linear("_u", xn), 0)
+            act = self.glu(self.linear("_g", xn), self.linear("_u", xn))
             out += np.float64(np.float32(wt)) * self.linear("_d", act).astype(np.float64)
         return out.astype(np.float32)
 

@@ -33,7 +33,7 @@ MOE_TYPE_NAMES = {**TYPE_NAMES, Q8_1: "q8_1"}
 
 def build(force: bool = False) -> str:
     """Compile the oracle (gcc).  Building the checker is not using it."""
-    srcs = [os.path.join(_HERE, f) for f in ("ggml_oracle.c", "llama_oracle.c", "ggml_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("ggml_oracle.c", "llama_oracle.c", "cpu_path_oracle.c", "ggml_oracle.h")]
     if (not force and os.path.exists(_LIB_PATH)
             and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
         return _LIB_PATH
@@ -56,6 +56,10 @@ def lib() -> C.CDLL:
         _lib.orc_fp32_to_fp16.argtypes = [C.c_float]
         _lib.orc_glu_act.restype = C.c_float
         _lib.orc_glu_act.argtypes = [C.c_float, C.c_int]
+        _lib.orc_fast_exp.restype = C.c_float
+        _lib.orc_fast_exp.argtypes = [C.c_float]
+        _lib.orc_silu_engine.restype = C.c_float
+        _lib.orc_silu_engine.argtypes = [C.c_float]
     return _lib
 
 
@@ -209,6 +213,15 @@ def gemv_cpu_fast(t: int, w: np.ndarray, n: int, k: int, x: np.ndarray) -> np.nd
     return out
 
 
+def gemv_engine(t: int, w: np.ndarray, n: int, k: int, x: np.ndarray) -> np.ndarray:
+    """b = 1 matvec in the decode engine's f32 summation order (cpu_path_oracle.c orc_gemv_engine): the HIP engine equals it bit for bit."""
+    x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
+    out = np.empty((1, n), dtype=np.float32)
+    if lib().orc_gemv_engine(t, _p(w), n, k, _p(x), _p(out)) != 0:
+        raise ValueError(f"the decode engine does not take ggml type {t}")
+    return out
+
+
 # ---------------------------------------------------------------- glue
 def rms_norm(x: np.ndarray, w: np.ndarray, eps: float) -> np.ndarray:
     x = np.ascontiguousarray(x, dtype=np.float32)
@@ -247,6 +260,64 @@ def attention(q, k, v, scale: float, softcap: float = 1.0) -> np.ndarray:
     s, kvh, _ = k.shape
     out = np.empty_like(q)
     lib().orc_attention(_p(q), _p(k), _p(v), _p(out), t, s, h, kvh, hd, C.c_float(scale), C.c_float(softcap))
+    return out
+
+
+# ---------------------------------------------------------------- the in-tree CPU decode path and the engine's orders (cpu_path_oracle.c)
+def fast_exp(x: float) -> float:
+    return float(lib().orc_fast_exp(C.c_float(x)))
+
+
+def rms_norm_candle(x: np.ndarray, w: np.ndarray, eps: float) -> np.ndarray:
+    """candle_nn::ops::rms_norm on the CPU: f32 sum of squares in element order, x / sqrt(mean + eps) * w."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    out = np.empty_like(x)
+    d = x.shape[-1]
+    lib().orc_rms_norm_candle(_p(x), _p(w), _p(out), x.size // d, d, C.c_float(eps))
+    return out
+
+
+def rms_norm_engine(x: np.ndarray, w: np.ndarray, eps: float) -> np.ndarray:
+    """Same expression with the decode engine's summation tree (csrc/dec_core.cuh act_finish)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    out = np.empty_like(x)
+    d = x.shape[-1]
+    lib().orc_rms_norm_engine(_p(x), _p(w), _p(out), x.size // d, d, C.c_float(eps))
+    return out
+
+
+def fused_glu_engine(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    out = np.empty_like(a)
+    lib().orc_fused_glu_engine(_p(a), _p(b), _p(out), C.c_int64(a.size))
+    return out
+
+
+def attention_single_q_cpu(q, k, v, scale: float, n_kv_chunks: int = 1) -> np.ndarray:
+    """attention/backends/cpu/single_q.rs for ONE query token: q [H, hd], k / v [S, KVH, hd] f32 -> [H, hd]."""
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    k = np.ascontiguousarray(k, dtype=np.float32)
+    v = np.ascontiguousarray(v, dtype=np.float32)
+    h, hd = q.shape
+    s, kvh, _ = k.shape
+    out = np.empty_like(q)
+    lib().orc_attention_single_q_cpu(_p(q), _p(k), _p(v), _p(out), s, h, kvh, hd, C.c_float(scale), int(n_kv_chunks))
+    return out
+
+
+def attention_engine(q, k, v, scale: float, bpw: int = 1) -> np.ndarray:
+    """The decode engine's attention order (csrc/dec_attn2.cuh), head size 128: q [H, 128], k / v [S, KVH, 128] -> [H, 128]."""
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    k = np.ascontiguousarray(k, dtype=np.float32)
+    v = np.ascontiguousarray(v, dtype=np.float32)
+    h, hd = q.shape
+    assert hd == 128
+    s, kvh, _ = k.shape
+    out = np.empty_like(q)
+    lib().orc_attention_engine(_p(q), _p(k), _p(v), _p(out), s, h, kvh, C.c_float(scale), int(bpw))
     return out
 
 

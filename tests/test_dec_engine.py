@@ -3,8 +3,12 @@
 integer block dots, f32 combination.  Checked against oracle B (oracle/ggml_oracle.c orc_matmul_cpu: dot_kquant_q8K / dot_legacy_q8).
 Same test bodies on the wave64 host emulation (CPU suite) and on the MI355X (`-m gpu`).
 
-Tolerance: with identical activations the integer parts are exact, so only the f32 summation order over the blocks of a row differs:
-|got - want| <= 4 * 2^-23 * sqrt(blocks) * sum|terms| is generous; the tests use 2e-5 * max|want| + that bound's typical size."""
+Two bars per case (round 3):
+  * BIT EQUALITY with the engine-order restatement (oracle/cpu_path_oracle.c: orc_gemv_engine, orc_rms_norm_engine, orc_fused_glu_engine,
+    orc_attention_engine): the same integers, the same f32 products, the kernel's documented summation order -- written from the format
+    definitions and the order's description, not from the kernel source;
+  * the generic ggml order (orc_matmul_cpu) within the f32-order tolerance: with identical activations the integer parts are exact, so only the
+    f32 summation order over the blocks of a row differs: 2e-5 * max|want| is generous."""
 import ctypes as C
 
 import numpy as np
@@ -49,8 +53,11 @@ def check_proj(O, be, tname, n, k, b, mode, seed=0):
     rs = 0.5
     assert fn(C.byref(m), n, None, xb.ptr, k, None, 0.0, ob.ptr, n, mode, rs, None, b, be.stream) == 0
     got = ob.numpy()
+    eng = np.concatenate([O.gemv_engine(t, packed, n, k, r) for r in x], axis=0)
     if mode:
         want = base * np.float32(rs) + want
+        eng = base * np.float32(rs) + eng * np.float32(1.0)
+    assert np.array_equal(got, eng), (tname, n, k, b, "engine-order oracle", float(np.abs(got - eng).max()))
     tol = 2e-5 * np.abs(want).max()
     assert np.abs(got - want).max() <= tol, (tname, n, k, b, float(np.abs(got - want).max()), tol)
 
@@ -74,18 +81,21 @@ def test_proj_gpu(oracle, dev, tname, n, k, b, mode):
 
 
 def check_norm_proj(O, be, tname, n, k, b):
-    """RMSNorm fused into the prologue: the normed row feeds the quantizer; a 1-ulp difference of the norm can move single quants by one
-    step, so the bar here is the quantization step, not the f32 order."""
+    """RMSNorm fused into the prologue (candle's x / sqrt(mean + eps) * w): bit-equal to the engine-order restatement (same expression, the
+    kernel's summation tree); against candle's in-order sum a 1-ulp difference of the norm can move single quants by one step, so that bar
+    is the quantization step, not the f32 order."""
     t = getattr(O, tname)
     packed = _weights(O, t, n, k, 3)
     keep, m = repack(be, O, t, packed, n, k)
     rng = np.random.default_rng(5)
     x = rng.standard_normal((b, k)).astype(np.float32)
     nw = (1.0 + 0.1 * rng.standard_normal(k)).astype(np.float32)
-    want = O.matmul_cpu(t, packed, n, k, O.rms_norm(x, nw, 1e-5))
+    want = O.matmul_cpu(t, packed, n, k, O.rms_norm_candle(x, nw, 1e-5))
     xb, nb, ob = be.buf(x), be.buf(nw), be.buf(np.zeros((b, n), dtype=np.float32))
     assert be.sym("mrs_dec_proj", PROJ, C.c_int)(C.byref(m), n, None, xb.ptr, k, nb.ptr, 1e-5, ob.ptr, n, 0, 1.0, None, b, be.stream) == 0
     got = ob.numpy()
+    eng = np.concatenate([O.gemv_engine(t, packed, n, k, r) for r in O.rms_norm_engine(x, nw, 1e-5)], axis=0)
+    assert np.array_equal(got, eng), (tname, n, k, b, "engine-order oracle", float(np.abs(got - eng).max()))
     assert np.abs(got - want).max() <= 2e-3 * np.abs(want).max()
     assert np.median(np.abs(got - want)) <= 2e-5 * np.abs(want).max()  # most outputs see identical quants
 
@@ -120,6 +130,10 @@ def check_gate_up(O, be, tname, n, k, b, experts=0, sel=0):
     fn = be.sym("mrs_dec_gate_up", GLU, C.c_int)
     assert fn(C.byref(mg), C.byref(mu), n, selb.ptr if selb else None, xb.ptr, k, None, 0.0, 0, ob.ptr, n, b, be.stream) == 0
     got = ob.numpy()
+    ge = np.concatenate([O.gemv_engine(t, pg[sel * n:(sel + 1) * n], n, k, r) for r in x], axis=0)
+    ue = np.concatenate([O.gemv_engine(t, pu[sel * n:(sel + 1) * n], n, k, r) for r in x], axis=0)
+    eng = O.fused_glu_engine(ge, ue)
+    assert np.array_equal(got, eng), (tname, n, k, b, "engine-order oracle", float(np.abs(got - eng).max()))
     assert np.abs(got - want).max() <= 3e-5 * np.abs(want).max() + 1e-7
 
 
@@ -204,46 +218,78 @@ ATTN_Q8K = [C.c_void_p] * 5 + [C.c_int, C.c_float, C.c_void_p, C.c_void_p] + [C.
 PROJ_IMG = [C.POINTER(Mat), C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]
 
 
-def check_fused_attention(O, be, heads, kvh, ctxs, max_ctx, kv_dtype=1, n_out=24, waves=None):
-    """mrs_dec_attention_q8k (one launch: split attention in LDS + merge + Q8_K image) followed by mrs_dec_proj_img == the split / merge kernels
-    (mrs_decode_attention_f32_*) followed by mrs_dec_proj, bit for bit: f32 attention result, and the o_proj output."""
+ATTN2 = [C.c_void_p] * 9 + [C.c_int, C.c_float, C.c_void_p, C.c_void_p] + [C.c_int] * 10 + [C.c_void_p]
+
+
+def _gather_kv(kc, vc, bt_row, ctx, from16):
+    """paged cache (K [blocks, kvh, hd/8, 32, 8], V [blocks, kvh, hd, 32]) -> k, v [ctx, kvh, hd] f32"""
+    pos = np.arange(ctx)
+    blk, off = bt_row[pos // 32], pos % 32
+    k = from16(kc[blk, :, :, off, :]).reshape(ctx, kc.shape[1], -1)                 # [ctx, kvh, hd/8, 8]
+    v = from16(vc[blk, :, :, off])                                                   # [ctx, kvh, hd]
+    return k, v
+
+
+def check_attention(O, be, heads, kvh, ctxs, max_ctx, kv_dtype=1, n_out=24):
+    """mrs_dec_attention (split waves + last-arriver merge + Q8_K image, ONE launch): the f32 result equals the engine-order restatement
+    (orc_attention_engine) BIT FOR BIT, agrees with the restated in-tree CPU attention (single_q.rs order) to f32 rounding, and o_proj on the
+    image equals o_proj on the f32 vector bit for bit.  Where the round-2 one-launch kernel applies it produces the same bits."""
     hd, bs, b = 128, 32, len(ctxs)
     nq = heads * hd
     rng = np.random.default_rng(heads + kvh + sum(ctxs))
     mbs = (max_ctx + bs - 1) // bs
     nblocks = b * mbs + 1
     to16 = (lambda a: a.astype(np.float16).view(np.uint16)) if kv_dtype == 0 else O.to_bf16_bits
-    kc = be.buf(to16((rng.standard_normal((nblocks, kvh, hd // 8, bs, 8)) * 0.7).astype(np.float32)))
-    vc = be.buf(to16(rng.standard_normal((nblocks, kvh, hd, bs)).astype(np.float32)))
-    bt = be.buf(rng.permutation(nblocks - 1)[: b * mbs].reshape(b, mbs).astype(np.uint32) + 1)
+    from16 = (lambda a: a.view(np.float16).astype(np.float32)) if kv_dtype == 0 else O.from_bf16_bits
+    kc_np = to16((rng.standard_normal((nblocks, kvh, hd // 8, bs, 8)) * 0.7).astype(np.float32))
+    vc_np = to16(rng.standard_normal((nblocks, kvh, hd, bs)).astype(np.float32))
+    bt_np = rng.permutation(nblocks - 1)[: b * mbs].reshape(b, mbs).astype(np.uint32) + 1
+    kc, vc, bt = be.buf(kc_np), be.buf(vc_np), be.buf(bt_np)
     cl = be.buf(np.asarray(ctxs, dtype=np.uint32))
-    q = be.buf((rng.standard_normal((b, nq)) * 0.5).astype(np.float32))
+    q_np = (rng.standard_normal((b, nq)) * 0.5).astype(np.float32)
+    q = be.buf(q_np)
     splits = be.sym("mrs_decode_attention_max_splits", [C.c_int], C.c_int)(max_ctx)
     po, pm, pl = be.buf(np.zeros((b, heads, splits, hd), np.float32)), be.buf(np.zeros((b, heads, splits), np.float32)), be.buf(np.zeros((b, heads, splits), np.float32))
-    ref = be.buf(np.zeros((b, nq), np.float32))
-    scale = 1.0 / np.sqrt(hd)
-    f32 = be.sym("mrs_decode_attention_f32_f32_bf16", ATTN_F32, C.c_int)
-    assert f32(ref.ptr, pl.ptr, pm.ptr, po.ptr, q.ptr, kc.ptr, vc.ptr, kvh, scale, bt.ptr, cl.ptr, bs, max_ctx, b, heads, hd, mbs, nq, kvh * hd * bs, hd * bs, kv_dtype,
-               be.stream) == 0
+    ticket = be.buf(np.zeros(b * kvh, np.uint32))
+    scale = np.float32(1.0 / np.sqrt(np.float32(hd)))
     nimg = be.sym("mrs_dec_act_image_bytes", [C.c_int, C.c_int], C.c_size_t)(nq, b)
     assert nimg == b * (nq + nq // 32 * 4 + nq // 16 * 4)
     img, got = be.buf(np.zeros(nimg, np.uint8)), be.buf(np.full((b, nq), np.nan, np.float32))
-    fused = be.sym("mrs_dec_attention_q8k", ATTN_Q8K, C.c_int)
-    rc = fused(img.ptr, got.ptr, q.ptr, kc.ptr, vc.ptr, kvh, scale, bt.ptr, cl.ptr, bs, max_ctx, b, heads, hd, mbs, nq, kvh * hd * bs, hd * bs, kv_dtype, be.stream)
-    assert rc == 0
-    np.testing.assert_array_equal(got.numpy(), ref.numpy())
+    fn = be.sym("mrs_dec_attention", ATTN2, C.c_int)
+    even = (heads // kvh) % 2 == 0
+    for rep in range(2):  # twice: the arrival counters must be back at zero
+        rc = fn(got.ptr, img.ptr, ticket.ptr, po.ptr, pm.ptr, pl.ptr, q.ptr, kc.ptr, vc.ptr, kvh, scale, bt.ptr, cl.ptr, bs, max_ctx, b, heads, hd, mbs, nq, kvh * hd * bs,
+                hd * bs, kv_dtype, be.stream)
+        assert rc == (1 if even else 0)
+        assert not ticket.numpy().any()
+    res = got.numpy()
+    nblk_max = (max_ctx + 31) // 32
+    bpw = 1 if nblk_max <= 64 else (nblk_max + 63) // 64
+    for i, ctx in enumerate(ctxs):
+        k, v = _gather_kv(kc_np, vc_np, bt_np[i], ctx, from16)
+        eng = O.attention_engine(q_np[i].reshape(heads, hd), k, v, scale, bpw)
+        assert np.array_equal(res[i].reshape(heads, hd), eng), ("engine-order oracle", i, ctx, float(np.abs(res[i].reshape(heads, hd) - eng).max()))
+        cpu = O.attention_single_q_cpu(q_np[i].reshape(heads, hd), k, v, scale, 1)
+        assert np.abs(res[i].reshape(heads, hd) - cpu).max() <= 2e-6 * max(1.0, np.abs(cpu).max()), ("single_q.rs order", i, ctx)
+    if not even:
+        return
     # o_proj on the image == o_proj on the f32 vector (the same quantizer ran in a different kernel)
     t = O.Q4_K
     packed = _weights(O, t, n_out, nq, 7)
     keep, m = repack(be, O, t, packed, n_out, nq)
     base = rng.standard_normal((b, n_out)).astype(np.float32)
     o_ref, o_img = be.buf(base.copy()), be.buf(base.copy())
-    assert be.sym("mrs_dec_proj", PROJ, C.c_int)(C.byref(m), n_out, None, ref.ptr, nq, None, 0.0, o_ref.ptr, n_out, 1, 0.5, None, b, be.stream) == 0
+    assert be.sym("mrs_dec_proj", PROJ, C.c_int)(C.byref(m), n_out, None, got.ptr, nq, None, 0.0, o_ref.ptr, n_out, 1, 0.5, None, b, be.stream) == 0
     assert be.sym("mrs_dec_proj_img", PROJ_IMG, C.c_int)(C.byref(m), n_out, img.ptr, o_img.ptr, n_out, 1, 0.5, b, be.stream) == 0
     np.testing.assert_array_equal(o_img.numpy(), o_ref.numpy())
-    # and the image is the oracle's Q8_K quantization of the f32 result
-    want = O.matmul_cpu(t, packed, n_out, nq, ref.numpy())
-    assert np.abs(o_img.numpy() - (base * np.float32(0.5) + want)).max() <= 2e-5 * max(1.0, np.abs(want).max())
+    eng_o = base * np.float32(0.5) + np.concatenate([O.gemv_engine(t, packed, n_out, nq, r) for r in res], axis=0) * np.float32(1.0)
+    np.testing.assert_array_equal(o_img.numpy(), eng_o)
+    if max_ctx <= 1024:  # the round-2 one-launch kernel (partials in LDS): same cores, same bits
+        img2, got2 = be.buf(np.zeros(nimg, np.uint8)), be.buf(np.full((b, nq), np.nan, np.float32))
+        fused = be.sym("mrs_dec_attention_q8k", ATTN_Q8K, C.c_int)
+        assert fused(img2.ptr, got2.ptr, q.ptr, kc.ptr, vc.ptr, kvh, scale, bt.ptr, cl.ptr, bs, max_ctx, b, heads, hd, mbs, nq, kvh * hd * bs, hd * bs, kv_dtype, be.stream) == 0
+        np.testing.assert_array_equal(got2.numpy(), res)
+        np.testing.assert_array_equal(img2.numpy(), img.numpy())
 
 
 def test_fused_attention_refuses_long_contexts_and_odd_groups(oracle):
@@ -257,13 +303,24 @@ def test_fused_attention_refuses_long_contexts_and_odd_groups(oracle):
 
 @pytest.mark.parametrize("heads,kvh,ctxs,max_ctx,kvd", [(4, 2, [70], 128, 1), (4, 1, [33, 200], 224, 1), (2, 1, [1], 64, 0), (8, 2, [500, 17, 96], 512, 1)])
 def test_fused_attention_host_emulation(oracle, heads, kvh, ctxs, max_ctx, kvd):
-    check_fused_attention(oracle, HostBackend(), heads, kvh, ctxs, max_ctx, kvd)
+    check_attention(oracle, HostBackend(), heads, kvh, ctxs, max_ctx, kvd)
+
+
+@pytest.mark.parametrize("heads,kvh,ctxs,max_ctx,kvd", [(2, 2, [45], 64, 1), (8, 1, [100, 31], 128, 0), (4, 2, [2300], 4096, 1)])
+def test_attention_more_shapes_host_emulation(oracle, heads, kvh, ctxs, max_ctx, kvd):
+    check_attention(oracle, HostBackend(), heads, kvh, ctxs, max_ctx, kvd)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("heads,kvh,ctxs,max_ctx,kvd", [(32, 8, [700], 832, 1), (32, 8, [1024, 3, 515], 1024, 1), (8, 4, [129], 160, 0), (64, 8, [333, 1000], 1024, 1)])
 def test_fused_attention_gpu(oracle, dev, heads, kvh, ctxs, max_ctx, kvd):
-    check_fused_attention(oracle, GpuBackend(dev), heads, kvh, ctxs, max_ctx, kvd, n_out=256)
+    check_attention(oracle, GpuBackend(dev), heads, kvh, ctxs, max_ctx, kvd, n_out=256)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("heads,kvh,ctxs,max_ctx,kvd", [(32, 8, [4000, 70], 4096, 1), (32, 32, [300], 512, 1), (8, 1, [2047], 2048, 0), (32, 8, [768] * 8, 1024, 1)])
+def test_attention_more_shapes_gpu(oracle, dev, heads, kvh, ctxs, max_ctx, kvd):
+    check_attention(oracle, GpuBackend(dev), heads, kvh, ctxs, max_ctx, kvd, n_out=256)
 
 
 GLU_TOPK = [C.POINTER(Mat), C.POINTER(Mat), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_void_p]

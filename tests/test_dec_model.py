@@ -1,8 +1,15 @@
-"""north_star parity: the decode engine (ext_dec.hip, reference CPU-path arithmetic) through the C++ runner vs oracle B
-(oracle/llama_ref.py mode="cpu": candle QMatMul semantics -- Q8_K / Q8_0 activations -- f32 norm / RoPE / SiLU / softmax, eager KV cache).
-Bar (BASELINE.json north_star): max |logit_gpu - logit_cpu| <= 1e-3 * max |logit| at every position and identical greedy token ids.
-The engine's only freedom against the oracle is f32 summation order (norm sums, block sums of a row, attention sums); where that moves a
-value across a rounding step of the int8 activation quantizer a single logit can move by more than the f32 noise, hence 1e-3 and not 1e-6.
+"""north_star parity: the decode engine (ext_dec.hip, reference CPU-path arithmetic) through the C++ runner vs the whole-model restatement of the
+reference CPU path (oracle/llama_ref.py + oracle/cpu_path_oracle.c).  Round 3: two bars.
+
+(1) BIT EQUALITY with mode="engine": the reference CPU path's arithmetic -- Q8_K / Q8_0 activation quantizers, integer block dots, d_w * d_x products,
+    candle's rms_norm expression, the in-tree CPU attention's online softmax with its fast_exp, SiLU, RoPE, residual adds -- evaluated in the f32
+    summation orders the kernels document.  Every logit of every position must be identical, hence also every greedy id.
+(2) Distance to mode="cpu" (ggml's generic 8-lane GEMV order, candle's in-order rms sum, single_q.rs's tile order): two evaluations that differ in f32
+    summation order ONLY agree to ~1e-6 until the first time a rounding difference moves one int8 activation quant across a rounding step, and then
+    sit at the int8 noise floor (oracle-only experiment, profiles/round3_parity.md: at 8B layer shapes ANY two orders, cpu vs cpu_fast included, are
+    1.4e-2 .. 3e-2 apart from the second token on).  BASELINE's 1e-3 is therefore met before the first flip and unattainable after it for any
+    implementation that does not reproduce one specific build's summation order; the tests hold the engine to the spread that two CPU orders show
+    on the same model and tokens (factor 1.25 on the means), and to 1e-2 on the tiny model.
 KV pages: f16 (the reference CPU path's default KV dtype) and bf16 (the dtype of the GPU pipelines), each against the oracle with the same KV rounding."""
 import numpy as np
 import pytest
@@ -57,22 +64,42 @@ def _greedy_parity(oracle, m, ref, cfg, steps, bar, exact_frac=None):
     return max(rels)
 
 
+def _bit_parity(m, ref, cfg, steps):
+    """Greedy decode from token 1000 % vocab; engine and engine-order oracle must produce identical logits (hence ids) at every position."""
+    tok = 1000 % cfg.vocab_size
+    for pos in range(steps):
+        want = ref.step(tok, pos)
+        m.set_state([tok], [pos])
+        got = m.forward_logits(1)[0].float().cpu().numpy()
+        assert np.array_equal(got, want), f"position {pos}: {int((got != want).sum())} of {got.size} logits differ, max |d| = {float(np.abs(got - want).max()):.3e}"
+        tok = int(got.argmax())
+
+
 @pytest.mark.parametrize("mix,kv", [("q4km", "f16"), ("q4km", "bf16"), ("q8", "f16"), ("q5", "bf16")])
-def test_engine_equals_cpu_path_oracle_tiny_model(oracle, dev, request, mix, kv):
-    """Tiny dims (hidden 512): the engine's arithmetic IS oracle B's -- most positions agree to f32 noise (<= 1e-5); where an f32-order
-    difference moves one activation across an int8 rounding step, this small model moves by up to ~1e-2 (one step of one of 512 quants)."""
+def test_engine_bit_identical_to_engine_order_oracle_tiny_model(oracle, dev, request, mix, kv):
+    """The decode engine == LlamaRef(mode="engine") bit for bit: every logit of every greedy position (all four weight-type mixes, both page dtypes)."""
     from oracle import llama_ref
     emu = request.config.getoption("--host-emulation")
-    steps = 6 if emu else 48
+    cfg, w, m, cos, sin = _mk(oracle, dev, {"q4km": Q4KM, "q8": Q8, "q5": Q5}[mix](oracle), kv)
+    _bit_parity(m, llama_ref.LlamaRef(cfg, w, cos, sin, mode="engine", kv_dtype=kv), cfg, 5 if emu else 48)
+
+
+@pytest.mark.parametrize("mix,kv", [("q4km", "f16"), ("q4km", "bf16"), ("q8", "f16"), ("q5", "bf16")])
+def test_engine_vs_cpu_order_oracle_tiny_model(oracle, dev, request, mix, kv):
+    """Tiny dims (hidden 512) against the reference's own summation orders (mode="cpu"): positions agree to f32 noise (<= 1e-5) except where an
+    f32-order difference moves one activation across an int8 rounding step; bar 1e-2 of max |logit| at every position, identical greedy ids."""
+    from oracle import llama_ref
+    emu = request.config.getoption("--host-emulation")
+    steps = 5 if emu else 48
     cfg, w, m, cos, sin = _mk(oracle, dev, {"q4km": Q4KM, "q8": Q8, "q5": Q5}[mix](oracle), kv)
     ref = llama_ref.LlamaRef(cfg, w, cos, sin, mode="cpu", kv_dtype=kv)
-    worst = _greedy_parity(oracle, m, ref, cfg, steps, 3e-2, exact_frac=None if emu else 2)
+    worst = _greedy_parity(oracle, m, ref, cfg, steps, 1e-2, exact_frac=None if emu else steps // 2)
     print(f"{mix}/{kv}: worst |dlogit| / max|logit| over {steps} greedy steps = {worst:.2e}")
 
 
 def _mk_8b_dims(oracle, dev, kv_dtype, layers=2, vocab=4096, seed=3):
-    """Llama-3-8B layer shapes (hidden 4096, 32 / 8 heads of 128, ffn 14336), Q4_K_M type mix, random valid blocks (the quantizer search over
-    0.5 G weights would take minutes), `layers` layers and a small vocabulary so the CPU oracle finishes in seconds per token."""
+    """Llama-3-8B layer shapes (hidden 4096, 32 / 8 heads of 128, ffn 14336), Q4_K_M type mix, SURVEY 8(d) weights: N(0, 0.02^2) through the GGML
+    quantizers (the oracle's, ~1 minute for two layers), `layers` layers and a small vocabulary so the CPU oracle finishes in seconds per token."""
     import torch
     from mistralrs_amd.gguf import GgmlDType, QTensor
     from mistralrs_amd.llama import Llama, LlamaConfig, rope_tables
@@ -84,7 +111,7 @@ def _mk_8b_dims(oracle, dev, kv_dtype, layers=2, vocab=4096, seed=3):
 
     def blocks(t, n, kk, scale):
         k[0] += 1
-        return (t, O.random_blocks(t, n, kk, seed=k[0], d_scale=scale))
+        return (t, O.quantize(t, (np.random.default_rng(k[0]).standard_normal((n, kk), dtype=np.float32) * np.float32(0.02))))
     rng = np.random.default_rng(seed)
     w["token_embd.weight"] = blocks(O.Q4_K, vocab, d, 1.0)
     w["output.weight"] = blocks(O.Q6_K, vocab, d, 0.02)
@@ -115,25 +142,24 @@ def _mk_8b_dims(oracle, dev, kv_dtype, layers=2, vocab=4096, seed=3):
 
 @pytest.mark.parametrize("kv", ["f16", "bf16"])
 def test_north_star_parity_8b_layer_shapes(oracle, dev, request, kv):
-    """BASELINE.json north_star: logits within 1e-3 (relative to max |logit|) of the reference CPU path and bit-exact greedy ids, at Llama-3-8B
-    layer shapes over 48 greedy tokens.
-    What "the CPU path" pins is the arithmetic (Q8_K activations, integer block dots, f32 combination), not the f32 summation order -- candle's
-    AVX2 / AVX-512 / NEON / scalar builds each sum in a different order.  Two CPU evaluations of that arithmetic in different orders (oracle
-    modes "cpu" and "cpu_fast") differ by 2e-3 .. 1e-2 on this synthetic model (f32 noise of ~1e-6 in a GEMV output moves a few int8 activation
-    quants per token across a rounding step), so 1e-3 is below the path's own spread.  The test therefore measures that spread on the same
-    token sequence and holds the engine to it: engine-vs-cpu <= max(1e-3, 2.5 x the worst cpu-vs-cpu_fast distance), mean likewise, and
-    identical greedy ids wherever the CPU path's own top-2 margin exceeds the distance."""
+    """Llama-3-8B layer shapes (2 layers, N(0, 0.02^2) weights through the GGML quantizers), 24 greedy tokens, teacher-forced on the CPU-order run:
+    (1) engine == mode="engine" bit for bit at every position;
+    (2) distance to mode="cpu" next to the distance between two CPU orders (mode "cpu" vs mode "cpu_fast" with two kv chunks): after the first moved
+        int8 quant every pair of orders sits at the same noise floor, so the engine's mean distance must not exceed 1.25 x the CPU pair's, its
+        worst position 1.25 x the CPU pair's worst, and greedy ids must agree wherever the CPU run's top-2 margin exceeds both distances."""
     from oracle import llama_ref
     if request.config.getoption("--host-emulation"):
         pytest.skip("8B layer shapes are for the device")
     cfg, w, m, cos, sin = _mk_8b_dims(oracle, dev, kv)
     ref = llama_ref.LlamaRef(cfg, w, cos, sin, mode="cpu", kv_dtype=kv)
-    alt = llama_ref.LlamaRef(cfg, w, cos, sin, mode="cpu_fast", kv_dtype=kv)
+    alt = llama_ref.LlamaRef(cfg, w, cos, sin, mode="cpu_fast", kv_dtype=kv, n_kv_chunks=2)
+    mirror = llama_ref.LlamaRef(cfg, w, cos, sin, mode="engine", kv_dtype=kv)
     tok, eng, spread, flips, cpu_flips = 1000 % cfg.vocab_size, [], [], 0, 0
-    for pos in range(48):
-        want, other = ref.step(tok, pos), alt.step(tok, pos)
+    for pos in range(24):
+        want, other, exact = ref.step(tok, pos), alt.step(tok, pos), mirror.step(tok, pos)
         m.set_state([tok], [pos])
         got = m.forward_logits(1)[0].float().cpu().numpy()
+        assert np.array_equal(got, exact), f"position {pos}: engine differs from the engine-order oracle ({int((got != exact).sum())} logits, max {float(np.abs(got - exact).max()):.3e})"
         scale = np.abs(want).max()
         eng.append(float(np.abs(got - want).max() / scale))
         spread.append(float(np.abs(other - want).max() / scale))
@@ -145,9 +171,10 @@ def test_north_star_parity_8b_layer_shapes(oracle, dev, request, kv):
         if int(other.argmax()) != int(want.argmax()):
             cpu_flips += 1
         tok = int(want.argmax())
-    print(f"8B layer shapes / kv {kv}: engine-vs-cpu worst {max(eng):.2e} mean {np.mean(eng):.2e}; cpu-vs-cpu_fast worst {max(spread):.2e} mean {np.mean(spread):.2e}; near-ties {flips}; positions where the two CPU orders pick different ids: {cpu_flips}")
-    assert max(eng) <= max(1e-3, 2.5 * max(spread)), (max(eng), max(spread))
-    assert np.mean(eng) <= max(1e-3, 2.5 * np.mean(spread)), (np.mean(eng), np.mean(spread))
+    print(f"8B layer shapes / kv {kv}: engine == engine-order oracle at 24 / 24 positions; engine-vs-cpu worst {max(eng):.2e} mean {np.mean(eng):.2e}; "
+          f"cpu-vs-cpu_b worst {max(spread):.2e} mean {np.mean(spread):.2e}; near-ties {flips}; positions where the two CPU orders pick different ids: {cpu_flips}")
+    assert max(eng) <= max(1e-3, 1.25 * max(spread)), (max(eng), max(spread))
+    assert np.mean(eng) <= max(1e-3, 1.25 * np.mean(spread)), (np.mean(eng), np.mean(spread))
 
 
 def test_engine_graph_loop_batch_and_chunked_prefill(oracle, dev, request):
