@@ -9,8 +9,9 @@ batch 1, replayed from a HIP graph; the timed region is exactly K steps after W 
 barrier + torch.cuda.synchronize(); `value` = decoded tokens/s over all ranks (max time over ranks).
 Method mirrors `mistralrs bench` (mistralrs-cli/src/commands/bench.rs:52-55,253-305): synthetic prompt tokens
 1000 + (start+i) % 2048, EOS disabled, greedy; prefill tok/s = prompt_len / TTFT is reported next to it.
-Weights are synthetic (no network): random valid GGUF blocks with the llama.cpp Q4_K_M tensor-type map; inputs are
-resident in HBM when the timed region starts.
+Weights are synthetic (no network), SURVEY 8(d): N(0, 0.02^2) per tensor (seed = f(tensor index)), norm weights 1 + N(0, 0.01), quantized ON THE GPU by the
+device ISQ quantizers (csrc/ext_isq.hip: bit-identical to GGML's reference quantizers) with the llama.cpp Q4_K_M tensor-type map (`--weights blocks` = random
+valid block bytes, the fast variant for pure kernel timing); inputs are resident in HBM when the timed region starts.
 Multi-GPU: `--gpus N` with N > 1 runs ONE model tensor-parallel over the N GPUs (one process per GPU, RCCL all-reduce after every
 row-parallel projection; "scaling": "strong"); launched by torch.distributed.run, or self-spawned when WORLD_SIZE is not set.
 `--model auto` = Llama-3-8B (BASELINE configs[1]) for N < 8 and Llama-3-70B, 2048 prefill (configs[3]) for N = 8; `--replicas` = N independent copies.
@@ -50,7 +51,7 @@ def q4_k_m_types(n_layers: int):
     return out
 
 
-def build_model(cfg, device, seed=0, max_new_tokens=4096, tp=None, quant="q4_k_m"):
+def build_model(cfg, device, seed=0, max_new_tokens=4096, tp=None, quant="q4_k_m", weights="gaussian"):
     """Synthetic model of `cfg`'s (per-rank) dims.  tp = (rank, world): the column / row-parallel shards (q / k / v / gate / up rows, o / down
     columns: distributed/layers.rs:695-975,1160-1616) get rank-specific random blocks of the SHARD's shape -- the bytes and the arithmetic of a
     real shard without materialising the unsharded 40 GB tensor on every GPU -- while the replicated tensors (embedding, norms, lm_head) use
@@ -73,6 +74,10 @@ def build_model(cfg, device, seed=0, max_new_tokens=4096, tp=None, quant="q4_k_m
             from mistralrs_amd.gguf import GgmlDType
             gw = torch.Generator(device=device).manual_seed(tseed)
             m.set_tensor(name, isq.quantize((torch.randn(n, k, device=device, generator=gw) * 0.02).to(torch.bfloat16), GgmlDType.Q8_0))
+        elif weights == "gaussian":  # N(0, 0.02^2) through the GGML quantizer of the tensor's type (on the device, bit-identical to GGML)
+            from mistralrs_amd import isq
+            gw = torch.Generator(device=device).manual_seed(tseed)
+            m.set_tensor(name, isq.quantize(torch.randn(n, k, device=device, generator=gw) * 0.02, t))
         else:
             m.set_tensor(name, random_qtensor(t, n, k, device, tseed))
     for i in range(cfg.num_layers):
@@ -82,13 +87,8 @@ def build_model(cfg, device, seed=0, max_new_tokens=4096, tp=None, quant="q4_k_m
     return m
 
 
-def cpu_baseline(model, cfg, budget_s=12.0):
-    """Reference CPU path (oracle B restatement, llama_oracle.c): decode a few tokens of the SAME synthetic model on the
-    host cores.  Bounded sample; thread count picked by a quick calibration (cgroup quotas make nproc unreliable)."""
-    import numpy as np
-    from mistralrs_amd.llama import rope_tables
-    from oracle import llama_ref, oracle as O
-    O.build()
+def host_weights(model):
+    """The model's tensors as the CPU restatement takes them (GGUF name -> (ggml type id, packed uint8 [N, row_bytes]) or f32 array)."""
     w = {}
     for name, t in model._keep.items():
         if "#" in name:  # decode-layout copies of the same tensors
@@ -97,6 +97,20 @@ def cpu_baseline(model, cfg, budget_s=12.0):
             w[name] = (t.dtype.id, t.data.cpu().numpy().reshape(t.shape[0], -1))
         else:
             w[name] = t.cpu().numpy()
+    return w
+
+
+def cpu_baseline(model, cfg, budget_s=12.0, positions=16):
+    """Reference CPU path on the host cores, the SAME synthetic model (oracle/llama_ref.py + llama_oracle.c / cpu_path_oracle.c):
+      * timing ("port"): mode "cpu_fast" (Q8_K / Q8_0 activations, integer block dots, OpenMP rows), greedy from an empty context;
+      * parity material, teacher-forced on that run's tokens: mode "cpu" (ggml's generic GEMV order, candle's in-order rms sum, single_q.rs attention) and
+        mode "engine" (the same arithmetic in the decode engine's documented summation orders: the HIP engine must equal it bit for bit).
+    Thread count picked by a quick calibration (cgroup quotas make nproc unreliable)."""
+    import numpy as np
+    from mistralrs_amd.llama import rope_tables
+    from oracle import llama_ref, oracle as O
+    O.build()
+    w = host_weights(model)
     cos, sin = rope_tables(cfg)
     # calibrate threads on one big matvec
     tname = "blk.0.ffn_gate.weight"
@@ -114,26 +128,28 @@ def cpu_baseline(model, cfg, budget_s=12.0):
         if dt < best[0]:
             best = (dt, thr)
     O.set_threads(best[1])
-    ref = llama_ref.LlamaRef(cfg, w, cos, sin, mode="cpu_fast", kv_dtype="bf16")
+    ref = llama_ref.LlamaRef(cfg, w, cos, sin, mode="cpu_fast", kv_dtype="bf16", n_kv_chunks=2)
     # same token rule as the GPU run, from an empty context; the GPU side repeats exactly this (token by token through the decode engine)
-    # for the greedy_match check, so the two token lists are comparable
-    tok, n, toks, logits, t0 = 1000 % cfg.vocab_size, 0, [], [], time.perf_counter()
-    while True:
+    tok, n, toks, logits_b, t0 = 1000 % cfg.vocab_size, 0, [], [], time.perf_counter()
+    el = 0.0
+    while n < positions:
         lg = ref.step(tok, n)
-        logits.append(np.asarray(lg, dtype=np.float32).copy())
+        logits_b.append(np.asarray(lg, dtype=np.float32).copy())
         tok, n = int(lg.argmax()), n + 1
         toks.append(tok)
-        el = time.perf_counter() - t0
-        if el > budget_s or n >= 16:
-            break
-    # calibration for the parity figures below: the SAME arithmetic in the other f32 summation order (oracle mode "cpu": ggml's generic lane order),
-    # teacher-forced on the same tokens for the first positions -- how far two CPU evaluations of the reference path are from each other on this model
-    alt = llama_ref.LlamaRef(cfg, w, cos, sin, mode="cpu", kv_dtype="bf16")
-    alt_logits = [np.asarray(alt.step(t, p), dtype=np.float32).copy() for p, t in enumerate(([1000 % cfg.vocab_size] + toks[:-1])[:8])]
-    return {"value": round(n / el, 3), "unit": "tokens/s", "cores": best[1], "kind": "port",
-            "sample": f"{n} greedy decode tokens from an empty context, same synthetic {cfg.num_layers}-layer Q4_K_M weights, "
-                      f"oracle-B restatement of the candle CPU path (Q8_K activations, OpenMP rows, gcc -O3 -march=native); "
-                      f"host reports {os.cpu_count()} logical CPUs"}, toks, logits, alt_logits
+        if el == 0.0 and (time.perf_counter() - t0 > budget_s or n >= positions):
+            el, n_timed = time.perf_counter() - t0, n  # the timed sample ends here; the remaining positions are parity material only
+    fed = ([1000 % cfg.vocab_size] + toks[:-1])[:positions]
+    nblk = (cfg.max_context_len + 31) // 32
+    runs = {"cpu": llama_ref.LlamaRef(cfg, w, cos, sin, mode="cpu", kv_dtype="bf16"),
+            "engine": llama_ref.LlamaRef(cfg, w, cos, sin, mode="engine", kv_dtype="bf16", attn_bpw=1 if nblk <= 64 else (nblk + 63) // 64)}
+    logits = {k: [np.asarray(r.step(t, p), dtype=np.float32).copy() for p, t in enumerate(fed)] for k, r in runs.items()}
+    logits["cpu_b"] = logits_b
+    base = {"value": round(n_timed / el, 3), "unit": "tokens/s", "cores": best[1], "kind": "port",
+            "sample": f"{n_timed} greedy decode tokens from an empty context, same synthetic {cfg.num_layers}-layer Q4_K_M weights, "
+                      f"restatement of the candle CPU path (Q8_K activations, integer block dots, OpenMP rows, gcc -O3 -march=native); "
+                      f"host reports {os.cpu_count()} logical CPUs"}
+    return base, fed, logits
 
 
 def measured_traffic(model_name, quant="q4_k_m"):
@@ -164,6 +180,9 @@ def main():
     ap.add_argument("--tp", action="store_true", help="(default for N > 1) ONE model sharded tensor-parallel over the N GPUs")
     ap.add_argument("--replicas", action="store_true", help="N > 1: N independent replicas (weak scaling) instead of tensor parallelism")
     ap.add_argument("--model", choices=["auto", "8b", "70b"], default="auto", help="auto: 70b (configs[3]) when N == 8, else 8b (configs[1])")
+    ap.add_argument("--weights", choices=["gaussian", "blocks"], default="gaussian",
+                    help="gaussian (default): N(0, 0.02^2) through the device ISQ quantizers (SURVEY 8d); blocks: random valid block bytes (fast variant for pure kernel timing)")
+    ap.add_argument("--parity-positions", type=int, default=16, help="greedy positions of the CPU-path parity leg")
     ap.add_argument("--quant", choices=["q4_k_m", "q8_0_isq"], default="q4_k_m",
                     help="q8_0_isq = BASELINE configs[2]: every linear quantized in situ from bf16 weights to Q8_0 on the GPU (mistralrs_amd.isq, role of generate_isq!)")
     a = ap.parse_args()
@@ -236,7 +255,7 @@ def main():
         cfg.head_dim = cfg.head_dim  # keep the global head_dim
         cfg.num_heads, cfg.num_kv_heads, cfg.intermediate_size = D.local_dims(cfg.num_heads, cfg.num_kv_heads, cfg.intermediate_size, world)
         cfg.tp_world_size, cfg.tp_rank = world, rank
-    model = build_model(cfg, dev, seed=0 if tp else rank, max_new_tokens=a.warmup + a.steps + 8, tp=(rank, world) if tp else None, quant=a.quant)
+    model = build_model(cfg, dev, seed=0 if tp else rank, max_new_tokens=a.warmup + a.steps + 8, tp=(rank, world) if tp else None, quant=a.quant, weights=a.weights)
     comm, p2p = None, None
     if tp:
         from mistralrs_amd import distributed as D
@@ -397,43 +416,59 @@ def main():
         out["allreduce"] = ar
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
-            out["cpu_baseline"], cpu_toks, cpu_logits, alt_logits = cpu_baseline(model, cfg)
-            # parity of the same model on the GPU (decode engine, token by token from an empty context) vs the CPU-path restatement:
-            # (1) teacher-forced on the CPU run's tokens: logit error per position and, where the arg-max differs, how close the CPU run's own top two were;
-            # (2) greedy_match: the free-running greedy tokens (one near-tie flip changes every later token)
             import numpy as np
-            fed, rel, rel_alt, cpu_spread, agree, flips = [1000 % cfg.vocab_size] + cpu_toks[:-1], [], [], [], 0, []
+            out["cpu_baseline"], fed, cl = cpu_baseline(model, cfg, positions=a.parity_positions)
+            # ---- parity of the same model on the GPU (decode engine, token by token from an empty context)
+            # (1) teacher-forced on the CPU run's tokens: engine logits vs the engine-order restatement (must be IDENTICAL), vs the reference's own orders
+            #     (mode "cpu" = a), and the distance between two CPU orders (a vs b = "cpu_fast" + 2 kv chunks) as the calibration of what order alone does
+            # (2) greedy_match: free-running greedy ids of the engine vs CPU order a
+            gl = []
             for pos, t in enumerate(fed):
                 model.set_state([t], [pos])
-                g = model.forward_logits(1)[0].float().cpu().numpy()
-                c = cpu_logits[pos]
-                scale = float(np.abs(c).max())
-                rel.append(float(np.abs(g - c).max()) / scale)
-                if pos < len(alt_logits):
-                    rel_alt.append(float(np.abs(g - alt_logits[pos]).max()) / scale)
-                    cpu_spread.append(float(np.abs(c - alt_logits[pos]).max()) / scale)
-                if int(g.argmax()) == int(c.argmax()):
-                    agree += 1
-                else:
-                    flips.append({"position": pos, "cpu_margin_over_max_logit": float(c.max() - c[int(g.argmax())]) / scale, "logit_error_over_max_logit": rel[-1]})
-            tok, gpu_toks = 1000 % cfg.vocab_size, []
-            for pos in range(len(cpu_toks)):
-                model.set_state([tok], [pos])
-                tok = int(model.forward_logits(1)[0].argmax())
-                gpu_toks.append(tok)
-            out["greedy_match"] = gpu_toks == cpu_toks
-            out["greedy_match_detail"] = {"tokens": len(cpu_toks), "first_difference": next((i for i, (x, y) in enumerate(zip(gpu_toks, cpu_toks)) if x != y), None),
-                                          "teacher_forced": {"argmax_agree": agree, "positions": len(fed), "logit_error_over_max_logit_max": round(max(rel), 6),
-                                                             "logit_error_over_max_logit_first": round(rel[0], 9),
-                                                             "first_positions": {"n": len(cpu_spread), "gpu_vs_cpu_order_a": [round(v, 5) for v in rel[:len(cpu_spread)]],
-                                                                                 "gpu_vs_cpu_order_b": [round(v, 5) for v in rel_alt],
-                                                                                 "cpu_order_a_vs_cpu_order_b": [round(v, 5) for v in cpu_spread]},
-                                                             "argmax_flips": flips[:4]},
-                                          "note": "a 32-layer random-init model amplifies every int8 rounding flip: two f32 summation orders of the SAME CPU-path arithmetic (oracle modes cpu_fast = a, cpu = b) "
-                                                  "already differ by cpu_order_a_vs_cpu_order_b on this model, and the engine agrees with either to 3e-7 until the first flip (1-4 layers: "
-                                                  "profiles/round2_parity_depth.md); tests/test_dec_model.py holds the engine to 2.5 x that spread at 8B layer shapes"}
+                gl.append(model.forward_logits(1)[0].float().cpu().numpy())
+            rel = lambda x, y, ref: float(np.abs(x - y).max() / np.abs(ref).max())
+            e_a = [rel(g, c, c) for g, c in zip(gl, cl["cpu"])]
+            e_b = [rel(g, c, ca) for g, c, ca in zip(gl, cl["cpu_b"], cl["cpu"])]
+            a_b = [rel(c, d, c) for c, d in zip(cl["cpu"], cl["cpu_b"])]
+            ident = [bool(np.array_equal(g, c)) for g, c in zip(gl, cl["engine"])]
+            e_e = [float(np.abs(g - c).max()) for g, c in zip(gl, cl["engine"])]
+            ids = lambda ls: [int(x.argmax()) for x in ls]
+            flips = [{"position": p, "cpu_a_top2_margin_over_max_logit": float((np.sort(c)[-1] - np.sort(c)[-2]) / np.abs(c).max()), "engine_vs_cpu_a": e_a[p]}
+                     for p, (g, c) in enumerate(zip(gl, cl["cpu"])) if int(g.argmax()) != int(c.argmax())]
+            # free-running greedy: engine vs a free-running CPU-order-a run
+            from mistralrs_amd.llama import rope_tables
+            from oracle import llama_ref
+            cos, sin = rope_tables(cfg)
+            cpu_a = llama_ref.LlamaRef(cfg, host_weights(model), cos, sin, mode="cpu", kv_dtype="bf16")
+            tg = tc = 1000 % cfg.vocab_size
+            gpu_toks, cpu_toks = [], []
+            for pos in range(len(fed)):
+                model.set_state([tg], [pos])
+                tg = int(model.forward_logits(1)[0].argmax())
+                gpu_toks.append(tg)
+                if gpu_toks[:pos] == cpu_toks[:pos]:  # the CPU run only has to continue while the prefixes agree
+                    tc = int(cpu_a.step(tc, pos).argmax())
+                    cpu_toks.append(tc)
+            n_cmp = len(cpu_toks)
+            out["greedy_match"] = gpu_toks[:n_cmp] == cpu_toks and n_cmp == len(fed)
+            out["parity"] = {
+                "weights": "N(0, 0.02^2) per tensor through the GGML quantizers (device ISQ, bit-identical to GGML), Q4_K_M type map" if a.weights == "gaussian" else "random valid block bytes",
+                "positions": len(fed),
+                "engine_vs_engine_order_restatement": {"bit_identical_positions": int(sum(ident)), "max_abs_logit_diff": max(e_e), "greedy_ids_identical": ids(gl) == ids(cl["engine"]),
+                                                       "what": "oracle/cpu_path_oracle.c: the reference CPU path's arithmetic (Q8_K activations, integer block dots, candle rms_norm, single_q.rs softmax with fast_exp) in the engine's documented f32 summation orders"},
+                "teacher_forced_max_logit_error_over_max_logit": {"engine_vs_cpu_order_a": [round(v, 6) for v in e_a], "engine_vs_cpu_order_b": [round(v, 6) for v in e_b],
+                                                                  "cpu_order_a_vs_cpu_order_b": [round(v, 6) for v in a_b]},
+                "mean": {"engine_vs_cpu_order_a": round(float(np.mean(e_a)), 6), "cpu_order_a_vs_cpu_order_b": round(float(np.mean(a_b)), 6),
+                         "ratio": round(float(np.mean(e_a) / max(np.mean(a_b), 1e-12)), 3)},
+                "argmax_agree_with_cpu_order_a": {"engine": int(sum(x == y for x, y in zip(ids(gl), ids(cl["cpu"])))), "cpu_order_b": int(sum(x == y for x, y in zip(ids(cl["cpu_b"]), ids(cl["cpu"]))))},
+                "argmax_flips": flips[:4],
+                "greedy_free_running": {"tokens_compared": n_cmp, "first_difference": next((i for i, (x, y) in enumerate(zip(gpu_toks, cpu_toks)) if x != y), None)},
+                "note": "cpu order a = ggml generic 8-lane GEMV order + candle in-order rms sum + single_q.rs tile order (1 kv chunk); b = one f32 term per superblock + 2 kv chunks. "
+                        "Orders that differ ONLY in f32 summation agree to ~1e-6 until a rounding difference moves one int8 activation quant across a rounding step, then sit at the int8 "
+                        "noise floor (profiles/round3_parity.md); the engine's arithmetic is pinned by the bit-identical restatement, its distance to a by the a-vs-b calibration."}
         except Exception as e:  # the baseline is a reported extra, never fatal
-            out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+            import traceback
+            out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port", "sample": f"failed: {e}: {traceback.format_exc()[-400:]}"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

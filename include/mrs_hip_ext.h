@@ -79,7 +79,7 @@ int mrs_dec_attention_q8k(void *img_out, float *out_f32, const float *q, const v
 int mrs_dec_attention(float *out_f32, void *img_out, unsigned *ticket, float *part_o, float *part_m, float *part_l, const float *q, const void *k_cache,
                       const void *v_cache, int num_kv_heads, float scale, const uint32_t *block_tables, const uint32_t *context_lens, int block_size,
                       int max_context_len, int num_seqs, int num_heads, int head_size, int max_blocks_per_seq, int q_stride, int kv_block_stride,
-                      int kv_head_stride, int kv_dtype, void *stream);
+                      int kv_head_stride, int kv_dtype, int sliding_window /* > 0: attend the last W positions only (Mistral), 0 = all */, void *stream);
 size_t mrs_dec_proj_img_max_bytes(void); /* largest activation image mrs_dec_proj_img stages */
 /* GEMV on a pre-quantized activation image (K-quant weights only; -3: image larger than the prologue's staging registers) */
 int mrs_dec_proj_img(const mrs_dec_mat *w, int n, const void *x_img, float *out, int ld_out, int mode, float resid_scale, int b, void *stream);
@@ -181,6 +181,9 @@ int mrs_rms_norm_bf16_slabs(const float *x, const float *w, int M, int K, float 
  * softmax(scale * Q K^T + causal) V on the bf16 matrix cores with K / V read straight from the paged cache (the chunk has been
  * scattered with reshape_and_cache first); role of Sdpa::run_attention in the prompt branch of PagedAttention::forward
  * (attention/mod.rs:254-372, paged_attention.rs:1413-1475).  head_size 128, block_size 32, bf16 cache; -1 otherwise. */
+int mrs_prefill_attention_window_f32_bf16(const float *q, const void *key_cache, const void *value_cache, const uint32_t *block_table, float *out,
+                                          int T, int start_pos, int num_heads, int num_kv_heads, int head_size, int block_size, int q_stride,
+                                          int o_stride, int kv_block_stride, int kv_head_stride, float scale, int sliding_window, void *stream);
 int mrs_prefill_attention_f32_bf16(const float *q, const void *key_cache, const void *value_cache, const uint32_t *block_table, float *out,
                                    int T, int start_pos, int num_heads, int num_kv_heads, int head_size, int block_size, int q_stride,
                                    int o_stride, int kv_block_stride, int kv_head_stride, float scale, void *stream);
@@ -203,6 +206,8 @@ typedef struct {
   int32_t num_experts;        /* 0 = dense FFN; > 0: Mixtral-style sparse MoE FFN in every layer (models/mixtral.rs:236-304) */
   int32_t num_experts_per_tok; /* top-k of the router (softmax over all experts -> top-k -> renormalise) */
   int32_t kv_f16;             /* decode engine only: 1 = f16 KV pages (the reference CPU path's default KV dtype, kv_cache/mod.rs:66-89), 0 = bf16 */
+  int32_t sliding_window;     /* > 0: Mistral sliding-window attention -- a query attends the last W positions, itself included (GGUF
+                                 <arch>.attention.sliding_window, gguf/normal_config.rs:792-796); decode engine + MFMA prefill only; 0 = full causal */
 } mrs_llama_config;
 
 typedef struct {  /* all device pointers, owned by the caller */
@@ -222,6 +227,17 @@ typedef struct {  /* all device pointers, owned by the caller */
 } mrs_llama_buffers;
 
 size_t mrs_llama_workspace_bytes(const mrs_llama_config *cfg);
+/* ---- prompt GEMM, round 3 (csrc/ext_gemm2.hip): weights in MFMA operand layout, no LDS round trip for the weight operand.
+ * Role: fast_mmq::{plain, fused_qkv, fused_glu} (mistralrs-quant/src/gguf/fast_mmq.rs:528-635,762-821); same arithmetic and bits as mrs_gemm_q_bf16_multi.
+ * mrs_gemm2_repack: GGUF blocks [n][k / 256] (Q4_K, Q6_K) -> the layout (load time).  mrs_gemm2_q_bf16_multi: out[i] [M][ldo[i]] (+)= x . W_i^T for up to
+ * three tensors of one type; x_slabs = bf16 k-slab-major [K/64][M][64]; workspace (may be NULL) = f32 split-K partials.  Returns 0, -1 bad arguments,
+ * -3 = shape / type served by mrs_gemm_q_bf16_multi (M <= 128, other types). */
+int mrs_gemm2_supported(int ggml_type);
+size_t mrs_gemm2_repack_bytes(int ggml_type, long long n, long long k);
+int mrs_gemm2_repack(const void *gguf_blocks, int ggml_type, long long n, long long k, void *dst, void *stream);
+int mrs_gemm2_q_bf16_multi(int nseg, const void *const *w, const int *N, float *const *out, const int *ldo, int ggml_type, int K, const void *x_slabs, int M,
+                           int accumulate, void *workspace, size_t workspace_bytes, void *stream);
+int mrs_llama_set_gemm2_tensor(void *model, const char *name, const void *planes); /* MFMA-layout copy of a dense linear registered with mrs_llama_set_tensor */
 /* decode-layout copy (mrs_dec_repack output, caller-owned) of a linear tensor already registered with mrs_llama_set_tensor */
 int mrs_llama_set_dec_tensor(void *model, const char *name, const void *planes);
 int mrs_llama_set_fused_attention(void *model, int on); /* decode engine: 1 = one-launch attention + Q8_K image for contexts <= 1024 (mrs_dec_attention_q8k), 0 (default: measured faster) = split + merge kernels */

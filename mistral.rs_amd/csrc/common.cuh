@@ -142,8 +142,7 @@ __device__ __forceinline__ float fast_exp_ref(float x) {
   const float LOG2E = 1.44269504088896340736f, C0 = 0.6933594f, C1 = -2.1219444e-4f;
   x = fminf(fmaxf(x, -87.0f), 87.0f);
   const float zx = x * LOG2E;
-  const float zt = truncf(zx);
-  const float z = fabsf(zx - zt) >= 0.5f ? zt + copysignf(1.0f, zx) : zt;
+  const float z = truncf(zx + copysignf(0.49999997f, zx));  // == roundf(zx) for every |zx| <= 129 (exhaustive: tests/test_oracle.py)
   const float r = x - z * C0 - z * C1;
   const float r2 = r * r;
   const float p = r + r2 * (0.5f + r * (0.16666546f + r * (0.041665795f + r * (0.00833345f + r * 0.0013920345f))));

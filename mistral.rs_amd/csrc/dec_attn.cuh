@@ -20,15 +20,18 @@ struct AttnArgs {
   float *out;                // [seqs][heads * 128]
   int num_heads, num_kv_heads, max_blocks_per_seq, q_stride, kv_block_stride, kv_head_stride, bpw, max_splits, num_seqs;
   float scale;
+  int window;  // > 0: a query attends the last `window` positions only, itself included (Mistral sliding window; mask rule of
+               // mistralrs-core/src/paged_attention/layers/paged_attention.rs:551-553: key <= pos - window is too old); 0 = all
 };
 
 // q_s: G * 128 floats, p_s: G * 32 floats of wave-private LDS; the item covers query heads [head0, head0 + G) of kv head kvh
 // blocks [b0, b1) of the sequence; sink(g, o0, o1, m, l) receives the un-normalised partial of query head head0 + g (o0 / o1: dims lane / lane + 64)
 template <int G, class CT, class Sink>
-__device__ __forceinline__ void attn_split_core(const AttnArgs &a, int kvh, int head0, int seq, int b0, int b1, float *q_s, float *p_s, Sink sink) {
+__device__ __forceinline__ void attn_split_core(const AttnArgs &a, int kvh, int head0, int seq, int b0, int b1, float *q_s, float *p_s, Sink sink, int first_page = -1) {
   constexpr int HD = 128, BS = 32;
   const int lane = lane_opaque();
   const int ctx = (int)a.context_lens[seq];
+  const int lo = a.window > 0 && ctx > a.window ? ctx - a.window : 0;  // first position inside the window (the query sits at ctx - 1)
   if (b0 >= b1) return;  // wave-uniform
   const float *qg = a.q + (size_t)seq * a.q_stride + (size_t)head0 * HD;
   for (int i = lane * 4; i < G * HD; i += 256) *(float4 *)(q_s + i) = *(const float4 *)(qg + i);
@@ -39,7 +42,7 @@ __device__ __forceinline__ void attn_split_core(const AttnArgs &a, int kvh, int 
 #pragma unroll
   for (int g = 0; g < G; ++g) { m[g] = -FLT_MAX; l[g] = 0.f; o0[g] = 0.f; o1[g] = 0.f; }
   for (int b = b0; b < b1; ++b) {
-    const size_t base = (size_t)bt[b] * a.kv_block_stride + (size_t)kvh * a.kv_head_stride;
+    const size_t base = (size_t)(b == b0 && first_page >= 0 ? (unsigned)first_page : bt[b]) * a.kv_block_stride + (size_t)kvh * a.kv_head_stride;  // first_page: loaded by the caller ahead of the context length
     const uint16_t *kb = a.k_cache + base + (size_t)(half * 8) * BS * 8 + t * 8;
     const uint16_t *vb = a.v_cache + base;
     int4 kr[8], vr[8];
@@ -64,7 +67,7 @@ __device__ __forceinline__ void attn_split_core(const AttnArgs &a, int kvh, int 
         s[g] = fmaf(qb.x, kf[4], s[g]); s[g] = fmaf(qb.y, kf[5], s[g]); s[g] = fmaf(qb.z, kf[6], s[g]); s[g] = fmaf(qb.w, kf[7], s[g]);
       }
     }
-    const bool valid = b * BS + t < ctx;
+    const bool valid = b * BS + t < ctx && b * BS + t >= lo;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       float v = s[g] + __shfl_xor(s[g], 32, 64);
@@ -77,9 +80,13 @@ __device__ __forceinline__ void attn_split_core(const AttnArgs &a, int kvh, int 
       float ps = p;
       ps += dpp_f<0xB1>(ps); ps += dpp_f<0x4E>(ps); ps += dpp_f<0x141>(ps); ps += dpp_f<0x140>(ps);
       ps += __shfl_xor(ps, 16, 64);
-      const float alpha = fast_exp_ref(m[g] - mn);
-      l[g] = l[g] * alpha + ps;
-      o0[g] *= alpha; o1[g] *= alpha;
+      if (b == b0) {  // first block of the split: l = o = 0, so l * alpha + ps == ps and o * alpha == 0 bit for bit -- no correction to compute
+        l[g] = ps;
+      } else {
+        const float alpha = fast_exp_ref(m[g] - mn);
+        l[g] = l[g] * alpha + ps;
+        o0[g] *= alpha; o1[g] *= alpha;
+      }
       m[g] = mn;
       if (half == 0) p_s[g * BS + t] = p;
     }

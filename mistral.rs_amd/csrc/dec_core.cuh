@@ -105,7 +105,12 @@ template <int CTRL> __device__ __forceinline__ int dppi(int v) { return __builti
 #define MRS_ACT_MAXW (8192 / (MRS_DEC_NT * 4))
 #endif
 constexpr int ACT_MAXV = MRS_ACT_MAXV, ACT_MAXW = MRS_ACT_MAXW;  // register-resident pieces: rows of <= 16384 values (8192 with a norm)
-struct ActPre { v4u xv[ACT_MAXV]; v4u wv[ACT_MAXW]; };
+// NV / NWV register-resident float4 pieces of the activation row / of the norm weights per thread.  The loads are unconditional (exact vmcnt
+// bookkeeping), and a load past the row still costs its ~16 cycles in the texture addresser: with 8 + 4 pieces per wave the out-of-range ones of a
+// 4096-wide row cost ~0.5 us per launch, so rows of <= 2 pieces (4096 values at 512 threads) run a <2, 2> instantiation (round 3)
+template <int NV_, int NWV_> struct ActPreT { static constexpr int NV = NV_, NWV = NWV_; v4u xv[NV_]; v4u wv[NWV_]; };
+using ActPre = ActPreT<ACT_MAXV, ACT_MAXW>;
+using ActPreSmall = ActPreT<2, 2>;
 __device__ __forceinline__ float4 as_f4(v4u v) { return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)); }
 
 // SC1: loads at agent scope (bypass the CU's L1) -- the persistent step kernel reads vectors that other CUs wrote a moment ago
@@ -113,15 +118,15 @@ template <bool SC1> __device__ __forceinline__ v4u ld_act(__amdgpu_buffer_rsrc_t
   if constexpr (SC1) return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16);
   else return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
 }
-template <bool SC1> __device__ __forceinline__ ActPre act_issue(const float *x, const float *nw, int K) {
-  ActPre p;
+template <bool SC1, class AP = ActPre> __device__ __forceinline__ AP act_issue(const float *x, const float *nw, int K) {
+  AP p;
   const unsigned off = (unsigned)tid_opaque() * 16u;
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)x, (short)0, K * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)(nw ? nw : x), (short)0, nw ? K * 4 : 0, 0x00020000);
 #pragma unroll
-  for (int j = 0; j < ACT_MAXV; ++j) p.xv[j] = ld_act<SC1>(rx, off + (unsigned)j * (unsigned)(ACT_STRIDE * 4));  // beyond K: out of range, zeros, no traffic
+  for (int j = 0; j < AP::NV; ++j) p.xv[j] = ld_act<SC1>(rx, off + (unsigned)j * (unsigned)(ACT_STRIDE * 4));  // beyond K: out of range, zeros, no traffic
 #pragma unroll
-  for (int j = 0; j < ACT_MAXW; ++j) p.wv[j] = ld_act<false>(rw, off + (unsigned)j * (unsigned)(ACT_STRIDE * 4));
+  for (int j = 0; j < AP::NWV; ++j) p.wv[j] = ld_act<false>(rw, off + (unsigned)j * (unsigned)(ACT_STRIDE * 4));
   return p;
 }
 
@@ -149,11 +154,10 @@ __device__ __forceinline__ float wave_sum_all(float v) {
 }
 
 
-// round half away from zero (C roundf / Rust f32::round) for |x| < 2^23, exact: trunc + a compare on the exact fraction
-__device__ __forceinline__ float round_away(float x) {
-  const float t = truncf(x);
-  return fabsf(x - t) >= 0.5f ? t + copysignf(1.0f, x) : t;
-}
+// round half away from zero (C roundf / Rust f32::round): trunc(x + copysign(0.49999997, x)) -- the largest float below one half -- equals roundf(x)
+// for EVERY float with |x| <= 129 (checked exhaustively, 2.2e9 values: tests/test_oracle.py::test_round_trick_exhaustive); the quantizers only round
+// products inside [-128, 128].  Three instructions instead of eight.
+__device__ __forceinline__ float round_away(float x) { return truncf(x + copysignf(0.49999997f, x)); }
 
 // x / m for the RmsNorm (candle: x / sqrt(mean + eps) * w): y = 1 / m correctly rounded (computed once per column), then Markstein's final step
 // q0 = x y, r = x - m q0 (exact in the fma), q = q0 + r y -- the correctly rounded quotient (checked against `/`: tests/test_dec_engine.py)
@@ -168,12 +172,14 @@ __device__ __forceinline__ float div_by(float x, float m, float y) {
 __device__ __forceinline__ void quantize4(float4 v, int e, int qoff, bool in, int mode, char *qc, float *dc, int *bsc) {
   const int lane = lane_opaque();
   if (mode == ACT_Q8K) {
-    const float ax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    // largest and smallest of the lane's four values: |.|max for the scale, and the two ballots below need one compare each
+    const float hi4 = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)), lo4 = fminf(fminf(v.x, v.y), fminf(v.z, v.w));
+    const float ax = fmaxf(hi4, -lo4);
     const float amax = wave_max_all(ax);
     // candle keeps the FIRST element with the largest magnitude and its sign decides iscale.  Only when +amax and -amax both occur in the block
     // does the order matter: two ballots settle the common case, the exact first-index search runs for such ties only (wave-uniform branch).
-    const unsigned long long bp = __ballot(v.x == amax || v.y == amax || v.z == amax || v.w == amax);
-    const unsigned long long bn = __ballot(v.x == -amax || v.y == -amax || v.z == -amax || v.w == -amax);
+    const unsigned long long bp = __ballot(hi4 == amax);
+    const unsigned long long bn = __ballot(lo4 == -amax);
     float mx = bn == 0 ? amax : -amax;
     if (bp != 0 && bn != 0 && amax != 0.f) {
       const int cand = fabsf(v.x) == amax ? 0 : (fabsf(v.y) == amax ? 1 : (fabsf(v.z) == amax ? 2 : (fabsf(v.w) == amax ? 3 : 1 << 20)));
@@ -189,11 +195,12 @@ __device__ __forceinline__ void quantize4(float4 v, int e, int qoff, bool in, in
       q2 = (int)fminf(127.f, round_away(iscale * v.z)); q3 = (int)fminf(127.f, round_away(iscale * v.w));
       dd = 1.0f / iscale;
     }
-    int s = (q0 + q1) + (q2 + q3);
+    const int packed = (q0 & 0xff) | ((q1 & 0xff) << 8) | ((q2 & 0xff) << 16) | ((q3 & 0xff) << 24);
+    int s = dot4(packed, 0x01010101, 0);  // q0 + q1 + q2 + q3 (signed bytes)
     s += dppi<0xB1>(s);
     s += dppi<0x4E>(s);  // 4 lanes = one 16-run
     if (in) {
-      *(int *)(qc + qoff) = (q0 & 0xff) | ((q1 & 0xff) << 8) | ((q2 & 0xff) << 16) | ((q3 & 0xff) << 24);
+      *(int *)(qc + qoff) = packed;
       if ((lane & 3) == 0) bsc[e >> 4] = s;
       if (lane == 0) dc[e >> 8] = dd;
     }
@@ -214,8 +221,8 @@ __device__ __forceinline__ void quantize4(float4 v, int e, int qoff, bool in, in
 // Whole workgroup, ends with a barrier.  `red` = NCOLS * NW floats of LDS scratch.  pre = act_issue() of column 0.
 // All columns' sums of squares go through ONE barrier (per column: the same per-thread / wave / workgroup summation order as a single-column call, so a
 // batched step stays bit-identical to single sequences), then every column is quantized: 2 barriers per launch instead of 2 per column.
-template <int NCOLS, bool SC1>
-__device__ __forceinline__ Act act_finish(char *smem, float *red, const ActPre &pre, const float *__restrict__ x, int ldx, const float *__restrict__ nw, float eps,
+template <int NCOLS, bool SC1, class AP = ActPre>
+__device__ __forceinline__ Act act_finish(char *smem, float *red, const AP &pre, const float *__restrict__ x, int ldx, const float *__restrict__ nw, float eps,
                                           int K, int mode, unsigned long long *tlp = nullptr) {
   const int tid = tid_opaque(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef MRS_DEC_TIMELINE
@@ -241,8 +248,8 @@ __device__ __forceinline__ Act act_finish(char *smem, float *red, const ActPre &
       float ss = 0.f;
       auto sq = [&](float4 v4) { ss = fmaf(v4.x, v4.x, ss); ss = fmaf(v4.y, v4.y, ss); ss = fmaf(v4.z, v4.z, ss); ss = fmaf(v4.w, v4.w, ss); };
 #pragma unroll
-      for (int j = 0; j < ACT_MAXV; ++j) if (j < nv) sq(c == 0 ? as_f4(pre.xv[j]) : xload(j));
-      for (int j = ACT_MAXV; j < nv; ++j) sq(xload(j));
+      for (int j = 0; j < AP::NV; ++j) if (j < nv) sq(c == 0 ? as_f4(pre.xv[j]) : xload(j));
+      for (int j = AP::NV; j < nv; ++j) sq(xload(j));
       ss = wave_sum_all(ss);
       if (lane == 0) red[c * NW + wave] = ss;
     }
@@ -275,9 +282,9 @@ __device__ __forceinline__ Act act_finish(char *smem, float *red, const ActPre &
       quantize4(v, e, qoff0 + j * ACT_STRIDE, e < K, mode, qc, dc, bsc);
     };
 #pragma unroll
-    for (int j = 0; j < ACT_MAXV; ++j)
-      if (j < nv) one(j, c == 0 ? as_f4(pre.xv[j]) : xload(j), j < ACT_MAXW ? as_f4(pre.wv[j < ACT_MAXW ? j : 0]) : (nw ? wload(j) : make_float4(1.f, 1.f, 1.f, 1.f)));
-    for (int j = ACT_MAXV; j < nv; ++j) one(j, xload(j), nw ? wload(j) : make_float4(1.f, 1.f, 1.f, 1.f));
+    for (int j = 0; j < AP::NV; ++j)
+      if (j < nv) one(j, c == 0 ? as_f4(pre.xv[j]) : xload(j), j < AP::NWV ? as_f4(pre.wv[j < AP::NWV ? j : 0]) : (nw ? wload(j) : make_float4(1.f, 1.f, 1.f, 1.f)));
+    for (int j = AP::NV; j < nv; ++j) one(j, xload(j), nw ? wload(j) : make_float4(1.f, 1.f, 1.f, 1.f));
   }
   MRS_TLP(20);  // wave 0 quantized its share
   __syncthreads();
@@ -296,7 +303,7 @@ template <int D> struct ActStager {
   bool staged;  // wave-uniform; false: finish() runs the whole prologue (act_finish)
   float inv, nm;
   __device__ __forceinline__ int first_q() const { return nw ? 3 : 1; }
-  __device__ __forceinline__ void quant(int j, const ActPre &pre) {
+  template <class AP> __device__ __forceinline__ void quant(int j, const AP &pre) {
     const int tid = tid_opaque(), wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qoff0 = (((tid >> 2) ^ sb_mask(wave)) << 4) | ((tid & 3) << 2);
     char *q = smem;
@@ -305,12 +312,12 @@ template <int D> struct ActStager {
     const int e = tid * 4 + j * ACT_STRIDE;
     float4 v = as_f4(pre.xv[j]);
     if (nw) {
-      const float4 w4 = as_f4(pre.wv[j < ACT_MAXW ? j : 0]);
+      const float4 w4 = as_f4(pre.wv[j < AP::NWV ? j : 0]);
       v.x = div_by(v.x, nm, inv) * w4.x; v.y = div_by(v.y, nm, inv) * w4.y; v.z = div_by(v.z, nm, inv) * w4.z; v.w = div_by(v.w, nm, inv) * w4.w;
     }
     quantize4(v, e, qoff0 + j * ACT_STRIDE, e < K, mode, q, d, bs);
   }
-  template <int I> __device__ __forceinline__ void stage(const ActPre &pre) {
+  template <int I, class AP> __device__ __forceinline__ void stage(const AP &pre) {
     if (!staged) return;
     const int tid = tid_opaque(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nv = (K + ACT_STRIDE - 1) / ACT_STRIDE;
@@ -319,7 +326,7 @@ template <int D> struct ActStager {
         float ss = 0.f;
         auto sq = [&](float4 v4) { ss = fmaf(v4.x, v4.x, ss); ss = fmaf(v4.y, v4.y, ss); ss = fmaf(v4.z, v4.z, ss); ss = fmaf(v4.w, v4.w, ss); };
 #pragma unroll
-        for (int j = 0; j < ACT_MAXV; ++j) if (j < nv) sq(as_f4(pre.xv[j]));
+        for (int j = 0; j < AP::NV; ++j) if (j < nv) sq(as_f4(pre.xv[j]));
         ss = wave_sum_all(ss);
         if (lane == 0) red[wave] = ss;
       } else if constexpr (I == 2) {
@@ -329,21 +336,21 @@ template <int D> struct ActStager {
         if constexpr (NW == 16) tot += ((r[8] + r[9]) + (r[10] + r[11])) + ((r[12] + r[13]) + (r[14] + r[15]));
         nm = sqrtf(tot / (float)K + eps);
         inv = 1.0f / nm;
-      } else if constexpr (I >= 3 && I - 3 < ACT_MAXV) {
+      } else if constexpr (I >= 3 && I - 3 < AP::NV) {
         if (I - 3 < nv) quant(I - 3, pre);
       }
     } else {
-      if constexpr (I >= 1 && I - 1 < ACT_MAXV) {
+      if constexpr (I >= 1 && I - 1 < AP::NV) {
         if (I - 1 < nv) quant(I - 1, pre);
       }
     }
   }
   // passes the stages did not reach + the closing barrier (staged), or the whole prologue
-  __device__ __forceinline__ Act finish(const ActPre &pre) {
+  template <class AP> __device__ __forceinline__ Act finish(const AP &pre) {
     const int nv = (K + ACT_STRIDE - 1) / ACT_STRIDE;
     const int done = D - first_q();
 #pragma unroll
-    for (int j = 0; j < ACT_MAXV; ++j) if (j >= done && j < nv) quant(j, pre);
+    for (int j = 0; j < AP::NV; ++j) if (j >= done && j < nv) quant(j, pre);
     __syncthreads();
     return Act{smem, (const float *)(smem + (size_t)K), (const int *)(smem + (size_t)K + (size_t)(K / 32) * 4), K};
   }

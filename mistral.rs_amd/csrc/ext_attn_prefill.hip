@@ -36,6 +36,7 @@ struct PrefillAttnArgs {
   float *out;                 // [T][o_stride] f32
   int T, start_pos, num_heads, num_kv_heads, q_stride, o_stride, kv_block_stride, kv_head_stride;
   float scale;
+  int window;  // > 0: sliding window (key <= pos - window is masked, paged_attention/layers/paged_attention.rs:551-553); 0 = causal only
 };
 
 template <int G>
@@ -51,6 +52,8 @@ __global__ void __launch_bounds__(64 * G) prefill_attn_kernel(const PrefillAttnA
   const int total_len = a.start_pos + a.T;            // keys [0, total_len) are valid in the cache
   const int last_q_pos = a.start_pos + min(qt * 32 + 31, a.T - 1);
   const int nkb = last_q_pos / BS + 1;                // key blocks this tile attends
+  const int first_q_pos = a.start_pos + qt * 32;
+  const int kb0 = a.window > 0 && first_q_pos >= a.window ? (first_q_pos - a.window + 1) / BS : 0;  // blocks before it are too old for every query of the tile
 
   // Q^T fragments: 8 d-steps of 16 dims; lane (query ql, half kh) holds dims dstep*16 + kh*8 .. +8
   bf16x8 qf[8];
@@ -70,7 +73,7 @@ __global__ void __launch_bounds__(64 * G) prefill_attn_kernel(const PrefillAttnA
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m = -FLT_MAX, l = 0.f;
 
-  for (int kb = 0; kb < nkb; ++kb) {
+  for (int kb = kb0; kb < nkb; ++kb) {
     const size_t base = (size_t)a.block_table[kb] * a.kv_block_stride + (size_t)kvh * a.kv_head_stride;
     // ---- S^T = K Q^T (32 keys x 32 queries)
     const uint16_t *kp = a.k_cache + base + (size_t)(kh * BS + ql) * 8;
@@ -97,7 +100,7 @@ __global__ void __launch_bounds__(64 * G) prefill_attn_kernel(const PrefillAttnA
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int kpos = kb * BS + (r & 3) + 8 * (r >> 2) + 4 * kh;
-      sv[r] = kpos <= p_q ? sacc[r] * a.scale : -FLT_MAX;
+      sv[r] = kpos <= p_q && (a.window <= 0 || kpos + a.window > p_q) ? sacc[r] * a.scale : -FLT_MAX;
       mx = fmaxf(mx, sv[r]);
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -167,15 +170,26 @@ __global__ void __launch_bounds__(64 * G) prefill_attn_kernel(const PrefillAttnA
 
 // q [T][q_stride] f32 over a bf16 paged cache (block 32, head_dim 128), positions start_pos .. start_pos+T-1, keys 0 .. start_pos+T-1
 // already in the cache.  out [T][o_stride] f32.  Returns 0, -1 for unsupported shapes (caller falls back to paged_attention).
+extern "C" int mrs_prefill_attention_window_f32_bf16(const float *q, const void *key_cache, const void *value_cache, const uint32_t *block_table,
+                                                     float *out, int T, int start_pos, int num_heads, int num_kv_heads, int head_size, int block_size,
+                                                     int q_stride, int o_stride, int kv_block_stride, int kv_head_stride, float scale, int sliding_window, void *stream);
 extern "C" int mrs_prefill_attention_f32_bf16(const float *q, const void *key_cache, const void *value_cache, const uint32_t *block_table,
                                               float *out, int T, int start_pos, int num_heads, int num_kv_heads, int head_size, int block_size,
                                               int q_stride, int o_stride, int kv_block_stride, int kv_head_stride, float scale, void *stream) {
+  return mrs_prefill_attention_window_f32_bf16(q, key_cache, value_cache, block_table, out, T, start_pos, num_heads, num_kv_heads, head_size, block_size, q_stride, o_stride,
+                                               kv_block_stride, kv_head_stride, scale, 0, stream);
+}
+// sliding_window > 0: query at position p attends keys (p - W, p] only (Mistral; eager_attention_mask / the prompt mask of
+// mistralrs-core/src/paged_attention/layers/paged_attention.rs:551-553); key blocks that are too old for every query of a tile are skipped
+extern "C" int mrs_prefill_attention_window_f32_bf16(const float *q, const void *key_cache, const void *value_cache, const uint32_t *block_table,
+                                                     float *out, int T, int start_pos, int num_heads, int num_kv_heads, int head_size, int block_size,
+                                                     int q_stride, int o_stride, int kv_block_stride, int kv_head_stride, float scale, int sliding_window, void *stream) {
   using namespace mrs;
   if (T <= 0) return 0;
   if (head_size != 128 || block_size != 32 || num_heads % num_kv_heads) return -1;
   const int G = num_heads / num_kv_heads;
   PrefillAttnArgs a{q, (const uint16_t *)key_cache, (const uint16_t *)value_cache, block_table, out, T, start_pos, num_heads, num_kv_heads,
-                    q_stride, o_stride, kv_block_stride, kv_head_stride, scale};
+                    q_stride, o_stride, kv_block_stride, kv_head_stride, scale, sliding_window > 0 ? sliding_window : 0};
   const dim3 grid((T + 31) / 32, num_kv_heads);
   hipStream_t s = (hipStream_t)stream;
   switch (G) {

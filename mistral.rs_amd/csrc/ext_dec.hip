@@ -36,6 +36,7 @@ struct GemvArgs {
   float *q_out; void *k_cache, *v_cache; const int64_t *slot_mapping; const int32_t *positions; const float *cos_t, *sin_t;
   int head_dim, rot_pairs, num_kv_heads, block_size, cache_x, kv_f16;
   int units, units_per_wave;
+  int upw3[3];  // EPI_QKV: RoPE pairs per wave of q, k, v (the byte-heaviest tensors get the shorter runs; 0 = units_per_wave)
   int wstart[4];  // EPI_QKV: first wave of q, k, v and the total
   const int32_t *expert_sel;  // stacked experts [E * nrows][K]: rows of expert e start at e * nrows (nullptr = dense)
   const float *acc_scale;     // RESID: out = out * resid_scale + (*acc_scale) * W.x  (routing weight)
@@ -68,7 +69,7 @@ struct GemvArgs {
 #define MRS_DEC_STREAM(TYPE_EXPR, NC, SEGCOL, sg, epi, skip)                                                                         \
   MRS_DEC_TYPE_SWITCH(TYPE_EXPR, {                                                                                                   \
     ActStager<Tile<TT>::DEPTH> stg_{smem, red, a.x, a.norm_w, a.eps, K, act_mode_for(TT), a.tl ? a.tl + blockIdx.x * 32 : nullptr, can_stage, 1.0f, 1.0f};                          \
-    auto pro2 = [&](const ActPre &p_) -> Act {                                                                                       \
+    auto pro2 = [&](const AP &p_) -> Act {                                                                                       \
       if (!stg_.staged) return pro(p_);                                                                                              \
       MRS_TLW(a, 1);                                                                                                                 \
       const Act r_ = stg_.finish(p_);                                                                                                \
@@ -97,7 +98,7 @@ __device__ __forceinline__ float rl(float v, int lane) { return __builtin_bit_ca
 // first, then sync() waits for the grid, then the activations are loaded at agent scope and quantized.  Launch-per-phase: LATE = false, the
 // activation loads go out before the ring (they are at the head of the wave's in-order load queue) and sync() is empty.
 struct NoSync { __device__ __forceinline__ void operator()() const {} };
-template <int NCOLS, int EPI, bool LATE = false, class Sync = NoSync>
+template <int NCOLS, int EPI, bool LATE = false, class Sync = NoSync, class AP = ActPre>
 __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float *red, Sync sync = Sync()) {
   const int tid0 = tid_opaque();
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6), lane = tid0 & 63;  // readfirstlane: lets hipcc keep everything derived from the wave index in SGPRs
@@ -105,27 +106,27 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
   const int K = a.K;
   MRS_TL(a, 0, 0);
   // the activation image is staged once per workgroup
-  auto pre = [&]() -> ActPre {
-    if constexpr (LATE) return ActPre{};
+  auto pre = [&]() -> AP {
+    if constexpr (LATE) return AP{};
     // a pre-quantized image goes through the same registers: its 16-byte pieces sit at tid * 16 + j * NT * 16, like the f32 vector's
-    else return act_issue<false>(a.x_img ? (const float *)a.x_img : a.x, a.x_img ? nullptr : a.norm_w, a.x_img ? (int)(act_bytes(K, NCOLS) / 4) : K);
+    else return act_issue<false, AP>(a.x_img ? (const float *)a.x_img : a.x, a.x_img ? nullptr : a.norm_w, a.x_img ? (int)(act_bytes(K, NCOLS) / 4) : K);
   };
-  auto pro = [&](const ActPre &p) -> Act {
+  auto pro = [&](const AP &p) -> Act {
     if constexpr (LATE) {
       sync();
-      const ActPre late = act_issue<MRS_DEC_AGENT_IO != 0>(a.x, a.norm_w, K);
-      return act_finish<NCOLS, MRS_DEC_AGENT_IO != 0>(smem, red, late, a.x, a.ldx, a.norm_w, a.eps, K, act_mode_for(a.m[0].type));
+      const AP late = act_issue<MRS_DEC_AGENT_IO != 0, AP>(a.x, a.norm_w, K);
+      return act_finish<NCOLS, MRS_DEC_AGENT_IO != 0, AP>(smem, red, late, a.x, a.ldx, a.norm_w, a.eps, K, act_mode_for(a.m[0].type));
     } else {
       if (a.x_img) {
 #pragma unroll
-        for (int j = 0; j < ACT_MAXV; ++j)
+        for (int j = 0; j < AP::NV; ++j)
           if ((size_t)(tid0 * 16 + j * NT * 16) < act_bytes(K, NCOLS)) *(v4u *)(smem + tid0 * 16 + j * NT * 16) = p.xv[j];
         __syncthreads();
         return Act{smem, (const float *)(smem + (size_t)NCOLS * K), (const int *)(smem + (size_t)NCOLS * K + (size_t)NCOLS * (K / 32) * 4), K};
       }
       if (a.ablate & 1) { __syncthreads(); return Act{smem, (const float *)(smem + (size_t)NCOLS * K), (const int *)(smem + (size_t)NCOLS * K + (size_t)NCOLS * (K / 32) * 4), K}; }
       MRS_TLW(a, 1);  // ring issued (per wave: slots 1..8)
-      const Act r = act_finish<NCOLS, false>(smem, red, p, a.x, a.ldx, a.norm_w, a.eps, K, act_mode_for(a.m[0].type), a.tl ? a.tl + blockIdx.x * 32 : nullptr);
+      const Act r = act_finish<NCOLS, false, AP>(smem, red, p, a.x, a.ldx, a.norm_w, a.eps, K, act_mode_for(a.m[0].type), a.tl ? a.tl + blockIdx.x * 32 : nullptr);
       MRS_TL(a, 0, 10);  // prologue done (after its last barrier)
       return r;
     }
@@ -134,7 +135,7 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
   int u0 = min(gw * a.units_per_wave, a.units), u1 = min(u0 + a.units_per_wave, a.units);
   int slot = 0;
   if (a.slots > 1) {  // the launcher made units_per_wave a divisor of nrows: a wave never straddles two experts
-    slot = u0 / a.nrows[0];
+    slot = min(u0 / a.nrows[0], a.slots - 1);  // a tail wave without units (u0 == units) must not index expert_sel[slots] (advisor, round 2)
     u0 -= slot * a.nrows[0]; u1 -= slot * a.nrows[0];
   }
   const int eoff = a.expert_sel ? a.expert_sel[slot] * a.nrows[0] : 0;
@@ -213,7 +214,9 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
     const int mi = gw >= a.wstart[2] ? 2 : (gw >= a.wstart[1] ? 1 : 0);
     const int npairs = (mi == 0 ? a.nrows[0] : (mi == 1 ? a.nrows[1] : a.nrows[2])) >> 1;
     const int w0 = mi == 0 ? a.wstart[0] : (mi == 1 ? a.wstart[1] : a.wstart[2]);
-    const int p0 = min((gw - w0) * a.units_per_wave, npairs), p1 = min(p0 + a.units_per_wave, npairs);
+    const int upw_sel = mi == 0 ? a.upw3[0] : (mi == 1 ? a.upw3[1] : a.upw3[2]);
+    const int upw_i = upw_sel > 0 ? upw_sel : a.units_per_wave;
+    const int p0 = min((gw - w0) * upw_i, npairs), p1 = min(p0 + upw_i, npairs);
     const int r0 = 2 * p0;
     // epilogue operands up front: lane i <-> pair i of the wave
     float pcs[NCOLS], psn[NCOLS];
@@ -278,11 +281,12 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
   }
 }
 
-template <int NCOLS, int EPI>
+// SMALL: rows of <= 2 register-resident pieces per thread (ActPreSmall): the one-column launches of 4096-wide rows
+template <int NCOLS, int EPI, bool SMALL = false>
 __global__ void __launch_bounds__(NT) dec_gemv_kernel(const GemvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ float red[8 * NW];  // RMSNorm partials: [column][wave]
-  gemv_phase<NCOLS, EPI>(a, smem, red);
+  gemv_phase<NCOLS, EPI, false, NoSync, typename std::conditional<SMALL, ActPreSmall, ActPre>::type>(a, smem, red);
   MRS_TLW(a, 11);  // per-wave end: slots 11..18
 }
 
@@ -534,8 +538,8 @@ __global__ void __launch_bounds__(FUSED_NW * 64) decode_attn_fused_kernel(const 
 }
 
 // ------------------------------------------------------------------------------------------------ decode attention, split + last-arriver merge
-// Round 3 default.  Grid (kv heads, sequences, ceil(max splits / 4)), 4 waves = 4 splits per workgroup, no barrier in the split phase (as
-// decode_attn_wave_kernel).  Instead of a second launch for the merge (4.9 us + a kernel boundary per layer), every workgroup publishes its
+// Round 3.  Grid (kv heads, sequences, ceil(max splits / 4)), 4 waves = 4 splits per workgroup, no barrier in the split phase (as
+// decode_attn_wave_kernel).  TICKET variant: instead of a second launch for the merge (4.9 us + a kernel boundary per layer), every workgroup publishes its
 // partials write-through at agent scope, drains its stores and takes a ticket on the (sequence, kv head) counter; the workgroup that draws the
 // last ticket merges all G heads of the kv head: wave w = query heads 2w, 2w + 1 (256 output values = ONE Q8_K superblock of the attention
 // vector), lane = 4 consecutive dims, sequential over the splits (attn_merge_core's order).  It writes the f32 result and -- what o_proj's
@@ -547,51 +551,30 @@ struct Attn2Args {
   unsigned *ticket;  // [seqs][kv heads], zero at rest
   uint8_t *img;      // Q8_K image of [seqs] columns of num_heads * 128 values, or nullptr (odd GQA groups: the caller's o_proj quantizes)
 };
-template <int G, class CT>
-__global__ void __launch_bounds__(256) dec_attn2_kernel(const Attn2Args a) {
-  constexpr int HD = 128;
-  __shared__ __attribute__((aligned(16))) float q_s[4][G * HD + G * 32];
-  __shared__ int last_s;
+// merge of one (sequence, kv head): wave w <-> query heads (2w, 2w + 1) of the group (G == 1: wave 0, one head in lanes 0..31), lane = 4 consecutive
+// dims, sequential over the splits.  AGENT: the partials were published by other workgroups of the SAME launch (sc1 loads); else plain loads.
+template <int G, bool AGENT>
+__device__ __forceinline__ void attn2_merge(const Attn2Args &a, int kvh, int seq, int ns, int wave, int lane, int ncols) {
+  constexpr int HD = 128, NP = (G + 1) / 2;
   const AttnArgs &t = a.t;
-  const int tid = tid_opaque(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kvh = blockIdx.x, seq = blockIdx.y;
-  const int nblk = ((int)t.context_lens[seq] + 31) / 32;
-  const int ns = (nblk + t.bpw - 1) / t.bpw, nwg = (ns + 3) / 4;
-  if ((int)blockIdx.z >= nwg) return;  // workgroup-uniform: no split of this sequence lands here
-  const int split = blockIdx.z * 4 + wave, head0 = kvh * G;
-  if (split < ns) {
-    const int b0 = split * t.bpw, b1 = min(b0 + t.bpw, nblk);
-    attn_split_core<G, CT>(t, kvh, head0, seq, b0, b1, q_s[wave], q_s[wave] + G * HD, [&](int g, float o0, float o1, float m, float l) {
-      const size_t pi = ((size_t)seq * t.num_heads + head0 + g) * t.max_splits + split;
-      __hip_atomic_store(t.part_o + pi * HD + lane, o0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(t.part_o + pi * HD + lane + 64, o1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (lane == 0) {
-        __hip_atomic_store(t.part_m + pi, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(t.part_l + pi, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    });
-  }
-  MRS_WAIT_VMCNT0();  // this wave's partials have left the CU
-  __syncthreads();
-  unsigned *tk = a.ticket + (size_t)seq * t.num_kv_heads + kvh;
-  if (tid == 0) last_s = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nwg - 1);
-  __syncthreads();
-  if (!last_s) return;
-  if (tid == 0) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every other workgroup of this (seq, kv head) has already drawn
-  // ---- merge: wave w <-> heads (2w, 2w + 1) of the group (G == 1: wave 0, one head in lanes 0..31)
-  constexpr int NP = (G + 1) / 2;
   if (wave >= NP) return;
-  const int hsel = lane >> 5, head = head0 + 2 * wave + hsel;
+  const int head0 = kvh * G, hsel = lane >> 5, head = head0 + 2 * wave + hsel;
   const bool live = 2 * wave + hsel < G;
   const size_t pA = ((size_t)seq * t.num_heads + head0 + 2 * wave) * t.max_splits;                 // partials of head A (lanes 0..31)
   const size_t pB = ((size_t)seq * t.num_heads + head0 + min(2 * wave + 1, G - 1)) * t.max_splits;  // head B (lanes 32..63)
-  auto ldw = [&](const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  auto ldw = [&](const float *p) { if constexpr (AGENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else return *p; };
   const float mA = lane < ns ? ldw(t.part_m + pA + lane) : -FLT_MAX, lA = lane < ns ? ldw(t.part_l + pA + lane) : 0.f;
   const float mB = lane < ns ? ldw(t.part_m + pB + lane) : -FLT_MAX, lB = lane < ns ? ldw(t.part_l + pB + lane) : 0.f;
-  const float wA = fast_exp_ref(mA - wave_max(mA)), wB = fast_exp_ref(mB - wave_max(mB));
-  // one descriptor for both heads' partials (wave-uniform); the lanes of head B add its distance
+  // one descriptor for both heads' partials (wave-uniform); the lanes of head B add its distance.  The partial outputs of up to 16 splits are
+  // requested before anything is consumed
   const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)(t.part_o + pA * HD), (short)0, (int)((pB - pA + ns) * HD * 4), 0x00020000);
   const unsigned off0 = (unsigned)(lane & 31) * 16u + (hsel ? (unsigned)((pB - pA) * HD * 4) : 0u);
+  constexpr int MB = 16;
+  constexpr int AUX = AGENT ? 16 : 0;
+  v4u r[MB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i) r[i] = __builtin_amdgcn_raw_buffer_load_b128(ro, off0 + (unsigned)i * 512u, 0, AUX);  // past the last split of head B: out of range, zeros
+  const float wA = fast_exp_ref(mA - wave_max(mA)), wB = fast_exp_ref(mB - wave_max(mB));
   float s_all = 0.f;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   auto step = [&](int j, v4u raw) {
@@ -603,24 +586,85 @@ __global__ void __launch_bounds__(256) dec_attn2_kernel(const Attn2Args a) {
     const float t0 = o.x * wj, t1 = o.y * wj, t2 = o.z * wj, t3 = o.w * wj;
     acc.x = acc.x + t0; acc.y = acc.y + t1; acc.z = acc.z + t2; acc.w = acc.w + t3;
   };
-  int j = 0;
-  for (; j + 4 <= ns; j += 4) {  // four agent-scope (sc1) loads in flight per lane
-    const v4u r0 = __builtin_amdgcn_raw_buffer_load_b128(ro, off0 + (unsigned)(j + 0) * 512u, 0, 16), r1 = __builtin_amdgcn_raw_buffer_load_b128(ro, off0 + (unsigned)(j + 1) * 512u, 0, 16);
-    const v4u r2 = __builtin_amdgcn_raw_buffer_load_b128(ro, off0 + (unsigned)(j + 2) * 512u, 0, 16), r3 = __builtin_amdgcn_raw_buffer_load_b128(ro, off0 + (unsigned)(j + 3) * 512u, 0, 16);
-    step(j, r0); step(j + 1, r1); step(j + 2, r2); step(j + 3, r3);
+  for (int j0 = 0; j0 < ns; j0 += MB) {
+    if (j0 > 0) {
+#pragma unroll
+      for (int i = 0; i < MB; ++i) r[i] = __builtin_amdgcn_raw_buffer_load_b128(ro, off0 + (unsigned)(j0 + i) * 512u, 0, AUX);
+    }
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+      if (j0 + i < ns) step(j0 + i, r[i]);  // wave-uniform
   }
-  for (; j < ns; ++j) step(j, __builtin_amdgcn_raw_buffer_load_b128(ro, off0 + (unsigned)j * 512u, 0, 16));
   const float inv = 1.0f / s_all;
   const float4 v = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
   if (t.out && live) *(float4 *)(t.out + ((size_t)seq * t.num_heads + head) * HD + (lane & 31) * 4) = v;
   if (a.img) {  // G even: the wave's 256 values = superblock (head0 + 2 wave) / 2 of column seq
-    const int K = t.num_heads * HD, ncols = gridDim.y, sb = (head0 + 2 * wave) >> 1;
+    const int K = t.num_heads * HD, sb = (head0 + 2 * wave) >> 1;
     char *qc = (char *)a.img + (size_t)seq * K;
     float *dc = (float *)(a.img + (size_t)ncols * K) + (size_t)seq * (K / 32);
     int *bsc = (int *)(a.img + (size_t)ncols * K + (size_t)ncols * (K / 32) * 4) + (size_t)seq * (K / 16);
     const int e = sb * 256 + lane * 4, piece = e >> 4;
     quantize4(v, e, ((piece ^ sb_mask(sb)) << 4) | ((lane & 3) << 2), true, ACT_Q8K, qc, dc, bsc);
   }
+}
+
+// TICKET: one launch (the last workgroup of a (sequence, kv head) merges); else the split phase only and dec_attn2_merge_kernel follows
+template <int G, class CT, bool TICKET>
+__global__ void __launch_bounds__(256) dec_attn2_kernel(const Attn2Args a) {
+  constexpr int HD = 128;
+  __shared__ __attribute__((aligned(16))) float q_s[4][G * HD + G * 32];
+  __shared__ int last_s;
+  const AttnArgs &t = a.t;
+  const int tid = tid_opaque(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kvh = blockIdx.x, seq = blockIdx.y;
+  const int split = blockIdx.z * 4 + wave, head0 = kvh * G;
+  // the first page index of the split does not depend on the context length: both scalar loads leave together (they used to be a chain)
+  const unsigned blk_first = t.block_tables[(size_t)seq * t.max_blocks_per_seq + min(split * t.bpw, t.max_blocks_per_seq - 1)];
+  const int nblk = ((int)t.context_lens[seq] + 31) / 32;
+  const int ns = (nblk + t.bpw - 1) / t.bpw, nwg = (ns + 3) / 4;
+  if ((int)blockIdx.z >= nwg) return;  // workgroup-uniform: no split of this sequence lands here
+  if (split < ns) {
+    const int b0 = split * t.bpw, b1 = min(b0 + t.bpw, nblk);
+    const int ctx_w = (int)t.context_lens[seq], lo_w = t.window > 0 && ctx_w > t.window ? ctx_w - t.window : 0;
+    auto publish = [&](int g, float o0, float o1, float m, float l) {
+      const size_t pi = ((size_t)seq * t.num_heads + head0 + g) * t.max_splits + split;
+      if constexpr (TICKET) {
+        __hip_atomic_store(t.part_o + pi * HD + lane, o0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(t.part_o + pi * HD + lane + 64, o1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) {
+          __hip_atomic_store(t.part_m + pi, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(t.part_l + pi, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      } else {
+        t.part_o[pi * HD + lane] = o0;
+        t.part_o[pi * HD + lane + 64] = o1;
+        if (lane == 0) { t.part_m[pi] = m; t.part_l[pi] = l; }
+      }
+    };
+    if (b1 * 32 <= lo_w) {  // every block of the split lies before the sliding window: the partial a fully masked pass would give, without reading K / V
+#pragma unroll
+      for (int g = 0; g < G; ++g) publish(g, 0.f, 0.f, -FLT_MAX, 0.f);
+    } else {
+      attn_split_core<G, CT>(t, kvh, head0, seq, b0, b1, q_s[wave], q_s[wave] + G * HD, publish, (int)blk_first);
+    }
+  }
+  if constexpr (TICKET) {
+    MRS_WAIT_VMCNT0();  // this wave's partials have left the CU
+    __syncthreads();
+    unsigned *tk = a.ticket + (size_t)seq * t.num_kv_heads + kvh;
+    if (tid == 0) last_s = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nwg - 1);
+    __syncthreads();
+    if (!last_s) return;
+    if (tid == 0) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every other workgroup of this (seq, kv head) has already drawn
+    attn2_merge<G, true>(a, kvh, seq, ns, wave, lane, gridDim.y);
+  }
+}
+// the merge as its own launch: grid (kv heads, sequences), (G + 1) / 2 waves
+template <int G>
+__global__ void __launch_bounds__(64 * ((G + 1) / 2)) dec_attn2_merge_kernel(const Attn2Args a) {
+  const int tid = tid_opaque(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nblk = ((int)a.t.context_lens[blockIdx.y] + 31) / 32;
+  attn2_merge<G, false>(a, blockIdx.x, blockIdx.y, (nblk + a.t.bpw - 1) / a.t.bpw, wave, lane, gridDim.y);
 }
 
 // experiment support (-DMRS_DEC_TIMELINE builds): mrs_dec_timeline(buf, cap) hands the launchers a device buffer of cap records of 256 x 32 stamps;
@@ -652,23 +696,72 @@ template <int EPI> struct Launch {
     a.units_per_wave = upw;
     int grid = (a.units + upw * NW - 1) / (upw * NW);
     if (EPI == EPI_QKV) {
+      // pairs per wave per tensor: start from the common figure, then shorten the runs of the tensor with the most bytes per wave while the waves
+      // still fit one workgroup per CU (8B: q 2 / k 1 / v 1 pairs -> 256 workgroups instead of 192, the Q6_K v rows no longer the long pole)
+      static const int bal = [] { const char *e = getenv("MRS_DEC_QKV_BALANCE"); return e ? atoi(e) : 1; }();
+      int u3[3] = {upw, upw, upw};
+      auto waves_of = [&](const int *u) { int w = 0; for (int i = 0; i < 3; ++i) w += ((a.nrows[i] >> 1) + u[i] - 1) / u[i]; return w; };
+      auto row_bytes = [&](int i) { const Planes p = plane_layout(a.m[i].type, 1, a.K); return (double)p.total; };
+      for (int it = 0; bal && it < 8; ++it) {
+        int best = -1; double worst = 0;
+        for (int i = 0; i < 3; ++i) { const double b = u3[i] * 2 * row_bytes(i); if (u3[i] > 1 && b > worst) { worst = b; best = i; } }
+        if (best < 0) break;
+        int t3[3] = {u3[0], u3[1], u3[2]};
+        // the heaviest first; if it does not fit, try the others in turn
+        bool moved = false;
+        for (int k = 0; k < 3 && !moved; ++k) {
+          const int i = (best + k) % 3;
+          if (t3[i] <= 1) continue;
+          t3[i] -= 1;
+          if (waves_of(t3) <= 256 * NW) { u3[i] = t3[i]; moved = true; } else t3[i] += 1;
+        }
+        if (!moved) break;
+      }
       a.wstart[0] = 0;
-      for (int i = 0; i < 3; ++i) a.wstart[i + 1] = a.wstart[i] + ((a.nrows[i] >> 1) + upw - 1) / upw;
+      for (int i = 0; i < 3; ++i) { a.upw3[i] = u3[i]; a.wstart[i + 1] = a.wstart[i] + ((a.nrows[i] >> 1) + u3[i] - 1) / u3[i]; }
       grid = (a.wstart[3] + NW - 1) / NW;
     }
     size_t lds = (act_bytes(a.K, NCOLS) + 15) & ~(size_t)15;
     if (lds > 158 * 1024) return -2;
     { static long pad = -1; if (pad < 0) { const char *e = getenv("MRS_DEC_LDS_PAD"); pad = e ? atol(e) : 0; } if ((size_t)pad > lds && pad <= 158 * 1024) lds = (size_t)pad; }  // experiment: > 80 KiB forces one workgroup per CU
-    auto kern = dec_gemv_kernel<NCOLS, EPI>;
+    if constexpr (NCOLS == 1 && EPI != EPI_RESID2) {
+      static const int small_on = [] { const char *e = getenv("MRS_DEC_SMALL"); return e ? atoi(e) : 1; }();
+      const size_t pieces = a.x_img ? act_bytes(a.K, NCOLS) : (size_t)a.K * 4;  // bytes that travel through the prologue's registers
+      if (small_on && pieces <= (size_t)ActPreSmall::NV * NT * 16) {
+        a.staged = a.staged && (!a.norm_w || a.K <= ActPreSmall::NWV * ACT_STRIDE);
+        auto kern = dec_gemv_kernel<NCOLS, EPI, true>;
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024); attr = true; }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, s, a);
+        return 0;
+      }
+    }
+    auto kern = dec_gemv_kernel<NCOLS, EPI, false>;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024); attr = true; }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, s, a);
     return 0;
   }
+  // activation columns [c0, ...) of a batched launch: every per-column pointer moves
+  static GemvArgs shift_cols(GemvArgs a, int c0) {
+    if (a.x) a.x += (size_t)c0 * a.ldx;
+    if (a.out) a.out += (size_t)c0 * a.out_stride;
+    if (a.q_out) a.q_out += (size_t)c0 * a.nrows[0];
+    if (a.positions) a.positions += c0;
+    if (a.slot_mapping) a.slot_mapping += c0;
+    return a;
+  }
   static int run(const GemvArgs &a, int b, hipStream_t s) {
 #ifdef MRS_DEC_EXP_B1  // experiment builds: batch 1 only (an eighth of the compile time)
     return b == 1 ? go<1>(a, s) : -1;
 #endif
+    // the activation image of all columns must fit LDS (1.375 K bytes per column): wider batches run as column groups, each a launch of its own
+    // (Llama-3-70B down_proj, K = 28672: 4 columns per launch) -- advisor, round 2: such batches used to fail with -2
+    if (b > 1 && !a.x_img && act_bytes(a.K, b) > 158 * 1024) {
+      const int half = b / 2;
+      const int rc = run(a, half, s);
+      return rc ? rc : run(shift_cols(a, half), b - half, s);
+    }
     switch (b) {
     case 1: return go<1>(a, s); case 2: return go<2>(a, s); case 3: return go<3>(a, s); case 4: return go<4>(a, s);
     case 5: return go<5>(a, s); case 6: return go<6>(a, s); case 7: return go<7>(a, s); case 8: return go<8>(a, s);
@@ -819,7 +912,7 @@ extern "C" int mrs_dec_attention_q8k(void *img_out, float *out_f32, const float 
 extern "C" int mrs_dec_attention(float *out_f32, void *img_out, unsigned *ticket, float *part_o, float *part_m, float *part_l, const float *q, const void *k_cache,
                                  const void *v_cache, int num_kv_heads, float scale, const uint32_t *block_tables, const uint32_t *context_lens, int block_size,
                                  int max_context_len, int num_seqs, int num_heads, int head_size, int max_blocks_per_seq, int q_stride, int kv_block_stride,
-                                 int kv_head_stride, int kv_dtype, void *stream) {
+                                 int kv_head_stride, int kv_dtype, int sliding_window, void *stream) {
   if (!ticket || !part_o || !part_m || !part_l || block_size != 32 || head_size != 128 || num_seqs <= 0 || num_kv_heads <= 0 || num_heads % num_kv_heads ||
       (kv_dtype != 0 && kv_dtype != 1) || max_context_len <= 0) return -1;
   const int G = num_heads / num_kv_heads;
@@ -832,6 +925,7 @@ extern "C" int mrs_dec_attention(float *out_f32, void *img_out, unsigned *ticket
   t.part_o = part_o; t.part_m = part_m; t.part_l = part_l; t.out = out_f32;
   t.num_heads = num_heads; t.num_kv_heads = num_kv_heads; t.max_blocks_per_seq = max_blocks_per_seq; t.q_stride = q_stride;
   t.kv_block_stride = kv_block_stride; t.kv_head_stride = kv_head_stride; t.num_seqs = num_seqs; t.scale = scale;
+  t.window = sliding_window > 0 ? sliding_window : 0;
   const int nblk = (max_context_len + 31) / 32;
   t.bpw = nblk <= 64 ? 1 : (nblk + 63) / 64;                        // == dec_bpw() of paged_attention.hip: at most 64 splits
   t.max_splits = mrs_decode_attention_max_splits(max_context_len);  // stride of the partials, as in the two-launch route
@@ -839,7 +933,19 @@ extern "C" int mrs_dec_attention(float *out_f32, void *img_out, unsigned *ticket
   const int nsplit = (nblk + t.bpw - 1) / t.bpw;
   const dim3 grid(num_kv_heads, num_seqs, (nsplit + 3) / 4);
   hipStream_t s = (hipStream_t)stream;
-#define MRS_A2(GG, CT) hipLaunchKernelGGL((dec_attn2_kernel<GG, CT>), grid, dim3(256), 0, s, a)
+  // MRS_DEC_ATTN_TICKET (default 1): the merge inside the split launch (last arriver); 0 = a second launch for the merge.  Measured on the MI355X
+  // (profiles/round3_decode.md): the hand-off (write-through partials, drain, device-scope ticket, sc1 loads) costs about what the second launch and its
+  // boundary cost -- 472.8 vs 465.4 tok/s for the whole step
+  static const int one_launch = [] { const char *e = getenv("MRS_DEC_ATTN_TICKET"); return e ? atoi(e) : 1; }();
+  const dim3 mgrid(num_kv_heads, num_seqs);
+#define MRS_A2(GG, CT)                                                                                                   \
+  do {                                                                                                                   \
+    if (one_launch) hipLaunchKernelGGL((dec_attn2_kernel<GG, CT, true>), grid, dim3(256), 0, s, a);                      \
+    else {                                                                                                               \
+      hipLaunchKernelGGL((dec_attn2_kernel<GG, CT, false>), grid, dim3(256), 0, s, a);                                   \
+      hipLaunchKernelGGL((dec_attn2_merge_kernel<GG>), mgrid, dim3(64 * ((GG + 1) / 2)), 0, s, a);                       \
+    }                                                                                                                    \
+  } while (0)
 #define MRS_A2G(CT) switch (G) { case 1: MRS_A2(1, CT); break; case 2: MRS_A2(2, CT); break; case 4: MRS_A2(4, CT); break; default: MRS_A2(8, CT); break; }
   if (kv_dtype == 1) { MRS_A2G(bf16_t) } else { MRS_A2G(f16_t) }
 #undef MRS_A2G

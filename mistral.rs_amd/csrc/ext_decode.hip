@@ -590,6 +590,11 @@ __global__ void __launch_bounds__(1024) moe_router_kernel(const float *__restric
     for (int k = 0; k < top_k; ++k) {
       int best = -1; float bv = -INFINITY;
       for (int e = 0; e < E; ++e) if (!((used >> e) & 1ull) && lg[e] > bv) { bv = lg[e]; best = e; }
+      if (best < 0) {  // every remaining logit is NaN or -inf (no comparison was true): take the lowest unused expert instead of shifting by -1 /
+                       // storing expert -1 (advisor, rounds 1-2); its weight is NaN / 0 as the arithmetic gives it
+        for (int e = 0; e < E && best < 0; ++e) if (!((used >> e) & 1ull)) best = e;
+        bv = lg[best];
+      }
       used |= 1ull << best;
       const float p = expf(bv - mx) / den;
       ids[(size_t)tok * top_k + k] = best;

@@ -68,6 +68,7 @@ struct QTensor {
   const void *data = nullptr;
   int dtype = -1;
   int64_t rows = 0, cols = 0;
+  mutable const void *g2 = nullptr;  // MFMA-layout copy for the prompt GEMM of ext_gemm2.hip (mrs_gemm2_repack; caller-owned, optional)
   size_t nbytes() const { const auto *t = type_info(dtype); return t ? (size_t)rows * (cols / t->block) * t->bytes : 0; }
 };
 
@@ -487,7 +488,7 @@ class Llama {
         const bool want_img = bl.dout.type != 8 && (cfg.num_heads / kvh) % 2 == 0 && mrs_dec_act_image_bytes(nq, b) <= mrs_dec_proj_img_max_bytes();
         const int rc2 = mrs_dec_attention(want_img ? nullptr : ws.attn, want_img ? ws.attn_img : nullptr, ws.attn_ticket, (float *)ws.attn_ws, ws.max_logits, ws.exp_sums, ws.q,
                                           bl.key_cache, bl.value_cache, kvh, 1.0f / sqrtf((float)hd), bufs.block_tables, bufs.context_lens, bs, eff_max, b, cfg.num_heads, hd,
-                                          cfg.max_blocks_per_seq, nq, kvh * hd * bs, hd * bs, kvd, s);
+                                          cfg.max_blocks_per_seq, nq, kvh * hd * bs, hd * bs, kvd, cfg.sliding_window, s);
         if (rc2 < 0) return fail("mrs_dec_attention refused the shape");
         const int prc = rc2 == 1 ? mrs_dec_proj_img(&bl.dout, d, ws.attn_img, ws.h, d, 1, rs, b, s)
                                  : mrs_dec_proj(&bl.dout, d, nullptr, ws.attn, nq, nullptr, 0.f, ws.h, d, 1, rs, nullptr, b, s);
@@ -638,6 +639,7 @@ class Llama {
     const int64_t st = (int64_t)(intptr_t)s;
     // T > 128: the 256-row-tile kernel over bf16 activations (converted once per GEMM group), split-K partials in `part`
     const bool big = T > prefill_big_min() && !getenv("MRS_PREFILL_SMALL_TILES");
+    static const bool use_gemm2 = [] { const char *e = getenv("MRS_PREFILL_GEMM2"); return !e || atoi(e) != 0; }();
     const size_t part_bytes = big ? mrs_gemm_q_bf16_workspace_bytes(T) : 0;
     void *xb = big ? take(t * std::max(std::max(d, nq), ff) * 2) : nullptr, *part = big ? take(part_bytes) : nullptr;
     void *xg = big ? take(t * ff * 2) : nullptr;  // output slabs of the fused gate / up GEMM (it reads xb while it writes)
@@ -654,7 +656,12 @@ class Llama {
       int rc;
       if (big) {
         xb_src = nullptr;
-        rc = to_bf16(x, K) || mrs_gemm_q_bf16_multi(1, &w->data, &N, &out, &N, w->dtype, K, xb, T, acc, part, part_bytes, s);
+        rc = to_bf16(x, K);
+        // round 3: weights in MFMA layout feed the matrix cores straight from global memory (ext_gemm2.hip); -3 = shape / type of ext_gemm.hip
+        int r2 = -3;
+        if (!rc && w->g2 && use_gemm2) r2 = mrs_gemm2_q_bf16_multi(1, &w->g2, &N, &out, &N, w->dtype, K, xb, T, acc, part, part_bytes, s);
+        if (!rc && r2 == -3) rc = mrs_gemm_q_bf16_multi(1, &w->data, &N, &out, &N, w->dtype, K, xb, T, acc, part, part_bytes, s);
+        else if (!rc) rc = r2;
         xb_src = nullptr;
       } else rc = mrs_gemm_q_f32(w->data, w->dtype, N, K, x, K, out, N, T, acc, s);
       if (rc) return fail("prefill: no GEMM for ggml dtype %d (K=%d)", w->dtype, K);
@@ -671,11 +678,21 @@ class Llama {
       for (size_t i = 0; i < m.size(); ++i) {
         if (done[i]) continue;
         const int ty = m[i]->get_qtensor()->dtype;
-        const void *w[3]; float *oo[3]; int nn[3], ld[3], c = 0;
+        const void *w[3], *w2[3]; float *oo[3]; int nn[3], ld[3], c = 0;
+        bool all_g2 = use_gemm2;
         for (size_t j = i; j < m.size(); ++j)
-          if (!done[j] && m[j]->get_qtensor()->dtype == ty) { w[c] = m[j]->get_qtensor()->data; oo[c] = o[j]; nn[c] = n[j]; ld[c] = n[j]; ++c; done[j] = true; }
-        const int rc = big ? (to_bf16(x, K) || mrs_gemm_q_bf16_multi(c, w, nn, oo, ld, ty, K, xb, T, 0, part, part_bytes, s))
-                           : mrs_gemm_q_f32_multi(c, w, nn, oo, ld, ty, K, x, K, T, 0, s);
+          if (!done[j] && m[j]->get_qtensor()->dtype == ty) {
+            w[c] = m[j]->get_qtensor()->data; w2[c] = m[j]->get_qtensor()->g2; all_g2 = all_g2 && w2[c] != nullptr;
+            oo[c] = o[j]; nn[c] = n[j]; ld[c] = n[j]; ++c; done[j] = true;
+          }
+        int rc;
+        if (big) {
+          rc = to_bf16(x, K);
+          int r2 = -3;
+          if (!rc && all_g2) r2 = mrs_gemm2_q_bf16_multi(c, w2, nn, oo, ld, ty, K, xb, T, 0, part, part_bytes, s);
+          if (!rc && r2 == -3) rc = mrs_gemm_q_bf16_multi(c, w, nn, oo, ld, ty, K, xb, T, 0, part, part_bytes, s);
+          else if (!rc) rc = r2;
+        } else rc = mrs_gemm_q_f32_multi(c, w, nn, oo, ld, ty, K, x, K, T, 0, s);
         if (rc) return fail("prefill: no GEMM for ggml dtype %d (K=%d)", ty, K);
       }
       xb_src = nullptr;
@@ -697,8 +714,9 @@ class Llama {
       reshape_and_cache(k, v, bl.key_cache, bl.value_cache, (int64_t *)pa.slot_mapping, T, cfg.num_kv_heads, hd, bs, 8, nkv, nkv, s, 2, 1, nullptr, nullptr);
       // causal attention over the pages just written: MFMA flash kernel (head_dim 128 / block 32), else prompt token t = "sequence" t
       // of the decode-style kernel with context_lens[t] = pos + 1
-      if (mrs_prefill_attention_f32_bf16(q, bl.key_cache, bl.value_cache, pa.block_tables, attn, T, start_pos, cfg.num_heads, kvh, hd, bs, nq, nq,
-                                         kvh * hd * bs, hd * bs, 1.0f / sqrtf((float)hd), s) != 0) {
+      if (mrs_prefill_attention_window_f32_bf16(q, bl.key_cache, bl.value_cache, pa.block_tables, attn, T, start_pos, cfg.num_heads, kvh, hd, bs, nq, nq,
+                                                kvh * hd * bs, hd * bs, 1.0f / sqrtf((float)hd), cfg.sliding_window, s) != 0) {
+        if (cfg.sliding_window > 0) return fail("prefill: sliding-window attention needs the MFMA flash kernel's shapes (head_dim 128, block 32)");
         // fallback for head / block sizes outside the flash kernel: prompt token t = "sequence" t of the decode-style kernel.  v1 keeps all logits of
         // a sequence in LDS, so long contexts with few (token, head) pairs take v2 over 512-token partitions with the runner's partial buffers
         if (use_v1) {
@@ -770,6 +788,9 @@ class Llama {
 
   int forward_logits(int b, hipStream_t s) const {
     if (check_ready(b)) return -1;
+    // sliding-window attention (Mistral) exists in the decode engine's split attention and in the MFMA prefill only: every other path would silently attend everything
+    if (cfg.sliding_window > 0 && (cfg.use_fused != 2 || !attn2 || fused_attn || dec_persist))
+      return fail("sliding_window %d needs the decode engine with its default attention (use_fused = 2, MRS_DEC_ATTN2 / MRS_DEC_FUSED_ATTN / MRS_DEC_PERSIST unset)", cfg.sliding_window);
     if (cfg.use_fused == 2) {  // the engine never falls back silently: its arithmetic (Q8_K activations) differs from the Q8_1 paths
       if (!engine_ok()) return fail("decode engine: needs interleaved RoPE, head_dim 128, block 32, q4_k/q5_k/q6_k/q8_0 linears and a decode-layout copy of every linear");
       return forward_engine(b, s);
@@ -901,6 +922,32 @@ extern "C" int mrs_llama_set_dec_tensor(void *mm, const char *cname, const void 
     if (rest == "ffn_down_exps.weight") return bind(b.ddown_exps, &b.down_exps);
   }
   return mrs_host::fail("decode layout: tensor %s has no decode-engine role", cname);
+}
+// MFMA-layout copy (mrs_gemm2_repack output, caller-owned) of a dense linear already registered with mrs_llama_set_tensor: the prompt GEMMs of
+// ext_gemm2.hip read it; tensors without one (or of a type it does not take) keep the GGUF-block kernels of ext_gemm.hip
+extern "C" int mrs_llama_set_gemm2_tensor(void *mm, const char *cname, const void *planes) {
+  Llama &m = *(Llama *)mm;
+  const std::string name = cname;
+  auto bind = [&](const std::unique_ptr<mrs_host::GgufMatMul> &l) {
+    const mrs_host::QTensor *t = l ? l->get_qtensor() : nullptr;
+    if (!t || !t->data) return mrs_host::fail("MFMA layout for %s: register the tensor with mrs_llama_set_tensor first", cname);
+    if (!mrs_gemm2_repack_bytes(t->dtype, t->rows, t->cols)) return mrs_host::fail("MFMA layout for %s: ggml dtype %d / shape not supported", cname, t->dtype);
+    t->g2 = planes;
+    return 0;
+  };
+  int layer = -1, consumed = 0;
+  if (sscanf(cname, "blk.%d.%n", &layer, &consumed) == 1 && consumed > 0 && layer >= 0 && layer < m.cfg.num_layers) {
+    mrs_host::Block &b = m.blocks[layer];
+    const std::string rest = name.substr(consumed);
+    if (rest == "attn_q.weight") return bind(b.q_proj);
+    if (rest == "attn_k.weight") return bind(b.k_proj);
+    if (rest == "attn_v.weight") return bind(b.v_proj);
+    if (rest == "attn_output.weight") return bind(b.o_proj);
+    if (rest == "ffn_gate.weight") return bind(b.gate_proj);
+    if (rest == "ffn_up.weight") return bind(b.up_proj);
+    if (rest == "ffn_down.weight") return bind(b.down_proj);
+  }
+  return mrs_host::fail("MFMA layout: tensor %s has no prompt-GEMM role", cname);
 }
 extern "C" int mrs_llama_set_mode(void *m, int use_fused) {
   if (use_fused < 0 || use_fused > 2) return mrs_host::fail("mrs_llama_set_mode: 0, 1 or 2");

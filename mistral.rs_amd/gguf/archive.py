@@ -167,22 +167,49 @@ class GgufArchive:
 
         def req(k):
             if f"{arch}.{k}" not in md:
-                raise GgufError(f"GGUF metadata key {arch}.{k} is missing")
+                raise GgufError(f"GGUF metadata is missing required key `{arch}.{k}`")
             return md[f"{arch}.{k}"]
-        heads = int(req("attention.head_count"))
-        d = int(req("embedding_length"))
+
+        def req_uint(k, nonzero=False):
+            v = req(k)
+            if isinstance(v, bool) or not isinstance(v, (int, np.integer)) or int(v) < 0:
+                raise GgufError(f"GGUF metadata `{arch}.{k}` must be a non-negative integer fitting this platform")
+            if nonzero and int(v) == 0:
+                raise GgufError(f"GGUF metadata `{arch}.{k}` has no non-zero value")
+            return int(v)
+        # StandardFields::read_with_intermediate_size (gguf/normal_config.rs:897-925): every field below is REQUIRED there -- no silent defaults
+        heads = req_uint("attention.head_count")
+        d = req_uint("embedding_length")
+        kv_heads = req_uint("attention.head_count_kv", nonzero=True)
+        ctx_len = req_uint("context_length")
+        eps = md.get(f"{arch}.attention.layer_norm_rms_epsilon", md.get(f"{arch}.attention.layer_norm_epsilon"))
+        if eps is None:  # normal_config.rs:748-761
+            raise GgufError(f"Standalone `{arch}` config requires `{arch}.attention.layer_norm_rms_epsilon` or `{arch}.attention.layer_norm_epsilon`")
         vocab = md.get(f"{arch}.vocab_size")
         if vocab is None:
             vocab = len(md["tokenizer.ggml.tokens"]) if "tokenizer.ggml.tokens" in md else self.tensors["token_embd.weight"].shape[0]
-        rope_dim = int(md.get(f"{arch}.rope.dimension_count", d // heads))
+        # head_dim = attention.key_length when present, else embedding_length / head_count, which must divide (normal_config.rs:780-791);
+        # rope.dimension_count is the ROTATED width (partial rotary), not the head size
+        key_len = md.get(f"{arch}.attention.key_length")
+        if key_len is not None:
+            head_dim = int(key_len)
+        else:
+            if d % heads:
+                raise GgufError(f"GGUF metadata: embedding length / attention head count ({d} / {heads}) is not an integer")
+            head_dim = d // heads
+        rope_dim = int(md.get(f"{arch}.rope.dimension_count", head_dim))
+        if rope_dim != head_dim:
+            raise GgufError(f"partial rotary embeddings ({arch}.rope.dimension_count = {rope_dim}, head size {head_dim}) are outside this runner")
+        window = md.get(f"{arch}.attention.sliding_window")  # 0 = absent (normal_config.rs:792-796)
+        window = int(window) if window else None
         scaling = None
         if md.get(f"{arch}.rope.scaling.type") == "linear":
             scaling = RopeScaling("linear", float(md.get(f"{arch}.rope.scaling.factor", 1.0)))
-        kw = dict(hidden_size=d, intermediate_size=int(req("feed_forward_length")), num_layers=int(req("block_count")), num_heads=heads,
-                  num_kv_heads=int(md.get(f"{arch}.attention.head_count_kv", heads)), vocab_size=int(vocab), head_dim=rope_dim,
-                  rms_eps=float(md.get(f"{arch}.attention.layer_norm_rms_epsilon", 1e-5)), rope_theta=float(md.get(f"{arch}.rope.freq_base", 10000.0)),
+        kw = dict(hidden_size=d, intermediate_size=req_uint("feed_forward_length"), num_layers=req_uint("block_count"), num_heads=heads,
+                  num_kv_heads=kv_heads, vocab_size=int(vocab), head_dim=head_dim,
+                  rms_eps=float(eps), rope_theta=float(md.get(f"{arch}.rope.freq_base", 10000.0)),
                   rope_scaling=scaling, rope_interleaved=True,  # GGUF llama/mistral: adjacent pairs (normal_registry.rs:446-461)
-                  max_position_embeddings=int(md.get(f"{arch}.context_length", 8192)),
+                  max_position_embeddings=ctx_len, sliding_window=window,
                   # Mixtral ships as architecture "llama" with expert_count / expert_used_count (gguf/normal_config.rs)
                   num_experts=int(md.get(f"{arch}.expert_count", 0) or 0), num_experts_per_tok=int(md.get(f"{arch}.expert_used_count", 2) or 2))
         kw.update(overrides)

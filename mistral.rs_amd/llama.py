@@ -6,6 +6,7 @@ for a fixed batch (slot mapping rule of pipeline/inputs_processor.rs:900-922), a
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 from dataclasses import dataclass, field
 
@@ -51,6 +52,9 @@ class LlamaConfig:
     tp_rank: int = 0
     num_experts: int = 0           # > 0: Mixtral-style sparse MoE FFN in every layer (models/mixtral.rs:236-304)
     num_experts_per_tok: int = 2   # router top-k
+    # Mistral: a query attends the last `sliding_window` positions, itself included (GGUF <arch>.attention.sliding_window, normal_config.rs:792-796;
+    # mask rule paged_attention/layers/paged_attention.rs:551-553); None = full causal attention
+    sliding_window: int | None = None
 
     def __post_init__(self):
         if self.head_dim is None:
@@ -110,7 +114,7 @@ class _Cfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("hidden_size", "intermediate_size", "num_layers", "num_heads", "num_kv_heads", "head_dim",
                                          "vocab_size", "rot_dim", "rope_interleaved")] + [("rms_eps", C.c_float)] + \
                [(n, C.c_int32) for n in ("block_size", "max_blocks_per_seq", "max_batch", "max_context_len", "use_fused", "world_size", "rank",
-                                         "num_experts", "num_experts_per_tok", "kv_f16")]
+                                         "num_experts", "num_experts_per_tok", "kv_f16", "sliding_window")]
 
 
 class _PrefillArgs(C.Structure):
@@ -158,11 +162,16 @@ class Llama:
         L.mrs_dec_repack_bytes.restype = C.c_size_t
         L.mrs_dec_repack_bytes.argtypes = [C.c_int, C.c_longlong, C.c_longlong]
         L.mrs_dec_repack.argtypes = [C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p]
+        L.mrs_gemm2_repack_bytes.restype = C.c_size_t
+        L.mrs_gemm2_repack_bytes.argtypes = [C.c_int, C.c_longlong, C.c_longlong]
+        L.mrs_gemm2_repack.argtypes = [C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p]
+        L.mrs_llama_set_gemm2_tensor.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
+        self._gemm2_wanted = os.environ.get("MRS_PREFILL_GEMM2", "1") != "0"
         L.mrs_last_error.restype = C.c_char_p
         c = _Cfg(cfg.hidden_size, cfg.intermediate_size, cfg.num_layers, cfg.num_heads, cfg.num_kv_heads, cfg.head_dim,
                  cfg.vocab_size, cfg.head_dim, int(cfg.rope_interleaved), cfg.rms_eps, cfg.block_size, cfg.max_blocks_per_seq,
                  cfg.max_batch, cfg.max_context_len, int(cfg.use_fused), cfg.tp_world_size, cfg.tp_rank, cfg.num_experts,
-                 cfg.num_experts_per_tok if cfg.num_experts else 0, int(cfg.kv_dtype == "f16"))
+                 cfg.num_experts_per_tok if cfg.num_experts else 0, int(cfg.kv_dtype == "f16"), int(cfg.sliding_window or 0))
         self._c = c
         self._h = L.mrs_llama_create(C.byref(c))
         if not self._h:
@@ -255,6 +264,14 @@ class Llama:
                     self._chk(self._L.mrs_dec_repack(t.data.data_ptr(), t.dtype.id, t.shape[0], t.shape[1], planes.data_ptr(), self._stream()))
                     self._keep[name + "#dec"] = planes
                     self._chk(self._L.mrs_llama_set_dec_tensor(self._h, name.encode(), planes.data_ptr()))
+            # MFMA layout for the prompt GEMM of ext_gemm2.hip (dense per-layer linears of the types it takes): a third copy of the same bits, made once
+            if self._gemm2_wanted and name.startswith("blk.") and "_exps" not in name:
+                nb2 = self._L.mrs_gemm2_repack_bytes(t.dtype.id, t.shape[0], t.shape[1])
+                if nb2:
+                    g2 = torch.empty(nb2, dtype=torch.uint8, device=self.device)
+                    self._chk(self._L.mrs_gemm2_repack(t.data.data_ptr(), t.dtype.id, t.shape[0], t.shape[1], g2.data_ptr(), self._stream()))
+                    self._keep[name + "#g2"] = g2
+                    self._chk(self._L.mrs_llama_set_gemm2_tensor(self._h, name.encode(), g2.data_ptr()))
         else:
             t = t.to(self.device, torch.float32).contiguous()
             self._keep[name] = t

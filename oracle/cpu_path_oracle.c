@@ -218,8 +218,15 @@ static float tree32(const float *in) {
   for (int i = 0; i < 32; ++i) a[i] = b[i] + b[(i & ~15) | (15 - (i & 15))];
   return a[0] + a[16];
 }
+void orc_attention_engine_w(const float *q, const float *k, const float *v, float *out, int kv_len, int H, int KVH, float scale, int bpw, int window);
 void orc_attention_engine(const float *q, const float *k, const float *v, float *out, int kv_len, int H, int KVH, float scale, int bpw) {
+  orc_attention_engine_w(q, k, v, out, kv_len, H, KVH, scale, bpw, 0);
+}
+/* window > 0: positions below kv_len - window are masked like positions past the context (score -FLT_MAX, p = 0); a split that lies entirely before the
+ * window keeps (m, l, o) = (-FLT_MAX, 0, 0) -- what the masked pass computes, and what the kernel publishes without reading K / V */
+void orc_attention_engine_w(const float *q, const float *k, const float *v, float *out, int kv_len, int H, int KVH, float scale, int bpw, int window) {
   enum { HD = 128, BS = 32 };
+  const int lo = window > 0 && kv_len > window ? kv_len - window : 0;
   const int G = H / KVH, nblk = (kv_len + BS - 1) / BS;
   if (bpw < 1) bpw = 1;
   const int ns = (nblk + bpw - 1) / bpw;
@@ -236,7 +243,7 @@ void orc_attention_engine(const float *q, const float *k, const float *v, float 
         float sc[BS], p[BS], mx = -FLT_MAX;
         for (int t = 0; t < BS; ++t) {
           const int pos = b * BS + t;
-          if (pos < kv_len) {
+          if (pos < kv_len && pos >= lo) {
             const float *kr = k + ((size_t)pos * KVH + kvh) * HD;
             float s0 = 0.0f, s1 = 0.0f;
             for (int d = 0; d < 64; ++d) s0 = fmaf(qh[d], kr[d], s0);
@@ -248,7 +255,7 @@ void orc_attention_engine(const float *q, const float *k, const float *v, float 
           mx = fmaxf(mx, sc[t]);
         }
         const float mn = fmaxf(m, mx);
-        for (int t = 0; t < BS; ++t) p[t] = b * BS + t < kv_len ? orc_fast_exp(sc[t] - mn) : 0.0f;
+        for (int t = 0; t < BS; ++t) p[t] = b * BS + t < kv_len && b * BS + t >= lo ? orc_fast_exp(sc[t] - mn) : 0.0f;
         const float ps = tree32(p);
         const float alpha = orc_fast_exp(m - mn);
         l = l * alpha + ps;
@@ -394,4 +401,20 @@ int orc_gemv_engine(int type, const void *W, int N, int K, const float *x, float
   }
   free(y);
   return 0;
+}
+
+/* trunc(x + copysign(0.49999997f, x)) (the device's round-half-away, dec_core.cuh round_away / common.cuh fast_exp_ref) against roundf over EVERY
+ * float with |x| <= limit: returns the number of mismatches (tests/test_oracle.py holds it to 0 for limit = 129) */
+int64_t orc_round_trick_mismatches(float limit) {
+  uint32_t top;
+  memcpy(&top, &limit, 4);
+  int64_t bad = 0;
+#pragma omp parallel for reduction(+ : bad) schedule(static)
+  for (uint32_t b = 0; b <= top; ++b) {
+    float x;
+    memcpy(&x, &b, 4);
+    if (truncf(x + copysignf(0.49999997f, x)) != roundf(x)) ++bad;
+    if (truncf(-x + copysignf(0.49999997f, -x)) != roundf(-x)) ++bad;
+  }
+  return bad;
 }

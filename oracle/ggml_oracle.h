@@ -90,9 +90,11 @@ void orc_attention_single_q_cpu(const float *q, const float *k, const float *v, 
 void orc_rms_norm_candle(const float *x, const float *w, float *out, int rows, int d, float eps); /* x / sqrt(mean + eps) * w, f32 sums in order */
 void orc_rms_norm_engine(const float *x, const float *w, float *out, int rows, int d, float eps); /* same expression, the engine's summation tree */
 int64_t orc_div_by_mismatches(const float *x, const float *m, int64_t n);                                   /* dec_core.cuh div_by vs `/` */
+int64_t orc_round_trick_mismatches(float limit);                                                      /* the device round-half-away vs roundf, exhaustive */
 float orc_silu_engine(float x);                                                                   /* x / (1 + fast_exp(-x)) */
 void orc_fused_glu_engine(const float *a, const float *b, float *out, int64_t n);
 void orc_attention_engine(const float *q, const float *k, const float *v, float *out, int kv_len, int H, int KVH, float scale, int bpw);
+void orc_attention_engine_w(const float *q, const float *k, const float *v, float *out, int kv_len, int H, int KVH, float scale, int bpw, int window); /* sliding window */
 /* llama_oracle.c: the reference CPU matvec with ONE f32 term per superblock, added in superblock order (a second CPU summation order) */
 int orc_gemv_cpu_fast(int type, const void *W, int N, int K, const float *x, float *out);
 /* cpu_path_oracle.c: the same integers and products in the decode engine's summation order (64 per-lane chains + butterfly) */

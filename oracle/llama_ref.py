@@ -65,8 +65,11 @@ class LlamaRef:
 
     def attend(self, q, k, v, scale):
         """q [1, H, hd]; k, v [S, KVH, hd]"""
+        w = getattr(self.cfg, "sliding_window", None) or 0
         if self.mode == "engine":
-            return O.attention_engine(q[0], k, v, scale, self.attn_bpw)[None]
+            return O.attention_engine(q[0], k, v, scale, self.attn_bpw, w)[None]
+        if w and k.shape[0] > w:  # the reference gathers the last W positions and runs its SDPA over them (DecodePlan::GatherSdpa, paged_attention/plan.rs:116-138)
+            k, v = k[-w:], v[-w:]
         if self.mode in ("cpu", "cpu_fast"):
             return O.attention_single_q_cpu(q[0], k, v, scale, self.n_kv_chunks)[None]
         return O.attention(q, k, v, scale)

@@ -308,8 +308,9 @@ def attention_single_q_cpu(q, k, v, scale: float, n_kv_chunks: int = 1) -> np.nd
     return out
 
 
-def attention_engine(q, k, v, scale: float, bpw: int = 1) -> np.ndarray:
-    """The decode engine's attention order (csrc/dec_attn2.cuh), head size 128: q [H, 128], k / v [S, KVH, 128] -> [H, 128]."""
+def attention_engine(q, k, v, scale: float, bpw: int = 1, window: int = 0) -> np.ndarray:
+    """The decode engine's attention order (csrc/dec_attn.cuh + ext_dec.hip dec_attn2_kernel), head size 128: q [H, 128], k / v [S, KVH, 128] -> [H, 128].
+    window > 0: only the last `window` positions are attended (masked in place: the 32-token blocks stay anchored at position 0, as in the paged cache)."""
     q = np.ascontiguousarray(q, dtype=np.float32)
     k = np.ascontiguousarray(k, dtype=np.float32)
     v = np.ascontiguousarray(v, dtype=np.float32)
@@ -317,7 +318,7 @@ def attention_engine(q, k, v, scale: float, bpw: int = 1) -> np.ndarray:
     assert hd == 128
     s, kvh, _ = k.shape
     out = np.empty_like(q)
-    lib().orc_attention_engine(_p(q), _p(k), _p(v), _p(out), s, h, kvh, C.c_float(scale), int(bpw))
+    lib().orc_attention_engine_w(_p(q), _p(k), _p(v), _p(out), s, h, kvh, C.c_float(scale), int(bpw), int(window or 0))
     return out
 
 

@@ -139,3 +139,46 @@ def test_mixtral_gguf_loads_and_matches_direct_build(oracle, dev, tmp_path):
     for pos, tok in enumerate([3, 77, 200, 511]):
         m.set_state([tok], [pos]); direct.set_state([tok], [pos])
         assert torch.equal(m.forward_logits(1), direct.forward_logits(1))
+
+
+def _meta_only(archive, tmp_path, md, name="m.gguf"):
+    """a GGUF with metadata `md` and one small tensor (config synthesis does not read tensor data)"""
+    from mistralrs_amd.gguf import GgmlDType
+    path = os.path.join(str(tmp_path), name)
+    archive.write_gguf(path, md, {"token_embd.weight": (GgmlDType.F32, (4, 8), np.zeros(32, np.float32).view(np.uint8))})
+    return path
+
+
+def test_config_synthesis_follows_normal_config_rs(oracle, tmp_path):
+    """gguf/normal_config.rs:748-796,897-925: head_dim = attention.key_length when present (else embedding_length / head_count, NOT
+    rope.dimension_count), attention.sliding_window (0 = absent), and head_count_kv / context_length / the norm epsilon are REQUIRED -- a file
+    without them is rejected with the reference's message instead of getting a silent default (advisor, rounds 1-2)."""
+    import mistralrs_amd  # noqa: F401
+    from mistralrs_amd.gguf import archive
+    base = {"general.architecture": "mistral", "mistral.embedding_length": 4096, "mistral.feed_forward_length": 14336, "mistral.block_count": 32,
+            "mistral.attention.head_count": 32, "mistral.attention.head_count_kv": 8, "mistral.attention.layer_norm_rms_epsilon": 1e-5,
+            "mistral.rope.freq_base": 1000000.0, "mistral.context_length": 32768, "mistral.vocab_size": 32000, "mistral.attention.sliding_window": 4096}
+    with archive.GgufArchive(_meta_only(archive, tmp_path, base)) as ar:
+        c = ar.llama_config()
+        assert (c.head_dim, c.sliding_window, c.num_kv_heads, c.max_position_embeddings, c.rope_theta) == (128, 4096, 8, 32768, 1000000.0)
+    with archive.GgufArchive(_meta_only(archive, tmp_path, {**base, "mistral.attention.sliding_window": 0, "mistral.attention.key_length": 128,
+                                                            "mistral.rope.dimension_count": 128}, "b.gguf")) as ar:
+        c = ar.llama_config()
+        assert c.sliding_window is None and c.head_dim == 128
+    # key_length wins over embedding_length / head_count (e.g. Mistral-Nemo: 5120 / 32 = 160, key_length 128)
+    nemo = {**base, "mistral.embedding_length": 5120, "mistral.attention.key_length": 128, "mistral.rope.dimension_count": 128}
+    with archive.GgufArchive(_meta_only(archive, tmp_path, nemo, "c.gguf")) as ar:
+        assert ar.llama_config().head_dim == 128
+    for missing, msg in (("mistral.attention.head_count_kv", "missing required key `mistral.attention.head_count_kv`"),
+                         ("mistral.context_length", "missing required key `mistral.context_length`"),
+                         ("mistral.attention.layer_norm_rms_epsilon", "requires `mistral.attention.layer_norm_rms_epsilon` or `mistral.attention.layer_norm_epsilon`")):
+        md = {k: v for k, v in base.items() if k != missing}
+        with archive.GgufArchive(_meta_only(archive, tmp_path, md, "d.gguf")) as ar:
+            with pytest.raises(archive.GgufError, match=msg.replace(".", r"\.").replace("`", "`")):
+                ar.llama_config()
+    with archive.GgufArchive(_meta_only(archive, tmp_path, {**base, "mistral.attention.head_count_kv": 0}, "e.gguf")) as ar:
+        with pytest.raises(archive.GgufError, match="has no non-zero value"):
+            ar.llama_config()
+    with archive.GgufArchive(_meta_only(archive, tmp_path, {**base, "mistral.embedding_length": 4100}, "f.gguf")) as ar:
+        with pytest.raises(archive.GgufError, match="is not an integer"):
+            ar.llama_config()

@@ -130,3 +130,89 @@ def test_q8_1_padding_and_zero_blocks(oracle):
     blk = y[1, :36]
     assert blk[4:9].view(np.int8).tolist() == [1, -2, 3, -127, 1]  # roundf(0.5/1) = 1 (half away from zero)
     assert not y[1, 36 * 22:].any()  # zero padding beyond kx
+
+
+# ---------------------------------------------------------------- round 3: the restated in-tree CPU path and the device's exact-arithmetic shortcuts
+def test_round_trick_exhaustive(oracle):
+    """The device rounds half away from zero (candle's .round(), the Q8_K / Q8_0 activation quantizers, fast_exp) as trunc(x + copysign(0.49999997, x)):
+    identical to roundf for EVERY float with |x| <= 129 (2.2e9 values; the quantizers round products in [-128, 128], fast_exp |x log2 e| <= 126)."""
+    import ctypes as C
+    L = oracle.lib()
+    L.orc_round_trick_mismatches.restype = C.c_int64
+    assert L.orc_round_trick_mismatches(C.c_float(129.0)) == 0
+
+
+def test_device_quotient_equals_ieee_division(oracle):
+    """RmsNorm's x / m on the device = one correctly rounded reciprocal + q0 = x y, r = fma(-m, q0, x), q = fma(r, y, q0) (dec_core.cuh div_by):
+    equal to the IEEE quotient on 2e7 random pairs over six decades and for divisors with an all-ones mantissa."""
+    import ctypes as C
+    L = oracle.lib()
+    L.orc_div_by_mismatches.restype = C.c_int64
+    rng = np.random.default_rng(1)
+    n = 20_000_000
+    x = (rng.standard_normal(n) * 10 ** rng.uniform(-3, 3, n)).astype(np.float32)
+    m = (10 ** rng.uniform(-3, 3, n)).astype(np.float32)
+    assert L.orc_div_by_mismatches(oracle._p(x), oracle._p(m), C.c_int64(n)) == 0
+    m = np.full(1 << 16, np.frombuffer(np.uint32(0x3fffffff).tobytes(), np.float32)[0], np.float32)
+    x = rng.standard_normal(m.size).astype(np.float32)
+    assert L.orc_div_by_mismatches(oracle._p(x), oracle._p(m), C.c_int64(m.size)) == 0
+
+
+def test_fast_exp_matches_elem_rs_definition(oracle):
+    """orc_fast_exp = attention/backends/cpu/elem.rs:417-433 restated in numpy f32, operation for operation; ~1e-7 relative to exp on [-87, 0]."""
+    xs = np.concatenate([np.linspace(-87, 0, 20001, dtype=np.float32), np.float32([-100.0, 0.25, 3.0, 87.0, 100.0])])
+    f = np.float32
+    want = []
+    for x in xs:
+        x = f(min(max(x, f(-87.0)), f(87.0)))
+        zx = f(x * f(1.44269504088896340736))
+        z = f(np.trunc(zx + np.copysign(f(0.5), zx))) if abs(zx - np.trunc(zx)) != 0.5 else f(np.trunc(zx) + np.copysign(f(1.0), zx))
+        r = f(f(x - f(z * f(0.6933594))) - f(z * f(-2.1219444e-4)))
+        r2 = f(r * r)
+        p = f(r + f(r2 * f(f(0.5) + f(r * f(f(0.16666546) + f(r * f(f(0.041665795) + f(r * f(f(0.00833345) + f(r * f(0.0013920345)))))))))))
+        e = np.frombuffer(np.uint32((int(z) + 127) << 23).tobytes(), np.float32)[0]
+        want.append(f(e * f(f(1.0) + p)))
+    got = np.float32([oracle.fast_exp(float(x)) for x in xs])
+    assert np.array_equal(got, np.float32(want))
+    inside = xs <= 0
+    assert np.abs(got[inside] / np.exp(np.clip(xs[inside].astype(np.float64), -87, 87)) - 1).max() < 3e-7
+
+
+def test_cpu_attention_restatement_vs_f64(oracle):
+    """single_q.rs restated (portable elem.rs bodies) and the engine-order attention both agree with the f64 softmax attention to f32 rounding, for one
+    and several kv chunks (the reference derives the chunk count from its thread pool)."""
+    rng = np.random.default_rng(0)
+    H, KVH, hd, S = 8, 2, 128, 700
+    q = rng.standard_normal((H, hd)).astype(np.float32)
+    k = rng.standard_normal((S, KVH, hd)).astype(np.float32)
+    v = rng.standard_normal((S, KVH, hd)).astype(np.float32)
+    sc = np.float32(1 / np.sqrt(np.float32(hd)))
+    ref = oracle.attention(q[None], k, v, sc)[0]
+    for got in (oracle.attention_single_q_cpu(q, k, v, sc, 1), oracle.attention_single_q_cpu(q, k, v, sc, 3), oracle.attention_engine(q, k, v, sc, 1),
+                oracle.attention_engine(q, k, v, sc, 4)):
+        assert np.abs(got - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max())
+
+
+def test_rms_norm_restatements(oracle):
+    """candle's expression (x / sqrt(mean + eps) * w) in element order and in the engine's summation tree vs the f64 form: <= 4 ulp-ish."""
+    rng = np.random.default_rng(2)
+    for d in (512, 4096, 14336):
+        x = rng.standard_normal((2, d)).astype(np.float32)
+        w = (1 + 0.05 * rng.standard_normal(d)).astype(np.float32)
+        ref = oracle.rms_norm(x, w, 1e-5)
+        for got in (oracle.rms_norm_candle(x, w, 1e-5), oracle.rms_norm_engine(x, w, 1e-5)):
+            assert np.abs(got - ref).max() <= 4e-6 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("name", ["Q4_K", "Q5_K", "Q6_K", "Q8_0"])
+def test_three_cpu_gemv_orders_agree(oracle, name):
+    """ggml's generic 8-lane order (orc_matmul_cpu), one term per superblock (orc_gemv_cpu_fast) and the engine's order (orc_gemv_engine): the same
+    integers and products, three f32 summation orders -> equal to f32 rounding, ragged row lengths included."""
+    t = getattr(oracle, name)
+    rng = np.random.default_rng(5)
+    for n, k in ((32, 4096), (8, 14336), (8, 256), (8, 2304)):
+        w = oracle.quantize(t, (rng.standard_normal((n, k)) * 0.02).astype(np.float32))
+        x = rng.standard_normal((1, k)).astype(np.float32)
+        a, b, c = oracle.matmul_cpu(t, w, n, k, x), oracle.gemv_cpu_fast(t, w, n, k, x), oracle.gemv_engine(t, w, n, k, x)
+        tol = 2e-6 * np.abs(a).max()
+        assert np.abs(a - b).max() <= tol and np.abs(a - c).max() <= tol
