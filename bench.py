@@ -65,9 +65,13 @@ def build_model(cfg, device, seed=0, max_new_tokens=4096, tp=None, quant="q4_k_m
               "ffn_gate": (ff, d), "ffn_up": (ff, d), "ffn_down": (d, ff)}
     types = q4_k_m_types(cfg.num_layers)
     g = torch.Generator(device="cpu").manual_seed(seed)
+    E = cfg.num_experts
     for i, (name, t) in enumerate(types.items()):
         sharded = name not in ("token_embd.weight", "output.weight")
         n, k = shapes[name.split(".")[2]] if sharded else (cfg.vocab_size, d)
+        role = name.split(".")[2] if sharded else ""
+        if E and role in ("ffn_gate", "ffn_up", "ffn_down"):  # Mixtral: experts stacked along the row axis, [E * n][k] packed blocks (weight_source.rs:1835)
+            name, n = name.replace(role, role + "_exps"), E * n
         tseed = seed * 1000 + i + (7919 * (tp[0] + 1) if tp and sharded else 0)
         if quant == "q8_0_isq":  # in-situ quantisation: bf16 weights -> Q8_0 blocks on the device (utils/isq.rs:323-361 does this on the host cores)
             from mistralrs_amd import isq
@@ -80,6 +84,8 @@ def build_model(cfg, device, seed=0, max_new_tokens=4096, tp=None, quant="q4_k_m
             m.set_tensor(name, isq.quantize(torch.randn(n, k, device=device, generator=gw) * 0.02, t))
         else:
             m.set_tensor(name, random_qtensor(t, n, k, device, tseed))
+    for i in range(cfg.num_layers if E else 0):
+        m.set_tensor(f"blk.{i}.ffn_gate_inp.weight", 0.05 * torch.randn(E, d, generator=g))  # F32 router (models/mixtral.rs:262-304)
     for i in range(cfg.num_layers):
         for nm in ("attn_norm", "ffn_norm"):
             m.set_tensor(f"blk.{i}.{nm}.weight", 1.0 + 0.01 * torch.randn(d, generator=g))
@@ -152,6 +158,36 @@ def cpu_baseline(model, cfg, budget_s=12.0, positions=16):
     return base, fed, logits
 
 
+def dropin_rate(model, cfg, prompt, steps, device):
+    """What an UNMODIFIED mistralrs-core host gets from the drop-in libraries: the literal reference launch sequence of a decode step through the
+    reference ABI (launch_mmvq_gguf_quantize_q8_1_* + launch_mmvq_gguf_<t>_* per projection, rotary_embedding, reshape_and_cache, paged_attention_v1 / v2,
+    add_rms_norm_*; runner mode use_fused = 0) on the same weights, replayed from a HIP graph like the engine."""
+    import copy
+    import torch
+    from mistralrs_amd.llama import Llama
+    c2 = copy.copy(cfg)
+    c2.use_fused, c2.decode_engine = False, False
+    m2 = Llama(c2, device, max_new_tokens=steps + 16)
+    for name, t in model._keep.items():
+        if "#" not in name:
+            m2.set_tensor(name, t)  # the same device tensors (GGUF blocks); no decode-layout copies in this mode
+    assert m2.decode_path == "reference-sequence", m2.decode_path
+    last = m2.prefill(prompt, 0)
+    m2.set_state([int(last.argmax())], [len(prompt)])
+    m2.step_counter.zero_()
+    m2.capture_decode_graph(1)
+    for _ in range(4):
+        m2.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m2.replay()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    avg_ctx = len(prompt) + 4 + steps / 2
+    return steps / dt, m2.decode_bytes(1, int(avg_ctx)) * (steps / dt) / HBM_PEAK
+
+
 def measured_traffic(model_name, quant="q4_k_m"):
     """HBM bytes per launch of the dominant kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE on this same command,
     x2 gfx950 correction; scripts/profile_round.sh -> profiles/round1_hbm_traffic.json).  Counters cannot be read from inside the
@@ -176,10 +212,12 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="sequences decoded concurrently (1..8; BASELINE configs use 1): value = batch * steps / time")
     ap.add_argument("--shard-shapes", type=int, default=0, help="single GPU, no collectives: run ONE rank's shard shapes of a TP = N model (shape smoke test for --gpus N)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in launch sequence leg (dropin_tokens_per_sec)")
     ap.add_argument("--small", action="store_true", help="tiny config (smoke / CI), not the benchmark")
     ap.add_argument("--tp", action="store_true", help="(default for N > 1) ONE model sharded tensor-parallel over the N GPUs")
     ap.add_argument("--replicas", action="store_true", help="N > 1: N independent replicas (weak scaling) instead of tensor parallelism")
-    ap.add_argument("--model", choices=["auto", "8b", "70b"], default="auto", help="auto: 70b (configs[3]) when N == 8, else 8b (configs[1])")
+    ap.add_argument("--model", choices=["auto", "8b", "70b", "mixtral"], default="auto",
+                    help="auto: 70b (configs[3]) when N == 8, else 8b (configs[1]); mixtral: Mixtral-8x7B-shaped sparse MoE (configs[4]; TP = 2 with --gpus 2)")
     ap.add_argument("--weights", choices=["gaussian", "blocks"], default="gaussian",
                     help="gaussian (default): N(0, 0.02^2) through the device ISQ quantizers (SURVEY 8d); blocks: random valid block bytes (fast variant for pure kernel timing)")
     ap.add_argument("--parity-positions", type=int, default=16, help="greedy positions of the CPU-path parity leg")
@@ -239,6 +277,9 @@ def main():
         cfg = LlamaConfig(hidden_size=512, intermediate_size=1024, num_layers=2, num_heads=8, num_kv_heads=2, vocab_size=2048,
                           head_dim=64, max_batch=8, max_context_len=max_ctx, max_position_embeddings=max(8192, max_ctx))
         name = "tiny-llama (smoke)"
+    elif a.model == "mixtral":
+        cfg = LlamaConfig.mixtral_8x7b(max_batch=8, max_context_len=max_ctx, max_position_embeddings=max(8192, max_ctx))
+        name = "Mixtral-8x7B-shaped (8 experts, top-2)"
     elif big:
         cfg = LlamaConfig.llama3_70b(max_batch=8, max_context_len=max_ctx, max_position_embeddings=max(8192, max_ctx))
         name = "Llama-3-70B"
@@ -340,16 +381,26 @@ def main():
     st = torch.cuda.current_stream().cuda_stream
     assert model.decode_path == "engine", model.decode_path
     layers = []
+    moe = cfg.num_experts > 0
+    sfx = "_exps" if moe else ""
     for i in range(cfg.num_layers):
-        g, u = model._keep[f"blk.{i}.ffn_gate.weight"], model._keep[f"blk.{i}.ffn_up.weight"]
-        layers.append((Mat(model._keep[f"blk.{i}.ffn_gate.weight#dec"].data_ptr(), g.dtype.id, g.shape[0], g.shape[1]),
-                       Mat(model._keep[f"blk.{i}.ffn_up.weight#dec"].data_ptr(), u.dtype.id, u.shape[0], u.shape[1]),
-                       model._keep[f"blk.{i}.ffn_norm.weight"], g.nbytes() + u.nbytes()))
+        g, u = model._keep[f"blk.{i}.ffn_gate{sfx}.weight"], model._keep[f"blk.{i}.ffn_up{sfx}.weight"]
+        layers.append((Mat(model._keep[f"blk.{i}.ffn_gate{sfx}.weight#dec"].data_ptr(), g.dtype.id, g.shape[0], g.shape[1]),
+                       Mat(model._keep[f"blk.{i}.ffn_up{sfx}.weight#dec"].data_ptr(), u.dtype.id, u.shape[0], u.shape[1]),
+                       model._keep[f"blk.{i}.ffn_norm.weight"], (g.nbytes() + u.nbytes()) * (cfg.num_experts_per_tok / cfg.num_experts if moe else 1)))
+    if moe:  # the top-k experts' gate / up rows in ONE launch (mrs_dec_gate_up_topk); expert ids on the device
+        ext.mrs_dec_gate_up_topk.argtypes = [MP, MP, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        sel = torch.tensor([1, 5][: cfg.num_experts_per_tok], dtype=torch.int32, device=dev)
+        act = torch.empty(cfg.num_experts_per_tok, cfg.intermediate_size, device=dev)
 
     def gate_up_pass():
         for mg, mu, nw, _ in layers:
-            rc = ext.mrs_dec_gate_up(C.byref(mg), C.byref(mu), cfg.intermediate_size, None, h.data_ptr(), cfg.hidden_size, nw.data_ptr(), cfg.rms_eps, 0,
-                                     act.data_ptr(), cfg.intermediate_size, 1, st)
+            if moe:
+                rc = ext.mrs_dec_gate_up_topk(C.byref(mg), C.byref(mu), cfg.intermediate_size, sel.data_ptr(), cfg.num_experts_per_tok, h.data_ptr(), nw.data_ptr(), cfg.rms_eps, 0,
+                                              act.data_ptr(), cfg.intermediate_size, st)
+            else:
+                rc = ext.mrs_dec_gate_up(C.byref(mg), C.byref(mu), cfg.intermediate_size, None, h.data_ptr(), cfg.hidden_size, nw.data_ptr(), cfg.rms_eps, 0,
+                                         act.data_ptr(), cfg.intermediate_size, 1, st)
             assert rc == 0
     gate_up_pass()
     torch.cuda.synchronize()
@@ -361,7 +412,7 @@ def main():
     k1.record()
     torch.cuda.synchronize()
     kern_s = k0.elapsed_time(k1) / 1e3 / (reps * len(layers))
-    kern_bytes = layers[0][3]  # algorithmic bytes per launch: the two GGUF weight tensors (the decode layout holds the same bits + 2.8 % for 8-bit scales)
+    kern_bytes = int(layers[0][3])  # algorithmic bytes per launch: the two GGUF weight tensors (the decode layout holds the same bits + 2.8 % for 8-bit scales)
     achieved = kern_bytes / kern_s
 
     # ---------------- tensor parallel: cost of the decode all-reduces (2 per layer, [1, hidden] f32) measured on the same communicator
@@ -414,6 +465,15 @@ def main():
     }
     if ar is not None:
         out["allreduce"] = ar
+    if world == 1 and B == 1 and not a.no_dropin and not a.small and a.quant == "q4_k_m" and not moe:
+        try:
+            d_tok, d_frac = dropin_rate(model, cfg, prompt, min(a.steps, 64), dev)
+            out["dropin_tokens_per_sec"] = round(d_tok, 2)
+            out["dropin_step_roofline_frac"] = round(d_frac, 4)
+            out["dropin_note"] = "the reference's own launch sequence through the drop-in C ABI (use_fused = 0: ~16 launches per layer, Q8_1 activations) -- what an unmodified Rust host gets; value / step_roofline_frac above are the MI355X-native engine (C++ runner)"
+        except Exception as e:
+            out["dropin_tokens_per_sec"] = None
+            out["dropin_note"] = f"failed: {e}"
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
             import numpy as np
@@ -450,7 +510,9 @@ def main():
                     tc = int(cpu_a.step(tc, pos).argmax())
                     cpu_toks.append(tc)
             n_cmp = len(cpu_toks)
-            out["greedy_match"] = gpu_toks[:n_cmp] == cpu_toks and n_cmp == len(fed)
+            out["greedy_match"] = gpu_toks[:n_cmp] == cpu_toks and n_cmp == len(fed)  # vs CPU order a (the reference's own summation orders), free-running
+            out["greedy_match_engine_order_restatement"] = bool(all(ident))  # identical logits => identical ids: the engine vs the CPU evaluation of the same arithmetic in its order
+            out["greedy_match_between_cpu_orders"] = ids(cl["cpu_b"]) == ids(cl["cpu"])  # calibration: do two CPU summation orders pick the same ids on this model (teacher-forced)
             out["parity"] = {
                 "weights": "N(0, 0.02^2) per tensor through the GGML quantizers (device ISQ, bit-identical to GGML), Q4_K_M type map" if a.weights == "gaussian" else "random valid block bytes",
                 "positions": len(fed),

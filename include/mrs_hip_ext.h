@@ -365,6 +365,8 @@ int mrs_comm_nranks(void *comm); /* ncclCommCount */
  * mailbox over xGMI (one hop), polls its own mailbox and sums in rank order (bit-identical on all ranks); graph-capturable; messages larger than
  * max_elems return -2 (keep RCCL for those).  Replaces ncclAllReduce at distributed/mod.rs:584-587 for [b, hidden] messages. */
 size_t mrs_p2p_mailbox_bytes(int world, size_t max_elems);
+void *mrs_p2p_alloc_mailbox(size_t bytes); /* zeroed FINE-GRAINED / uncached device memory (hipExtMallocWithFlags): peers write into it while the owner polls it */
+void mrs_p2p_free_mailbox(void *p);
 int mrs_ipc_get_handle(void *dev_ptr, void *out64);      /* hipIpcGetMemHandle */
 void *mrs_ipc_open_handle(const void *in64);             /* hipIpcOpenMemHandle */
 int mrs_ipc_close_handle(void *ptr);

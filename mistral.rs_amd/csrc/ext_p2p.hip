@@ -9,6 +9,8 @@
 //            ordering assumption about the fabric);
 //   reduce:  each rank polls the `world` slots of its own mailbox until every granule carries the current sequence number and adds them in
 //            rank order -- every rank computes bit-identical sums (the reference's NCCL ring does not guarantee that).
+// Round 3: a call runs as up to 8 workgroups (the posting side drives the xGMI links from several CUs), neighbouring granules leave as one 16-byte
+// store, a granule that never arrives turns its element into NaN, and mailboxes come from mrs_p2p_alloc_mailbox (fine-grained / uncached memory).
 // Two mailbox halves alternate (sequence parity): a rank that is already posting all-reduce n+1 cannot overwrite granules a slower peer still
 // reads for n, and nobody can start n+2 before every peer has posted n+1, i.e. finished reading n.
 // One workgroup per call (the message is a few thousand values; latency, not bandwidth), no host work: the sequence number lives in device
@@ -25,11 +27,11 @@ namespace mrs_host { int fail(const char *fmt, ...); }
 namespace mrs {
 namespace p2p {
 
-constexpr int MAX_WORLD = 16, NT = 1024;
+constexpr int MAX_WORLD = 16, NT = 1024, MAX_WG = 8;
 struct Comm {
   int rank, world;
   unsigned long long *mail[MAX_WORLD];  // mail[r]: base of rank r's mailbox, [2 parity][world src][max_elems] granules
-  unsigned *state;                      // own device memory: [0] sequence number of the last finished call, [1] error flag
+  unsigned *state;                      // own device memory: [0] sequence number of the last finished call, [1] error flag, [2] workgroup arrivals of the running call
   size_t max_elems;
 };
 
@@ -37,64 +39,101 @@ struct Comm {
 #define MRS_P2P_STORE(P, V) __hip_atomic_store((P), (V), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
 #define MRS_P2P_LOAD(P) __hip_atomic_load((P), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
 #endif
+// two neighbouring granules as ONE 16-byte system-scope store (round 3: half the xGMI write transactions; a granule validates itself, so the pair
+// needs no atomicity beyond each 8-byte half -- the guide observes none torn, and a torn pair would still be two valid granules)
+__device__ __forceinline__ void store2(unsigned long long *p, unsigned long long g0, unsigned long long g1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  const u64x2 v = {g0, g1};
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+#else
+  MRS_P2P_STORE(p, g0);
+  MRS_P2P_STORE(p + 1, g1);
+#endif
+}
 
+// the slice of the message this workgroup owns (even boundaries: pairs stay together)
+__device__ __forceinline__ void wg_slice(size_t count, size_t &i0, size_t &i1) {
+  const size_t per = ((count + gridDim.x - 1) / gridDim.x + 1) & ~(size_t)1;
+  i0 = (size_t)blockIdx.x * per;
+  i1 = i0 + per < count ? i0 + per : count;
+  if (i0 > count) i0 = count;
+}
 __device__ __forceinline__ void post(const Comm &c, const float *buf, size_t count, unsigned seq) {
   const size_t half = (size_t)(seq & 1) * c.world * c.max_elems;
-  for (size_t i = threadIdx.x; i < count; i += NT) {
-    const unsigned long long g = (unsigned long long)__float_as_uint(buf[i]) | ((unsigned long long)seq << 32);
-    for (int r = 0; r < c.world; ++r) MRS_P2P_STORE(c.mail[r] + half + (size_t)c.rank * c.max_elems + i, g);
+  size_t i0, i1;
+  wg_slice(count, i0, i1);
+  const bool pairs = (c.max_elems & 1) == 0;
+  for (size_t i = i0 + 2 * (size_t)threadIdx.x; i < i1; i += 2 * NT) {
+    const unsigned long long g0 = (unsigned long long)__float_as_uint(buf[i]) | ((unsigned long long)seq << 32);
+    const bool two = i + 1 < i1;
+    const unsigned long long g1 = two ? (unsigned long long)__float_as_uint(buf[i + 1]) | ((unsigned long long)seq << 32) : 0ull;
+    for (int r = 0; r < c.world; ++r) {
+      unsigned long long *p = c.mail[r] + half + (size_t)c.rank * c.max_elems + i;
+      if (two && pairs) store2(p, g0, g1);
+      else { MRS_P2P_STORE(p, g0); if (two) MRS_P2P_STORE(p + 1, g1); }
+    }
   }
 }
-// returns false if a granule never arrived (bounded spin)
+// returns false if a granule never arrived (bounded spin); such elements become NaN (advisor, round 2: a timed-out sum must not look like data)
 __device__ __forceinline__ bool reduce(const Comm &c, float *buf, size_t count, unsigned seq) {
   const size_t half = (size_t)(seq & 1) * c.world * c.max_elems;
+  size_t i0, i1;
+  wg_slice(count, i0, i1);
   bool ok = true;
-  for (size_t i = threadIdx.x; i < count; i += NT) {
+  for (size_t i = i0 + threadIdx.x; i < i1; i += NT) {
     float sum = 0.f;
+    bool mine = true;
     for (int r = 0; r < c.world; ++r) {
       const unsigned long long *p = c.mail[c.rank] + half + (size_t)r * c.max_elems + i;
       unsigned long long g = MRS_P2P_LOAD(p);
       for (unsigned spins = 0; (unsigned)(g >> 32) != seq; ++spins) {
-        if (spins > (1u << 24)) { ok = false; break; }
+        if (spins > (1u << 24)) { mine = false; break; }
         __builtin_amdgcn_s_sleep(1);
         g = MRS_P2P_LOAD(p);
       }
       sum += __uint_as_float((unsigned)g);  // rank order: identical bits on every rank
     }
-    buf[i] = sum;
+    buf[i] = mine ? sum : __uint_as_float(0x7fc00000u);
+    ok = ok && mine;
   }
   return ok;
 }
+// the LAST workgroup of a call advances the sequence number: every workgroup read state[0] before it arrived, so the number cannot move under a
+// workgroup that has not started yet
+__device__ __forceinline__ void finish(const Comm &c, unsigned seq, bool ok) {
+  if (!ok) c.state[1] = 1;
+  __syncthreads();  // every thread of this workgroup has read state[0] and finished its elements
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(c.state + 2, 1u) == gridDim.x - 1) { c.state[2] = 0; __threadfence(); c.state[0] = seq; }
+  }
+}
 
 __global__ void __launch_bounds__(NT) all_reduce_kernel(const Comm c, float *buf, size_t count) {
-  const unsigned seq = c.state[0] + 1;
+  const unsigned seq = *(volatile unsigned *)c.state + 1;
   post(c, buf, count, seq);
-  const bool ok = reduce(c, buf, count, seq);
-  if (!ok) c.state[1] = 1;
-  __syncthreads();  // every thread has read state[0]
-  if (threadIdx.x == 0) c.state[0] = seq;
+  finish(c, seq, reduce(c, buf, count, seq));
 }
 // the two halves as separate launches (tests on a sequential schedule: post on every rank, then reduce on every rank)
-__global__ void __launch_bounds__(NT) post_kernel(const Comm c, const float *buf, size_t count) { post(c, buf, count, c.state[0] + 1); }
+__global__ void __launch_bounds__(NT) post_kernel(const Comm c, const float *buf, size_t count) { post(c, buf, count, *(volatile unsigned *)c.state + 1); }
 __global__ void __launch_bounds__(NT) reduce_kernel(const Comm c, float *buf, size_t count) {
-  const unsigned seq = c.state[0] + 1;
-  if (!reduce(c, buf, count, seq)) c.state[1] = 1;
-  __syncthreads();
-  if (threadIdx.x == 0) c.state[0] = seq;
+  const unsigned seq = *(volatile unsigned *)c.state + 1;
+  finish(c, seq, reduce(c, buf, count, seq));
 }
 
-// several ranks of one address space as the workgroups of ONE grid (single-GPU test of the real polling path: the workgroups of a grid are
-// co-resident, kernels on different streams of one device need not be)
+// several ranks of one address space in ONE grid (single-GPU test of the real polling path: the workgroups of a grid are co-resident, kernels on
+// different streams of one device need not be): blockIdx.y = rank, blockIdx.x = the rank's workgroups
 struct Group { Comm c[MAX_WORLD]; float *buf[MAX_WORLD]; };
 __global__ void __launch_bounds__(NT) all_reduce_group_kernel(const Group g, size_t count) {
-  const Comm &c = g.c[blockIdx.x];
-  float *buf = g.buf[blockIdx.x];
-  const unsigned seq = c.state[0] + 1;
+  const Comm &c = g.c[blockIdx.y];
+  float *buf = g.buf[blockIdx.y];
+  const unsigned seq = *(volatile unsigned *)c.state + 1;
   post(c, buf, count, seq);
-  if (!reduce(c, buf, count, seq)) c.state[1] = 1;
-  __syncthreads();
-  if (threadIdx.x == 0) c.state[0] = seq;
+  finish(c, seq, reduce(c, buf, count, seq));
 }
+// workgroups of one call: ~2048 values each, at most MAX_WG (the posting side drives the 7 xGMI links from several CUs at once)
+static inline int wgs_for(size_t count) { const size_t w = (count + 2047) / 2048; return (int)(w < 1 ? 1 : (w > MAX_WG ? MAX_WG : w)); }
 
 }  // namespace p2p
 }  // namespace mrs
@@ -102,6 +141,19 @@ __global__ void __launch_bounds__(NT) all_reduce_group_kernel(const Group g, siz
 using mrs::p2p::Comm;
 
 extern "C" size_t mrs_p2p_mailbox_bytes(int world, size_t max_elems) { return world > 0 ? (size_t)2 * world * max_elems * 8 + 256 : 0; }
+// A mailbox must be FINE-GRAINED / uncached device memory: peers write into it over xGMI while the owner's kernel polls it, and HIP only guarantees
+// in-kernel visibility of peer writes for such allocations (advisor, round 2: a torch.zeros mailbox is coarse-grained; the local L2 may keep a stale line
+// of a half that was read two calls earlier).  Zeroed; free with mrs_p2p_free_mailbox.
+extern "C" void *mrs_p2p_alloc_mailbox(size_t bytes) {
+  void *p = nullptr;
+  if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess || !p) {
+    p = nullptr;
+    if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess || !p) { mrs_host::fail("mrs_p2p_alloc_mailbox: no fine-grained device memory (%zu bytes)", bytes); return nullptr; }
+  }
+  if (hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); mrs_host::fail("mrs_p2p_alloc_mailbox: memset failed"); return nullptr; }
+  return p;
+}
+extern "C" void mrs_p2p_free_mailbox(void *p) { if (p) (void)hipFree(p); }
 // hipIpcGetMemHandle / hipIpcOpenMemHandle of a mailbox (64-byte handles, exchanged by the host framework); HSA_ENABLE_IPC_MODE_LEGACY=0 on this stack
 extern "C" int mrs_ipc_get_handle(void *dev_ptr, void *out64) {
   hipIpcMemHandle_t h;
@@ -140,17 +192,17 @@ extern "C" int mrs_p2p_all_reduce_sum_f32(void *comm, float *buf, size_t count, 
   const Comm &c = *(Comm *)comm;
   if (count > c.max_elems) return -2;
   if (!count) return 0;
-  hipLaunchKernelGGL(mrs::p2p::all_reduce_kernel, dim3(1), dim3(mrs::p2p::NT), 0, (hipStream_t)stream, c, buf, count);
+  hipLaunchKernelGGL(mrs::p2p::all_reduce_kernel, dim3(mrs::p2p::wgs_for(count)), dim3(mrs::p2p::NT), 0, (hipStream_t)stream, c, buf, count);
   return 0;
 }
 extern "C" int mrs_p2p_post(void *comm, const float *buf, size_t count, void *stream) {
   if (!comm || count > ((Comm *)comm)->max_elems) return -2;
-  hipLaunchKernelGGL(mrs::p2p::post_kernel, dim3(1), dim3(mrs::p2p::NT), 0, (hipStream_t)stream, *(Comm *)comm, buf, count);
+  hipLaunchKernelGGL(mrs::p2p::post_kernel, dim3(mrs::p2p::wgs_for(count)), dim3(mrs::p2p::NT), 0, (hipStream_t)stream, *(Comm *)comm, buf, count);
   return 0;
 }
 extern "C" int mrs_p2p_reduce(void *comm, float *buf, size_t count, void *stream) {
   if (!comm || count > ((Comm *)comm)->max_elems) return -2;
-  hipLaunchKernelGGL(mrs::p2p::reduce_kernel, dim3(1), dim3(mrs::p2p::NT), 0, (hipStream_t)stream, *(Comm *)comm, buf, count);
+  hipLaunchKernelGGL(mrs::p2p::reduce_kernel, dim3(mrs::p2p::wgs_for(count)), dim3(mrs::p2p::NT), 0, (hipStream_t)stream, *(Comm *)comm, buf, count);
   return 0;
 }
 // error word of the last calls (1: a granule never arrived -- a peer is not running the same sequence of all-reduces); blocking read
@@ -169,6 +221,6 @@ extern "C" int mrs_p2p_all_reduce_group(void *const *comms, float *const *bufs, 
     g.c[i] = *(Comm *)comms[i];
     g.buf[i] = bufs[i];
   }
-  hipLaunchKernelGGL(mrs::p2p::all_reduce_group_kernel, dim3(n), dim3(mrs::p2p::NT), 0, (hipStream_t)stream, g, count);
+  hipLaunchKernelGGL(mrs::p2p::all_reduce_group_kernel, dim3(mrs::p2p::wgs_for(count), n), dim3(mrs::p2p::NT), 0, (hipStream_t)stream, g, count);
   return 0;
 }

@@ -639,7 +639,7 @@ class Llama {
     const int64_t st = (int64_t)(intptr_t)s;
     // T > 128: the 256-row-tile kernel over bf16 activations (converted once per GEMM group), split-K partials in `part`
     const bool big = T > prefill_big_min() && !getenv("MRS_PREFILL_SMALL_TILES");
-    static const bool use_gemm2 = [] { const char *e = getenv("MRS_PREFILL_GEMM2"); return !e || atoi(e) != 0; }();
+    static const bool use_gemm2 = [] { const char *e = getenv("MRS_PREFILL_GEMM2"); return e && atoi(e) != 0; }();  // opt-in: measured slower than gemm_qc at T = 512 (profiles/round3_prefill.md)
     const size_t part_bytes = big ? mrs_gemm_q_bf16_workspace_bytes(T) : 0;
     void *xb = big ? take(t * std::max(std::max(d, nq), ff) * 2) : nullptr, *part = big ? take(part_bytes) : nullptr;
     void *xg = big ? take(t * ff * 2) : nullptr;  // output slabs of the fused gate / up GEMM (it reads xb while it writes)

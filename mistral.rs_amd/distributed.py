@@ -29,6 +29,9 @@ class Shard:
     world_size: int = 1
     offset: int | None = None
     length: int | None = None
+    # > 0: the tensor is `stacked` experts along the row axis ([E * n, k]); a dim-0 shard then means rows [lo, hi) of EACH expert and must go through
+    # shard_stacked_experts -- shard_qtensor refuses it (advisor, round 2: first rows / world of the stack would be whole leading experts, silently wrong)
+    stacked: int = 0
 
     def bounds(self, size: int) -> tuple[int, int]:
         if self.offset is not None:
@@ -89,6 +92,8 @@ def shard_qtensor(w: QTensor, shard: Shard) -> QTensor:
     data = w.data.view(n, rb)
     if shard.world_size == 1 and shard.offset is None:
         return w
+    if shard.stacked:
+        raise ValueError(f"stacked-expert shard ({shard.stacked} experts): use shard_stacked_experts / shard_llama_tensor, not shard_qtensor")
     if shard.dim == 0:
         lo, hi = shard.bounds(n)
         return QTensor(dt, (hi - lo, k), data[lo:hi].contiguous().view(-1))
@@ -123,13 +128,26 @@ def llama_tensor_shard(name: str, cfg_total: dict, rank: int, world_size: int) -
     if world_size == 1:
         return None
     leaf = name.split(".")[-2] if name.startswith("blk.") else name
+    E = int(cfg_total.get("num_experts", 0) or 0) if leaf.endswith("_exps") else 0
+    if leaf.endswith("_exps") and E <= 0:
+        raise ValueError(f"{name}: stacked experts need cfg_total['num_experts']")
     if leaf in ("attn_q", "ffn_gate", "ffn_up", "ffn_gate_exps", "ffn_up_exps"):  # stacked experts: per expert (shard_stacked_experts)
-        return Shard(0, rank, world_size)
+        return Shard(0, rank, world_size, stacked=E)
     if leaf in ("attn_k", "attn_v"):
         return compute_kv_shard(cfg_total["num_kv_heads"], cfg_total["head_dim"], rank, world_size)
     if leaf in ("attn_output", "ffn_down", "ffn_down_exps"):
-        return Shard(1, rank, world_size)
+        return Shard(1, rank, world_size, stacked=E)
     return None
+
+
+def shard_llama_tensor(name: str, w: QTensor, cfg_total: dict, rank: int, world_size: int) -> QTensor:
+    """One entry point for a loader: the rank's shard of GGUF tensor `name` (dense linears through shard_qtensor, stacked experts per expert)."""
+    sh = llama_tensor_shard(name, cfg_total, rank, world_size)
+    if sh is None:
+        return w
+    if sh.stacked:
+        return shard_stacked_experts(w, sh.stacked, Shard(sh.dim, sh.rank, sh.world_size))
+    return shard_qtensor(w, sh)
 
 
 def local_dims(num_heads: int, num_kv_heads: int, intermediate_size: int, world_size: int) -> tuple[int, int, int]:
@@ -215,17 +233,22 @@ class P2PAllReduce:
         L.mrs_last_error.restype = C.c_char_p
         self._L, self.rank, self.world_size, self.max_elems = L, rank, world_size, max_elems
         torch.cuda.set_device(device)
-        self.mailbox = torch.zeros(L.mrs_p2p_mailbox_bytes(world_size, max_elems), dtype=torch.uint8, device=device)
-        torch.cuda.synchronize()
+        # fine-grained / uncached device memory (hipExtMallocWithFlags inside the extension): peers write into it while our kernel polls it
+        L.mrs_p2p_alloc_mailbox.restype = C.c_void_p
+        L.mrs_p2p_alloc_mailbox.argtypes = [C.c_size_t]
+        L.mrs_p2p_free_mailbox.argtypes = [C.c_void_p]
+        self.mailbox_ptr = L.mrs_p2p_alloc_mailbox(L.mrs_p2p_mailbox_bytes(world_size, max_elems))
+        if not self.mailbox_ptr:
+            raise RuntimeError((L.mrs_last_error() or b"").decode())
         mine = (C.c_char * 64)()
-        if L.mrs_ipc_get_handle(self.mailbox.data_ptr(), mine) != 0:
+        if L.mrs_ipc_get_handle(self.mailbox_ptr, mine) != 0:
             raise RuntimeError((L.mrs_last_error() or b"").decode())
         handles = [None] * world_size
         dist.all_gather_object(handles, bytes(mine))
         ptrs = (C.c_void_p * world_size)()
         for r, hb in enumerate(handles):
             if r == rank:
-                ptrs[r] = self.mailbox.data_ptr()
+                ptrs[r] = self.mailbox_ptr
             else:
                 p = L.mrs_ipc_open_handle(C.create_string_buffer(hb, 64))
                 if not p:

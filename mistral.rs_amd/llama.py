@@ -166,7 +166,7 @@ class Llama:
         L.mrs_gemm2_repack_bytes.argtypes = [C.c_int, C.c_longlong, C.c_longlong]
         L.mrs_gemm2_repack.argtypes = [C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p]
         L.mrs_llama_set_gemm2_tensor.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
-        self._gemm2_wanted = os.environ.get("MRS_PREFILL_GEMM2", "1") != "0"
+        self._gemm2_wanted = os.environ.get("MRS_PREFILL_GEMM2", "0") not in ("", "0")
         L.mrs_last_error.restype = C.c_char_p
         c = _Cfg(cfg.hidden_size, cfg.intermediate_size, cfg.num_layers, cfg.num_heads, cfg.num_kv_heads, cfg.head_dim,
                  cfg.vocab_size, cfg.head_dim, int(cfg.rope_interleaved), cfg.rms_eps, cfg.block_size, cfg.max_blocks_per_seq,
@@ -305,12 +305,12 @@ class Llama:
         return "engine" if (self._engine_wanted and self._engine_ok) else ("fused" if self.cfg.use_fused else "reference-sequence")
 
     def set_decode_persist(self, mode: int) -> None:
-        """Decode engine at b = 1: 1 = one persistent launch per step (default), 2 = the same kernel one phase per launch, 0 = per-phase kernels."""
+        """Decode engine at b = 1: 0 = per-phase kernels (default: measured faster on the MI355X), 1 = one persistent launch per step, 2 = the same kernel one phase per launch."""
         self._chk(self._L.mrs_llama_set_dec_persist(self._h, mode))
         self._graph = None
 
     def set_fused_attention(self, on: bool) -> None:
-        """Decode engine: one-launch attention + Q8_K image for contexts <= 1024 vs the split + merge kernels (default: measured faster); same bits."""
+        """Decode engine: True = the round-2 one-launch attention with the partials in LDS (contexts <= 1024; measured slower, off by default), False = the split kernel with the last-arriver merge (default); same bits."""
         self._L.mrs_llama_set_fused_attention.argtypes = [C.c_void_p, C.c_int]
         self._chk(self._L.mrs_llama_set_fused_attention(self._h, int(on)))
         self._graph = None
@@ -334,6 +334,7 @@ class Llama:
 
     def capture_decode_graph(self, b: int = 1) -> None:
         """Capture one decode step (forward + greedy sample + state advance) into a HIP graph."""
+        self._graph_batch = b
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):  # warm-up outside capture (lazy module loads, attribute sets)
@@ -353,7 +354,8 @@ class Llama:
     def replay(self) -> None:
         # the captured step advances device-side state; refuse to run it past the buffers it indexes (tokens_out, block table, RoPE tables)
         if self._replays_left is None:  # one read-back per set_state(): replays that stay inside the context window and the token buffer
-            self._replays_left = int(min(self.cfg.max_context_len - 1 - int(self.positions.max().item()), self.tokens_out.shape[1] - int(self.step_counter.item())))
+            b = getattr(self, "_graph_batch", None) or self.positions.numel()  # only the sequences of the captured batch count (stale entries of earlier, larger batches do not)
+            self._replays_left = int(min(self.cfg.max_context_len - 1 - int(self.positions[:b].max().item()), self.tokens_out.shape[1] - int(self.step_counter.item())))
         if self._replays_left <= 0:
             raise ValueError("replay(): the decode graph would run past max_new_tokens / max_context_len; set_state() to a new position first")
         self._replays_left -= 1

@@ -49,6 +49,10 @@ enum { hipSuccess = 0 };
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipMemset(void *p, int v, size_t n) { memset(p, v, n); return hipSuccess; }  // "device" memory is host memory
+enum { hipDeviceMallocUncached = 3, hipDeviceMallocFinegrained = 1 };
+static inline hipError_t hipExtMallocWithFlags(void **p, size_t n, unsigned) { *p = malloc(n); return *p ? hipSuccess : (hipError_t)2; }
+static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void *d, const void *s_, size_t n, int, hipStream_t) { memcpy(d, s_, n); return hipSuccess; }
 static inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
@@ -258,6 +262,7 @@ extern "C" inline __bf16 __truncsfbf2(float f) {
 #define __builtin_amdgcn_s_sleep(N) ((void)0)
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __hip_atomic_fetch_add(P, V, ORDER, SCOPE) atomicAdd((P), (V))
+static inline void __threadfence() {}
 #define __hip_atomic_load(P, ORDER, SCOPE) (*(P))
 #define __hip_atomic_store(P, V, ORDER, SCOPE) (*(P) = (V))
 enum { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipDeviceAttributeMultiprocessorCount = 63, hipIpcMemLazyEnablePeerAccess = 1 };

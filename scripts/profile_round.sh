@@ -5,12 +5,12 @@ set -u
 export TMPDIR=/tmp
 OUT=gpurun_out/${1:-final}
 mkdir -p $OUT
-(timeout 1500 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3) > $OUT/pytest_gpu.log
+(timeout 1500 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error|FAILED|Fatal" | tail -12) > $OUT/pytest_gpu.log
 (timeout 900 python bench.py 2>&1 | tail -1) > $OUT/bench_default.log
 (timeout 300 python __graft_entry__.py smoke 2>&1 | tail -2) > $OUT/smoke.log
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o r -- python bench.py --no-cpu-baseline > $OUT/kt.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o r -- python bench.py --no-cpu-baseline --steps 32 > $OUT/fetch.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o r -- python bench.py --no-cpu-baseline --steps 32 > $OUT/write.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o r -- python bench.py --no-cpu-baseline --no-dropin --steps 32 > $OUT/fetch.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o r -- python bench.py --no-cpu-baseline --no-dropin --steps 32 > $OUT/write.log 2>&1
 tail -1 $OUT/kt.log | cut -c1-300
 cat $OUT/pytest_gpu.log $OUT/smoke.log
 cut -c1-1200 $OUT/bench_default.log

@@ -218,7 +218,7 @@ ATTN_Q8K = [C.c_void_p] * 5 + [C.c_int, C.c_float, C.c_void_p, C.c_void_p] + [C.
 PROJ_IMG = [C.POINTER(Mat), C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]
 
 
-ATTN2 = [C.c_void_p] * 9 + [C.c_int, C.c_float, C.c_void_p, C.c_void_p] + [C.c_int] * 10 + [C.c_void_p]
+ATTN2 = [C.c_void_p] * 9 + [C.c_int, C.c_float, C.c_void_p, C.c_void_p] + [C.c_int] * 11 + [C.c_void_p]
 
 
 def _gather_kv(kc, vc, bt_row, ctx, from16):
@@ -230,7 +230,7 @@ def _gather_kv(kc, vc, bt_row, ctx, from16):
     return k, v
 
 
-def check_attention(O, be, heads, kvh, ctxs, max_ctx, kv_dtype=1, n_out=24):
+def check_attention(O, be, heads, kvh, ctxs, max_ctx, kv_dtype=1, n_out=24, window=0):
     """mrs_dec_attention (split waves + last-arriver merge + Q8_K image, ONE launch): the f32 result equals the engine-order restatement
     (orc_attention_engine) BIT FOR BIT, agrees with the restated in-tree CPU attention (single_q.rs order) to f32 rounding, and o_proj on the
     image equals o_proj on the f32 vector bit for bit.  Where the round-2 one-launch kernel applies it produces the same bits."""
@@ -259,7 +259,7 @@ def check_attention(O, be, heads, kvh, ctxs, max_ctx, kv_dtype=1, n_out=24):
     even = (heads // kvh) % 2 == 0
     for rep in range(2):  # twice: the arrival counters must be back at zero
         rc = fn(got.ptr, img.ptr, ticket.ptr, po.ptr, pm.ptr, pl.ptr, q.ptr, kc.ptr, vc.ptr, kvh, scale, bt.ptr, cl.ptr, bs, max_ctx, b, heads, hd, mbs, nq, kvh * hd * bs,
-                hd * bs, kv_dtype, be.stream)
+                hd * bs, kv_dtype, window, be.stream)
         assert rc == (1 if even else 0)
         assert not ticket.numpy().any()
     res = got.numpy()
@@ -267,9 +267,10 @@ def check_attention(O, be, heads, kvh, ctxs, max_ctx, kv_dtype=1, n_out=24):
     bpw = 1 if nblk_max <= 64 else (nblk_max + 63) // 64
     for i, ctx in enumerate(ctxs):
         k, v = _gather_kv(kc_np, vc_np, bt_np[i], ctx, from16)
-        eng = O.attention_engine(q_np[i].reshape(heads, hd), k, v, scale, bpw)
+        eng = O.attention_engine(q_np[i].reshape(heads, hd), k, v, scale, bpw, window)
         assert np.array_equal(res[i].reshape(heads, hd), eng), ("engine-order oracle", i, ctx, float(np.abs(res[i].reshape(heads, hd) - eng).max()))
-        cpu = O.attention_single_q_cpu(q_np[i].reshape(heads, hd), k, v, scale, 1)
+        lo = max(0, ctx - window) if window else 0   # the query sits at position ctx - 1: keys <= ctx - 1 - window are masked
+        cpu = O.attention_single_q_cpu(q_np[i].reshape(heads, hd), k[lo:], v[lo:], scale, 1)
         assert np.abs(res[i].reshape(heads, hd) - cpu).max() <= 2e-6 * max(1.0, np.abs(cpu).max()), ("single_q.rs order", i, ctx)
     if not even:
         return
@@ -284,7 +285,7 @@ def check_attention(O, be, heads, kvh, ctxs, max_ctx, kv_dtype=1, n_out=24):
     np.testing.assert_array_equal(o_img.numpy(), o_ref.numpy())
     eng_o = base * np.float32(0.5) + np.concatenate([O.gemv_engine(t, packed, n_out, nq, r) for r in res], axis=0) * np.float32(1.0)
     np.testing.assert_array_equal(o_img.numpy(), eng_o)
-    if max_ctx <= 1024:  # the round-2 one-launch kernel (partials in LDS): same cores, same bits
+    if max_ctx <= 1024 and not window:  # the round-2 one-launch kernel (partials in LDS): same cores, same bits
         img2, got2 = be.buf(np.zeros(nimg, np.uint8)), be.buf(np.full((b, nq), np.nan, np.float32))
         fused = be.sym("mrs_dec_attention_q8k", ATTN_Q8K, C.c_int)
         assert fused(img2.ptr, got2.ptr, q.ptr, kc.ptr, vc.ptr, kvh, scale, bt.ptr, cl.ptr, bs, max_ctx, b, heads, hd, mbs, nq, kvh * hd * bs, hd * bs, kv_dtype, be.stream) == 0
@@ -321,6 +322,17 @@ def test_fused_attention_gpu(oracle, dev, heads, kvh, ctxs, max_ctx, kvd):
 @pytest.mark.parametrize("heads,kvh,ctxs,max_ctx,kvd", [(32, 8, [4000, 70], 4096, 1), (32, 32, [300], 512, 1), (8, 1, [2047], 2048, 0), (32, 8, [768] * 8, 1024, 1)])
 def test_attention_more_shapes_gpu(oracle, dev, heads, kvh, ctxs, max_ctx, kvd):
     check_attention(oracle, GpuBackend(dev), heads, kvh, ctxs, max_ctx, kvd, n_out=256)
+
+
+@pytest.mark.parametrize("heads,kvh,ctxs,max_ctx,window", [(32, 8, [700, 40, 257], 832, 256), (8, 2, [2047, 100], 2048, 100), (32, 8, [4096], 4096, 4096)])
+def test_attention_sliding_window_host_emulation(oracle, heads, kvh, ctxs, max_ctx, window):
+    check_attention(oracle, HostBackend(), heads, kvh, ctxs, max_ctx, 1, window=window)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("heads,kvh,ctxs,max_ctx,window", [(32, 8, [700, 40, 257], 832, 256), (8, 2, [2047, 100], 2048, 100), (32, 8, [4096, 33], 4096, 1024)])
+def test_attention_sliding_window_gpu(oracle, dev, heads, kvh, ctxs, max_ctx, window):
+    check_attention(oracle, GpuBackend(dev), heads, kvh, ctxs, max_ctx, 1, n_out=256, window=window)
 
 
 GLU_TOPK = [C.POINTER(Mat), C.POINTER(Mat), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_void_p]

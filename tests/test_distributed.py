@@ -54,8 +54,17 @@ def test_shard_stacked_experts(oracle):
     dn = D.shard_stacked_experts(qt, E, D.Shard(1, 0, 2))
     assert dn.shape == (E * n, k // 2)
     np.testing.assert_array_equal(dn.data.view(E * n, rb // 2).numpy(), packed[:, : rb // 2])
-    assert D.llama_tensor_shard("blk.0.ffn_gate_exps.weight", {}, 1, 2) == D.Shard(0, 1, 2) and D.llama_tensor_shard("blk.0.ffn_down_exps.weight", {}, 1, 2) == D.Shard(1, 1, 2)
-    assert D.llama_tensor_shard("blk.0.ffn_gate_inp.weight", {}, 1, 2) is None  # the router is replicated
+    tot = {"num_experts": E}
+    assert D.llama_tensor_shard("blk.0.ffn_gate_exps.weight", tot, 1, 2) == D.Shard(0, 1, 2, stacked=E)
+    assert D.llama_tensor_shard("blk.0.ffn_down_exps.weight", tot, 1, 2) == D.Shard(1, 1, 2, stacked=E)
+    assert D.llama_tensor_shard("blk.0.ffn_gate_inp.weight", tot, 1, 2) is None  # the router is replicated
+    # a stacked-expert shard cannot go through the dense path by accident (advisor, round 2): it raises, and shard_llama_tensor dispatches
+    with pytest.raises(ValueError, match="stacked-expert shard"):
+        D.shard_qtensor(qt, D.llama_tensor_shard("blk.0.ffn_gate_exps.weight", tot, 1, 2))
+    with pytest.raises(ValueError, match="num_experts"):
+        D.llama_tensor_shard("blk.0.ffn_gate_exps.weight", {}, 1, 2)
+    got = D.shard_llama_tensor("blk.0.ffn_gate_exps.weight", qt, tot, 1, 2)
+    assert got.shape == up.shape and torch.equal(got.data, up.data)
 
 
 def test_shard_qtensor_blocks(oracle):
@@ -185,14 +194,14 @@ def _tp_runner_worker(rank, world, port, q, experts=0):
 
     def build(cfg, r, ws):
         m = Llama(cfg, dev, max_new_tokens=8)
-        total = {"num_kv_heads": kvh, "head_dim": hd}
+        total = {"num_kv_heads": kvh, "head_dim": hd, "num_experts": experts}
         for name, val in w.items():
             if isinstance(val, tuple):
                 dt = GgmlDType.from_id(val[0])
                 qt = QTensor.from_numpy(dt, (val[1].shape[0], val[1].shape[1] // dt.type_size * dt.block_size), val[1], dev)
                 sh = D.llama_tensor_shard(name, total, r, ws)
                 if sh is not None and "_exps" in name:
-                    qt = D.shard_stacked_experts(qt, experts, sh)  # every expert cut like a dense FFN matrix
+                    qt = D.shard_stacked_experts(qt, experts, D.Shard(sh.dim, sh.rank, sh.world_size))  # every expert cut like a dense FFN matrix
                 elif sh is not None:
                     qt = D.shard_qtensor(qt, sh)
                 m.set_tensor(name, qt)
@@ -402,11 +411,20 @@ def test_p2p_all_reduce_gpu_split_and_concurrent(dev):
     from tests.abi_backends import GpuBackend
     be = GpuBackend(dev)
     check_p2p_all_reduce_split_launches(be, 4, 4096)
-    world, count = 8, 8192
-    boxes, comms = _p2p_world(be, world, 16384)
+    # (ii) soak (advisor, round 2): mailboxes from mrs_p2p_alloc_mailbox (fine-grained / uncached memory, as the product allocates them), 8 "ranks" x up to
+    # 8 workgroups each in one grid, 24 back-to-back calls that reuse both parity halves, message sizes that exercise one / several workgroups, odd tails
+    world, max_elems = 8, 16384
+    nbytes = be.sym("mrs_p2p_mailbox_bytes", [C.c_int, C.c_size_t], C.c_size_t)(world, max_elems)
+    alloc = be.sym("mrs_p2p_alloc_mailbox", [C.c_size_t], C.c_void_p)
+    raw = [alloc(nbytes) for _ in range(world)]
+    assert all(raw)
+    ptrs = (C.c_void_p * world)(*raw)
+    create = be.sym("mrs_p2p_create", [C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_size_t], C.c_void_p)
+    comms = [create(r, world, ptrs, max_elems) for r in range(world)]
     grp = be.sym("mrs_p2p_all_reduce_group", [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_size_t, C.c_void_p], C.c_int)
     cs = (C.c_void_p * world)(*comms)
-    for it in range(6):
+    for it in range(24):
+        count = (8192, 4097, 1, 16384, 2048, 300)[it % 6]
         xs = [torch.randn(count, device=dev) for _ in range(world)]
         want = torch.zeros(count, device=dev)
         for x in xs:
@@ -417,3 +435,5 @@ def test_p2p_all_reduce_gpu_split_and_concurrent(dev):
         for r in range(world):
             assert torch.equal(xs[r], want), (it, r)
     assert all(be.sym("mrs_p2p_error", [C.c_void_p], C.c_int)(c) == 0 for c in comms)
+    for p_ in raw:
+        be.sym("mrs_p2p_free_mailbox", [C.c_void_p], None)(p_)
