@@ -190,17 +190,20 @@ def dropin_rate(model, cfg, prompt, steps, device):
 
 def measured_traffic(model_name, quant="q4_k_m"):
     """HBM bytes per launch of the dominant kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE on this same command,
-    x2 gfx950 correction; scripts/profile_round.sh -> profiles/round1_hbm_traffic.json).  Counters cannot be read from inside the
+    x2 gfx950 correction; scripts/profile_round.sh -> profiles/round<N>_hbm_traffic.json).  Counters cannot be read from inside the
     timed process, so the figure is the last profiled one for this kernel and workload; null for any other workload."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round2_hbm_traffic.json")
-    try:
-        ks = json.load(open(path))["kernels"]
-        k = next(v for name, v in ks.items() if "dec_gemv_kernel<1, 2>" in name)  # NCOLS = 1, EPI_GLU
-    except (OSError, KeyError, ValueError, StopIteration):
-        return {"traffic": None}
+    here = os.path.dirname(os.path.abspath(__file__))
     if "8B" not in model_name or quant != "q4_k_m":  # the profiled workload is the Q4_K_M model; ISQ Q8_0 streams twice the bytes
         return {"traffic": None}
-    return {"traffic": int(k["read_bytes_per_launch"] + k["write_bytes_per_launch"]), "traffic_source": "profiles/round2_hbm_traffic.json"}
+    for rel in ("profiles/round3_hbm_traffic.json", "profiles/round2_hbm_traffic.json"):  # newest committed pass first
+        try:
+            ks = json.load(open(os.path.join(here, rel)))["kernels"]
+            # NCOLS = 1, EPI_GLU: `dec_gemv_kernel<1, 2, true>` since round 3 (third parameter: the short activation prefetch), `<1, 2>` before
+            k = next(v for name, v in ks.items() if "dec_gemv_kernel<1, 2, true>" in name or "dec_gemv_kernel<1, 2>" in name)
+        except (OSError, KeyError, ValueError, StopIteration):
+            continue
+        return {"traffic": int(k["read_bytes_per_launch"] + k["write_bytes_per_launch"]), "traffic_source": rel}
+    return {"traffic": None}
 
 
 def main():

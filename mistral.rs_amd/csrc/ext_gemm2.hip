@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256) repack2_kernel(const uint8_t *__restrict_
   const int sb = (int)(c >> 2), cc = (int)(c & 3);
   const bool live = row < n;
   if constexpr (TYPE == T_Q4_K) {
-    const uint8_t *b = src + ((size_t)row * (size_t)(k / 256) + (size_t)sb) * 144;
+    const uint8_t *b = src + ((size_t)(live ? row : 0) * (size_t)(k / 256) + (size_t)sb) * 144;  // padding rows of the last tile never touch memory past the tensor
     uint8_t *q = dst + L.q + (size_t)gid * 16;
     for (int t = 0; t < 2; ++t)
       for (int j = 0; j < 8; ++j) q[t * 8 + j] = live ? b[16 + cc * 32 + t * 16 + kh * 8 + j] : 0;
@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(256) repack2_kernel(const uint8_t *__restrict_
       }
     }
   } else {  // Q6_K
-    const uint8_t *b = src + ((size_t)row * (size_t)(k / 256) + (size_t)sb) * 210;
+    const uint8_t *b = src + ((size_t)(live ? row : 0) * (size_t)(k / 256) + (size_t)sb) * 210;
     const uint8_t *ql = b, *qh = b + 128;
     const int8_t *scs = (const int8_t *)(b + 192);
     uint32_t lo[4] = {0, 0, 0, 0}, hi[2] = {0, 0};

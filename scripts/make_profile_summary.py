@@ -36,7 +36,7 @@ def main():
         w = write.get(k, [0.0])
         out[k] = {"launches": len(v), "fetch_size_kb_avg": sum(v) / len(v), "read_bytes_per_launch": 2.0 * 1024.0 * sum(v) / len(v),
                   "write_size_kb_avg": sum(w) / len(w), "write_bytes_per_launch": 1024.0 * sum(w) / len(w)}
-    meta = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python bench.py --no-cpu-baseline --steps 32",
+    meta = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python bench.py --no-cpu-baseline --no-dropin --steps 32",
             "correction": "FETCH_SIZE is in KB and counts 64 B per 128-B request on gfx950 for wide coalesced reads: read bytes = 2 * 1024 * FETCH_SIZE",
             "kernels": out}
     with open(os.path.join(root, "profiles", f"{tag}_hbm_traffic.json"), "w") as f:

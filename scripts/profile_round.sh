@@ -5,7 +5,8 @@ set -u
 export TMPDIR=/tmp
 OUT=gpurun_out/${1:-final}
 mkdir -p $OUT
-(timeout 1500 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error|FAILED|Fatal" | tail -12) > $OUT/pytest_gpu.log
+timeout 1800 python -m pytest tests -q -m gpu -rf > $OUT/pytest_gpu_full.log 2>&1
+(grep -E "passed|failed|error|FAILED|Fatal|fault" $OUT/pytest_gpu_full.log | tail -12) > $OUT/pytest_gpu.log
 (timeout 900 python bench.py 2>&1 | tail -1) > $OUT/bench_default.log
 (timeout 300 python __graft_entry__.py smoke 2>&1 | tail -2) > $OUT/smoke.log
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o r -- python bench.py --no-cpu-baseline > $OUT/kt.log 2>&1

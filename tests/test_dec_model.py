@@ -11,6 +11,7 @@ reference CPU path (oracle/llama_ref.py + oracle/cpu_path_oracle.c).  Round 3: t
     implementation that does not reproduce one specific build's summation order; the tests hold the engine to the spread that two CPU orders show
     on the same model and tokens (factor 1.25 on the means), and to the size of one moved quant (3e-2) on the tiny model.
 KV pages: f16 (the reference CPU path's default KV dtype) and bf16 (the dtype of the GPU pipelines), each against the oracle with the same KV rounding."""
+import os
 import numpy as np
 import pytest
 
@@ -365,7 +366,7 @@ def test_sliding_window_decode_and_prefill(oracle, dev, request):
     mirror = llama_ref.LlamaRef(cfg, w, cos, sin, mode="engine", kv_dtype="bf16")
     ref = llama_ref.LlamaRef(cfg, w, cos, sin, mode="cpu", kv_dtype="bf16")
     full = llama_ref.LlamaRef(type("C", (), {**cfg.__dict__, "sliding_window": None})(), w, cos, sin, mode="engine", kv_dtype="bf16")
-    steps = 44 if emu else 120
+    steps = (0 if os.environ.get('MRS_TEST_WINDOW_TAIL_ONLY') else 44) if emu else 120
     tok, worst, differs_from_full = 1000 % cfg.vocab_size, 0.0, False
     for pos in range(steps):
         exact, want, nowin = mirror.step(tok, pos), ref.step(tok, pos), full.step(tok, pos)
@@ -378,11 +379,11 @@ def test_sliding_window_decode_and_prefill(oracle, dev, request):
         if pos < W:
             assert np.array_equal(exact, nowin)  # inside the window nothing is masked
         tok = int(got.argmax())
-    assert differs_from_full, "the window never changed the result: the test does not exercise it"
+    assert differs_from_full or os.environ.get('MRS_TEST_WINDOW_TAIL_ONLY'), "the window never changed the result: the test does not exercise it"
     assert worst <= 5e-2, worst  # one or two moved int8 quants on a 512-wide model over 120 positions (3.7e-2 measured on the MI355X)
-    if emu:
-        return
-    import torch
+    import os, torch
+    if emu and not os.environ.get("MRS_TEST_WINDOW_PREFILL"):
+        return  # minutes on the host emulation: opt-in there
     cfg2, w2, m2, _, _ = _mk(oracle, dev, Q4KM(oracle), "bf16", max_batch=1, sliding_window=W)
     prompt = [(1000 + 3 * i) % cfg.vocab_size for i in range(70)]
     lp = m2.prefill(prompt, 0)
@@ -391,11 +392,13 @@ def test_sliding_window_decode_and_prefill(oracle, dev, request):
     for pos, t in enumerate(prompt):
         m3.set_state([t], [pos])
         ld = m3.forward_logits(1)[0].clone()
+    print(f"window prefill vs decode: {float((lp - ld).abs().max()) / float(ld.abs().max()):.3e}")
     assert float((lp - ld).abs().max()) <= 5e-2 * float(ld.abs().max())
     # and the decode step after the prefill reads the pages the prefill wrote through the same window
     nxt = int(ld.argmax())
     m2.set_state([nxt], [len(prompt)]); m3.set_state([nxt], [len(prompt)])
     a, b = m2.forward_logits(1)[0], m3.forward_logits(1)[0]
+    print(f"first decode after the prompt: {float((a - b).abs().max()) / float(b.abs().max()):.3e}")
     assert float((a - b).abs().max()) <= 5e-2 * float(b.abs().max())
 
 
