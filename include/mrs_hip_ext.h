@@ -292,7 +292,14 @@ int mrs_isq_quantize(const void *src, int src_dtype, void *dst, long long n_elem
 /* QuantMethod::dequantize_w for GGUF blocks (mistralrs-quant/src/gguf/mod.rs:430-432 -> candle QTensor::dequantize): packed [nrows][K/blk]
  * of ggml_type 2,3,6,7,8,10..14 -> dense [nrows][K] of out_dtype 0 f32 / 1 f16 / 30 bf16; w = scale*q - offset in f32 (the format spec of
  * kernels/gguf_affine_packed/marlin_gguf_affine_repack.cu:141-278), one rounding to the output dtype.  Returns 0 / -1. */
+/* importance-weighted ISQ (candle QTensor::quantize_imatrix; reference call sites gguf/mod.rs:238-252): Q4_K / Q5_K / Q6_K targets, imatrix f32 [k] on the device */
+int mrs_isq_quantize_imatrix(const void *src, int src_dtype, void *dst, long long nrows, int k, int ggml_type, const float *imatrix, void *stream);
 int mrs_dequantize(const void *w, int ggml_type, long long nrows, int K, void *out, int out_dtype, void *stream);
+/* imatrix statistics of a layer (mistralrs-quant/src/imatrix.rs:73-135: ImatrixLayerStats::process / process_routed): accum[c] += sum over rows of
+ * x[r][c]^2 in row order; routed: every (token, slot) row is added to accum[ids[t][s]] and counts[ids[t][s]] += 1.  dtype 0 f32 / 1 f16 / 30 bf16. */
+int mrs_imatrix_accumulate(const void *x, int dtype, long long rows, int cols, float *accum, void *stream);
+int mrs_imatrix_accumulate_routed(const void *x, int dtype, const uint32_t *ids, int n, int k, int cols, int per_slot, int num_experts, float *accum,
+                                  float *counts, void *stream);
 
 /* ---------------------------------------------------------------- paged KV cache manager (host/kv_cache_manager.cpp; host code only)
  * Block pool with prefix caching + per-request block tracking: the C++ counterpart of mistralrs-core/src/paged_attention/

@@ -90,8 +90,69 @@ __device__ __forceinline__ float isq_make_qkx2(const float (&x)[32], const float
 }
 
 // Q4_K (FIVE = false, 144 B) / Q5_K (FIVE = true, 176 B): 8 lanes per superblock, lane j = sub-block j
-template <class T, bool FIVE>
-__global__ void __launch_bounds__(256) isq_q45_k_kernel(const T *__restrict__ src, uint8_t *__restrict__ out, size_t nsuper) {
+// make_qp_quants(8, 63, x, L, qw) of GGML's importance-weighted quantizers: the 6-bit super-scale search over the eight sub-block scales (or mins)
+__device__ __forceinline__ float isq_make_qp8(const float (&x)[8], int (&L)[8], const float (&qw)[8]) {
+  constexpr int nmax = 63;
+  float mx = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) if (x[i] > mx) mx = x[i];
+  if (!(mx != 0.f)) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) L[i] = 0;
+    return 0.f;
+  }
+  float iscale = nmax / mx;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) L[i] = isq_nearest_int(iscale * x[i]);
+  const float scale = 1 / iscale;
+  float best_mse = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { const float diff = x[i] - scale * L[i]; best_mse += qw[i] * diff * diff; }
+  for (int is = -4; is <= 4; ++is) {
+    if (is == 0) continue;
+    const float iscale_is = (0.1f * is + nmax) / mx, scale_is = 1 / iscale_is;
+    float mse = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int l = min(nmax, isq_nearest_int(iscale_is * x[i]));
+      const float diff = x[i] - scale_is * l;
+      mse += qw[i] * diff * diff;
+    }
+    if (mse < best_mse) { best_mse = mse; iscale = iscale_is; }
+  }
+  float sumlx = 0, suml2 = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int l = min(nmax, isq_nearest_int(iscale * x[i]));
+    L[i] = l;
+    sumlx += qw[i] * x[i] * l;
+    suml2 += qw[i] * l * l;
+  }
+  for (int itry = 0; itry < 5; ++itry) {
+    int n_changed = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float w = qw[i];
+      float slx = sumlx - w * x[i] * L[i], sl2 = suml2 - w * L[i] * L[i];
+      if (slx > 0 && sl2 > 0) {
+        const int new_l = min(nmax, isq_nearest_int(x[i] * sl2 / slx));
+        if (new_l != L[i]) {
+          slx += w * x[i] * new_l;
+          sl2 += w * new_l * new_l;
+          if (slx * slx * suml2 > sumlx * sumlx * sl2) { L[i] = new_l; sumlx = slx; suml2 = sl2; ++n_changed; }
+        }
+      }
+    }
+    if (!n_changed) break;
+  }
+  return sumlx / suml2;
+}
+
+// IM: GGML's quantize_row_q{4,5}_K_impl with quant_weights qw[k] (one importance value per input column, shared by the rows): weights
+// qw * sqrt(sigma2 + x^2) with sigma2 = 2 * sum(x^2) / 256 over the superblock, 37 candidate scales per sub-block, 6-bit scales by make_qp_quants.
+template <class T, bool FIVE, bool IM = false>
+__global__ void __launch_bounds__(256) isq_q45_k_kernel(const T *__restrict__ src, uint8_t *__restrict__ out, size_t nsuper, const float *__restrict__ qw = nullptr,
+                                                        int sb_per_row = 0) {
   constexpr int NMAX = FIVE ? 31 : 15, TS = FIVE ? 176 : 144;
   const int lane = threadIdx.x & 63, j = lane & 7, base = lane & ~7;
   const size_t sb_raw = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 3;
@@ -102,22 +163,46 @@ __global__ void __launch_bounds__(256) isq_q45_k_kernel(const T *__restrict__ sr
   float sum_x2 = 0;
 #pragma unroll
   for (int l = 0; l < 32; ++l) { x[l] = to_f<T>(p[l]); sum_x2 += x[l] * x[l]; }
-  const float av_x = sqrtf(sum_x2 / 32);
-#pragma unroll
-  for (int l = 0; l < 32; ++l) w[l] = av_x + fabsf(x[l]);
-  float mn_j;
-  const float sc_j = FIVE ? isq_make_qkx2(x, w, 31, -0.5f, 0.1f, 15, mn_j) : isq_make_qkx2(x, w, 15, -1.f, 0.1f, 20, mn_j);
-  float max_scale = sc_j > 0 ? sc_j : 0.f, max_min = mn_j > 0 ? mn_j : 0.f;  // `if (scales[j] > max_scale)` from +0: never -0, never NaN
-#pragma unroll
-  for (int m = 1; m < 8; m <<= 1) { max_scale = fmaxf(max_scale, __shfl_xor(max_scale, m, 64)); max_min = fmaxf(max_min, __shfl_xor(max_min, m, 64)); }
-  const float inv_scale = max_scale > 0 ? 63.f / max_scale : 0.f, inv_min = max_min > 0 ? 63.f / max_min : 0.f;
-  const int ls = min(63, isq_nearest_int(inv_scale * sc_j)), lm = min(63, isq_nearest_int(inv_min * mn_j));
-  // header (lane 0 of the group): half d, half dmin, 12 bytes of 6-bit scales / mins (get_scale_min_k4 layout)
-  const int mine = (ls & 0xff) | ((lm & 0xff) << 8);
+  float mn_j, sc_j;
   int all[8];
+  uint16_t dbits, mbits;
+  if constexpr (IM) {
+    // sigma2 over the whole superblock in element order (every lane of the group walks the 256 values: load-time work, and the order is the definition)
+    float tot = 0;
+    const T *p0 = src + sb * 256;
+    for (int l = 0; l < 256; ++l) { const float v = to_f<T>(p0[l]); tot += v * v; }
+    const float sigma2 = 2 * tot / 256;
+    const float *q = qw + (sb % (size_t)sb_per_row) * 256 + (size_t)j * 32;
+    float sumw = 0;
 #pragma unroll
-  for (int g = 0; g < 8; ++g) all[g] = __shfl(mine, base + g, 64);
-  const uint16_t dbits = float_to_half_bits(max_scale / 63.f), mbits = float_to_half_bits(max_min / 63.f);
+    for (int l = 0; l < 32; ++l) { w[l] = q[l] * sqrtf(sigma2 + x[l] * x[l]); sumw += w[l]; }
+    sc_j = isq_make_qkx2(x, w, NMAX, -0.9f, 0.05f, 36, mn_j);  // make_qkx3_quants with the weights given
+    float scs[8], mns[8], sws[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) { scs[g] = __shfl(sc_j, base + g, 64); mns[g] = __shfl(mn_j, base + g, 64); sws[g] = __shfl(sumw, base + g, 64); }
+    int Ls[8], Lm[8];
+    const float d_block = isq_make_qp8(scs, Ls, sws), m_block = isq_make_qp8(mns, Lm, sws);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) all[g] = (Ls[g] & 0xff) | ((Lm[g] & 0xff) << 8);
+    dbits = float_to_half_bits(d_block);
+    mbits = float_to_half_bits(m_block);
+  } else {
+    const float av_x = sqrtf(sum_x2 / 32);
+#pragma unroll
+    for (int l = 0; l < 32; ++l) w[l] = av_x + fabsf(x[l]);
+    sc_j = FIVE ? isq_make_qkx2(x, w, 31, -0.5f, 0.1f, 15, mn_j) : isq_make_qkx2(x, w, 15, -1.f, 0.1f, 20, mn_j);
+    float max_scale = sc_j > 0 ? sc_j : 0.f, max_min = mn_j > 0 ? mn_j : 0.f;  // `if (scales[j] > max_scale)` from +0: never -0, never NaN
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) { max_scale = fmaxf(max_scale, __shfl_xor(max_scale, m, 64)); max_min = fmaxf(max_min, __shfl_xor(max_min, m, 64)); }
+    const float inv_scale = max_scale > 0 ? 63.f / max_scale : 0.f, inv_min = max_min > 0 ? 63.f / max_min : 0.f;
+    const int ls = min(63, isq_nearest_int(inv_scale * sc_j)), lm = min(63, isq_nearest_int(inv_min * mn_j));
+    // header (lane 0 of the group): half d, half dmin, 12 bytes of 6-bit scales / mins (get_scale_min_k4 layout)
+    const int mine = (ls & 0xff) | ((lm & 0xff) << 8);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) all[g] = __shfl(mine, base + g, 64);
+    dbits = float_to_half_bits(max_scale / 63.f);
+    mbits = float_to_half_bits(max_min / 63.f);
+  }
   uint8_t *y = out + sb * TS;
   uint8_t sc12[12];  // every lane builds the packed header (cheap) so that its own (sc, m) come out of the bytes exactly as a reader decodes them
 #pragma unroll
@@ -182,8 +267,10 @@ __global__ void __launch_bounds__(256) isq_q45_k_kernel(const T *__restrict__ sr
 }
 
 // Q6_K (210 B, 2-byte aligned): 16 lanes per superblock, lane ib = 16-weight sub-block ib
-template <class T>
-__global__ void __launch_bounds__(256) isq_q6_k_kernel(const T *__restrict__ src, uint8_t *__restrict__ out, size_t nsuper) {
+// IM: GGML's quantize_row_q6_K_impl with quant_weights -- the importance values themselves weight the 19-candidate scale search
+template <class T, bool IM = false>
+__global__ void __launch_bounds__(256) isq_q6_k_kernel(const T *__restrict__ src, uint8_t *__restrict__ out, size_t nsuper, const float *__restrict__ qw = nullptr,
+                                                       int sb_per_row = 0) {
   const int lane = threadIdx.x & 63, ib = lane & 15, base = lane & ~15;
   const size_t sb_raw = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 4;
   const bool live = sb_raw < nsuper;
@@ -192,7 +279,13 @@ __global__ void __launch_bounds__(256) isq_q6_k_kernel(const T *__restrict__ src
   const T *p = src + sb * 256 + (size_t)ib * 16;
 #pragma unroll
   for (int i = 0; i < 16; ++i) x[i] = to_f<T>(p[i]);
-  // make_qx_quants(16, 32, x, L): rmse_type 1, no weights
+  float wq[16];  // rmse_type 1: x^2, or the importance values
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    if constexpr (IM) wq[i] = qw[(sb % (size_t)sb_per_row) * 256 + (size_t)ib * 16 + i];
+    else wq[i] = x[i] * x[i];
+  }
+  // make_qx_quants(16, 32, x, L, 1, weights)
   int L[16];
   float scale;
   {
@@ -209,7 +302,7 @@ __global__ void __launch_bounds__(256) isq_q6_k_kernel(const T *__restrict__ src
       for (int i = 0; i < 16; ++i) {
         const int l = max(-32, min(31, isq_nearest_int(iscale * x[i])));
         L[i] = l + 32;
-        const float w = x[i] * x[i];
+        const float w = wq[i];
         sumlx += w * x[i] * l;
         suml2 += w * l * l;
       }
@@ -222,7 +315,7 @@ __global__ void __launch_bounds__(256) isq_q6_k_kernel(const T *__restrict__ src
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int l = max(-32, min(31, isq_nearest_int(iscale * x[i])));
-          const float w = x[i] * x[i];
+          const float w = wq[i];
           sumlx += w * x[i] * l;
           suml2 += w * l * l;
         }
@@ -345,9 +438,21 @@ template <class T> static int isq_dispatch(const T *src, uint8_t *dst, size_t n,
   case 3: { const size_t nb = n / 32; hipLaunchKernelGGL((isq_legacy_kernel<T, 3>), dim3((unsigned)((nb + 255) / 256)), block, 0, s, src, dst, nb); return 0; }
   case 6: { const size_t nb = n / 32; hipLaunchKernelGGL((isq_legacy_kernel<T, 6>), dim3((unsigned)((nb + 255) / 256)), block, 0, s, src, dst, nb); return 0; }
   case 7: { const size_t nb = n / 32; hipLaunchKernelGGL((isq_legacy_kernel<T, 7>), dim3((unsigned)((nb + 255) / 256)), block, 0, s, src, dst, nb); return 0; }
-  case 12: { const size_t nb = n / 256; hipLaunchKernelGGL((isq_q45_k_kernel<T, false>), dim3((unsigned)((nb + 31) / 32)), block, 0, s, src, dst, nb); return 0; }
-  case 13: { const size_t nb = n / 256; hipLaunchKernelGGL((isq_q45_k_kernel<T, true>), dim3((unsigned)((nb + 31) / 32)), block, 0, s, src, dst, nb); return 0; }
-  case 14: { const size_t nb = n / 256; hipLaunchKernelGGL((isq_q6_k_kernel<T>), dim3((unsigned)((nb + 15) / 16)), block, 0, s, src, dst, nb); return 0; }
+  case 12: { const size_t nb = n / 256; hipLaunchKernelGGL((isq_q45_k_kernel<T, false, false>), dim3((unsigned)((nb + 31) / 32)), block, 0, s, src, dst, nb, (const float *)nullptr, 0); return 0; }
+  case 13: { const size_t nb = n / 256; hipLaunchKernelGGL((isq_q45_k_kernel<T, true, false>), dim3((unsigned)((nb + 31) / 32)), block, 0, s, src, dst, nb, (const float *)nullptr, 0); return 0; }
+  case 14: { const size_t nb = n / 256; hipLaunchKernelGGL((isq_q6_k_kernel<T, false>), dim3((unsigned)((nb + 15) / 16)), block, 0, s, src, dst, nb, (const float *)nullptr, 0); return 0; }
+  default: return -1;
+  }
+}
+
+template <class T> static int isq_dispatch_imatrix(const T *src, uint8_t *dst, size_t nrows, int k, int type, const float *qw, hipStream_t s) {
+  const dim3 block(256);
+  const size_t nb = nrows * (size_t)(k / 256);
+  const int spr = k / 256;
+  switch (type) {
+  case 12: hipLaunchKernelGGL((isq_q45_k_kernel<T, false, true>), dim3((unsigned)((nb + 31) / 32)), block, 0, s, src, dst, nb, qw, spr); return 0;
+  case 13: hipLaunchKernelGGL((isq_q45_k_kernel<T, true, true>), dim3((unsigned)((nb + 31) / 32)), block, 0, s, src, dst, nb, qw, spr); return 0;
+  case 14: hipLaunchKernelGGL((isq_q6_k_kernel<T, true>), dim3((unsigned)((nb + 15) / 16)), block, 0, s, src, dst, nb, qw, spr); return 0;
   default: return -1;
   }
 }
@@ -388,6 +493,36 @@ template <class OUT> static int dequantize_dispatch(const uint8_t *w, OUT *out, 
 #undef MRS_DQ
 }
 
+// ------------------------------------------------------------------------------------------------ imatrix statistics
+// ImatrixLayerStats::process / process_routed (mistralrs-quant/src/imatrix.rs:73-135): per input column, the sum of squares of the activations a
+// layer has seen (`inp.sqr().sum(0)` added to the accumulator; routed layers scatter every (token, slot) row into its expert's accumulator with
+// `index_add`).  One thread per column walks the rows in order, so the f32 sums do not depend on the launch geometry.
+template <class T>
+__global__ void __launch_bounds__(256) imatrix_dense_kernel(const T *__restrict__ x, float *__restrict__ accum, long long rows, int cols) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.0f;
+  for (long long r = 0; r < rows; ++r) { const float v = to_f<T>(x[r * cols + c]); s += v * v; }
+  accum[c] = accum[c] + s;
+}
+// x: [n][in] (a token's row goes to all k of its experts) or [n * k][in] (per_slot: row t * k + s goes to ids[t][s] only); ids: [n * k]
+template <class T>
+__global__ void __launch_bounds__(256) imatrix_routed_kernel(const T *__restrict__ x, const uint32_t *__restrict__ ids, float *__restrict__ accum,
+                                                             float *__restrict__ counts, int n, int k, int cols, int per_slot, int num_experts) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < cols) {
+    for (int s = 0; s < n * k; ++s) {
+      const uint32_t e = ids[s];
+      if (e >= (uint32_t)num_experts) continue;  // candle's index_add would refuse the id; nothing is written here
+      const float v = to_f<T>(x[(size_t)(per_slot ? s : s / k) * cols + c]);
+      accum[(size_t)e * cols + c] += v * v;
+    }
+  }
+  if (c == 0)
+    for (int s = 0; s < n * k; ++s)
+      if (ids[s] < (uint32_t)num_experts) counts[ids[s]] += 1.0f;
+}
+
 }  // namespace mrs
 
 // src: dense [N*K] elements, dtype 0 = f32, 1 = f16, 30 = bf16 (ggml ids); dst: N*K/32*34 bytes.  Returns 0 / -1.
@@ -421,6 +556,21 @@ extern "C" int mrs_isq_quantize(const void *src, int src_dtype, void *dst, long 
   }
 }
 
+// Importance-weighted ISQ (QTensor::quantize_imatrix; call sites gguf/mod.rs:238-252, utils/isq.rs generate_isq_imatrix!): src dense [nrows][k],
+// imatrix f32 [k] on the device (one value per input column, shared by the rows), ggml_type 12 Q4_K / 13 Q5_K / 14 Q6_K.  Returns 0, -1 for other
+// types / dtypes or k % 256 != 0 (the caller then quantizes without the importance vector, as the reference does for non-K-quant targets).
+extern "C" int mrs_isq_quantize_imatrix(const void *src, int src_dtype, void *dst, long long nrows, int k, int ggml_type, const float *imatrix, void *stream) {
+  if (nrows <= 0) return 0;
+  if (!src || !dst || !imatrix || k <= 0 || k % 256) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  switch (src_dtype) {
+  case 0: return mrs::isq_dispatch_imatrix<float>((const float *)src, (uint8_t *)dst, (size_t)nrows, k, ggml_type, imatrix, s);
+  case 1: return mrs::isq_dispatch_imatrix<mrs::f16_t>((const mrs::f16_t *)src, (uint8_t *)dst, (size_t)nrows, k, ggml_type, imatrix, s);
+  case 30: return mrs::isq_dispatch_imatrix<mrs::bf16_t>((const mrs::bf16_t *)src, (uint8_t *)dst, (size_t)nrows, k, ggml_type, imatrix, s);
+  default: return -1;
+  }
+}
+
 // QuantMethod::dequantize_w for GGUF blocks (gguf/mod.rs:430-432 -> QTensor::dequantize): packed [nrows][K/blk] -> dense [nrows][K] of
 // out_dtype 0 = f32, 1 = f16, 30 = bf16 (values computed in f32, one rounding).  Returns 0, -1 for an unknown type / dtype or K not a
 // multiple of the block size.
@@ -433,6 +583,35 @@ extern "C" int mrs_dequantize(const void *w, int ggml_type, long long nrows, int
   case 0: return mrs::dequantize_dispatch<float>((const uint8_t *)w, (float *)out, nrows, K, ggml_type, s);
   case 1: return mrs::dequantize_dispatch<mrs::f16_t>((const uint8_t *)w, (mrs::f16_t *)out, nrows, K, ggml_type, s);
   case 30: return mrs::dequantize_dispatch<mrs::bf16_t>((const uint8_t *)w, (mrs::bf16_t *)out, nrows, K, ggml_type, s);
+  default: return -1;
+  }
+}
+
+// imatrix statistics (imatrix.rs:73-135).  x: [rows][cols] of dtype 0 = f32 / 1 = f16 / 30 = bf16; accum: f32 [cols], updated in place.
+extern "C" int mrs_imatrix_accumulate(const void *x, int dtype, long long rows, int cols, float *accum, void *stream) {
+  if (!x || !accum || rows < 0 || cols <= 0) return -1;
+  if (rows == 0) return 0;
+  const dim3 grid((unsigned)((cols + 255) / 256)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (dtype) {
+  case 0: hipLaunchKernelGGL(mrs::imatrix_dense_kernel<float>, grid, block, 0, s, (const float *)x, accum, rows, cols); return 0;
+  case 1: hipLaunchKernelGGL(mrs::imatrix_dense_kernel<mrs::f16_t>, grid, block, 0, s, (const mrs::f16_t *)x, accum, rows, cols); return 0;
+  case 30: hipLaunchKernelGGL(mrs::imatrix_dense_kernel<mrs::bf16_t>, grid, block, 0, s, (const mrs::bf16_t *)x, accum, rows, cols); return 0;
+  default: return -1;
+  }
+}
+// routed layers: ids [n][k] u32 expert of every (token, slot); x [n][cols] (per_slot = 0) or [n][k][cols] (per_slot = 1); accum f32 [num_experts][cols],
+// counts f32 [num_experts], both updated in place.
+extern "C" int mrs_imatrix_accumulate_routed(const void *x, int dtype, const uint32_t *ids, int n, int k, int cols, int per_slot, int num_experts,
+                                             float *accum, float *counts, void *stream) {
+  if (!x || !ids || !accum || !counts || n < 0 || k <= 0 || cols <= 0 || num_experts <= 0) return -1;
+  if (n == 0) return 0;
+  const dim3 grid((unsigned)((cols + 255) / 256)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (dtype) {
+  case 0: hipLaunchKernelGGL(mrs::imatrix_routed_kernel<float>, grid, block, 0, s, (const float *)x, ids, accum, counts, n, k, cols, per_slot, num_experts); return 0;
+  case 1: hipLaunchKernelGGL(mrs::imatrix_routed_kernel<mrs::f16_t>, grid, block, 0, s, (const mrs::f16_t *)x, ids, accum, counts, n, k, cols, per_slot, num_experts); return 0;
+  case 30: hipLaunchKernelGGL(mrs::imatrix_routed_kernel<mrs::bf16_t>, grid, block, 0, s, (const mrs::bf16_t *)x, ids, accum, counts, n, k, cols, per_slot, num_experts); return 0;
   default: return -1;
   }
 }

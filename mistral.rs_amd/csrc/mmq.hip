@@ -18,6 +18,7 @@
 // Scale products (d * sc, dmin * m) stay in f32; the reference's Q2_K tile loader rounds them to half.
 #include "common.cuh"
 #include "gguf_blocks.cuh"
+#include <stdlib.h>
 
 namespace mrs {
 
@@ -223,9 +224,135 @@ __global__ void __launch_bounds__(256) mmq_kernel(MmqArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ matrix-core route (Q4_K / Q5_K, DS4 activations)
+// The integer dot of one 32-value sub-block is ONE v_mfma_i32_32x32x32_i8: A = 32 activation columns x 32 ints (from the block_q8_1_mmq scratch,
+// staged through LDS once per workgroup), B = 32 ints x 32 weight rows (each lane unpacks the 16 nibbles of ITS row straight from the GGUF block:
+// lane l = row l % 32, k half l / 32 -- the same 16 bytes serve sub-blocks 2c (low nibbles) and 2c + 1 (high nibbles)).  The result lane holds
+// weight row l % 32 and 16 activation columns, so the per-sub-block fix-up  acc += (d sc_j)(row) d8_j(col) isum - (dmin m_j)(row) s8_j(col)
+// has its row factors in two lane registers and its column factors as f32 pairs in LDS (converted from the half2 headers when the tile is staged;
+// every lane of a k half reads the same address: broadcast).  Same integers, same stored sums as mmq_kernel; only the f32 summation order differs
+// (sub-block order per output instead of lane-strided partial sums).  Arithmetic cost: 16 cvt + 16 mul + 32 fma per MFMA -- the route is VALU-bound
+// about 8 : 1, which still is ~5 x the v_dot4 kernel.  Workgroup tile 128 weight rows x 128 columns, wave tile 32 x 128.
+typedef int mm_v4i __attribute__((ext_vector_type(4)));
+typedef int mm_v16i __attribute__((ext_vector_type(16)));
+constexpr int MM_ROWS = 128, MM_COLS = 128;
+
+template <int TYPE, class OUT>
+__global__ void __launch_bounds__(256, 2) mmq_mfma_kernel(MmqArgs a) {  // 2 workgroups per CU (<= 256 VGPRs: 168 spills ~90 values)
+  static_assert(TYPE == T_Q4_K || TYPE == T_Q5_K, "DS4 K-quants with 32-value sub-blocks");
+  constexpr int TS = Fmt<TYPE>::TS, QS = TYPE == T_Q4_K ? 16 : 48;  // block bytes, offset of qs[128]
+  __shared__ __attribute__((aligned(16))) uint8_t raw[2 * MM_COLS * MMQ_BLOCK_BYTES];  // [k block of 128][column][144 B]
+  __shared__ __attribute__((aligned(16))) float hdr[8 * MM_COLS * 2];                  // [sub-block][column]{d8, s8}
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 5;
+  const int64_t col_low = a.expert_bounds ? a.expert_bounds[blockIdx.z] : 0;
+  const int64_t col_high = a.expert_bounds ? a.expert_bounds[blockIdx.z + 1] : a.ncols_y;
+  const int64_t c0 = col_low + (int64_t)blockIdx.y * MM_COLS;
+  if (c0 >= col_high) return;  // workgroup-uniform
+  const int64_t row = (int64_t)blockIdx.x * MM_ROWS + wave * 32 + (lane & 31);
+  const int64_t rowc = row < a.nrows_x ? row : a.nrows_x - 1;  // surplus rows are computed on the last row and dropped
+  const uint8_t *wrow = a.x + ((int64_t)blockIdx.z * a.stride_channel_x + rowc * a.stride_row_x) * TS;
+  const int nsb = (int)(a.ncols_x / 256);
+  float acc[4][16];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+  const mm_v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int sb = 0; sb < nsb; ++sb) {
+    // this lane's row: header + scales, its 16 bytes of each 64-value chunk (and the fifth bits)
+    const uint8_t *b = wrow + (int64_t)sb * TS;
+    const int4 h = ld16_a16(b);
+    int4 q[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) q[c] = ld16_a16(b + QS + 32 * c + 16 * kh);
+    int4 q5 = make_int4(0, 0, 0, 0);
+    if constexpr (TYPE == T_Q5_K) q5 = ld16_a16(b + 16 + 16 * kh);
+    __syncthreads();  // the previous superblock's tile has been read by every wave
+    // stage the activation tile: thread = (k block tid / 128, column tid % 128) copies its 144-byte block (columns past the range re-read the last one)
+    {
+      const int kb = tid >> 7, cc = tid & (MM_COLS - 1);
+      const int64_t col = c0 + cc < col_high ? c0 + cc : col_high - 1;
+      const uint8_t *src = a.y + ((int64_t)(2 * sb + kb) * a.ncols_y + col) * MMQ_BLOCK_BYTES;
+      uint8_t *dstb = raw + (kb * MM_COLS + cc) * MMQ_BLOCK_BYTES;
+      const int4 v0 = ld16_a16(src);
+#pragma unroll
+      for (int pc = 1; pc < 9; ++pc) *(int4 *)(dstb + pc * 16) = ld16_a16(src + pc * 16);
+      *(int4 *)dstb = v0;
+      const int w4[4] = {v0.x, v0.y, v0.z, v0.w};  // the four half2 {d, s} of the block's 32-value groups
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float *o = hdr + ((kb * 4 + g) * MM_COLS + cc) * 2;
+        o[0] = half_bits_to_float((uint16_t)((unsigned)w4[g] & 0xffffu));
+        o[1] = half_bits_to_float((uint16_t)((unsigned)w4[g] >> 16));
+      }
+    }
+    __syncthreads();
+    const float d = half_bits_to_float((uint16_t)((unsigned)h.x & 0xffffu)), dmin = half_bits_to_float((uint16_t)((unsigned)h.x >> 16));
+    const unsigned sw[3] = {(unsigned)h.y, (unsigned)h.z, (unsigned)h.w};
+    auto sbyte = [&](int i) { return (sw[i >> 2] >> (8 * (i & 3))) & 0xffu; };
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      unsigned sc, mn;  // get_scale_min_k4
+      if (j < 4) { sc = sbyte(j) & 63u; mn = sbyte(j + 4) & 63u; }
+      else { sc = (sbyte(j + 4) & 15u) | ((sbyte(j - 4) >> 6) << 4); mn = (sbyte(j + 4) >> 4) | ((sbyte(j) >> 6) << 4); }
+      const float dsc = d * (float)sc, ndm = -(dmin * (float)mn);
+      __builtin_amdgcn_sched_barrier(0);  // keep the eight sub-blocks apart: hoisting their LDS reads / MFMAs over each other costs 450 VGPRs
+      const int c = j >> 1, hi = j & 1;
+      const int qq[4] = {q[c].x, q[c].y, q[c].z, q[c].w}, q5w[4] = {q5.x, q5.y, q5.z, q5.w};
+      mm_v4i bf;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        unsigned v = ((unsigned)qq[e] >> (4 * hi)) & 0x0f0f0f0fu;
+        if constexpr (TYPE == T_Q5_K) v |= (((unsigned)q5w[e] >> j) & 0x01010101u) << 4;
+        bf[e] = (int)v;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (t) __builtin_amdgcn_sched_barrier(0);
+        const mm_v4i af = *(const mm_v4i *)(raw + ((j >> 2) * MM_COLS + 32 * t + (lane & 31)) * MMQ_BLOCK_BYTES + 16 + 32 * (j & 3) + 16 * kh);
+        const mm_v16i is = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf, zero, 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 h0 = *(const float4 *)(hdr + (j * MM_COLS + 32 * t + 8 * g + 4 * kh) * 2);
+          const float4 h1 = *(const float4 *)(hdr + (j * MM_COLS + 32 * t + 8 * g + 4 * kh + 2) * 2);
+          acc[t][4 * g + 0] = fmaf(ndm, h0.y, fmaf((float)is[4 * g + 0], dsc * h0.x, acc[t][4 * g + 0]));
+          acc[t][4 * g + 1] = fmaf(ndm, h0.w, fmaf((float)is[4 * g + 1], dsc * h0.z, acc[t][4 * g + 1]));
+          acc[t][4 * g + 2] = fmaf(ndm, h1.y, fmaf((float)is[4 * g + 2], dsc * h1.x, acc[t][4 * g + 2]));
+          acc[t][4 * g + 3] = fmaf(ndm, h1.w, fmaf((float)is[4 * g + 3], dsc * h1.z, acc[t][4 * g + 3]));
+        }
+      }
+    }
+  }
+  if (row >= a.nrows_x) return;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int64_t col = c0 + 32 * t + 8 * (i >> 2) + 4 * kh + (i & 3);
+      if (col < col_high) {
+        const int64_t dcol = a.ids_dst ? a.ids_dst[col] : col;
+        ((OUT *)a.dst)[dcol * a.nrows_dst + row] = from_f<OUT>(acc[t][i]);
+      }
+    }
+}
+
+template <int TYPE> constexpr bool mmq_has_mfma() { return TYPE == T_Q4_K || TYPE == T_Q5_K; }
+// prompt-sized launches of the two DS4 K-quants go to the matrix cores (MRS_MMQ_MFMA=0: keep the v_dot4 kernel, for A/B measurements)
+static bool mmq_mfma_wanted() {
+  static const bool on = [] { const char *e = getenv("MRS_MMQ_MFMA"); return !e || atoi(e) != 0; }();
+  return on;
+}
+
 template <int TYPE, class OUT> static void launch_mmq_t(const MmqArgs &a, int64_t channels, int64_t ncols_max, void *stream) {
   constexpr int NC = 8;
   if (a.nrows_x <= 0 || ncols_max <= 0 || channels <= 0) return;
+  if constexpr (mmq_has_mfma<TYPE>()) {
+    if (mmq_mfma_wanted() && ncols_max >= 48 && a.nrows_x >= 32 && a.ncols_x % 256 == 0) {
+      const dim3 grid((unsigned)((a.nrows_x + MM_ROWS - 1) / MM_ROWS), (unsigned)((ncols_max + MM_COLS - 1) / MM_COLS), (unsigned)channels);
+      hipLaunchKernelGGL((mmq_mfma_kernel<TYPE, OUT>), grid, dim3(256), 0, (hipStream_t)stream, a);
+      return;
+    }
+  }
   const unsigned gy = (unsigned)((ncols_max + NC - 1) / NC), gz = (unsigned)channels;
   // 4 rows per wave once that still leaves >= 2 workgroups per CU (256 CUs); small launches keep one row per wave to fill the chip
   if (((a.nrows_x + 15) / 16) * (int64_t)gy * gz >= 512) {

@@ -48,6 +48,8 @@ class GgufMatMul:
         if prompt_route not in ("auto", "gemm", "mmq"):
             raise ValueError("GgufMatMul: prompt_route must be auto, gemm or mmq")
         self.w, self.b, self.prompt_route = q_weight, b, prompt_route
+        from ..imatrix import ImatrixLayerStats
+        self.stats = ImatrixLayerStats.empty()  # gguf/mod.rs:47: interior-mutable, shared by clones of the layer
 
     # ---- trait surface (lib.rs:1515-1688)
     def get_qtensor(self) -> QTensor:
@@ -90,6 +92,7 @@ class GgufMatMul:
         return None
 
     def forward_raw(self, a: torch.Tensor) -> torch.Tensor:
+        self.stats.process(a)  # gguf/mod.rs:441: free when no collection is running
         out = self.try_fast_forward(a)
         if out is None:
             raise ValueError(f"GgufMatMul: no GPU route for {self.w.dtype.name} weights with {a.dtype} activations of shape {tuple(a.shape)}")
@@ -125,6 +128,29 @@ class GgufMatMul:
         if target is None or target == self.w.dtype:
             return self
         return GgufMatMul(isq.quantize(self.dequantize_w(torch.float32), target), self.b, self.prompt_route)
+
+    # ---- imatrix collection (gguf/mod.rs:710-739)
+    def begin_track_stats(self) -> None:
+        dims = self.w.shape
+        dev = self.w.data.device
+        if len(dims) == 3:  # stacked [E, out, in] expert weights collect per expert through the routed path
+            self.stats.enable_routed(dims[0], dims[2], dev)
+        else:
+            self.stats.enable(dims[-1], dev)
+
+    def process_routed_stats(self, x: torch.Tensor, ids: torch.Tensor) -> None:
+        self.stats.process_routed(x, ids)
+
+    def stats_snapshot(self):
+        return self.stats.snapshot()
+
+    def end_track_stats(self) -> torch.Tensor:
+        if not self.stats.is_enabled():
+            raise ValueError("`gguf` is not tracking stats.")
+        try:
+            return self.stats.compute_imatrix()
+        finally:
+            self.stats.clear()
 
     # ---- UQFF (gguf/mod.rs:260-280,755-793)
     def serialize_uqff(self, prefix: str) -> dict:

@@ -438,6 +438,190 @@ static void quantize_q6_K(const float *x, uint8_t *y, int64_t k) {
   }
 }
 
+/* ---- importance-weighted K-quant quantizers: public GGML `quantize_row_q{4,5,6}_K_impl` with quant_weights (what candle's
+ * QTensor::quantize_imatrix runs for these formats; candle is a git dependency that is not in the tree: "parity unpinned").  Call sites in the
+ * reference: mistralrs-quant/src/gguf/mod.rs:238-252 (expert stacks), utils/isq.rs generate_isq_imatrix!.  qw has one entry per input column
+ * (k of them), shared by every row. */
+static float make_qp_quants(int n, int nmax, const float *x, uint8_t *L, const float *qw) {
+  float max = 0;
+  for (int i = 0; i < n; ++i) if (x[i] > max) max = x[i];
+  if (!max) { for (int i = 0; i < n; ++i) L[i] = 0; return 0.f; }
+  float iscale = nmax / max;
+  for (int i = 0; i < n; ++i) L[i] = (uint8_t)nearest_int(iscale * x[i]);
+  float scale = 1 / iscale, best_mse = 0;
+  for (int i = 0; i < n; ++i) { float diff = x[i] - scale * L[i]; best_mse += qw[i] * diff * diff; }
+  for (int is = -4; is <= 4; ++is) {
+    if (is == 0) continue;
+    float iscale_is = (0.1f * is + nmax) / max, scale_is = 1 / iscale_is, mse = 0;
+    for (int i = 0; i < n; ++i) {
+      int l = imin(nmax, nearest_int(iscale_is * x[i]));
+      float diff = x[i] - scale_is * l;
+      mse += qw[i] * diff * diff;
+    }
+    if (mse < best_mse) { best_mse = mse; iscale = iscale_is; }
+  }
+  float sumlx = 0, suml2 = 0;
+  for (int i = 0; i < n; ++i) {
+    int l = imin(nmax, nearest_int(iscale * x[i]));
+    L[i] = (uint8_t)l;
+    sumlx += qw[i] * x[i] * l; suml2 += qw[i] * l * l;
+  }
+  for (int itry = 0; itry < 5; ++itry) {
+    int n_changed = 0;
+    for (int i = 0; i < n; ++i) {
+      float w = qw[i], slx = sumlx - w * x[i] * L[i], sl2 = suml2 - w * L[i] * L[i];
+      if (slx > 0 && sl2 > 0) {
+        int new_l = imin(nmax, nearest_int(x[i] * sl2 / slx));
+        if (new_l != L[i]) {
+          slx += w * x[i] * new_l; sl2 += w * new_l * new_l;
+          if (slx * slx * suml2 > sumlx * sumlx * sl2) { L[i] = (uint8_t)new_l; sumlx = slx; suml2 = sl2; ++n_changed; }
+        }
+      }
+    }
+    if (!n_changed) break;
+  }
+  return sumlx / suml2;
+}
+
+static void quantize_q4_5_K_imatrix(int type, const float *x, uint8_t *y, int64_t k, const float *qw_row) {
+  const int five = type == ORC_Q5_K;
+  const int nmax = five ? 31 : 15;
+  const int ts = orc_type_size(type);
+  uint8_t L[QK_K], Laux[32], Ls[8], Lm[8];
+  float weights[32], mins[8], scales[8], sw[8];
+  for (int64_t i = 0; i < k / QK_K; ++i, x += QK_K, y += ts) {
+    float sum_x2 = 0;
+    for (int l = 0; l < QK_K; ++l) sum_x2 += x[l] * x[l];
+    const float sigma2 = 2 * sum_x2 / QK_K;
+    for (int j = 0; j < 8; ++j) {
+      const float *qw = qw_row + QK_K * i + 32 * j;
+      for (int l = 0; l < 32; ++l) weights[l] = qw[l] * sqrtf(sigma2 + x[32 * j + l] * x[32 * j + l]);
+      float sumw = 0;
+      for (int l = 0; l < 32; ++l) sumw += weights[l];
+      sw[j] = sumw;
+      scales[j] = make_qkx2_quants(32, nmax, x + 32 * j, weights, L + 32 * j, &mins[j], Laux, -0.9f, 0.05f, 36, 0); /* make_qkx3_quants with weights given */
+    }
+    const float d_block = make_qp_quants(8, 63, scales, Ls, sw), m_block = make_qp_quants(8, 63, mins, Lm, sw);
+    uint8_t *sc12 = y + 4;
+    memset(sc12, 0, 12);
+    for (int j = 0; j < 8; ++j) {
+      uint8_t ls = Ls[j], lm = Lm[j];
+      if (j < 4) { sc12[j] = ls; sc12[j + 4] = lm; }
+      else {
+        sc12[j + 4] = (uint8_t)((ls & 0xF) | ((lm & 0xF) << 4));
+        sc12[j - 4] |= (uint8_t)((ls >> 4) << 6);
+        sc12[j] |= (uint8_t)((lm >> 4) << 6);
+      }
+    }
+    st16(y, orc_fp32_to_fp16(d_block));
+    st16(y + 2, orc_fp32_to_fp16(m_block));
+    float dd = orc_fp16_to_fp32(ld16(y)), dmin = orc_fp16_to_fp32(ld16(y + 2));
+    for (int j = 0; j < 8; ++j) {
+      uint8_t sc, m; k4_scale_min(j, sc12, &sc, &m);
+      float d = dd * sc;
+      if (!d) { for (int ii = 0; ii < 32; ++ii) L[32 * j + ii] = 0; continue; }
+      float dm = dmin * m;
+      for (int ii = 0; ii < 32; ++ii) {
+        int l = nearest_int((x[32 * j + ii] + dm) / d);
+        L[32 * j + ii] = (uint8_t)imax(0, imin(nmax, l));
+      }
+    }
+    if (!five) {
+      uint8_t *q = y + 16;
+      for (int j = 0; j < QK_K; j += 64, q += 32)
+        for (int l = 0; l < 32; ++l) q[l] = (uint8_t)(L[j + l] | (L[j + l + 32] << 4));
+    } else {
+      uint8_t *qh = y + 16, *ql = y + 48;
+      memset(qh, 0, 32);
+      uint8_t m1 = 1, m2 = 2;
+      for (int n = 0; n < QK_K; n += 64, ql += 32, m1 <<= 2, m2 <<= 2)
+        for (int j = 0; j < 32; ++j) {
+          int l1 = L[n + j], l2 = L[n + j + 32];
+          if (l1 > 15) { l1 -= 16; qh[j] |= m1; }
+          if (l2 > 15) { l2 -= 16; qh[j] |= m2; }
+          ql[j] = (uint8_t)(l1 | (l2 << 4));
+        }
+    }
+  }
+}
+
+static float make_qx_quants_w(int n, int nmax, const float *x, int8_t *L, const float *qw) { /* rmse_type 1 with the weights given */
+  float max = 0, amax = 0;
+  for (int i = 0; i < n; ++i) { float ax = fabsf(x[i]); if (ax > amax) { amax = ax; max = x[i]; } }
+  if (amax < 1e-15f) { for (int i = 0; i < n; ++i) L[i] = 0; return 0.f; }
+  float iscale = -nmax / max, sumlx = 0, suml2 = 0;
+  for (int i = 0; i < n; ++i) {
+    int l = nearest_int(iscale * x[i]);
+    l = imax(-nmax, imin(nmax - 1, l));
+    L[i] = (int8_t)(l + nmax);
+    sumlx += qw[i] * x[i] * l; suml2 += qw[i] * l * l;
+  }
+  float scale = suml2 ? sumlx / suml2 : 0.0f;
+  float best = scale * sumlx;
+  for (int is = -9; is <= 9; ++is) {
+    if (is == 0) continue;
+    iscale = -(nmax + 0.1f * is) / max;
+    sumlx = suml2 = 0;
+    for (int i = 0; i < n; ++i) {
+      int l = nearest_int(iscale * x[i]);
+      l = imax(-nmax, imin(nmax - 1, l));
+      sumlx += qw[i] * x[i] * l; suml2 += qw[i] * l * l;
+    }
+    if (suml2 > 0 && sumlx * sumlx > best * suml2) {
+      for (int i = 0; i < n; ++i) {
+        int l = nearest_int(iscale * x[i]);
+        L[i] = (int8_t)(nmax + imax(-nmax, imin(nmax - 1, l)));
+      }
+      scale = sumlx / suml2; best = scale * sumlx;
+    }
+  }
+  return scale;
+}
+
+static void quantize_q6_K_imatrix(const float *x, uint8_t *y, int64_t k, const float *qw_row) {
+  int8_t L[QK_K];
+  float scales[16];
+  for (int64_t i = 0; i < k / QK_K; ++i, x += QK_K, y += 210) {
+    float max_scale = 0, max_abs = 0;
+    for (int ib = 0; ib < 16; ++ib) {
+      float s = make_qx_quants_w(16, 32, x + 16 * ib, L + 16 * ib, qw_row + QK_K * i + 16 * ib); /* the importance values themselves are the weights */
+      scales[ib] = s;
+      if (fabsf(s) > max_abs) { max_abs = fabsf(s); max_scale = s; }
+    }
+    if (max_abs < 1e-15f) { memset(y, 0, 210); continue; }
+    float iscale = -128.f / max_scale;
+    st16(y + 208, orc_fp32_to_fp16(1 / iscale));
+    int8_t *sc = (int8_t *)(y + 192);
+    for (int ib = 0; ib < 16; ++ib) sc[ib] = (int8_t)imin(127, nearest_int(iscale * scales[ib]));
+    float dall = orc_fp16_to_fp32(ld16(y + 208));
+    for (int j = 0; j < 16; ++j) {
+      float d = dall * sc[j];
+      if (!d) continue;
+      for (int ii = 0; ii < 16; ++ii) {
+        int l = nearest_int(x[16 * j + ii] / d);
+        L[16 * j + ii] = (int8_t)(imax(-32, imin(31, l)) + 32);
+      }
+    }
+    uint8_t *ql = y, *qh = y + 128;
+    for (int j = 0; j < QK_K; j += 128, ql += 64, qh += 32)
+      for (int l = 0; l < 32; ++l) {
+        uint8_t q1 = L[j + l] & 0xF, q2 = L[j + l + 32] & 0xF, q3 = L[j + l + 64] & 0xF, q4 = L[j + l + 96] & 0xF;
+        ql[l] = (uint8_t)(q1 | (q3 << 4));
+        ql[l + 32] = (uint8_t)(q2 | (q4 << 4));
+        qh[l] = (uint8_t)((L[j + l] >> 4) | ((L[j + l + 32] >> 4) << 2) | ((L[j + l + 64] >> 4) << 4) | ((L[j + l + 96] >> 4) << 6));
+      }
+  }
+}
+
+/* one row of k values with the importance vector qw[k]; 0 ok, -1 for a type without a weighted quantizer here */
+int orc_quantize_row_imatrix(int type, const float *x, void *blocks, int64_t k, const float *qw) {
+  switch (type) {
+  case ORC_Q4_K: case ORC_Q5_K: quantize_q4_5_K_imatrix(type, x, (uint8_t *)blocks, k, qw); return 0;
+  case ORC_Q6_K: quantize_q6_K_imatrix(x, (uint8_t *)blocks, k, qw); return 0;
+  default: return -1;
+  }
+}
+
 static void quantize_legacy(int type, const float *x, uint8_t *y, int64_t k) {
   const int ts = orc_type_size(type);
   for (int64_t i = 0; i < k / 32; ++i, x += 32, y += ts) {

@@ -42,6 +42,7 @@ uint16_t orc_fp32_to_bf16(float f);      /* round-to-nearest-even */
 /* weights: blocks <-> f32 */
 void orc_dequantize_row(int type, const void *blocks, float *out, int64_t k);
 int  orc_quantize_row(int type, const float *x, void *blocks, int64_t k); /* 0 ok, -1 unsupported */
+int  orc_quantize_row_imatrix(int type, const float *x, void *blocks, int64_t k, const float *qw); /* Q4_K / Q5_K / Q6_K with importance weights qw[k] (GGML quantize_row_*_impl) */
 /* fill n_blocks of `type` with random-but-valid block bytes (finite, sane scales) */
 void orc_random_blocks(int type, void *blocks, int64_t n_blocks, uint64_t seed, float d_scale);
 

@@ -215,6 +215,31 @@ static hiphost_f32x16 mfma_32x32x16_bf16(hiphost_bf16x8 a, hiphost_bf16x8 b, hip
 }
 }  // namespace hiphost
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, CBSZ, ABID, BLGP) hiphost::mfma_32x32x16_bf16((A), (B), (C))
+// v_mfma_i32_32x32x32_i8: D = A (32 x 32 int8) * B (32 x 32 int8) + C, exact in int32.  Lane l holds A[l % 32][16 * (l / 32) + j] and
+// B[16 * (l / 32) + j][l % 32] (j = 0..15, 16 consecutive bytes); C / D as every 32 x 32 MFMA (the layout of the accumulators is dtype-independent).
+// Which 16 k a lane half holds does not change the result as long as A and B agree -- they do by symmetry.
+typedef int hiphost_i32x4 __attribute__((ext_vector_type(4)));
+typedef int hiphost_i32x16 __attribute__((ext_vector_type(16)));
+namespace hiphost {
+inline int8_t mfma_a8[MAX_THREADS][16], mfma_b8[MAX_THREADS][16];
+static hiphost_i32x16 mfma_32x32x32_i8(hiphost_i32x4 a, hiphost_i32x4 b, hiphost_i32x16 c) {
+  const int tid = linear_tid(), w = tid / WAVE, lane = tid & (WAVE - 1), base = w * WAVE;
+  memcpy(mfma_a8[tid], &a, 16);
+  memcpy(mfma_b8[tid], &b, 16);
+  wave_barrier(w, 0);
+  const int col = lane & 31, hi = lane >> 5;
+  hiphost_i32x16 d = c;
+  for (int i = 0; i < 16; ++i) {
+    const int row = 8 * (i / 4) + 4 * hi + (i % 4);
+    int acc = 0;
+    for (int k = 0; k < 32; ++k) acc += (int)mfma_a8[base + row + 32 * (k / 16)][k % 16] * (int)mfma_b8[base + col + 32 * (k / 16)][k % 16];
+    d[i] = c[i] + acc;
+  }
+  wave_barrier(w, 0);
+  return d;
+}
+}  // namespace hiphost
+#define __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B, C, CBSZ, ABID, BLGP) hiphost::mfma_32x32x32_i8((A), (B), (C))
 // buffer resource: base + byte range; raw_buffer_load returns zeros out of range (as the hardware's bounds check does)
 struct __amdgpu_buffer_rsrc_t { const char *base; unsigned bytes; };
 static inline __amdgpu_buffer_rsrc_t hiphost_make_rsrc(void *p, int bytes) { return __amdgpu_buffer_rsrc_t{(const char *)p, (unsigned)bytes}; }

@@ -100,6 +100,21 @@ def quantize(t: int, w: np.ndarray) -> np.ndarray:
     return out
 
 
+def quantize_imatrix(t: int, w: np.ndarray, imatrix: np.ndarray) -> np.ndarray:
+    """w [N, K] f32 with the importance vector imatrix [K] (shared by every row) -> packed uint8 [N, row_bytes]: GGML's quantize_row_q{4,5,6}_K_impl
+    with quant_weights (what candle's QTensor::quantize_imatrix runs; call sites gguf/mod.rs:238-252)."""
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    qw = np.ascontiguousarray(imatrix, dtype=np.float32)
+    n, k = w.shape
+    if qw.shape != (k,):
+        raise ValueError("imatrix must have one entry per input column")
+    out = np.zeros((n, row_bytes(t, k)), dtype=np.uint8)
+    for r in range(n):
+        if lib().orc_quantize_row_imatrix(t, _p(w[r]), _p(out[r]), C.c_int64(k), _p(qw)) != 0:
+            raise ValueError(f"oracle has no importance-weighted quantizer for ggml type {t}")
+    return out
+
+
 def dequantize(t: int, blocks: np.ndarray, k: int) -> np.ndarray:
     blocks = np.ascontiguousarray(blocks, dtype=np.uint8)
     n = blocks.size // row_bytes(t, k)

@@ -196,6 +196,8 @@ def check_mmq_row_paths(oracle, be, t, n, k, cols):
     fn(None, W.ptr, Y.ptr, D7.ptr, k, 7, cols, k // oracle.block_size(t), 7, 0, 256, 160 << 10, 64, 0, be.stream)
     got = D.numpy().astype(np.float64)
     assert (np.abs(got - want) <= _tol(k, mag, want, "f32")).all()
+    if oracle.TYPE_NAMES[t] in ("q4_k", "q5_k") and cols >= 48:
+        return  # prompt-sized launches of the DS4 K-quants run on the matrix cores (mmq_mfma_kernel): same integers, another f32 summation order
     assert np.array_equal(D.numpy()[:, :7], D7.numpy())
 
 
@@ -211,7 +213,39 @@ def test_mmq_moe_host_emulation(oracle, tname):
     check_mmq_moe(oracle, HostBackend(), t, 6, 256, 4, [3, 0, 9, 1])
 
 
+MFMA_CASES = [("q4_k", "f32", 200, 512, 70), ("q5_k", "bf16", 33, 256, 130), ("q4_k", "f16", 129, 768, 48)]
+
+
+@pytest.mark.parametrize("tname,dt,n,k,cols", MFMA_CASES)
+def test_mmq_matrix_core_route_host_emulation(oracle, tname, dt, n, k, cols):
+    """launch_mmq_gguf_{q4_k,q5_k} with >= 48 columns and >= 32 rows: one v_mfma_i32_32x32x32_i8 per 32-value sub-block (csrc/mmq.hip mmq_mfma_kernel);
+    ragged row / column tiles; the same budget against the f64 oracle as the v_dot4 kernel."""
+    t = {v: k_ for k_, v in oracle.TYPE_NAMES.items()}[tname]
+    check_mmq(oracle, HostBackend(), t, dt, n, k, cols)
+
+
+@pytest.mark.parametrize("tname", ["q4_k", "q5_k"])
+def test_mmq_matrix_core_route_moe_host_emulation(oracle, tname):
+    t = {v: k for k, v in oracle.TYPE_NAMES.items()}[tname]
+    check_mmq_moe(oracle, HostBackend(), t, 40, 256, 3, [50, 0, 70])
+
+
 # ------------------------------------------------------------------------------------------------ MI355X
+@pytest.mark.gpu
+@pytest.mark.parametrize("tname,dt,n,k,cols", MFMA_CASES + [("q4_k", "f32", 1030, 4096, 512), ("q5_k", "f32", 4100, 1024, 257)])
+def test_mmq_matrix_core_route_gpu(oracle, dev, tname, dt, n, k, cols):
+    t = {v: k_ for k_, v in oracle.TYPE_NAMES.items()}[tname]
+    check_mmq(oracle, GpuBackend(dev), t, dt, n, k, cols)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tname", ["q4_k", "q5_k"])
+def test_mmq_matrix_core_route_moe_gpu(oracle, dev, tname):
+    t = {v: k for k, v in oracle.TYPE_NAMES.items()}[tname]
+    check_mmq_moe(oracle, GpuBackend(dev), t, 40, 256, 3, [50, 0, 70])
+    check_mmq_moe(oracle, GpuBackend(dev), t, 200, 1024, 8, [64, 100, 0, 2, 130, 8, 1, 300])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("layout,dt,rows,k,gather", HOST_Q + [(1, "bf16", 512, 4096, False), (0, "f16", 64, 14336, True)])
 def test_mmq_quantize_abi_gpu(oracle, dev, layout, dt, rows, k, gather):
