@@ -336,7 +336,102 @@ __global__ void __launch_bounds__(256, 2) mmq_mfma_kernel(MmqArgs a) {  // 2 wor
     }
 }
 
-template <int TYPE> constexpr bool mmq_has_mfma() { return TYPE == T_Q4_K || TYPE == T_Q5_K; }
+// Q6_K (D4 activations: one f32 scale per 32 values, no sums): the scales change every 16 values, so the unit is v_mfma_i32_32x32x16_i8 -- lane l
+// holds weight row l % 32 and the 8 values 8 (l / 32) + j of a 16-run; 6-bit values are re-centred to q - 32 (signed bytes), which removes the offset
+// term.  The run of index r = 8 h + 2 q + lh (half, quarter, 16-half) starts at element 128 h + 32 q + 16 lh of the superblock, its low bits are
+// nibble (q >> 1) of ql[64 h + 32 (q & 1) + 16 lh ..], its high bits the 2-bit field q of qh[32 h + 16 lh ..].  Twice the fix-ups per weight of
+// the Q4_K route (16 cvt + 8 pk_mul + 8 pk_fma per 16 k): about 0.6 x its rate.
+template <class OUT>
+__global__ void __launch_bounds__(256, 2) mmq_mfma_q6k_kernel(MmqArgs a) {
+  constexpr int TS = 210;
+  __shared__ __attribute__((aligned(16))) uint8_t raw[2 * MM_COLS * MMQ_BLOCK_BYTES];
+  __shared__ __attribute__((aligned(16))) float hdr[8 * MM_COLS];                       // [32-value group][column] d8
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 5;
+  const int64_t col_low = a.expert_bounds ? a.expert_bounds[blockIdx.z] : 0;
+  const int64_t col_high = a.expert_bounds ? a.expert_bounds[blockIdx.z + 1] : a.ncols_y;
+  const int64_t c0 = col_low + (int64_t)blockIdx.y * MM_COLS;
+  if (c0 >= col_high) return;
+  const int64_t row = (int64_t)blockIdx.x * MM_ROWS + wave * 32 + (lane & 31);
+  const int64_t rowc = row < a.nrows_x ? row : a.nrows_x - 1;
+  const uint8_t *wrow = a.x + ((int64_t)blockIdx.z * a.stride_channel_x + rowc * a.stride_row_x) * TS;
+  const int nsb = (int)(a.ncols_x / 256);
+  float acc[4][16];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+  const mm_v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int sb = 0; sb < nsb; ++sb) {
+    const uint8_t *b = wrow + (int64_t)sb * TS;
+    int2_a2 ql8[2][2][2], qh8[2][2];  // [h][q & 1][lh], [h][lh]: this lane's 8 bytes (2-byte aligned blocks)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int lh = 0; lh < 2; ++lh) {
+        qh8[h][lh] = *(const int2_a2 *)(b + 128 + 32 * h + 16 * lh + 8 * kh);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) ql8[h][p][lh] = *(const int2_a2 *)(b + 64 * h + 32 * p + 16 * lh + 8 * kh);
+      }
+    const int4 scw = ld16_a2(b + 192);
+    const float d = half_bits_to_float(ld2(b + 208));
+    __syncthreads();
+    {
+      const int kb = tid >> 7, cc = tid & (MM_COLS - 1);
+      const int64_t col = c0 + cc < col_high ? c0 + cc : col_high - 1;
+      const uint8_t *src = a.y + ((int64_t)(2 * sb + kb) * a.ncols_y + col) * MMQ_BLOCK_BYTES;
+      uint8_t *dstb = raw + (kb * MM_COLS + cc) * MMQ_BLOCK_BYTES;
+      const int4 v0 = ld16_a16(src);
+#pragma unroll
+      for (int pc = 1; pc < 9; ++pc) *(int4 *)(dstb + pc * 16) = ld16_a16(src + pc * 16);
+      const int w4[4] = {v0.x, v0.y, v0.z, v0.w};  // D4: four f32 scales
+#pragma unroll
+      for (int g = 0; g < 4; ++g) hdr[(kb * 4 + g) * MM_COLS + cc] = __int_as_float(w4[g]);
+    }
+    __syncthreads();
+    const int sc4[4] = {scw.x, scw.y, scw.z, scw.w};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      __builtin_amdgcn_sched_barrier(0);
+      const int h = r >> 3, q = (r >> 1) & 3, lh = r & 1;
+      const float dsc = d * (float)(int)(int8_t)(((unsigned)sc4[r >> 2] >> (8 * (r & 3))) & 0xffu);
+      const int lw[2] = {ql8[h][q & 1][lh].x, ql8[h][q & 1][lh].y}, hw[2] = {qh8[h][lh].x, qh8[h][lh].y};
+      unsigned bw[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const unsigned v = (((unsigned)lw[e] >> (4 * (q >> 1))) & 0x0f0f0f0fu) | ((((unsigned)hw[e] >> (2 * q)) & 0x03030303u) << 4);
+        bw[e] = ((v | 0x80808080u) - 0x20202020u) ^ 0x80808080u;  // per byte q - 32, no borrow across bytes
+      }
+      const long bf = (long)(((unsigned long long)bw[1] << 32) | bw[0]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (t) __builtin_amdgcn_sched_barrier(0);
+        const long af = *(const long *)(raw + ((r >> 3) * MM_COLS + 32 * t + (lane & 31)) * MMQ_BLOCK_BYTES + 16 + 16 * (r & 7) + 8 * kh);
+        const mm_v16i is = __builtin_amdgcn_mfma_i32_32x32x16_i8(af, bf, zero, 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 h0 = *(const float4 *)(hdr + (r >> 1) * MM_COLS + 32 * t + 8 * g + 4 * kh);
+          acc[t][4 * g + 0] = fmaf((float)is[4 * g + 0], dsc * h0.x, acc[t][4 * g + 0]);
+          acc[t][4 * g + 1] = fmaf((float)is[4 * g + 1], dsc * h0.y, acc[t][4 * g + 1]);
+          acc[t][4 * g + 2] = fmaf((float)is[4 * g + 2], dsc * h0.z, acc[t][4 * g + 2]);
+          acc[t][4 * g + 3] = fmaf((float)is[4 * g + 3], dsc * h0.w, acc[t][4 * g + 3]);
+        }
+      }
+    }
+  }
+  if (row >= a.nrows_x) return;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int64_t col = c0 + 32 * t + 8 * (i >> 2) + 4 * kh + (i & 3);
+      if (col < col_high) {
+        const int64_t dcol = a.ids_dst ? a.ids_dst[col] : col;
+        ((OUT *)a.dst)[dcol * a.nrows_dst + row] = from_f<OUT>(acc[t][i]);
+      }
+    }
+}
+
+template <int TYPE> constexpr bool mmq_has_mfma() { return TYPE == T_Q4_K || TYPE == T_Q5_K || TYPE == T_Q6_K; }
 // prompt-sized launches of the two DS4 K-quants go to the matrix cores (MRS_MMQ_MFMA=0: keep the v_dot4 kernel, for A/B measurements)
 static bool mmq_mfma_wanted() {
   static const bool on = [] { const char *e = getenv("MRS_MMQ_MFMA"); return !e || atoi(e) != 0; }();
@@ -349,7 +444,8 @@ template <int TYPE, class OUT> static void launch_mmq_t(const MmqArgs &a, int64_
   if constexpr (mmq_has_mfma<TYPE>()) {
     if (mmq_mfma_wanted() && ncols_max >= 48 && a.nrows_x >= 32 && a.ncols_x % 256 == 0) {
       const dim3 grid((unsigned)((a.nrows_x + MM_ROWS - 1) / MM_ROWS), (unsigned)((ncols_max + MM_COLS - 1) / MM_COLS), (unsigned)channels);
-      hipLaunchKernelGGL((mmq_mfma_kernel<TYPE, OUT>), grid, dim3(256), 0, (hipStream_t)stream, a);
+      if constexpr (TYPE == T_Q6_K) hipLaunchKernelGGL((mmq_mfma_q6k_kernel<OUT>), grid, dim3(256), 0, (hipStream_t)stream, a);
+      else hipLaunchKernelGGL((mmq_mfma_kernel<TYPE, OUT>), grid, dim3(256), 0, (hipStream_t)stream, a);
       return;
     }
   }

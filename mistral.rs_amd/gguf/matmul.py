@@ -43,8 +43,8 @@ class GgufMatMul:
     """Weight-owning quantized linear op; immutable after construction (objects are shared like `Arc<dyn QuantMethod>`)."""
 
     def __init__(self, q_weight: QTensor, b: torch.Tensor | None = None, prompt_route: str = "auto"):
-        if len(q_weight.shape) != 2:
-            raise ValueError("GgufMatMul: weight must be [N, K]")
+        if len(q_weight.shape) not in (2, 3):
+            raise ValueError("GgufMatMul: weight must be [N, K] (or a stacked [E, N, K] expert tensor: ISQ / statistics only)")
         if prompt_route not in ("auto", "gemm", "mmq"):
             raise ValueError("GgufMatMul: prompt_route must be auto, gemm or mmq")
         self.w, self.b, self.prompt_route = q_weight, b, prompt_route
@@ -73,7 +73,7 @@ class GgufMatMul:
 
     def try_fast_forward(self, a: torch.Tensor):
         """gguf/mod.rs:298-323: None when no fast route applies."""
-        if not fast_mmvq.supports(self.w.dtype) or a.dtype not in _OUT:
+        if not fast_mmvq.supports(self.w.dtype) or a.dtype not in _OUT or len(self.w.shape) != 2:
             return None
         k = a.shape[-1]
         flat = a.numel() // k if k else 0
@@ -121,13 +121,23 @@ class GgufMatMul:
         from .. import isq
         return None if dtype is None else isq.get_quantization_behaviour(self.w.shape, dtype)
 
-    def apply_isq(self, dtype: GgmlDType | None) -> "GgufMatMul":
-        """Re-quantize to `dtype` (with the reference's fallback chain); None keeps the layer.  Dequantize -> quantize on the device."""
+    def apply_isq(self, dtype: GgmlDType | None, imatrix_weight=None) -> "GgufMatMul":
+        """Re-quantize to `dtype` (with the reference's fallback chain); None keeps the layer.  Dequantize -> quantize on the device.  With an
+        importance vector (gguf/mod.rs:633-700: `imatrix_weight`) the layer is always re-quantized, through the weighted quantizer when the target
+        has one; a stacked [E, out, in] weight goes slab by slab (`quantize_expert_stack`)."""
         from .. import isq
-        target = self.plan_isq(dtype)
-        if target is None or target == self.w.dtype:
+        if dtype is None:
             return self
-        return GgufMatMul(isq.quantize(self.dequantize_w(torch.float32), target), self.b, self.prompt_route)
+        if len(self.w.shape) == 3:
+            out = isq.quantize_expert_stack(self.dequantize_w(torch.float32), dtype, imatrix_weight)
+            return GgufMatMul(out, self.b, self.prompt_route)
+        target = self.plan_isq(dtype)
+        if target is None or (target == self.w.dtype and imatrix_weight is None):
+            return self
+        dense = self.dequantize_w(torch.float32)
+        if imatrix_weight is not None and isq.imatrix_capable(target):
+            return GgufMatMul(isq.quantize_imatrix(dense, imatrix_weight, target), self.b, self.prompt_route)
+        return GgufMatMul(isq.quantize(dense, target), self.b, self.prompt_route)
 
     # ---- imatrix collection (gguf/mod.rs:710-739)
     def begin_track_stats(self) -> None:

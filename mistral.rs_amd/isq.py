@@ -69,3 +69,64 @@ def quantize(w: torch.Tensor, dtype: GgmlDType) -> QTensor:
     if fn(w.data_ptr(), _SRC[w.dtype], out.data_ptr(), n * k, dtype.id, torch.cuda.current_stream().cuda_stream) != 0:
         raise ValueError("isq: quantizer refused the tensor")
     return QTensor(dtype, (n, k), out)
+
+
+
+def imatrix_capable(dtype: GgmlDType) -> bool:
+    """gguf/mod.rs:221-224: the K-quants take an importance vector; of those, Q4_K / Q5_K / Q6_K have a device quantizer here."""
+    return dtype in (GgmlDType.Q4K, GgmlDType.Q5K, GgmlDType.Q6K)
+
+
+def quantize_imatrix(w: torch.Tensor, imatrix, dtype: GgmlDType) -> QTensor:
+    """`QTensor::quantize_imatrix`: w dense [N, K] on the GPU, imatrix one f32 per input column (`ImatrixLayerStats.compute_imatrix`, or a vector
+    of a `.cimatrix` file).  Raises ValueError for targets without a weighted quantizer (callers fall back to `quantize`, as
+    `quantize_expert_stack` does, gguf/mod.rs:247-252)."""
+    if w.dim() != 2 or not w.is_cuda:
+        raise ValueError("isq: expected a 2-D GPU weight")
+    if w.dtype not in _SRC:
+        raise ValueError(f"isq: unsupported source dtype {w.dtype}")
+    if not imatrix_capable(dtype):
+        raise ValueError(f"isq: {dtype.name} has no importance-weighted device quantizer")
+    n, k = w.shape
+    if k % dtype.block_size:
+        raise ValueError(f"isq: last dimension {k} is not a multiple of the {dtype.name} block size {dtype.block_size}")
+    im = torch.as_tensor(imatrix, dtype=torch.float32).to(w.device).contiguous().reshape(-1)
+    if im.numel() != k:
+        raise ValueError(f"isq: imatrix has {im.numel()} entries, the weight {k} input columns")
+    w = w.contiguous()
+    out = torch.empty(n * (k // dtype.block_size) * dtype.type_size, dtype=torch.uint8, device=w.device)
+    _lib.load("quant"); _lib.load("paged_attn"); _lib.load("core")
+    fn = _lib.sym("ext", "mrs_isq_quantize_imatrix", [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p], C.c_int)
+    if fn(w.data_ptr(), _SRC[w.dtype], out.data_ptr(), n, k, dtype.id, im.data_ptr(), torch.cuda.current_stream().cuda_stream) != 0:
+        raise ValueError("isq: the weighted quantizer refused the tensor")
+    return QTensor(dtype, (n, k), out)
+
+
+def quantize_expert_stack(stack: torch.Tensor, dtype: GgmlDType, imatrix=None) -> QTensor:
+    """`GgufMatMul::quantize_expert_stack` (gguf/mod.rs:200-262): a stacked [E, out, in] expert tensor is quantized slab by slab -- row-block
+    formats never cross expert boundaries, so the byte concatenation equals quantizing the whole stack.  `imatrix` is [in] (shared) or [E * in]
+    (per expert, flattened); any other length is ignored with a warning; an all-zero vector (an expert that saw no traffic) and targets without
+    a weighted quantizer fall back to the plain quantizer."""
+    import warnings
+    if stack.dim() != 3 or not stack.is_cuda:
+        raise ValueError("isq: expected a stacked [E, out, in] GPU tensor")
+    e_n, out_dim, in_dim = stack.shape
+    target = get_quantization_behaviour((out_dim, in_dim), dtype)
+    if target is None:
+        raise ValueError("isq: the expert slabs are not quantizable (the reference keeps them dense: F32)")
+    im = None
+    if imatrix is not None:
+        im = torch.as_tensor(imatrix, dtype=torch.float32).reshape(-1)
+        if im.numel() not in (in_dim, e_n * in_dim):
+            warnings.warn(f"Expert stack imatrix length {im.numel()} matches neither in_dim {in_dim} nor {e_n}x{in_dim}; quantizing without it.")
+            im = None
+    parts = []
+    for e in range(e_n):
+        v = None
+        if im is not None:
+            v = im if im.numel() == in_dim else im[e * in_dim:(e + 1) * in_dim]
+        if v is not None and imatrix_capable(target) and bool((v != 0).any()):
+            parts.append(quantize_imatrix(stack[e], v, target).data)
+        else:
+            parts.append(quantize(stack[e], target).data)
+    return QTensor(target, (e_n, out_dim, in_dim), torch.cat(parts))

@@ -240,6 +240,26 @@ static hiphost_i32x16 mfma_32x32x32_i8(hiphost_i32x4 a, hiphost_i32x4 b, hiphost
 }
 }  // namespace hiphost
 #define __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B, C, CBSZ, ABID, BLGP) hiphost::mfma_32x32x32_i8((A), (B), (C))
+// v_mfma_i32_32x32x16_i8 (the CDNA3 form, kept on gfx950): 8 bytes per lane, k = 8 * (l / 32) + j
+namespace hiphost {
+static hiphost_i32x16 mfma_32x32x16_i8(long a, long b, hiphost_i32x16 c) {
+  const int tid = linear_tid(), w = tid / WAVE, lane = tid & (WAVE - 1), base = w * WAVE;
+  memcpy(mfma_a8[tid], &a, 8);
+  memcpy(mfma_b8[tid], &b, 8);
+  wave_barrier(w, 0);
+  const int col = lane & 31, hi = lane >> 5;
+  hiphost_i32x16 d = c;
+  for (int i = 0; i < 16; ++i) {
+    const int row = 8 * (i / 4) + 4 * hi + (i % 4);
+    int acc = 0;
+    for (int k = 0; k < 16; ++k) acc += (int)mfma_a8[base + row + 32 * (k / 8)][k % 8] * (int)mfma_b8[base + col + 32 * (k / 8)][k % 8];
+    d[i] = c[i] + acc;
+  }
+  wave_barrier(w, 0);
+  return d;
+}
+}  // namespace hiphost
+#define __builtin_amdgcn_mfma_i32_32x32x16_i8(A, B, C, CBSZ, ABID, BLGP) hiphost::mfma_32x32x16_i8((A), (B), (C))
 // buffer resource: base + byte range; raw_buffer_load returns zeros out of range (as the hardware's bounds check does)
 struct __amdgpu_buffer_rsrc_t { const char *base; unsigned bytes; };
 static inline __amdgpu_buffer_rsrc_t hiphost_make_rsrc(void *p, int bytes) { return __amdgpu_buffer_rsrc_t{(const char *)p, (unsigned)bytes}; }

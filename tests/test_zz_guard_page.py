@@ -20,7 +20,7 @@ be = HostBackend()
 libc = C.CDLL(None, use_errno=True)
 libc.mprotect.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
 n, K, sym = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
-t = O.Q6_K if sym in ("norm_proj", "gemm_q6", "gemm2_q6") else O.Q4_K
+t = O.Q6_K if sym in ("norm_proj", "gemm_q6", "gemm2_q6", "mmq_mfma_q6") else O.Q4_K
 w = O.random_blocks(t, n, K if sym != "hqq" else 256, seed=1, d_scale=0.02).reshape(-1)
 page = mmap.PAGESIZE
 keep = []
@@ -83,15 +83,16 @@ elif sym in ("gemm2", "gemm2_q6"):
     got = out.numpy()
     assert np.isfinite(got).all() and np.abs(got - want).max() <= 1e-3 * np.abs(want).max()
     print("guard page intact"); sys.exit(0)
-elif sym == "mmq":
-    # prompt-sized drop-in launcher (launch_mmq_gguf_q4_k): weights and the block_q8_1_mmq activations end at guard pages
-    cols = 37
+elif sym in ("mmq", "mmq_mfma", "mmq_mfma_q6"):
+    # prompt-sized drop-in launcher (launch_mmq_gguf_q4_k / q6_k): weights and the block_q8_1_mmq activations end at guard pages; >= 48 columns take the
+    # matrix-core kernels (ragged 128 x 128 tiles: surplus rows / columns re-read the last one)
+    cols = 37 if sym == "mmq" else 50
     xm = np.random.default_rng(2).standard_normal((cols, K)).astype(np.float32)
     y = O.quantize_q8_1_mmq(xm, O.mmq_layout(t))
     yp = guarded(y)
     D = be.buf(np.full((cols, n), 7.0, np.float32))
     P, L, I = C.c_void_p, C.c_int64, C.c_int
-    fn = be.sym("launch_mmq_gguf_q4_k", [P, P, P, P] + [L] * 5 + [I, I, L, I, I, P])
+    fn = be.sym("launch_mmq_gguf_q6_k" if sym == "mmq_mfma_q6" else "launch_mmq_gguf_q4_k", [P, P, P, P] + [L] * 5 + [I, I, L, I, I, P])
     fn(None, dst, yp, D.ptr, K, n, cols, K // 256, n, 0, 256, 160 << 10, 64, 0, be.stream)
     want, mag = O.matmul_q8_1_mmq(t, w.reshape(n, -1), n, K, y)
     got = D.numpy().astype(np.float64)
@@ -207,7 +208,7 @@ print("guard page intact")
 @pytest.mark.parametrize("n,k,sym,env", [(600, 512, "norm_proj", {"MRS_PROJ_WGS": "2"}), (129, 1024, "mmvq", {}), (2049, 256, "mmvq", {}),
                                          (200, 512, "gemm", {"MRS_GEMM_VARIANT": "1"}), (200, 512, "gemm", {"MRS_GEMM_VARIANT": "0"}), (130, 256, "gemm_q6", {}), (200, 512, "gemm2", {}), (130, 256, "gemm2_q6", {}),
                                          (70, 512, "dec_proj", {}), (2049, 256, "dec_proj", {}),
-                                         (70, 512, "mmq", {}), (129, 256, "mmq", {}), (50, 512, "imoe", {}), (128, 256, "hqq", {}), (64, 2064, "hqq", {}),
+                                         (70, 512, "mmq", {}), (129, 256, "mmq", {}), (70, 512, "mmq_mfma", {}), (129, 256, "mmq_mfma", {}), (70, 512, "mmq_mfma_q6", {}), (50, 512, "imoe", {}), (128, 256, "hqq", {}), (64, 2064, "hqq", {}),
                                          (96, 256, "attn", {}), (33, 256, "attn", {}), (70, 256, "prefill_attn", {}), (33, 256, "prefill_attn", {})])
 def test_row_less_waves_do_not_read_past_the_tensor(n, k, sym, env):
     r = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT}, str(n), str(k), sym], capture_output=True, text=True, timeout=600,
