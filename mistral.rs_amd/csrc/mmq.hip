@@ -431,7 +431,134 @@ __global__ void __launch_bounds__(256, 2) mmq_mfma_q6k_kernel(MmqArgs a) {
     }
 }
 
-template <int TYPE> constexpr bool mmq_has_mfma() { return TYPE == T_Q4_K || TYPE == T_Q5_K || TYPE == T_Q6_K; }
+// The 32-value block formats (Q8_0, Q4_0, Q4_1, Q5_0, Q5_1): one MFMA per weight block; the loop runs over 128-value k blocks (one activation
+// block per column: 18 KiB of LDS per stage).  w = s q - o per block (gguf_blocks.cuh load_slice): s = d; o = 8 d / -m / 16 d / -m / 0.  The offset
+// meets the STORED sum of the 32 activations where the layout has one (DS4: Q4_0, Q4_1, Q5_1) and d8 * SUM(u) elsewhere (D4: Q5_0; Q8_0 has no
+// offset) -- the sum of the ints is formed once per (column, block) when the tile is staged.
+template <int TYPE, class OUT>
+__global__ void __launch_bounds__(256, 2) mmq_mfma_b32_kernel(MmqArgs a) {
+  static_assert(TYPE == T_Q8_0 || TYPE == T_Q4_0 || TYPE == T_Q4_1 || TYPE == T_Q5_0 || TYPE == T_Q5_1, "32-value blocks");
+  constexpr int TS = Fmt<TYPE>::TS, LAYOUT = MmqLayout<TYPE>::value;
+  constexpr bool OFF = Fmt<TYPE>::HAS_OFFSET;
+  __shared__ __attribute__((aligned(16))) uint8_t raw[MM_COLS * MMQ_BLOCK_BYTES];   // [column][144 B]
+  __shared__ __attribute__((aligned(16))) float hdr[4 * MM_COLS * 2];               // [32-value group][column]{d8, s8}
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 5;
+  const int64_t col_low = a.expert_bounds ? a.expert_bounds[blockIdx.z] : 0;
+  const int64_t col_high = a.expert_bounds ? a.expert_bounds[blockIdx.z + 1] : a.ncols_y;
+  const int64_t c0 = col_low + (int64_t)blockIdx.y * MM_COLS;
+  if (c0 >= col_high) return;
+  const int64_t row = (int64_t)blockIdx.x * MM_ROWS + wave * 32 + (lane & 31);
+  const int64_t rowc = row < a.nrows_x ? row : a.nrows_x - 1;
+  const uint8_t *wrow = a.x + ((int64_t)blockIdx.z * a.stride_channel_x + rowc * a.stride_row_x) * TS;
+  const int nkb = (int)(a.ncols_x / 128);  // launch_mmq_t sends K % 128 != 0 to the v_dot4 kernel
+  float acc[4][16];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+  const mm_v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int kb = 0; kb < nkb; ++kb) {
+    // this lane's four weight blocks: scale, offset, its 16 values (k half kh) as signed / unsigned bytes
+    mm_v4i bf[4];
+    float sc[4], no[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint8_t *blk = wrow + (int64_t)(kb * 4 + j) * TS;
+      const float d = half_bits_to_float(ld2(blk));
+      sc[j] = d;
+      int4 v;
+      if constexpr (TYPE == T_Q8_0) {
+        v = ld16_a2(blk + 2 + 16 * kh);
+        no[j] = 0.0f;
+      } else {
+        constexpr int QO = TYPE == T_Q4_0 ? 2 : TYPE == T_Q4_1 ? 4 : TYPE == T_Q5_0 ? 6 : 8;
+        v = and4(shr4(ld16_a2(blk + QO), 4 * kh), 0x0F0F0F0F);  // values 0..15 are the low nibbles, 16..31 the high nibbles of the same 16 bytes
+        if constexpr (TYPE == T_Q5_0 || TYPE == T_Q5_1) {
+          const unsigned qh = (unsigned)ld4_a2(blk + (TYPE == T_Q5_0 ? 2 : 4)) >> (16 * kh);
+          v.x |= spread4(qh, 4); v.y |= spread4(qh >> 4, 4); v.z |= spread4(qh >> 8, 4); v.w |= spread4(qh >> 12, 4);
+        }
+        if constexpr (TYPE == T_Q4_0) no[j] = -(8.0f * d);
+        else if constexpr (TYPE == T_Q5_0) no[j] = -(16.0f * d);
+        else no[j] = half_bits_to_float(ld2(blk + 2));  // w = d q + m: o = -m
+      }
+      bf[j] = mm_v4i{v.x, v.y, v.z, v.w};
+    }
+    __syncthreads();
+    if (tid < MM_COLS) {
+      const int cc = tid;
+      const int64_t col = c0 + cc < col_high ? c0 + cc : col_high - 1;
+      const uint8_t *src = a.y + ((int64_t)kb * a.ncols_y + col) * MMQ_BLOCK_BYTES;
+      uint8_t *dstb = raw + cc * MMQ_BLOCK_BYTES;
+      const int4 v0 = ld16_a16(src);
+      const int w4[4] = {v0.x, v0.y, v0.z, v0.w};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int4 u0 = ld16_a16(src + 16 + 32 * g), u1 = ld16_a16(src + 32 + 32 * g);
+        *(int4 *)(dstb + 16 + 32 * g) = u0;
+        *(int4 *)(dstb + 32 + 32 * g) = u1;
+        float d8, s8 = 0.0f;
+        if constexpr (LAYOUT == MMQ_DS4) {
+          d8 = half_bits_to_float((uint16_t)((unsigned)w4[g] & 0xffffu));
+          s8 = half_bits_to_float((uint16_t)((unsigned)w4[g] >> 16));
+        } else {
+          d8 = __int_as_float(w4[g]);
+          if constexpr (OFF) {
+            const int4 ones = make_int4(0x01010101, 0x01010101, 0x01010101, 0x01010101);
+            s8 = d8 * (float)(dot16(ones, u0) + dot16(ones, u1));
+          }
+        }
+        if constexpr (OFF) {
+          hdr[(g * MM_COLS + cc) * 2] = d8;
+          hdr[(g * MM_COLS + cc) * 2 + 1] = s8;
+        } else {
+          hdr[g * MM_COLS + cc] = d8;  // no offset term: the scales alone, four columns per 16-byte read
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (t) __builtin_amdgcn_sched_barrier(0);
+        const mm_v4i af = *(const mm_v4i *)(raw + (32 * t + (lane & 31)) * MMQ_BLOCK_BYTES + 16 + 32 * j + 16 * kh);
+        const mm_v16i is = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[j], zero, 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          if constexpr (OFF) {
+            const float4 h0 = *(const float4 *)(hdr + (j * MM_COLS + 32 * t + 8 * g + 4 * kh) * 2);
+            const float4 h1 = *(const float4 *)(hdr + (j * MM_COLS + 32 * t + 8 * g + 4 * kh + 2) * 2);
+            acc[t][4 * g + 0] = fmaf(no[j], h0.y, fmaf((float)is[4 * g + 0], sc[j] * h0.x, acc[t][4 * g + 0]));
+            acc[t][4 * g + 1] = fmaf(no[j], h0.w, fmaf((float)is[4 * g + 1], sc[j] * h0.z, acc[t][4 * g + 1]));
+            acc[t][4 * g + 2] = fmaf(no[j], h1.y, fmaf((float)is[4 * g + 2], sc[j] * h1.x, acc[t][4 * g + 2]));
+            acc[t][4 * g + 3] = fmaf(no[j], h1.w, fmaf((float)is[4 * g + 3], sc[j] * h1.z, acc[t][4 * g + 3]));
+          } else {
+            const float4 h0 = *(const float4 *)(hdr + j * MM_COLS + 32 * t + 8 * g + 4 * kh);
+            acc[t][4 * g + 0] = fmaf((float)is[4 * g + 0], sc[j] * h0.x, acc[t][4 * g + 0]);
+            acc[t][4 * g + 1] = fmaf((float)is[4 * g + 1], sc[j] * h0.y, acc[t][4 * g + 1]);
+            acc[t][4 * g + 2] = fmaf((float)is[4 * g + 2], sc[j] * h0.z, acc[t][4 * g + 2]);
+            acc[t][4 * g + 3] = fmaf((float)is[4 * g + 3], sc[j] * h0.w, acc[t][4 * g + 3]);
+          }
+        }
+      }
+    }
+  }
+  if (row >= a.nrows_x) return;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int64_t col = c0 + 32 * t + 8 * (i >> 2) + 4 * kh + (i & 3);
+      if (col < col_high) {
+        const int64_t dcol = a.ids_dst ? a.ids_dst[col] : col;
+        ((OUT *)a.dst)[dcol * a.nrows_dst + row] = from_f<OUT>(acc[t][i]);
+      }
+    }
+}
+
+template <int TYPE> constexpr bool mmq_is_b32() { return TYPE == T_Q8_0 || TYPE == T_Q4_0 || TYPE == T_Q4_1 || TYPE == T_Q5_0 || TYPE == T_Q5_1; }
+template <int TYPE> constexpr bool mmq_has_mfma() { return TYPE == T_Q4_K || TYPE == T_Q5_K || TYPE == T_Q6_K || mmq_is_b32<TYPE>(); }
 // prompt-sized launches of the two DS4 K-quants go to the matrix cores (MRS_MMQ_MFMA=0: keep the v_dot4 kernel, for A/B measurements)
 static bool mmq_mfma_wanted() {
   static const bool on = [] { const char *e = getenv("MRS_MMQ_MFMA"); return !e || atoi(e) != 0; }();
@@ -442,9 +569,10 @@ template <int TYPE, class OUT> static void launch_mmq_t(const MmqArgs &a, int64_
   constexpr int NC = 8;
   if (a.nrows_x <= 0 || ncols_max <= 0 || channels <= 0) return;
   if constexpr (mmq_has_mfma<TYPE>()) {
-    if (mmq_mfma_wanted() && ncols_max >= 48 && a.nrows_x >= 32 && a.ncols_x % 256 == 0) {
+    if (mmq_mfma_wanted() && ncols_max >= 48 && a.nrows_x >= 32 && a.ncols_x % (mmq_is_b32<TYPE>() ? 128 : 256) == 0) {
       const dim3 grid((unsigned)((a.nrows_x + MM_ROWS - 1) / MM_ROWS), (unsigned)((ncols_max + MM_COLS - 1) / MM_COLS), (unsigned)channels);
       if constexpr (TYPE == T_Q6_K) hipLaunchKernelGGL((mmq_mfma_q6k_kernel<OUT>), grid, dim3(256), 0, (hipStream_t)stream, a);
+      else if constexpr (mmq_is_b32<TYPE>()) hipLaunchKernelGGL((mmq_mfma_b32_kernel<TYPE, OUT>), grid, dim3(256), 0, (hipStream_t)stream, a);
       else hipLaunchKernelGGL((mmq_mfma_kernel<TYPE, OUT>), grid, dim3(256), 0, (hipStream_t)stream, a);
       return;
     }
