@@ -195,6 +195,9 @@ void launch_pack_3bit_kernel(const uint32_t *d_input, int32_t *d_output, size_t 
 void launch_pack_4bit_kernel(const uint8_t *d_input, uint8_t *d_output, size_t num_input_elements, size_t input_width, void *stream);
 void launch_pack_8bit_kernel(const uint8_t *d_input, uint8_t *d_output, size_t num_elements, void *stream);
 
+/* MI355X-native addition (not in the reference ABI): tile policy of the int8-MFMA MMQ kernels, see csrc/mmq.hip */
+void mrs_mmq_set_small_tiles_below(int n);
+
 #ifdef __cplusplus
 }
 #endif

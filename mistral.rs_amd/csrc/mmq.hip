@@ -235,10 +235,11 @@ __global__ void __launch_bounds__(256) mmq_kernel(MmqArgs a) {
 // about 8 : 1, which still is ~5 x the v_dot4 kernel.  Workgroup tile 128 weight rows x 128 columns, wave tile 32 x 128.
 typedef int mm_v4i __attribute__((ext_vector_type(4)));
 typedef int mm_v16i __attribute__((ext_vector_type(16)));
-constexpr int MM_ROWS = 128, MM_COLS = 128;
+// workgroup tile: NW waves x 32 weight rows by NT x 32 activation columns (4 x 4 = 128 x 128 for launches that fill the chip, 2 x 2 for the others)
 
-template <int TYPE, class OUT>
-__global__ void __launch_bounds__(256, 2) mmq_mfma_kernel(MmqArgs a) {  // 2 workgroups per CU (<= 256 VGPRs: 168 spills ~90 values)
+template <int TYPE, class OUT, int NW, int NT>
+__global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 3) mmq_mfma_kernel(MmqArgs a) {
+  constexpr int MM_ROWS = 32 * NW, MM_COLS = 32 * NT, NTHR = 64 * NW;  // 2 workgroups per CU (<= 256 VGPRs: 168 spills ~90 values)
   static_assert(TYPE == T_Q4_K || TYPE == T_Q5_K, "DS4 K-quants with 32-value sub-blocks");
   constexpr int TS = Fmt<TYPE>::TS, QS = TYPE == T_Q4_K ? 16 : 48;  // block bytes, offset of qs[128]
   __shared__ __attribute__((aligned(16))) uint8_t raw[2 * MM_COLS * MMQ_BLOCK_BYTES];  // [k block of 128][column][144 B]
@@ -252,9 +253,9 @@ __global__ void __launch_bounds__(256, 2) mmq_mfma_kernel(MmqArgs a) {  // 2 wor
   const int64_t rowc = row < a.nrows_x ? row : a.nrows_x - 1;  // surplus rows are computed on the last row and dropped
   const uint8_t *wrow = a.x + ((int64_t)blockIdx.z * a.stride_channel_x + rowc * a.stride_row_x) * TS;
   const int nsb = (int)(a.ncols_x / 256);
-  float acc[4][16];
+  float acc[NT][16];
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
   const mm_v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -269,8 +270,8 @@ __global__ void __launch_bounds__(256, 2) mmq_mfma_kernel(MmqArgs a) {  // 2 wor
     if constexpr (TYPE == T_Q5_K) q5 = ld16_a16(b + 16 + 16 * kh);
     __syncthreads();  // the previous superblock's tile has been read by every wave
     // stage the activation tile: thread = (k block tid / 128, column tid % 128) copies its 144-byte block (columns past the range re-read the last one)
-    {
-      const int kb = tid >> 7, cc = tid & (MM_COLS - 1);
+    for (int p = tid; p < 2 * MM_COLS; p += NTHR) {
+      const int kb = p / MM_COLS, cc = p % MM_COLS;
       const int64_t col = c0 + cc < col_high ? c0 + cc : col_high - 1;
       const uint8_t *src = a.y + ((int64_t)(2 * sb + kb) * a.ncols_y + col) * MMQ_BLOCK_BYTES;
       uint8_t *dstb = raw + (kb * MM_COLS + cc) * MMQ_BLOCK_BYTES;
@@ -307,7 +308,7 @@ __global__ void __launch_bounds__(256, 2) mmq_mfma_kernel(MmqArgs a) {  // 2 wor
         bf[e] = (int)v;
       }
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < NT; ++t) {
         if (t) __builtin_amdgcn_sched_barrier(0);
         const mm_v4i af = *(const mm_v4i *)(raw + ((j >> 2) * MM_COLS + 32 * t + (lane & 31)) * MMQ_BLOCK_BYTES + 16 + 32 * (j & 3) + 16 * kh);
         const mm_v16i is = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf, zero, 0, 0, 0);
@@ -325,7 +326,7 @@ __global__ void __launch_bounds__(256, 2) mmq_mfma_kernel(MmqArgs a) {  // 2 wor
   }
   if (row >= a.nrows_x) return;
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int64_t col = c0 + 32 * t + 8 * (i >> 2) + 4 * kh + (i & 3);
@@ -341,8 +342,9 @@ __global__ void __launch_bounds__(256, 2) mmq_mfma_kernel(MmqArgs a) {  // 2 wor
 // term.  The run of index r = 8 h + 2 q + lh (half, quarter, 16-half) starts at element 128 h + 32 q + 16 lh of the superblock, its low bits are
 // nibble (q >> 1) of ql[64 h + 32 (q & 1) + 16 lh ..], its high bits the 2-bit field q of qh[32 h + 16 lh ..].  Twice the fix-ups per weight of
 // the Q4_K route (16 cvt + 8 pk_mul + 8 pk_fma per 16 k): about 0.6 x its rate.
-template <class OUT>
-__global__ void __launch_bounds__(256, 2) mmq_mfma_q6k_kernel(MmqArgs a) {
+template <class OUT, int NW, int NT>
+__global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 3) mmq_mfma_q6k_kernel(MmqArgs a) {
+  constexpr int MM_ROWS = 32 * NW, MM_COLS = 32 * NT, NTHR = 64 * NW;
   constexpr int TS = 210;
   __shared__ __attribute__((aligned(16))) uint8_t raw[2 * MM_COLS * MMQ_BLOCK_BYTES];
   __shared__ __attribute__((aligned(16))) float hdr[8 * MM_COLS];                       // [32-value group][column] d8
@@ -355,9 +357,9 @@ __global__ void __launch_bounds__(256, 2) mmq_mfma_q6k_kernel(MmqArgs a) {
   const int64_t rowc = row < a.nrows_x ? row : a.nrows_x - 1;
   const uint8_t *wrow = a.x + ((int64_t)blockIdx.z * a.stride_channel_x + rowc * a.stride_row_x) * TS;
   const int nsb = (int)(a.ncols_x / 256);
-  float acc[4][16];
+  float acc[NT][16];
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
   const mm_v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -375,8 +377,8 @@ __global__ void __launch_bounds__(256, 2) mmq_mfma_q6k_kernel(MmqArgs a) {
     const int4 scw = ld16_a2(b + 192);
     const float d = half_bits_to_float(ld2(b + 208));
     __syncthreads();
-    {
-      const int kb = tid >> 7, cc = tid & (MM_COLS - 1);
+    for (int p = tid; p < 2 * MM_COLS; p += NTHR) {
+      const int kb = p / MM_COLS, cc = p % MM_COLS;
       const int64_t col = c0 + cc < col_high ? c0 + cc : col_high - 1;
       const uint8_t *src = a.y + ((int64_t)(2 * sb + kb) * a.ncols_y + col) * MMQ_BLOCK_BYTES;
       uint8_t *dstb = raw + (kb * MM_COLS + cc) * MMQ_BLOCK_BYTES;
@@ -403,7 +405,7 @@ __global__ void __launch_bounds__(256, 2) mmq_mfma_q6k_kernel(MmqArgs a) {
       }
       const long bf = (long)(((unsigned long long)bw[1] << 32) | bw[0]);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < NT; ++t) {
         if (t) __builtin_amdgcn_sched_barrier(0);
         const long af = *(const long *)(raw + ((r >> 3) * MM_COLS + 32 * t + (lane & 31)) * MMQ_BLOCK_BYTES + 16 + 16 * (r & 7) + 8 * kh);
         const mm_v16i is = __builtin_amdgcn_mfma_i32_32x32x16_i8(af, bf, zero, 0, 0, 0);
@@ -420,7 +422,7 @@ __global__ void __launch_bounds__(256, 2) mmq_mfma_q6k_kernel(MmqArgs a) {
   }
   if (row >= a.nrows_x) return;
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int64_t col = c0 + 32 * t + 8 * (i >> 2) + 4 * kh + (i & 3);
@@ -435,8 +437,9 @@ __global__ void __launch_bounds__(256, 2) mmq_mfma_q6k_kernel(MmqArgs a) {
 // block per column: 18 KiB of LDS per stage).  w = s q - o per block (gguf_blocks.cuh load_slice): s = d; o = 8 d / -m / 16 d / -m / 0.  The offset
 // meets the STORED sum of the 32 activations where the layout has one (DS4: Q4_0, Q4_1, Q5_1) and d8 * SUM(u) elsewhere (D4: Q5_0; Q8_0 has no
 // offset) -- the sum of the ints is formed once per (column, block) when the tile is staged.
-template <int TYPE, class OUT>
-__global__ void __launch_bounds__(256, 2) mmq_mfma_b32_kernel(MmqArgs a) {
+template <int TYPE, class OUT, int NW, int NT>
+__global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 3) mmq_mfma_b32_kernel(MmqArgs a) {
+  constexpr int MM_ROWS = 32 * NW, MM_COLS = 32 * NT, NTHR = 64 * NW;
   static_assert(TYPE == T_Q8_0 || TYPE == T_Q4_0 || TYPE == T_Q4_1 || TYPE == T_Q5_0 || TYPE == T_Q5_1, "32-value blocks");
   constexpr int TS = Fmt<TYPE>::TS, LAYOUT = MmqLayout<TYPE>::value;
   constexpr bool OFF = Fmt<TYPE>::HAS_OFFSET;
@@ -451,9 +454,9 @@ __global__ void __launch_bounds__(256, 2) mmq_mfma_b32_kernel(MmqArgs a) {
   const int64_t rowc = row < a.nrows_x ? row : a.nrows_x - 1;
   const uint8_t *wrow = a.x + ((int64_t)blockIdx.z * a.stride_channel_x + rowc * a.stride_row_x) * TS;
   const int nkb = (int)(a.ncols_x / 128);  // launch_mmq_t sends K % 128 != 0 to the v_dot4 kernel
-  float acc[4][16];
+  float acc[NT][16];
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
   const mm_v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -484,8 +487,7 @@ __global__ void __launch_bounds__(256, 2) mmq_mfma_b32_kernel(MmqArgs a) {
       bf[j] = mm_v4i{v.x, v.y, v.z, v.w};
     }
     __syncthreads();
-    if (tid < MM_COLS) {
-      const int cc = tid;
+    for (int cc = tid; cc < MM_COLS; cc += NTHR) {
       const int64_t col = c0 + cc < col_high ? c0 + cc : col_high - 1;
       const uint8_t *src = a.y + ((int64_t)kb * a.ncols_y + col) * MMQ_BLOCK_BYTES;
       uint8_t *dstb = raw + cc * MMQ_BLOCK_BYTES;
@@ -520,7 +522,7 @@ __global__ void __launch_bounds__(256, 2) mmq_mfma_b32_kernel(MmqArgs a) {
     for (int j = 0; j < 4; ++j) {
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < NT; ++t) {
         if (t) __builtin_amdgcn_sched_barrier(0);
         const mm_v4i af = *(const mm_v4i *)(raw + (32 * t + (lane & 31)) * MMQ_BLOCK_BYTES + 16 + 32 * j + 16 * kh);
         const mm_v16i is = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[j], zero, 0, 0, 0);
@@ -546,7 +548,7 @@ __global__ void __launch_bounds__(256, 2) mmq_mfma_b32_kernel(MmqArgs a) {
   }
   if (row >= a.nrows_x) return;
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int64_t col = c0 + 32 * t + 8 * (i >> 2) + 4 * kh + (i & 3);
@@ -560,6 +562,11 @@ __global__ void __launch_bounds__(256, 2) mmq_mfma_b32_kernel(MmqArgs a) {
 template <int TYPE> constexpr bool mmq_is_b32() { return TYPE == T_Q8_0 || TYPE == T_Q4_0 || TYPE == T_Q4_1 || TYPE == T_Q5_0 || TYPE == T_Q5_1; }
 template <int TYPE> constexpr bool mmq_has_mfma() { return TYPE == T_Q4_K || TYPE == T_Q5_K || TYPE == T_Q6_K || mmq_is_b32<TYPE>(); }
 // prompt-sized launches of the two DS4 K-quants go to the matrix cores (MRS_MMQ_MFMA=0: keep the v_dot4 kernel, for A/B measurements)
+static int g_mmq_small_below = -1;  // < 0: not set yet (MRS_MMQ_SMALL_TILES_BELOW, default 384 = 1.5 workgroups of 128 x 128 per CU)
+static int mmq_small_tiles_below() {
+  if (g_mmq_small_below < 0) { const char *e = getenv("MRS_MMQ_SMALL_TILES_BELOW"); g_mmq_small_below = e ? atoi(e) : 384; }
+  return g_mmq_small_below;
+}
 static bool mmq_mfma_wanted() {
   static const bool on = [] { const char *e = getenv("MRS_MMQ_MFMA"); return !e || atoi(e) != 0; }();
   return on;
@@ -570,10 +577,19 @@ template <int TYPE, class OUT> static void launch_mmq_t(const MmqArgs &a, int64_
   if (a.nrows_x <= 0 || ncols_max <= 0 || channels <= 0) return;
   if constexpr (mmq_has_mfma<TYPE>()) {
     if (mmq_mfma_wanted() && ncols_max >= 48 && a.nrows_x >= 32 && a.ncols_x % (mmq_is_b32<TYPE>() ? 128 : 256) == 0) {
-      const dim3 grid((unsigned)((a.nrows_x + MM_ROWS - 1) / MM_ROWS), (unsigned)((ncols_max + MM_COLS - 1) / MM_COLS), (unsigned)channels);
-      if constexpr (TYPE == T_Q6_K) hipLaunchKernelGGL((mmq_mfma_q6k_kernel<OUT>), grid, dim3(256), 0, (hipStream_t)stream, a);
-      else if constexpr (mmq_is_b32<TYPE>()) hipLaunchKernelGGL((mmq_mfma_b32_kernel<TYPE, OUT>), grid, dim3(256), 0, (hipStream_t)stream, a);
-      else hipLaunchKernelGGL((mmq_mfma_kernel<TYPE, OUT>), grid, dim3(256), 0, (hipStream_t)stream, a);
+      // 128 x 128 tiles when they give every CU its two workgroups, 64 x 64 tiles otherwise (a 4096-row tensor at 512 columns: 128 -> 512 workgroups)
+      const int64_t big = ((a.nrows_x + 127) / 128) * ((ncols_max + 127) / 128) * channels;
+      if (big >= mmq_small_tiles_below()) {
+        const dim3 grid((unsigned)((a.nrows_x + 127) / 128), (unsigned)((ncols_max + 127) / 128), (unsigned)channels);
+        if constexpr (TYPE == T_Q6_K) hipLaunchKernelGGL((mmq_mfma_q6k_kernel<OUT, 4, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);
+        else if constexpr (mmq_is_b32<TYPE>()) hipLaunchKernelGGL((mmq_mfma_b32_kernel<TYPE, OUT, 4, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((mmq_mfma_kernel<TYPE, OUT, 4, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);
+      } else {
+        const dim3 grid((unsigned)((a.nrows_x + 63) / 64), (unsigned)((ncols_max + 63) / 64), (unsigned)channels);
+        if constexpr (TYPE == T_Q6_K) hipLaunchKernelGGL((mmq_mfma_q6k_kernel<OUT, 2, 2>), grid, dim3(128), 0, (hipStream_t)stream, a);
+        else if constexpr (mmq_is_b32<TYPE>()) hipLaunchKernelGGL((mmq_mfma_b32_kernel<TYPE, OUT, 2, 2>), grid, dim3(128), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((mmq_mfma_kernel<TYPE, OUT, 2, 2>), grid, dim3(128), 0, (hipStream_t)stream, a);
+      }
       return;
     }
   }
@@ -611,6 +627,9 @@ static void launch_mmq_moe(const void *x, const void *y, const int32_t *ids_dst,
 }
 
 }  // namespace mrs
+
+// tile policy of the matrix-core route (tests / measurements): launches with fewer than `n` 128 x 128 tiles take 64 x 64 tiles; 0 = always 128 x 128
+extern "C" void mrs_mmq_set_small_tiles_below(int n) { mrs::g_mmq_small_below = n < 0 ? 0 : n; }
 
 #define MRS_MMQ_QUANTIZE(NAME, LAYOUT)                                                                                                            \
   extern "C" void launch_mmq_quantize_q8_1_##NAME(const void *x, const int32_t *ids, void *vy, int type_x, int64_t ne00, int64_t s01, int64_t s02, \

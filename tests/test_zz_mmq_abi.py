@@ -219,10 +219,18 @@ MFMA_CASES = [("q4_k", "f32", 200, 512, 70), ("q5_k", "bf16", 33, 256, 130), ("q
 
 @pytest.mark.parametrize("tname,dt,n,k,cols", MFMA_CASES)
 def test_mmq_matrix_core_route_host_emulation(oracle, tname, dt, n, k, cols):
-    """launch_mmq_gguf_{q4_k,q5_k} with >= 48 columns and >= 32 rows: one v_mfma_i32_32x32x32_i8 per 32-value sub-block (csrc/mmq.hip mmq_mfma_kernel);
-    ragged row / column tiles; the same budget against the f64 oracle as the v_dot4 kernel."""
+    """launch_mmq_gguf_<t> with >= 48 columns and >= 32 rows: one v_mfma_i32_32x32x32_i8 per 32-value sub-block (csrc/mmq.hip mmq_mfma_*_kernel);
+    ragged row / column tiles in both tile sizes (64 x 64 for small launches, 128 x 128 otherwise); the same budget against the f64 oracle as the
+    v_dot4 kernel."""
     t = {v: k_ for k_, v in oracle.TYPE_NAMES.items()}[tname]
-    check_mmq(oracle, HostBackend(), t, dt, n, k, cols)
+    be = HostBackend()
+    policy = be.sym("mrs_mmq_set_small_tiles_below", [I], None)
+    try:
+        for below in (1 << 30, 0):
+            policy(below)
+            check_mmq(oracle, be, t, dt, n, k, cols)
+    finally:
+        policy(384)
 
 
 @pytest.mark.parametrize("tname", ["q4_k", "q5_k", "q6_k", "q8_0", "q5_0", "q4_1"])
@@ -236,7 +244,14 @@ def test_mmq_matrix_core_route_moe_host_emulation(oracle, tname):
 @pytest.mark.parametrize("tname,dt,n,k,cols", MFMA_CASES + [("q4_k", "f32", 1030, 4096, 512), ("q5_k", "f32", 4100, 1024, 257), ("q6_k", "f32", 1030, 4096, 512), ("q8_0", "f32", 1030, 4096, 512), ("q4_0", "f32", 515, 2048, 300)])
 def test_mmq_matrix_core_route_gpu(oracle, dev, tname, dt, n, k, cols):
     t = {v: k_ for k_, v in oracle.TYPE_NAMES.items()}[tname]
-    check_mmq(oracle, GpuBackend(dev), t, dt, n, k, cols)
+    be = GpuBackend(dev)
+    policy = be.sym("mrs_mmq_set_small_tiles_below", [I], None)
+    try:
+        for below in (1 << 30, 0):
+            policy(below)
+            check_mmq(oracle, be, t, dt, n, k, cols)
+    finally:
+        policy(384)
 
 
 @pytest.mark.gpu
