@@ -152,4 +152,15 @@ __device__ __forceinline__ float fast_exp_ref(float x) {
 // SiLU of the decode engine: x / (1 + exp(-x)) (mistralrs-quant/src/utils/ops.rs:2601-2612) with the exponential above
 __device__ __forceinline__ float silu_engine(float x) { return x / (1.0f + fast_exp_ref(-x)); }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per KERNEL (keyed by its address: a `static bool` inside a generic lambda is shared by every
+// kernel with the same function-pointer type); not an operation a stream capture tolerates on every call.  Host only.
+inline void lds_attr_once(const void *kern, int bytes) {
+  static const void *done[64];
+  static int n = 0;
+  for (int i = 0; i < n; ++i)
+    if (done[i] == kern) return;
+  (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (n < 64) done[n++] = kern;
+}
+
 }  // namespace mrs

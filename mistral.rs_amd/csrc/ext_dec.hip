@@ -896,8 +896,7 @@ extern "C" int mrs_dec_attention_q8k(void *img_out, float *out_f32, const float 
   const size_t lds = ((size_t)2 * ns_cap * 128 + 2 * 2 * ns_cap + 2 * 128 + (size_t)nw * (2 * 128 + 2 * 32)) * 4;
   const dim3 grid(num_kv_heads * (G / 2), num_seqs);
   auto go = [&](auto kern) {
-    static bool attr = false;  // per instantiation
-    if (!attr) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024); attr = true; }
+    lds_attr_once((const void *)kern, 158 * 1024);
     hipLaunchKernelGGL(kern, grid, dim3(nw * 64), lds, (hipStream_t)stream, t, (uint8_t *)img_out, out_f32, G, ns_cap);
   };
   if (kv_dtype == 1) { if (nw == 8) go(decode_attn_fused_kernel<2, bf16_t, 8>); else go(decode_attn_fused_kernel<2, bf16_t, 12>); }

@@ -137,8 +137,7 @@ template <int BITS, class T> static int launch(const Args &a, int b, hipStream_t
   auto go = [&](auto kern, int ncols) {
     const size_t lds = (size_t)ncols * a.K * 4 + 2 * CH * 4;
     if (lds > 158 * 1024) return -2;
-    static bool attr = false;  // per instantiation; not an operation a stream capture tolerates on every call
-    if (!attr) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024); attr = true; }
+    lds_attr_once((const void *)kern, 158 * 1024);
     hipLaunchKernelGGL(kern, grid, block, lds, s, a);
     return 0;
   };

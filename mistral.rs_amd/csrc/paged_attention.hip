@@ -20,30 +20,55 @@ static void pa_check(const char *what) {
   if (e != hipSuccess) { fprintf(stderr, "HIP error in %s: %s\n", what, hipGetErrorString(e)); exit((int)e); }
 }
 
-static size_t pa_lds_bytes(int G, int HD, int LS) {
-  const size_t body = (size_t)G * LS > (size_t)PA_NW * G * HD ? (size_t)G * LS : (size_t)PA_NW * G * HD;
-  return ((size_t)G * HD + body + 2 * (size_t)G * PA_NW) * sizeof(float);
+static size_t pa_lds_bytes(int G, int HD, int LS, int nw = PA_NW) {
+  const size_t body = (size_t)G * LS > (size_t)nw * G * HD ? (size_t)G * LS : (size_t)nw * G * HD;
+  return ((size_t)G * HD + body + 2 * (size_t)G * nw) * sizeof(float);
+}
+// a launch that leaves most CUs without a workgroup (batch-1 decode: heads x partitions) is a latency chain per workgroup: more waves walk the
+// partition's 32-token blocks in parallel.  MRS_PA_WIDE = 0 (off) / 8 / 16 waves (default 8).
+static int pa_wide() {  // -1: default (16 waves with one head per workgroup: 104 VGPRs; 8 with two: 246)
+  static const int w = [] { const char *e = getenv("MRS_PA_WIDE"); const int v = e ? atoi(e) : -1; return v == 16 ? 16 : (v == 0 ? 0 : (v == 8 ? 8 : -1)); }();
+  return w;
+}
+
+template <class T, class CT, int HD, int BS, int G, int PART, int NW>
+static void pa_launch_nw(const PagedAttnArgs &a, dim3 grid, hipStream_t s) {
+  auto kern = paged_attention_kernel<T, CT, HD, BS, G, PART, true, NW>;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), pa_lds_bytes(G, HD, a.logits_stride, NW), s, a);
 }
 
 template <class T, class CT, int HD, int BS, int G, int PART>
 static void pa_launch(const PagedAttnArgs &a, int num_seqs, int max_parts, hipStream_t s) {
-  auto kern = paged_attention_kernel<T, CT, HD, BS, G, PART, true, PA_NW>;
-  const size_t lds = pa_lds_bytes(G, HD, a.logits_stride);
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-  hipLaunchKernelGGL(kern, dim3(a.num_heads / G, num_seqs, PART > 0 ? max_parts : 1), dim3(PA_NW * 64), lds, s, a);
+  const dim3 grid(a.num_heads / G, num_seqs, PART > 0 ? max_parts : 1);
+  if constexpr (HD == 128 && BS == 32 && G <= 2) {  // the shapes of the headline models; elsewhere the 4-wave kernel stays the only instantiation
+    int w = pa_wide();
+    if (w < 0) w = G == 1 ? 16 : 8;
+    if (w == 16 && G != 1) w = 8;  // 16 waves cap the kernel at 128 VGPRs: only the one-head instantiation fits without scratch
+    if (w && (long)grid.x * grid.y * grid.z <= 256 && pa_lds_bytes(G, HD, a.logits_stride, w) <= PA_LDS_MAX) {
+      if constexpr (G == 1) { if (w == 16) return pa_launch_nw<T, CT, HD, BS, G, PART, 16>(a, grid, s); }
+      return pa_launch_nw<T, CT, HD, BS, G, PART, 8>(a, grid, s);
+    }
+  }
+  pa_launch_nw<T, CT, HD, BS, G, PART, PA_NW>(a, grid, s);
 }
 
 template <class T, class CT, int HD, int BS, int PART>
 static void pa_pick_g(const PagedAttnArgs &a, int num_seqs, int max_parts, hipStream_t s) {
   const int qpk = a.num_heads / a.num_kv_heads;
-  auto fits = [&](int G) { return qpk % G == 0 && pa_lds_bytes(G, HD, a.logits_stride) <= PA_LDS_MAX; };
+  // few (sequence, kv head, partition) triples: one query head per workgroup puts 4-8 x the workgroups on the chip (K / V are re-read per head out of L2);
+  // MRS_PA_MAX_G overrides (measurements)
+  static const int env_g = [] { const char *e = getenv("MRS_PA_MAX_G"); return e ? atoi(e) : 0; }();
+  const long triples = (long)a.num_kv_heads * num_seqs * (PART > 0 ? max_parts : 1);
+  const int max_g = env_g > 0 ? env_g : (triples <= 32 ? 1 : 8);
+  auto fits = [&](int G) { return G <= max_g && qpk % G == 0 && pa_lds_bytes(G, HD, a.logits_stride) <= PA_LDS_MAX; };
   if constexpr (HD <= 128 && BS >= 16) {
     if (fits(8)) return pa_launch<T, CT, HD, BS, 8, PART>(a, num_seqs, max_parts, s);
     if (fits(4)) return pa_launch<T, CT, HD, BS, 4, PART>(a, num_seqs, max_parts, s);
     if (fits(2)) return pa_launch<T, CT, HD, BS, 2, PART>(a, num_seqs, max_parts, s);
   }
-  if (!fits(1)) {
+  if (pa_lds_bytes(1, HD, a.logits_stride) > PA_LDS_MAX) {
     fprintf(stderr, "paged_attention (gfx950): context of %d tokens does not fit the 160 KiB LDS logits buffer; use v2\n", a.logits_stride);
     exit(2);
   }
