@@ -40,10 +40,11 @@ __device__ __forceinline__ int isq_nearest_int(float f) { return (int)rintf(f); 
 
 // make_qkx2_quants(32, nmax, x, w, .., rmin, rdelta, nstep, use_mad = false): only the returned scale and *the_min matter to the callers
 // (the quants are recomputed after the 6-bit scale rounding), so L / Laux are not materialised: a candidate's quants are re-derived where needed.
-__device__ __forceinline__ float isq_make_qkx2(const float (&x)[32], const float (&w)[32], int nmax, float rmin, float rdelta, int nstep, float &the_min) {
+template <int N = 32, bool MAD = false>
+__device__ __forceinline__ float isq_make_qkx2(const float (&x)[N], const float (&w)[N], int nmax, float rmin, float rdelta, int nstep, float &the_min) {
   float mn = x[0], mx = x[0], sum_w = w[0], sum_x = sum_w * x[0];
 #pragma unroll
-  for (int i = 1; i < 32; ++i) {
+  for (int i = 1; i < N; ++i) {
     if (x[i] < mn) mn = x[i];
     if (x[i] > mx) mx = x[i];
     sum_w += w[i];
@@ -53,17 +54,17 @@ __device__ __forceinline__ float isq_make_qkx2(const float (&x)[32], const float
   if (mx == mn) { the_min = -mn; return 0.f; }
   float iscale = nmax / (mx - mn), scale = 1 / iscale, best_mad = 0;
 #pragma unroll
-  for (int i = 0; i < 32; ++i) {
+  for (int i = 0; i < N; ++i) {
     const int l = max(0, min(nmax, isq_nearest_int(iscale * (x[i] - mn))));
     float diff = scale * l + mn - x[i];
-    diff = diff * diff;
+    diff = MAD ? fabsf(diff) : diff * diff;
     best_mad += w[i] * diff;
   }
   for (int is = 0; is <= nstep; ++is) {
     iscale = (rmin + rdelta * is + nmax) / (mx - mn);
     float sum_l = 0, sum_l2 = 0, sum_xl = 0;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
+    for (int i = 0; i < N; ++i) {
       const int l = max(0, min(nmax, isq_nearest_int(iscale * (x[i] - mn))));
       sum_l += w[i] * l;
       sum_l2 += w[i] * l * l;
@@ -76,10 +77,10 @@ __device__ __forceinline__ float isq_make_qkx2(const float (&x)[32], const float
       if (this_min > 0) { this_min = 0; this_scale = sum_xl / sum_l2; }
       float mad = 0;
 #pragma unroll
-      for (int i = 0; i < 32; ++i) {
+      for (int i = 0; i < N; ++i) {
         const int l = max(0, min(nmax, isq_nearest_int(iscale * (x[i] - mn))));  // Laux[i]
         float diff = this_scale * l + this_min - x[i];
-        diff = diff * diff;
+        diff = MAD ? fabsf(diff) : diff * diff;
         mad += w[i] * diff;
       }
       if (mad < best_mad) { best_mad = mad; scale = this_scale; mn = this_min; }  // the following candidates use the updated min, as GGML does
@@ -377,6 +378,169 @@ __global__ void __launch_bounds__(256) isq_q6_k_kernel(const T *__restrict__ src
   }
 }
 
+// Q2_K (84 B: 16 x {4-bit scale | 4-bit min << 4}, 64 B of 2-bit quants, half d, half dmin) -- quantize_row_q2_K_ref: 16 lanes per superblock,
+// lane ib = 16-weight sub-block; make_qkx2_quants(16, 3, x, |x|, .., -0.5, 0.1, 15, use_mad = true).
+template <class T>
+__global__ void __launch_bounds__(256) isq_q2_k_kernel(const T *__restrict__ src, uint8_t *__restrict__ out, size_t nsuper) {
+  const int lane = threadIdx.x & 63, ib = lane & 15, base = lane & ~15;
+  const size_t sb_raw = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+  const bool live = sb_raw < nsuper;
+  const size_t sb = live ? sb_raw : nsuper - 1;
+  float x[16], w[16];
+  const T *p = src + sb * 256 + (size_t)ib * 16;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { x[i] = to_f<T>(p[i]); w[i] = fabsf(x[i]); }
+  float mn;
+  const float sc = isq_make_qkx2<16, true>(x, w, 3, -0.5f, 0.1f, 15, mn);
+  float max_scale = sc > 0 ? sc : 0.f, max_min = mn > 0 ? mn : 0.f;
+#pragma unroll
+  for (int m = 1; m < 16; m <<= 1) { max_scale = fmaxf(max_scale, __shfl_xor(max_scale, m, 64)); max_min = fmaxf(max_min, __shfl_xor(max_min, m, 64)); }
+  int ls = 0, lm = 0;
+  uint16_t dbits = float_to_half_bits(0.f), mbits = float_to_half_bits(0.f);
+  if (max_scale > 0) { ls = isq_nearest_int((15.f / max_scale) * sc); dbits = float_to_half_bits(max_scale / 15.f); }
+  if (max_min > 0) { lm = isq_nearest_int((15.f / max_min) * mn); mbits = float_to_half_bits(max_min / 15.f); }
+  const uint8_t scb = (uint8_t)((uint8_t)ls | (uint8_t)(lm << 4));  // exactly the byte a reader decodes: `scales[j] = l; scales[j] |= l << 4`
+  const float d = half_bits_to_float(dbits) * (float)(scb & 0xF), dm = half_bits_to_float(mbits) * (float)(scb >> 4);
+  uint32_t lo[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    int l = 0;
+    if (d != 0.f) l = max(0, min(3, isq_nearest_int((x[i] + dm) / d)));
+    lo[i >> 2] |= (uint32_t)l << (8 * (i & 3));
+  }
+  uint8_t *y = out + sb * 84;
+  if (live) {
+    y[ib] = scb;
+    if (ib == 0) { *(uint16_t *)(y + 80) = dbits; *(uint16_t *)(y + 82) = mbits; }
+  }
+  // qs[32 h + l] = L[q = 0][l] | L[1][l] << 2 | L[2][l] << 4 | L[3][l] << 6 over the quarters of half h: lanes ib, ib + 2, ib + 4, ib + 6
+  const int qt = (ib >> 1) & 3, h = ib >> 3, par = ib & 1;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const uint32_t q1 = (uint32_t)__shfl((int)lo[g], base + ((ib + 2) & 15), 64), q2 = (uint32_t)__shfl((int)lo[g], base + ((ib + 4) & 15), 64),
+                   q3 = (uint32_t)__shfl((int)lo[g], base + ((ib + 6) & 15), 64);
+    if (live && qt == 0) ((uint32_t *)(y + 16 + 32 * h + 16 * par))[g] = lo[g] | (q1 << 2) | (q2 << 4) | (q3 << 6);
+  }
+}
+
+// Q3_K (110 B: 32 B high-bit mask, 64 B of 2-bit quants, 12 B of 6-bit scales, half d) -- quantize_row_q3_K_ref: make_q3_quants(16, 4, x, L, true)
+// per sub-block (first guess + up to 5 refinement sweeps), super-scale -32 / (scale of largest magnitude).
+template <class T>
+__global__ void __launch_bounds__(256) isq_q3_k_kernel(const T *__restrict__ src, uint8_t *__restrict__ out, size_t nsuper) {
+  const int lane = threadIdx.x & 63, ib = lane & 15, base = lane & ~15;
+  const size_t sb_raw = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+  const bool live = sb_raw < nsuper;
+  const size_t sb = live ? sb_raw : nsuper - 1;
+  float x[16];
+  const T *p = src + sb * 256 + (size_t)ib * 16;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) x[i] = to_f<T>(p[i]);
+  int L[16];
+  float scale;
+  {
+    constexpr int nmax = 4;
+    float mx = 0, amax = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const float ax = fabsf(x[i]); if (ax > amax) { amax = ax; mx = x[i]; } }
+    if (amax < 1e-15f) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) L[i] = 0;
+      scale = 0.f;
+    } else {
+      const float iscale = -nmax / mx;
+      float sumlx = 0, suml2 = 0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int l = max(-nmax, min(nmax - 1, isq_nearest_int(iscale * x[i])));
+        L[i] = l;
+        const float w = x[i] * x[i];
+        sumlx += w * x[i] * l;
+        suml2 += w * l * l;
+      }
+      for (int itry = 0; itry < 5; ++itry) {
+        int n_changed = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float w = x[i] * x[i];
+          float slx = sumlx - w * x[i] * L[i];
+          if (slx > 0) {
+            float sl2 = suml2 - w * L[i] * L[i];
+            const int new_l = max(-nmax, min(nmax - 1, isq_nearest_int(x[i] * sl2 / slx)));
+            if (new_l != L[i]) {
+              slx += w * x[i] * new_l;
+              sl2 += w * new_l * new_l;
+              if (sl2 > 0 && slx * slx * suml2 > sumlx * sumlx * sl2) { L[i] = new_l; sumlx = slx; suml2 = sl2; ++n_changed; }
+            }
+          }
+        }
+        if (!n_changed) break;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) L[i] += nmax;
+      scale = sumlx / suml2;
+    }
+  }
+  // the scale of largest magnitude, first sub-block on ties (`if (scale > amax)` over |scale|)
+  float best_abs = fabsf(scale), best_s = scale;
+  int best_i = ib;
+#pragma unroll
+  for (int m = 1; m < 16; m <<= 1) {
+    const float oa = __shfl_xor(best_abs, m, 64), os = __shfl_xor(best_s, m, 64);
+    const int oi = __shfl_xor(best_i, m, 64);
+    if (oa > best_abs || (oa == best_abs && oi < best_i)) { best_abs = oa; best_s = os; best_i = oi; }
+  }
+  const bool any = best_abs > 0.f;  // `if (max_scale)`: max_scale is only ever set to a scale whose magnitude exceeded 0
+  const float iscale = any ? -32.f / best_s : 0.f;
+  const int l6 = any ? max(-32, min(31, isq_nearest_int(iscale * scale))) + 32 : 0;  // 6-bit code; all twelve bytes stay 0 without a scale
+  const uint16_t dbits = any ? float_to_half_bits(1 / iscale) : float_to_half_bits(0.f);
+  int all[16];
+#pragma unroll
+  for (int g = 0; g < 16; ++g) all[g] = __shfl(l6, base + g, 64);
+  uint8_t *y = out + sb * 110;
+  if (live && ib < 12) {
+    uint8_t b;
+    if (ib < 8) b = (uint8_t)((all[ib] & 0xF) | ((all[ib + 8] & 0xF) << 4));
+    else { const int m = ib - 8; b = (uint8_t)((all[m] >> 4) | ((all[m + 4] >> 4) << 2) | ((all[m + 8] >> 4) << 4) | ((all[m + 12] >> 4) << 6)); }
+    y[96 + ib] = b;
+  }
+  if (live && ib == 0) *(uint16_t *)(y + 108) = dbits;
+  const float d = half_bits_to_float(dbits) * (float)(l6 - 32);  // the reader's 6-bit scale minus 32 (-32 for an all-zero block: d = -0 -> the first quants stay)
+  if (d != 0.f) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) L[i] = max(-4, min(3, isq_nearest_int(x[i] / d))) + 4;
+  }
+  // high bits: element 16 ib + i -> hmask[16 (ib & 1) + i] bit ib >> 1; low two bits as Q2_K
+  uint32_t lo[4] = {0, 0, 0, 0}, hb = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    int l = L[i];
+    if (l > 3) { hb |= 1u << i; l -= 4; }
+    lo[i >> 2] |= (uint32_t)l << (8 * (i & 3));
+  }
+  const int qt = (ib >> 1) & 3, h = ib >> 3, par = ib & 1;
+  uint32_t hm[4] = {0, 0, 0, 0};  // byte i (of this parity's 16) = sum over the 8 lanes of the parity of bit i << (their ib >> 1)
+#pragma unroll
+  for (int kq = 0; kq < 8; ++kq) {
+    const uint32_t o = (uint32_t)__shfl((int)hb, base + 2 * kq + par, 64);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) hm[i >> 2] |= ((o >> i) & 1u) << (8 * (i & 3) + kq);
+  }
+  if (live && ib < 2) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { ((uint16_t *)(y + 16 * par))[2 * g] = (uint16_t)hm[g]; ((uint16_t *)(y + 16 * par))[2 * g + 1] = (uint16_t)(hm[g] >> 16); }
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const uint32_t q1 = (uint32_t)__shfl((int)lo[g], base + ((ib + 2) & 15), 64), q2 = (uint32_t)__shfl((int)lo[g], base + ((ib + 4) & 15), 64),
+                   q3 = (uint32_t)__shfl((int)lo[g], base + ((ib + 6) & 15), 64);
+    if (live && qt == 0) {
+      const uint32_t v = lo[g] | (q1 << 2) | (q2 << 4) | (q3 << 6);
+      uint16_t *q = (uint16_t *)(y + 32 + 32 * h + 16 * par);  // 110-byte blocks: 2-byte aligned
+      q[2 * g] = (uint16_t)v; q[2 * g + 1] = (uint16_t)(v >> 16);
+    }
+  }
+}
+
 // Q4_0 / Q5_0 / Q4_1 / Q5_1: one thread per 32-weight block (quantize_row_q{4,5}_{0,1}_ref)
 template <class T, int TYPE>
 __global__ void __launch_bounds__(256) isq_legacy_kernel(const T *__restrict__ src, uint8_t *__restrict__ out, size_t nblocks) {
@@ -438,6 +602,8 @@ template <class T> static int isq_dispatch(const T *src, uint8_t *dst, size_t n,
   case 3: { const size_t nb = n / 32; hipLaunchKernelGGL((isq_legacy_kernel<T, 3>), dim3((unsigned)((nb + 255) / 256)), block, 0, s, src, dst, nb); return 0; }
   case 6: { const size_t nb = n / 32; hipLaunchKernelGGL((isq_legacy_kernel<T, 6>), dim3((unsigned)((nb + 255) / 256)), block, 0, s, src, dst, nb); return 0; }
   case 7: { const size_t nb = n / 32; hipLaunchKernelGGL((isq_legacy_kernel<T, 7>), dim3((unsigned)((nb + 255) / 256)), block, 0, s, src, dst, nb); return 0; }
+  case 10: { const size_t nb = n / 256; hipLaunchKernelGGL((isq_q2_k_kernel<T>), dim3((unsigned)((nb + 15) / 16)), block, 0, s, src, dst, nb); return 0; }
+  case 11: { const size_t nb = n / 256; hipLaunchKernelGGL((isq_q3_k_kernel<T>), dim3((unsigned)((nb + 15) / 16)), block, 0, s, src, dst, nb); return 0; }
   case 12: { const size_t nb = n / 256; hipLaunchKernelGGL((isq_q45_k_kernel<T, false, false>), dim3((unsigned)((nb + 31) / 32)), block, 0, s, src, dst, nb, (const float *)nullptr, 0); return 0; }
   case 13: { const size_t nb = n / 256; hipLaunchKernelGGL((isq_q45_k_kernel<T, true, false>), dim3((unsigned)((nb + 31) / 32)), block, 0, s, src, dst, nb, (const float *)nullptr, 0); return 0; }
   case 14: { const size_t nb = n / 256; hipLaunchKernelGGL((isq_q6_k_kernel<T, false>), dim3((unsigned)((nb + 15) / 16)), block, 0, s, src, dst, nb, (const float *)nullptr, 0); return 0; }
@@ -540,12 +706,12 @@ extern "C" int mrs_isq_quantize_q8_0(const void *src, int src_dtype, void *dst, 
   }
 }
 
-// ISQ to any GGML target of `generate_isq!` that the GGUF kernels read: ggml_type 2 Q4_0, 3 Q4_1, 6 Q5_0, 7 Q5_1, 8 Q8_0, 12 Q4_K, 13 Q5_K,
-// 14 Q6_K.  src dtype as above.  Returns 0, -1 for an unknown dtype / type or when n_elements is not a multiple of the block size (the
+// ISQ to any GGML target of `generate_isq!` that the GGUF kernels read: ggml_type 2 Q4_0, 3 Q4_1, 6 Q5_0, 7 Q5_1, 8 Q8_0, 10 Q2_K, 11 Q3_K,
+// 12 Q4_K, 13 Q5_K, 14 Q6_K.  src dtype as above.  Returns 0, -1 for an unknown dtype / type or when n_elements is not a multiple of the block size (the
 // reference then falls back to another dtype: utils/isq.rs:249-287).  Blocks are bit-identical to GGML's reference quantizers.
 extern "C" int mrs_isq_quantize(const void *src, int src_dtype, void *dst, long long n_elements, int ggml_type, void *stream) {
   if (n_elements <= 0) return 0;
-  const int blk = (ggml_type >= 12 && ggml_type <= 14) ? 256 : 32;
+  const int blk = (ggml_type >= 10 && ggml_type <= 14) ? 256 : 32;
   if (n_elements % blk) return -1;
   hipStream_t s = (hipStream_t)stream;
   switch (src_dtype) {

@@ -1,6 +1,6 @@
 """In-situ quantization: host-side mirror of `apply_isq` for the GGML targets (mistralrs-quant/src/utils/isq.rs:24-83,247-287,323-361,
 gguf/mod.rs:633-708).  The dense weight (bf16 / f16 / f32, as loaded from safetensors) is quantized ON THE GPU into standard GGML
-blocks (Q4_0 Q4_1 Q5_0 Q5_1 Q8_0 Q4_K Q5_K Q6_K, bit-identical to GGML's reference quantizers) and becomes a `QTensor` that the GGUF
+blocks (Q4_0 Q4_1 Q5_0 Q5_1 Q8_0 Q2_K Q3_K Q4_K Q5_K Q6_K, bit-identical to GGML's reference quantizers) and becomes a `QTensor` that the GGUF
 kernels consume -- `IsqType::Q4K` ... -> `GgufMatMul`.  `get_quantization_behaviour` mirrors the reference's dtype fallback chain."""
 from __future__ import annotations
 
@@ -33,7 +33,8 @@ def quantize_q8_0(w: torch.Tensor) -> QTensor:
     return QTensor(GgmlDType.Q8_0, (n, k), out)
 
 
-_ISQ_TARGETS = (GgmlDType.Q4_0, GgmlDType.Q4_1, GgmlDType.Q5_0, GgmlDType.Q5_1, GgmlDType.Q8_0, GgmlDType.Q4K, GgmlDType.Q5K, GgmlDType.Q6K)
+_ISQ_TARGETS = (GgmlDType.Q4_0, GgmlDType.Q4_1, GgmlDType.Q5_0, GgmlDType.Q5_1, GgmlDType.Q8_0, GgmlDType.Q2K, GgmlDType.Q3K, GgmlDType.Q4K, GgmlDType.Q5K,
+                GgmlDType.Q6K)
 # get_fallback (utils/isq.rs:247-261): the 32-wide `Q` formats are more lenient than the 256-wide `K` formats
 _FALLBACK = {GgmlDType.Q2K: GgmlDType.Q4_0, GgmlDType.Q3K: GgmlDType.Q4_0, GgmlDType.Q4K: GgmlDType.Q4_1, GgmlDType.Q5K: GgmlDType.Q5_0,
              GgmlDType.Q6K: GgmlDType.Q5_1, GgmlDType.Q8K: GgmlDType.Q8_1}

@@ -438,6 +438,133 @@ static void quantize_q6_K(const float *x, uint8_t *y, int64_t k) {
   }
 }
 
+/* ---- Q2_K / Q3_K: public GGML quantize_row_q2_K_ref / quantize_row_q3_K_ref (make_qkx2_quants with |x| weights and mean-absolute error;
+ * make_q3_quants with its 5 refinement sweeps).  ISQ targets IsqType::Q2K / Q3K (mistralrs-quant/src/lib.rs:818-819, utils/isq.rs generate_isq!).
+ * As the other quantizers: a restatement of the published algorithm behind a dependency that is not in the tree ("parity unpinned"). */
+static void quantize_q2_K(const float *x, uint8_t *y, int64_t k) {
+  uint8_t L[QK_K], Laux[16];
+  float weights[16], mins[16], scales[16];
+  const float q4scale = 15.f;
+  for (int64_t i = 0; i < k / QK_K; ++i, x += QK_K, y += 84) {
+    float max_scale = 0, max_min = 0;
+    for (int j = 0; j < 16; ++j) {
+      for (int l = 0; l < 16; ++l) weights[l] = fabsf(x[16 * j + l]);
+      scales[j] = make_qkx2_quants(16, 3, x + 16 * j, weights, L + 16 * j, &mins[j], Laux, -0.5f, 0.1f, 15, 1);
+      if (scales[j] > max_scale) max_scale = scales[j];
+      if (mins[j] > max_min) max_min = mins[j];
+    }
+    uint8_t *sc = y, *qs = y + 16;
+    if (max_scale > 0) {
+      float iscale = q4scale / max_scale;
+      for (int j = 0; j < 16; ++j) sc[j] = (uint8_t)nearest_int(iscale * scales[j]);
+      st16(y + 80, orc_fp32_to_fp16(max_scale / q4scale));
+    } else {
+      for (int j = 0; j < 16; ++j) sc[j] = 0;
+      st16(y + 80, orc_fp32_to_fp16(0.f));
+    }
+    if (max_min > 0) {
+      float iscale = q4scale / max_min;
+      for (int j = 0; j < 16; ++j) sc[j] |= (uint8_t)(nearest_int(iscale * mins[j]) << 4);
+      st16(y + 82, orc_fp32_to_fp16(max_min / q4scale));
+    } else {
+      st16(y + 82, orc_fp32_to_fp16(0.f));
+    }
+    const float dd = orc_fp16_to_fp32(ld16(y + 80)), dmin = orc_fp16_to_fp32(ld16(y + 82));
+    for (int j = 0; j < 16; ++j) {
+      const float d = dd * (sc[j] & 0xF);
+      if (!d) { for (int ii = 0; ii < 16; ++ii) L[16 * j + ii] = 0; continue; }  /* as quantize_q4_5_K here: a scale that rounds to 0 stores zeros */
+      const float dm = dmin * (sc[j] >> 4);
+      for (int ii = 0; ii < 16; ++ii) {
+        int l = nearest_int((x[16 * j + ii] + dm) / d);
+        L[16 * j + ii] = (uint8_t)imax(0, imin(3, l));
+      }
+    }
+    for (int j = 0; j < QK_K; j += 128)
+      for (int l = 0; l < 32; ++l) qs[j / 4 + l] = (uint8_t)(L[j + l] | (L[j + l + 32] << 2) | (L[j + l + 64] << 4) | (L[j + l + 96] << 6));
+  }
+}
+
+static float make_q3_quants(int n, int nmax, const float *x, int8_t *L) { /* do_rmse = true */
+  float max = 0, amax = 0;
+  for (int i = 0; i < n; ++i) { float ax = fabsf(x[i]); if (ax > amax) { amax = ax; max = x[i]; } }
+  if (amax < 1e-15f) { for (int i = 0; i < n; ++i) L[i] = 0; return 0.f; }
+  float iscale = -nmax / max, sumlx = 0, suml2 = 0;
+  for (int i = 0; i < n; ++i) {
+    int l = nearest_int(iscale * x[i]);
+    l = imax(-nmax, imin(nmax - 1, l));
+    L[i] = (int8_t)l;
+    float w = x[i] * x[i];
+    sumlx += w * x[i] * l; suml2 += w * l * l;
+  }
+  for (int itry = 0; itry < 5; ++itry) {
+    int n_changed = 0;
+    for (int i = 0; i < n; ++i) {
+      float w = x[i] * x[i];
+      float slx = sumlx - w * x[i] * L[i];
+      if (slx > 0) {
+        float sl2 = suml2 - w * L[i] * L[i];
+        int new_l = nearest_int(x[i] * sl2 / slx);
+        new_l = imax(-nmax, imin(nmax - 1, new_l));
+        if (new_l != L[i]) {
+          slx += w * x[i] * new_l; sl2 += w * new_l * new_l;
+          if (sl2 > 0 && slx * slx * suml2 > sumlx * sumlx * sl2) { L[i] = (int8_t)new_l; sumlx = slx; suml2 = sl2; ++n_changed; }
+        }
+      }
+    }
+    if (!n_changed) break;
+  }
+  for (int i = 0; i < n; ++i) L[i] = (int8_t)(L[i] + nmax);
+  return sumlx / suml2;
+}
+
+static void quantize_q3_K(const float *x, uint8_t *y, int64_t k) {
+  int8_t L[QK_K];
+  float scales[16];
+  for (int64_t i = 0; i < k / QK_K; ++i, x += QK_K, y += 110) {
+    float max_scale = 0, amax = 0;
+    for (int j = 0; j < 16; ++j) {
+      scales[j] = make_q3_quants(16, 4, x + 16 * j, L + 16 * j);
+      float a = fabsf(scales[j]);
+      if (a > amax) { amax = a; max_scale = scales[j]; }
+    }
+    uint8_t *hmask = y, *qs = y + 32, *sc12 = y + 96;
+    memset(sc12, 0, 12);
+    if (max_scale) {
+      float iscale = -32.f / max_scale;
+      for (int j = 0; j < 16; ++j) {
+        int l = nearest_int(iscale * scales[j]);
+        l = imax(-32, imin(31, l)) + 32;
+        if (j < 8) sc12[j] = (uint8_t)(l & 0xF);
+        else sc12[j - 8] |= (uint8_t)((l & 0xF) << 4);
+        l >>= 4;
+        sc12[j % 4 + 8] |= (uint8_t)(l << (2 * (j / 4)));
+      }
+      st16(y + 108, orc_fp32_to_fp16(1 / iscale));
+    } else {
+      st16(y + 108, orc_fp32_to_fp16(0.f));
+    }
+    int8_t sc16[16];
+    q3k_scales(sc12, sc16);
+    const float dd = orc_fp16_to_fp32(ld16(y + 108));
+    for (int j = 0; j < 16; ++j) {
+      float d = dd * sc16[j];
+      if (!d) continue;  /* the quants of make_q3_quants (0..7) stay */
+      for (int ii = 0; ii < 16; ++ii) {
+        int l = nearest_int(x[16 * j + ii] / d);
+        L[16 * j + ii] = (int8_t)(imax(-4, imin(3, l)) + 4);
+      }
+    }
+    memset(hmask, 0, 32);
+    int m = 0; uint8_t hm = 1;  /* the high bit of the first 32 quants goes to bit 0, of the next 32 to bit 1, ... */
+    for (int j = 0; j < QK_K; ++j) {
+      if (L[j] > 3) { hmask[m] |= hm; L[j] -= 4; }
+      if (++m == 32) { m = 0; hm <<= 1; }
+    }
+    for (int j = 0; j < QK_K; j += 128)
+      for (int l = 0; l < 32; ++l) qs[j / 4 + l] = (uint8_t)(L[j + l] | (L[j + l + 32] << 2) | (L[j + l + 64] << 4) | (L[j + l + 96] << 6));
+  }
+}
+
 /* ---- importance-weighted K-quant quantizers: public GGML `quantize_row_q{4,5,6}_K_impl` with quant_weights (what candle's
  * QTensor::quantize_imatrix runs for these formats; candle is a git dependency that is not in the tree: "parity unpinned").  Call sites in the
  * reference: mistralrs-quant/src/gguf/mod.rs:238-252 (expert stacks), utils/isq.rs generate_isq_imatrix!.  qw has one entry per input column
@@ -674,6 +801,8 @@ int orc_quantize_row(int type, const float *x, void *blocks, int64_t k) {
   case ORC_F16: for (int64_t i = 0; i < k; ++i) ((uint16_t *)blocks)[i] = orc_fp32_to_fp16(x[i]); return 0;
   case ORC_BF16: for (int64_t i = 0; i < k; ++i) ((uint16_t *)blocks)[i] = orc_fp32_to_bf16(x[i]); return 0;
   case ORC_Q4_0: case ORC_Q4_1: case ORC_Q5_0: case ORC_Q5_1: case ORC_Q8_0: quantize_legacy(type, x, blocks, k); return 0;
+  case ORC_Q2_K: quantize_q2_K(x, blocks, k); return 0;
+  case ORC_Q3_K: quantize_q3_K(x, blocks, k); return 0;
   case ORC_Q4_K: case ORC_Q5_K: quantize_q4_5_K(type, x, blocks, k); return 0;
   case ORC_Q6_K: quantize_q6_K(x, blocks, k); return 0;
   case ORC_Q8_K: orc_quantize_q8_K(x, blocks, k); return 0;

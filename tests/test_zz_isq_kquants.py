@@ -1,4 +1,4 @@
-"""ISQ on the device for every GGML target the GGUF kernels read (`mrs_isq_quantize`: Q4_0 Q4_1 Q5_0 Q5_1 Q8_0 Q4_K Q5_K Q6_K; reference:
+"""ISQ on the device for every GGML target the GGUF kernels read (`mrs_isq_quantize`: Q4_0 Q4_1 Q5_0 Q5_1 Q8_0 Q2_K Q3_K Q4_K Q5_K Q6_K; reference:
 `generate_isq!` -> candle `QTensor::quantize` on the host cores, mistralrs-quant/src/utils/isq.rs:323-361).  The device blocks must be
 BIT-IDENTICAL to the oracle's restatement of GGML's reference quantizers (make_qkx2_quants / make_qx_quants searches included), from f32,
 f16 and bf16 sources, including degenerate blocks.  Same body on the wave64 host emulation (CPU) and on the MI355X (`-m gpu`);
@@ -11,7 +11,7 @@ import pytest
 from tests.abi_backends import GpuBackend, HostBackend
 from tests.util import round_through
 
-TARGETS = ["Q4_0", "Q4_1", "Q5_0", "Q5_1", "Q8_0", "Q4_K", "Q5_K", "Q6_K"]
+TARGETS = ["Q4_0", "Q4_1", "Q5_0", "Q5_1", "Q8_0", "Q2_K", "Q3_K", "Q4_K", "Q5_K", "Q6_K"]
 SRC_CODE = {"f32": 0, "f16": 1, "bf16": 30}
 
 
@@ -51,7 +51,7 @@ def test_isq_partial_workgroups_host_emulation(oracle):
     be = HostBackend()
     fn = be.sym("mrs_isq_quantize", [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p], C.c_int)
     rng = np.random.default_rng(1)
-    for t, nblk in ((oracle.Q4_K, 33), (oracle.Q5_K, 1), (oracle.Q6_K, 17), (oracle.Q8_0, 9), (oracle.Q4_0, 257)):
+    for t, nblk in ((oracle.Q4_K, 33), (oracle.Q5_K, 1), (oracle.Q6_K, 17), (oracle.Q2_K, 17), (oracle.Q3_K, 5), (oracle.Q8_0, 9), (oracle.Q4_0, 257)):
         k = oracle.block_size(t) * nblk
         w = rng.standard_normal((1, k)).astype(np.float32)
         want = oracle.quantize(t, w)
