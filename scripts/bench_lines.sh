@@ -1,4 +1,6 @@
 #!/bin/bash
+# Evidence pass of a round in one gpurun call: scripts/profile_round.sh (GPU suite, default bench line, smoke, rocprofv3 kernel trace + PMC passes), then the
+# other bench lines of profiles/round<N>_bench_lines.md.
 cd /root/repo
 export TMPDIR=/tmp
 bash scripts/profile_round.sh round3
