@@ -927,6 +927,7 @@ extern "C" int mrs_dec_attention(float *out_f32, void *img_out, unsigned *ticket
   t.window = sliding_window > 0 ? sliding_window : 0;
   const int nblk = (max_context_len + 31) / 32;
   t.bpw = nblk <= 64 ? 1 : (nblk + 63) / 64;                        // == dec_bpw() of paged_attention.hip: at most 64 splits
+  { static const int force = [] { const char *e = getenv("MRS_DEC_ATTN_BPW"); return e ? atoi(e) : 0; }(); if (force > 0) t.bpw = force; }  // measurements only: the oracle's order follows the rule above
   t.max_splits = mrs_decode_attention_max_splits(max_context_len);  // stride of the partials, as in the two-launch route
   a.ticket = ticket; a.img = with_img ? (uint8_t *)img_out : nullptr;
   const int nsplit = (nblk + t.bpw - 1) / t.bpw;
