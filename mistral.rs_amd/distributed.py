@@ -237,27 +237,44 @@ class P2PAllReduce:
         L.mrs_p2p_alloc_mailbox.restype = C.c_void_p
         L.mrs_p2p_alloc_mailbox.argtypes = [C.c_size_t]
         L.mrs_p2p_free_mailbox.argtypes = [C.c_void_p]
+        # Every step that can fail on one rank only is followed by an exchange of the outcome, so that all ranks leave through the same door
+        # (a rank that raised while its peers sit in a collective would hang the job instead of falling back to RCCL).
+        err, mine = None, (C.c_char * 64)()
         self.mailbox_ptr = L.mrs_p2p_alloc_mailbox(L.mrs_p2p_mailbox_bytes(world_size, max_elems))
         if not self.mailbox_ptr:
-            raise RuntimeError((L.mrs_last_error() or b"").decode())
-        mine = (C.c_char * 64)()
-        if L.mrs_ipc_get_handle(self.mailbox_ptr, mine) != 0:
-            raise RuntimeError((L.mrs_last_error() or b"").decode())
-        handles = [None] * world_size
-        dist.all_gather_object(handles, bytes(mine))
+            err = "mailbox allocation: " + (L.mrs_last_error() or b"").decode()
+        elif L.mrs_ipc_get_handle(self.mailbox_ptr, mine) != 0:
+            err = "hipIpcGetMemHandle: " + (L.mrs_last_error() or b"").decode()
+        got = [None] * world_size
+        dist.all_gather_object(got, (err, bytes(mine)))
+        bad = [f"rank {r}: {e}" for r, (e, _) in enumerate(got) if e]
+        if bad:
+            self._release()
+            raise RuntimeError("p2p all-reduce unavailable (" + "; ".join(bad) + ")")
         ptrs = (C.c_void_p * world_size)()
-        for r, hb in enumerate(handles):
+        for r, (_, hb) in enumerate(got):
             if r == rank:
                 ptrs[r] = self.mailbox_ptr
-            else:
-                p = L.mrs_ipc_open_handle(C.create_string_buffer(hb, 64))
-                if not p:
-                    raise RuntimeError((L.mrs_last_error() or b"").decode())
-                ptrs[r] = p
-        dist.barrier()  # every mailbox is zeroed and mapped before the first granule is written
+                continue
+            p = L.mrs_ipc_open_handle(C.create_string_buffer(hb, 64))
+            if not p:
+                err = f"hipIpcOpenMemHandle(rank {r}): " + (L.mrs_last_error() or b"").decode()
+                break
+            ptrs[r] = p
+        got2 = [None] * world_size
+        dist.all_gather_object(got2, err)  # also the barrier: every mailbox is zeroed and mapped before the first granule is written
+        bad = [f"rank {r}: {e}" for r, e in enumerate(got2) if e]
+        if bad:
+            self._release()
+            raise RuntimeError("p2p all-reduce unavailable (" + "; ".join(bad) + ")")
         self.handle = L.mrs_p2p_create(rank, world_size, ptrs, max_elems)
         if not self.handle:
             raise RuntimeError((L.mrs_last_error() or b"").decode())
+
+    def _release(self) -> None:
+        if getattr(self, "mailbox_ptr", None):
+            self._L.mrs_p2p_free_mailbox(self.mailbox_ptr)
+            self.mailbox_ptr = None
 
     def all_reduce_(self, t: torch.Tensor) -> torch.Tensor:
         assert t.dtype == torch.float32 and t.is_contiguous()

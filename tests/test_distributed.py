@@ -308,6 +308,33 @@ def test_rccl_comm_world1_and_runner(oracle, dev):
             dist.destroy_process_group()
 
 
+@pytest.mark.gpu
+def test_p2p_all_reduce_class_world1_ipc_handle_on_fine_grained_memory(dev):
+    """`P2PAllReduce` set-up on one rank: the mailbox comes from hipExtMallocWithFlags (uncached: a peer's store must reach a kernel that is already
+    polling), and `hipIpcGetMemHandle` has to accept that allocation -- the step a multi-GPU run depends on and a 1-GPU box can still execute.  World 1:
+    the all-reduce is the identity, twice (both parities), without an error flag."""
+    import torch
+    import torch.distributed as dist
+    from mistralrs_amd import distributed as D
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29633", rank=0, world_size=1)
+        created = True
+    try:
+        p2p = D.P2PAllReduce(0, 1, dev, max_elems=4096)
+        x = torch.arange(3000, dtype=torch.float32, device=dev) * 0.5 - 7
+        for _ in range(3):
+            y = x.clone()
+            p2p.all_reduce_(y)
+            torch.cuda.synchronize()
+            assert torch.equal(y, x) and p2p.error() == 0
+        with pytest.raises(RuntimeError, match="larger than the mailboxes"):
+            p2p.all_reduce_(torch.zeros(5000, dtype=torch.float32, device=dev))
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_llama3_70b_tp8_placement_shapes():
     """BASELINE configs[3] (Llama-3-70B Q4_K_M, TP=8): per-rank shapes as SURVEY 8a lists them (q 1024x8192, k/v 128x8192 = one KV head
     per rank, o 8192x1024, gate/up 3584x8192, down 8192x3584) and every row-parallel cut on a 256-weight superblock boundary."""
