@@ -342,12 +342,16 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 3) mmq_mfma_kernel(MmqA
 // term.  The run of index r = 8 h + 2 q + lh (half, quarter, 16-half) starts at element 128 h + 32 q + 16 lh of the superblock, its low bits are
 // nibble (q >> 1) of ql[64 h + 32 (q & 1) + 16 lh ..], its high bits the 2-bit field q of qh[32 h + 16 lh ..].  Twice the fix-ups per weight of
 // the Q4_K route (16 cvt + 8 pk_mul + 8 pk_fma per 16 k): about 0.6 x its rate.
-template <class OUT, int NW, int NT>
-__global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 3) mmq_mfma_q6k_kernel(MmqArgs a) {
+template <int TYPE, class OUT, int NW, int NT>
+__global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 3) mmq_mfma_k16_kernel(MmqArgs a) {
+  static_assert(TYPE == T_Q6_K || TYPE == T_Q3_K || TYPE == T_Q2_K, "K-quants with 16-value scales: Q6_K / Q3_K (no minimum, D4 activations), Q2_K (minimum, D2S6)");
+  constexpr bool Q2 = TYPE == T_Q2_K;
   constexpr int MM_ROWS = 32 * NW, MM_COLS = 32 * NT, NTHR = 64 * NW;
-  constexpr int TS = 210;
+  constexpr int TS = Fmt<TYPE>::TS;
   __shared__ __attribute__((aligned(16))) uint8_t raw[2 * MM_COLS * MMQ_BLOCK_BYTES];
-  __shared__ __attribute__((aligned(16))) float hdr[8 * MM_COLS];                       // [32-value group][column] d8
+  // D4 (Q6_K, Q3_K): [32-value group 8][column] d8.  D2S6 (Q2_K): [16-value run 16][column]{d8 of the run's 64-value half, the partner of the minimum:
+  // the stored sum of the run for the first 96 values of a 128-block, d8 * SUM(u) for the last 32 (mmq_gguf.cuh:70-89)}
+  __shared__ __attribute__((aligned(16))) float hdr[(Q2 ? 32 : 8) * MM_COLS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 5;
   const int64_t col_low = a.expert_bounds ? a.expert_bounds[blockIdx.z] : 0;
   const int64_t col_high = a.expert_bounds ? a.expert_bounds[blockIdx.z + 1] : a.ncols_y;
@@ -365,17 +369,51 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 3) mmq_mfma_q6k_kernel(
   const mm_v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int sb = 0; sb < nsb; ++sb) {
     const uint8_t *b = wrow + (int64_t)sb * TS;
-    int2_a2 ql8[2][2][2], qh8[2][2];  // [h][q & 1][lh], [h][lh]: this lane's 8 bytes (2-byte aligned blocks)
+    // this lane's 8 bytes of every piece (2-byte aligned blocks).  Q6_K: ql8 [h][q & 1][lh] low nibbles, qh8 [h][lh] 2-bit fields, 16 int8 scales.
+    // Q3_K (hmask[32] qs[64] scales[12] d): ql8 [h][0][lh] = qs bytes (2-bit field q), qh8 [0][lh] = hmask bytes (bit 4 h + q), 6-bit scales minus 32.
+    int2_a2 ql8[2][2][2], qh8[2][2];
+    int sc4[4];
+    float d, dmin = 0.0f;
+    if constexpr (Q2) {  // scales[16] (scale | min << 4), qs[64], half d, half dmin: 84 B, 4-byte aligned
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int lh = 0; lh < 2; ++lh) { ql8[h][0][lh] = *(const int2_a2 *)(b + 16 + 32 * h + 16 * lh + 8 * kh); ql8[h][1][lh] = ql8[h][0][lh]; qh8[h][lh] = ql8[h][0][lh]; }
+      const int4 scw = ld16_a4(b);
+      sc4[0] = scw.x; sc4[1] = scw.y; sc4[2] = scw.z; sc4[3] = scw.w;
+      const unsigned dd = (unsigned)ld4_a2(b + 80);
+      d = half_bits_to_float((uint16_t)(dd & 0xffffu));
+      dmin = half_bits_to_float((uint16_t)(dd >> 16));
+    } else if constexpr (TYPE == T_Q6_K) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int lh = 0; lh < 2; ++lh) {
+          qh8[h][lh] = *(const int2_a2 *)(b + 128 + 32 * h + 16 * lh + 8 * kh);
+#pragma unroll
+          for (int p = 0; p < 2; ++p) ql8[h][p][lh] = *(const int2_a2 *)(b + 64 * h + 32 * p + 16 * lh + 8 * kh);
+        }
+      const int4 scw = ld16_a2(b + 192);
+      sc4[0] = scw.x; sc4[1] = scw.y; sc4[2] = scw.z; sc4[3] = scw.w;
+      d = half_bits_to_float(ld2(b + 208));
+    } else {
 #pragma unroll
       for (int lh = 0; lh < 2; ++lh) {
-        qh8[h][lh] = *(const int2_a2 *)(b + 128 + 32 * h + 16 * lh + 8 * kh);
+        qh8[0][lh] = *(const int2_a2 *)(b + 16 * lh + 8 * kh);
+        qh8[1][lh] = qh8[0][lh];
 #pragma unroll
-        for (int p = 0; p < 2; ++p) ql8[h][p][lh] = *(const int2_a2 *)(b + 64 * h + 32 * p + 16 * lh + 8 * kh);
+        for (int h = 0; h < 2; ++h) { ql8[h][0][lh] = *(const int2_a2 *)(b + 32 + 32 * h + 16 * lh + 8 * kh); ql8[h][1][lh] = ql8[h][0][lh]; }
       }
-    const int4 scw = ld16_a2(b + 192);
-    const float d = half_bits_to_float(ld2(b + 208));
+      const unsigned s0 = (unsigned)ld4_a2(b + 96), s1 = (unsigned)ld4_a2(b + 100), s2 = (unsigned)ld4_a2(b + 104);
+      // scale j = (j < 8 ? s[j] & 15 : s[j - 8] >> 4) | ((s[8 + j % 4] >> 2 (j / 4)) & 3) << 4, minus 32: four per dword, as signed bytes
+      const unsigned lo[4] = {s0 & 0x0f0f0f0fu, s1 & 0x0f0f0f0fu, (s0 >> 4) & 0x0f0f0f0fu, (s1 >> 4) & 0x0f0f0f0fu};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const unsigned v = lo[g] | (((s2 >> (2 * g)) & 0x03030303u) << 4);
+        sc4[g] = (int)(((v | 0x80808080u) - 0x20202020u) ^ 0x80808080u);
+      }
+      d = half_bits_to_float(ld2(b + 108));
+    }
     __syncthreads();
     for (int p = tid; p < 2 * MM_COLS; p += NTHR) {
       const int kb = p / MM_COLS, cc = p % MM_COLS;
@@ -385,23 +423,45 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 3) mmq_mfma_q6k_kernel(
       const int4 v0 = ld16_a16(src);
 #pragma unroll
       for (int pc = 1; pc < 9; ++pc) *(int4 *)(dstb + pc * 16) = ld16_a16(src + pc * 16);
-      const int w4[4] = {v0.x, v0.y, v0.z, v0.w};  // D4: four f32 scales
+      const int w4[4] = {v0.x, v0.y, v0.z, v0.w};
+      if constexpr (Q2) {  // D2S6: two half scales (per 64 values), six half sums (16-runs 0..5); runs 6, 7 sum their ints
+        const float dh[2] = {half_bits_to_float((uint16_t)((unsigned)w4[0] & 0xffffu)), half_bits_to_float((uint16_t)((unsigned)w4[0] >> 16))};
+        const int4 ones = make_int4(0x01010101, 0x01010101, 0x01010101, 0x01010101);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) hdr[(kb * 4 + g) * MM_COLS + cc] = __int_as_float(w4[g]);
+        for (int r = 0; r < 8; ++r) {
+          float so;
+          if (r < 6) so = half_bits_to_float((uint16_t)(((unsigned)w4[1 + r / 2] >> (16 * (r & 1))) & 0xffffu));
+          else so = dh[1] * (float)dot16(ones, *(const int4 *)(dstb + 16 + 16 * r));
+          float *o = hdr + ((kb * 8 + r) * MM_COLS + cc) * 2;
+          o[0] = dh[r >> 2];
+          o[1] = so;
+        }
+      } else {  // D4: four f32 scales
+#pragma unroll
+        for (int g = 0; g < 4; ++g) hdr[(kb * 4 + g) * MM_COLS + cc] = __int_as_float(w4[g]);
+      }
     }
     __syncthreads();
-    const int sc4[4] = {scw.x, scw.y, scw.z, scw.w};
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       __builtin_amdgcn_sched_barrier(0);
       const int h = r >> 3, q = (r >> 1) & 3, lh = r & 1;
-      const float dsc = d * (float)(int)(int8_t)(((unsigned)sc4[r >> 2] >> (8 * (r & 3))) & 0xffu);
+      const unsigned scb = ((unsigned)sc4[r >> 2] >> (8 * (r & 3))) & 0xffu;
+      const float dsc = Q2 ? d * (float)(scb & 15u) : d * (float)(int)(int8_t)scb;
+      const float ndm = Q2 ? -(dmin * (float)(scb >> 4)) : 0.0f;
       const int lw[2] = {ql8[h][q & 1][lh].x, ql8[h][q & 1][lh].y}, hw[2] = {qh8[h][lh].x, qh8[h][lh].y};
       unsigned bw[2];
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const unsigned v = (((unsigned)lw[e] >> (4 * (q >> 1))) & 0x0f0f0f0fu) | ((((unsigned)hw[e] >> (2 * q)) & 0x03030303u) << 4);
-        bw[e] = ((v | 0x80808080u) - 0x20202020u) ^ 0x80808080u;  // per byte q - 32, no borrow across bytes
+        if constexpr (Q2) {
+          bw[e] = ((unsigned)lw[e] >> (2 * q)) & 0x03030303u;  // 0..3: the minimum is a separate term
+        } else if constexpr (TYPE == T_Q6_K) {
+          const unsigned v = (((unsigned)lw[e] >> (4 * (q >> 1))) & 0x0f0f0f0fu) | ((((unsigned)hw[e] >> (2 * q)) & 0x03030303u) << 4);
+          bw[e] = ((v | 0x80808080u) - 0x20202020u) ^ 0x80808080u;  // per byte q - 32, no borrow across bytes
+        } else {
+          const unsigned v = (((unsigned)lw[e] >> (2 * q)) & 0x03030303u) | ((((unsigned)hw[e] >> (4 * h + q)) & 0x01010101u) << 2);
+          bw[e] = ((v | 0x80808080u) - 0x04040404u) ^ 0x80808080u;  // per byte q - 4
+        }
       }
       const long bf = (long)(((unsigned long long)bw[1] << 32) | bw[0]);
 #pragma unroll
@@ -411,11 +471,20 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 3) mmq_mfma_q6k_kernel(
         const mm_v16i is = __builtin_amdgcn_mfma_i32_32x32x16_i8(af, bf, zero, 0, 0, 0);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const float4 h0 = *(const float4 *)(hdr + (r >> 1) * MM_COLS + 32 * t + 8 * g + 4 * kh);
-          acc[t][4 * g + 0] = fmaf((float)is[4 * g + 0], dsc * h0.x, acc[t][4 * g + 0]);
-          acc[t][4 * g + 1] = fmaf((float)is[4 * g + 1], dsc * h0.y, acc[t][4 * g + 1]);
-          acc[t][4 * g + 2] = fmaf((float)is[4 * g + 2], dsc * h0.z, acc[t][4 * g + 2]);
-          acc[t][4 * g + 3] = fmaf((float)is[4 * g + 3], dsc * h0.w, acc[t][4 * g + 3]);
+          if constexpr (Q2) {
+            const float4 h0 = *(const float4 *)(hdr + (r * MM_COLS + 32 * t + 8 * g + 4 * kh) * 2);
+            const float4 h1 = *(const float4 *)(hdr + (r * MM_COLS + 32 * t + 8 * g + 4 * kh + 2) * 2);
+            acc[t][4 * g + 0] = fmaf(ndm, h0.y, fmaf((float)is[4 * g + 0], dsc * h0.x, acc[t][4 * g + 0]));
+            acc[t][4 * g + 1] = fmaf(ndm, h0.w, fmaf((float)is[4 * g + 1], dsc * h0.z, acc[t][4 * g + 1]));
+            acc[t][4 * g + 2] = fmaf(ndm, h1.y, fmaf((float)is[4 * g + 2], dsc * h1.x, acc[t][4 * g + 2]));
+            acc[t][4 * g + 3] = fmaf(ndm, h1.w, fmaf((float)is[4 * g + 3], dsc * h1.z, acc[t][4 * g + 3]));
+          } else {
+            const float4 h0 = *(const float4 *)(hdr + (r >> 1) * MM_COLS + 32 * t + 8 * g + 4 * kh);
+            acc[t][4 * g + 0] = fmaf((float)is[4 * g + 0], dsc * h0.x, acc[t][4 * g + 0]);
+            acc[t][4 * g + 1] = fmaf((float)is[4 * g + 1], dsc * h0.y, acc[t][4 * g + 1]);
+            acc[t][4 * g + 2] = fmaf((float)is[4 * g + 2], dsc * h0.z, acc[t][4 * g + 2]);
+            acc[t][4 * g + 3] = fmaf((float)is[4 * g + 3], dsc * h0.w, acc[t][4 * g + 3]);
+          }
         }
       }
     }
@@ -560,7 +629,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 3) mmq_mfma_b32_kernel(
 }
 
 template <int TYPE> constexpr bool mmq_is_b32() { return TYPE == T_Q8_0 || TYPE == T_Q4_0 || TYPE == T_Q4_1 || TYPE == T_Q5_0 || TYPE == T_Q5_1; }
-template <int TYPE> constexpr bool mmq_has_mfma() { return TYPE == T_Q4_K || TYPE == T_Q5_K || TYPE == T_Q6_K || mmq_is_b32<TYPE>(); }
+template <int TYPE> constexpr bool mmq_has_mfma() { return TYPE == T_Q4_K || TYPE == T_Q5_K || TYPE == T_Q6_K || TYPE == T_Q3_K || TYPE == T_Q2_K || mmq_is_b32<TYPE>(); }
 // prompt-sized launches of the two DS4 K-quants go to the matrix cores (MRS_MMQ_MFMA=0: keep the v_dot4 kernel, for A/B measurements)
 static int g_mmq_small_below = -1;  // < 0: not set yet (MRS_MMQ_SMALL_TILES_BELOW, default 384 = 1.5 workgroups of 128 x 128 per CU)
 static int mmq_small_tiles_below() {
@@ -581,12 +650,12 @@ template <int TYPE, class OUT> static void launch_mmq_t(const MmqArgs &a, int64_
       const int64_t big = ((a.nrows_x + 127) / 128) * ((ncols_max + 127) / 128) * channels;
       if (big >= mmq_small_tiles_below()) {
         const dim3 grid((unsigned)((a.nrows_x + 127) / 128), (unsigned)((ncols_max + 127) / 128), (unsigned)channels);
-        if constexpr (TYPE == T_Q6_K) hipLaunchKernelGGL((mmq_mfma_q6k_kernel<OUT, 4, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);
+        if constexpr (TYPE == T_Q6_K || TYPE == T_Q3_K || TYPE == T_Q2_K) hipLaunchKernelGGL((mmq_mfma_k16_kernel<TYPE, OUT, 4, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);
         else if constexpr (mmq_is_b32<TYPE>()) hipLaunchKernelGGL((mmq_mfma_b32_kernel<TYPE, OUT, 4, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);
         else hipLaunchKernelGGL((mmq_mfma_kernel<TYPE, OUT, 4, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);
       } else {
         const dim3 grid((unsigned)((a.nrows_x + 63) / 64), (unsigned)((ncols_max + 63) / 64), (unsigned)channels);
-        if constexpr (TYPE == T_Q6_K) hipLaunchKernelGGL((mmq_mfma_q6k_kernel<OUT, 2, 2>), grid, dim3(128), 0, (hipStream_t)stream, a);
+        if constexpr (TYPE == T_Q6_K || TYPE == T_Q3_K || TYPE == T_Q2_K) hipLaunchKernelGGL((mmq_mfma_k16_kernel<TYPE, OUT, 2, 2>), grid, dim3(128), 0, (hipStream_t)stream, a);
         else if constexpr (mmq_is_b32<TYPE>()) hipLaunchKernelGGL((mmq_mfma_b32_kernel<TYPE, OUT, 2, 2>), grid, dim3(128), 0, (hipStream_t)stream, a);
         else hipLaunchKernelGGL((mmq_mfma_kernel<TYPE, OUT, 2, 2>), grid, dim3(128), 0, (hipStream_t)stream, a);
       }

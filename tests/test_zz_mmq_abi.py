@@ -196,7 +196,7 @@ def check_mmq_row_paths(oracle, be, t, n, k, cols):
     fn(None, W.ptr, Y.ptr, D7.ptr, k, 7, cols, k // oracle.block_size(t), 7, 0, 256, 160 << 10, 64, 0, be.stream)
     got = D.numpy().astype(np.float64)
     assert (np.abs(got - want) <= _tol(k, mag, want, "f32")).all()
-    if oracle.TYPE_NAMES[t] not in ("q2_k", "q3_k") and cols >= 48 and k % 256 == 0:
+    if cols >= 48 and k % 256 == 0:
         return  # prompt-sized launches of the DS4 K-quants run on the matrix cores (mmq_mfma_kernel): same integers, another f32 summation order
     assert np.array_equal(D.numpy()[:, :7], D7.numpy())
 
@@ -214,7 +214,8 @@ def test_mmq_moe_host_emulation(oracle, tname):
 
 
 MFMA_CASES = [("q4_k", "f32", 200, 512, 70), ("q5_k", "bf16", 33, 256, 130), ("q4_k", "f16", 129, 768, 48), ("q6_k", "f32", 200, 512, 70), ("q6_k", "bf16", 40, 256, 129),
-              ("q8_0", "f32", 200, 384, 70), ("q4_0", "f16", 45, 128, 130), ("q4_1", "f32", 33, 640, 48), ("q5_0", "f32", 100, 256, 64), ("q5_1", "bf16", 64, 384, 50)]
+              ("q8_0", "f32", 200, 384, 70), ("q4_0", "f16", 45, 128, 130), ("q4_1", "f32", 33, 640, 48), ("q5_0", "f32", 100, 256, 64), ("q5_1", "bf16", 64, 384, 50),
+              ("q3_k", "f32", 200, 512, 70), ("q3_k", "f16", 33, 256, 129), ("q2_k", "f32", 200, 512, 70), ("q2_k", "bf16", 40, 768, 49)]
 
 
 @pytest.mark.parametrize("tname,dt,n,k,cols", MFMA_CASES)
@@ -233,7 +234,7 @@ def test_mmq_matrix_core_route_host_emulation(oracle, tname, dt, n, k, cols):
         policy(384)
 
 
-@pytest.mark.parametrize("tname", ["q4_k", "q5_k", "q6_k", "q8_0", "q5_0", "q4_1"])
+@pytest.mark.parametrize("tname", ["q4_k", "q5_k", "q6_k", "q8_0", "q5_0", "q4_1", "q3_k", "q2_k"])
 def test_mmq_matrix_core_route_moe_host_emulation(oracle, tname):
     t = {v: k for k, v in oracle.TYPE_NAMES.items()}[tname]
     check_mmq_moe(oracle, HostBackend(), t, 40, 256, 3, [50, 0, 70])
@@ -241,7 +242,7 @@ def test_mmq_matrix_core_route_moe_host_emulation(oracle, tname):
 
 # ------------------------------------------------------------------------------------------------ MI355X
 @pytest.mark.gpu
-@pytest.mark.parametrize("tname,dt,n,k,cols", MFMA_CASES + [("q4_k", "f32", 1030, 4096, 512), ("q5_k", "f32", 4100, 1024, 257), ("q6_k", "f32", 1030, 4096, 512), ("q8_0", "f32", 1030, 4096, 512), ("q4_0", "f32", 515, 2048, 300)])
+@pytest.mark.parametrize("tname,dt,n,k,cols", MFMA_CASES + [("q4_k", "f32", 1030, 4096, 512), ("q5_k", "f32", 4100, 1024, 257), ("q6_k", "f32", 1030, 4096, 512), ("q8_0", "f32", 1030, 4096, 512), ("q4_0", "f32", 515, 2048, 300), ("q3_k", "f32", 1030, 4096, 512), ("q2_k", "f32", 515, 2048, 300)])
 def test_mmq_matrix_core_route_gpu(oracle, dev, tname, dt, n, k, cols):
     t = {v: k_ for k_, v in oracle.TYPE_NAMES.items()}[tname]
     be = GpuBackend(dev)
@@ -255,7 +256,7 @@ def test_mmq_matrix_core_route_gpu(oracle, dev, tname, dt, n, k, cols):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tname", ["q4_k", "q5_k", "q6_k", "q8_0", "q5_0", "q4_1"])
+@pytest.mark.parametrize("tname", ["q4_k", "q5_k", "q6_k", "q8_0", "q5_0", "q4_1", "q3_k", "q2_k"])
 def test_mmq_matrix_core_route_moe_gpu(oracle, dev, tname):
     t = {v: k for k, v in oracle.TYPE_NAMES.items()}[tname]
     check_mmq_moe(oracle, GpuBackend(dev), t, 40, 256, 3, [50, 0, 70])
