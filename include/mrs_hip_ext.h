@@ -51,6 +51,11 @@ int mrs_dec_repack(const void *gguf_blocks, int ggml_type, long long n, long lon
 int mrs_dec_qkv(const mrs_dec_mat *wq, const mrs_dec_mat *wk, const mrs_dec_mat *wv, const float *h, int ldh, const float *norm_w, float eps,
                 float *q_out, void *k_cache, void *v_cache, const int64_t *slot_mapping, const int32_t *positions, const float *cos_t,
                 const float *sin_t, int head_dim, int rot_pairs, int num_kv_heads, int block_size, int kv_dtype, int b, void *stream);
+/* rotate-half ("neox") RoPE: wq / wk repacked from rows in pair order (inside every head the original rows 0, hd/2, 1, hd/2 + 1, ...); results land in the
+ * model's dim order (RotaryEmbedding::forward with is_gpt_neox, mistralrs-core/src/layers.rs:2978); needs rot_pairs * 2 == head_dim */
+int mrs_dec_qkv_neox(const mrs_dec_mat *wq, const mrs_dec_mat *wk, const mrs_dec_mat *wv, const float *h, int ldh, const float *norm_w, float eps,
+                     float *q_out, void *k_cache, void *v_cache, const int64_t *slot_mapping, const int32_t *positions, const float *cos_t,
+                     const float *sin_t, int head_dim, int rot_pairs, int num_kv_heads, int block_size, int kv_dtype, int b, void *stream);
 /* RmsNorm + act(W_g x) * (W_u x) -> act_out f32 [b][ld_out]; n = rows per expert, expert_sel = device pointer to the expert id (NULL: dense) */
 int mrs_dec_gate_up(const mrs_dec_mat *wg, const mrs_dec_mat *wu, int n, const int32_t *expert_sel, const float *h, int ldh, const float *norm_w,
                     float eps, int activation, float *act_out, int ld_out, int b, void *stream);

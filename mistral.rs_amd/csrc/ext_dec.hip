@@ -36,6 +36,7 @@ struct GemvArgs {
   float *q_out; void *k_cache, *v_cache; const int64_t *slot_mapping; const int32_t *positions; const float *cos_t, *sin_t;
   int head_dim, rot_pairs, num_kv_heads, block_size, cache_x, kv_f16;
   int units, units_per_wave;
+  int neox;     // EPI_QKV: rows of q / k are stored in PAIR order (original rows i, i + head_dim / 2 of a head adjacent): rotate-half RoPE; results go back to i, i + head_dim / 2
   int upw3[3];  // EPI_QKV: RoPE pairs per wave of q, k, v (the byte-heaviest tensors get the shorter runs; 0 = units_per_wave)
   int wstart[4];  // EPI_QKV: first wave of q, k, v and the total
   const int32_t *expert_sel;  // stacked experts [E * nrows][K]: rows of expert e start at e * nrows (nullptr = dense)
@@ -245,6 +246,9 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
       const int lr = row - 1;          // even row of the pair
       const int pi = (lr - r0) >> 1;   // pair index inside the wave
       const int head = lr / a.head_dim, dd = lr % a.head_dim;
+      // where the two results live: adjacent dims (interleaved RoPE), or dims i and i + head_dim / 2 when the rows were stored in pair order (v: never)
+      const bool nx = a.neox && mi < 2;
+      const int d0 = nx ? dd >> 1 : dd, d1 = nx ? d0 + (a.head_dim >> 1) : dd + 1;
 #pragma unroll
       for (int c = 0; c < NCOLS; ++c) {
         const float cs = rl(pcs[c], pi), sn = rl(psn[c], pi);
@@ -252,8 +256,8 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
         rope_pair<float>(prev[c], sum[c], cs, sn, x, y);
         if (lane == 0) {
           if (mi == 0) {
-            st_out<LATE>(a.q_out + (size_t)c * a.nrows[0] + lr, x);
-            st_out<LATE>(a.q_out + (size_t)c * a.nrows[0] + lr + 1, y);
+            st_out<LATE>(a.q_out + (size_t)c * a.nrows[0] + head * a.head_dim + d0, x);
+            st_out<LATE>(a.q_out + (size_t)c * a.nrows[0] + head * a.head_dim + d1, y);
           } else {
             const int64_t slot = slots[c];
             if (slot >= 0) {
@@ -262,9 +266,9 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
               const uint16_t xb = a.kv_f16 ? float_to_half_bits(x) : float_to_bf16_bits(x), yb = a.kv_f16 ? float_to_half_bits(y) : float_to_bf16_bits(y);
               if (mi == 1) {
                 const int X = a.cache_x;
-                const int64_t o = ((blk * a.num_kv_heads + head) * (a.head_dim / X) + dd / X) * a.block_size * X + off * X + dd % X;
-                kc[o] = xb;
-                kc[o + 1] = yb;  // dd is even and X is even: same 16-byte group
+                const int64_t hb = (blk * a.num_kv_heads + head) * (a.head_dim / X);
+                kc[(hb + d0 / X) * a.block_size * X + off * X + d0 % X] = xb;
+                kc[(hb + d1 / X) * a.block_size * X + off * X + d1 % X] = yb;  // interleaved: d1 = d0 + 1, same 16-byte group
               } else {
                 const int64_t o = ((blk * a.num_kv_heads + head) * a.head_dim + dd) * a.block_size + off;
                 vc[o] = xb;
@@ -802,10 +806,12 @@ extern "C" int mrs_dec_repack(const void *gguf_blocks, int type, long long n, lo
 
 // q, k, v projections of the decode step: h [b][ldh] f32 -> RMSNorm -> quantize -> GEMV -> RoPE (interleaved pairs) -> q_out f32 [b][nq],
 // k / v into the paged cache (kv_dtype 1 = bf16, 0 = f16).  All three tensors must share the activation format (K-quants or Q8_0).
-extern "C" int mrs_dec_qkv(const mrs_dec_mat_c *wq, const mrs_dec_mat_c *wk, const mrs_dec_mat_c *wv, const float *h, int ldh, const float *norm_w, float eps,
-                           float *q_out, void *k_cache, void *v_cache, const int64_t *slot_mapping, const int32_t *positions, const float *cos_t,
-                           const float *sin_t, int head_dim, int rot_pairs, int num_kv_heads, int block_size, int kv_dtype, int b, void *stream) {
+static int dec_qkv_impl(const mrs_dec_mat_c *wq, const mrs_dec_mat_c *wk, const mrs_dec_mat_c *wv, const float *h, int ldh, const float *norm_w, float eps,
+                        float *q_out, void *k_cache, void *v_cache, const int64_t *slot_mapping, const int32_t *positions, const float *cos_t,
+                        const float *sin_t, int head_dim, int rot_pairs, int num_kv_heads, int block_size, int kv_dtype, int b, int neox, void *stream) {
   GemvArgs a{};
+  a.neox = neox;
+  if (neox && rot_pairs * 2 != head_dim) return -1;  // pair order (i, i + head_dim / 2) is the rotate-half pairing only when every dim rotates
   if (!wq || !wk || !wv || !make_mat(a.m[0], wq->planes, wq->type, wq->n, wq->k) || !make_mat(a.m[1], wk->planes, wk->type, wk->n, wk->k) ||
       !make_mat(a.m[2], wv->planes, wv->type, wv->n, wv->k)) return -1;
   if (wq->k != wk->k || wq->k != wv->k || ((wq->n | wk->n | wv->n | head_dim) & 1)) return -1;
@@ -817,6 +823,21 @@ extern "C" int mrs_dec_qkv(const mrs_dec_mat_c *wq, const mrs_dec_mat_c *wk, con
   a.block_size = block_size; a.cache_x = 8; a.kv_f16 = kv_dtype == 0;
   a.units = (a.nrows[0] + a.nrows[1] + a.nrows[2]) / 2;
   return Launch<EPI_QKV>::run(a, b, (hipStream_t)stream);
+}
+extern "C" int mrs_dec_qkv(const mrs_dec_mat_c *wq, const mrs_dec_mat_c *wk, const mrs_dec_mat_c *wv, const float *h, int ldh, const float *norm_w, float eps,
+                           float *q_out, void *k_cache, void *v_cache, const int64_t *slot_mapping, const int32_t *positions, const float *cos_t,
+                           const float *sin_t, int head_dim, int rot_pairs, int num_kv_heads, int block_size, int kv_dtype, int b, void *stream) {
+  return dec_qkv_impl(wq, wk, wv, h, ldh, norm_w, eps, q_out, k_cache, v_cache, slot_mapping, positions, cos_t, sin_t, head_dim, rot_pairs, num_kv_heads, block_size,
+                      kv_dtype, b, 0, stream);
+}
+// Rotate-half ("neox") RoPE, as safetensors Llama / Mistral checkpoints use it (RotaryEmbedding::forward with is_gpt_neox, layers.rs:2978): the planes of
+// wq and wk must have been repacked from rows in PAIR order -- inside every head the original rows 0, hd/2, 1, hd/2 + 1, ... -- so that a wave still holds
+// both members of a pair; the results are written back to dims i and i + hd/2 (q_out and the K pages keep the model's dim order).  wv: original order.
+extern "C" int mrs_dec_qkv_neox(const mrs_dec_mat_c *wq, const mrs_dec_mat_c *wk, const mrs_dec_mat_c *wv, const float *h, int ldh, const float *norm_w, float eps,
+                                float *q_out, void *k_cache, void *v_cache, const int64_t *slot_mapping, const int32_t *positions, const float *cos_t,
+                                const float *sin_t, int head_dim, int rot_pairs, int num_kv_heads, int block_size, int kv_dtype, int b, void *stream) {
+  return dec_qkv_impl(wq, wk, wv, h, ldh, norm_w, eps, q_out, k_cache, v_cache, slot_mapping, positions, cos_t, sin_t, head_dim, rot_pairs, num_kv_heads, block_size,
+                      kv_dtype, b, 1, stream);
 }
 
 // gate / up: h -> RMSNorm -> quantize -> act(W_g . x) * (W_u . x) -> act_out f32 [b][ld_out].  expert_sel != nullptr: stacked experts

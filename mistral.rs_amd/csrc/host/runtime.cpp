@@ -419,7 +419,8 @@ class Llama {
   // ---- decode engine (ext_dec.hip): the reference CPU path's arithmetic -- f32 activations quantized to Q8_K / Q8_0 inside the GEMV
   //      kernels (candle QMatMul::forward, gguf/mod.rs:465-478), f32 norm / RoPE / SiLU / softmax -- over decode-layout weights
   bool engine_ok() const {
-    if (cfg.use_fused != 2 || !cfg.rope_interleaved || cfg.head_dim != 128 || cfg.block_size != 32 || (cfg.head_dim & 1)) return false;
+    if (cfg.use_fused != 2 || cfg.head_dim != 128 || cfg.block_size != 32 || (cfg.head_dim & 1)) return false;
+    if (!cfg.rope_interleaved && cfg.rot_dim != cfg.head_dim) return false;  // rotate-half RoPE: the pair-order layout of q / k covers full rotary only
     const int g = cfg.num_heads / cfg.num_kv_heads;
     if (g != 1 && g != 2 && g != 4 && g != 8) return false;
     if (!dlm_head.planes) return false;
@@ -439,7 +440,7 @@ class Llama {
     const int eff_max = std::min(cfg.max_blocks_per_seq * bs, cfg.max_context_len);
     // one sequence on one GPU, dense FFN: the whole step is ONE persistent launch (mrs_dec_step); everything else goes phase by phase
     // dec_persist: 1 = one launch per step, 2 = the same kernel launched phase by phase (debugging / per-phase profiles / the host emulation), 0 = off
-    if (dec_persist && b == 1 && cfg.world_size <= 1 && cfg.num_experts == 0) {
+    if (dec_persist && b == 1 && cfg.world_size <= 1 && cfg.num_experts == 0 && cfg.rope_interleaved) {  // the step table has no rotate-half qkv phase
       int rc = 0;
       if (!dec_table_ready && !dec_table_unfit) {
         std::vector<mrs_dec_layer> ls(blocks.size());
@@ -472,8 +473,9 @@ class Llama {
     }
     if (wte->embedding_forward_raw(bufs.input_ids, b, ws.h, s)) return -1;
     for (const Block &bl : blocks) {
-      if (mrs_dec_qkv(&bl.dq, &bl.dk, &bl.dv, ws.h, d, bl.input_layernorm, cfg.rms_eps, ws.q, bl.key_cache, bl.value_cache, bufs.slot_mapping, bufs.positions,
-                      bufs.cos_table, bufs.sin_table, hd, cfg.rot_dim / 2, kvh, bs, kvd, b, s))
+      // rotate-half RoPE: the caller registered q / k decode planes in pair order (mrs_dec_qkv_neox; llama.py permutes the rows before the repack)
+      if ((cfg.rope_interleaved ? mrs_dec_qkv : mrs_dec_qkv_neox)(&bl.dq, &bl.dk, &bl.dv, ws.h, d, bl.input_layernorm, cfg.rms_eps, ws.q, bl.key_cache, bl.value_cache,
+                                                                  bufs.slot_mapping, bufs.positions, bufs.cos_table, bufs.sin_table, hd, cfg.rot_dim / 2, kvh, bs, kvd, b, s))
         return fail("mrs_dec_qkv refused the layer");
       // short contexts: attention + merge + Q8_K quantization in one launch, o_proj copies the activation image (-3: shape outside that kernel)
       int arc = fused_attn && bl.dout.type != 8 /* Q8_0 weights take Q8_0 activations */ ? mrs_dec_attention_q8k(ws.attn_img, nullptr, ws.q, bl.key_cache, bl.value_cache, kvh, 1.0f / sqrtf((float)hd), bufs.block_tables,

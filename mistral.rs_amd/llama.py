@@ -182,10 +182,12 @@ class Llama:
         if cfg.kv_dtype not in ("bf16", "f16"):
             raise ValueError("kv_dtype must be bf16 or f16")
         # decode engine: wanted unless switched off; possible while every linear registered so far has a decode layout
-        self._engine_wanted = cfg.decode_engine is not False and cfg.use_fused and cfg.rope_interleaved and cfg.head_dim == 128 and cfg.block_size == 32 \
-            and cfg.num_heads // cfg.num_kv_heads in (1, 2, 4, 8)
+        # rotate-half ("neox") RoPE (safetensors Llama / Mistral, RotaryEmbedding::forward with is_gpt_neox): the engine takes it with the q / k rows in pair
+        # order (set_tensor permutes them for the decode layout), full rotary only
+        self._engine_wanted = cfg.decode_engine is not False and cfg.use_fused and cfg.head_dim == 128 and cfg.block_size == 32 \
+            and cfg.num_heads // cfg.num_kv_heads in (1, 2, 4, 8) and (cfg.rope_interleaved or getattr(cfg, "rot_dim", cfg.head_dim) == cfg.head_dim)
         if cfg.decode_engine and not self._engine_wanted:
-            raise ValueError("decode_engine needs use_fused, interleaved RoPE, head_dim 128, block_size 32 and a GQA group of 1 / 2 / 4 / 8")
+            raise ValueError("decode_engine needs use_fused, head_dim 128, block_size 32, a GQA group of 1 / 2 / 4 / 8 and (with rotate-half RoPE) full rotary")
         if cfg.kv_dtype == "f16" and not self._engine_wanted:
             raise ValueError("f16 KV pages are a decode-engine feature")
         self._engine_ok = self._engine_wanted
@@ -261,7 +263,16 @@ class Llama:
                     self._engine_ok = False
                 else:
                     planes = torch.empty(nb, dtype=torch.uint8, device=self.device)
-                    self._chk(self._L.mrs_dec_repack(t.data.data_ptr(), t.dtype.id, t.shape[0], t.shape[1], planes.data_ptr(), self._stream()))
+                    src = t.data
+                    if not self.cfg.rope_interleaved and name.endswith((".attn_q.weight", ".attn_k.weight")):
+                        # pair order for mrs_dec_qkv_neox: inside every head the rows 0, hd/2, 1, hd/2 + 1, ... (rows are whole byte ranges of the packed tensor)
+                        hd = self.cfg.head_dim
+                        rows = t.data.view(t.shape[0] // hd, hd, -1)
+                        order = torch.stack([torch.arange(hd // 2), torch.arange(hd // 2) + hd // 2], dim=1).reshape(-1).to(self.device)
+                        src = rows[:, order, :].contiguous().view(-1)
+                    self._chk(self._L.mrs_dec_repack(src.data_ptr(), t.dtype.id, t.shape[0], t.shape[1], planes.data_ptr(), self._stream()))
+                    if src is not t.data:
+                        torch.cuda.current_stream().synchronize()  # the permuted copy dies with this call
                     self._keep[name + "#dec"] = planes
                     self._chk(self._L.mrs_llama_set_dec_tensor(self._h, name.encode(), planes.data_ptr()))
             # MFMA layout for the prompt GEMM of ext_gemm2.hip (dense per-layer linears of the types it takes): a third copy of the same bits, made once

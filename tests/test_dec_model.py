@@ -23,14 +23,14 @@ Q5 = lambda O: dict(embd=O.Q5_K, q=O.Q5_K, k=O.Q5_K, v=O.Q5_K, o=O.Q5_K, gate=O.
 
 
 def _mk(oracle, dev, types, kv_dtype="bf16", heads=4, kvh=2, layers=2, hidden=512, ff=1024, vocab=512, max_batch=4, seed=0, experts=0, max_new=160, max_ctx=192,
-        sliding_window=None):
+        sliding_window=None, rope_interleaved=True):
     import torch
     from mistralrs_amd.gguf import GgmlDType, QTensor
     from mistralrs_amd.llama import Llama, LlamaConfig, rope_tables
     from oracle import llama_ref
     cfg = LlamaConfig(hidden_size=hidden, intermediate_size=ff, num_layers=layers, num_heads=heads, num_kv_heads=kvh, vocab_size=vocab, head_dim=128,
                       rope_theta=10000.0, max_position_embeddings=max(256, max_ctx), max_batch=max_batch, max_context_len=max_ctx, decode_engine=True, kv_dtype=kv_dtype,
-                      num_experts=experts, num_experts_per_tok=2, sliding_window=sliding_window)
+                      num_experts=experts, num_experts_per_tok=2, sliding_window=sliding_window, rope_interleaved=rope_interleaved)
     w = llama_ref.synth_weights(cfg, types, seed=seed)
     m = Llama(cfg, dev, max_new_tokens=max_new)
     for name, val in w.items():
@@ -84,6 +84,42 @@ def test_engine_bit_identical_to_engine_order_oracle_tiny_model(oracle, dev, req
     emu = request.config.getoption("--host-emulation")
     cfg, w, m, cos, sin = _mk(oracle, dev, {"q4km": Q4KM, "q8": Q8, "q5": Q5}[mix](oracle), kv)
     _bit_parity(m, llama_ref.LlamaRef(cfg, w, cos, sin, mode="engine", kv_dtype=kv), cfg, 5 if emu else 48)
+
+
+@pytest.mark.parametrize("mix,kv", [("q4km", "bf16"), ("q8", "f16")])
+def test_engine_rotate_half_rope_bit_identical_and_prefill_consistent(oracle, dev, request, mix, kv):
+    """Rotate-half ("neox") RoPE, as safetensors Llama / Mistral checkpoints carry it (RotaryEmbedding::forward with is_gpt_neox, layers.rs:2978): the
+    engine's qkv phase runs on q / k planes repacked in pair order (rows i, i + hd/2 adjacent: llama.py set_tensor) and writes the results back to the
+    model's dim order -- every logit equals LlamaRef(mode="engine") with rope_interleaved = False, and differs from the interleaved model (the test
+    exercises the switch); on the device a prompt through the MFMA prefill (rotary kernel in neox mode on the unpermuted weights) leaves pages the
+    engine decodes from consistently."""
+    from oracle import llama_ref
+    emu = request.config.getoption("--host-emulation")
+    types = {"q4km": Q4KM, "q8": Q8}[mix](oracle)
+    cfg, w, m, cos, sin = _mk(oracle, dev, types, kv, rope_interleaved=False)
+    m.set_decode_persist(0)  # the persistent step has no rotate-half qkv phase (the runner falls back to per-phase launches by itself as well)
+    ref = llama_ref.LlamaRef(cfg, w, cos, sin, mode="engine", kv_dtype=kv)
+    inter = llama_ref.LlamaRef(type("C", (), {**cfg.__dict__, "rope_interleaved": True})(), w, cos, sin, mode="engine", kv_dtype=kv)
+    tok, differs = 1000 % cfg.vocab_size, False
+    for pos in range(4 if emu else 40):
+        want, other = ref.step(tok, pos), inter.step(tok, pos)
+        m.set_state([tok], [pos])
+        got = m.forward_logits(1)[0].float().cpu().numpy()
+        assert np.array_equal(got, want), f"position {pos}: engine differs from the rotate-half engine-order oracle"
+        differs = differs or not np.array_equal(want, other)
+        tok = int(got.argmax())
+    assert differs, "rotate-half and interleaved RoPE gave the same logits: the switch is not exercised"
+    if emu or kv != "bf16":
+        return
+    import torch
+    prompt = [(1000 + 3 * i) % cfg.vocab_size for i in range(40)]
+    _, _, m2, _, _ = _mk(oracle, dev, types, kv, rope_interleaved=False)
+    _, _, m3, _, _ = _mk(oracle, dev, types, kv, rope_interleaved=False)
+    lp = m2.prefill(prompt, 0)
+    for pos, t in enumerate(prompt):
+        m3.set_state([t], [pos])
+        ld = m3.forward_logits(1)[0].clone()
+    assert float((lp - ld).abs().max()) <= 5e-2 * float(ld.abs().max())
 
 
 @pytest.mark.parametrize("mix,kv", [("q4km", "f16"), ("q4km", "bf16"), ("q8", "f16"), ("q5", "bf16")])
