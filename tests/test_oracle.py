@@ -216,3 +216,41 @@ def test_three_cpu_gemv_orders_agree(oracle, name):
         a, b, c = oracle.matmul_cpu(t, w, n, k, x), oracle.gemv_cpu_fast(t, w, n, k, x), oracle.gemv_engine(t, w, n, k, x)
         tol = 2e-6 * np.abs(a).max()
         assert np.abs(a - b).max() <= tol and np.abs(a - c).max() <= tol
+
+
+# ---- the reference's own tests of its CPU attention (mistralrs-core/src/attention/backends/cpu/tests.rs), restated against the restatement -------------
+def _naive_attention(q, k, v, scale=1.0):
+    """tests.rs:26-58 naive_attention for one query token: softmax(q k^T) v per head, f64."""
+    h, d = q.shape
+    out = np.empty((h, d))
+    for i in range(h):
+        logits = (k[:, i, :].astype(np.float64) @ q[i].astype(np.float64)) * scale
+        w = np.exp(logits - logits.max())
+        out[i] = (w / w.sum()) @ v[:, i, :].astype(np.float64)
+    return out
+
+
+def test_reference_cpu_attention_tests_hold_for_the_restatement(oracle):
+    """tests.rs:60-108: `test_flash_attn_cpu_single_q` (all ones, h 2, d 4, 2 keys) and `test_flash_attn_cpu_single_q_multiple_kv_chunks` (h 4, d 8, 1024
+    keys, inputs (x % 17) / 17, (x % 19) / 19, (x % 23) / 23, n_kv_groups 1, softmax_scale 1) with the reference's EPS = 1e-4, for one kv chunk and for
+    the chunk counts a multi-threaded run takes (single_q.rs splits the keys over threads)."""
+    q, k, v = np.ones((2, 4), np.float32), np.ones((2, 2, 4), np.float32), np.ones((2, 2, 4), np.float32)
+    assert np.abs(oracle.attention_single_q_cpu(q, k, v, 1.0, 1) - _naive_attention(q, k, v)).max() < 1e-4
+    h, d, kv = 4, 8, 1024
+    q = (np.arange(h * d) % 17 / 17.0).astype(np.float32).reshape(h, d)
+    k = (np.arange(kv * h * d) % 19 / 19.0).astype(np.float32).reshape(kv, h, d)
+    v = (np.arange(kv * h * d) % 23 / 23.0).astype(np.float32).reshape(kv, h, d)
+    want = _naive_attention(q, k, v)
+    for chunks in (1, 2, 8, 64):
+        assert np.abs(oracle.attention_single_q_cpu(q, k, v, 1.0, chunks) - want).max() < 1e-4, chunks
+
+
+def test_reference_softmax_row_check_holds_for_fast_exp(oracle):
+    """avx.rs:807-836 (`avx_kernels_match_reference`): the row softmax built on `fast_exp` sums to the libm value within 1e-3 for rows sin(0.13 i) of
+    16 / 64 / 128 / 131 elements -- the reference's own accuracy statement for the polynomial the engine uses."""
+    for n in (16, 64, 128, 131):
+        a = np.sin(np.arange(n, dtype=np.float32) * np.float32(0.13)).astype(np.float32)
+        m = a.max()
+        got = float(sum(np.float64(oracle.fast_exp(float(x))) for x in (a - m)))
+        want = float(np.exp((a - m).astype(np.float64)).sum())
+        assert abs(got - want) / want < 1e-3
