@@ -110,6 +110,25 @@ class HqqLayer:
     def __init__(self, w_q, zeros, scales, w_shape, cfg: HqqConfig, bias=None):
         self.w_q, self.zeros, self.scales, self.w_shape, self.cfg, self.bias = w_q, zeros, scales, tuple(w_shape), cfg, bias
 
+    # ---- UQFF (hqq/mod.rs:1268-1336): the 8- and 4-bit widths have a UQFF type; artifacts load whole
+    def uqff_type(self):
+        return {8: "HQQ8", 4: "HQQ4"}.get(self.cfg.bits)
+
+    def serialize_uqff(self, prefix: str) -> dict:
+        from . import uqff
+        c = self.cfg
+        cpu = lambda t: None if t is None else t.detach().cpu().contiguous()
+        return uqff.serialize_hqq_layer(prefix, cpu(self.w_q), cpu(self.scales), cpu(self.zeros), self.w_shape, c.bits, c.group_size, c.axis,
+                                        c.optimization_steps, c.round_zeros, c.channel_wise, cpu(self.bias))
+
+    @classmethod
+    def from_uqff(cls, reader, prefix: str, device, shard=None) -> "HqqLayer":
+        d = reader.load_hqq_layer(prefix, shard)
+        cfg = HqqConfig(bits=d.bits, group_size=d.group_size, axis=d.axis, optimization_steps=d.optimization_steps, round_zeros=d.round_zeros,
+                        channel_wise=d.channel_wise)
+        to = lambda t: None if t is None else t.to(device)
+        return cls(to(d.w_q), to(d.zeros), to(d.scales), d.w_shape, cfg, to(d.bias))
+
     @classmethod
     def quantize(cls, w: torch.Tensor, cfg: HqqConfig) -> "HqqLayer":
         """HqqLayer::quantize (quantize.rs:9-84) with optimize_weights_proximal_legacy (optimize.rs:44-95)."""

@@ -117,14 +117,60 @@ def serialize_gguf_layer(prefix: str, dtype: GgmlDType, shape, packed, bias=None
     return out
 
 
+def serialize_hqq_layer(prefix: str, w_q, scales, zeros, w_shape, bits: int, group_size: int, axis: int, optimization_steps, round_zeros: bool,
+                        channel_wise: bool, bias=None) -> dict:
+    """`HqqLayer::serialize_uqff` (mistralrs-quant/src/hqq/mod.rs:1275-1318): name -> numpy array, in the reference's order.  Only the 8- and 4-bit widths
+    have a UQFF type (`uqff_type`, :1268-1274: HQQ8 / HQQ4); `optimization_steps` None is stored as 0."""
+    if bits not in (8, 4):
+        raise ValueError("Cannot serialize unsupported HQQ bit width as UQFF.")
+    out = {
+        f"{prefix}.{WEIGHT_FORMAT_SUFFIX}": np.array(SERDE_HQQ, dtype=np.uint8),
+        f"{prefix}.weight": w_q,          # numpy or torch (CPU) tensors, dtype preserved (u8 quants; f32 / f16 / bf16 scales and zeros)
+        f"{prefix}.weight.scales": scales,
+        f"{prefix}.weight.zeros": zeros,
+        f"{prefix}.weight.shape": np.array(list(w_shape), dtype=np.uint32),
+        f"{prefix}.weight.bits": np.array(bits, dtype=np.uint8),
+        f"{prefix}.weight.group_size": np.array(group_size, dtype=np.uint32),
+        f"{prefix}.weight.axis": np.array(axis, dtype=np.uint8),
+        f"{prefix}.weight.optimization_steps": np.array(optimization_steps or 0, dtype=np.uint32),
+        f"{prefix}.weight.round_zeros": np.array(int(bool(round_zeros)), dtype=np.uint8),
+        f"{prefix}.weight.channel_wise": np.array(int(bool(channel_wise)), dtype=np.uint8),
+    }
+    if bias is not None:
+        out[f"{prefix}.bias"] = bias
+    return out
+
+
+@dataclass
+class HqqLayerData:
+    """What `HqqLayer::from_uqff` reads back (hqq/mod.rs:797-826)."""
+    w_q: "torch.Tensor"      # CPU tensors in the stored dtypes
+    scales: "torch.Tensor"
+    zeros: "torch.Tensor"
+    w_shape: tuple
+    bits: int
+    group_size: int
+    axis: int
+    optimization_steps: int | None
+    round_zeros: bool
+    channel_wise: bool
+    bias: "torch.Tensor | None"
+
+
 def write(path: str, layers: dict) -> None:
-    """Version tensors + the given entries as one safetensors file."""
-    from safetensors.numpy import save_file
+    """Version tensors + the given entries as one safetensors file.  Values are numpy arrays, or torch tensors where numpy has no dtype for them (bf16 HQQ
+    scales / zeros): the file then goes through safetensors.torch, same bytes on disk."""
     tensors = dict(version_tensors())
     for k, v in layers.items():
         if k in tensors:
             raise ValueError(f"duplicate UQFF tensor `{k}`")
         tensors[k] = v
+    if any(not isinstance(v, np.ndarray) for v in tensors.values()):
+        import torch
+        from safetensors.torch import save_file as save_torch
+        save_torch({k: (v.detach().cpu().contiguous() if isinstance(v, torch.Tensor) else torch.from_numpy(v if v.ndim == 0 else np.ascontiguousarray(v))) for k, v in tensors.items()}, path)  # 0-d scalars stay 0-d (uqff/tensor.rs:52-58)
+        return
+    from safetensors.numpy import save_file
     save_file(tensors, path)
 
 
@@ -142,6 +188,7 @@ class UqffReader:
 
     def __init__(self, path: str):
         from safetensors import safe_open
+        self._path = path
         self._f = safe_open(path, framework="np")
         self._keys = set(self._f.keys())
         missing = [k for k in VERSION_KEYS if k not in self._keys]
@@ -222,3 +269,46 @@ class UqffReader:
             dims[dim] = n
         bias, mode = self.load_bias(prefix, rng, len(dims))
         return GgufLayer(dt, tuple(dims), np.ascontiguousarray(weight), bias, mode)
+
+    def load_hqq_layer(self, prefix: str, shard: Shard | None = None) -> HqqLayerData:
+        """`HqqLayer::from_uqff` (hqq/mod.rs:797-826): HQQ artifacts load whole (no sharded loading), 0 optimization steps mean None."""
+        if shard is not None and not (shard.offset is None and shard.world_size == 1):
+            raise ValueError("HQQ UQFF artifacts do not support sharded loading.")
+        if self.serde_type(prefix) != SERDE_HQQ:
+            raise ValueError(f"`{prefix}` is not an HQQ layer (format {self.serde_type(prefix)})")
+        bits = self.load_u8_scalar(f"{prefix}.weight.bits")
+        if bits not in (8, 4, 3, 2, 1):
+            raise ValueError(f"Unexpected value for HQQ bits: {bits}")
+        group = self.load_u32_scalar(f"{prefix}.weight.group_size")
+        if group == 0:
+            raise ValueError("HQQ group_size must be non-zero")
+        axis = self.load_u8_scalar(f"{prefix}.weight.axis")
+        if axis not in (0, 1):
+            raise ValueError(f"Unexpected value for HQQ axis: {axis}")
+        steps = self.load_u32_scalar(f"{prefix}.weight.optimization_steps")
+        key = f"{prefix}.bias"
+        return HqqLayerData(self._get_torch(f"{prefix}.weight"), self._get_torch(f"{prefix}.weight.scales"), self._get_torch(f"{prefix}.weight.zeros"),
+                            tuple(self.load_u32_vec(f"{prefix}.weight.shape")), bits, group, axis, steps or None,
+                            self.load_u8_scalar(f"{prefix}.weight.round_zeros") != 0, self.load_u8_scalar(f"{prefix}.weight.channel_wise") != 0,
+                            self._get_torch(key) if key in self._keys else None)
+
+    def _get_torch(self, key: str):
+        """A tensor in its stored dtype (bf16 has no numpy dtype): second handle on the same file, opened on first use."""
+        if key not in self._keys:
+            raise ValueError(f"Missing UQFF tensor `{key}`")
+        if getattr(self, "_ft", None) is None:
+            from safetensors import safe_open
+            self._ft = safe_open(self._path, framework="pt")
+        return self._ft.get_tensor(key)
+
+    def isq_type(self, prefix: str) -> str:
+        """`isq_type_from_uqff` of the layer's serde type: the GGML dtype name for GGUF layers, HQQ8 / HQQ4 for HQQ layers (hqq/mod.rs:1327-1336)."""
+        t = self.serde_type(prefix)
+        if t == SERDE_GGUF:
+            return GgmlDType.from_id(self.load_u32_scalar(f"{prefix}.weight.dtype")).name
+        if t == SERDE_HQQ:
+            bits = self.load_u8_scalar(f"{prefix}.weight.bits")
+            if bits in (8, 4):
+                return f"HQQ{bits}"
+            raise ValueError("Cannot convert HQQ bit width to an ISQ type.")
+        raise ValueError(f"serde type {t} has no reader here")
