@@ -73,6 +73,22 @@ def quantize(w: torch.Tensor, dtype: GgmlDType) -> QTensor:
 
 
 
+def supports_imatrix(dtype: GgmlDType) -> bool:
+    """`IsqType::supports_imatrix` (mistralrs-quant/src/lib.rs:1038-1043): the five K-quants consume an importance vector.  Of those, Q2_K and Q3_K have no
+    weighted DEVICE quantizer yet (`imatrix_capable`): with an importance vector they are quantized by the plain quantizer here."""
+    return dtype in (GgmlDType.Q2K, GgmlDType.Q3K, GgmlDType.Q4K, GgmlDType.Q5K, GgmlDType.Q6K)
+
+
+def pack_factor(dtype: GgmlDType, src_bytes: int = 2) -> int:
+    """`IsqType::pack_factor` for the GGML targets (lib.rs:946-957,996-1016 `block_pack_factor`): the integer factor by which the reference's loader divides
+    the dense element count to size an ISQ'd tensor: floor(block * src_bytes / type_size), lowered while block / factor * src_bytes < type_size."""
+    dense = dtype.block_size * src_bytes
+    factor = max(dense // max(dtype.type_size, 1), 1)
+    while factor > 1 and dtype.block_size // factor * src_bytes < dtype.type_size:
+        factor -= 1
+    return factor
+
+
 def imatrix_capable(dtype: GgmlDType) -> bool:
     """gguf/mod.rs:221-224: the K-quants take an importance vector; of those, Q4_K / Q5_K / Q6_K have a device quantizer here."""
     return dtype in (GgmlDType.Q4K, GgmlDType.Q5K, GgmlDType.Q6K)
