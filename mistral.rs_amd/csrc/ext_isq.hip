@@ -92,29 +92,30 @@ __device__ __forceinline__ float isq_make_qkx2(const float (&x)[N], const float 
 
 // Q4_K (FIVE = false, 144 B) / Q5_K (FIVE = true, 176 B): 8 lanes per superblock, lane j = sub-block j
 // make_qp_quants(8, 63, x, L, qw) of GGML's importance-weighted quantizers: the 6-bit super-scale search over the eight sub-block scales (or mins)
-__device__ __forceinline__ float isq_make_qp8(const float (&x)[8], int (&L)[8], const float (&qw)[8]) {
-  constexpr int nmax = 63;
+template <int N = 8, int NMAX = 63>
+__device__ __forceinline__ float isq_make_qp8(const float (&x)[N], int (&L)[N], const float (&qw)[N]) {
+  constexpr int nmax = NMAX;
   float mx = 0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) if (x[i] > mx) mx = x[i];
+  for (int i = 0; i < N; ++i) if (x[i] > mx) mx = x[i];
   if (!(mx != 0.f)) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) L[i] = 0;
+    for (int i = 0; i < N; ++i) L[i] = 0;
     return 0.f;
   }
   float iscale = nmax / mx;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) L[i] = isq_nearest_int(iscale * x[i]);
+  for (int i = 0; i < N; ++i) L[i] = isq_nearest_int(iscale * x[i]);
   const float scale = 1 / iscale;
   float best_mse = 0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { const float diff = x[i] - scale * L[i]; best_mse += qw[i] * diff * diff; }
+  for (int i = 0; i < N; ++i) { const float diff = x[i] - scale * L[i]; best_mse += qw[i] * diff * diff; }
   for (int is = -4; is <= 4; ++is) {
     if (is == 0) continue;
     const float iscale_is = (0.1f * is + nmax) / mx, scale_is = 1 / iscale_is;
     float mse = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < N; ++i) {
       const int l = min(nmax, isq_nearest_int(iscale_is * x[i]));
       const float diff = x[i] - scale_is * l;
       mse += qw[i] * diff * diff;
@@ -123,7 +124,7 @@ __device__ __forceinline__ float isq_make_qp8(const float (&x)[8], int (&L)[8], 
   }
   float sumlx = 0, suml2 = 0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < N; ++i) {
     const int l = min(nmax, isq_nearest_int(iscale * x[i]));
     L[i] = l;
     sumlx += qw[i] * x[i] * l;
@@ -132,7 +133,7 @@ __device__ __forceinline__ float isq_make_qp8(const float (&x)[8], int (&L)[8], 
   for (int itry = 0; itry < 5; ++itry) {
     int n_changed = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < N; ++i) {
       const float w = qw[i];
       float slx = sumlx - w * x[i] * L[i], sl2 = suml2 - w * L[i] * L[i];
       if (slx > 0 && sl2 > 0) {
@@ -378,10 +379,54 @@ __global__ void __launch_bounds__(256) isq_q6_k_kernel(const T *__restrict__ src
   }
 }
 
+// make_qx_quants(16, NMAX, x, L, rmse_type 1, weights) of GGML: L = quant + NMAX, returns the scale (19 candidate scales)
+template <int NMAX>
+__device__ __forceinline__ float isq_make_qx16(const float (&x)[16], const float (&wq)[16], int (&L)[16]) {
+  float mx = 0, amax = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { const float ax = fabsf(x[i]); if (ax > amax) { amax = ax; mx = x[i]; } }
+  if (amax < 1e-15f) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) L[i] = 0;
+    return 0.f;
+  }
+  float iscale = -NMAX / mx, sumlx = 0, suml2 = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int l = max(-NMAX, min(NMAX - 1, isq_nearest_int(iscale * x[i])));
+    L[i] = l + NMAX;
+    sumlx += wq[i] * x[i] * l;
+    suml2 += wq[i] * l * l;
+  }
+  float scale = suml2 ? sumlx / suml2 : 0.0f;
+  float best = scale * sumlx;
+  for (int is = -9; is <= 9; ++is) {
+    if (is == 0) continue;
+    iscale = -(NMAX + 0.1f * is) / mx;
+    sumlx = suml2 = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int l = max(-NMAX, min(NMAX - 1, isq_nearest_int(iscale * x[i])));
+      sumlx += wq[i] * x[i] * l;
+      suml2 += wq[i] * l * l;
+    }
+    if (suml2 > 0 && sumlx * sumlx > best * suml2) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) L[i] = NMAX + max(-NMAX, min(NMAX - 1, isq_nearest_int(iscale * x[i])));
+      scale = sumlx / suml2;
+      best = scale * sumlx;
+    }
+  }
+  return scale;
+}
+
 // Q2_K (84 B: 16 x {4-bit scale | 4-bit min << 4}, 64 B of 2-bit quants, half d, half dmin) -- quantize_row_q2_K_ref: 16 lanes per superblock,
 // lane ib = 16-weight sub-block; make_qkx2_quants(16, 3, x, |x|, .., -0.5, 0.1, 15, use_mad = true).
-template <class T>
-__global__ void __launch_bounds__(256) isq_q2_k_kernel(const T *__restrict__ src, uint8_t *__restrict__ out, size_t nsuper) {
+// IM: quantize_row_q2_K_impl -- weights qw * sqrt(sigma2 + x^2) with sigma2 = sum(x^2) / 256, make_qkx3_quants(16, 3, .., -0.9, 0.05, 36), 4-bit scales and
+// minimums by make_qp_quants(16, 15, .., sw)
+template <class T, bool IM = false>
+__global__ void __launch_bounds__(256) isq_q2_k_kernel(const T *__restrict__ src, uint8_t *__restrict__ out, size_t nsuper, const float *__restrict__ qw = nullptr,
+                                                       int sb_per_row = 0) {
   const int lane = threadIdx.x & 63, ib = lane & 15, base = lane & ~15;
   const size_t sb_raw = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 4;
   const bool live = sb_raw < nsuper;
@@ -390,15 +435,36 @@ __global__ void __launch_bounds__(256) isq_q2_k_kernel(const T *__restrict__ src
   const T *p = src + sb * 256 + (size_t)ib * 16;
 #pragma unroll
   for (int i = 0; i < 16; ++i) { x[i] = to_f<T>(p[i]); w[i] = fabsf(x[i]); }
-  float mn;
-  const float sc = isq_make_qkx2<16, true>(x, w, 3, -0.5f, 0.1f, 15, mn);
-  float max_scale = sc > 0 ? sc : 0.f, max_min = mn > 0 ? mn : 0.f;
-#pragma unroll
-  for (int m = 1; m < 16; m <<= 1) { max_scale = fmaxf(max_scale, __shfl_xor(max_scale, m, 64)); max_min = fmaxf(max_min, __shfl_xor(max_min, m, 64)); }
+  float mn, sc;
   int ls = 0, lm = 0;
   uint16_t dbits = float_to_half_bits(0.f), mbits = float_to_half_bits(0.f);
-  if (max_scale > 0) { ls = isq_nearest_int((15.f / max_scale) * sc); dbits = float_to_half_bits(max_scale / 15.f); }
-  if (max_min > 0) { lm = isq_nearest_int((15.f / max_min) * mn); mbits = float_to_half_bits(max_min / 15.f); }
+  if constexpr (IM) {
+    float tot = 0;  // sigma2 over the superblock in element order (every lane of the group walks the 256 values)
+    const T *p0 = src + sb * 256;
+    for (int l = 0; l < 256; ++l) { const float v = to_f<T>(p0[l]); tot += v * v; }
+    const float sigma2 = tot / 256;
+    const float *q = qw + (sb % (size_t)sb_per_row) * 256 + (size_t)ib * 16;
+    float sumw = 0;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) { w[l] = q[l] * sqrtf(sigma2 + x[l] * x[l]); sumw += w[l]; }
+    sc = isq_make_qkx2<16, false>(x, w, 3, -0.9f, 0.05f, 36, mn);
+    float scs[16], mns[16], sws[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) { scs[g] = __shfl(sc, base + g, 64); mns[g] = __shfl(mn, base + g, 64); sws[g] = __shfl(sumw, base + g, 64); }
+    int Ls[16], Lm[16];
+    const float dmv = isq_make_qp8<16, 15>(scs, Ls, sws), mmv = isq_make_qp8<16, 15>(mns, Lm, sws);
+    dbits = float_to_half_bits(dmv);
+    mbits = float_to_half_bits(mmv);
+#pragma unroll
+    for (int g = 0; g < 16; ++g) if (g == ib) { ls = Ls[g]; lm = Lm[g]; }
+  } else {
+    sc = isq_make_qkx2<16, true>(x, w, 3, -0.5f, 0.1f, 15, mn);
+    float max_scale = sc > 0 ? sc : 0.f, max_min = mn > 0 ? mn : 0.f;
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) { max_scale = fmaxf(max_scale, __shfl_xor(max_scale, m, 64)); max_min = fmaxf(max_min, __shfl_xor(max_min, m, 64)); }
+    if (max_scale > 0) { ls = isq_nearest_int((15.f / max_scale) * sc); dbits = float_to_half_bits(max_scale / 15.f); }
+    if (max_min > 0) { lm = isq_nearest_int((15.f / max_min) * mn); mbits = float_to_half_bits(max_min / 15.f); }
+  }
   const uint8_t scb = (uint8_t)((uint8_t)ls | (uint8_t)(lm << 4));  // exactly the byte a reader decodes: `scales[j] = l; scales[j] |= l << 4`
   const float d = half_bits_to_float(dbits) * (float)(scb & 0xF), dm = half_bits_to_float(mbits) * (float)(scb >> 4);
   uint32_t lo[4] = {0, 0, 0, 0};
@@ -425,8 +491,11 @@ __global__ void __launch_bounds__(256) isq_q2_k_kernel(const T *__restrict__ src
 
 // Q3_K (110 B: 32 B high-bit mask, 64 B of 2-bit quants, 12 B of 6-bit scales, half d) -- quantize_row_q3_K_ref: make_q3_quants(16, 4, x, L, true)
 // per sub-block (first guess + up to 5 refinement sweeps), super-scale -32 / (scale of largest magnitude).
-template <class T>
-__global__ void __launch_bounds__(256) isq_q3_k_kernel(const T *__restrict__ src, uint8_t *__restrict__ out, size_t nsuper) {
+// IM: quantize_row_q3_K_impl -- make_qx_quants(16, 4, x, L, 1, qw * sqrt(sigma2 + x^2)) with sigma2 = 2 sum(x^2) / 256 per sub-block, then the sixteen scales
+// by make_qx_quants(16, 32, scales, Ls, 1, sw) (their 6-bit codes and the super-scale together)
+template <class T, bool IM = false>
+__global__ void __launch_bounds__(256) isq_q3_k_kernel(const T *__restrict__ src, uint8_t *__restrict__ out, size_t nsuper, const float *__restrict__ qw = nullptr,
+                                                       int sb_per_row = 0) {
   const int lane = threadIdx.x & 63, ib = lane & 15, base = lane & ~15;
   const size_t sb_raw = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 4;
   const bool live = sb_raw < nsuper;
@@ -437,7 +506,18 @@ __global__ void __launch_bounds__(256) isq_q3_k_kernel(const T *__restrict__ src
   for (int i = 0; i < 16; ++i) x[i] = to_f<T>(p[i]);
   int L[16];
   float scale;
-  {
+  float sumw_im = 0;
+  if constexpr (IM) {
+    float tot = 0;
+    const T *p0 = src + sb * 256;
+    for (int l = 0; l < 256; ++l) { const float v = to_f<T>(p0[l]); tot += v * v; }
+    const float sigma2 = 2 * tot / 256;
+    const float *q = qw + (sb % (size_t)sb_per_row) * 256 + (size_t)ib * 16;
+    float wq[16];
+#pragma unroll
+    for (int l = 0; l < 16; ++l) { wq[l] = q[l] * sqrtf(sigma2 + x[l] * x[l]); sumw_im += wq[l]; }
+    scale = isq_make_qx16<4>(x, wq, L);
+  } else {
     constexpr int nmax = 4;
     float mx = 0, amax = 0;
 #pragma unroll
@@ -489,10 +569,24 @@ __global__ void __launch_bounds__(256) isq_q3_k_kernel(const T *__restrict__ src
     const int oi = __shfl_xor(best_i, m, 64);
     if (oa > best_abs || (oa == best_abs && oi < best_i)) { best_abs = oa; best_s = os; best_i = oi; }
   }
-  const bool any = best_abs > 0.f;  // `if (max_scale)`: max_scale is only ever set to a scale whose magnitude exceeded 0
-  const float iscale = any ? -32.f / best_s : 0.f;
-  const int l6 = any ? max(-32, min(31, isq_nearest_int(iscale * scale))) + 32 : 0;  // 6-bit code; all twelve bytes stay 0 without a scale
-  const uint16_t dbits = any ? float_to_half_bits(1 / iscale) : float_to_half_bits(0.f);
+  int l6;
+  uint16_t dbits;
+  if constexpr (IM) {
+    float scs[16], sws[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) { scs[g] = __shfl(scale, base + g, 64); sws[g] = __shfl(sumw_im, base + g, 64); }
+    int Ls[16];
+    const float d_block = isq_make_qx16<32>(scs, sws, Ls);  // codes already carry the + 32
+    dbits = float_to_half_bits(d_block);
+    l6 = 0;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) if (g == ib) l6 = Ls[g];
+  } else {
+    const bool any = best_abs > 0.f;  // `if (max_scale)`: max_scale is only ever set to a scale whose magnitude exceeded 0
+    const float iscale = any ? -32.f / best_s : 0.f;
+    l6 = any ? max(-32, min(31, isq_nearest_int(iscale * scale))) + 32 : 0;  // 6-bit code; all twelve bytes stay 0 without a scale
+    dbits = any ? float_to_half_bits(1 / iscale) : float_to_half_bits(0.f);
+  }
   int all[16];
 #pragma unroll
   for (int g = 0; g < 16; ++g) all[g] = __shfl(l6, base + g, 64);
@@ -602,8 +696,8 @@ template <class T> static int isq_dispatch(const T *src, uint8_t *dst, size_t n,
   case 3: { const size_t nb = n / 32; hipLaunchKernelGGL((isq_legacy_kernel<T, 3>), dim3((unsigned)((nb + 255) / 256)), block, 0, s, src, dst, nb); return 0; }
   case 6: { const size_t nb = n / 32; hipLaunchKernelGGL((isq_legacy_kernel<T, 6>), dim3((unsigned)((nb + 255) / 256)), block, 0, s, src, dst, nb); return 0; }
   case 7: { const size_t nb = n / 32; hipLaunchKernelGGL((isq_legacy_kernel<T, 7>), dim3((unsigned)((nb + 255) / 256)), block, 0, s, src, dst, nb); return 0; }
-  case 10: { const size_t nb = n / 256; hipLaunchKernelGGL((isq_q2_k_kernel<T>), dim3((unsigned)((nb + 15) / 16)), block, 0, s, src, dst, nb); return 0; }
-  case 11: { const size_t nb = n / 256; hipLaunchKernelGGL((isq_q3_k_kernel<T>), dim3((unsigned)((nb + 15) / 16)), block, 0, s, src, dst, nb); return 0; }
+  case 10: { const size_t nb = n / 256; hipLaunchKernelGGL((isq_q2_k_kernel<T, false>), dim3((unsigned)((nb + 15) / 16)), block, 0, s, src, dst, nb, (const float *)nullptr, 0); return 0; }
+  case 11: { const size_t nb = n / 256; hipLaunchKernelGGL((isq_q3_k_kernel<T, false>), dim3((unsigned)((nb + 15) / 16)), block, 0, s, src, dst, nb, (const float *)nullptr, 0); return 0; }
   case 12: { const size_t nb = n / 256; hipLaunchKernelGGL((isq_q45_k_kernel<T, false, false>), dim3((unsigned)((nb + 31) / 32)), block, 0, s, src, dst, nb, (const float *)nullptr, 0); return 0; }
   case 13: { const size_t nb = n / 256; hipLaunchKernelGGL((isq_q45_k_kernel<T, true, false>), dim3((unsigned)((nb + 31) / 32)), block, 0, s, src, dst, nb, (const float *)nullptr, 0); return 0; }
   case 14: { const size_t nb = n / 256; hipLaunchKernelGGL((isq_q6_k_kernel<T, false>), dim3((unsigned)((nb + 15) / 16)), block, 0, s, src, dst, nb, (const float *)nullptr, 0); return 0; }
@@ -616,6 +710,8 @@ template <class T> static int isq_dispatch_imatrix(const T *src, uint8_t *dst, s
   const size_t nb = nrows * (size_t)(k / 256);
   const int spr = k / 256;
   switch (type) {
+  case 10: hipLaunchKernelGGL((isq_q2_k_kernel<T, true>), dim3((unsigned)((nb + 15) / 16)), block, 0, s, src, dst, nb, qw, spr); return 0;
+  case 11: hipLaunchKernelGGL((isq_q3_k_kernel<T, true>), dim3((unsigned)((nb + 15) / 16)), block, 0, s, src, dst, nb, qw, spr); return 0;
   case 12: hipLaunchKernelGGL((isq_q45_k_kernel<T, false, true>), dim3((unsigned)((nb + 31) / 32)), block, 0, s, src, dst, nb, qw, spr); return 0;
   case 13: hipLaunchKernelGGL((isq_q45_k_kernel<T, true, true>), dim3((unsigned)((nb + 31) / 32)), block, 0, s, src, dst, nb, qw, spr); return 0;
   case 14: hipLaunchKernelGGL((isq_q6_k_kernel<T, true>), dim3((unsigned)((nb + 15) / 16)), block, 0, s, src, dst, nb, qw, spr); return 0;
@@ -723,7 +819,7 @@ extern "C" int mrs_isq_quantize(const void *src, int src_dtype, void *dst, long 
 }
 
 // Importance-weighted ISQ (QTensor::quantize_imatrix; call sites gguf/mod.rs:238-252, utils/isq.rs generate_isq_imatrix!): src dense [nrows][k],
-// imatrix f32 [k] on the device (one value per input column, shared by the rows), ggml_type 12 Q4_K / 13 Q5_K / 14 Q6_K.  Returns 0, -1 for other
+// imatrix f32 [k] on the device (one value per input column, shared by the rows), ggml_type 10 Q2_K / 11 Q3_K / 12 Q4_K / 13 Q5_K / 14 Q6_K.  Returns 0, -1 for other
 // types / dtypes or k % 256 != 0 (the caller then quantizes without the importance vector, as the reference does for non-K-quant targets).
 extern "C" int mrs_isq_quantize_imatrix(const void *src, int src_dtype, void *dst, long long nrows, int k, int ggml_type, const float *imatrix, void *stream) {
   if (nrows <= 0) return 0;

@@ -74,8 +74,8 @@ def quantize(w: torch.Tensor, dtype: GgmlDType) -> QTensor:
 
 
 def supports_imatrix(dtype: GgmlDType) -> bool:
-    """`IsqType::supports_imatrix` (mistralrs-quant/src/lib.rs:1038-1043): the five K-quants consume an importance vector.  Of those, Q2_K and Q3_K have no
-    weighted DEVICE quantizer yet (`imatrix_capable`): with an importance vector they are quantized by the plain quantizer here."""
+    """`IsqType::supports_imatrix` (mistralrs-quant/src/lib.rs:1038-1043): the five K-quants consume an importance vector; every one of them has a weighted
+    device quantizer (`imatrix_capable` is the same set)."""
     return dtype in (GgmlDType.Q2K, GgmlDType.Q3K, GgmlDType.Q4K, GgmlDType.Q5K, GgmlDType.Q6K)
 
 
@@ -90,8 +90,8 @@ def pack_factor(dtype: GgmlDType, src_bytes: int = 2) -> int:
 
 
 def imatrix_capable(dtype: GgmlDType) -> bool:
-    """gguf/mod.rs:221-224: the K-quants take an importance vector; of those, Q4_K / Q5_K / Q6_K have a device quantizer here."""
-    return dtype in (GgmlDType.Q4K, GgmlDType.Q5K, GgmlDType.Q6K)
+    """gguf/mod.rs:221-224: the K-quants take an importance vector; all five have a weighted device quantizer (`mrs_isq_quantize_imatrix`)."""
+    return supports_imatrix(dtype)
 
 
 def quantize_imatrix(w: torch.Tensor, imatrix, dtype: GgmlDType) -> QTensor:

@@ -740,11 +740,97 @@ static void quantize_q6_K_imatrix(const float *x, uint8_t *y, int64_t k, const f
   }
 }
 
+/* Q2_K / Q3_K with importance weights: GGML quantize_row_q2_K_impl / quantize_row_q3_K_impl (as above: published algorithm, unpinned). */
+static void quantize_q2_K_imatrix(const float *x, uint8_t *y, int64_t k, const float *qw_row) {
+  uint8_t L[QK_K], Laux[16], Ls[16], Lm[16];
+  float weight[16], mins[16], scales[16], sw[16];
+  for (int64_t i = 0; i < k / QK_K; ++i, x += QK_K, y += 84) {
+    float sumx2 = 0;
+    for (int j = 0; j < QK_K; ++j) sumx2 += x[j] * x[j];
+    const float sigma2 = sumx2 / QK_K;
+    for (int j = 0; j < 16; ++j) {
+      const float *qw = qw_row + QK_K * i + 16 * j;
+      for (int l = 0; l < 16; ++l) weight[l] = qw[l] * sqrtf(sigma2 + x[16 * j + l] * x[16 * j + l]);
+      sw[j] = 0;
+      for (int l = 0; l < 16; ++l) sw[j] += weight[l];
+      scales[j] = make_qkx2_quants(16, 3, x + 16 * j, weight, L + 16 * j, &mins[j], Laux, -0.9f, 0.05f, 36, 0);
+    }
+    float dm = make_qp_quants(16, 15, scales, Ls, sw), mm = make_qp_quants(16, 15, mins, Lm, sw);
+    st16(y + 80, orc_fp32_to_fp16(dm));
+    st16(y + 82, orc_fp32_to_fp16(mm));
+    dm = orc_fp16_to_fp32(ld16(y + 80));
+    mm = orc_fp16_to_fp32(ld16(y + 82));
+    uint8_t *sc = y, *qs = y + 16;
+    for (int j = 0; j < 16; ++j) sc[j] = (uint8_t)(Ls[j] | (Lm[j] << 4));
+    for (int j = 0; j < 16; ++j) {
+      const float d = dm * (sc[j] & 0xF);
+      if (!d) { for (int ii = 0; ii < 16; ++ii) L[16 * j + ii] = 0; continue; }  /* as the plain quantizer here */
+      const float m = mm * (sc[j] >> 4);
+      for (int ii = 0; ii < 16; ++ii) {
+        int l = nearest_int((x[16 * j + ii] + m) / d);
+        L[16 * j + ii] = (uint8_t)imax(0, imin(3, l));
+      }
+    }
+    for (int j = 0; j < QK_K; j += 128)
+      for (int l = 0; l < 32; ++l) qs[j / 4 + l] = (uint8_t)(L[j + l] | (L[j + l + 32] << 2) | (L[j + l + 64] << 4) | (L[j + l + 96] << 6));
+  }
+}
+
+static void quantize_q3_K_imatrix(const float *x, uint8_t *y, int64_t k, const float *qw_row) {
+  int8_t L[QK_K], Ls[16];
+  float scales[16], weight[16], sw[16];
+  for (int64_t i = 0; i < k / QK_K; ++i, x += QK_K, y += 110) {
+    float sumx2 = 0;
+    for (int j = 0; j < QK_K; ++j) sumx2 += x[j] * x[j];
+    const float sigma2 = 2 * sumx2 / QK_K;
+    for (int j = 0; j < 16; ++j) {
+      const float *qw = qw_row + QK_K * i + 16 * j;
+      for (int l = 0; l < 16; ++l) weight[l] = qw[l] * sqrtf(sigma2 + x[16 * j + l] * x[16 * j + l]);
+      float sumw = 0;
+      for (int l = 0; l < 16; ++l) sumw += weight[l];
+      sw[j] = sumw;
+      scales[j] = make_qx_quants_w(16, 4, x + 16 * j, L + 16 * j, weight);
+    }
+    uint8_t *hmask = y, *qs = y + 32, *sc12 = y + 96;
+    memset(sc12, 0, 12);
+    const float d_block = make_qx_quants_w(16, 32, scales, Ls, sw);
+    for (int j = 0; j < 16; ++j) {
+      int l = Ls[j];
+      if (j < 8) sc12[j] = (uint8_t)(l & 0xF);
+      else sc12[j - 8] |= (uint8_t)((l & 0xF) << 4);
+      l >>= 4;
+      sc12[j % 4 + 8] |= (uint8_t)(l << (2 * (j / 4)));
+    }
+    st16(y + 108, orc_fp32_to_fp16(d_block));
+    int8_t sc16[16];
+    q3k_scales(sc12, sc16);
+    const float dd = orc_fp16_to_fp32(ld16(y + 108));
+    for (int j = 0; j < 16; ++j) {
+      float d = dd * sc16[j];
+      if (!d) continue;
+      for (int ii = 0; ii < 16; ++ii) {
+        int l = nearest_int(x[16 * j + ii] / d);
+        L[16 * j + ii] = (int8_t)(imax(-4, imin(3, l)) + 4);
+      }
+    }
+    memset(hmask, 0, 32);
+    int m = 0; uint8_t hm = 1;
+    for (int j = 0; j < QK_K; ++j) {
+      if (L[j] > 3) { hmask[m] |= hm; L[j] -= 4; }
+      if (++m == 32) { m = 0; hm <<= 1; }
+    }
+    for (int j = 0; j < QK_K; j += 128)
+      for (int l = 0; l < 32; ++l) qs[j / 4 + l] = (uint8_t)(L[j + l] | (L[j + l + 32] << 2) | (L[j + l + 64] << 4) | (L[j + l + 96] << 6));
+  }
+}
+
 /* one row of k values with the importance vector qw[k]; 0 ok, -1 for a type without a weighted quantizer here */
 int orc_quantize_row_imatrix(int type, const float *x, void *blocks, int64_t k, const float *qw) {
   switch (type) {
   case ORC_Q4_K: case ORC_Q5_K: quantize_q4_5_K_imatrix(type, x, (uint8_t *)blocks, k, qw); return 0;
   case ORC_Q6_K: quantize_q6_K_imatrix(x, (uint8_t *)blocks, k, qw); return 0;
+  case ORC_Q2_K: quantize_q2_K_imatrix(x, (uint8_t *)blocks, k, qw); return 0;
+  case ORC_Q3_K: quantize_q3_K_imatrix(x, (uint8_t *)blocks, k, qw); return 0;
   default: return -1;
   }
 }

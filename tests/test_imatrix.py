@@ -2,7 +2,7 @@
 
 Reference: `mistralrs-quant/src/imatrix.rs` (statistics, `.cimatrix`; its unit tests :234-452 are restated below), `gguf/mod.rs:200-262`
 (`quantize_expert_stack`), `:633-700` (`apply_isq` with `imatrix_weight`), `:710-739` (`begin/end_track_stats`).  The weighted quantizers are candle's
-`QTensor::quantize_imatrix` = GGML's `quantize_row_q{4,5,6}_K_impl` with quant_weights; candle is a git dependency outside the tree, so the oracle
+`QTensor::quantize_imatrix` = GGML's `quantize_row_q{2,3,4,5,6}_K_impl` with quant_weights; candle is a git dependency outside the tree, so the oracle
 restates the public GGML algorithm ("parity unpinned") and the device blocks must equal it bit for bit.  C-ABI bodies run on the wave64 host emulation
 (CPU) and on the MI355X; the Python surface (`ImatrixLayerStats`, `GgufMatMul`, `isq`) needs device tensors: `-m gpu`."""
 import ctypes as C
@@ -55,14 +55,14 @@ def check_isq_imatrix(oracle, be, tname, src):
     assert ew(d_w) <= ew(d_p)
 
 
-@pytest.mark.parametrize("tname", ["Q4_K", "Q5_K", "Q6_K"])
+@pytest.mark.parametrize("tname", ["Q2_K", "Q3_K", "Q4_K", "Q5_K", "Q6_K"])
 @pytest.mark.parametrize("src", ["f32", "bf16", "f16"])
 def test_isq_imatrix_host_emulation(oracle, tname, src):
     check_isq_imatrix(oracle, HostBackend(), tname, src)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tname", ["Q4_K", "Q5_K", "Q6_K"])
+@pytest.mark.parametrize("tname", ["Q2_K", "Q3_K", "Q4_K", "Q5_K", "Q6_K"])
 @pytest.mark.parametrize("src", ["f32", "bf16"])
 def test_isq_imatrix_gpu(oracle, dev, tname, src):
     check_isq_imatrix(oracle, GpuBackend(dev), tname, src)

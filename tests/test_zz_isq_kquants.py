@@ -105,7 +105,7 @@ def test_isq_host_tables():
     from mistralrs_amd import isq
     from mistralrs_amd.gguf.qtensor import GgmlDType as G
     assert [t.name for t in G if isq.supports_imatrix(t)] == ["Q2K", "Q3K", "Q4K", "Q5K", "Q6K"]
-    assert all(isq.supports_imatrix(t) for t in G if isq.imatrix_capable(t))
+    assert all(isq.supports_imatrix(t) == isq.imatrix_capable(t) for t in G)
     # bf16 source: Q4_K 256 * 2 / 144 = 3.55 -> 3 (256 / 3 * 2 = 170 >= 144); Q8_0 32 * 2 / 34 -> 1; Q4_0 64 / 18 -> 3 (32 / 3 * 2 = 20 >= 18); Q6_K 512 / 210 -> 2
     assert isq.pack_factor(G.Q4K) == 3 and isq.pack_factor(G.Q8_0) == 1 and isq.pack_factor(G.Q4_0) == 3 and isq.pack_factor(G.Q6K) == 2
     assert isq.pack_factor(G.Q2K) == 6 and isq.pack_factor(G.Q4K, 4) == 7   # 512 / 84 = 6; f32 source: 1024 / 144 = 7 (256 / 7 * 4 = 144 >= 144)
