@@ -65,7 +65,9 @@ def check_proj(O, be, tname, n, k, b, mode, seed=0):
 CASES = [("Q4_K", 70, 512, 1, 0), ("Q4_K", 33, 1024, 2, 1), ("Q4_K", 16, 4096, 1, 1), ("Q4_K", 9, 768, 3, 0), ("Q4_K", 24, 3584, 1, 0),
          ("Q5_K", 40, 512, 1, 0), ("Q5_K", 12, 2048, 2, 1),
          ("Q6_K", 50, 512, 1, 0), ("Q6_K", 20, 4096, 1, 1), ("Q6_K", 7, 768, 8, 0), ("Q6_K", 10, 3584, 2, 0),
-         ("Q8_0", 40, 512, 1, 0), ("Q8_0", 18, 1056, 2, 1), ("Q8_0", 8, 4096, 1, 0)]
+         ("Q8_0", 40, 512, 1, 0), ("Q8_0", 18, 1056, 2, 1), ("Q8_0", 8, 4096, 1, 0),
+         # activation rows of a 70B down_proj (K = 28672): 5 and 8 columns exceed the LDS budget of one launch and run as column groups (advisor, round 2)
+         ("Q4_K", 5, 28672, 5, 1), ("Q6_K", 3, 28672, 8, 0)]
 
 
 @pytest.mark.parametrize("tname,n,k,b,mode", CASES)
