@@ -214,7 +214,7 @@ def _tp_runner_worker(rank, world, port, q, experts=0):
                          rope_theta=10000.0, max_position_embeddings=256, max_batch=2, max_context_len=64, tp_world_size=world, tp_rank=rank, **moe)
     mt = build(tp_cfg, rank, world)
     mt.set_comm(Comm())
-    toks = [(1000 + i) % vocab for i in range(4)]
+    toks = [(1000 + i) % vocab for i in range(2 if experts else 4)]  # MoE on the host emulation: ~25 s per position and model
     outs = []
     for pos, t in enumerate(toks):      # fused decode path, one all-reduce per row-parallel projection
         mt.set_state([t], [pos])
