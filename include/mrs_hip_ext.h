@@ -38,11 +38,12 @@ int mrs_decode_proj_scaled(const void *w, int type, int n, int K, const void *y_
 int mrs_vec_add_f32(float *a, const float *b, size_t n, void *stream); /* a += b */
 int mrs_decode_norm_proj(const void *w, int type, int n, int K, const float *h, const float *norm_w, float eps, float *out,
                          int out_stride, int b, void *stream);
-/* ---------------------------------------------------------------- decode engine (ext_dec.hip, dec_core.cuh)
+/* ---------------------------------------------------------------- decode engine (ext_dec.hip, dec_gemv.cuh, dec_core2.cuh)
  * The batch <= 8 decode step in the arithmetic of the reference CPU path (GgufMatMul::forward_raw -> candle QMatMul with f32
  * activations, mistralrs-quant/src/gguf/mod.rs:465-478): activations are quantized to Q8_K (K-quants) / Q8_0 (Q8_0 weights) inside
- * the kernels, integer block dots, f32 combination -- north_star's parity target.  Weights are read from a DECODE LAYOUT made once at
- * load time from the unmodified GGUF blocks (same bits, row-major planes; Q4_K / Q5_K sub-block scales expanded from 6 to 8 bits). */
+ * the kernels, integer block dots, f32 combination in the order "ORD-U" (one term per 256-value superblock, four runs, dec_core2.cuh) that the prompt
+ * GEMM (mrs_gemm_qi) shares -- north_star's parity target.  Weights are read from a DECODE LAYOUT made once at load time from the unmodified GGUF
+ * blocks (same bits; records of up to 64 superblocks, one superblock per lane; Q4_K / Q5_K sub-block scales expanded from 6 to 8 bits).  K % 256 == 0. */
 typedef struct { const void *planes; int type; long long n, k; } mrs_dec_mat; /* planes: mrs_dec_repack output for a [n][k] tensor */
 int mrs_dec_supported(int ggml_type);                         /* q4_k q5_k q6_k q8_0 */
 size_t mrs_dec_repack_bytes(int ggml_type, long long n, long long k); /* 0 = unsupported type / shape */
@@ -67,14 +68,8 @@ int mrs_dec_proj_top2(const mrs_dec_mat *w, int n, const int32_t *expert_sel, co
 /* (RmsNorm when norm_w) + GEMV; mode 0: out = W x; mode 1: out = out * resid_scale + s * W x with s = *acc_scale (NULL: 1) */
 int mrs_dec_proj(const mrs_dec_mat *w, int n, const int32_t *expert_sel, const float *x, int ldx, const float *norm_w, float eps, float *out,
                  int ld_out, int mode, float resid_scale, const float *acc_scale, int b, void *stream);
-/* Short-context decode attention in one launch (max_context_len <= 1024, head size 128, block 32, even GQA group): split-KV attention with the
- * partials in LDS, merge, and the Q8_K quantization o_proj's prologue would do; img_out = activation image of b columns x num_heads * 128 values
- * (mrs_dec_act_image_bytes) for mrs_dec_proj_img, out_f32 (may be NULL) = the f32 result.  Same bits as mrs_decode_attention_f32_* followed by
- * mrs_dec_proj.  Returns -3 when the shape is outside the kernel (caller falls back), -1 on bad arguments. */
+/* bytes of the pre-quantized activation image of b columns of k values (the layout the GEMV prologue builds in LDS) */
 size_t mrs_dec_act_image_bytes(int k, int b);
-int mrs_dec_attention_q8k(void *img_out, float *out_f32, const float *q, const void *k_cache, const void *v_cache, int num_kv_heads, float scale,
-                          const uint32_t *block_tables, const uint32_t *context_lens, int block_size, int max_context_len, int num_seqs, int num_heads,
-                          int head_size, int max_blocks_per_seq, int q_stride, int kv_block_stride, int kv_head_stride, int kv_dtype, void *stream);
 /* Decode attention of the engine in ONE launch (round 3 default): split-KV waves (32-token blocks, f32 online softmax through the reference's
  * fast_exp, attention/backends/cpu/elem.rs:417-433) publish their partials; the last workgroup to arrive on the (sequence, kv head) ticket merges them
  * in the order of single_q.rs run_barrier and writes out_f32 [b][num_heads * 128] (may be NULL when an image is requested) and, for even GQA groups
@@ -85,32 +80,9 @@ int mrs_dec_attention(float *out_f32, void *img_out, unsigned *ticket, float *pa
                       const void *v_cache, int num_kv_heads, float scale, const uint32_t *block_tables, const uint32_t *context_lens, int block_size,
                       int max_context_len, int num_seqs, int num_heads, int head_size, int max_blocks_per_seq, int q_stride, int kv_block_stride,
                       int kv_head_stride, int kv_dtype, int sliding_window /* > 0: attend the last W positions only (Mistral), 0 = all */, void *stream);
-size_t mrs_dec_proj_img_max_bytes(void); /* largest activation image mrs_dec_proj_img stages */
-/* GEMV on a pre-quantized activation image (K-quant weights only; -3: image larger than the prologue's staging registers) */
+size_t mrs_dec_proj_img_max_bytes(void); /* largest activation image mrs_dec_proj_img takes (the LDS budget) */
+/* GEMV on a pre-quantized activation image (K-quant weights only) */
 int mrs_dec_proj_img(const mrs_dec_mat *w, int n, const void *x_img, float *out, int ld_out, int mode, float resid_scale, int b, void *stream);
-/* Persistent decode step: ONE launch runs phases [phase_begin, phase_end) of a decode step for one sequence (b = 1) on a grid of resident
- * workgroups (one per CU) with device-side phase barriers; the weight stream of a phase starts before the barrier in front of it completes.
- * Phase ids: 0 = embedding, 1 + 6 l + {0 qkv, 1 attention splits, 2 attention merge, 3 o_proj, 4 gate/up, 5 down}, 1 + 6 L = final norm + lm_head.
- * Same arithmetic and bits as the launch-per-phase calls above (mrs_dec_qkv, mrs_decode_attention_f32_*, mrs_dec_proj, mrs_dec_gate_up).
- * Returns 0; -3 = shape / batch outside the persistent kernel (use the per-phase calls); -1 = bad arguments. */
-typedef struct { mrs_dec_mat q, k, v, o, gate, up, down; const float *attn_norm, *ffn_norm; void *k_cache, *v_cache; } mrs_dec_layer;
-typedef struct {
-  int num_layers;
-  mrs_dec_mat lm_head; const float *final_norm;
-  const void *embd; int embd_type;              /* token_embd.weight as registered (GGUF blocks or f32 / f16 / bf16) */
-  const int32_t *input_ids;
-  float *h, *q, *attn, *act, *logits, *part_o, *part_m, *part_l; /* h [hidden], q / attn [heads * 128], act [ffn], logits [vocab]; attention partials as mrs_decode_attention_* */
-  const uint32_t *block_tables, *context_lens; const int32_t *positions; const int64_t *slot_mapping; const float *cos_t, *sin_t;
-  int hidden, num_heads, num_kv_heads, head_dim, rot_pairs, ff, vocab, block_size, max_blocks_per_seq, max_context_len;
-  float eps, resid_scale;
-  int kv_dtype;                                 /* 1 = bf16 pages, 0 = f16 */
-} mrs_dec_step_args;
-size_t mrs_dec_step_table_bytes(int num_layers);
-int mrs_dec_step_num_phases(int num_layers);
-/* host -> device phase table of a model (blocking copy, load-time); all pointers must outlive the table */
-int mrs_dec_build_step_table(const mrs_dec_step_args *args, const mrs_dec_layer *layers, void *device_table);
-/* sync: 8 bytes of device memory (arrival counter, error flag: non-zero after a launch = the grid was not resident); max_k = longest GEMV row */
-int mrs_dec_step(const void *device_table, int num_layers, int max_k, void *sync, int phase_begin, int phase_end, void *stream);
 /* Fused HQQ dequant-GEMV for decode (ext_hqq_gemv.hip): out [b][ldo] = x [b][ldx] . W^T (+ bias) straight from the packed 4-bit / 8-bit HQQ tensor (group 64, axis 0),
  * b <= 8; dtype 0 = f32, 1 = f16, 2 = bf16 for x / scale / zero / bias / out.  Role: HqqLayer::forward_raw (hqq/mod.rs:1092-1100,1163-1171) without materialising
  * dequantize_w(); the dequantized values are bit-identical to dequantize_{4,8}bit_u8_kernel_*.  -1 = outside the fused kernel (keep dequantize + dense matmul). */
@@ -245,8 +217,6 @@ int mrs_gemm2_q_bf16_multi(int nseg, const void *const *w, const int *N, float *
 int mrs_llama_set_gemm2_tensor(void *model, const char *name, const void *planes); /* MFMA-layout copy of a dense linear registered with mrs_llama_set_tensor */
 /* decode-layout copy (mrs_dec_repack output, caller-owned) of a linear tensor already registered with mrs_llama_set_tensor */
 int mrs_llama_set_dec_tensor(void *model, const char *name, const void *planes);
-int mrs_llama_set_fused_attention(void *model, int on); /* decode engine: 1 = one-launch attention + Q8_K image for contexts <= 1024 (mrs_dec_attention_q8k), 0 (default: measured faster) = split + merge kernels */
-int mrs_llama_set_dec_persist(void *model, int mode); /* decode engine, b = 1: 1 = one persistent launch per step (default), 2 = same kernel phase by phase, 0 = per-phase kernels */
 int mrs_llama_set_mode(void *model, int use_fused); /* switch the decode path (values of mrs_llama_config.use_fused) */
 void *mrs_llama_create(const mrs_llama_config *cfg);
 void mrs_llama_destroy(void *model);

@@ -56,11 +56,13 @@ def libraries():
     optional = {
         "libmistralrsquant.so": ["quant_ops.hip", "mmq.hip", "moe.hip", "gemv.hip", "hqq.hip"],
         "libmistralrscuda.so": ["core_ops.hip"],
-        "libmrs_hip_ext.so": ["ext_decode.hip", "ext_dec.hip", "ext_gemm.hip", "ext_gemm2.hip", "ext_attn_prefill.hip", "ext_comm.hip", "ext_p2p.hip", "ext_hqq_gemv.hip", "ext_isq.hip",
+        "libmrs_hip_ext.so": ["ext_decode.hip", "ext_dec.hip", "ext_dec2.hip", "ext_gemm.hip", "ext_gemm2.hip", "ext_attn_prefill.hip", "ext_comm.hip", "ext_p2p.hip", "ext_hqq_gemv.hip", "ext_isq.hip", "ext_prefetch.hip",
                               "host/runtime.cpp", "host/kv_cache_manager.cpp"],
     }
     # experiment knob (default off): MRS_DECODE_MIN_WAVES=4 caps the decode GEMV kernels at 128 VGPRs (csrc/ext_decode.hip); use with --force
     decode_defs = {"ext_decode.hip": (f"-DMRS_DECODE_MIN_WAVES={os.environ['MRS_DECODE_MIN_WAVES']}",)} if os.environ.get("MRS_DECODE_MIN_WAVES") else {}
+    if os.path.exists(os.path.join(CSRC, "ext_dec_gemv.hip")):  # the GEMV phase kernel of the decode engine, one translation unit per activation-column count
+        libs.setdefault("libmrs_hip_ext.so", []).extend(_tu("ext_dec_gemv.hip", f"ext_dec_gemv_nc{nc}.o", (f"-DMRS_DEC_NC={nc}",)) for nc in range(1, 9))
     for lib, srcs in optional.items():
         for s in srcs:
             if os.path.exists(os.path.join(CSRC, s)):

@@ -179,7 +179,6 @@ struct Workspace {  // carve-up of the caller's scratch
   int32_t *moe_ids;         // [B][top_k]
   float *moe_w;             // [B][top_k]
   void *moe_y;              // [top_k] Q8_1 rows of the selected experts' activations
-  void *dec_table, *dec_sync;  // persistent decode step: device table of layers, 2 x u32 sync words
   float *moe_act;           // decode engine: [top_k][intermediate] f32 activations of the selected experts
   void *attn_img;           // decode engine: Q8_K activation image of the attention result (mrs_dec_attention / mrs_dec_attention_q8k -> mrs_dec_proj_img)
   unsigned *attn_ticket;    // decode engine: [max_batch][kv heads] arrival counters of mrs_dec_attention (zero at rest)
@@ -196,10 +195,7 @@ class Llama {
   mrs_llama_buffers bufs{};
   Workspace ws{};
   bool have_bufs = false;
-  mutable bool dec_table_ready = false, dec_table_unfit = false;
-  int dec_persist = [] { const char *e = getenv("MRS_DEC_PERSIST"); return e ? atoi(e) : 0; }();  // default 0: measured slower than per-phase kernels on MI355X
   int attn2 = [] { const char *e = getenv("MRS_DEC_ATTN2"); return e ? atoi(e) : 1; }();  // decode engine attention: 1 = split kernel with the last-arriver merge + Q8_K image for o_proj (round 3, one launch), 0 = split + merge launches
-  int fused_attn = [] { const char *e = getenv("MRS_DEC_FUSED_ATTN"); return e ? atoi(e) : 0; }();  // decode engine: one-launch attention for contexts <= 1024; measured 1-5 % SLOWER per token than split + merge (profiles/round2_decode_experiments.md 5): off
   void *comm = nullptr;  // RCCL communicator (ext_comm.hip) when cfg.world_size > 1
   void *p2p = nullptr;   // one-shot peer-mailbox all-reduce (ext_p2p.hip) for decode-sized messages
 
@@ -228,7 +224,6 @@ class Llama {
     t += align(ya) + align(yb);
     t += align(B * c.num_heads * parts * c.head_dim * 4) + 2 * align(B * c.num_heads * parts * 4);
     t += align(B * 8);
-    t += align(mrs_dec_step_table_bytes(c.num_layers)) + align(64);  // persistent decode step: layer table, sync words
     t += align(mrs_dec_act_image_bytes((int)nq, (int)B)) + align(B * (size_t)c.num_kv_heads * 4);
     if (c.num_experts > 0) {
       const size_t k = std::max(1, (int)c.num_experts_per_tok);
@@ -256,10 +251,8 @@ class Llama {
     ws.exp_sums = (float *)take(B * cfg.num_heads * parts * 4);
     ws.max_logits = (float *)take(B * cfg.num_heads * parts * 4);
     ws.sample_scratch = take(B * 8);
-    ws.dec_table = take(mrs_dec_step_table_bytes(cfg.num_layers)); ws.dec_sync = take(64);
     ws.attn_img = take(mrs_dec_act_image_bytes((int)nq, (int)B));
     ws.attn_ticket = (unsigned *)take(B * (size_t)cfg.num_kv_heads * 4);
-    dec_table_ready = false; dec_table_unfit = false;
     if (cfg.num_experts > 0) {
       const size_t k = std::max(1, (int)cfg.num_experts_per_tok);
       ws.moe_ids = (int32_t *)take(B * k * 4); ws.moe_w = (float *)take(B * k * 4);
@@ -438,54 +431,13 @@ class Llama {
     const int d = cfg.hidden_size, hd = cfg.head_dim, nq = cfg.num_heads * hd, ff = cfg.intermediate_size, kvd = cfg.kv_f16 ? 0 : 1;
     const int bs = cfg.block_size, kvh = cfg.num_kv_heads;
     const int eff_max = std::min(cfg.max_blocks_per_seq * bs, cfg.max_context_len);
-    // one sequence on one GPU, dense FFN: the whole step is ONE persistent launch (mrs_dec_step); everything else goes phase by phase
-    // dec_persist: 1 = one launch per step, 2 = the same kernel launched phase by phase (debugging / per-phase profiles / the host emulation), 0 = off
-    if (dec_persist && b == 1 && cfg.world_size <= 1 && cfg.num_experts == 0 && cfg.rope_interleaved) {  // the step table has no rotate-half qkv phase
-      int rc = 0;
-      if (!dec_table_ready && !dec_table_unfit) {
-        std::vector<mrs_dec_layer> ls(blocks.size());
-        for (size_t i = 0; i < blocks.size(); ++i) {
-          const Block &bl = blocks[i];
-          ls[i] = mrs_dec_layer{bl.dq, bl.dk, bl.dv, bl.dout, bl.dgate, bl.dup, bl.ddown, bl.input_layernorm, bl.post_attention_layernorm, bl.key_cache, bl.value_cache};
-        }
-        const QTensor *te = wte->get_qtensor();
-        mrs_dec_step_args a{};
-        a.num_layers = cfg.num_layers; a.lm_head = dlm_head; a.final_norm = ln_f; a.embd = te->data; a.embd_type = te->dtype;
-        a.input_ids = bufs.input_ids; a.h = ws.h; a.q = ws.q; a.attn = ws.attn; a.act = ws.act; a.logits = bufs.logits;
-        a.part_o = (float *)ws.attn_ws; a.part_m = ws.max_logits; a.part_l = ws.exp_sums;
-        a.block_tables = bufs.block_tables; a.context_lens = bufs.context_lens; a.positions = bufs.positions; a.slot_mapping = bufs.slot_mapping;
-        a.cos_t = bufs.cos_table; a.sin_t = bufs.sin_table; a.hidden = d; a.num_heads = cfg.num_heads; a.num_kv_heads = kvh; a.head_dim = hd;
-        a.rot_pairs = cfg.rot_dim / 2; a.ff = ff; a.vocab = cfg.vocab_size; a.block_size = bs; a.max_blocks_per_seq = cfg.max_blocks_per_seq;
-        a.max_context_len = cfg.max_context_len; a.eps = cfg.rms_eps; a.resid_scale = 1.0f; a.kv_dtype = kvd;
-        rc = mrs_dec_build_step_table(&a, ls.data(), ws.dec_table);
-        if (rc == -1) return fail("decode engine: step table refused");
-        dec_table_ready = rc == 0;
-        dec_table_unfit = rc == -3;
-      }
-      if (dec_table_unfit) rc = -3;
-      if (rc == 0) {
-        const int np = mrs_dec_step_num_phases(cfg.num_layers), max_k = std::max(std::max(d, ff), nq);
-        if (dec_persist == 2) for (int p = 0; p < np && rc == 0; ++p) rc = mrs_dec_step(ws.dec_table, cfg.num_layers, max_k, ws.dec_sync, p, p + 1, s);
-        else rc = mrs_dec_step(ws.dec_table, cfg.num_layers, max_k, ws.dec_sync, 0, np, s);
-      }
-      if (rc == 0) return 0;
-      if (rc != -3) return fail("mrs_dec_step failed (%d)", rc);
-    }
     if (wte->embedding_forward_raw(bufs.input_ids, b, ws.h, s)) return -1;
     for (const Block &bl : blocks) {
       // rotate-half RoPE: the caller registered q / k decode planes in pair order (mrs_dec_qkv_neox; llama.py permutes the rows before the repack)
       if ((cfg.rope_interleaved ? mrs_dec_qkv : mrs_dec_qkv_neox)(&bl.dq, &bl.dk, &bl.dv, ws.h, d, bl.input_layernorm, cfg.rms_eps, ws.q, bl.key_cache, bl.value_cache,
                                                                   bufs.slot_mapping, bufs.positions, bufs.cos_table, bufs.sin_table, hd, cfg.rot_dim / 2, kvh, bs, kvd, b, s))
         return fail("mrs_dec_qkv refused the layer");
-      // short contexts: attention + merge + Q8_K quantization in one launch, o_proj copies the activation image (-3: shape outside that kernel)
-      int arc = fused_attn && bl.dout.type != 8 /* Q8_0 weights take Q8_0 activations */ ? mrs_dec_attention_q8k(ws.attn_img, nullptr, ws.q, bl.key_cache, bl.value_cache, kvh, 1.0f / sqrtf((float)hd), bufs.block_tables,
-                                                    bufs.context_lens, bs, eff_max, b, cfg.num_heads, hd, cfg.max_blocks_per_seq, nq, kvh * hd * bs, hd * bs, kvd, s)
-                           : -3;
-      if (arc == 0) arc = mrs_dec_proj_img(&bl.dout, d, ws.attn_img, ws.h, d, 1, rs, b, s);
-      if (arc != 0 && arc != -3) return fail("fused decode attention / o_proj failed (%d)", arc);
-      if (arc == 0) {
-        if (all_reduce(ws.h, (size_t)b * d, s)) return fail("o_proj all-reduce failed: %s", g_last_error.c_str());
-      } else if (attn2) {
+      if (attn2) {
         // one launch: splits + last-arriver merge; even GQA groups hand o_proj the Q8_K image of the result (Q8_0 weights take Q8_0 activations: f32 result)
         const bool want_img = bl.dout.type != 8 && (cfg.num_heads / kvh) % 2 == 0 && mrs_dec_act_image_bytes(nq, b) <= mrs_dec_proj_img_max_bytes();
         const int rc2 = mrs_dec_attention(want_img ? nullptr : ws.attn, want_img ? ws.attn_img : nullptr, ws.attn_ticket, (float *)ws.attn_ws, ws.max_logits, ws.exp_sums, ws.q,
@@ -791,7 +743,7 @@ class Llama {
   int forward_logits(int b, hipStream_t s) const {
     if (check_ready(b)) return -1;
     // sliding-window attention (Mistral) exists in the decode engine's split attention and in the MFMA prefill only: every other path would silently attend everything
-    if (cfg.sliding_window > 0 && (cfg.use_fused != 2 || !attn2 || fused_attn || dec_persist))
+    if (cfg.sliding_window > 0 && (cfg.use_fused != 2 || !attn2))
       return fail("sliding_window %d needs the decode engine with its default attention (use_fused = 2, MRS_DEC_ATTN2 / MRS_DEC_FUSED_ATTN / MRS_DEC_PERSIST unset)", cfg.sliding_window);
     if (cfg.use_fused == 2) {  // the engine never falls back silently: its arithmetic (Q8_K activations) differs from the Q8_1 paths
       if (!engine_ok()) return fail("decode engine: needs interleaved RoPE, head_dim 128, block 32, q4_k/q5_k/q6_k/q8_0 linears and a decode-layout copy of every linear");
@@ -903,7 +855,6 @@ extern "C" int mrs_llama_set_dec_tensor(void *mm, const char *cname, const void 
     if (!t || !t->data) return mrs_host::fail("decode layout for %s: register the tensor with mrs_llama_set_tensor first", cname);
     if (!mrs_dec_repack_bytes(t->dtype, t->rows, t->cols)) return mrs_host::fail("decode layout for %s: ggml dtype %d / shape not supported", cname, t->dtype);
     slot = mrs_dec_mat{planes, t->dtype, (long long)t->rows, (long long)t->cols};
-    m.dec_table_ready = false; m.dec_table_unfit = false;
     return 0;
   };
   auto lin = [&](mrs_dec_mat &slot, const std::unique_ptr<mrs_host::GgufMatMul> &l) { return bind(slot, l ? l->get_qtensor() : nullptr); };
@@ -956,17 +907,10 @@ extern "C" int mrs_llama_set_mode(void *m, int use_fused) {
   ((Llama *)m)->cfg.use_fused = use_fused;
   return 0;
 }
-extern "C" int mrs_llama_set_dec_persist(void *m, int mode) {
-  if (mode < 0 || mode > 2) return mrs_host::fail("mrs_llama_set_dec_persist: 0, 1 or 2");
-  ((Llama *)m)->dec_persist = mode;
-  return 0;
-}
-extern "C" int mrs_llama_set_fused_attention(void *m, int on) { ((Llama *)m)->fused_attn = on ? 1 : 0; return 0; }
 extern "C" int mrs_llama_set_kv_cache(void *m, int layer, void *k, void *v) {
   Llama &l = *(Llama *)m;
   if (layer < 0 || layer >= l.cfg.num_layers) return mrs_host::fail("kv cache: layer %d out of range", layer);
   l.blocks[layer].key_cache = k; l.blocks[layer].value_cache = v;
-  l.dec_table_ready = false; l.dec_table_unfit = false;
   return 0;
 }
 extern "C" int mrs_llama_set_buffers(void *m, const mrs_llama_buffers *b) { return ((Llama *)m)->set_buffers(*b); }

@@ -158,7 +158,6 @@ class Llama:
         L.mrs_llama_set_comm.argtypes = [C.c_void_p, C.c_void_p]
         L.mrs_llama_set_dec_tensor.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
         L.mrs_llama_set_mode.argtypes = [C.c_void_p, C.c_int]
-        L.mrs_llama_set_dec_persist.argtypes = [C.c_void_p, C.c_int]
         L.mrs_dec_repack_bytes.restype = C.c_size_t
         L.mrs_dec_repack_bytes.argtypes = [C.c_int, C.c_longlong, C.c_longlong]
         L.mrs_dec_repack.argtypes = [C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p]
@@ -314,17 +313,6 @@ class Llama:
     def decode_path(self) -> str:
         """'engine' (ext_dec.hip, reference CPU-path arithmetic), 'fused' (round-1 kernels, Q8_1) or 'reference-sequence'."""
         return "engine" if (self._engine_wanted and self._engine_ok) else ("fused" if self.cfg.use_fused else "reference-sequence")
-
-    def set_decode_persist(self, mode: int) -> None:
-        """Decode engine at b = 1: 0 = per-phase kernels (default: measured faster on the MI355X), 1 = one persistent launch per step, 2 = the same kernel one phase per launch."""
-        self._chk(self._L.mrs_llama_set_dec_persist(self._h, mode))
-        self._graph = None
-
-    def set_fused_attention(self, on: bool) -> None:
-        """Decode engine: True = the round-2 one-launch attention with the partials in LDS (contexts <= 1024; measured slower, off by default), False = the split kernel with the last-arriver merge (default); same bits."""
-        self._L.mrs_llama_set_fused_attention.argtypes = [C.c_void_p, C.c_int]
-        self._chk(self._L.mrs_llama_set_fused_attention(self._h, int(on)))
-        self._graph = None
 
     def _set_mode(self) -> None:
         mode = 2 if (self._engine_wanted and self._engine_ok) else int(bool(self.cfg.use_fused))

@@ -298,107 +298,101 @@ int64_t orc_div_by_mismatches(const float *x, const float *m, int64_t n) {
   return bad;
 }
 
-/* ================================================================== the engine's GEMV order (mistral.rs_amd/csrc/dec_core.cuh)
+/* ================================================================== the engine's GEMV order "ORD-U" (mistral.rs_amd/csrc/dec_core2.cuh, ext_gemm_qi.hip)
  * Same integers and the same f32 products as the reference CPU matvec (activation row -> Q8_K / Q8_0, integer dots per sub-block, d_w * d_x scaling;
- * orc_matmul_cpu / orc_gemv_cpu_fast); the f32 SUMMATION ORDER of a row is the kernel's: the row is cut into units of 32 (Q4_K, Q5_K), 64 (Q6_K) or 16
- * (Q8_0) weights, unit u goes to lane u % 64 of tile u / 64; a lane keeps one f32 chain over its tiles
- *     K-quants:  acc = fma(d_w d_x, (float)isum_unit, acc);  Q4_K / Q5_K also  acc = fma(-(dmin_w d_x), (float)msum_unit, acc)
- *     Q8_0:      lanes 2b, 2b + 1 hold the two halves of 32-block b; the even lane adds (float)isum_block * d_w * d_x
- * and the 64 chains are combined by wave_sum_all_64 (above).  Written from the format definitions, not from the kernel source. */
+ * orc_matmul_cpu / orc_gemv_cpu_fast).  The f32 combination is ONE order shared by the batch-1 GEMV, the batched GEMV and the prompt GEMM on the matrix cores:
+ *     T_sb  one f32 term per 256-value superblock from its EXACT integer sums:
+ *             Q4_K / Q5_K:  fma(d_w d_x, (float)isum, -((dmin_w d_x) (float)msum))      isum = sum_j sc_j <q_j, a_j>,  msum = sum_j m_j sum(a_j)
+ *             Q6_K:         (d_w d_x) (float)isum                                       isum = sum_r sc_r <q_r - 32, a_r>
+ *             Q8_0:         t = ((float)isum_0 dw_0) dx_0;  t = t + ((float)isum_b dw_b) dx_b  for the 8 blocks of the 256 values in order
+ *     the row's S superblocks are cut into 4 runs of Cs = ceil(S / 4); c_p = the T of run p added left to right (an empty run is +0)
+ *     row = ((c_0 + c_1) + c_2) + c_3
+ * Written from the format definitions, not from the kernel source. */
 static void k4sm(int j, const uint8_t *p, int *sc, int *mn) {
   if (j < 4) { *sc = p[j] & 63; *mn = p[j + 4] & 63; }
   else { *sc = (p[j + 4] & 0xF) | ((p[j - 4] >> 6) << 4); *mn = (p[j + 4] >> 4) | ((p[j] >> 6) << 4); }
 }
 static inline float h2f_(const uint8_t *p) { uint16_t v; memcpy(&v, p, 2); return orc_fp16_to_fp32(v); }
 
-static float row_engine_q45K(int type, const uint8_t *w, int S, const uint8_t *y) {
-  const int ts = type == ORC_Q4_K ? 144 : 176, upr = S * 8, tpr = (upr + 63) / 64;
-  float acc[64] = {0};
-  for (int t = 0; t < tpr; ++t)
-    for (int lane = 0; lane < 64; ++lane) {
-      const int u = t * 64 + lane;
-      if (u >= upr) continue;
-      const int sb = u >> 3, c = (u >> 1) & 3, hp = u & 1, ra = 4 * c + hp, rb = ra + 2;
-      const uint8_t *b = w + (size_t)sb * ts, *yb = y + (size_t)sb * 292;
-      float yd; memcpy(&yd, yb, 4);
-      const int8_t *q8 = (const int8_t *)(yb + 4);
-      int16_t bs[16]; memcpy(bs, yb + 260, 32);
-      const uint8_t *qh = b + 16, *qs = b + (type == ORC_Q4_K ? 16 : 48);
-      int sca, ma, scb, mb;
-      k4sm(2 * c, b + 4, &sca, &ma);
-      k4sm(2 * c + 1, b + 4, &scb, &mb);
-      int da = 0, db = 0;
-      for (int i = 0; i < 16; ++i) {
-        const int l = hp * 16 + i;
-        int lo = qs[c * 32 + l] & 0xF, hi = qs[c * 32 + l] >> 4;
-        if (type == ORC_Q5_K) { lo |= ((qh[l] >> (2 * c)) & 1) << 4; hi |= ((qh[l] >> (2 * c + 1)) & 1) << 4; }
-        da += lo * q8[ra * 16 + i];
-        db += hi * q8[rb * 16 + i];
-      }
-      const int isum = scb * db + sca * da, msum = mb * bs[rb] + ma * bs[ra];
-      const float d = h2f_(b), dmin = h2f_(b + 2);
-      acc[lane] = fmaf(d * yd, (float)isum, acc[lane]);
-      acc[lane] = fmaf(-(dmin * yd), (float)msum, acc[lane]);
+/* exact integer sums of one superblock against one Q8_K activation block (292 B: d f32, 256 int8, 16 int16 sums) */
+static float term_q45K(int type, const uint8_t *b, const uint8_t *yb) {
+  float yd; memcpy(&yd, yb, 4);
+  const int8_t *q8 = (const int8_t *)(yb + 4);
+  const uint8_t *qh = b + 16, *qs = b + (type == ORC_Q4_K ? 16 : 48);
+  int32_t isum = 0, msum = 0;
+  for (int j = 0; j < 8; ++j) {  /* sub-block j: 32 values at 32 j */
+    int sc, mn; k4sm(j, b + 4, &sc, &mn);
+    int32_t dj = 0, bs = 0;
+    for (int l = 0; l < 32; ++l) {
+      int q = (j & 1) ? (qs[(j >> 1) * 32 + l] >> 4) : (qs[(j >> 1) * 32 + l] & 0xF);
+      if (type == ORC_Q5_K) q |= ((qh[l] >> j) & 1) << 4;
+      dj += q * q8[32 * j + l];
+      bs += q8[32 * j + l];
     }
-  return wave_sum_all_64(acc);
+    isum += sc * dj;
+    msum += mn * bs;
+  }
+  const float d = h2f_(b), dmin = h2f_(b + 2);
+  return fmaf(d * yd, (float)isum, -((dmin * yd) * (float)msum));
+}
+static float term_q6K(const uint8_t *b, const uint8_t *yb) {
+  float yd; memcpy(&yd, yb, 4);
+  const int8_t *q8 = (const int8_t *)(yb + 4);
+  const uint8_t *ql = b, *qhh = b + 128;
+  const int8_t *sc = (const int8_t *)(b + 192);
+  int32_t isum = 0;
+  for (int r = 0; r < 16; ++r) {
+    int32_t dsum = 0;
+    for (int i = 0; i < 16; ++i) {
+      const int e = r * 16 + i, hh = e / 128, pos = e % 32, qt = (e % 128) / 32, ii = hh * 64 + pos + (qt % 2) * 32;
+      const int lo = qt < 2 ? (ql[ii] & 15) : (ql[ii] >> 4), hi = (qhh[hh * 32 + pos] >> (qt * 2)) & 3;
+      dsum += ((lo | (hi << 4)) - 32) * q8[e];
+    }
+    isum += sc[r] * dsum;
+  }
+  return (h2f_(b + 208) * yd) * (float)isum;
+}
+static float term_q8_0(const uint8_t *w /* 8 blocks of 34 B */, const uint8_t *y /* 8 Q8_0 blocks of 34 B */) {
+  float t = 0.0f;
+  for (int blk = 0; blk < 8; ++blk) {
+    const int8_t *a = (const int8_t *)(w + (size_t)blk * 34 + 2), *b = (const int8_t *)(y + (size_t)blk * 34 + 2);
+    int32_t s = 0;
+    for (int l = 0; l < 32; ++l) s += a[l] * b[l];
+    const float p = (float)s * h2f_(w + (size_t)blk * 34) * h2f_(y + (size_t)blk * 34);
+    t = blk == 0 ? p : t + p;
+  }
+  return t;
+}
+/* combine the S superblock terms of a row in ORD-U order */
+float orc_ordu_combine(const float *T, int S) {
+  const int Cs = (S + 3) / 4;
+  float c[4];
+  for (int p = 0; p < 4; ++p) {
+    const int a = p * Cs, e = a + Cs < S ? a + Cs : S;
+    float v = 0.0f;
+    for (int sb = a; sb < e; ++sb) v = sb == a ? T[sb] : v + T[sb];
+    c[p] = v;
+  }
+  return ((c[0] + c[1]) + c[2]) + c[3];
+}
+static float row_engine(int type, const uint8_t *w, int S, const uint8_t *y) {
+  float T[1024];
+  for (int sb = 0; sb < S; ++sb)
+    T[sb] = type == ORC_Q6_K ? term_q6K(w + (size_t)sb * 210, y + (size_t)sb * 292)
+          : type == ORC_Q8_0 ? term_q8_0(w + (size_t)sb * 272, y + (size_t)sb * 272)
+          : term_q45K(type, w + (size_t)sb * (type == ORC_Q4_K ? 144 : 176), y + (size_t)sb * 292);
+  return orc_ordu_combine(T, S);
 }
 
-static float row_engine_q6K(const uint8_t *w, int S, const uint8_t *y) {
-  const int upr = S * 4, tpr = (upr + 63) / 64;
-  float acc[64] = {0};
-  for (int t = 0; t < tpr; ++t)
-    for (int lane = 0; lane < 64; ++lane) {
-      const int u = t * 64 + lane;
-      if (u >= upr) continue;
-      const int sb = u >> 2, h = (u >> 1) & 1, j = u & 1, r = 8 * h + 2 * j;
-      const uint8_t *b = w + (size_t)sb * 210, *yb = y + (size_t)sb * 292;
-      const uint8_t *ql = b, *qhh = b + 128;
-      const int8_t *sc = (const int8_t *)(b + 192);
-      float yd; memcpy(&yd, yb, 4);
-      const int8_t *q8 = (const int8_t *)(yb + 4);
-      const int runs[4] = {r, r + 1, r + 4, r + 5};
-      int tot = 0;
-      for (int k = 0; k < 4; ++k) {
-        int dsum = 0;
-        for (int i = 0; i < 16; ++i) {
-          const int e = runs[k] * 16 + i, hh = e / 128, pos = e % 32, qt = (e % 128) / 32, ii = hh * 64 + pos + (qt % 2) * 32;
-          const int lo = qt < 2 ? (ql[ii] & 15) : (ql[ii] >> 4), hi = (qhh[hh * 32 + pos] >> (qt * 2)) & 3;
-          dsum += ((lo | (hi << 4)) - 32) * q8[e];
-        }
-        tot += sc[runs[k]] * dsum;
-      }
-      acc[lane] = fmaf(h2f_(b + 208) * yd, (float)tot, acc[lane]);
-    }
-  return wave_sum_all_64(acc);
-}
-
-static float row_engine_q8_0(const uint8_t *w, int K, const uint8_t *y /* Q8_0 blocks, 34 B */) {
-  const int nblk = K / 32, tpr = (K / 16 + 63) / 64;
-  float acc[64] = {0};
-  for (int t = 0; t < tpr; ++t)
-    for (int lane = 0; lane < 64; lane += 2) {  /* the odd lane of a pair adds 0 */
-      const int blk = t * 32 + (lane >> 1);
-      if (blk >= nblk) continue;
-      const int8_t *a = (const int8_t *)(w + (size_t)blk * 34 + 2), *b = (const int8_t *)(y + (size_t)blk * 34 + 2);
-      int s = 0;
-      for (int l = 0; l < 32; ++l) s += a[l] * b[l];
-      acc[lane] = acc[lane] + (float)s * h2f_(w + (size_t)blk * 34) * h2f_(y + (size_t)blk * 34);
-    }
-  return wave_sum_all_64(acc);
-}
-
-/* out[N] = W[N,K] . x[K] in the engine's order.  Returns 0, or -1 for a type the engine does not take. */
+/* out[N] = W[N,K] . x[K] in the engine's order.  Returns 0, or -1 for a type / shape the engine does not take (K must be a multiple of 256). */
 int orc_gemv_engine(int type, const void *W, int N, int K, const float *x, float *out) {
-  if (type != ORC_Q4_K && type != ORC_Q5_K && type != ORC_Q6_K && type != ORC_Q8_0) return -1;
+  if ((type != ORC_Q4_K && type != ORC_Q5_K && type != ORC_Q6_K && type != ORC_Q8_0) || K % 256 || K / 256 > 1024) return -1;
   const int kq = type != ORC_Q8_0;
   const size_t row_bytes = (size_t)(K / orc_block_size(type)) * orc_type_size(type);
   uint8_t *y = malloc(kq ? (size_t)(K / 256) * 292 : (size_t)(K / 32) * 34);
   if (kq) orc_quantize_q8_K(x, y, K); else orc_quantize_row(ORC_Q8_0, x, y, K);
 #pragma omp parallel for schedule(static)
-  for (int n = 0; n < N; ++n) {
-    const uint8_t *w = (const uint8_t *)W + (size_t)n * row_bytes;
-    out[n] = type == ORC_Q6_K ? row_engine_q6K(w, K / 256, y) : type == ORC_Q8_0 ? row_engine_q8_0(w, K, y) : row_engine_q45K(type, w, K / 256, y);
-  }
+  for (int n = 0; n < N; ++n) out[n] = row_engine(type, (const uint8_t *)W + (size_t)n * row_bytes, K / 256, y);
   free(y);
   return 0;
 }

@@ -16,6 +16,8 @@ def main():
     ap.add_argument("--reps", type=int, default=4)
     ap.add_argument("--old", action="store_true")
     ap.add_argument("--phases", default="qkv,o,gate_up,down4,down6,lm_head")
+    ap.add_argument("--v2", action="store_true", help="time the round-4 core's plain launcher (mrs_dec2_gemv) on one tensor of each phase's bytes")
+    ap.add_argument("--hot", action="store_true", help="two rotating buffers per phase, replayed 8 x inside the graph: the weights stay in the 256 MiB Infinity Cache")
     a = ap.parse_args()
     import torch
     import mistralrs_amd  # noqa: F401
@@ -95,17 +97,38 @@ def main():
         old = lambda st: L.mrs_decode_norm_proj(ws[0][0].data.data_ptr(), 14, 128256, d, h.data_ptr(), nw.data_ptr(), 1e-5, logits.data_ptr(), 128256, b, st)
         return ws, new, old, nbytes(ws[0][0])
 
+    L.mrs_dec2_repack_bytes.restype = C.c_size_t
+    L.mrs_dec2_repack_bytes.argtypes = [C.c_int, C.c_longlong, C.c_longlong]
+    L.mrs_dec2_repack.argtypes = [C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p]
+    L.mrs_dec2_gemv.argtypes = [MP, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    big_out = torch.empty(b, 128256, device=dev)
+
+    def ph_v2(dt, n, k, x, norm):
+        def f(i):
+            w = random_qtensor(dt, n, k, dev, 500 + i)
+            nb = L.mrs_dec2_repack_bytes(dt.id, n, k)
+            p = torch.empty(nb, dtype=torch.uint8, device=dev)
+            assert L.mrs_dec2_repack(w.data.data_ptr(), dt.id, n, k, p.data_ptr(), st) == 0
+            torch.cuda.synchronize()
+            m = Mat(p.data_ptr(), dt.id, n, k)
+            new = lambda st: L.mrs_dec2_gemv(C.byref(m), x.data_ptr(), k, nw.data_ptr() if norm else None, 1e-5, big_out.data_ptr(), 128256, b, st)
+            return (p, m), new, new, w.data.numel()
+        return f
+
     table = {"qkv": ph_qkv, "o": ph_proj(Q4, d, nq, attn, nq, ya, 4096 // 32), "gate_up": ph_gate_up, "down4": ph_proj(Q4, d, ff, act, ff, yb, 14336 // 32),
              "down6": ph_proj(Q6, d, ff, act, ff, yb, 14336 // 32), "lm_head": ph_lm}
+    if a.v2:
+        table = {"qkv": ph_v2(Q4, nq + 2 * nkv, d, h, True), "o": ph_v2(Q4, d, nq, attn, False), "gate_up": ph_v2(Q4, 2 * ff, d, h, True),
+                 "down4": ph_v2(Q4, d, ff, act, False), "down6": ph_v2(Q6, d, ff, act, False), "lm_head": ph_v2(Q6, 128256, d, h, True)}
     for name in a.phases.split(","):
         mk = table[name]
         insts, total = [], 0
-        while total < 1.2e9 and len(insts) < 64:
+        while (total < 1.2e9 and len(insts) < 64) if not a.hot else len(insts) < (1 if name == "lm_head" else 2):
             inst = mk(len(insts))
             insts.append(inst)
             total += inst[3]
         for which in (("new", 1),) + ((("old", 2),) if a.old else ()):
-            fns = [inst[which[1]] for inst in insts]
+            fns = [inst[which[1]] for inst in insts] * (8 if a.hot else 1)
             for f in fns:
                 assert f(torch.cuda.current_stream().cuda_stream) == 0
             torch.cuda.synchronize()
@@ -131,7 +154,7 @@ def main():
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / (a.reps * len(fns))
             print(json.dumps({"phase": name, "impl": which[0], "b": b, "MB": round(insts[0][3] / 1e6, 2), "us": round(us, 2), "TBps": round(insts[0][3] / us / 1e6, 3),
-                              "frac_8TBps": round(insts[0][3] / us / 1e6 / 8.0, 3), "buffers": len(insts)}), flush=True)
+                              "frac_8TBps": round(insts[0][3] / us / 1e6 / 8.0, 3), "buffers": len(insts), "hot": bool(a.hot), "v2": bool(a.v2)}), flush=True)
         del insts
         torch.cuda.empty_cache()
 

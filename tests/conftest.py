@@ -30,7 +30,6 @@ def _enter_host_emulation():
     import mistralrs_amd  # noqa: F401
     from mistralrs_amd import _lib
     HostBackend.global_symbols = True
-    os.environ["MRS_DEC_PERSIST"] = "2"  # workgroups run one after the other here: the persistent decode step is exercised phase by phase
     lib = HostBackend.lib()
     for key in ("quant", "paged_attn", "core", "ext"):
         _lib._cache[key] = lib

@@ -97,7 +97,6 @@ def test_engine_rotate_half_rope_bit_identical_and_prefill_consistent(oracle, de
     emu = request.config.getoption("--host-emulation")
     types = {"q4km": Q4KM, "q8": Q8}[mix](oracle)
     cfg, w, m, cos, sin = _mk(oracle, dev, types, kv, rope_interleaved=False)
-    m.set_decode_persist(0)  # the persistent step has no rotate-half qkv phase (the runner falls back to per-phase launches by itself as well)
     ref = llama_ref.LlamaRef(cfg, w, cos, sin, mode="engine", kv_dtype=kv)
     inter = llama_ref.LlamaRef(type("C", (), {**cfg.__dict__, "rope_interleaved": True})(), w, cos, sin, mode="engine", kv_dtype=kv)
     tok, differs = 1000 % cfg.vocab_size, False
@@ -317,48 +316,6 @@ def test_engine_graph_loop_batch_and_chunked_prefill(oracle, dev, request):
         assert torch.equal(both[0], alone), f"batched != single at position {pos}"
 
 
-def test_persistent_step_equals_phase_launches(oracle, dev, request):
-    """The persistent step kernel (one launch, device-side phase barriers, weight stream running across the seams) == the same kernel launched
-    phase by phase == the per-phase kernels, bit for bit, over a prompt and a few generated tokens -- at a context long enough for several
-    attention splits.  A stale read across a phase barrier (visibility bug) would show up here as a difference."""
-    import torch
-    emu = request.config.getoption("--host-emulation")
-    outs = {}
-    for mode in ((2, 0) if emu else (1, 2, 0)):
-        cfg, w, m, cos, sin = _mk(oracle, dev, Q4KM(oracle), "bf16")
-        m.set_decode_persist(mode)
-        toks, seq = [(1000 + 7 * i) % cfg.vocab_size for i in range(3 if emu else 70)], []
-        for pos, t in enumerate(toks):
-            m.set_state([t], [pos])
-            seq.append(m.forward_logits(1)[0].clone())
-        if not emu:
-            torch.cuda.synchronize()
-        outs[mode] = torch.stack(seq)
-    ref = outs[0]
-    for mode, o in outs.items():
-        assert torch.equal(o, ref), f"decode_persist mode {mode} differs from the per-phase kernels: {float((o - ref).abs().max())}"
-
-
-def test_fused_attention_path_equals_split_merge_path(oracle, dev, request):
-    """Per-phase engine with the one-launch attention (split partials in LDS + merge + Q8_K image, o_proj on the image) == the same engine with
-    the split and merge kernels and o_proj's own quantizer: identical logits over a sequence (single and batched)."""
-    import torch
-    emu = request.config.getoption("--host-emulation")
-    outs = {}
-    for fused in (True, False):
-        cfg, w, m, cos, sin = _mk(oracle, dev, Q4KM(oracle), "bf16", max_batch=2)
-        m.set_decode_persist(0)
-        m.set_fused_attention(fused)
-        toks, seq = [(1000 + 7 * i) % cfg.vocab_size for i in range(3 if emu else 70)], []
-        for pos, t in enumerate(toks):
-            m.set_state([t, (t + 5) % cfg.vocab_size], [pos, pos])
-            seq.append(m.forward_logits(2).clone())
-        if not emu:
-            torch.cuda.synchronize()
-        outs[fused] = torch.stack(seq)
-    assert torch.equal(outs[True], outs[False]), float((outs[True] - outs[False]).abs().max())
-
-
 def test_short_prompt_in_long_context_and_replay_guard(oracle, dev, request):
     """(advisor, round 1) a prompt of <= 16 tokens must prefill when max_context_len > 512 (the v1 / v2 rule of the fallback attention used to refuse
     before the MFMA flash kernel was even tried), and a captured decode graph must not be replayed past max_new_tokens / max_context_len."""
@@ -398,7 +355,6 @@ def test_sliding_window_decode_and_prefill(oracle, dev, request):
     emu = request.config.getoption("--host-emulation")
     W = 40
     cfg, w, m, cos, sin = _mk(oracle, dev, Q4KM(oracle), "bf16", max_batch=1, sliding_window=W)
-    m.set_decode_persist(0)  # the window lives in the per-phase attention (the persistent step refuses it)
     mirror = llama_ref.LlamaRef(cfg, w, cos, sin, mode="engine", kv_dtype="bf16")
     ref = llama_ref.LlamaRef(cfg, w, cos, sin, mode="cpu", kv_dtype="bf16")
     full = llama_ref.LlamaRef(type("C", (), {**cfg.__dict__, "sliding_window": None})(), w, cos, sin, mode="engine", kv_dtype="bf16")
@@ -424,7 +380,6 @@ def test_sliding_window_decode_and_prefill(oracle, dev, request):
     prompt = [(1000 + 3 * i) % cfg.vocab_size for i in range(70)]
     lp = m2.prefill(prompt, 0)
     cfg3, w3, m3, _, _ = _mk(oracle, dev, Q4KM(oracle), "bf16", max_batch=1, sliding_window=W)
-    m2.set_decode_persist(0); m3.set_decode_persist(0)
     for pos, t in enumerate(prompt):
         m3.set_state([t], [pos])
         ld = m3.forward_logits(1)[0].clone()

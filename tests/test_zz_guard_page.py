@@ -149,17 +149,13 @@ elif sym == "attn":
     sc = 1.0 / np.sqrt(hd)
     assert be.sym("mrs_decode_attention_f32_f32_bf16", A, C.c_int)(ref.ptr, pl.ptr, pm.ptr, po.ptr, q.ptr, kp, vp, kvh, sc, bt.ptr, cl.ptr, bs, mbs * bs, 1, heads, hd, mbs, heads * hd,
                                                                    kvh * hd * bs, hd * bs, 1, be.stream) == 0
-    img = be.buf(np.zeros(heads * hd * 2, np.uint8))
-    assert be.sym("mrs_dec_attention_q8k", B, C.c_int)(img.ptr, got.ptr, q.ptr, kp, vp, kvh, sc, bt.ptr, cl.ptr, bs, mbs * bs, 1, heads, hd, mbs, heads * hd, kvh * hd * bs, hd * bs, 1,
-                                                       be.stream) == 0
-    # round-1 kernels (v_exp_f32, their own merge order) vs the engine's (reference fast_exp, run_barrier merge order): f32 rounding apart
-    assert np.isfinite(ref.numpy()).all() and np.abs(ref.numpy() - got.numpy()).max() <= 4e-6 * max(1.0, np.abs(ref.numpy()).max())
-    # the engine's one-launch split + last-arriver merge: same cores as the LDS variant, same bits
+    # the engine's one-launch split + last-arriver merge (reference fast_exp, run_barrier merge order) vs the round-1 kernels (v_exp_f32, their own merge order): f32 rounding apart
     A2 = [C.c_void_p] * 9 + [C.c_int, C.c_float, C.c_void_p, C.c_void_p] + [C.c_int] * 11 + [C.c_void_p]
-    img2, got2, ticket = be.buf(np.zeros(heads * hd * 2, np.uint8)), be.buf(np.zeros((1, heads * hd), np.float32)), be.buf(np.zeros(kvh, np.uint32))
+    nimg = be.sym("mrs_dec_act_image_bytes", [C.c_int, C.c_int], C.c_size_t)(heads * hd, 1)
+    img2, got2, ticket = be.buf(np.zeros(nimg, np.uint8)), be.buf(np.zeros((1, heads * hd), np.float32)), be.buf(np.zeros(kvh, np.uint32))
     assert be.sym("mrs_dec_attention", A2, C.c_int)(got2.ptr, img2.ptr, ticket.ptr, po.ptr, pm.ptr, pl.ptr, q.ptr, kp, vp, kvh, sc, bt.ptr, cl.ptr, bs, mbs * bs, 1, heads, hd, mbs,
                                                     heads * hd, kvh * hd * bs, hd * bs, 1, 0, be.stream) == 1
-    assert np.array_equal(got2.numpy(), got.numpy()) and np.array_equal(img2.numpy(), img.numpy())
+    assert np.isfinite(ref.numpy()).all() and np.abs(ref.numpy() - got2.numpy()).max() <= 4e-6 * max(1.0, np.abs(ref.numpy()).max())
     print("guard page intact"); sys.exit(0)
 elif sym == "prefill_attn":
     # prompt attention (MFMA flash kernel reading the paged cache with 16-byte loads): pages end at guard pages, the prompt's last block is the last page,
