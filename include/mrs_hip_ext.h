@@ -204,17 +204,27 @@ typedef struct {  /* all device pointers, owned by the caller */
 } mrs_llama_buffers;
 
 size_t mrs_llama_workspace_bytes(const mrs_llama_config *cfg);
-/* ---- prompt GEMM, round 3 (csrc/ext_gemm2.hip): weights in MFMA operand layout, no LDS round trip for the weight operand.
- * Role: fast_mmq::{plain, fused_qkv, fused_glu} (mistralrs-quant/src/gguf/fast_mmq.rs:528-635,762-821); same arithmetic and bits as mrs_gemm_q_bf16_multi.
- * mrs_gemm2_repack: GGUF blocks [n][k / 256] (Q4_K, Q6_K) -> the layout (load time).  mrs_gemm2_q_bf16_multi: out[i] [M][ldo[i]] (+)= x . W_i^T for up to
- * three tensors of one type; x_slabs = bf16 k-slab-major [K/64][M][64]; workspace (may be NULL) = f32 split-K partials.  Returns 0, -1 bad arguments,
- * -3 = shape / type served by mrs_gemm_q_bf16_multi (M <= 128, other types). */
-int mrs_gemm2_supported(int ggml_type);
-size_t mrs_gemm2_repack_bytes(int ggml_type, long long n, long long k);
-int mrs_gemm2_repack(const void *gguf_blocks, int ggml_type, long long n, long long k, void *dst, void *stream);
-int mrs_gemm2_q_bf16_multi(int nseg, const void *const *w, const int *N, float *const *out, const int *ldo, int ggml_type, int K, const void *x_slabs, int M,
-                           int accumulate, void *workspace, size_t workspace_bytes, void *stream);
-int mrs_llama_set_gemm2_tensor(void *model, const char *name, const void *planes); /* MFMA-layout copy of a dense linear registered with mrs_llama_set_tensor */
+/* ---- prompts in the decode engine's arithmetic (csrc/ext_gemm_qi.hip, round 4): the role of the reference CPU prompt path (QMatMul f32 fallback per activation
+ * row, mistralrs-quant/src/gguf/mod.rs:465-478): Q8_K activation rows x Q4_K / Q6_K weights as EXACT integers on v_mfma_f32_32x32x16_f16, combined in the f32
+ * order of the decode engine -- row t of the result equals mrs_dec_proj on row t bit for bit.
+ * mrs_gemm_qi_repack: GGUF blocks [n][k / 256] -> the MFMA-order copy (load time).  mrs_qi_quantize: x f32 [T][ldx] (RmsNorm in the engine's order when norm_w;
+ * x2 != NULL: rows are silu(x) * x2, xtmp = f32 scratch [T][K]) -> the GEMM's operand buffers `act` (mrs_qi_act_bytes).  mrs_gemm_qi: out[t * ldo + n] (+)= W[n] . act[t].
+ * mrs_prefill_attention_exact: causal attention of T prompt tokens over the paged cache, per token exactly mrs_dec_attention's arithmetic (context_lens[t] =
+ * position + 1, block_table = the sequence's row, max_context_len = the model's).  Returns 0; -1 bad arguments / type; -2 shape beyond the kernel's LDS budget. */
+size_t mrs_gemm_qi_repack_bytes(int ggml_type, long long n, long long k); /* 0 = unsupported type (q4_k, q6_k) / shape (k % 256) */
+int mrs_gemm_qi_repack(const void *gguf_blocks, int ggml_type, long long n, long long k, void *dst, void *stream);
+size_t mrs_qi_act_bytes(int T, int K);
+int mrs_qi_quantize(const float *x, const float *x2, int ldx, const float *norm_w, float eps, int T, int K, void *act, float *xtmp, void *stream);
+int mrs_gemm_qi(const void *w_qi, int ggml_type, int N, int K, const void *act, int T, float *out, int ldo, int accumulate, void *stream);
+int mrs_prefill_attention_exact(const float *q, const void *k_cache, const void *v_cache, const uint32_t *block_table, const uint32_t *context_lens, float *out, int T,
+                                int num_heads, int num_kv_heads, int head_size, int block_size, int q_stride, int kv_block_stride, int kv_head_stride, float scale,
+                                int max_context_len, int kv_dtype, int sliding_window, void *stream);
+int mrs_llama_set_qi_tensor(void *model, const char *name, const void *planes); /* MFMA-order copy of a dense linear registered with mrs_llama_set_tensor */
+int mrs_llama_prefill_is_exact(void *model); /* 1: mrs_llama_prefill runs in the decode engine's arithmetic (every dense linear has its MFMA-order copy, decode engine on, TP = 1, no experts) */
+/* diagnostics: pull a byte range through the Infinity Cache (ext_prefetch.hip); one wave of K-deep v_mfma_f32_32x32x16_f16 on caller operands (the exactness
+ * premise of mrs_gemm_qi, tests/test_gemm_qi.py) */
+int mrs_l3_prefetch(const void *p, size_t bytes, int workgroups, void *sink, void *stream);
+int mrs_mfma_f16_int_probe(const void *a, const void *b, float *out, int ksteps, void *stream);
 /* decode-layout copy (mrs_dec_repack output, caller-owned) of a linear tensor already registered with mrs_llama_set_tensor */
 int mrs_llama_set_dec_tensor(void *model, const char *name, const void *planes);
 int mrs_llama_set_mode(void *model, int use_fused); /* switch the decode path (values of mrs_llama_config.use_fused) */

@@ -391,7 +391,7 @@ template <int TYPE> struct Tile;
 // mask), hs[16] = the 8 sub-block scales, then the 8 mins, as bytes; hd = d | dmin << 16 (f16 bits).  Sub-block 2c <- low nibbles of pieces 2c, 2c+1
 // (activation runs 4c, 4c+1), sub-block 2c+1 <- high nibbles (runs 4c+2, 4c+3).
 #ifndef MRS_DEC2_NS_Q4K
-#define MRS_DEC2_NS_Q4K 4
+#define MRS_DEC2_NS_Q4K 2
 #endif
 #ifndef MRS_DEC2_NS_Q6K
 #define MRS_DEC2_NS_Q6K 2
@@ -449,7 +449,7 @@ template <> struct Tile<T_Q4_K> {
 // Q5_K slot: q[8][16] = the GGUF qs bytes; xh[2][16]: dword i (0..7) = the fifth bits of piece i: bit 8 j' + k = bit of LOW-nibble weight 4 k + j' (k = dword of
 // the piece, j' = byte), bit 8 j' + 4 + k = of the HIGH-nibble weight; hs, hd as Q4_K
 template <> struct Tile<T_Q5_K> {
-  static constexpr int NS = 3;
+  static constexpr int NS = 2;
   struct Raw { v4u q[8]; v4u xh[2]; v4u hs; unsigned hd; };
   static __device__ __forceinline__ Raw load(__amdgpu_buffer_rsrc_t rs, unsigned rec, int a, int A, bool ok) {
     Raw r;
@@ -552,7 +552,7 @@ template <> struct Tile<T_Q6_K> {
 
 // Q8_0 "superblock" = 8 consecutive blocks of 32: q[16][16] = the int8 quants in element order, dh[16] = the 8 f16 scales.  Activations: Q8_0 blocks.
 template <> struct Tile<T_Q8_0> {
-  static constexpr int NS = 2;
+  static constexpr int NS = 1;
   struct Raw { v4u q[16]; v4u dh; };
   static __device__ __forceinline__ Raw load(__amdgpu_buffer_rsrc_t rs, unsigned rec, int a, int A, bool ok) {
     Raw r;
@@ -603,8 +603,9 @@ template <int TYPE, int NCOLS, int C0> struct TermCols {
 // A workgroup owns the UNITS [u0, u1) of a launch; unit u = rgpu consecutive record groups (a record group = R consecutive rows) of each of the launch's
 // nseg tensors (gate and up rows of the same index travel together; rgpu = 2 keeps a RoPE pair in one wave when R = 1).  Waves take units one at a time from a
 // counter in LDS (the first one statically), so a wave that starts late -- the prologue waves of the SPEC schedule -- simply ends up with fewer; a wave
-// keeps up to NS records requested ahead of the one it is computing.  epi(seg, row, sum, aux) is called once per finished row with wave-uniform sums; inside a
-// unit: segment 0 before segment 1, rows ascending.  aux(unit, seg, rgl) runs when a record is REQUESTED (operands of the epilogue -- residual values, RoPE
+// keeps up to NS records requested ahead of the one it is computing.  epi(seg, row0, nvalid, rgl, sums, aux) is called once per finished record group; inside a
+// unit: segment 0 before segment 1, record groups ascending; the call is lane-parallel: every lane of row rr = lane / (64 / R) of the group holds that row's sum,
+// lane rr * (64 / R) is the row's owner, nvalid rows exist.  aux(unit, seg, rgl) runs when a record is REQUESTED (operands of the epilogue -- residual values, RoPE
 // factors -- travel with the weights instead of costing a dependent load after the row sum); its result comes back to epi for that record's rows.
 struct Job {
   Mat mat[2];
@@ -747,14 +748,10 @@ __device__ __forceinline__ void stream(const Job &jb, int K, int ncols_img, int 
             const float c2 = __shfl(s[c], rbase + 2 * g.LPC + g.W - 1, 64), c3 = __shfl(s[c], rbase + 3 * g.LPC + g.W - 1, 64);
             tot[c] = ((c0 + c1) + c2) + c3;
           }
-          const int urow = meta[i].unit * jb.rgpu * g.R + meta[i].rgl * g.R;          // row index of the launch (slot * rows-per-slot + local row)
+          // every lane of a row holds the row's sum; lane rr * lpr is the row's "owner".  One epilogue call per record group, lane-parallel over its R rows
+          const int urow = meta[i].unit * jb.rgpu * g.R + meta[i].rgl * g.R;          // first row of the group in the launch's numbering (slot * rows-per-slot + local row)
           const int lrow = urow - (meta[i].unit / jb.upe) * (jb.upe * jb.rgpu * g.R);  // local row inside the expert slot
-          for (int rr = 0; rr < g.R && lrow + rr < jb.nrows; ++rr) {
-            float sum[NCOLS];
-#pragma unroll
-            for (int c = 0; c < NCOLS; ++c) sum[c] = rlf(tot[c], rr * lpr);
-            epi(cseg, urow + rr, rr, sum, auxv[i]);
-          }
+          epi(cseg, urow, min(g.R, jb.nrows - lrow), meta[i].rgl, tot, auxv[i]);
         }
         issue(ring[i], meta[i], auxv[i]);
         if (nrec < 10) MRS_TL2(jb, 4 + nrec);

@@ -29,36 +29,51 @@ struct GemvArgs {
   unsigned long long *tl;
 };
 
-#define MRS_DEC_TYPE_SWITCH(t, ...)                              \
-  switch (t) {                                                   \
-  case T_Q4_K: { constexpr int TT = T_Q4_K; __VA_ARGS__ } break; \
-  case T_Q5_K: { constexpr int TT = T_Q5_K; __VA_ARGS__ } break; \
-  case T_Q6_K: { constexpr int TT = T_Q6_K; __VA_ARGS__ } break; \
-  case T_Q8_0: { constexpr int TT = T_Q8_0; __VA_ARGS__ } break; \
-  default: break;                                                \
+// TMASK: which weight formats a kernel instantiation contains (bit 0 Q4_K, 1 Q5_K, 2 Q6_K, 3 Q8_0).  One kernel with all four carries the register
+// footprint of the fattest format; the QKV phase (three tensors, usually two formats, the heaviest epilogue) is instantiated per format set.
+enum : int { TM_Q4K = 1, TM_Q5K = 2, TM_Q6K = 4, TM_Q80 = 8, TM_ALL = 15 };
+__host__ __device__ constexpr int tmask_of(int type) { return type == T_Q4_K ? TM_Q4K : type == T_Q5_K ? TM_Q5K : type == T_Q6_K ? TM_Q6K : type == T_Q8_0 ? TM_Q80 : 0; }
+#define MRS_DEC_TYPE_SWITCH(t, ...)                                                              \
+  switch (t) {                                                                                   \
+  case T_Q4_K: if constexpr ((TMASK & TM_Q4K) != 0) { constexpr int TT = T_Q4_K; __VA_ARGS__ } break; \
+  case T_Q5_K: if constexpr ((TMASK & TM_Q5K) != 0) { constexpr int TT = T_Q5_K; __VA_ARGS__ } break; \
+  case T_Q6_K: if constexpr ((TMASK & TM_Q6K) != 0) { constexpr int TT = T_Q6_K; __VA_ARGS__ } break; \
+  case T_Q8_0: if constexpr ((TMASK & TM_Q80) != 0) { constexpr int TT = T_Q8_0; __VA_ARGS__ } break; \
+  default: break;                                                                                \
   }
 
 template <int N> struct AuxV { float a[N], b[N]; };
 
-template <int NCOLS, int EPI, bool SPEC>
+template <int NCOLS, int EPI, bool SPEC, int TMASK>
 __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float *red, int *ctr) {
   const int tid0 = tid_opaque();
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6), lane = tid0 & 63;
   const int K = a.K;
   const Geo g = geo_for(K);
-  // which tensor this workgroup streams (QKV: one of three), its units and its share of them
+  // which tensor this workgroup streams (QKV: one of three), its units and its share of them.  Every field is read into a local FIRST and the locals are
+  // selected: a select between kernel-argument ADDRESSES makes hipcc copy the whole argument block to scratch memory and index it there.
+  const int w1 = a.wg0[1], w2 = a.wg0[2], w3 = a.wg0[3];
+  const int un0 = a.units[0], un1 = a.units[1], un2 = a.units[2];
+  const int nr0 = a.nrows[0], nr1 = a.nrows[1], nr2 = a.nrows[2];
+  const uint8_t *b0 = a.m[0].base, *b1 = a.m[1].base, *b2 = a.m[2].base;
+  const unsigned by0 = a.m[0].bytes, by1 = a.m[1].bytes, by2 = a.m[2].bytes;
+  const int ty0 = a.m[0].type, ty1 = a.m[1].type, ty2 = a.m[2].type;
+  const int bx = (int)blockIdx.x;
   int mi = 0;
-  if constexpr (EPI == EPI_QKV) mi = (int)blockIdx.x >= a.wg0[2] ? 2 : ((int)blockIdx.x >= a.wg0[1] ? 1 : 0);
-  const int wgb = EPI == EPI_QKV ? (mi == 0 ? a.wg0[0] : (mi == 1 ? a.wg0[1] : a.wg0[2])) : 0;
-  const int wge = EPI == EPI_QKV ? (mi == 0 ? a.wg0[1] : (mi == 1 ? a.wg0[2] : a.wg0[3])) : (int)gridDim.x;
-  const int units = EPI == EPI_QKV ? (mi == 0 ? a.units[0] : (mi == 1 ? a.units[1] : a.units[2])) : a.units[0];
-  const int nwg = wge - wgb, wi = (int)blockIdx.x - wgb;
+  if constexpr (EPI == EPI_QKV) mi = bx >= w2 ? 2 : (bx >= w1 ? 1 : 0);
+  const int wgb = EPI == EPI_QKV ? (mi == 0 ? 0 : (mi == 1 ? w1 : w2)) : 0;
+  const int wge = EPI == EPI_QKV ? (mi == 0 ? w1 : (mi == 1 ? w2 : w3)) : (int)gridDim.x;
+  const int units = EPI == EPI_QKV ? (mi == 0 ? un0 : (mi == 1 ? un1 : un2)) : un0;
+  const int nwg = wge - wgb, wi = bx - wgb;
   Job jb{};
   jb.nseg = (EPI == EPI_GLU || EPI == EPI_RESID2) ? 2 : 1;
   jb.rgpu = a.rgpu;
-  jb.mat[0] = mi == 0 ? a.m[0] : (mi == 1 ? a.m[1] : a.m[2]);
-  jb.mat[1] = EPI == EPI_GLU ? a.m[1] : a.m[0];
-  jb.nrows = mi == 0 ? a.nrows[0] : (mi == 1 ? a.nrows[1] : a.nrows[2]);
+  jb.mat[0].base = mi == 0 ? b0 : (mi == 1 ? b1 : b2);
+  jb.mat[0].bytes = mi == 0 ? by0 : (mi == 1 ? by1 : by2);
+  jb.mat[0].type = mi == 0 ? ty0 : (mi == 1 ? ty1 : ty2);
+  jb.mat[0].n = 0; jb.mat[0].k = K;
+  if constexpr (EPI == EPI_GLU) { jb.mat[1].base = b1; jb.mat[1].bytes = by1; jb.mat[1].type = ty1; jb.mat[1].n = 0; jb.mat[1].k = K; } else jb.mat[1] = jb.mat[0];
+  jb.nrows = mi == 0 ? nr0 : (mi == 1 ? nr1 : nr2);
   jb.u0 = (int)((long long)wi * units / nwg); jb.u1 = (int)((long long)(wi + 1) * units / nwg);
   jb.sel = a.expert_sel; jb.sel_mode = EPI == EPI_RESID2 ? 2 : 1;
   jb.upe = EPI == EPI_RESID2 ? units : units / (a.slots > 1 ? a.slots : 1);
@@ -69,38 +84,39 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
   constexpr int NCI = EPI == EPI_RESID2 ? 2 : NCOLS;  // columns of the activation image
 
   // the activation prologue (dec_core2.cuh): a pre-quantized image is copied, an f32 vector is normalised / quantized on the ALL or the SPEC schedule
-  ActRegs<2> pre;
-  SpecRegs spre;
+  // (the registers of the two schedules are never live together: the struct is chosen at compile time)
+  using PreT = typename std::conditional<SPEC, SpecRegs, ActRegs<2>>::type;
+  PreT pre;
   const size_t img_bytes = act_bytes(K, NCI);
   auto stage = [&](int st) {
-    if (a.x_img) {
-      if (st == 0) pre = img_issue_all<2>(a.x_img, img_bytes); else img_finish_all<2>(smem, pre, a.x_img, img_bytes);
-    } else if constexpr (SPEC) {
-      if (st == 0) spre = act_issue_spec(a.x, a.norm_w, K, wave); else act_finish_spec<NCI>(smem, spre, a.x, a.ldx, a.norm_w, a.eps, K, mode, wave);
+    if constexpr (SPEC) {
+      if (st == 0) pre = act_issue_spec(a.x, a.norm_w, K, wave); else act_finish_spec<NCI>(smem, pre, a.x, a.ldx, a.norm_w, a.eps, K, mode, wave);
     } else {
-      if (st == 0) pre = act_issue_all<2>(a.x, a.norm_w, K); else act_finish_all<NCI, 2>(smem, red, pre, a.x, a.ldx, a.norm_w, a.eps, K, mode);
+      if (a.x_img) { if (st == 0) pre = img_issue_all<2>(a.x_img, img_bytes); else img_finish_all<2>(smem, pre, a.x_img, img_bytes); }
+      else if (st == 0) pre = act_issue_all<2>(a.x, a.norm_w, K);
+      else act_finish_all<NCI, 2>(smem, red, pre, a.x, a.ldx, a.norm_w, a.eps, K, mode);
     }
   };
-
+  const int lpr = 4 * g.LPC;             // lanes per row of a record group: row rr of the group = lanes [rr * lpr, (rr + 1) * lpr), owner = the first
+  const int rr = lane / lpr;
+  const bool own = (lane & (lpr - 1)) == 0;
   if constexpr (EPI == EPI_STORE || EPI == EPI_RESID) {
     const float ascale = a.acc_scale ? *a.acc_scale : 1.0f;
-    // residual values travel with the record: lane rr <-> row rr of the record group
+    // residual values travel with the record (requested behind its weights): the owner lane of a row loads the row's old value
     auto auxf = [&](int unit, int, int rgl) {
       AuxV<NCOLS> v;
-      const int row = (unit * jb.rgpu + rgl) * g.R + lane;
+      const int row = (unit * jb.rgpu + rgl) * g.R + rr;
 #pragma unroll
-      for (int c = 0; c < NCOLS; ++c) { v.a[c] = 0.f; v.b[c] = 0.f; if (EPI == EPI_RESID && lane < g.R && row < jb.nrows) v.a[c] = a.out[(size_t)c * a.out_stride + row]; }
+      for (int c = 0; c < NCOLS; ++c) { v.a[c] = 0.f; v.b[c] = 0.f; if (EPI == EPI_RESID && own && row < jb.nrows) v.a[c] = a.out[(size_t)c * a.out_stride + row]; }
       return v;
     };
-    auto epi = [&](int, int row, int rr, const float(&sum)[NCOLS], const AuxV<NCOLS> &ax) {
+    auto epi = [&](int, int row0, int nvalid, int, const float(&sum)[NCOLS], const AuxV<NCOLS> &ax) {
+      if (own && rr < nvalid) {
 #pragma unroll
-      for (int c = 0; c < NCOLS; ++c) {
-        float *o = a.out + (size_t)c * a.out_stride + row;
-        if constexpr (EPI == EPI_RESID) {
-          const float old = rlf(ax.a[c], rr);
-          if (lane == 0) *o = old * a.resid_scale + sum[c] * ascale;
-        } else {
-          if (lane == 0) *o = sum[c];
+        for (int c = 0; c < NCOLS; ++c) {
+          float *o = a.out + (size_t)c * a.out_stride + row0 + rr;
+          if constexpr (EPI == EPI_RESID) *o = ax.a[c] * a.resid_scale + sum[c] * ascale;
+          else *o = sum[c];
         }
       }
     };
@@ -111,97 +127,100 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
     // roundings of two consecutive EPI_RESID launches, bit for bit
     static_assert(EPI != EPI_RESID2 || NCOLS == 1, "one accumulator column; the image has two");
     const float w0 = a.acc_scale[0], w1 = a.acc_scale[1];
-    float s0save = 0.0f;  // lane rr keeps the first expert's sum of row rr of the record group
+    float s0save = 0.0f;  // the first expert's sums of the record group
     auto auxf = [&](int unit, int seg, int rgl) {
       AuxV<1> v; v.a[0] = 0.f; v.b[0] = 0.f;
-      const int row = (unit * jb.rgpu + rgl) * g.R + lane;
-      if (seg == 1 && lane < g.R && row < jb.nrows) v.a[0] = a.out[row];
+      const int row = (unit * jb.rgpu + rgl) * g.R + rr;
+      if (seg == 1 && own && row < jb.nrows) v.a[0] = a.out[row];
       return v;
     };
-    auto epi = [&](int seg, int row, int rr, const float(&sum)[1], const AuxV<1> &ax) {
+    auto epi = [&](int seg, int row0, int nvalid, int, const float(&sum)[1], const AuxV<1> &ax) {
       if (seg == 0) {
-        s0save = lane == rr ? sum[0] : s0save;
-      } else {
-        const float s0 = rlf(s0save, rr), old = rlf(ax.a[0], rr);
-        const float h1 = old * a.resid_scale + s0 * w0;
-        if (lane == 0) a.out[row] = h1 * 1.0f + sum[0] * w1;
+        s0save = sum[0];
+      } else if (own && rr < nvalid) {
+        const float h1 = ax.a[0] * a.resid_scale + s0save * w0;
+        a.out[row0 + rr] = h1 * 1.0f + sum[0] * w1;
       }
     };
     MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, 1, SPEC, true>(jb, K, NCI, mode, smem, ctr, stage, auxf, epi); })
   } else if constexpr (EPI == EPI_GLU) {
-    float gsave[NCOLS];  // lane rr keeps gate row rr of the record group until the matching up row arrives
+    float gsave[NCOLS];  // the gate sums of the record group until the matching up rows arrive (same unit, same lanes)
 #pragma unroll
     for (int c = 0; c < NCOLS; ++c) gsave[c] = 0.0f;
     auto auxf = [](int, int, int) { return NoAux{}; };
-    auto epi = [&](int seg, int row, int rr, const float(&sum)[NCOLS], const NoAux &) {
+    auto epi = [&](int seg, int row0, int nvalid, int, const float(&sum)[NCOLS], const NoAux &) {
+      if (seg == 0) {
 #pragma unroll
-      for (int c = 0; c < NCOLS; ++c) {
-        if (seg == 0) {
-          gsave[c] = lane == rr ? sum[c] : gsave[c];
-        } else {
-          const float gt = rlf(gsave[c], rr);
-          const int slot = a.slots > 1 ? row / a.nrows[0] : 0;
-          if (lane == 0) a.out[(size_t)slot * a.slot_out_stride + (size_t)c * a.out_stride + (row - slot * a.nrows[0])] = (a.activation == 0 ? silu_engine(gt) : glu_act(gt, a.activation)) * sum[c];
-        }
+        for (int c = 0; c < NCOLS; ++c) gsave[c] = sum[c];
+      } else if (own && rr < nvalid) {
+        const int row = row0 + rr;
+        const int slot = a.slots > 1 ? row / a.nrows[0] : 0;
+#pragma unroll
+        for (int c = 0; c < NCOLS; ++c)
+          a.out[(size_t)slot * a.slot_out_stride + (size_t)c * a.out_stride + (row - slot * a.nrows[0])] = (a.activation == 0 ? silu_engine(gsave[c]) : glu_act(gsave[c], a.activation)) * sum[c];
       }
     };
     MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, NCOLS, SPEC>(jb, K, NCI, mode, smem, ctr, stage, auxf, epi); })
   } else {  // EPI_QKV: rows 2i, 2i + 1 of a tensor are a RoPE pair; a record group holds whole pairs (R >= 2) or a unit holds two record groups (R = 1)
-    // RoPE factors and the KV slot travel with the record: lane pp <-> pair pp of the record group
+    // positions and KV slots: a handful of scalars, loaded before anything else; the RoPE factors travel with the record (owner lanes of the pair's two rows)
+    int posv[NCOLS], slotv[NCOLS];  // slots are block * block_size + offset of a cache that fits 32-bit indexing per layer (checked by the launcher)
+#pragma unroll
+    for (int c = 0; c < NCOLS; ++c) { posv[c] = a.positions[c]; slotv[c] = mi == 0 ? 0 : (int)a.slot_mapping[c]; }
     auto auxf = [&](int unit, int, int rgl) {
       AuxV<NCOLS> v;
-      const int row = (unit * jb.rgpu + rgl) * g.R + 2 * lane;
-      const int pair_i = (row % a.head_dim) >> 1;
-      const bool rot = mi < 2 && pair_i < a.rot_pairs;
+      const int row = (unit * jb.rgpu + rgl) * g.R + rr;
+      const int pair_i = (int)((unsigned)row % (unsigned)a.head_dim) >> 1;
+      const bool rot = mi < 2 && pair_i < a.rot_pairs && own && row < jb.nrows;
 #pragma unroll
       for (int c = 0; c < NCOLS; ++c) {
         v.a[c] = 1.0f; v.b[c] = 0.0f;  // identity rotation for v and unrotated dims (x*1 - y*0 = x exactly)
-        if (rot && 2 * lane < (g.R > 1 ? g.R : 2) && row < jb.nrows) {
-          const size_t ti = (size_t)a.positions[c] * a.rot_pairs + pair_i;
-          v.a[c] = a.cos_t[ti]; v.b[c] = a.sin_t[ti];
-        }
+        if (rot) { const size_t ti = (size_t)posv[c] * a.rot_pairs + pair_i; v.a[c] = a.cos_t[ti]; v.b[c] = a.sin_t[ti]; }
       }
       return v;
     };
-    float prev[NCOLS];
+    float prev[NCOLS];  // R = 1: the even row's sum waits for the odd row's record group
 #pragma unroll
     for (int c = 0; c < NCOLS; ++c) prev[c] = 0.0f;
-    auto epi = [&](int, int row, int rr, const float(&sum)[NCOLS], const AuxV<NCOLS> &ax) {  // row = local row of tensor mi
-      if ((row & 1) == 0) {
+    auto epi = [&](int, int row0, int nvalid, int rgl, const float(&sum)[NCOLS], const AuxV<NCOLS> &ax) {  // rows are local rows of tensor mi
+      const bool single = g.R == 1;
+      if (single && (rgl & 1) == 0) {
 #pragma unroll
         for (int c = 0; c < NCOLS; ++c) prev[c] = sum[c];
         return;
       }
-      const int lr = row - 1;          // even row of the pair
-      const int pi = g.R > 1 ? (rr >> 1) : 0;  // pair index inside the record group (R = 1: the pair spans two record groups, factors loaded by lane 0 of each)
-      const int head = lr / a.head_dim, dd = lr % a.head_dim;
+      const int row = row0 + rr;                   // this lane's row; its pair partner sits lpr lanes away (R = 1: in prev)
+      const bool odd = single ? true : (row & 1) != 0;
+      const int lr = single ? row - 1 : (row & ~1);  // even row of the pair
+      const int head = (int)((unsigned)lr / (unsigned)a.head_dim), dd = lr - head * a.head_dim;
       // where the two results live: adjacent dims (interleaved RoPE), or dims i and i + head_dim / 2 when the rows were stored in pair order (v: never)
       const bool nx = a.neox && mi < 2;
       const int d0 = nx ? dd >> 1 : dd, d1 = nx ? d0 + (a.head_dim >> 1) : dd + 1;
 #pragma unroll
       for (int c = 0; c < NCOLS; ++c) {
-        const float cs = rlf(ax.a[c], pi), sn = rlf(ax.b[c], pi);
+        const float other = single ? prev[c] : __shfl(sum[c], lane ^ lpr, 64);
+        const float xs = odd ? other : sum[c], ys = odd ? sum[c] : other;
         float x, y;
-        rope_pair<float>(prev[c], sum[c], cs, sn, x, y);
-        if (lane == 0) {
+        rope_pair<float>(xs, ys, ax.a[c], ax.b[c], x, y);
+        const bool wr0 = single ? own : (own && rr < nvalid && !odd), wr1 = single ? own : (own && rr < nvalid && odd);  // R = 1: one lane writes both
+        if (wr0 || wr1) {
           if (mi == 0) {
-            a.q_out[(size_t)c * a.nrows[0] + head * a.head_dim + d0] = x;
-            a.q_out[(size_t)c * a.nrows[0] + head * a.head_dim + d1] = y;
+            if (wr0) a.q_out[(size_t)c * a.nrows[0] + head * a.head_dim + d0] = x;
+            if (wr1) a.q_out[(size_t)c * a.nrows[0] + head * a.head_dim + d1] = y;
           } else {
-            const int64_t slot = a.slot_mapping[c];
+            const int slot = slotv[c];
             if (slot >= 0) {
-              const int64_t blk = slot / a.block_size, off = slot % a.block_size;
+              const unsigned blk = (unsigned)slot / (unsigned)a.block_size, off = (unsigned)slot % (unsigned)a.block_size;
               uint16_t *kc = (uint16_t *)a.k_cache, *vc = (uint16_t *)a.v_cache;
               const uint16_t xb = a.kv_f16 ? float_to_half_bits(x) : float_to_bf16_bits(x), yb = a.kv_f16 ? float_to_half_bits(y) : float_to_bf16_bits(y);
               if (mi == 1) {
                 const int X = a.cache_x;
-                const int64_t hb = (blk * a.num_kv_heads + head) * (a.head_dim / X);
-                kc[(hb + d0 / X) * a.block_size * X + off * X + d0 % X] = xb;
-                kc[(hb + d1 / X) * a.block_size * X + off * X + d1 % X] = yb;  // interleaved: d1 = d0 + 1, same 16-byte group
+                const size_t hb = ((size_t)blk * a.num_kv_heads + head) * (size_t)(a.head_dim / X);
+                if (wr0) kc[(hb + (unsigned)d0 / (unsigned)X) * a.block_size * X + off * X + (unsigned)d0 % (unsigned)X] = xb;
+                if (wr1) kc[(hb + (unsigned)d1 / (unsigned)X) * a.block_size * X + off * X + (unsigned)d1 % (unsigned)X] = yb;
               } else {
-                const int64_t o = ((blk * a.num_kv_heads + head) * a.head_dim + dd) * a.block_size + off;
-                vc[o] = xb;
-                vc[o + a.block_size] = yb;
+                const size_t o = (((size_t)blk * a.num_kv_heads + head) * a.head_dim + dd) * a.block_size + off;
+                if (wr0) vc[o] = xb;
+                if (wr1) vc[o + a.block_size] = yb;
               }
             }
           }
@@ -212,17 +231,17 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
   }
 }
 
-template <int NCOLS, int EPI, bool SPEC>
+template <int NCOLS, int EPI, bool SPEC, int TMASK = TM_ALL>
 __global__ void __launch_bounds__(NT) dec_gemv_kernel(const GemvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ float red[8 * 8];  // RMSNorm partials: [column][wave]
   __shared__ int ctr;           // the workgroup's unit counter
-  gemv_phase<NCOLS, EPI, SPEC>(a, smem, red, &ctr);
+  gemv_phase<NCOLS, EPI, SPEC, TMASK>(a, smem, red, &ctr);
 }
 
 
 // launch one GEMV phase with NCOLS activation columns (ext_dec_gemv.hip, one definition per NCOLS)
-template <int NCOLS> int gemv_launch(int epi, bool spec, int grid, size_t lds, const GemvArgs &a, hipStream_t s);
+template <int NCOLS> int gemv_launch(int epi, bool spec, int tmask, int grid, size_t lds, const GemvArgs &a, hipStream_t s);
 
 }  // namespace dec
 }  // namespace mrs

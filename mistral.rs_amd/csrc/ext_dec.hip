@@ -285,8 +285,10 @@ template <int EPI> struct Launch {
     // SPEC when a workgroup's weight requests keep its memory pipe busy for microseconds and there is a prologue worth hiding
     bool spec = !a.x_img && total_bytes / (size_t)grid > 96 * 1024;
     { static const int force = [] { const char *e = getenv("MRS_DEC_SPEC"); return e ? atoi(e) : -1; }(); if (force >= 0 && !a.x_img) spec = force != 0; }
-    if (NCOLS > 1) spec = false;  // the SPEC schedule is built for one column
-    return gemv_launch<NCOLS>(EPI, spec, grid, lds, a, s);
+    if (NCOLS > 1 || EPI == EPI_QKV) spec = false;  // the SPEC schedule is built for one column; the QKV launch is small
+    int tmask = 0;
+    for (int i = 0; i < (EPI == EPI_QKV ? 3 : 1); ++i) tmask |= tmask_of(a.m[i].type);
+    return gemv_launch<NCOLS>(EPI, spec, tmask, grid, lds, a, s);
   }
   // activation columns [c0, ...) of a batched launch: every per-column pointer moves
   static GemvArgs shift_cols(GemvArgs a, int c0) {

@@ -131,10 +131,12 @@ __global__ void __launch_bounds__(NT) dec2_plain_kernel(const PlainArgs a) {
   jb.nseg = 1; jb.rgpu = 1; jb.mat[0] = a.m; jb.nrows = a.m.n; jb.tl = a.tl; jb.sel = nullptr; jb.sel_mode = 1; jb.upe = a.units > 0 ? a.units : 1; jb.ergs = 0;
   jb.u0 = (int)((long long)blockIdx.x * a.units / gridDim.x); jb.u1 = (int)((long long)(blockIdx.x + 1) * a.units / gridDim.x);
   auto noaux = [](int, int, int) { return NoAux{}; };
-  auto epi = [&](int, int row, int, const float(&sum)[NCOLS], const NoAux &) {
-    if (lane == 0) {
+  const Geo g = geo_for(K);
+  const int lpr = 4 * g.LPC, rr = lane / lpr;
+  auto epi = [&](int, int row0, int nvalid, int, const float(&sum)[NCOLS], const NoAux &) {
+    if ((lane & (lpr - 1)) == 0 && rr < nvalid) {
 #pragma unroll
-      for (int c = 0; c < NCOLS; ++c) a.out[(size_t)c * a.out_stride + row] = sum[c];
+      for (int c = 0; c < NCOLS; ++c) a.out[(size_t)c * a.out_stride + row0 + rr] = sum[c];
     }
   };
   if constexpr (SPEC) {

@@ -68,7 +68,7 @@ struct QTensor {
   const void *data = nullptr;
   int dtype = -1;
   int64_t rows = 0, cols = 0;
-  mutable const void *g2 = nullptr;  // MFMA-layout copy for the prompt GEMM of ext_gemm2.hip (mrs_gemm2_repack; caller-owned, optional)
+  mutable const void *qi = nullptr;  // MFMA-order copy for the exact-integer prompt GEMM of ext_gemm_qi.hip (mrs_gemm_qi_repack; caller-owned, optional)
   size_t nbytes() const { const auto *t = type_info(dtype); return t ? (size_t)rows * (cols / t->block) * t->bytes : 0; }
 };
 
@@ -507,6 +507,7 @@ class Llama {
     b += align(t * nkv * 4) * 2;      // k, v
     b += align(t * ff * 4) * 3;       // gate, up, act
     b += align((pad_to((int)d, MATRIX_ROW_PADDING) / 32) * 36);  // Q8_1 scratch of the last-token lm_head GEMV
+    b += align(mrs_qi_act_bytes(T, (int)std::max(std::max(d, nq), ff)));  // exact prompt path: Q8_K operands of T rows (f16 quants, scales, run sums)
     if (T > prefill_big_min()) b += align(t * std::max(std::max(d, nq), ff) * 2) + align(mrs_gemm_q_bf16_workspace_bytes(T)) + align(t * ff * 2);  // bf16 activations + split-K partials + act(gate)*up slabs of the fused gate/up GEMM
     if (c.num_experts > 0) {  // MoE FFN of the prompt: routes = T * top_k rows in expert-sorted order
       const size_t tk = (size_t)std::max(1, (int)c.num_experts_per_tok), r = t * tk, E = (size_t)c.num_experts;
@@ -566,6 +567,53 @@ class Llama {
     if (all_reduce(m.sum, (size_t)T * d, s)) return fail("prefill: moe all-reduce failed: %s", g_last_error.c_str());
     return mrs_vec_add_f32(h, m.sum, (size_t)T * d, s) ? fail("prefill: residual add failed") : 0;
   }
+  // ---- prompts in the decode engine's arithmetic (round 4): every linear = Q8_K activation rows x exact-integer MFMA GEMM in the engine's f32 order
+  //      (ext_gemm_qi.hip), attention = the decode kernels' per-block partials and merge per query token, RoPE / cache write / SiLU / residual adds = the decode
+  //      expressions.  A prompt token's hidden states, KV pages and logits are bit for bit what a token-by-token decode produces (tests/test_prefill_exact.py);
+  //      the role in the reference is the CPU prompt path (QMatMul f32 fallback per row, gguf/mod.rs:465-478; attention/backends/cpu).
+  bool prefill_exact_ok() const {
+    static const int want = [] { const char *e = getenv("MRS_PREFILL_EXACT"); return e ? atoi(e) : 1; }();
+    if (!want || cfg.use_fused != 2 || !engine_ok() || cfg.world_size > 1 || cfg.num_experts > 0 || cfg.head_dim != 128 || cfg.block_size != 32) return false;
+    const int G = cfg.num_heads / std::max(1, (int)cfg.num_kv_heads);
+    if (cfg.num_heads % cfg.num_kv_heads || (G != 1 && G != 2 && G != 4)) return false;
+    for (const Block &bl : blocks) {
+      const GgufMatMul *ls[7] = {bl.q_proj.get(), bl.k_proj.get(), bl.v_proj.get(), bl.o_proj.get(), bl.gate_proj.get(), bl.up_proj.get(), bl.down_proj.get()};
+      for (const GgufMatMul *l : ls)
+        if (!l || !l->get_qtensor() || !l->get_qtensor()->qi) return false;
+    }
+    return dlm_head.planes != nullptr;
+  }
+  int prefill_exact(const mrs_llama_prefill_args &pa, int T, float *h, float *q, float *k, float *v, float *attn, float *g, float *u, float *act, void *qact,
+                    hipStream_t s) const {
+    const int d = cfg.hidden_size, hd = cfg.head_dim, nq = cfg.num_heads * hd, nkv = cfg.num_kv_heads * hd, ff = cfg.intermediate_size;
+    const int bs = cfg.block_size, kvh = cfg.num_kv_heads, kvd = cfg.kv_f16 ? 0 : 1;
+    const int eff_max = std::min(cfg.max_blocks_per_seq * bs, cfg.max_context_len);
+    const int64_t st = (int64_t)(intptr_t)s;
+    auto lin = [&](const GgufMatMul &m, int N, int K, float *out, int acc) -> int {
+      const QTensor *w = m.get_qtensor();
+      return mrs_gemm_qi(w->qi, w->dtype, N, K, qact, T, out, N, acc, s) ? fail("prefill (exact): mrs_gemm_qi refused ggml dtype %d (N=%d K=%d)", w->dtype, N, K) : 0;
+    };
+    if (wte->embedding_forward_raw(pa.token_ids, T, h, s)) return -1;
+    for (size_t li = 0; li < blocks.size(); ++li) {
+      const Block &bl = blocks[li];
+      if (mrs_qi_quantize(h, nullptr, d, bl.input_layernorm, cfg.rms_eps, T, d, qact, nullptr, s)) return fail("prefill (exact): activation quantizer refused K=%d", d);
+      if (lin(*bl.q_proj, nq, d, q, 0) || lin(*bl.k_proj, nkv, d, k, 0) || lin(*bl.v_proj, nkv, d, v, 0)) return -1;
+      rotary_embedding_positions(q, k, (void *)bufs.cos_table, (void *)bufs.sin_table, (void *)pa.positions, cfg.rope_interleaved ? 0 : 1, hd, T,
+                                 cfg.rot_dim / 2, cfg.max_context_len, cfg.num_heads, cfg.num_kv_heads, nq, nkv, 2, st);
+      reshape_and_cache(k, v, bl.key_cache, bl.value_cache, (int64_t *)pa.slot_mapping, T, cfg.num_kv_heads, hd, bs, 8, nkv, nkv, s, 2, kvd == 1 ? 1 : 0, nullptr, nullptr);
+      if (mrs_prefill_attention_exact(q, bl.key_cache, bl.value_cache, pa.block_tables, pa.context_lens, attn, T, cfg.num_heads, kvh, hd, bs, nq, kvh * hd * bs, hd * bs,
+                                      1.0f / sqrtf((float)hd), eff_max, kvd, cfg.sliding_window, s))
+        return fail("prefill (exact): attention refused the shape");
+      if (mrs_qi_quantize(attn, nullptr, nq, nullptr, 0.f, T, nq, qact, nullptr, s) || lin(*bl.o_proj, d, nq, h, 1)) return -1;
+      if (mrs_qi_quantize(h, nullptr, d, bl.post_attention_layernorm, cfg.rms_eps, T, d, qact, nullptr, s)) return -1;
+      if (lin(*bl.gate_proj, ff, d, g, 0) || lin(*bl.up_proj, ff, d, u, 0)) return -1;
+      if (mrs_qi_quantize(g, u, ff, nullptr, 0.f, T, ff, qact, act, s) || lin(*bl.down_proj, d, ff, h, 1)) return -1;
+    }
+    // ctx.logits: only the last prompt token reaches lm_head (llama.rs:514-517): the decode engine's final norm + lm_head launch
+    if (mrs_dec_proj(&dlm_head, cfg.vocab_size, nullptr, h + (size_t)(T - 1) * d, d, ln_f, cfg.rms_eps, pa.logits, cfg.vocab_size, 0, 1.0f, nullptr, 1, s))
+      return fail("prefill (exact): lm_head refused");
+    return 0;
+  }
   int prefill(const mrs_llama_prefill_args &pa, int T, hipStream_t s) const {
     if (T <= 0) return fail("prefill: T must be positive");
     const int start_pos = pa.start_pos;
@@ -579,6 +627,10 @@ class Llama {
     float *q = (float *)take(t * nq * 4), *attn = (float *)take(t * nq * 4);
     float *k = (float *)take(t * nkv * 4), *v = (float *)take(t * nkv * 4);
     float *g = (float *)take(t * ff * 4), *u = (float *)take(t * ff * 4), *act = (float *)take(t * ff * 4);
+    if (prefill_exact_ok()) {
+      void *qact = take(mrs_qi_act_bytes(T, std::max(std::max(d, nq), ff)));
+      return prefill_exact(pa, T, h, q, k, v, attn, g, u, act, qact, s);
+    }
     MoePrefillBufs moe{};
     if (cfg.num_experts > 0) {
       const size_t tk = (size_t)cfg.num_experts_per_tok, r = t * tk, E = (size_t)cfg.num_experts;
@@ -593,7 +645,6 @@ class Llama {
     const int64_t st = (int64_t)(intptr_t)s;
     // T > 128: the 256-row-tile kernel over bf16 activations (converted once per GEMM group), split-K partials in `part`
     const bool big = T > prefill_big_min() && !getenv("MRS_PREFILL_SMALL_TILES");
-    static const bool use_gemm2 = [] { const char *e = getenv("MRS_PREFILL_GEMM2"); return e && atoi(e) != 0; }();  // opt-in: measured slower than gemm_qc at T = 512 (profiles/round3_prefill.md)
     const size_t part_bytes = big ? mrs_gemm_q_bf16_workspace_bytes(T) : 0;
     void *xb = big ? take(t * std::max(std::max(d, nq), ff) * 2) : nullptr, *part = big ? take(part_bytes) : nullptr;
     void *xg = big ? take(t * ff * 2) : nullptr;  // output slabs of the fused gate / up GEMM (it reads xb while it writes)
@@ -611,11 +662,7 @@ class Llama {
       if (big) {
         xb_src = nullptr;
         rc = to_bf16(x, K);
-        // round 3: weights in MFMA layout feed the matrix cores straight from global memory (ext_gemm2.hip); -3 = shape / type of ext_gemm.hip
-        int r2 = -3;
-        if (!rc && w->g2 && use_gemm2) r2 = mrs_gemm2_q_bf16_multi(1, &w->g2, &N, &out, &N, w->dtype, K, xb, T, acc, part, part_bytes, s);
-        if (!rc && r2 == -3) rc = mrs_gemm_q_bf16_multi(1, &w->data, &N, &out, &N, w->dtype, K, xb, T, acc, part, part_bytes, s);
-        else if (!rc) rc = r2;
+        if (!rc) rc = mrs_gemm_q_bf16_multi(1, &w->data, &N, &out, &N, w->dtype, K, xb, T, acc, part, part_bytes, s);
         xb_src = nullptr;
       } else rc = mrs_gemm_q_f32(w->data, w->dtype, N, K, x, K, out, N, T, acc, s);
       if (rc) return fail("prefill: no GEMM for ggml dtype %d (K=%d)", w->dtype, K);
@@ -632,20 +679,16 @@ class Llama {
       for (size_t i = 0; i < m.size(); ++i) {
         if (done[i]) continue;
         const int ty = m[i]->get_qtensor()->dtype;
-        const void *w[3], *w2[3]; float *oo[3]; int nn[3], ld[3], c = 0;
-        bool all_g2 = use_gemm2;
+        const void *w[3]; float *oo[3]; int nn[3], ld[3], c = 0;
         for (size_t j = i; j < m.size(); ++j)
           if (!done[j] && m[j]->get_qtensor()->dtype == ty) {
-            w[c] = m[j]->get_qtensor()->data; w2[c] = m[j]->get_qtensor()->g2; all_g2 = all_g2 && w2[c] != nullptr;
+            w[c] = m[j]->get_qtensor()->data;
             oo[c] = o[j]; nn[c] = n[j]; ld[c] = n[j]; ++c; done[j] = true;
           }
         int rc;
         if (big) {
           rc = to_bf16(x, K);
-          int r2 = -3;
-          if (!rc && all_g2) r2 = mrs_gemm2_q_bf16_multi(c, w2, nn, oo, ld, ty, K, xb, T, 0, part, part_bytes, s);
-          if (!rc && r2 == -3) rc = mrs_gemm_q_bf16_multi(c, w, nn, oo, ld, ty, K, xb, T, 0, part, part_bytes, s);
-          else if (!rc) rc = r2;
+          if (!rc) rc = mrs_gemm_q_bf16_multi(c, w, nn, oo, ld, ty, K, xb, T, 0, part, part_bytes, s);
         } else rc = mrs_gemm_q_f32_multi(c, w, nn, oo, ld, ty, K, x, K, T, 0, s);
         if (rc) return fail("prefill: no GEMM for ggml dtype %d (K=%d)", ty, K);
       }
@@ -876,16 +919,16 @@ extern "C" int mrs_llama_set_dec_tensor(void *mm, const char *cname, const void 
   }
   return mrs_host::fail("decode layout: tensor %s has no decode-engine role", cname);
 }
-// MFMA-layout copy (mrs_gemm2_repack output, caller-owned) of a dense linear already registered with mrs_llama_set_tensor: the prompt GEMMs of
-// ext_gemm2.hip read it; tensors without one (or of a type it does not take) keep the GGUF-block kernels of ext_gemm.hip
-extern "C" int mrs_llama_set_gemm2_tensor(void *mm, const char *cname, const void *planes) {
+// MFMA-order copy (mrs_gemm_qi_repack output, caller-owned) of a dense linear already registered with mrs_llama_set_tensor: the exact-integer prompt GEMM
+// of ext_gemm_qi.hip reads it; a model whose dense linears all have one runs its prompts in the decode engine's arithmetic (Llama::prefill_exact)
+extern "C" int mrs_llama_set_qi_tensor(void *mm, const char *cname, const void *planes) {
   Llama &m = *(Llama *)mm;
   const std::string name = cname;
   auto bind = [&](const std::unique_ptr<mrs_host::GgufMatMul> &l) {
     const mrs_host::QTensor *t = l ? l->get_qtensor() : nullptr;
     if (!t || !t->data) return mrs_host::fail("MFMA layout for %s: register the tensor with mrs_llama_set_tensor first", cname);
-    if (!mrs_gemm2_repack_bytes(t->dtype, t->rows, t->cols)) return mrs_host::fail("MFMA layout for %s: ggml dtype %d / shape not supported", cname, t->dtype);
-    t->g2 = planes;
+    if (!mrs_gemm_qi_repack_bytes(t->dtype, t->rows, t->cols)) return mrs_host::fail("MFMA-order copy for %s: ggml dtype %d / shape not supported", cname, t->dtype);
+    t->qi = planes;
     return 0;
   };
   int layer = -1, consumed = 0;
@@ -924,5 +967,6 @@ extern "C" int mrs_llama_prefill(void *m, const mrs_llama_prefill_args *a, int T
   return l.prefill(*a, T, (hipStream_t)stream);
 }
 extern "C" double mrs_llama_prefill_flops(void *m, int T) { return ((Llama *)m)->prefill_flops(T); }
+extern "C" int mrs_llama_prefill_is_exact(void *m) { return ((Llama *)m)->prefill_exact_ok() ? 1 : 0; }
 extern "C" int mrs_llama_set_comm(void *m, void *comm) { ((Llama *)m)->comm = comm; return 0; }
 extern "C" int mrs_llama_set_p2p(void *m, void *p2p) { ((Llama *)m)->p2p = p2p; return 0; }

@@ -150,52 +150,3 @@ def fused_glu_bf16(w_gate: QTensor, w_up: QTensor, slabs: torch.Tensor, activati
     if fn(w_gate.data.data_ptr(), w_up.data.data_ptr(), w_gate.dtype.id, n, k, slabs.data_ptr(), m, int(activation), y.data_ptr(), torch.cuda.current_stream().cuda_stream):
         raise ValueError(f"fast_gemm.fused_glu_bf16: unsupported shape K={k} for {w_gate.dtype.name}")
     return y
-
-
-# ---------------------------------------------------------------- round 3: weights in MFMA operand layout (csrc/ext_gemm2.hip)
-def supports_mfma_layout(dtype: GgmlDType) -> bool:
-    return bool(_lib.sym("ext", "mrs_gemm2_supported", [C.c_int], C.c_int)(dtype.id))
-
-
-def to_mfma_layout(w: QTensor) -> torch.Tensor:
-    """GGUF blocks -> the load-time MFMA layout of ext_gemm2.hip (mrs_gemm2_repack): per 32-row tile and 64-k chunk one KiB that holds, lane by
-    lane, the quants of the lane's four B fragments; scales in a second plane.  A pure bit permutation (+ the 6-bit scale expansion)."""
-    n, k = w.shape
-    nb = _lib.sym("ext", "mrs_gemm2_repack_bytes", [C.c_int, C.c_longlong, C.c_longlong], C.c_size_t)(w.dtype.id, n, k)
-    if nb == 0:
-        raise ValueError(f"fast_gemm: no MFMA layout for {w.dtype.name} [{n}, {k}]")
-    dst = torch.empty(nb, dtype=torch.uint8, device=w.data.device)
-    rc = _lib.sym("ext", "mrs_gemm2_repack", [C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p], C.c_int)(
-        w.data.data_ptr(), w.dtype.id, n, k, dst.data_ptr(), torch.cuda.current_stream().cuda_stream)
-    if rc != 0:
-        raise ValueError("fast_gemm: mrs_gemm2_repack refused the tensor")
-    return dst
-
-
-def plain_mfma_layout(ws: list, layouts: list, xs: torch.Tensor, outs: list | None = None, accumulate: bool = False, split_k: bool = True) -> list:
-    """mrs_gemm2_q_bf16_multi: up to three weights of one type sharing the activations (fused q / k / v, gate / up).  ws: the QTensors (shapes / type),
-    layouts: their to_mfma_layout() copies.  Raises NotImplementedError for shapes that belong to plain_bf16 (M <= 128, other types)."""
-    k = ws[0].shape[1]
-    slabs = to_slabs(xs.reshape(-1, k).contiguous()) if xs.dtype == torch.float32 else xs
-    m = slabs.shape[1]
-    if outs is None:
-        outs = [torch.empty(m, w.shape[0], dtype=torch.float32, device=slabs.device) for w in ws]
-        accumulate = False
-    ntot = sum((w.shape[0] + 255) // 256 * 256 for w in ws)
-    wsb = 8 * m * ntot * 4 if split_k else 0
-    work = torch.empty(max(wsb, 16), dtype=torch.uint8, device=slabs.device)
-    c = len(ws)
-    wp = (C.c_void_p * c)(*[l.data_ptr() for l in layouts])
-    np_ = (C.c_int * c)(*[w.shape[0] for w in ws])
-    op = (C.c_void_p * c)(*[o.data_ptr() for o in outs])
-    ld = (C.c_int * c)(*[o.stride(0) for o in outs])
-    fn = _lib.sym("ext", "mrs_gemm2_q_bf16_multi", [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
-                                                    C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p], C.c_int)
-    rc = fn(c, wp, np_, op, ld, ws[0].dtype.id, k, slabs.data_ptr(), m, int(accumulate), work.data_ptr() if split_k else None, wsb,
-            torch.cuda.current_stream().cuda_stream)
-    if rc == -3:
-        raise NotImplementedError("fast_gemm: this shape / type is served by plain_bf16")
-    if rc != 0:
-        raise ValueError("fast_gemm: mrs_gemm2_q_bf16_multi refused the arguments")
-    torch.cuda.current_stream().synchronize()
-    return outs

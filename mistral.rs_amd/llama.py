@@ -161,11 +161,11 @@ class Llama:
         L.mrs_dec_repack_bytes.restype = C.c_size_t
         L.mrs_dec_repack_bytes.argtypes = [C.c_int, C.c_longlong, C.c_longlong]
         L.mrs_dec_repack.argtypes = [C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p]
-        L.mrs_gemm2_repack_bytes.restype = C.c_size_t
-        L.mrs_gemm2_repack_bytes.argtypes = [C.c_int, C.c_longlong, C.c_longlong]
-        L.mrs_gemm2_repack.argtypes = [C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p]
-        L.mrs_llama_set_gemm2_tensor.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
-        self._gemm2_wanted = os.environ.get("MRS_PREFILL_GEMM2", "0") not in ("", "0")
+        L.mrs_gemm_qi_repack_bytes.restype = C.c_size_t
+        L.mrs_gemm_qi_repack_bytes.argtypes = [C.c_int, C.c_longlong, C.c_longlong]
+        L.mrs_gemm_qi_repack.argtypes = [C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p]
+        L.mrs_llama_set_qi_tensor.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
+        self._exact_prefill_wanted = os.environ.get("MRS_PREFILL_EXACT", "1") not in ("", "0")
         L.mrs_last_error.restype = C.c_char_p
         c = _Cfg(cfg.hidden_size, cfg.intermediate_size, cfg.num_layers, cfg.num_heads, cfg.num_kv_heads, cfg.head_dim,
                  cfg.vocab_size, cfg.head_dim, int(cfg.rope_interleaved), cfg.rms_eps, cfg.block_size, cfg.max_blocks_per_seq,
@@ -274,14 +274,15 @@ class Llama:
                         torch.cuda.current_stream().synchronize()  # the permuted copy dies with this call
                     self._keep[name + "#dec"] = planes
                     self._chk(self._L.mrs_llama_set_dec_tensor(self._h, name.encode(), planes.data_ptr()))
-            # MFMA layout for the prompt GEMM of ext_gemm2.hip (dense per-layer linears of the types it takes): a third copy of the same bits, made once
-            if self._gemm2_wanted and name.startswith("blk.") and "_exps" not in name:
-                nb2 = self._L.mrs_gemm2_repack_bytes(t.dtype.id, t.shape[0], t.shape[1])
+            # MFMA-order copy for the exact-integer prompt GEMM (ext_gemm_qi.hip): dense per-layer linears of the types it takes; with every one present the
+            # runner prefills in the decode engine's arithmetic (Llama::prefill_exact).  A third copy of the same bits, made once.
+            if self._engine_wanted and self._exact_prefill_wanted and name.startswith("blk.") and "_exps" not in name:
+                nb2 = self._L.mrs_gemm_qi_repack_bytes(t.dtype.id, t.shape[0], t.shape[1])
                 if nb2:
-                    g2 = torch.empty(nb2, dtype=torch.uint8, device=self.device)
-                    self._chk(self._L.mrs_gemm2_repack(t.data.data_ptr(), t.dtype.id, t.shape[0], t.shape[1], g2.data_ptr(), self._stream()))
-                    self._keep[name + "#g2"] = g2
-                    self._chk(self._L.mrs_llama_set_gemm2_tensor(self._h, name.encode(), g2.data_ptr()))
+                    qi = torch.empty(nb2, dtype=torch.uint8, device=self.device)
+                    self._chk(self._L.mrs_gemm_qi_repack(t.data.data_ptr(), t.dtype.id, t.shape[0], t.shape[1], qi.data_ptr(), self._stream()))
+                    self._keep[name + "#qi"] = qi
+                    self._chk(self._L.mrs_llama_set_qi_tensor(self._h, name.encode(), qi.data_ptr()))
         else:
             t = t.to(self.device, torch.float32).contiguous()
             self._keep[name] = t
@@ -361,13 +362,16 @@ class Llama:
         self._graph.replay()
 
     def prefill(self, tokens, start_pos: int = 0, seq: int = 0) -> torch.Tensor:
-        """Prompt processing of one sequence on the bf16 matrix cores (mrs_llama_prefill): returns the last token's logits
-        [vocab] and leaves K/V of every prompt token in the sequence's pages.  Mirrors the prompt branch of the reference
+        """Prompt processing of one sequence (mrs_llama_prefill): returns the last token's logits [vocab] and leaves K/V of every prompt token in the
+        sequence's pages.  With the decode engine and Q4_K / Q6_K linears (`prefill_is_exact`) the prompt runs in the decode engine's arithmetic -- Q8_K
+        activation rows x exact-integer MFMA GEMMs, the decode kernels' attention per query -- and every logit and KV page equals what a token-by-token
+        decode produces; otherwise on the bf16 matrix cores (dequantized weights).  Mirrors the prompt branch of the reference
         (PagedAttention::forward try_regular_prompt + reshape_and_cache, paged_attention.rs:1413-1475)."""
+        self._set_mode()
         cfg, dev = self.cfg, self.device
         T = len(tokens)
-        if cfg.kv_dtype != "bf16":
-            raise ValueError("the MFMA prefill reads and writes bf16 KV pages; use prefill_chunked() with f16 pages")
+        if cfg.kv_dtype != "bf16" and not self.prefill_is_exact:
+            raise ValueError("the bf16 MFMA prefill reads and writes bf16 KV pages; use prefill_chunked() with f16 pages")
         if start_pos + T > cfg.max_context_len:
             raise ValueError("prompt does not fit max_context_len")
         pos = torch.arange(start_pos, start_pos + T, dtype=torch.int32, device=dev)
@@ -385,6 +389,13 @@ class Llama:
         self._chk(self._L.mrs_llama_prefill(self._h, C.byref(a), T, self._stream()))
         self._prefill_keep = (ids, pos, slots, bts, ctx)  # keep alive until the stream has consumed them
         return out
+
+    @property
+    def prefill_is_exact(self) -> bool:
+        """True when prefill() runs in the decode engine's arithmetic (csrc/ext_gemm_qi.hip; Llama::prefill_exact in host/runtime.cpp)."""
+        self._set_mode()
+        self._L.mrs_llama_prefill_is_exact.argtypes = [C.c_void_p]
+        return bool(self._L.mrs_llama_prefill_is_exact(self._h))
 
     def prefill_flops(self, T: int) -> float:
         return float(self._L.mrs_llama_prefill_flops(self._h, T))

@@ -215,6 +215,28 @@ static hiphost_f32x16 mfma_32x32x16_bf16(hiphost_bf16x8 a, hiphost_bf16x8 b, hip
 }
 }  // namespace hiphost
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, CBSZ, ABID, BLGP) hiphost::mfma_32x32x16_bf16((A), (B), (C))
+// v_mfma_f32_32x32x16_f16: same lane layout as the bf16 form, f16 operands.  Products of the small integers ext_gemm_qi.hip feeds it are exact and every
+// partial sum stays below 2^24, so the order of the k sum cannot matter (on the device tests/test_gemm_qi.py checks exactly that on adversarial operands).
+typedef _Float16 hiphost_f16x8 __attribute__((ext_vector_type(8)));
+namespace hiphost {
+inline _Float16 mfma_ah[MAX_THREADS][8], mfma_bh[MAX_THREADS][8];
+static hiphost_f32x16 mfma_32x32x16_f16(hiphost_f16x8 a, hiphost_f16x8 b, hiphost_f32x16 c) {
+  const int tid = linear_tid(), w = tid / WAVE, lane = tid & (WAVE - 1), base = w * WAVE;
+  for (int j = 0; j < 8; ++j) { mfma_ah[tid][j] = a[j]; mfma_bh[tid][j] = b[j]; }
+  wave_barrier(w, 0);
+  const int col = lane & 31, hi = lane >> 5;
+  hiphost_f32x16 d = c;
+  for (int i = 0; i < 16; ++i) {
+    const int row = 8 * (i / 4) + 4 * hi + (i % 4);
+    float acc = c[i];
+    for (int k = 0; k < 16; ++k) acc += (float)mfma_ah[base + row + 32 * (k / 8)][k % 8] * (float)mfma_bh[base + col + 32 * (k / 8)][k % 8];
+    d[i] = acc;
+  }
+  wave_barrier(w, 0);
+  return d;
+}
+}  // namespace hiphost
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, CBSZ, ABID, BLGP) hiphost::mfma_32x32x16_f16((A), (B), (C))
 // v_mfma_i32_32x32x32_i8: D = A (32 x 32 int8) * B (32 x 32 int8) + C, exact in int32.  Lane l holds A[l % 32][16 * (l / 32) + j] and
 // B[16 * (l / 32) + j][l % 32] (j = 0..15, 16 consecutive bytes); C / D as every 32 x 32 MFMA (the layout of the accumulators is dtype-independent).
 // Which 16 k a lane half holds does not change the result as long as A and B agree -- they do by symmetry.

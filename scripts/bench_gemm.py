@@ -10,7 +10,7 @@ def main():
     ap.add_argument("--t", type=int, default=512)
     ap.add_argument("--types", default="q4_k,q6_k")
     ap.add_argument("--big", action="store_true", help="256-row-tile kernel over bf16 activations (mrs_gemm_q_bf16_multi)")
-    ap.add_argument("--g2", action="store_true", help="weights in MFMA layout, B operand straight from global (mrs_gemm2_q_bf16_multi, csrc/ext_gemm2.hip)")
+    ap.add_argument("--qi", action="store_true", help="the exact-integer prompt GEMM in the decode engine's arithmetic (mrs_gemm_qi, csrc/ext_gemm_qi.hip); also times the activation quantizer")
     ap.add_argument("--mmq", action="store_true", help="the reference-ABI route instead: launch_mmq_quantize_q8_1_* + launch_mmq_gguf_<t> (fast_mmq.plain)")
     a = ap.parse_args()
     import torch
@@ -26,16 +26,21 @@ def main():
             out = torch.empty(a.t, n, device=dev)
             ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
             xb = fast_gemm.to_slabs(x) if a.big else None
-            if a.g2:
+            if a.qi:
                 import ctypes as C
                 from mistralrs_amd import _lib
-                lay = fast_gemm.to_mfma_layout(w)
-                xs = fast_gemm.to_slabs(x)
-                fn = _lib.sym("ext", "mrs_gemm2_q_bf16_multi", [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
-                                                                C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p], C.c_int)
-                wp, np_, op, ld = (C.c_void_p * 1)(lay.data_ptr()), (C.c_int * 1)(n), (C.c_void_p * 1)(out.data_ptr()), (C.c_int * 1)(n)
+                L = _lib.load("ext")
+                L.mrs_gemm_qi_repack_bytes.restype = C.c_size_t; L.mrs_gemm_qi_repack_bytes.argtypes = [C.c_int, C.c_longlong, C.c_longlong]
+                L.mrs_qi_act_bytes.restype = C.c_size_t; L.mrs_qi_act_bytes.argtypes = [C.c_int, C.c_int]
+                L.mrs_gemm_qi_repack.argtypes = [C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p]
+                L.mrs_qi_quantize.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+                L.mrs_gemm_qi.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
                 st = torch.cuda.current_stream().cuda_stream
-                run = lambda: fn(1, wp, np_, op, ld, w.dtype.id, k, xs.data_ptr(), a.t, 0, ws.data_ptr(), ws.numel(), st)
+                lay = torch.empty(L.mrs_gemm_qi_repack_bytes(w.dtype.id, n, k), dtype=torch.uint8, device=dev)
+                assert L.mrs_gemm_qi_repack(w.data.data_ptr(), w.dtype.id, n, k, lay.data_ptr(), st) == 0
+                actb = torch.empty(L.mrs_qi_act_bytes(a.t, k), dtype=torch.uint8, device=dev)
+                assert L.mrs_qi_quantize(x.data_ptr(), None, k, None, 0.0, a.t, k, actb.data_ptr(), None, st) == 0
+                run = lambda: L.mrs_gemm_qi(lay.data_ptr(), w.dtype.id, n, k, actb.data_ptr(), a.t, out.data_ptr(), n, 0, st)
             elif a.mmq:
                 run = lambda: fast_mmq.plain(w, x)
             elif a.big:

@@ -235,72 +235,3 @@ def test_prefill_gemm_at_bench_shapes(oracle, dev, tname, variant, m, n, k):
     finally:
         setv(-1)
 
-
-def _check_gemm2(oracle, dev, tname, m, shapes, k, split):
-    """ext_gemm2.hip (weights in MFMA layout, B operand straight from global) == the block kernels of ext_gemm.hip bit for bit when neither splits K
-    (same operands, same MFMA k order), and within the oracle-A bound in every case; fused segments, ragged M / N tiles."""
-    import torch
-    from mistralrs_amd.gguf import GgmlDType, QTensor, fast_gemm
-    t = getattr(oracle, tname)
-    rng = np.random.default_rng(m + sum(shapes) + k)
-    x = (rng.standard_normal((m, k)) * rng.uniform(0.2, 3.0, (m, 1))).astype(np.float32)
-    xt = torch.from_numpy(x).to(dev)
-    ws, packed = [], []
-    for n in shapes:
-        p = oracle.random_blocks(t, n, k, seed=n + k, d_scale=0.02)
-        packed.append(p)
-        ws.append(QTensor.from_numpy(GgmlDType.from_id(t), (n, k), p, dev))
-    lay = [fast_gemm.to_mfma_layout(w) for w in ws]
-    outs = fast_gemm.plain_mfma_layout(ws, lay, xt, split_k=split)
-    xb = round_through(x, "bf16").astype(np.float64)
-    for w, p, o in zip(ws, packed, outs):
-        got = o.cpu().numpy().astype(np.float64)
-        wb = round_through(oracle.dequantize(t, p, k), "bf16").astype(np.float64)
-        want, mag = xb @ wb.T, np.abs(xb) @ np.abs(wb).T
-        err = np.abs(got - want)
-        assert (err <= 2.0 ** -19 * mag + 1e-30).all(), float((err / (2.0 ** -19 * mag + 1e-30)).max())
-        if not split:
-            assert torch.equal(o, fast_gemm.plain_bf16(w, xt, split_k=False))
-    again = fast_gemm.plain_mfma_layout(ws, lay, xt, split_k=split)
-    assert all(torch.equal(a, b) for a, b in zip(outs, again))  # deterministic
-    base = [torch.randn_like(o) for o in outs]
-    acc = fast_gemm.plain_mfma_layout(ws, lay, xt, outs=[b.clone() for b in base], accumulate=True, split_k=split)
-    assert all(torch.equal(a, b + o) for a, b, o in zip(acc, base, outs))
-
-
-@pytest.mark.parametrize("tname", ["Q4_K", "Q6_K"])
-@pytest.mark.parametrize("m,shapes,k,split", [(300, (200,), 512, False), (257, (64, 40, 40), 1024, True), (129, (300,), 256, True), (512, (256, 256), 2048, False)])
-def test_gemm2_mfma_layout_kernel(oracle, dev, tname, m, shapes, k, split):
-    _check_gemm2(oracle, dev, tname, m, shapes, k, split)
-
-
-@pytest.mark.parametrize("tname", ["Q4_K", "Q6_K"])
-@pytest.mark.parametrize("m,shapes,k", [(512, (14336, 14336), 4096), (2048, (4096,), 14336), (512, (4096, 1024), 4096)])
-def test_gemm2_at_bench_shapes(oracle, dev, request, tname, m, shapes, k):
-    """Llama-3-8B prompt shapes (gate + up fused, down with split-K, q + k fused) through the MFMA-layout kernel == the block kernels bit for bit without split-K;
-    with split-K (as the runner launches it) within the oracle-A bound on sampled rows."""
-    import torch
-    if request.config.getoption("--host-emulation"):
-        pytest.skip("bench shapes are for the device")
-    from mistralrs_amd.gguf import GgmlDType, QTensor, fast_gemm
-    t = getattr(oracle, tname)
-    rng = np.random.default_rng(m + k)
-    x = (rng.standard_normal((m, k)) * rng.uniform(0.2, 3.0, (m, 1))).astype(np.float32)
-    xt = torch.from_numpy(x).to(dev)
-    ws, packed = [], []
-    for n in shapes:
-        p = oracle.random_blocks(t, n, k, seed=n + k, d_scale=0.02)
-        packed.append(p)
-        ws.append(QTensor.from_numpy(GgmlDType.from_id(t), (n, k), p, dev))
-    lay = [fast_gemm.to_mfma_layout(w) for w in ws]
-    nosplit = fast_gemm.plain_mfma_layout(ws, lay, xt, split_k=False)
-    for w, o in zip(ws, nosplit):
-        assert torch.equal(o, fast_gemm.plain_bf16(w, xt, split_k=False))
-    split = fast_gemm.plain_mfma_layout(ws, lay, xt, split_k=True)
-    xb = round_through(x, "bf16").astype(np.float64)
-    for w, p, o in zip(ws, packed, split):
-        rows = np.sort(rng.choice(w.shape[0], size=256, replace=False))
-        wb = round_through(oracle.dequantize(t, p[rows], k), "bf16").astype(np.float64)
-        want, mag = xb @ wb.T, np.abs(xb) @ np.abs(wb).T
-        got = o[:, torch.from_numpy(rows).to(dev)].cpu().numpy().astype(np.float64)
-        assert (np.abs(got - want) <= 2.0 ** -19 * mag + 1e-30).all()

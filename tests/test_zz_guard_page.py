@@ -20,7 +20,7 @@ be = HostBackend()
 libc = C.CDLL(None, use_errno=True)
 libc.mprotect.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
 n, K, sym = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
-t = O.Q6_K if sym in ("norm_proj", "gemm_q6", "gemm2_q6", "mmq_mfma_q6") else O.Q4_K
+t = O.Q6_K if sym in ("norm_proj", "gemm_q6", "gemm_qi_q6", "mmq_mfma_q6") else O.Q4_K
 w = O.random_blocks(t, n, K if sym != "hqq" else 256, seed=1, d_scale=0.02).reshape(-1)
 page = mmap.PAGESIZE
 keep = []
@@ -61,27 +61,27 @@ elif sym in ("gemm", "gemm_q6"):
     got = out.numpy()
     assert np.isfinite(got).all() and np.abs(got - want).max() <= 1e-3 * np.abs(want).max()
     print("guard page intact"); sys.exit(0)
-elif sym in ("gemm2", "gemm2_q6"):
-    # prompt GEMM with the weights in MFMA operand order (opt-in): the repack reads GGUF blocks that end at a guard page (the padding rows of the last
-    # 32-row tile must not be fetched), the GEMM reads a layout and activation slabs that end at guard pages; ragged N and M tiles
+elif sym in ("gemm_qi", "gemm_qi_q6"):
+    # prompt GEMM in the decode engine's arithmetic (ext_gemm_qi.hip): the repack reads GGUF blocks that end at a guard page (the padding rows of the last
+    # 32-row panel must not be fetched), the GEMM reads an MFMA-order copy and operand buffers that end at guard pages; ragged N and token tiles
     M = 150
-    nb2 = be.sym("mrs_gemm2_repack_bytes", [C.c_int, C.c_longlong, C.c_longlong], C.c_size_t)(t, n, K)
+    nb2 = be.sym("mrs_gemm_qi_repack_bytes", [C.c_int, C.c_longlong, C.c_longlong], C.c_size_t)(t, n, K)
     assert nb2 > 0
     lay = be.buf(np.zeros(nb2, np.uint8))
-    assert be.sym("mrs_gemm2_repack", [C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p], C.c_int)(dst, t, n, K, lay.ptr, be.stream) == 0
+    assert be.sym("mrs_gemm_qi_repack", [C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p], C.c_int)(dst, t, n, K, lay.ptr, be.stream) == 0
     lp = guarded(lay.numpy())
     xm = np.random.default_rng(1).standard_normal((M, K)).astype(np.float32)
-    slabs, xmb = be.buf(np.zeros((K // 64, M, 64), np.uint16)), be.buf(xm)
-    assert be.sym("mrs_convert_f32_bf16_slabs", [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p], C.c_int)(xmb.ptr, K, M, K, slabs.ptr, be.stream) == 0
-    sp = guarded(slabs.numpy())
+    xp = guarded(xm)
+    ab = be.sym("mrs_qi_act_bytes", [C.c_int, C.c_int], C.c_size_t)(M, K)
+    actb = be.buf(np.zeros(ab, np.uint8))
+    assert be.sym("mrs_qi_quantize", [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int)(
+        xp, None, K, None, 0.0, M, K, actb.ptr, None, be.stream) == 0
+    ap = guarded(actb.numpy())
     out = be.buf(np.full((M, n), np.nan, np.float32))
-    wp, np_, op, ld = (C.c_void_p * 1)(lp), (C.c_int * 1)(n), (C.c_void_p * 1)(out.ptr), (C.c_int * 1)(n)
-    fn = be.sym("mrs_gemm2_q_bf16_multi", [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p], C.c_int)
-    assert fn(1, wp, np_, op, ld, t, K, sp, M, 0, None, 0, be.stream) == 0
-    from tests.util import round_through
-    want = round_through(xm, "bf16").astype(np.float64) @ round_through(O.dequantize(t, w.reshape(n, -1), K), "bf16").astype(np.float64).T
-    got = out.numpy()
-    assert np.isfinite(got).all() and np.abs(got - want).max() <= 1e-3 * np.abs(want).max()
+    fn = be.sym("mrs_gemm_qi", [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p], C.c_int)
+    assert fn(lp, t, n, K, ap, M, out.ptr, n, 0, be.stream) == 0
+    want = np.concatenate([O.gemv_engine(t, w.reshape(n, -1), n, K, r) for r in xm], axis=0)
+    assert np.array_equal(out.numpy(), want)
     print("guard page intact"); sys.exit(0)
 elif sym in ("mmq", "mmq_mfma", "mmq_mfma_q6"):
     # prompt-sized drop-in launcher (launch_mmq_gguf_q4_k / q6_k): weights and the block_q8_1_mmq activations end at guard pages; >= 48 columns take the
@@ -202,7 +202,7 @@ print("guard page intact")
 
 
 @pytest.mark.parametrize("n,k,sym,env", [(600, 512, "norm_proj", {"MRS_PROJ_WGS": "2"}), (129, 1024, "mmvq", {}), (2049, 256, "mmvq", {}),
-                                         (200, 512, "gemm", {"MRS_GEMM_VARIANT": "1"}), (200, 512, "gemm", {"MRS_GEMM_VARIANT": "0"}), (130, 256, "gemm_q6", {}), (200, 512, "gemm2", {}), (130, 256, "gemm2_q6", {}),
+                                         (200, 512, "gemm", {"MRS_GEMM_VARIANT": "1"}), (200, 512, "gemm", {"MRS_GEMM_VARIANT": "0"}), (130, 256, "gemm_q6", {}), (200, 512, "gemm_qi", {}), (130, 256, "gemm_qi_q6", {}),
                                          (70, 512, "dec_proj", {}), (2049, 256, "dec_proj", {}),
                                          (70, 512, "mmq", {}), (129, 256, "mmq", {}), (70, 512, "mmq_mfma", {}), (129, 256, "mmq_mfma", {}), (70, 512, "mmq_mfma_q6", {}), (50, 512, "imoe", {}), (128, 256, "hqq", {}), (64, 2064, "hqq", {}),
                                          (96, 256, "attn", {}), (33, 256, "attn", {}), (70, 256, "prefill_attn", {}), (33, 256, "prefill_attn", {})])
