@@ -216,9 +216,13 @@ int mrs_gemm_qi_repack(const void *gguf_blocks, int ggml_type, long long n, long
 size_t mrs_qi_act_bytes(int T, int K);
 int mrs_qi_quantize(const float *x, const float *x2, int ldx, const float *norm_w, float eps, int T, int K, void *act, float *xtmp, void *stream);
 int mrs_gemm_qi(const void *w_qi, int ggml_type, int N, int K, const void *act, int T, float *out, int ldo, int accumulate, void *stream);
+/* the same with a workspace (mrs_gemm_qi_workspace_bytes(T, N) or more): launches with few workgroups run one workgroup per run of superblocks + a reduce -- same bits */
+size_t mrs_gemm_qi_workspace_bytes(int T, int max_n);
+int mrs_gemm_qi_ws(const void *w_qi, int ggml_type, int N, int K, const void *act, int T, float *out, int ldo, int accumulate, void *workspace, size_t workspace_bytes,
+                   void *stream);
 int mrs_prefill_attention_exact(const float *q, const void *k_cache, const void *v_cache, const uint32_t *block_table, const uint32_t *context_lens, float *out, int T,
                                 int num_heads, int num_kv_heads, int head_size, int block_size, int q_stride, int kv_block_stride, int kv_head_stride, float scale,
-                                int max_context_len, int kv_dtype, int sliding_window, void *stream);
+                                int max_context_len, int kv_dtype, int sliding_window, int max_prompt_ctx /* largest context_lens[t], or 0 */, void *stream);
 int mrs_llama_set_qi_tensor(void *model, const char *name, const void *planes); /* MFMA-order copy of a dense linear registered with mrs_llama_set_tensor */
 int mrs_llama_prefill_is_exact(void *model); /* 1: mrs_llama_prefill runs in the decode engine's arithmetic (every dense linear has its MFMA-order copy, decode engine on, TP = 1, no experts) */
 /* diagnostics: pull a byte range through the Infinity Cache (ext_prefetch.hip); one wave of K-deep v_mfma_f32_32x32x16_f16 on caller operands (the exactness

@@ -391,7 +391,7 @@ template <int TYPE> struct Tile;
 // mask), hs[16] = the 8 sub-block scales, then the 8 mins, as bytes; hd = d | dmin << 16 (f16 bits).  Sub-block 2c <- low nibbles of pieces 2c, 2c+1
 // (activation runs 4c, 4c+1), sub-block 2c+1 <- high nibbles (runs 4c+2, 4c+3).
 #ifndef MRS_DEC2_NS_Q4K
-#define MRS_DEC2_NS_Q4K 2
+#define MRS_DEC2_NS_Q4K 3
 #endif
 #ifndef MRS_DEC2_NS_Q6K
 #define MRS_DEC2_NS_Q6K 2
@@ -612,6 +612,8 @@ struct Job {
   int nseg, rgpu;
   int nrows;            // rows per tensor (per expert slot) that take part
   int u0, u1;           // this workgroup's units
+  int ring;             // records a wave keeps requested ahead (<= the format's NS register sets): measured on the MI355X, short launches want 1 (the time to the
+                        // first computed record decides), long streams the full ring (profiles/round4_decode.md)
   const int32_t *sel;   // stacked experts [E * rows][K]: device array of expert ids per slot, or nullptr (dense)
   int sel_mode;         // 1: slot = unit / upe (all top-k experts of a token in one launch; upe = every unit when there is one slot);  2: slot = segment
   int upe;              // units per expert slot
@@ -619,6 +621,8 @@ struct Job {
   unsigned long long *tl;  // experiments: 16 s_memrealtime stamps (100 MHz) per wave, or nullptr
 };
 #define MRS_TL2(jb, i) do { if ((jb).tl && (tid_opaque() & 63) == 0) (jb).tl[((size_t)blockIdx.x * NW + (tid_opaque() >> 6)) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// the lane of a record group's row rr that holds the row sum in the epilogue (and loads the row's epilogue operands)
+__host__ __device__ inline int owner_off(const Geo &g) { return 3 * g.LPC + g.W - 1; }
 struct RecMeta { int unit, seg, rgl, ts; };  // unit < 0: nothing was requested into the slot
 struct NoAux {};
 
@@ -649,10 +653,14 @@ __device__ __forceinline__ void stream(const Job &jb, int K, int ncols_img, int 
   int lunit = late ? -1 : jb.u0 + (spec ? wave - PW : wave), lpos = 0;
   bool started = !late;
   auto issue = [&](typename TL::Raw &slot, RecMeta &m, AuxT &ax) {
-    if (started && lunit >= 0 && lpos == rpu) {  // next unit from the counter (wave-uniform)
-      int nu = 0;
-      if (lane == 0) nu = atomicAdd(ctr, 1);
-      lunit = __builtin_amdgcn_readfirstlane(nu);
+    if (started && lunit >= 0 && lpos == rpu) {  // next unit (wave-uniform): ALL -- every NW-th unit, no traffic; SPEC -- from the counter in LDS (late waves take fewer)
+      if constexpr (SPEC) {
+        int nu = 0;
+        if (lane == 0) nu = atomicAdd(ctr, 1);
+        lunit = __builtin_amdgcn_readfirstlane(nu);
+      } else {
+        lunit += NW;
+      }
       lpos = 0;
     }
     const bool livel = started && lunit >= 0 && lunit < jb.u1;
@@ -672,9 +680,12 @@ __device__ __forceinline__ void stream(const Job &jb, int K, int ncols_img, int 
       lunit = -1;
     }
   };
+  const int nsr = jb.ring < 1 ? 1 : (jb.ring > NS ? NS : jb.ring);
+#pragma unroll
+  for (int i = 0; i < NS; ++i) meta[i] = RecMeta{-1, 0, 0, 0};
   auto fill = [&]() {
 #pragma unroll
-    for (int i = 0; i < NS; ++i) issue(ring[i], meta[i], auxv[i]);
+    for (int i = 0; i < NS; ++i) if (i < nsr) issue(ring[i], meta[i], auxv[i]);
   };
   // A CU has one in-order memory pipe: what the prologue needs from memory is requested (stage 0), by every wave that takes part, BEFORE any wave of the
   // workgroup requests weights -- the first barrier sits in between.  The branches below execute the same two barriers.
@@ -720,45 +731,74 @@ __device__ __forceinline__ void stream(const Job &jb, int K, int ncols_img, int 
   const int gbase = lane & ~(g.LPC - 1), rbase = lane & ~(lpr - 1);
   bool more = true;
   int nrec = 0;
+  // T of the record in slot i for this lane's superblock
+  auto terms = [&](int i, float (&T)[NCOLS]) {
+    const int sbi = meta[i].ts * g.W + j, sb = p * g.Cs + sbi;  // index inside the chunk, superblock
+    const bool live = lane_ok && sbi < g.Cs && sb < g.S;
+    TermCols<TYPE, NCOLS, 0>::run(ring[i], live ? sb : 0, live, act, SEGCOL ? meta[i].seg : 0, T);
+  };
+  // chunk scan, row combination, epilogue of slot i; then the slot's next request
+  auto finish = [&](int i, const float (&T)[NCOLS]) {
+    const int cts = meta[i].ts, cseg = meta[i].seg;
+    float s[NCOLS];
+#pragma unroll
+    for (int c = 0; c < NCOLS; ++c) s[c] = (cts > 0 && j == 0) ? carry[c] + T[c] : T[c];
+    for (int it = 1; it < g.W; ++it) {
+#pragma unroll
+      for (int c = 0; c < NCOLS; ++c) s[c] = dppf<0x121>(s[c]) + T[c];  // row_ror:1: lane i reads lane i - 1; after step `it` lane `it` of a group holds the sum of its first it + 1 terms
+    }
+    if (cts + 1 < g.TPC) {
+#pragma unroll
+      for (int c = 0; c < NCOLS; ++c) carry[c] = __shfl(s[c], gbase + g.W - 1, 64);
+    } else {
+      // the four chunk sums sit in lanes k * LPC + W - 1 of the row; row = ((c0 + c1) + c2) + c3 must end up (at least) in the row's OWNER lane 3 * LPC + W - 1.
+      // No LDS round trips (ds_bpermute) on this path: it is a serial latency chain behind every record.
+      float tot[NCOLS];
+      if (g.LPC == 4) {  // rows of 16 lanes = DPP rows: three row_ror:4 steps walk the sum from lane W - 1 to lane 12 + W - 1
+#pragma unroll
+        for (int c = 0; c < NCOLS; ++c) {
+          float u = dppf<0x124>(s[c]) + s[c];
+          u = dppf<0x124>(u) + s[c];
+          tot[c] = dppf<0x124>(u) + s[c];
+        }
+      } else if (g.LPC >= 8) {  // one or two rows per record: the chunk sums through readlane (scalar operands)
+#pragma unroll
+        for (int c = 0; c < NCOLS; ++c) {
+          const float a0 = rlf(s[c], g.W - 1), a1 = rlf(s[c], g.LPC + g.W - 1), a2 = rlf(s[c], 2 * g.LPC + g.W - 1), a3 = rlf(s[c], 3 * g.LPC + g.W - 1);
+          float t0 = ((a0 + a1) + a2) + a3;
+          if (g.LPC == 8) {
+            const float b0 = rlf(s[c], 32 + g.W - 1), b1 = rlf(s[c], 40 + g.W - 1), b2 = rlf(s[c], 48 + g.W - 1), b3 = rlf(s[c], 56 + g.W - 1);
+            const float t1 = ((b0 + b1) + b2) + b3;
+            t0 = lane < 32 ? t0 : t1;
+          }
+          tot[c] = t0;
+        }
+      } else {  // 8 or 16 rows per record (K <= 2048)
+#pragma unroll
+        for (int c = 0; c < NCOLS; ++c) {
+          const float c0 = __shfl(s[c], rbase + g.W - 1, 64), c1 = __shfl(s[c], rbase + g.LPC + g.W - 1, 64);
+          const float c2 = __shfl(s[c], rbase + 2 * g.LPC + g.W - 1, 64), c3 = __shfl(s[c], rbase + 3 * g.LPC + g.W - 1, 64);
+          tot[c] = ((c0 + c1) + c2) + c3;
+        }
+      }
+      // one epilogue call per record group, lane-parallel over its R rows: the owner lane of row rr is rr * lpr + 3 * LPC + W - 1 (owner_off())
+      const int urow = meta[i].unit * jb.rgpu * g.R + meta[i].rgl * g.R;          // first row of the group in the launch's numbering (slot * rows-per-slot + local row)
+      const int lrow = urow - (meta[i].unit / jb.upe) * (jb.upe * jb.rgpu * g.R);  // local row inside the expert slot
+      epi(cseg, urow, min(g.R, jb.nrows - lrow), meta[i].rgl, tot, auxv[i]);
+    }
+    issue(ring[i], meta[i], auxv[i]);
+    if (nrec < 10) MRS_TL2(jb, 4 + nrec);
+    ++nrec;
+  };
   while (more) {
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
-      if (more && meta[i].unit >= 0) {  // wave-uniform
-        const int cts = meta[i].ts, cseg = meta[i].seg;
-        const int sbi = cts * g.W + j;  // index inside the chunk
-        const int sb = p * g.Cs + sbi;
-        const bool live = lane_ok && sbi < g.Cs && sb < g.S;
-        float T[NCOLS];
-        TermCols<TYPE, NCOLS, 0>::run(ring[i], live ? sb : 0, live, act, SEGCOL ? cseg : 0, T);
-        float s[NCOLS];
-#pragma unroll
-        for (int c = 0; c < NCOLS; ++c) s[c] = (cts > 0 && j == 0) ? carry[c] + T[c] : T[c];
-        for (int it = 1; it < g.W; ++it) {
-#pragma unroll
-          for (int c = 0; c < NCOLS; ++c) s[c] = dppf<0x121>(s[c]) + T[c];  // row_ror:1: lane i reads lane i - 1; after step `it` lane `it` of a group holds the sum of its first it + 1 terms
-        }
-        if (cts + 1 < g.TPC) {
-#pragma unroll
-          for (int c = 0; c < NCOLS; ++c) carry[c] = __shfl(s[c], gbase + g.W - 1, 64);
-        } else {
-          float tot[NCOLS];
-#pragma unroll
-          for (int c = 0; c < NCOLS; ++c) {
-            const float c0 = __shfl(s[c], rbase + g.W - 1, 64), c1 = __shfl(s[c], rbase + g.LPC + g.W - 1, 64);
-            const float c2 = __shfl(s[c], rbase + 2 * g.LPC + g.W - 1, 64), c3 = __shfl(s[c], rbase + 3 * g.LPC + g.W - 1, 64);
-            tot[c] = ((c0 + c1) + c2) + c3;
-          }
-          // every lane of a row holds the row's sum; lane rr * lpr is the row's "owner".  One epilogue call per record group, lane-parallel over its R rows
-          const int urow = meta[i].unit * jb.rgpu * g.R + meta[i].rgl * g.R;          // first row of the group in the launch's numbering (slot * rows-per-slot + local row)
-          const int lrow = urow - (meta[i].unit / jb.upe) * (jb.upe * jb.rgpu * g.R);  // local row inside the expert slot
-          epi(cseg, urow, min(g.R, jb.nrows - lrow), meta[i].rgl, tot, auxv[i]);
-        }
-        issue(ring[i], meta[i], auxv[i]);
-        if (nrec < 10) MRS_TL2(jb, 4 + nrec);
-        ++nrec;
-      } else {
-        more = false;
-      }
+      if (i >= nsr) continue;
+      if (!(more && meta[i].unit >= 0)) { more = false; continue; }  // wave-uniform
+      // (two records at a time -- interleaving their integer dots -- was built and measured: the second set of accumulators spills, every launch 15-25 % slower)
+      float T0[NCOLS];
+      terms(i, T0);
+      finish(i, T0);
     }
   }
   MRS_TL2(jb, 14);

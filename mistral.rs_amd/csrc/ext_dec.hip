@@ -285,6 +285,14 @@ template <int EPI> struct Launch {
     // SPEC when a workgroup's weight requests keep its memory pipe busy for microseconds and there is a prologue worth hiding
     bool spec = !a.x_img && total_bytes / (size_t)grid > 96 * 1024;
     { static const int force = [] { const char *e = getenv("MRS_DEC_SPEC"); return e ? atoi(e) : -1; }(); if (force >= 0 && !a.x_img) spec = force != 0; }
+    // ring depth (Job::ring), measured per phase on the MI355X at Llama-3-8B shapes (profiles/round4_decode.md): gate / up (56 records per workgroup) and the
+    // small launches want ONE record ahead (the compute phase of these launches is issue-bound and starts at the prologue's barrier: requests queued behind it
+    // only delay the first record); down_proj (SPEC schedule, 16 records per workgroup of 8-12 KiB) and long streams (lm_head: hundreds of records per
+    // workgroup) keep the full ring
+    { static const int force = [] { const char *e = getenv("MRS_DEC_RING"); return e ? atoi(e) : 0; }();
+      const size_t per_wg = total_bytes / (size_t)grid;
+      const bool deep = per_wg > 768 * 1024 || (spec && NCOLS == 1 && (EPI == EPI_RESID || EPI == EPI_STORE || EPI == EPI_RESID2));
+      a.ring = force > 0 ? force : (deep ? 8 : 1); }
     if (NCOLS > 1 || EPI == EPI_QKV) spec = false;  // the SPEC schedule is built for one column; the QKV launch is small
     int tmask = 0;
     for (int i = 0; i < (EPI == EPI_QKV ? 3 : 1); ++i) tmask |= tmask_of(a.m[i].type);

@@ -117,7 +117,7 @@ struct PlainArgs {
   Mat m;
   const float *x; int ldx; const float *norm_w; float eps;
   float *out; int out_stride;
-  int units, spec;
+  int units, spec, ring;
   unsigned long long *tl;
 };
 template <int NCOLS, bool SPEC>
@@ -128,13 +128,13 @@ __global__ void __launch_bounds__(NT) dec2_plain_kernel(const PlainArgs a) {
   const int tid = tid_opaque(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int K = a.m.k, mode = act_mode_for(a.m.type);
   Job jb{};
-  jb.nseg = 1; jb.rgpu = 1; jb.mat[0] = a.m; jb.nrows = a.m.n; jb.tl = a.tl; jb.sel = nullptr; jb.sel_mode = 1; jb.upe = a.units > 0 ? a.units : 1; jb.ergs = 0;
+  jb.nseg = 1; jb.rgpu = 1; jb.ring = a.ring; jb.mat[0] = a.m; jb.nrows = a.m.n; jb.tl = a.tl; jb.sel = nullptr; jb.sel_mode = 1; jb.upe = a.units > 0 ? a.units : 1; jb.ergs = 0;
   jb.u0 = (int)((long long)blockIdx.x * a.units / gridDim.x); jb.u1 = (int)((long long)(blockIdx.x + 1) * a.units / gridDim.x);
   auto noaux = [](int, int, int) { return NoAux{}; };
   const Geo g = geo_for(K);
   const int lpr = 4 * g.LPC, rr = lane / lpr;
   auto epi = [&](int, int row0, int nvalid, int, const float(&sum)[NCOLS], const NoAux &) {
-    if ((lane & (lpr - 1)) == 0 && rr < nvalid) {
+    if ((lane & (lpr - 1)) == owner_off(g) && rr < nvalid) {
 #pragma unroll
       for (int c = 0; c < NCOLS; ++c) a.out[(size_t)c * a.out_stride + row0 + rr] = sum[c];
     }
@@ -187,6 +187,7 @@ extern "C" int mrs_dec2_gemv(const mrs_dec_mat_c2 *w, const float *x, int ldx, c
   const int grid = a.units < gmax ? a.units : gmax;
   const size_t wg_bytes = (size_t)((a.units + grid - 1) / grid) * g.TPC * dec2::rec_bytes(w->type, g);
   { static int force = -2; if (force == -2) { const char *e = getenv("MRS_DEC2_SPEC"); force = e ? atoi(e) : -1; } a.spec = force >= 0 ? force : (wg_bytes > 96 * 1024 ? 1 : 0); }
+  { static const int r = [] { const char *e = getenv("MRS_DEC2_RING"); return e ? atoi(e) : 0; }(); a.ring = r > 0 ? r : (a.spec ? 8 : 1); }
   const size_t lds = (dec2::act_bytes((int)w->k, b) + 15) & ~(size_t)15;
   if (lds > 158 * 1024) return -2;
   hipStream_t s = (hipStream_t)stream;

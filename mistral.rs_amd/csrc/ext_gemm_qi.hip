@@ -5,22 +5,25 @@
 // (d_w d_x) <integer dot> - (dmin_w d_x) <integer min term>.  Rounds 1-3 ran prompts in a different arithmetic (weights and activations rounded to bf16);
 // this kernel computes the reference's integers EXACTLY on v_mfma_f32_32x32x16_f16 and combines them in the f32 order of the decode engine ("ORD-U",
 // dec_core2.cuh / oracle orc_gemv_engine), so a token's logits and KV pages do not depend on whether it was part of a prompt or decoded:
-//   * the 6-bit sub-block scale is folded INTO the weight operand as an exact small integer in f16: Q4_K  sc (q - 8), |.| <= 504;  Q6_K  two operands
+//   * the 6-bit sub-block scale is folded INTO the weight operand as an exact small integer in f16: Q4_K  sc q <= 945;  Q6_K  two operands
 //     sl (q - 32) and sh (q - 32) with sc = 16 sh + sl, |.| <= 480 / 256.  The activation operand is the Q8_K quant as f16.  Every product and every partial
 //     sum of a superblock is an integer below 2^24, so the f32 accumulator of the matrix core holds the EXACT sum (tests/test_gemm_qi.py holds
 //     v_mfma_f32_32x32x16_f16 to that on adversarial operands); no per-sub-block scale multiply is left on the vector ALU;
-//   * Q4_K: isum = X + 8 Y with Y = sum_j sc_j bsum_j, msum = sum_j m_j bsum_j: two more MFMAs per superblock (K = the 16 run sums of the Q8_K block,
-//     scales duplicated per run), so (float)isum = fma(8, Y, X) and (float)msum = M are single roundings of exact integers -- what (float)int gives;
+//   * Q4_K: the operand is sc q (<= 945); the first and the second eight runs of a superblock go to two accumulators (<= 15.5 M each), (float)isum = XA + XB is
+//     one rounding of the exact integer -- what (float)int gives; msum = sum_j m_j bsum_j is one more MFMA per superblock (K = the 16 run sums of the Q8_K
+//     block, mins duplicated per run);
 //   * per superblock and output ONE f32 term T (the decode engine's expression), terms added left to right inside each of the row's four runs of
 //     superblocks, the four run sums left to right (dec_core2.cuh header).
 // Operands: weights in an MFMA-order copy made at load time (mrs_gemm_qi_repack: per 32-row panel and superblock, every lane's 16 bytes of a piece
 // contiguous: one buffer_load_dwordx4 per lane and piece, straight into registers); activations from mrs_qi_quantize (engine-order RmsNorm + the candle
 // Q8_K quantizer of dec_core2.cuh, then f16 in the operand's k order, slab-major [superblock][token][256]).
-// Tiling: workgroup 256 threads = 4 waves (one per SIMD), tile 128 weight rows x 128 tokens, wave 64 x 64 = 2 x 2 MFMA tiles; per superblock the 128
-// tokens' f16 quants (64 KiB) are staged in LDS (16-byte chunks XOR-swizzled by the token index: conflict-free ds_read_b128 fragments).
+// Tiling: workgroup 512 threads = 8 waves (two per SIMD: one wave's MFMAs run under the other's operand build and fix-up), tile 128 weight rows x 128
+// tokens, wave 32 x 64 = 1 x 2 MFMA tiles; per superblock the 128 tokens' f16 quants (64 KiB) are staged in LDS (16-byte chunks XOR-swizzled by the token
+// index: conflict-free ds_read_b128 fragments), double buffered: superblock s + 1 arrives by LDS-DMA (global_load_lds) while s is multiplied.
 #include "dec_core2.cuh"
 #include <stdio.h>
 #include <stdlib.h>
+#include <algorithm>
 
 namespace mrs {
 namespace qi {
@@ -29,6 +32,7 @@ using namespace mrs::dec2;
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 constexpr int REC_Q4K = 4096 + 512 + 128, REC_Q6K = 8192 + 512 + 128;
 __host__ __device__ constexpr int rec_bytes_qi(int type) { return type == T_Q4_K ? REC_Q4K : REC_Q6K; }
@@ -56,7 +60,7 @@ __global__ void __launch_bounds__(256) qi_repack_kernel(const uint8_t *__restric
   if constexpr (TYPE == T_Q4_K) {
     const uint8_t *b = src + ((size_t)row * S + sb) * 144, *qs = b + 16;
     for (int c = 0; c < 4; ++c) {
-      for (int k = 0; k < 8; ++k) { buf[k] = have ? qs[32 * c + 8 * hf + k] : 0x88; buf[8 + k] = have ? qs[32 * c + 16 + 8 * hf + k] : 0x88; }  // 0x88: q = 8 -> operand 0
+      for (int k = 0; k < 8; ++k) { buf[k] = have ? qs[32 * c + 8 * hf + k] : 0; buf[8 + k] = have ? qs[32 * c + 16 + 8 * hf + k] : 0; }
       *(v4u *)(rec + ((size_t)c * 64 + lane) * 16) = *(const v4u *)buf;
     }
     if (hf == 0) {
@@ -140,234 +144,252 @@ struct GemmArgs {
   const uint8_t *w; unsigned w_bytes; int type, N, K, T;
   const _Float16 *qf; const float *yd; const _Float16 *bsf;
   float *out; int ldo; int accumulate;  // out[t * ldo + n] (+)= row sum
+  float *part; int ksplit;              // ksplit = 4: workgroup z multiplies run z of the row's superblocks only and writes its sum to part[z][t][n]; the reduce kernel combines
 };
 constexpr int TN = 128, TT = 128;                   // workgroup tile: weight rows x tokens
-constexpr int LDS_ACT = TT * 512, LDS_YD = TT * 4, LDS_BS = TT * 48;
-constexpr int LDS_TOTAL = LDS_ACT + LDS_YD + LDS_BS;
+constexpr int GT = 512;                             // 8 waves: 4 (32-row panels) x 2 (64-token halves); two waves per SIMD overlap each other's MFMA and VALU phases
+constexpr int LDS_ACT = TT * 512, LDS_YD = TT * 4, LDS_BS = TT * 32;
+constexpr int LDS_BUF = LDS_ACT + LDS_YD + LDS_BS;  // one superblock of the tile's tokens; two buffers: the next superblock arrives by LDS-DMA during the MFMAs
+constexpr int LDS_TOTAL = 2 * LDS_BUF;
+
+// async global -> LDS copy, 16 / 4 bytes per lane: LDS destination = wave-uniform base + lane * size (the hardware's rule), source address per lane
+#ifndef MRS_GLDS16
+#define MRS_GLDS16(gptr, lbase) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr), (__attribute__((address_space(3))) void *)(lbase), 16, 0, 0)
+#define MRS_GLDS4(gptr, lbase) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr), (__attribute__((address_space(3))) void *)(lbase), 4, 0, 0)
+#endif
+#ifndef MRS_WAIT_VMCNT0
+#define MRS_WAIT_VMCNT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
 
 __device__ __forceinline__ h2 as_h2(unsigned v) { return __builtin_bit_cast(h2, v); }
-__device__ __forceinline__ unsigned as_u(h2 v) { return __builtin_bit_cast(unsigned, v); }
 __device__ __forceinline__ h8 mk_h8(h2 a, h2 b, h2 c, h2 d) { h8 r; r[0] = a[0]; r[1] = a[1]; r[2] = b[0]; r[3] = b[1]; r[4] = c[0]; r[5] = c[1]; r[6] = d[0]; r[7] = d[1]; return r; }
 __device__ __forceinline__ h2 pkfma(h2 x, h2 s, h2 c) { return __builtin_elementwise_fma(x, s, c); }
 // two bytes of a small unsigned integer -> (1024 + b0, 1024 + b1) as f16 (0x6400 = 1024: one unit per mantissa step up to 2047)
 __device__ __forceinline__ h2 magic(unsigned v, unsigned mask) { return as_h2((v & mask) | 0x64006400u); }
 
 template <int TYPE>
-__global__ void __launch_bounds__(256) gemm_qi_kernel(const GemmArgs a) {
+__global__ void __launch_bounds__(GT) gemm_qi_kernel(const GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char *act_s = smem;
-  float *yd_s = (float *)(smem + LDS_ACT);
-  char *bs_s = smem + LDS_ACT + LDS_YD;
   const int tid = tid_opaque(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nn = lane & 31, hf = lane >> 5;
   const int n0 = blockIdx.x * TN, t0 = blockIdx.y * TT;
-  const int wn = wave & 1, wt = wave >> 1;  // the wave's 64-row / 64-token half of the tile
+  const int wn = wave & 3, wt = wave >> 2;  // the wave's 32-row panel / 64-token half of the tile
   const int S = a.K / 256, Cs = (S + 3) / 4;
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, (short)0, (int)a.w_bytes, 0x00020000);
   constexpr int REC = rec_bytes_qi(TYPE), NPC = TYPE == T_Q4_K ? 4 : 8;
   struct WRegs { v4u q[NPC]; v4u hs; unsigned hd; };
-  WRegs wr[2];
-  auto load_w = [&](int sb) {
+  const unsigned panel = (unsigned)((n0 + wn * 32) >> 5);
+  auto load_w = [&](WRegs &wr, int sb) {
+    const unsigned rec = (panel * (unsigned)S + (unsigned)sb) * (unsigned)REC;  // panels past N: out of range -> zeros
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const unsigned panel = (unsigned)((n0 + wn * 64 + nt * 32) >> 5);
-      const unsigned rec = (panel * (unsigned)S + (unsigned)sb) * (unsigned)REC;  // panels past N: out of range -> zeros
+    for (int c = 0; c < NPC; ++c) wr.q[c] = __builtin_amdgcn_raw_buffer_load_b128(rw, rec + (unsigned)(c * 64 + lane) * 16u, 0, 0);
+    wr.hs = __builtin_amdgcn_raw_buffer_load_b128(rw, rec + (unsigned)(NPC * 1024) + (unsigned)nn * 16u, 0, 0);
+    wr.hd = __builtin_amdgcn_raw_buffer_load_b32(rw, rec + (unsigned)(NPC * 1024 + 512) + (unsigned)nn * 4u, 0, 0);
+  };
+  // stage superblock sb of the tile's tokens into buffer `buf` by LDS-DMA.  acts: 128 rows x 32 chunks of 16 B, chunk ch of row tr at position ch ^ (tr & 31);
+  // a DMA instruction fills 1 KiB = 2 rows lane by lane, so lane l of the instruction for rows (2 i, 2 i + 1) fetches chunk (l & 31) ^ (tr & 31) of row
+  // tr = 2 i + (l >> 5).  Rows past T re-read the last token (their outputs are never stored).
+  const int tlast = a.T - 1 - t0;  // last existing row of the tile
+  auto stage = [&](int sb, int buf) {
+    char *base = smem + buf * LDS_BUF;
+    const char *gq = (const char *)a.qf + ((size_t)sb * a.T + t0) * 512;
 #pragma unroll
-      for (int c = 0; c < NPC; ++c) wr[nt].q[c] = __builtin_amdgcn_raw_buffer_load_b128(rw, rec + (unsigned)(c * 64 + lane) * 16u, 0, 0);
-      wr[nt].hs = __builtin_amdgcn_raw_buffer_load_b128(rw, rec + (unsigned)(NPC * 1024) + (unsigned)nn * 16u, 0, 0);
-      wr[nt].hd = __builtin_amdgcn_raw_buffer_load_b32(rw, rec + (unsigned)(NPC * 1024 + 512) + (unsigned)nn * 4u, 0, 0);
+    for (int i = 0; i < 8; ++i) {
+      const int pair = wave * 8 + i;  // rows 2 pair, 2 pair + 1
+      const int tr = 2 * pair + hf, trc = min(tr, tlast);
+      MRS_GLDS16(gq + (size_t)trc * 512 + (((lane & 31) ^ (tr & 31)) << 4), base + pair * 1024);
+    }
+    if (wave < 2) {  // yd: 128 floats = 2 instructions of 64 x 4 B
+      const int tr = wave * 64 + lane;
+      MRS_GLDS4((const char *)a.yd + ((size_t)sb * a.T + t0 + min(tr, tlast)) * 4, base + LDS_ACT + wave * 256);
+    } else if (wave < 6) {  // run sums: 128 rows x 32 B = 4 instructions of 1 KiB
+      const int i = wave - 2, tr = i * 32 + (lane >> 1);
+      MRS_GLDS16((const char *)a.bsf + ((size_t)sb * a.T + t0 + min(tr, tlast)) * 32 + (lane & 1) * 16, base + LDS_ACT + LDS_YD + i * 1024);
     }
   };
-  f16v run[2][2], pend[2][2];
+  f16v run[2], pend[2];
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt)
+  for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
+    for (int v = 0; v < 16; ++v) { run[tt][v] = 0.f; pend[tt][v] = 0.f; }
+  WRegs wr, wnx;
+  const int sb_first = a.ksplit > 1 ? (int)blockIdx.z * ((a.K / 256 + 3) / 4) : 0;
+  if (sb_first < a.K / 256) { load_w(wr, sb_first); stage(sb_first, sb_first & 1); }
+  const int trow = wt * 64 + nn;  // + 32 tt: the token row whose fragment this lane supplies
+  // fragment of run r for this lane: chunk (2 r + hf) ^ (row & 31) of its token row; row & 31 == nn for both token tiles, so the 16 offsets are computed once
+  int aoff[16];
 #pragma unroll
-      for (int v = 0; v < 16; ++v) { run[nt][tt][v] = 0.f; pend[nt][tt][v] = 0.f; }
-  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void *)a.qf, (short)0, (int)((size_t)S * a.T * 512), 0x00020000);
-  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void *)a.yd, (short)0, (int)((size_t)S * a.T * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)a.bsf, (short)0, (int)((size_t)S * a.T * 32), 0x00020000);
-  const int tvalid = min(TT, a.T - t0);  // tokens of this tile that exist
-  for (int sb = 0; sb < S; ++sb) {
-    load_w(sb);
-    __syncthreads();  // every wave has finished reading the previous superblock's tokens
-    // stage the tile's tokens: 128 rows x 32 chunks of 16 B, chunk ch of token row tr at ch ^ (tr & 31)
-    {
-      const unsigned base = (unsigned)(((size_t)sb * a.T + t0) * 512);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int ci = tid + i * 256, tr = ci >> 5, ch = ci & 31;
-        v4u v = v4u{0u, 0u, 0u, 0u};
-        if (tr < tvalid) v = __builtin_amdgcn_raw_buffer_load_b128(rq, base + (unsigned)ci * 16u, 0, 0);
-        *(v4u *)(act_s + tr * 512 + ((ch ^ (tr & 31)) << 4)) = v;
-      }
-      if (tid < TT) yd_s[tid] = tid < tvalid ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ry, (unsigned)(((size_t)sb * a.T + t0 + tid) * 4), 0, 0)) : 0.f;
-      {
-        const int tr = tid >> 1, part = tid & 1;  // 128 rows x 2 halves of 16 B
-        v4u v = v4u{0u, 0u, 0u, 0u};
-        if (tr < tvalid) v = __builtin_amdgcn_raw_buffer_load_b128(rb, (unsigned)(((size_t)sb * a.T + t0 + tr) * 32 + part * 16), 0, 0);
-        *(v4u *)(bs_s + tr * 48 + part * 16) = v;
-      }
-    }
-    __syncthreads();
-    f16v X[2][2], X2[2][2];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+  for (int r = 0; r < 16; ++r) aoff[r] = trow * 512 + (((2 * r + hf) ^ nn) << 4);
+  const int sb_begin = a.ksplit > 1 ? (int)blockIdx.z * Cs : 0, sb_end = a.ksplit > 1 ? min(S, sb_begin + Cs) : S;
+  if (sb_begin >= sb_end) {
+    if (a.ksplit > 1) {  // a run without superblocks contributes +0
+      const int n = n0 + wn * 32 + nn;
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) { X[nt][tt][v] = 0.f; X2[nt][tt][v] = 0.f; }
-    const int trow = wt * 64 + nn;  // + 32 tt: the token row whose fragment this lane supplies
-    auto act_frag = [&](int tt, int run_i) -> h8 {
-      const int tr = trow + 32 * tt, ch = 2 * run_i + hf;
-      return *(const h8 *)(act_s + tr * 512 + ((ch ^ (tr & 31)) << 4));
-    };
-    if constexpr (TYPE == T_Q4_K) {
-      // scales as f16 pairs.  (1024 + q) - 1032 = q - 8 and (q - 8) sc are both exact in f16; a single fma with the addend -1032 sc would not be:
-      // 1032 sc is not an f16 value for odd sc >= 16
-      h2 sc2[2][8];
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const unsigned s01[2] = {wr[nt].hs.x, wr[nt].hs.y};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const _Float16 sj = (_Float16)(float)byte_of(s01[j >> 2], j & 3);
-          sc2[nt][j] = h2{sj, sj};
+        for (int v = 0; v < 16; ++v) {
+          const int t = t0 + wt * 64 + tt * 32 + 8 * (v >> 2) + 4 * hf + (v & 3);
+          if (n < a.N && t < a.T) a.part[((size_t)blockIdx.z * a.T + t) * a.N + n] = 0.f;
         }
-      }
-      const h2 m1032 = h2{(_Float16)(-1032.0f), (_Float16)(-1032.0f)};
-      auto wop = [&](unsigned v, h2 sc) -> h2 { return (magic(v, 0x000F000Fu) + m1032) * sc; };
+    }
+    return;
+  }
+  for (int sb = sb_begin; sb < sb_end; ++sb) {
+    const int buf = sb & 1;
+    MRS_WAIT_VMCNT0();  // this wave's DMA pieces of superblock sb (and the weights of sb) have landed
+    __syncthreads();    // everyone's have, and every wave has finished reading the other buffer
+    if (sb + 1 < sb_end) { stage(sb + 1, buf ^ 1); load_w(wnx, sb + 1); }
+    const char *act_s = smem + buf * LDS_BUF;
+    const float *yd_s = (const float *)(act_s + LDS_ACT);
+    const char *bs_s = act_s + LDS_ACT + LDS_YD;
+    f16v X[2], X2[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) { X[tt][v] = 0.f; X2[tt][v] = 0.f; }
+    auto act_frag = [&](int tt, int run_i) -> h8 { return *(const h8 *)(act_s + aoff[run_i] + tt * (32 * 512)); };
+    const bool cfirst = (sb % Cs) == 0;
+    const f2 keep2 = cfirst ? f2{0.f, 0.f} : f2{1.f, 1.f};  // the first term of a run of superblocks starts its sum (0 * run + t), the others add (1 * run + t: exact)
+    if constexpr (TYPE == T_Q4_K) {
+      // operand = sc q as an exact integer in f16 from ONE packed fma per pair of weights: (1024 + q) sc - 1024 sc for a nibble at bits 3:0 of a half-word,
+      // (1024 + 16 q) (sc / 16) - 64 sc for one at bits 7:4 (1024 sc, 64 sc and sc / 16 are exact in f16; 1032 sc, which q - 8 would need, is not).  With the
+      // unsigned q a superblock's sum can reach 30.9 M > 2^24, so runs 0 .. 7 and 8 .. 15 go to two accumulators (<= 15.5 M each, exact) and
+      // (float)isum = XA + XB is one rounding of the exact integer.
+      unsigned mg = 0x64006400u;
+      MRS_OPAQUE_TID(mg);  // keeps the constant in a VGPR: v_and_or_b32 takes one literal
+      auto lo4 = [&](unsigned v, h2 sc, h2 off) -> h2 { return pkfma(as_h2((v & 0x000F000Fu) | mg), sc, off); };
+      auto hi4 = [&](unsigned v, h2 sc16, h2 off) -> h2 { return pkfma(as_h2((v & 0x00F000F0u) | mg), sc16, off); };
+      const unsigned s01[2] = {wr.hs.x, wr.hs.y};
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
+        const float sa = (float)byte_of(s01[c >> 1], 2 * (c & 1)), sb2 = (float)byte_of(s01[c >> 1], 2 * (c & 1) + 1);
+        const h2 sl = h2{(_Float16)sa, (_Float16)sa}, ol = h2{(_Float16)(-1024.0f * sa), (_Float16)(-1024.0f * sa)};
+        const h2 sh = h2{(_Float16)(sb2 * 0.0625f), (_Float16)(sb2 * 0.0625f)}, oh = h2{(_Float16)(-64.0f * sb2), (_Float16)(-64.0f * sb2)};
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          h8 wlo[2], whi[2];
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt) {
-            const unsigned d0 = h == 0 ? wr[nt].q[c].x : wr[nt].q[c].z, d1 = h == 0 ? wr[nt].q[c].y : wr[nt].q[c].w;
-            const h2 sl = sc2[nt][2 * c], sh = sc2[nt][2 * c + 1];
-            wlo[nt] = mk_h8(wop(d0, sl), wop(d0 >> 8, sl), wop(d1, sl), wop(d1 >> 8, sl));
-            whi[nt] = mk_h8(wop(d0 >> 4, sh), wop(d0 >> 12, sh), wop(d1 >> 4, sh), wop(d1 >> 12, sh));
-          }
+          const unsigned d0 = h == 0 ? wr.q[c].x : wr.q[c].z, d1 = h == 0 ? wr.q[c].y : wr.q[c].w;
+          const unsigned e0 = d0 >> 8, e1 = d1 >> 8;
+          const h8 wlo = mk_h8(lo4(d0, sl, ol), lo4(e0, sl, ol), lo4(d1, sl, ol), lo4(e1, sl, ol));
+          const h8 whi = mk_h8(hi4(d0, sh, oh), hi4(e0, sh, oh), hi4(d1, sh, oh), hi4(e1, sh, oh));
 #pragma unroll
           for (int tt = 0; tt < 2; ++tt) {
-            const h8 alo = act_frag(tt, 4 * c + h), ahi = act_frag(tt, 4 * c + 2 + h);
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-              X[nt][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, wlo[nt], X[nt][tt], 0, 0, 0);
-              X[nt][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, whi[nt], X[nt][tt], 0, 0, 0);
+            if (c < 2) {
+              X[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(act_frag(tt, 4 * c + h), wlo, X[tt], 0, 0, 0);
+              X[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(act_frag(tt, 4 * c + 2 + h), whi, X[tt], 0, 0, 0);
+            } else {
+              X2[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(act_frag(tt, 4 * c + h), wlo, X2[tt], 0, 0, 0);
+              X2[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(act_frag(tt, 4 * c + 2 + h), whi, X2[tt], 0, 0, 0);
             }
           }
         }
       }
-      // Y = sum_run sc_{run / 2} bsum_run, M = sum_run m_{run / 2} bsum_run: operand slot (hf, jj) <-> run 8 hf + jj -> sub-block 4 hf + jj / 2
+      // M = sum_run m_{run / 2} bsum_run: operand slot (hf, jj) <-> run 8 hf + jj -> sub-block 4 hf + jj / 2
+      const unsigned mw = hf ? wr.hs.w : wr.hs.z;
+      h8 wm;
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const unsigned sw = hf ? wr[nt].hs.y : wr[nt].hs.x, mw = hf ? wr[nt].hs.w : wr[nt].hs.z;
-        h8 ws, wm;
+      for (int k = 0; k < 4; ++k) { const _Float16 mk = (_Float16)(float)byte_of(mw, k); wm[2 * k] = mk; wm[2 * k + 1] = mk; }
+      const float d = half_bits_to_float((uint16_t)(wr.hd & 0xffff)), dmin = half_bits_to_float((uint16_t)(wr.hd >> 16));
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const _Float16 sk = (_Float16)(float)byte_of(sw, k), mk = (_Float16)(float)byte_of(mw, k);
-          ws[2 * k] = sk; ws[2 * k + 1] = sk; wm[2 * k] = mk; wm[2 * k + 1] = mk;
-        }
-        const float d = half_bits_to_float((uint16_t)(wr[nt].hd & 0xffff)), dmin = half_bits_to_float((uint16_t)(wr[nt].hd >> 16));
+      for (int tt = 0; tt < 2; ++tt) {
+        const h8 bsf = *(const h8 *)(bs_s + (trow + 32 * tt) * 32 + hf * 16);
+        f16v zero;
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-          const h8 bsf = *(const h8 *)(bs_s + (trow + 32 * tt) * 48 + hf * 16);
-          f16v zero;
+        for (int v = 0; v < 16; ++v) zero[v] = 0.f;
+        const f16v M = __builtin_amdgcn_mfma_f32_32x32x16_f16(bsf, wm, zero, 0, 0, 0);
 #pragma unroll
-          for (int v = 0; v < 16; ++v) zero[v] = 0.f;
-          const f16v Y = __builtin_amdgcn_mfma_f32_32x32x16_f16(bsf, ws, zero, 0, 0, 0);
-          const f16v M = __builtin_amdgcn_mfma_f32_32x32x16_f16(bsf, wm, zero, 0, 0, 0);
+        for (int q4 = 0; q4 < 4; ++q4) {  // two outputs per instruction (v_pk_*_f32: the same IEEE operations per lane)
+          const float4 y4 = *(const float4 *)(yd_s + wt * 64 + tt * 32 + 8 * q4 + 4 * hf);
 #pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) {
-            const float4 y4 = *(const float4 *)(yd_s + wt * 64 + tt * 32 + 8 * q4 + 4 * hf);
-            const float ydv[4] = {y4.x, y4.y, y4.z, y4.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const int v = 4 * q4 + k;
-              const float If = fmaf(8.0f, Y[v], X[nt][tt][v]);  // (float)isum: one rounding of the exact integer X + 8 Y
-              const float t = fmaf(d * ydv[k], If, -((dmin * ydv[k]) * M[v]));
-              run[nt][tt][v] = (sb % Cs) == 0 ? t : run[nt][tt][v] + t;
-            }
+          for (int k = 0; k < 4; k += 2) {
+            const int v = 4 * q4 + k;
+            const f2 yd2 = k == 0 ? f2{y4.x, y4.y} : f2{y4.z, y4.w};
+            const f2 If = f2{X[tt][v], X[tt][v + 1]} + f2{X2[tt][v], X2[tt][v + 1]};  // (float)isum: one rounding of the exact integer
+            const f2 mm = (f2{dmin, dmin} * yd2) * f2{M[v], M[v + 1]};
+            const f2 t = __builtin_elementwise_fma(f2{d, d} * yd2, If, -mm);
+            const f2 r = __builtin_elementwise_fma(f2{run[tt][v], run[tt][v + 1]}, keep2, t);  // run * 1 + t, or (first superblock of a run) run * 0 + t
+            run[tt][v] = r[0]; run[tt][v + 1] = r[1];
           }
         }
       }
     } else {  // Q6_K
+      unsigned mg = 0x64006400u;
+      MRS_OPAQUE_TID(mg);
+      auto b2 = [&](unsigned v) -> h2 { return as_h2((v & 0x00FF00FFu) | mg); };  // (1024 + u0, 1024 + u1)
 #pragma unroll
       for (int g = 0; g < 8; ++g) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {  // run 2 g + h
-          h8 wl[2], wh[2];
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt) {
-            const unsigned d0 = h == 0 ? wr[nt].q[g].x : wr[nt].q[g].z, d1 = h == 0 ? wr[nt].q[g].y : wr[nt].q[g].w;
-            const int r = 2 * g + h;
-            const unsigned scw = r < 4 ? wr[nt].hs.x : r < 8 ? wr[nt].hs.y : r < 12 ? wr[nt].hs.z : wr[nt].hs.w;
-            const int sc = sbyte_of(scw, r & 3), sli = sc & 15, shi = sc >> 4;  // sc = 16 shi + sli
-            const _Float16 slf = (_Float16)(float)sli, shf = (_Float16)(float)shi;
-            const h2 sl = h2{slf, slf}, sh = h2{shf, shf};
-            const h2 ol = h2{(_Float16)(-1056.0f), (_Float16)(-1056.0f)} * sl, oh = h2{(_Float16)(-1056.0f), (_Float16)(-1056.0f)} * sh;  // -(1024 + 32) s: exact
-            const h2 p0 = magic(d0, 0x00FF00FFu), p1 = magic(d0 >> 8, 0x00FF00FFu), p2 = magic(d1, 0x00FF00FFu), p3 = magic(d1 >> 8, 0x00FF00FFu);
-            wl[nt] = mk_h8(pkfma(p0, sl, ol), pkfma(p1, sl, ol), pkfma(p2, sl, ol), pkfma(p3, sl, ol));
-            wh[nt] = mk_h8(pkfma(p0, sh, oh), pkfma(p1, sh, oh), pkfma(p2, sh, oh), pkfma(p3, sh, oh));
-          }
+          const unsigned d0 = h == 0 ? wr.q[g].x : wr.q[g].z, d1 = h == 0 ? wr.q[g].y : wr.q[g].w;
+          const int r = 2 * g + h;
+          const unsigned scw = r < 4 ? wr.hs.x : r < 8 ? wr.hs.y : r < 12 ? wr.hs.z : wr.hs.w;
+          const int sc = sbyte_of(scw, r & 3), sli = sc & 15, shi = sc >> 4;  // sc = 16 shi + sli
+          const float slf = (float)sli, shf = (float)shi;
+          // (1024 + u) s - 1056 s = (u - 32) s = (q - 32) s in one fma: 1056 s is an f16 value for |s| <= 15 (a multiple of 8 below 16384)
+          const h2 sl = h2{(_Float16)slf, (_Float16)slf}, sh = h2{(_Float16)shf, (_Float16)shf};
+          const h2 ol = h2{(_Float16)(-1056.0f * slf), (_Float16)(-1056.0f * slf)}, oh = h2{(_Float16)(-1056.0f * shf), (_Float16)(-1056.0f * shf)};
+          const h2 p0 = b2(d0), p1 = b2(d0 >> 8), p2 = b2(d1), p3 = b2(d1 >> 8);
+          const h8 wl = mk_h8(pkfma(p0, sl, ol), pkfma(p1, sl, ol), pkfma(p2, sl, ol), pkfma(p3, sl, ol));
+          const h8 wh = mk_h8(pkfma(p0, sh, oh), pkfma(p1, sh, oh), pkfma(p2, sh, oh), pkfma(p3, sh, oh));
 #pragma unroll
           for (int tt = 0; tt < 2; ++tt) {
-            const h8 af = act_frag(tt, 2 * g + h);
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-              X[nt][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, wl[nt], X[nt][tt], 0, 0, 0);
-              X2[nt][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, wh[nt], X2[nt][tt], 0, 0, 0);
-            }
+            const h8 af = act_frag(tt, r);
+            X[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, wl, X[tt], 0, 0, 0);
+            X2[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, wh, X2[tt], 0, 0, 0);
           }
         }
       }
+      const float d = half_bits_to_float((uint16_t)(wr.hd & 0xffff));
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const float d = half_bits_to_float((uint16_t)(wr[nt].hd & 0xffff));
+      for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const float4 y4 = *(const float4 *)(yd_s + wt * 64 + tt * 32 + 8 * q4 + 4 * hf);
 #pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) {
-            const float4 y4 = *(const float4 *)(yd_s + wt * 64 + tt * 32 + 8 * q4 + 4 * hf);
-            const float ydv[4] = {y4.x, y4.y, y4.z, y4.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const int v = 4 * q4 + k;
-              const float If = fmaf(16.0f, X2[nt][tt][v], X[nt][tt][v]);  // (float)isum
-              const float t = (d * ydv[k]) * If;
-              run[nt][tt][v] = (sb % Cs) == 0 ? t : run[nt][tt][v] + t;
-            }
+          for (int k = 0; k < 4; k += 2) {
+            const int v = 4 * q4 + k;
+            const f2 yd2 = k == 0 ? f2{y4.x, y4.y} : f2{y4.z, y4.w};
+            const f2 If = __builtin_elementwise_fma(f2{16.0f, 16.0f}, f2{X2[tt][v], X2[tt][v + 1]}, f2{X[tt][v], X[tt][v + 1]});  // (float)isum
+            const f2 t = (f2{d, d} * yd2) * If;
+            const f2 r = __builtin_elementwise_fma(f2{run[tt][v], run[tt][v + 1]}, keep2, t);
+            run[tt][v] = r[0]; run[tt][v + 1] = r[1];
           }
-      }
+        }
     }
-    if ((sb + 1) % Cs == 0 || sb + 1 == S) {  // a run of superblocks ends: its sum joins the row's left-to-right combination
+    if ((sb + 1) % Cs == 0 || sb + 1 == sb_end) {  // a run of superblocks ends: its sum joins the row's left-to-right combination
       const bool first = sb < Cs;
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
+      for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-          for (int v = 0; v < 16; ++v) pend[nt][tt][v] = first ? run[nt][tt][v] : pend[nt][tt][v] + run[nt][tt][v];
+        for (int v = 0; v < 16; ++v) pend[tt][v] = first ? run[tt][v] : pend[tt][v] + run[tt][v];
     }
+    if (sb + 1 < sb_end) wr = wnx;
   }
-  // runs that do not exist (S < 4 chunks) add +0: nothing to do.  Store: lane holds column n, rows t = 8 (v / 4) + 4 hf + v % 4 of each MFMA tile
+  // store: lane holds column n, rows t = 8 (v / 4) + 4 hf + v % 4 of each MFMA tile
+  const int n = n0 + wn * 32 + nn;
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const int n = n0 + wn * 64 + nt * 32 + nn;
+  for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int t = t0 + wt * 64 + tt * 32 + 8 * (v >> 2) + 4 * hf + (v & 3);
-        if (n < a.N && t < a.T) {
+    for (int v = 0; v < 16; ++v) {
+      const int t = t0 + wt * 64 + tt * 32 + 8 * (v >> 2) + 4 * hf + (v & 3);
+      if (n < a.N && t < a.T) {
+        if (a.ksplit > 1) a.part[((size_t)blockIdx.z * a.T + t) * a.N + n] = run[tt][v];  // one run per workgroup: its sum, combined by gemm_qi_reduce_kernel
+        else {
           float *o = a.out + (size_t)t * a.ldo + n;
-          *o = a.accumulate ? *o + pend[nt][tt][v] : pend[nt][tt][v];
+          *o = a.accumulate ? *o + pend[tt][v] : pend[tt][v];
         }
       }
-  }
+    }
+}
+// out[t][n] (+)= ((c0 + c1) + c2) + c3 of the four run sums (the row combination of ORD-U)
+__global__ void __launch_bounds__(256) gemm_qi_reduce_kernel(const float *__restrict__ part, float *__restrict__ out, int T, int N, int ldo, int accumulate) {
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4, tot = (size_t)T * N;
+  if (i >= tot) return;
+  const float4 c0 = *(const float4 *)(part + i), c1 = *(const float4 *)(part + tot + i), c2 = *(const float4 *)(part + 2 * tot + i), c3 = *(const float4 *)(part + 3 * tot + i);
+  float4 r = make_float4(((c0.x + c1.x) + c2.x) + c3.x, ((c0.y + c1.y) + c2.y) + c3.y, ((c0.z + c1.z) + c2.z) + c3.z, ((c0.w + c1.w) + c2.w) + c3.w);
+  const size_t t = i / N, n = i % N;  // N % 4 == 0: the four values share a row
+  float4 *o = (float4 *)(out + t * ldo + n);
+  if (accumulate) { const float4 old = *o; r.x = old.x + r.x; r.y = old.y + r.y; r.z = old.z + r.z; r.w = old.w + r.w; }
+  *o = r;
 }
 
 }  // namespace qi
@@ -416,7 +438,15 @@ extern "C" int mrs_qi_quantize(const float *x, const float *x2, int ldx, const f
   return 0;
 }
 // out[t * ldo + n] (+)= W[n] . act[t] for t < T, n < N in the decode engine's arithmetic and f32 order.  w_qi: mrs_gemm_qi_repack output; act: mrs_qi_quantize output.
+// workspace for the split launch of GEMMs with few workgroups (N * T small): 4 x T x N floats
+extern "C" size_t mrs_gemm_qi_workspace_bytes(int T, int max_n_split) { return (size_t)4 * (size_t)T * (size_t)max_n_split * 4; }
+extern "C" int mrs_gemm_qi_ws(const void *w_qi, int type, int N, int K, const void *act, int T, float *out, int ldo, int accumulate, void *workspace, size_t workspace_bytes,
+                              void *stream);
 extern "C" int mrs_gemm_qi(const void *w_qi, int type, int N, int K, const void *act, int T, float *out, int ldo, int accumulate, void *stream) {
+  return mrs_gemm_qi_ws(w_qi, type, N, K, act, T, out, ldo, accumulate, nullptr, 0, stream);
+}
+extern "C" int mrs_gemm_qi_ws(const void *w_qi, int type, int N, int K, const void *act, int T, float *out, int ldo, int accumulate, void *workspace, size_t workspace_bytes,
+                              void *stream) {
   if (!w_qi || !act || !out || !qi::qi_type(type) || N <= 0 || T <= 0 || K <= 0 || K % 256) return -1;
   qi::GemmArgs a{};
   a.w = (const uint8_t *)w_qi; a.w_bytes = (unsigned)qi::qi_tensor_bytes(type, N, K); a.type = type; a.N = N; a.K = K; a.T = T;
@@ -424,9 +454,14 @@ extern "C" int mrs_gemm_qi(const void *w_qi, int type, int N, int K, const void 
   qi_split((void *)act, T, K, &qf, &yd, &bsf);
   if ((size_t)(K / 256) * T * 512 >= 0x7fffffffull || qi::qi_tensor_bytes(type, N, K) >= 0xffffff00ull) return -2;
   a.qf = qf; a.yd = yd; a.bsf = bsf; a.out = out; a.ldo = ldo; a.accumulate = accumulate;
-  const dim3 grid((N + qi::TN - 1) / qi::TN, (T + qi::TT - 1) / qi::TT);
-  if (type == T_Q4_K) { auto kern = qi::gemm_qi_kernel<T_Q4_K>; lds_attr_once((const void *)kern, 158 * 1024); hipLaunchKernelGGL(kern, grid, dim3(256), qi::LDS_TOTAL, (hipStream_t)stream, a); }
-  else { auto kern = qi::gemm_qi_kernel<T_Q6_K>; lds_attr_once((const void *)kern, 158 * 1024); hipLaunchKernelGGL(kern, grid, dim3(256), qi::LDS_TOTAL, (hipStream_t)stream, a); }
+  dim3 grid((N + qi::TN - 1) / qi::TN, (T + qi::TT - 1) / qi::TT);
+  // few workgroups (o_proj / down_proj of a 512-token prompt: 128): one workgroup per run of superblocks, then the reduce -- the same additions in the same order
+  static const int split_max = [] { const char *e = getenv("MRS_GEMM_QI_SPLIT_BELOW"); return e ? atoi(e) : 200; }();
+  a.ksplit = 1; a.part = nullptr;
+  if ((int)(grid.x * grid.y) < split_max && K / 256 >= 4 && N % 4 == 0 && workspace && workspace_bytes >= (size_t)4 * T * N * 4) { a.ksplit = 4; a.part = (float *)workspace; grid.z = 4; }
+  if (type == T_Q4_K) { auto kern = qi::gemm_qi_kernel<T_Q4_K>; lds_attr_once((const void *)kern, 158 * 1024); hipLaunchKernelGGL(kern, grid, dim3(qi::GT), qi::LDS_TOTAL, (hipStream_t)stream, a); }
+  else { auto kern = qi::gemm_qi_kernel<T_Q6_K>; lds_attr_once((const void *)kern, 158 * 1024); hipLaunchKernelGGL(kern, grid, dim3(qi::GT), qi::LDS_TOTAL, (hipStream_t)stream, a); }
+  if (a.ksplit > 1) hipLaunchKernelGGL(qi::gemm_qi_reduce_kernel, dim3((unsigned)(((size_t)T * N / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a.part, out, T, N, ldo, accumulate);
   return 0;
 }
 
@@ -444,7 +479,7 @@ __global__ void __launch_bounds__(256) prefill_attn_exact_kernel(const dec::Attn
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int HD = 128;
   const int tid = tid_opaque(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kvh = blockIdx.x, t = blockIdx.y;
+  const int kvh = blockIdx.x, t = (int)gridDim.y - 1 - (int)blockIdx.y;  // longest contexts first
   const int ms = a.max_splits;
   float *po = (float *)smem;                       // [G][ms][128]
   float *pm = po + (size_t)G * ms * HD, *pl = pm + G * ms;  // [G][ms]
@@ -481,7 +516,7 @@ __global__ void __launch_bounds__(256) prefill_attn_exact_kernel(const dec::Attn
 // sequence's row; out f32 [T][num_heads * 128].  max_context_len = the model's (it fixes the split length exactly as in mrs_dec_attention).
 extern "C" int mrs_prefill_attention_exact(const float *q, const void *k_cache, const void *v_cache, const uint32_t *block_table, const uint32_t *context_lens, float *out,
                                            int T, int num_heads, int num_kv_heads, int head_size, int block_size, int q_stride, int kv_block_stride, int kv_head_stride,
-                                           float scale, int max_context_len, int kv_dtype, int sliding_window, void *stream) {
+                                           float scale, int max_context_len, int kv_dtype, int sliding_window, int max_prompt_ctx, void *stream) {
   if (!q || !out || head_size != 128 || block_size != 32 || T <= 0 || num_kv_heads <= 0 || num_heads % num_kv_heads || (kv_dtype != 0 && kv_dtype != 1)) return -1;
   const int G = num_heads / num_kv_heads;
   if (G != 1 && G != 2 && G != 4 && G != 8) return -1;
@@ -491,8 +526,10 @@ extern "C" int mrs_prefill_attention_exact(const float *q, const void *k_cache, 
   a.kv_block_stride = kv_block_stride; a.kv_head_stride = kv_head_stride; a.num_seqs = T; a.scale = scale; a.window = sliding_window > 0 ? sliding_window : 0;
   const int nblk = (max_context_len + 31) / 32;
   a.bpw = nblk <= 64 ? 1 : (nblk + 63) / 64;  // == mrs_dec_attention
-  a.max_splits = 64;
-  const size_t lds = ((size_t)G * 64 * 128 + 2 * (size_t)G * 64 + 4 * ((size_t)G * 128 + (size_t)G * 32)) * 4;
+  // partials kept in LDS: as many splits as the longest context of this prompt needs (<= 64 by the rule above); fewer splits = more workgroups per CU
+  const int need_ctx = max_prompt_ctx > 0 && max_prompt_ctx < max_context_len ? max_prompt_ctx : max_context_len;
+  a.max_splits = std::max(1, std::min(64, (((need_ctx + 31) / 32) + a.bpw - 1) / a.bpw));
+  const size_t lds = ((size_t)G * a.max_splits * 128 + 2 * (size_t)G * a.max_splits + 4 * ((size_t)G * 128 + (size_t)G * 32)) * 4;
   if (lds > 158 * 1024) return -2;
   const dim3 grid(num_kv_heads, T);
   hipStream_t s = (hipStream_t)stream;

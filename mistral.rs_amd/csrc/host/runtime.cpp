@@ -507,7 +507,7 @@ class Llama {
     b += align(t * nkv * 4) * 2;      // k, v
     b += align(t * ff * 4) * 3;       // gate, up, act
     b += align((pad_to((int)d, MATRIX_ROW_PADDING) / 32) * 36);  // Q8_1 scratch of the last-token lm_head GEMV
-    b += align(mrs_qi_act_bytes(T, (int)std::max(std::max(d, nq), ff)));  // exact prompt path: Q8_K operands of T rows (f16 quants, scales, run sums)
+    b += align(mrs_qi_act_bytes(T, (int)std::max(std::max(d, nq), ff))) + align(mrs_gemm_qi_workspace_bytes(T, (int)std::max(d, nq)));  // exact prompt path: Q8_K operands of T rows (f16 quants, scales, run sums) + run sums of split launches
     if (T > prefill_big_min()) b += align(t * std::max(std::max(d, nq), ff) * 2) + align(mrs_gemm_q_bf16_workspace_bytes(T)) + align(t * ff * 2);  // bf16 activations + split-K partials + act(gate)*up slabs of the fused gate/up GEMM
     if (c.num_experts > 0) {  // MoE FFN of the prompt: routes = T * top_k rows in expert-sorted order
       const size_t tk = (size_t)std::max(1, (int)c.num_experts_per_tok), r = t * tk, E = (size_t)c.num_experts;
@@ -584,14 +584,14 @@ class Llama {
     return dlm_head.planes != nullptr;
   }
   int prefill_exact(const mrs_llama_prefill_args &pa, int T, float *h, float *q, float *k, float *v, float *attn, float *g, float *u, float *act, void *qact,
-                    hipStream_t s) const {
+                    void *qws, size_t qws_bytes, hipStream_t s) const {
     const int d = cfg.hidden_size, hd = cfg.head_dim, nq = cfg.num_heads * hd, nkv = cfg.num_kv_heads * hd, ff = cfg.intermediate_size;
     const int bs = cfg.block_size, kvh = cfg.num_kv_heads, kvd = cfg.kv_f16 ? 0 : 1;
     const int eff_max = std::min(cfg.max_blocks_per_seq * bs, cfg.max_context_len);
     const int64_t st = (int64_t)(intptr_t)s;
     auto lin = [&](const GgufMatMul &m, int N, int K, float *out, int acc) -> int {
       const QTensor *w = m.get_qtensor();
-      return mrs_gemm_qi(w->qi, w->dtype, N, K, qact, T, out, N, acc, s) ? fail("prefill (exact): mrs_gemm_qi refused ggml dtype %d (N=%d K=%d)", w->dtype, N, K) : 0;
+      return mrs_gemm_qi_ws(w->qi, w->dtype, N, K, qact, T, out, N, acc, N <= std::max(d, nq) ? qws : nullptr, qws_bytes, s) ? fail("prefill (exact): mrs_gemm_qi refused ggml dtype %d (N=%d K=%d)", w->dtype, N, K) : 0;
     };
     if (wte->embedding_forward_raw(pa.token_ids, T, h, s)) return -1;
     for (size_t li = 0; li < blocks.size(); ++li) {
@@ -602,7 +602,7 @@ class Llama {
                                  cfg.rot_dim / 2, cfg.max_context_len, cfg.num_heads, cfg.num_kv_heads, nq, nkv, 2, st);
       reshape_and_cache(k, v, bl.key_cache, bl.value_cache, (int64_t *)pa.slot_mapping, T, cfg.num_kv_heads, hd, bs, 8, nkv, nkv, s, 2, kvd == 1 ? 1 : 0, nullptr, nullptr);
       if (mrs_prefill_attention_exact(q, bl.key_cache, bl.value_cache, pa.block_tables, pa.context_lens, attn, T, cfg.num_heads, kvh, hd, bs, nq, kvh * hd * bs, hd * bs,
-                                      1.0f / sqrtf((float)hd), eff_max, kvd, cfg.sliding_window, s))
+                                      1.0f / sqrtf((float)hd), eff_max, kvd, cfg.sliding_window, pa.start_pos + T, s))
         return fail("prefill (exact): attention refused the shape");
       if (mrs_qi_quantize(attn, nullptr, nq, nullptr, 0.f, T, nq, qact, nullptr, s) || lin(*bl.o_proj, d, nq, h, 1)) return -1;
       if (mrs_qi_quantize(h, nullptr, d, bl.post_attention_layernorm, cfg.rms_eps, T, d, qact, nullptr, s)) return -1;
@@ -629,7 +629,9 @@ class Llama {
     float *g = (float *)take(t * ff * 4), *u = (float *)take(t * ff * 4), *act = (float *)take(t * ff * 4);
     if (prefill_exact_ok()) {
       void *qact = take(mrs_qi_act_bytes(T, std::max(std::max(d, nq), ff)));
-      return prefill_exact(pa, T, h, q, k, v, attn, g, u, act, qact, s);
+      const size_t qws_bytes = mrs_gemm_qi_workspace_bytes(T, std::max(d, nq));
+      void *qws = take(qws_bytes);
+      return prefill_exact(pa, T, h, q, k, v, attn, g, u, act, qact, qws, qws_bytes, s);
     }
     MoePrefillBufs moe{};
     if (cfg.num_experts > 0) {

@@ -325,6 +325,9 @@ extern "C" inline __bf16 __truncsfbf2(float f) {
 #define __builtin_amdgcn_sched_group_barrier(MASK, SIZE, SYNC) ((void)0) /* instruction-order hint only */
 #define __builtin_amdgcn_sched_barrier(MASK) ((void)0)                  /* instruction-order hint only */
 #define MRS_OPAQUE_TID(t) ((void)0)
+// LDS-DMA (global_load_lds): LDS destination = wave-uniform base + lane * size, source address per lane; synchronous here
+#define MRS_GLDS16(gptr, lbase) memcpy((char *)(lbase) + (hiphost::linear_tid() & 63) * 16, (const void *)(gptr), 16)
+#define MRS_GLDS4(gptr, lbase) memcpy((char *)(lbase) + (hiphost::linear_tid() & 63) * 4, (const void *)(gptr), 4)
 #define MRS_WAIT_VMCNT0() ((void)0)                                     /* product code: s_waitcnt vmcnt(0) */
 #define __builtin_amdgcn_fence(ORDER, SCOPE) ((void)0)                  /* one workgroup runs at a time: nothing to order */
 #define __builtin_amdgcn_s_sleep(N) ((void)0)

@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--old", action="store_true")
     ap.add_argument("--phases", default="qkv,o,gate_up,down4,down6,lm_head")
     ap.add_argument("--v2", action="store_true", help="time the round-4 core's plain launcher (mrs_dec2_gemv) on one tensor of each phase's bytes")
+    ap.add_argument("--timeline", action="store_true", help="instead of timing: one cold launch per phase with the s_memrealtime stamps of dec_core2.cuh (MRS_TL2), medians per wave group")
     ap.add_argument("--hot", action="store_true", help="two rotating buffers per phase, replayed 8 x inside the graph: the weights stay in the 256 MiB Infinity Cache")
     a = ap.parse_args()
     import torch
@@ -127,6 +128,30 @@ def main():
             inst = mk(len(insts))
             insts.append(inst)
             total += inst[3]
+        if a.timeline:
+            import numpy as np
+            L.mrs_dec_timeline.argtypes = [C.c_void_p, C.c_int]
+            tl = torch.zeros(256 * 8 * 16, dtype=torch.int64, device=dev)
+            stc = torch.cuda.current_stream().cuda_stream
+            for i, inst in enumerate(insts[:6]):
+                L.mrs_dec_timeline(tl.data_ptr() if i == 5 else None, 1)
+                assert inst[1](stc) == 0
+                torch.cuda.synchronize()
+            L.mrs_dec_timeline(None, 0)
+            t = tl.cpu().numpy().reshape(256, 8, 16).astype(np.float64)
+            used = t[:, :, 0] > 0
+            t0 = t[:, :, 0][used].min()
+            rel = (t - t0) / 100.0
+
+            def med(sel, i):
+                v = rel[:, sel, i][t[:, sel, i] > 0]
+                return (round(float(np.median(v)), 2), round(float(v.max()), 2)) if v.size else None
+            for nm, sel in (("waves 0-3", slice(0, 4)), ("waves 4-7", slice(4, 8))):
+                print(name, nm, "(median, max us): entry", med(sel, 0), "issued", med(sel, 1), "prologue", med(sel, 2), "barrier", med(sel, 3), "rec1", med(sel, 4), "rec2", med(sel, 5),
+                      "rec3", med(sel, 6), "rec4", med(sel, 7), "end", med(sel, 14), flush=True)
+            del insts
+            torch.cuda.empty_cache()
+            continue
         for which in (("new", 1),) + ((("old", 2),) if a.old else ()):
             fns = [inst[which[1]] for inst in insts] * (8 if a.hot else 1)
             for f in fns:

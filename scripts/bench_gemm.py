@@ -34,13 +34,14 @@ def main():
                 L.mrs_qi_act_bytes.restype = C.c_size_t; L.mrs_qi_act_bytes.argtypes = [C.c_int, C.c_int]
                 L.mrs_gemm_qi_repack.argtypes = [C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p]
                 L.mrs_qi_quantize.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
-                L.mrs_gemm_qi.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+                L.mrs_gemm_qi_ws.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
                 st = torch.cuda.current_stream().cuda_stream
                 lay = torch.empty(L.mrs_gemm_qi_repack_bytes(w.dtype.id, n, k), dtype=torch.uint8, device=dev)
                 assert L.mrs_gemm_qi_repack(w.data.data_ptr(), w.dtype.id, n, k, lay.data_ptr(), st) == 0
                 actb = torch.empty(L.mrs_qi_act_bytes(a.t, k), dtype=torch.uint8, device=dev)
                 assert L.mrs_qi_quantize(x.data_ptr(), None, k, None, 0.0, a.t, k, actb.data_ptr(), None, st) == 0
-                run = lambda: L.mrs_gemm_qi(lay.data_ptr(), w.dtype.id, n, k, actb.data_ptr(), a.t, out.data_ptr(), n, 0, st)
+                wsq = torch.empty(4 * a.t * n * 4, dtype=torch.uint8, device=dev)
+                run = lambda: L.mrs_gemm_qi_ws(lay.data_ptr(), w.dtype.id, n, k, actb.data_ptr(), a.t, out.data_ptr(), n, 0, wsq.data_ptr(), wsq.numel(), st)
             elif a.mmq:
                 run = lambda: fast_mmq.plain(w, x)
             elif a.big:

@@ -39,6 +39,12 @@ def run_gemm(O, be, tname, n, k, T, norm, glu=False, acc=False, seed=0):
     rc = be.sym("mrs_gemm_qi", [VP, CI, CI, CI, VP, CI, VP, CI, CI, VP], CI)(wq.ptr, t, n, k, act.ptr, T, ob.ptr, n, 1 if acc else 0, be.stream)
     assert rc == 0, rc
     got = ob.numpy()
+    # the split launch (one workgroup per run of superblocks + the reduce kernel): the same additions in the same order
+    ws = be.buf(np.zeros(4 * T * n, np.float32))
+    ob2 = be.buf(base.copy())
+    rc = be.sym("mrs_gemm_qi_ws", [VP, CI, CI, CI, VP, CI, VP, CI, CI, VP, C.c_size_t, VP], CI)(wq.ptr, t, n, k, act.ptr, T, ob2.ptr, n, 1 if acc else 0, ws.ptr, 4 * T * n * 4, be.stream)
+    assert rc == 0, rc
+    assert np.array_equal(ob2.numpy(), got, equal_nan=True), "split launch differs from the single-pass launch"
     xin = O.fused_glu_engine(x, x2) if glu else x
     if norm:
         xin = O.rms_norm_engine(xin, nw, 1e-5)
@@ -48,7 +54,7 @@ def run_gemm(O, be, tname, n, k, T, norm, glu=False, acc=False, seed=0):
     return packed, x, got
 
 
-CASES = [("Q4_K", 40, 512, 5, 0), ("Q4_K", 130, 1024, 33, 1), ("Q4_K", 64, 4096, 7, 1), ("Q4_K", 33, 2816, 3, 0), ("Q6_K", 40, 512, 5, 0), ("Q6_K", 70, 1024, 130, 1),
+CASES = [("Q4_K", 40, 512, 5, 0), ("Q4_K", 36, 1280, 4, 1), ("Q4_K", 130, 1024, 33, 1), ("Q4_K", 64, 4096, 7, 1), ("Q4_K", 33, 2816, 3, 0), ("Q6_K", 40, 512, 5, 0), ("Q6_K", 70, 1024, 130, 1),
          ("Q6_K", 32, 3584, 4, 0)]
 
 

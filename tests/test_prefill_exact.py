@@ -12,7 +12,7 @@ from tests.test_dec_engine import ATTN2
 from tests.test_dec_model import Q4KM, _mk
 
 VP, CI = C.c_void_p, C.c_int
-PA = [VP, VP, VP, VP, VP, VP] + [CI] * 8 + [C.c_float, CI, CI, CI, VP]
+PA = [VP, VP, VP, VP, VP, VP] + [CI] * 8 + [C.c_float, CI, CI, CI, CI, VP]
 
 
 def check_attention(O, be, heads, kvh, T, max_ctx, kv_dtype=1, window=0, start=0):
@@ -33,7 +33,7 @@ def check_attention(O, be, heads, kvh, T, max_ctx, kv_dtype=1, window=0, start=0
     scale = np.float32(1.0 / np.sqrt(np.float32(hd)))
     got = be.buf(np.full((T, nq), np.nan, np.float32))
     rc = be.sym("mrs_prefill_attention_exact", PA, CI)(q.ptr, kc.ptr, vc.ptr, bt.ptr, cl.ptr, got.ptr, T, heads, kvh, hd, bs, nq, kvh * hd * bs, hd * bs, scale, max_ctx, kv_dtype,
-                                                         window, be.stream)
+                                                         window, start + T if (heads + T) % 2 else 0, be.stream)
     assert rc == 0, rc
     res = got.numpy()
     splits = be.sym("mrs_decode_attention_max_splits", [CI], CI)(max_ctx)
