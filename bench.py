@@ -106,12 +106,16 @@ def host_weights(model):
     return w
 
 
-def cpu_baseline(model, cfg, budget_s=12.0, positions=16):
-    """Reference CPU path on the host cores, the SAME synthetic model (oracle/llama_ref.py + llama_oracle.c / cpu_path_oracle.c):
-      * timing ("port"): mode "cpu_fast" (Q8_K / Q8_0 activations, integer block dots, OpenMP rows), greedy from an empty context;
-      * parity material, teacher-forced on that run's tokens: mode "cpu" (ggml's generic GEMV order, candle's in-order rms sum, single_q.rs attention) and
-        mode "engine" (the same arithmetic in the decode engine's documented summation orders: the HIP engine must equal it bit for bit).
-    Thread count picked by a quick calibration (cgroup quotas make nproc unreliable)."""
+def cpu_baseline(model, cfg, prompt, positions=16):
+    """Reference CPU path on the host cores, the SAME synthetic model (oracle/llama_ref.py + llama_oracle.c / cpu_path_oracle.c): the parity prompt
+    (`prompt`, >= 64 tokens, in ONE pass: per-row Q8_K activations, full.rs attention) followed by `positions` greedy decode steps.
+      * timing ("port"): mode "cpu_fast" (= cpu order b: one f32 term per superblock, 2 kv chunks, OpenMP rows); the timed sample is its decode steps;
+      * parity material, teacher-forced on that run's tokens:
+          "cpu"    order a: ggml's generic GEMV order, candle's in-order rms sum, full.rs (prompt) / single_q.rs (decode) attention
+          "engine" the same arithmetic in the decode engine's documented summation orders: the HIP engine must equal it bit for bit (prompt and decode)
+          "exact"  dequantized weights, NO activation quantization, f64 accumulation and glue: the model every quantized evaluation approximates
+    Every mode rounds K / V to bf16 on the way into the cache (the page format).  Thread count picked by a quick calibration (cgroup quotas make nproc unreliable).
+    Returns (baseline record, fed tokens, {mode: [positions + 1 logit vectors: last prompt position, then after each fed token]}, {mode: LlamaRef})."""
     import numpy as np
     from mistralrs_amd.llama import rope_tables
     from oracle import llama_ref, oracle as O
@@ -134,28 +138,32 @@ def cpu_baseline(model, cfg, budget_s=12.0, positions=16):
         if dt < best[0]:
             best = (dt, thr)
     O.set_threads(best[1])
-    ref = llama_ref.LlamaRef(cfg, w, cos, sin, mode="cpu_fast", kv_dtype="bf16", n_kv_chunks=2)
-    # same token rule as the GPU run, from an empty context; the GPU side repeats exactly this (token by token through the decode engine)
-    tok, n, toks, logits_b, t0 = 1000 % cfg.vocab_size, 0, [], [], time.perf_counter()
-    el = 0.0
-    while n < positions:
-        lg = ref.step(tok, n)
-        logits_b.append(np.asarray(lg, dtype=np.float32).copy())
-        tok, n = int(lg.argmax()), n + 1
-        toks.append(tok)
-        if el == 0.0 and (time.perf_counter() - t0 > budget_s or n >= positions):
-            el, n_timed = time.perf_counter() - t0, n  # the timed sample ends here; the remaining positions are parity material only
-    fed = ([1000 % cfg.vocab_size] + toks[:-1])[:positions]
+    P = len(prompt)
     nblk = (cfg.max_context_len + 31) // 32
-    runs = {"cpu": llama_ref.LlamaRef(cfg, w, cos, sin, mode="cpu", kv_dtype="bf16"),
-            "engine": llama_ref.LlamaRef(cfg, w, cos, sin, mode="engine", kv_dtype="bf16", attn_bpw=1 if nblk <= 64 else (nblk + 63) // 64)}
-    logits = {k: [np.asarray(r.step(t, p), dtype=np.float32).copy() for p, t in enumerate(fed)] for k, r in runs.items()}
-    logits["cpu_b"] = logits_b
-    base = {"value": round(n_timed / el, 3), "unit": "tokens/s", "cores": best[1], "kind": "port",
-            "sample": f"{n_timed} greedy decode tokens from an empty context, same synthetic {cfg.num_layers}-layer Q4_K_M weights, "
+    kw = {"cpu_b": dict(mode="cpu_fast", n_kv_chunks=2), "cpu": dict(mode="cpu"), "exact": dict(mode="exact"),
+          "engine": dict(mode="engine", attn_bpw=1 if nblk <= 64 else (nblk + 63) // 64)}
+    runs = {k: llama_ref.LlamaRef(cfg, w, cos, sin, kv_dtype="bf16", **v) for k, v in kw.items()}
+    f32 = lambda lg: np.asarray(lg, dtype=np.float32).copy()
+    # same token rule as the GPU run; the GPU side repeats exactly this (prefill of the prompt, then token by token through the decode engine)
+    t0 = time.perf_counter()
+    lb = [f32(runs["cpu_b"].prefill(prompt))]
+    t_prompt = time.perf_counter() - t0
+    fed, t0 = [], time.perf_counter()
+    for i in range(positions):
+        fed.append(int(lb[-1].argmax()))
+        lb.append(f32(runs["cpu_b"].step(fed[-1], P + i)))
+    el = time.perf_counter() - t0
+    logits = {"cpu_b": lb}
+    for k in ("cpu", "engine", "exact"):
+        logits[k] = [f32(runs[k].prefill(prompt))] + [f32(runs[k].step(t, P + i)) for i, t in enumerate(fed)]
+    base = {"value": round(positions / el, 3), "unit": "tokens/s", "cores": best[1], "kind": "port", "oracle_pinned": False,
+            "prompt_tokens_per_sec": round(P / t_prompt, 2),
+            "sample": f"{positions} greedy decode tokens after a {P}-token prompt (context {P}..{P + positions - 1}), same synthetic {cfg.num_layers}-layer Q4_K_M weights, "
                       f"restatement of the candle CPU path (Q8_K activations, integer block dots, OpenMP rows, gcc -O3 -march=native); "
-                      f"host reports {os.cpu_count()} logical CPUs"}
-    return base, fed, logits
+                      f"host reports {os.cpu_count()} logical CPUs",
+            "oracle_pinned_note": "candle / ggml sources are not in /root/reference (Cargo dependency): the CPU-path arithmetic is restated from the published ggml "
+                                  "algorithms and pinned on the reference's own CUDA sources compiled on the host (oracle/_ref) for the block formats, not on a candle run"}
+    return base, fed, logits, runs
 
 
 def dropin_rate(model, cfg, prompt, steps, device):
@@ -195,15 +203,196 @@ def measured_traffic(model_name, quant="q4_k_m"):
     here = os.path.dirname(os.path.abspath(__file__))
     if "8B" not in model_name or quant != "q4_k_m":  # the profiled workload is the Q4_K_M model; ISQ Q8_0 streams twice the bytes
         return {"traffic": None}
-    for rel in ("profiles/round3_hbm_traffic.json", "profiles/round2_hbm_traffic.json"):  # newest committed pass first
+    for rel in ("profiles/round4_hbm_traffic.json", "profiles/round3_hbm_traffic.json", "profiles/round2_hbm_traffic.json"):  # newest committed pass first
         try:
             ks = json.load(open(os.path.join(here, rel)))["kernels"]
-            # NCOLS = 1, EPI_GLU: `dec_gemv_kernel<1, 2, true>` since round 3 (third parameter: the short activation prefetch), `<1, 2>` before
-            k = next(v for name, v in ks.items() if "dec_gemv_kernel<1, 2, true>" in name or "dec_gemv_kernel<1, 2>" in name)
+            # NCOLS = 1, EPI_GLU: `dec_gemv_kernel<1, 2, (bool)1, 15>` in round 4 (SPEC schedule, every format), `<1, 2, true>` in round 3, `<1, 2>` before
+            k = next(v for name, v in ks.items() if "dec_gemv_kernel<1, 2" in name.replace("(bool)1", "true").replace("(int)", ""))
         except (OSError, KeyError, ValueError, StopIteration):
             continue
         return {"traffic": int(k["read_bytes_per_launch"] + k["write_bytes_per_launch"]), "traffic_source": rel}
     return {"traffic": None}
+
+
+def timed_run(model, cfg, prompt_len, steps, warmup, batch, sync, world, dev):
+    """One benchmark pass on an already built model: TTFT of a `prompt_len` prompt (reference method: prompt_len / time-to-first-token, host read-back of
+    the first token included), then the HIP graph of one decode step replayed `warmup` + `steps` times, EXACTLY `steps` of them timed between
+    barrier + synchronize on both sides (max over ranks)."""
+    import torch
+    import torch.distributed as dist
+    prompt = [(1000 + i % 2048) % cfg.vocab_size for i in range(prompt_len)]
+    model.prefill(prompt, 0)  # warm-up (lazy code-object loads, workspace allocation); the timed run overwrites the same pages
+    sync()
+    t0 = time.perf_counter()
+    last = model.prefill(prompt, 0)
+    first_tok = int(last.argmax())  # device -> host read-back of the first token: end of TTFT
+    ttft = time.perf_counter() - t0
+    B = max(1, min(8, batch))
+    for sq in range(1, B):  # the other sequences of a batched run: same prompt into their own pages (untimed)
+        model.prefill(prompt, 0, seq=sq)
+    # ---------------- decode: HIP graph of one step, replayed
+    model.set_state([first_tok] * B, [prompt_len] * B)
+    model.step_counter.zero_()
+    model.capture_decode_graph(B)
+    for _ in range(warmup):
+        model.replay()
+    sync()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(steps):
+        model.replay()
+    ev1.record()
+    sync()
+    wall = time.perf_counter() - t0
+    dev_s = ev0.elapsed_time(ev1) / 1e3
+    tmax = torch.tensor([wall], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    toks = model.tokens_out[0, : warmup + steps].cpu().numpy()
+    assert int(model.positions[0]) == prompt_len + warmup + steps, "decode state did not advance as expected"
+    return {"prompt": prompt, "ttft": ttft, "prefill_flops": model.prefill_flops(prompt_len), "B": B, "t_all": float(tmax.item()), "dev_s": dev_s, "toks": toks,
+            "first_tok": first_tok}
+
+
+def parity_leg(model, cfg, a, prefill_exact):
+    """The parity record of the bench line: the SAME model on the GPU and on the host cores, a `--parity-prompt` (64) token prompt prefilled in ONE pass on both
+    sides followed by `--parity-positions` (16) decode steps teacher-forced on the CPU run's greedy tokens.
+      (1) engine vs the engine-order restatement (oracle mode "engine"): logits of the last prompt position and of every decode position, and the K / V pages the
+          prefill wrote, must be IDENTICAL; the pages a token-by-token decode of the prompt writes must equal the prefill's bit for bit;
+      (2) distances: engine / cpu order a / cpu order b each against the EXACT model (dequantized weights, no activation quantization, f64), per position
+          (`vs_exact`): is the engine an equally valid sample of the reference arithmetic, not merely as far from a as b is;
+      (3) engine vs cpu order a and the a-vs-b calibration (as in earlier rounds), argmax agreement, free-running greedy ids."""
+    import numpy as np
+    import torch
+    P, D = a.parity_prompt, a.parity_positions
+    prompt = [(1000 + i % 2048) % cfg.vocab_size for i in range(P)]
+    base, fed, cl, runs = cpu_baseline(model, cfg, prompt, positions=D)
+    nb = (P + cfg.block_size - 1) // cfg.block_size
+
+    def pages():  # K / V of positions [0, P) of sequence 0 as [P, KVH, hd] bf16 bit patterns, every layer
+        ks, vs = [], []
+        for kc, vc in zip(model.key_caches, model.value_caches):
+            blk = model.block_tables[0, :nb].long()
+            k = kc[blk].permute(0, 3, 1, 2, 4).reshape(nb * cfg.block_size, cfg.num_kv_heads, cfg.head_dim)[:P]
+            v = vc[blk].permute(0, 3, 1, 2).reshape(nb * cfg.block_size, cfg.num_kv_heads, cfg.head_dim)[:P]
+            ks.append(k.contiguous().view(torch.int16).cpu().numpy())
+            vs.append(v.contiguous().view(torch.int16).cpu().numpy())
+        return np.stack(ks), np.stack(vs)
+
+    f32 = lambda t: t.float().cpu().numpy()
+    gl = [f32(model.prefill(prompt, 0))]
+    kp, vp = pages()
+    for i, t in enumerate(fed):
+        model.set_state([t], [P + i])
+        gl.append(f32(model.forward_logits(1)[0]))
+    # the same prompt token by token through the decode engine, into the same pages
+    for pos, t in enumerate(prompt):
+        model.set_state([t], [pos])
+        ld = f32(model.forward_logits(1)[0])
+    kd, vd = pages()
+    from oracle import oracle as O
+    ref = runs["engine"]
+    ko = np.stack([O.to_bf16_bits(np.stack(ref.k[l][:P])).view(np.int16) for l in range(cfg.num_layers)])
+    vo = np.stack([O.to_bf16_bits(np.stack(ref.v[l][:P])).view(np.int16) for l in range(cfg.num_layers)])
+    rel = lambda x, y, r: float(np.abs(x - y).max() / np.abs(r).max())
+    ex = cl["exact"]
+    e_x = [rel(g, c, c) for g, c in zip(gl, ex)]
+    a_x = [rel(g, c, c) for g, c in zip(cl["cpu"], ex)]
+    b_x = [rel(g, c, c) for g, c in zip(cl["cpu_b"], ex)]
+    e_a = [rel(g, c, c) for g, c in zip(gl, cl["cpu"])]
+    e_b = [rel(g, c, ca) for g, c, ca in zip(gl, cl["cpu_b"], cl["cpu"])]
+    a_b = [rel(c, d, c) for c, d in zip(cl["cpu"], cl["cpu_b"])]
+    ident = [bool(np.array_equal(g, c)) for g, c in zip(gl, cl["engine"])]
+    e_e = [float(np.abs(g - c).max()) for g, c in zip(gl, cl["engine"])]
+    ids = lambda ls: [int(x.argmax()) for x in ls]
+    ratio = [e / max(x, y, 1e-12) for e, x, y in zip(e_x, a_x, b_x)]
+    flips = [{"position": P - 1 + p, "cpu_a_top2_margin_over_max_logit": float((np.sort(c)[-1] - np.sort(c)[-2]) / np.abs(c).max()), "engine_vs_cpu_a": e_a[p]}
+             for p, (g, c) in enumerate(zip(gl, cl["cpu"])) if int(g.argmax()) != int(c.argmax())]
+    # free-running greedy from the prefilled prompt: engine vs a free-running CPU-order-a run (continues from runs["cpu"]'s prompt cache)
+    cpu_a = runs["cpu"]
+    for l in range(cfg.num_layers):
+        del cpu_a.k[l][P:], cpu_a.v[l][P:]
+    tg = tc = int(gl[0].argmax())
+    tc = int(cl["cpu"][0].argmax())
+    gpu_toks, cpu_toks = [tg], [tc]
+    model.prefill(prompt, 0)
+    for i in range(D):
+        model.set_state([tg], [P + i])
+        tg = int(model.forward_logits(1)[0].argmax())
+        gpu_toks.append(tg)
+        if gpu_toks[:-1] == cpu_toks:  # the CPU run only has to continue while the prefixes agree
+            tc = int(cpu_a.step(tc, P + i).argmax())
+            cpu_toks.append(tc)
+    n_cmp = len(cpu_toks)
+    rnd = lambda v: [round(x, 6) for x in v]
+    out = {
+        "greedy_match": gpu_toks[:n_cmp] == cpu_toks and n_cmp == D + 1,  # vs CPU order a (the reference's own summation orders), free-running after the shared prompt
+        "greedy_match_engine_order_restatement": bool(all(ident)),  # identical logits => identical ids: the engine vs the CPU evaluation of the same arithmetic in its order
+        "greedy_match_between_cpu_orders": ids(cl["cpu_b"]) == ids(cl["cpu"]),  # calibration: do two CPU summation orders pick the same ids on this model (teacher-forced)
+        "parity": {
+            "weights": "N(0, 0.02^2) per tensor through the GGML quantizers (device ISQ, bit-identical to GGML), Q4_K_M type map" if a.weights == "gaussian" else "random valid block bytes",
+            "prompt_tokens": P, "decode_positions": D, "positions": "index 0 = last prompt position, then one per decode step",
+            "prompt_arithmetic": "decode engine's (mrs_gemm_qi + per-query decode attention)" if prefill_exact else "bf16-operand MFMA (NOT the reference arithmetic)",
+            "oracle_pinned": False,
+            "engine_vs_engine_order_restatement": {
+                "bit_identical_positions": int(sum(ident)), "of": len(ident), "max_abs_logit_diff": max(e_e), "greedy_ids_identical": ids(gl) == ids(cl["engine"]),
+                "kv_pages_prefill_equal_oracle": bool(np.array_equal(kp, ko) and np.array_equal(vp, vo)),
+                "kv_pages_prefill_equal_token_by_token_decode": bool(np.array_equal(kp, kd) and np.array_equal(vp, vd)),
+                "prefill_logits_equal_token_by_token_decode": bool(np.array_equal(gl[0], ld)),
+                "what": "oracle/cpu_path_oracle.c: the reference CPU path's arithmetic (Q8_K activations, integer block dots, candle rms_norm, single_q.rs softmax with fast_exp) in the "
+                        "engine's documented f32 summation orders; LlamaRef.prefill == its own step loop"},
+            "vs_exact": {"engine": rnd(e_x), "cpu_order_a": rnd(a_x), "cpu_order_b": rnd(b_x), "engine_over_max_cpu": [round(r, 3) for r in ratio],
+                         "engine_within_1.05x_of_max_cpu_at_every_position": bool(max(ratio) <= 1.05),
+                         "mean": {"engine": round(float(np.mean(e_x)), 6), "cpu_order_a": round(float(np.mean(a_x)), 6), "cpu_order_b": round(float(np.mean(b_x)), 6)},
+                         "what": "max |logits - exact| / max |exact| per position; exact = dequantized weights, f32 activations without quantization, f64 accumulation and glue, same bf16 K / V rounding"},
+            "teacher_forced_max_logit_error_over_max_logit": {"engine_vs_cpu_order_a": rnd(e_a), "engine_vs_cpu_order_b": rnd(e_b), "cpu_order_a_vs_cpu_order_b": rnd(a_b)},
+            "mean": {"engine_vs_cpu_order_a": round(float(np.mean(e_a)), 6), "cpu_order_a_vs_cpu_order_b": round(float(np.mean(a_b)), 6),
+                     "ratio": round(float(np.mean(e_a) / max(np.mean(a_b), 1e-12)), 3)},
+            "argmax_agree_with_cpu_order_a": {"engine": int(sum(x == y for x, y in zip(ids(gl), ids(cl["cpu"])))), "cpu_order_b": int(sum(x == y for x, y in zip(ids(cl["cpu_b"]), ids(cl["cpu"])))),
+                                              "of": len(gl)},
+            "argmax_flips": flips[:4],
+            "greedy_free_running": {"tokens_compared": n_cmp, "first_difference": next((i for i, (x, y) in enumerate(zip(gpu_toks, cpu_toks)) if x != y), None)},
+            "note": "cpu order a = ggml generic 8-lane GEMV order + candle in-order rms sum + full.rs (prompt) / single_q.rs (decode, 1 kv chunk) attention; b = one f32 term per "
+                    "superblock + 2 kv chunks. Orders that differ ONLY in f32 summation agree to ~1e-6 until a rounding difference moves one int8 activation quant across a "
+                    "rounding step, then sit at the int8 noise floor of this random-weight model (profiles/round3_parity.md); the engine's arithmetic is pinned by the bit-identical "
+                    "restatement, its validity as a sample of the reference arithmetic by vs_exact."}}
+    return base, out
+
+
+def extra_config(kind, dev, steps=64, warmup=4, prompt_len=512):
+    """A second BASELINE.json configuration on the same GPU, after the headline run (N = 1, default flags only): the same timed_run() on a freshly built model.
+    kind: "q8_0_isq" = configs[2] (Llama-3-8B, every linear quantized in situ from bf16 to Q8_0 on the GPU), "mixtral" = configs[4]'s model on ONE GPU
+    (Mixtral-8x7B-shaped Q4_K_M, 26 GB: fits one MI355X; the TP = 2 form is `bench.py --model mixtral --gpus 2`)."""
+    import gc
+    import torch
+    from mistralrs_amd.llama import LlamaConfig
+    t_build = time.perf_counter()
+    max_ctx = (prompt_len + warmup + steps + 2 + 63) // 64 * 64
+    if kind == "mixtral":
+        cfg = LlamaConfig.mixtral_8x7b(max_batch=1, max_context_len=max_ctx, max_position_embeddings=max(8192, max_ctx))
+        model = build_model(cfg, dev, seed=0, max_new_tokens=warmup + steps + 8, quant="q4_k_m", weights="blocks")
+        name, wdesc = "Mixtral-8x7B-shaped (8 experts, top-2) GGUF Q4_K_M, TP=1", "random valid block bytes (46.7 B parameters: the gaussian + quantize pass is skipped to bound the run)"
+    else:
+        cfg = LlamaConfig.llama3_8b(max_batch=1, max_context_len=max_ctx, max_position_embeddings=max(8192, max_ctx))
+        model = build_model(cfg, dev, seed=0, max_new_tokens=warmup + steps + 8, quant="q8_0_isq", weights="gaussian")
+        name, wdesc = "Llama-3-8B ISQ Q8_0 (in situ from bf16, on the GPU), TP=1", "N(0, 0.02^2) bf16 weights quantized by the device ISQ pass"
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t_build
+
+    def sync():
+        torch.cuda.synchronize()
+    r = timed_run(model, cfg, prompt_len, steps, warmup, 1, sync, 1, dev)
+    step_bytes = model.decode_bytes(1, int(prompt_len + warmup + steps / 2))
+    out = {"workload": f"{name}, {prompt_len} prefill / {steps} decode, batch 1", "weights": wdesc, "decode_tokens_per_sec": round(steps / r["t_all"], 2),
+           "ms_per_step": round(1e3 * r["t_all"] / steps, 4), "steps": steps, "warmup": warmup, "step_bytes": int(step_bytes),
+           "step_roofline_frac": round(step_bytes * (steps / r["t_all"]) / HBM_PEAK, 4), "prefill_tokens_per_sec": round(prompt_len / r["ttft"], 1),
+           "ttft_ms": round(1e3 * r["ttft"], 2), "prefill_arithmetic": "decode engine's (exact)" if model.prefill_is_exact else "bf16-operand MFMA",
+           "decode_path": model.decode_path, "build_s": round(t_build, 1)}
+    del model
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -216,6 +405,8 @@ def main():
     ap.add_argument("--shard-shapes", type=int, default=0, help="single GPU, no collectives: run ONE rank's shard shapes of a TP = N model (shape smoke test for --gpus N)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in launch sequence leg (dropin_tokens_per_sec)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs legs (configs[2] ISQ Q8_0 and the configs[4] model on one GPU)")
+    ap.add_argument("--parity-prompt", type=int, default=64, help="prompt length of the CPU-path parity leg (prefilled in one pass on both sides)")
     ap.add_argument("--small", action="store_true", help="tiny config (smoke / CI), not the benchmark")
     ap.add_argument("--tp", action="store_true", help="(default for N > 1) ONE model sharded tensor-parallel over the N GPUs")
     ap.add_argument("--replicas", action="store_true", help="N > 1: N independent replicas (weak scaling) instead of tensor parallelism")
@@ -333,41 +524,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---------------- prefill (TTFT), reference method: prompt_len / time-to-first-token
-    prompt = [(1000 + i % 2048) % cfg.vocab_size for i in range(a.prompt_len)]
-    model.prefill(prompt, 0)  # warm-up (lazy code-object loads, workspace allocation); the timed run overwrites the same pages
-    sync()
-    t0 = time.perf_counter()
-    last = model.prefill(prompt, 0)
-    first_tok = int(last.argmax())  # device -> host read-back of the first token: end of TTFT
-    ttft = time.perf_counter() - t0
-    prefill_flops = model.prefill_flops(a.prompt_len)
-    B = max(1, min(8, a.batch))
-    for sq in range(1, B):  # the other sequences of a batched run: same prompt into their own pages (untimed)
-        model.prefill(prompt, 0, seq=sq)
-
-    # ---------------- decode: HIP graph of one step, replayed
-    model.set_state([first_tok] * B, [a.prompt_len] * B)
-    model.step_counter.zero_()
-    model.capture_decode_graph(B)
-    for _ in range(a.warmup):
-        model.replay()
-    sync()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(a.steps):
-        model.replay()
-    ev1.record()
-    sync()
-    wall = time.perf_counter() - t0
-    dev_s = ev0.elapsed_time(ev1) / 1e3
-    tmax = torch.tensor([wall], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    t_all = float(tmax.item())
-    toks = model.tokens_out[0, : a.warmup + a.steps].cpu().numpy()
-    assert int(model.positions[0]) == a.prompt_len + a.warmup + a.steps, "decode state did not advance as expected"
+    r = timed_run(model, cfg, a.prompt_len, a.steps, a.warmup, a.batch, sync, world, dev)
+    prompt, ttft, prefill_flops, B, t_all, dev_s, toks = r["prompt"], r["ttft"], r["prefill_flops"], r["B"], r["t_all"], r["dev_s"], r["toks"]
+    prefill_exact = bool(model.prefill_is_exact)
+    ttft_bf16 = None
+    if prefill_exact and world == 1:  # the same prompt through the bf16-operand MFMA GEMMs + flash attention (selectable: Llama.set_prefill_mode(0) / MRS_PREFILL_EXACT=0)
+        model.set_prefill_mode(0)
+        model.prefill(prompt, 0, seq=min(1, cfg.max_batch - 1))
+        sync()
+        t0 = time.perf_counter()
+        int(model.prefill(prompt, 0, seq=min(1, cfg.max_batch - 1)).argmax())
+        ttft_bf16 = time.perf_counter() - t0
+        model.set_prefill_mode(-1)
 
     # ---------------- roofline of the dominant kernel: the decode engine's gate/up phase (RMSNorm + Q8_K quantize + 2 x [ffn, d] GEMV + SiLU*up),
     # timed with HIP events on the launch stream over every layer's weights (>= 1 GB: nothing Infinity-Cache resident)
@@ -456,9 +624,13 @@ def main():
         "config": {"workload": f"{name} " + ("GGUF Q4_K_M" if a.quant == "q4_k_m" else "ISQ Q8_0 (in situ from bf16, on the GPU)") + f", TP={world if tp else 1}, {a.prompt_len} prefill / {a.steps} decode, batch {B}, paged KV bf16 (block 32)",
                    "parallelism": "tp1" if world == 1 else (f"tp{world}" if tp else f"replicas x{world}")},
         "prefill_tokens_per_sec": round(a.prompt_len / ttft, 1), "ttft_ms": round(1e3 * ttft, 2),
+        "prefill_arithmetic": ("decode engine's: Q8_K activation rows x exact-integer f16 MFMA block dots, one f32 term per superblock (mrs_gemm_qi), decode attention per query "
+                               "-- logits and KV pages identical to token-by-token decode" if prefill_exact else "bf16-operand MFMA (fused block dequant) + MFMA flash attention"),
         "prefill_roofline": {"bound": "mfma", "achieved": round(prefill_flops / ttft / 1e12, 1), "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s",
                              "frac": round(prefill_flops / ttft / MFMA_PEAK, 4), "flops": prefill_flops,
-                             "note": "fused block-dequant -> bf16 MFMA GEMMs (mrs_gemm_q_bf16_multi) + MFMA flash attention over the paged cache; whole prompt incl. the host read-back of the first token"},
+                             "note": ("exact-integer f16 MFMA GEMMs on Q8_K activation images (mrs_gemm_qi) + per-query decode attention over the paged cache"
+                                      if prefill_exact else "fused block-dequant -> bf16 MFMA GEMMs (mrs_gemm_q_bf16_multi) + MFMA flash attention over the paged cache")
+                                     + "; whole prompt incl. the host read-back of the first token"},
         "device_ms_per_step": round(1e3 * dev_s / a.steps, 4),
         "step_bytes": int(step_bytes), "step_roofline_frac": round(step_bytes * (a.steps / t_all) / HBM_PEAK, 4),
         "roofline": {"bound": "hbm", "kernel": "dec_gemv_kernel<1, EPI_GLU> (decode engine gate/up phase: RMSNorm + Q8_K quantize + gate/up GEMV + SiLU*up)",
@@ -466,6 +638,10 @@ def main():
                      "bytes_per_launch": int(kern_bytes), "us_per_launch": round(kern_s * 1e6, 2), **measured_traffic(name, a.quant)},
         "greedy_tokens_head": [int(t) for t in toks[a.warmup: a.warmup + 8]],
     }
+    if ttft_bf16 is not None:
+        out["prefill_bf16"] = {"tokens_per_sec": round(a.prompt_len / ttft_bf16, 1), "ttft_ms": round(1e3 * ttft_bf16, 2), "frac": round(prefill_flops / ttft_bf16 / MFMA_PEAK, 4),
+                               "note": "same prompt through the selectable bf16-operand path (Llama.set_prefill_mode(0) / MRS_PREFILL_EXACT=0): faster, but its logits and KV pages are "
+                                       "only close to (not identical with) the decode engine's -- the default keeps the reference CPU arithmetic"}
     if ar is not None:
         out["allreduce"] = ar
     if world == 1 and B == 1 and not a.no_dropin and not a.small and a.quant == "q4_k_m" and not moe:
@@ -479,61 +655,22 @@ def main():
             out["dropin_note"] = f"failed: {e}"
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
-            import numpy as np
-            out["cpu_baseline"], fed, cl = cpu_baseline(model, cfg, positions=a.parity_positions)
-            # ---- parity of the same model on the GPU (decode engine, token by token from an empty context)
-            # (1) teacher-forced on the CPU run's tokens: engine logits vs the engine-order restatement (must be IDENTICAL), vs the reference's own orders
-            #     (mode "cpu" = a), and the distance between two CPU orders (a vs b = "cpu_fast" + 2 kv chunks) as the calibration of what order alone does
-            # (2) greedy_match: free-running greedy ids of the engine vs CPU order a
-            gl = []
-            for pos, t in enumerate(fed):
-                model.set_state([t], [pos])
-                gl.append(model.forward_logits(1)[0].float().cpu().numpy())
-            rel = lambda x, y, ref: float(np.abs(x - y).max() / np.abs(ref).max())
-            e_a = [rel(g, c, c) for g, c in zip(gl, cl["cpu"])]
-            e_b = [rel(g, c, ca) for g, c, ca in zip(gl, cl["cpu_b"], cl["cpu"])]
-            a_b = [rel(c, d, c) for c, d in zip(cl["cpu"], cl["cpu_b"])]
-            ident = [bool(np.array_equal(g, c)) for g, c in zip(gl, cl["engine"])]
-            e_e = [float(np.abs(g - c).max()) for g, c in zip(gl, cl["engine"])]
-            ids = lambda ls: [int(x.argmax()) for x in ls]
-            flips = [{"position": p, "cpu_a_top2_margin_over_max_logit": float((np.sort(c)[-1] - np.sort(c)[-2]) / np.abs(c).max()), "engine_vs_cpu_a": e_a[p]}
-                     for p, (g, c) in enumerate(zip(gl, cl["cpu"])) if int(g.argmax()) != int(c.argmax())]
-            # free-running greedy: engine vs a free-running CPU-order-a run
-            from mistralrs_amd.llama import rope_tables
-            from oracle import llama_ref
-            cos, sin = rope_tables(cfg)
-            cpu_a = llama_ref.LlamaRef(cfg, host_weights(model), cos, sin, mode="cpu", kv_dtype="bf16")
-            tg = tc = 1000 % cfg.vocab_size
-            gpu_toks, cpu_toks = [], []
-            for pos in range(len(fed)):
-                model.set_state([tg], [pos])
-                tg = int(model.forward_logits(1)[0].argmax())
-                gpu_toks.append(tg)
-                if gpu_toks[:pos] == cpu_toks[:pos]:  # the CPU run only has to continue while the prefixes agree
-                    tc = int(cpu_a.step(tc, pos).argmax())
-                    cpu_toks.append(tc)
-            n_cmp = len(cpu_toks)
-            out["greedy_match"] = gpu_toks[:n_cmp] == cpu_toks and n_cmp == len(fed)  # vs CPU order a (the reference's own summation orders), free-running
-            out["greedy_match_engine_order_restatement"] = bool(all(ident))  # identical logits => identical ids: the engine vs the CPU evaluation of the same arithmetic in its order
-            out["greedy_match_between_cpu_orders"] = ids(cl["cpu_b"]) == ids(cl["cpu"])  # calibration: do two CPU summation orders pick the same ids on this model (teacher-forced)
-            out["parity"] = {
-                "weights": "N(0, 0.02^2) per tensor through the GGML quantizers (device ISQ, bit-identical to GGML), Q4_K_M type map" if a.weights == "gaussian" else "random valid block bytes",
-                "positions": len(fed),
-                "engine_vs_engine_order_restatement": {"bit_identical_positions": int(sum(ident)), "max_abs_logit_diff": max(e_e), "greedy_ids_identical": ids(gl) == ids(cl["engine"]),
-                                                       "what": "oracle/cpu_path_oracle.c: the reference CPU path's arithmetic (Q8_K activations, integer block dots, candle rms_norm, single_q.rs softmax with fast_exp) in the engine's documented f32 summation orders"},
-                "teacher_forced_max_logit_error_over_max_logit": {"engine_vs_cpu_order_a": [round(v, 6) for v in e_a], "engine_vs_cpu_order_b": [round(v, 6) for v in e_b],
-                                                                  "cpu_order_a_vs_cpu_order_b": [round(v, 6) for v in a_b]},
-                "mean": {"engine_vs_cpu_order_a": round(float(np.mean(e_a)), 6), "cpu_order_a_vs_cpu_order_b": round(float(np.mean(a_b)), 6),
-                         "ratio": round(float(np.mean(e_a) / max(np.mean(a_b), 1e-12)), 3)},
-                "argmax_agree_with_cpu_order_a": {"engine": int(sum(x == y for x, y in zip(ids(gl), ids(cl["cpu"])))), "cpu_order_b": int(sum(x == y for x, y in zip(ids(cl["cpu_b"]), ids(cl["cpu"]))))},
-                "argmax_flips": flips[:4],
-                "greedy_free_running": {"tokens_compared": n_cmp, "first_difference": next((i for i, (x, y) in enumerate(zip(gpu_toks, cpu_toks)) if x != y), None)},
-                "note": "cpu order a = ggml generic 8-lane GEMV order + candle in-order rms sum + single_q.rs tile order (1 kv chunk); b = one f32 term per superblock + 2 kv chunks. "
-                        "Orders that differ ONLY in f32 summation agree to ~1e-6 until a rounding difference moves one int8 activation quant across a rounding step, then sit at the int8 "
-                        "noise floor (profiles/round3_parity.md); the engine's arithmetic is pinned by the bit-identical restatement, its distance to a by the a-vs-b calibration."}
+            out["cpu_baseline"], par = parity_leg(model, cfg, a, prefill_exact)
+            out.update(par)
         except Exception as e:  # the baseline is a reported extra, never fatal
             import traceback
             out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port", "sample": f"failed: {e}: {traceback.format_exc()[-400:]}"}
+    if rank == 0 and world == 1 and not a.no_extra and not a.small and B == 1 and a.quant == "q4_k_m" and a.model in ("auto", "8b") and not a.shard_shapes:
+        out["extra_configs"] = {}
+        del model
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        for kind in ("q8_0_isq", "mixtral"):
+            try:
+                out["extra_configs"][kind] = extra_config(kind, dev)
+            except Exception as e:
+                out["extra_configs"][kind] = {"failed": f"{type(e).__name__}: {e}"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -225,6 +225,9 @@ int mrs_prefill_attention_exact(const float *q, const void *k_cache, const void 
                                 int max_context_len, int kv_dtype, int sliding_window, int max_prompt_ctx /* largest context_lens[t], or 0 */, void *stream);
 int mrs_llama_set_qi_tensor(void *model, const char *name, const void *planes); /* MFMA-order copy of a dense linear registered with mrs_llama_set_tensor */
 int mrs_llama_prefill_is_exact(void *model); /* 1: mrs_llama_prefill runs in the decode engine's arithmetic (every dense linear has its MFMA-order copy, decode engine on, TP = 1, no experts) */
+/* prompt arithmetic: 1 = the decode engine's (default where mrs_llama_prefill_is_exact allows it), 0 = bf16-operand MFMA GEMMs + MFMA flash attention (faster TTFT,
+ * logits within ~1e-2 of the engine's instead of identical), -1 = follow the MRS_PREFILL_EXACT environment variable */
+int mrs_llama_set_prefill_mode(void *model, int exact);
 /* diagnostics: pull a byte range through the Infinity Cache (ext_prefetch.hip); one wave of K-deep v_mfma_f32_32x32x16_f16 on caller operands (the exactness
  * premise of mrs_gemm_qi, tests/test_gemm_qi.py) */
 int mrs_l3_prefetch(const void *p, size_t bytes, int workgroups, void *sink, void *stream);

@@ -571,8 +571,10 @@ class Llama {
   //      (ext_gemm_qi.hip), attention = the decode kernels' per-block partials and merge per query token, RoPE / cache write / SiLU / residual adds = the decode
   //      expressions.  A prompt token's hidden states, KV pages and logits are bit for bit what a token-by-token decode produces (tests/test_prefill_exact.py);
   //      the role in the reference is the CPU prompt path (QMatMul f32 fallback per row, gguf/mod.rs:465-478; attention/backends/cpu).
+  int prefill_mode = -1;  // -1: MRS_PREFILL_EXACT (default 1); 0: bf16-operand MFMA prompt GEMMs (mrs_gemm_q_bf16_multi + flash attention); 1: exact path
   bool prefill_exact_ok() const {
-    static const int want = [] { const char *e = getenv("MRS_PREFILL_EXACT"); return e ? atoi(e) : 1; }();
+    static const int env_want = [] { const char *e = getenv("MRS_PREFILL_EXACT"); return e ? atoi(e) : 1; }();
+    const int want = prefill_mode >= 0 ? prefill_mode : env_want;
     if (!want || cfg.use_fused != 2 || !engine_ok() || cfg.world_size > 1 || cfg.num_experts > 0 || cfg.head_dim != 128 || cfg.block_size != 32) return false;
     const int G = cfg.num_heads / std::max(1, (int)cfg.num_kv_heads);
     if (cfg.num_heads % cfg.num_kv_heads || (G != 1 && G != 2 && G != 4)) return false;
@@ -970,5 +972,6 @@ extern "C" int mrs_llama_prefill(void *m, const mrs_llama_prefill_args *a, int T
 }
 extern "C" double mrs_llama_prefill_flops(void *m, int T) { return ((Llama *)m)->prefill_flops(T); }
 extern "C" int mrs_llama_prefill_is_exact(void *m) { return ((Llama *)m)->prefill_exact_ok() ? 1 : 0; }
+extern "C" int mrs_llama_set_prefill_mode(void *m, int exact) { ((Llama *)m)->prefill_mode = exact; return 0; }
 extern "C" int mrs_llama_set_comm(void *m, void *comm) { ((Llama *)m)->comm = comm; return 0; }
 extern "C" int mrs_llama_set_p2p(void *m, void *p2p) { ((Llama *)m)->p2p = p2p; return 0; }

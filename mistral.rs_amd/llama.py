@@ -397,6 +397,11 @@ class Llama:
         self._L.mrs_llama_prefill_is_exact.argtypes = [C.c_void_p]
         return bool(self._L.mrs_llama_prefill_is_exact(self._h))
 
+    def set_prefill_mode(self, exact: int) -> None:
+        """1: prompts in the decode engine's arithmetic (default where available), 0: bf16-operand MFMA GEMMs + flash attention, -1: MRS_PREFILL_EXACT."""
+        self._L.mrs_llama_set_prefill_mode.argtypes = [C.c_void_p, C.c_int]
+        self._chk(self._L.mrs_llama_set_prefill_mode(self._h, int(exact)))
+
     def prefill_flops(self, T: int) -> float:
         return float(self._L.mrs_llama_prefill_flops(self._h, T))
 

@@ -160,6 +160,85 @@ void orc_rms_norm_candle(const float *x, const float *w, float *out, int rows, i
   }
 }
 
+/* full.rs:118-196 run (f32: USE_BARRIER_POOL, logit_softcap == 0 -> compute_tiled_qblock) + full.rs:198-421 compute_tiled_qblock for the prompt of
+ * ONE sequence: q [q_len][H][hd], k / v [kv_len][KVH][hd] (already rounded to the cache dtype), out [q_len][H][hd].
+ * The mask is the causal (+ sliding window) 0 / -inf matrix of attention/mod.rs:74-103 eager_attention_mask, which full.rs:80-117 binary_mask_range
+ * classifies as Binary{start, end} for every row (mask.rs:13-31 row_with_id: one contiguous kv row per query) -- so no mask value is ever added to a
+ * score and each row only scores its live range [start, end): start = query_pos - window + 1 (when query_pos >= window), end = query_pos + 1 with
+ * query_pos = kv_len - q_len + row.  Q_BLOCK = 8 query rows share the K / V stream, KV_BLOCK = 128 positions per tile, ONE online-softmax correction
+ * per tile (fast_exp), P.V by mad over the whole tile span with dead slots zeroed (p == 0 skipped).  f32: EXPAND_SCORE = false (score_rows:
+ * dot4 / dot -> the portable dot body, see the header note on SIMD orders), pv_tile = false. */
+void orc_attention_full_cpu(const float *q, const float *k, const float *v, float *out, int q_len, int kv_len, int H, int KVH, int hd, float scale,
+                            int window) {
+  enum { Q_BLOCK = 8, KV_BLOCK = 128 };
+  const int rk2 = H / KVH, n_q_blocks = (q_len + Q_BLOCK - 1) / Q_BLOCK, prefix = kv_len > q_len ? kv_len - q_len : 0;
+#pragma omp parallel for schedule(dynamic)
+  for (int unit = 0; unit < H * n_q_blocks; ++unit) {
+    const int q_block_idx = unit % n_q_blocks, h_i = unit / n_q_blocks, k_head = h_i / rk2;
+    const int q_start = q_block_idx * Q_BLOCK, q_end = q_len < q_start + Q_BLOCK ? q_len : q_start + Q_BLOCK, nq = q_end - q_start;
+    int row_start[Q_BLOCK], row_end[Q_BLOCK], kv_lo = kv_len, kv_hi = 0;
+    for (int j = 0; j < nq; ++j) {
+      const int qp = prefix + q_start + j;
+      row_start[j] = window > 0 && qp >= window ? qp - window + 1 : 0;
+      row_end[j] = qp + 1 < kv_len ? qp + 1 : kv_len;
+      kv_lo = row_start[j] < kv_lo ? row_start[j] : kv_lo;
+      kv_hi = row_end[j] > kv_hi ? row_end[j] : kv_hi;
+    }
+    float *acc = calloc((size_t)nq * hd, sizeof(float));
+    float m[Q_BLOCK], s[Q_BLOCK], s_tile[Q_BLOCK * KV_BLOCK];
+    for (int j = 0; j < Q_BLOCK; ++j) { m[j] = -INFINITY; s[j] = 0.0f; }
+    for (int bs = kv_lo; bs < kv_hi; bs += KV_BLOCK) {
+      const int be = kv_hi < bs + KV_BLOCK ? kv_hi : bs + KV_BLOCK;
+      for (int j = 0; j < nq; ++j) { /* A: score the tile (live range only) */
+        const int lo = row_start[j] > bs ? row_start[j] : bs, hi = row_end[j] < be ? row_end[j] : be;
+        if (lo >= hi) continue;
+        const float *q_row = q + ((size_t)(q_start + j) * H + h_i) * hd;
+        for (int p = lo; p < hi; ++p) s_tile[j * KV_BLOCK + p - bs] = dot_f32_portable(q_row, k + ((size_t)p * KVH + k_head) * hd, hd) * scale;
+      }
+      for (int j = 0; j < nq; ++j) { /* B: one online-softmax correction per tile */
+        const int lo = row_start[j] > bs ? row_start[j] : bs, hi = row_end[j] < be ? row_end[j] : be;
+        if (lo >= hi) continue;
+        float *live = s_tile + j * KV_BLOCK + (lo - bs);
+        float bmax = -INFINITY;
+        for (int i = 0; i < hi - lo; ++i) bmax = live[i] > bmax ? live[i] : bmax;
+        if (bmax > m[j]) {
+          if (m[j] != -INFINITY) {
+            const float corr = orc_fast_exp(m[j] - bmax);
+            for (int d = 0; d < hd; ++d) acc[(size_t)j * hd + d] *= corr;
+            s[j] *= corr;
+          }
+          m[j] = bmax;
+        }
+        float local = 0.0f;
+        for (int i = 0; i < hi - lo; ++i) { live[i] = orc_fast_exp(live[i] - m[j]); local += live[i]; }
+        s[j] += local;
+      }
+      for (int j = 0; j < nq; ++j) { /* dead tile slots = 0 */
+        const int lo = row_start[j] > bs ? row_start[j] : bs, hi = row_end[j] < be ? row_end[j] : be;
+        float *row = s_tile + j * KV_BLOCK;
+        if (lo >= hi) { for (int i = 0; i < be - bs; ++i) row[i] = 0.0f; continue; }
+        for (int i = 0; i < lo - bs; ++i) row[i] = 0.0f;
+        for (int i = hi - bs; i < be - bs; ++i) row[i] = 0.0f;
+      }
+      for (int p = bs; p < be; ++p) { /* C: P.V, each v row shared by the q block (groups of 4 rows do not change any row's order) */
+        const float *v_row = v + ((size_t)p * KVH + k_head) * hd;
+        for (int j = 0; j < nq; ++j) {
+          const float pr = s_tile[j * KV_BLOCK + (p - bs)];
+          if (pr != 0.0f)
+            for (int d = 0; d < hd; ++d) acc[(size_t)j * hd + d] += v_row[d] * pr;
+        }
+      }
+    }
+    for (int j = 0; j < nq; ++j) {
+      const float inv_s = 1.0f / s[j];
+      float *o = out + ((size_t)(q_start + j) * H + h_i) * hd;
+      for (int d = 0; d < hd; ++d) o[d] = acc[(size_t)j * hd + d] * inv_s;
+    }
+    free(acc);
+  }
+}
+
+
 /* ================================================================== engine order */
 /* the 64-lane all-reduce of dec_core.cuh wave_sum_all: v += v[i^1]; v += v[i^2]; v += v[mirror within 8]; v += v[mirror within 16];
  * result = (lane0 + lane16) + (lane32 + lane48) */

@@ -31,6 +31,10 @@ def _round(x, dt):
     return x
 
 
+def p_moe_free(w: dict) -> bool:
+    return not any(n.endswith("ffn_gate_inp.weight") for n in w)
+
+
 class LlamaRef:
     def __init__(self, cfg, weights: dict, cos: np.ndarray, sin: np.ndarray, mode: str = "q8_1", kv_dtype: str = "bf16", attn_bpw: int = 1,
                  n_kv_chunks: int = 1):
@@ -50,7 +54,7 @@ class LlamaRef:
         if self.mode == "cpu":
             return O.matmul_cpu(t, packed, n, k, x.reshape(-1, k))
         if self.mode == "cpu_fast":  # one f32 term per superblock, superblock order (bench.py cpu_baseline)
-            return O.gemv_cpu_fast(t, packed, n, k, x.reshape(-1, k))
+            return np.concatenate([O.gemv_cpu_fast(t, packed, n, k, r) for r in x.reshape(-1, k)], axis=0)
         if self.mode == "engine":  # the decode engine's summation order
             return np.concatenate([O.gemv_engine(t, packed, n, k, r) for r in x.reshape(-1, k)], axis=0)
         return O.matmul_exact(t, packed, n, k, x.reshape(-1, k))
@@ -108,6 +112,49 @@ class LlamaRef:
             u = self.linear(p + "ffn_up.weight", xn)
             h = h + self.linear(p + "ffn_down.weight", self.glu(g, u))
         xn = self.norm(h, self.w["output_norm.weight"])
+        return self.linear("output.weight", xn)[0]
+
+    def prefill(self, tokens, start_pos: int = 0) -> np.ndarray:
+        """The whole prompt in one pass, layer by layer (models/llama.rs:487-518 with seq_len = T): every linear is the same per-row arithmetic as
+        `step` (candle QMatMul quantizes each activation row on its own: one Q8_K / Q8_0 image per token), RoPE / residuals per row, K / V of all T
+        positions enter the cache, then attention:
+          cpu / cpu_fast  attention/backends/cpu/full.rs (q_len > 1: Q_BLOCK x KV_BLOCK tiles, causal rows as binary ranges; cpu_path_oracle.c
+                          orc_attention_full_cpu) -- NOT the single_q.rs order `step` uses, so prefill != step in the last bits on a CPU too;
+          engine          per query the decode attention over positions <= its own (csrc/ext_gemm_qi.hip prefill_attn_exact_kernel = the decode
+                          kernels' split / merge per query): prefill == the step loop bit for bit, by construction;
+          others          the f64 reference attention per query.
+        Returns the logits of the LAST position [vocab] (the reference only projects the last row: llama.rs:513-516)."""
+        c = self.cfg
+        hd, H, KVH = c.head_dim, c.num_heads, c.num_kv_heads
+        T = len(tokens)
+        assert all(len(kl) == start_pos for kl in self.k), "cache out of sync with start_pos"
+        assert p_moe_free(self.w), "prefill(): dense models only"
+        h = self.embed([int(t) for t in tokens]).astype(np.float32)  # [T, d]
+        posv = np.arange(start_pos, start_pos + T, dtype=np.int32)
+        scale = np.float32(1.0 / np.sqrt(np.float32(hd)))
+        w = getattr(c, "sliding_window", None) or 0
+        for l in range(c.num_layers):
+            p = f"blk.{l}."
+            xn = self.norm(h, self.w[p + "attn_norm.weight"])
+            q = self.linear(p + "attn_q.weight", xn).reshape(T, H, hd)
+            k = self.linear(p + "attn_k.weight", xn).reshape(T, KVH, hd)
+            v = self.linear(p + "attn_v.weight", xn).reshape(T, KVH, hd)
+            q = O.rope(q, self.cos, self.sin, posv, not c.rope_interleaved)
+            k = O.rope(k, self.cos, self.sin, posv, not c.rope_interleaved)
+            for t in range(T):
+                self.k[l].append(_round(k[t], self.kv_dtype))
+                self.v[l].append(_round(v[t], self.kv_dtype))
+            K, V = np.stack(self.k[l]), np.stack(self.v[l])
+            if self.mode in ("cpu", "cpu_fast"):
+                att = O.attention_full_cpu(q, K, V, scale, w)
+            else:
+                att = np.concatenate([self.attend(q[t:t + 1], K[: start_pos + t + 1], V[: start_pos + t + 1], scale) for t in range(T)], axis=0)
+            h = h + self.linear(p + "attn_output.weight", att.reshape(T, H * hd))
+            xn = self.norm(h, self.w[p + "ffn_norm.weight"])
+            g = self.linear(p + "ffn_gate.weight", xn)
+            u = self.linear(p + "ffn_up.weight", xn)
+            h = h + self.linear(p + "ffn_down.weight", self.glu(g, u))
+        xn = self.norm(h[-1:], self.w["output_norm.weight"])
         return self.linear("output.weight", xn)[0]
 
     def moe(self, p: str, xn: np.ndarray) -> np.ndarray:

@@ -323,6 +323,19 @@ def attention_single_q_cpu(q, k, v, scale: float, n_kv_chunks: int = 1) -> np.nd
     return out
 
 
+def attention_full_cpu(q, k, v, scale: float, window: int = 0) -> np.ndarray:
+    """attention/backends/cpu/full.rs (tiled q-block path, causal / sliding-window binary mask rows) for the prompt of ONE sequence:
+    q [T, H, hd], k / v [S, KVH, hd] f32 (S >= T: the last T positions are the queries) -> [T, H, hd]."""
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    k = np.ascontiguousarray(k, dtype=np.float32)
+    v = np.ascontiguousarray(v, dtype=np.float32)
+    t, h, hd = q.shape
+    s, kvh, _ = k.shape
+    out = np.empty_like(q)
+    lib().orc_attention_full_cpu(_p(q), _p(k), _p(v), _p(out), t, s, h, kvh, hd, C.c_float(scale), int(window or 0))
+    return out
+
+
 def attention_engine(q, k, v, scale: float, bpw: int = 1, window: int = 0) -> np.ndarray:
     """The decode engine's attention order (csrc/dec_attn.cuh + ext_dec.hip dec_attn2_kernel), head size 128: q [H, 128], k / v [S, KVH, 128] -> [H, 128].
     window > 0: only the last `window` positions are attended (masked in place: the 32-token blocks stay anchored at position 0, as in the paged cache)."""

@@ -118,23 +118,44 @@ def test_engine_rotate_half_rope_bit_identical_and_prefill_consistent(oracle, de
     for pos, t in enumerate(prompt):
         m3.set_state([t], [pos])
         ld = m3.forward_logits(1)[0].clone()
-    assert float((lp - ld).abs().max()) <= 5e-2 * float(ld.abs().max())
+    if m2.prefill_is_exact:
+        assert torch.equal(lp.float(), ld.float()), "prefill (decode engine's arithmetic) != token-by-token decode"
+    else:
+        assert float((lp - ld).abs().max()) <= 5e-2 * float(ld.abs().max())
 
 
 @pytest.mark.parametrize("mix,kv", [("q4km", "f16"), ("q4km", "bf16"), ("q8", "f16"), ("q5", "bf16")])
-def test_engine_vs_cpu_order_oracle_tiny_model(oracle, dev, request, mix, kv):
-    """Tiny dims (hidden 512) against the reference's own summation orders (mode="cpu"): positions agree to f32 noise (<= 1e-5) until an f32-order
-    difference moves one activation across an int8 rounding step.  ONE such step of one of 512 quants moves this small model's logits by up to 2.5e-2
-    of max |logit| (measured on the MI355X, q4km / f16 pages, position 5) and stays in the KV cache, so the bar is 3e-2 at every position -- the size
-    of a single moved quant, not a tolerance on the arithmetic, which the bit-identity test above pins -- plus f32 noise at position 0 and
-    identical greedy ids outside near-ties."""
+def test_engine_vs_cpu_orders_against_the_exact_model_tiny_model(oracle, dev, request, mix, kv):
+    """Tiny dims (hidden 512), the engine's GPU logits next to the reference's own summation orders, each measured against the EXACT model (dequantized
+    weights, no activation quantization, f64): position 0 agrees with order a to f32 noise (no int8 quant has moved yet), and over the greedy rollout
+    the engine's mean distance to the exact model is within 5 % of the larger CPU order's (tests/test_parity_calibration.py explains why the mean, and
+    holds the same bar on the restatement without a GPU)."""
     from oracle import llama_ref
     emu = request.config.getoption("--host-emulation")
     steps = 5 if emu else 48
     cfg, w, m, cos, sin = _mk(oracle, dev, {"q4km": Q4KM, "q8": Q8, "q5": Q5}[mix](oracle), kv)
-    ref = llama_ref.LlamaRef(cfg, w, cos, sin, mode="cpu", kv_dtype=kv)
-    worst = _greedy_parity(oracle, m, ref, cfg, steps, 3e-2, exact_frac=None if emu else 1)
-    print(f"{mix}/{kv}: worst |dlogit| / max|logit| over {steps} greedy steps = {worst:.2e}")
+    _vs_exact(m, cfg, w, cos, sin, kv, steps, f"{mix}/{kv}", check=not emu)
+
+
+def _vs_exact(m, cfg, w, cos, sin, kv, steps, label, check=True, factor=1.05):
+    from oracle import llama_ref
+    mk = lambda **k: llama_ref.LlamaRef(cfg, w, cos, sin, kv_dtype=kv, **k)
+    runs = {"a": mk(mode="cpu"), "b": mk(mode="cpu_fast", n_kv_chunks=2), "x": mk(mode="exact")}
+    tok, err = 1000 % cfg.vocab_size, {"engine": [], "a": [], "b": []}
+    for pos in range(steps):
+        lg = {k: r.step(tok, pos) for k, r in runs.items()}
+        m.set_state([tok], [pos])
+        lg["engine"] = m.forward_logits(1)[0].float().cpu().numpy()
+        scale = np.abs(lg["x"]).max()
+        for k in err:
+            err[k].append(float(np.abs(lg[k] - lg["x"]).max() / scale))
+        if pos == 0:
+            assert np.abs(lg["engine"] - lg["a"]).max() <= 1e-5 * scale
+        tok = int(lg["a"].argmax())
+    mean = {k: float(np.mean(v)) for k, v in err.items()}
+    print(f"{label}: mean distance to the exact model over {steps} positions: engine {mean['engine']:.4f}, cpu a {mean['a']:.4f}, cpu b {mean['b']:.4f}")
+    if check:
+        assert mean["engine"] <= factor * max(mean["a"], mean["b"]), mean
 
 
 _W8B = {}  # (layers, vocab, seed) -> quantized weights: the GGML quantizer search over 0.5 G weights takes ~1 minute, once per session
@@ -190,10 +211,10 @@ def _mk_8b_dims(oracle, dev, kv_dtype, layers=2, vocab=4096, seed=3, max_ctx=256
 def test_north_star_parity_8b_layer_shapes(oracle, dev, request, kv):
     """Llama-3-8B layer shapes (2 layers, N(0, 0.02^2) weights through the GGML quantizers), 24 greedy tokens, teacher-forced on the CPU-order run:
     (1) engine == mode="engine" bit for bit at every position;
-    (2) distance to mode="cpu" next to the distance between two CPU orders (mode "cpu" vs mode "cpu_fast" with two kv chunks): after the first moved
-        int8 quant every pair of orders sits at the same noise floor, so the engine's mean distance must not exceed 1.5 x the CPU pair's, its
-        worst position 1.25 x the CPU pair's worst (measured on the MI355X over 24 positions: mean 1.10 x with f16 pages, 1.34 x with bf16 pages; worst
-        1.11 x -- a 24-sample ratio of two chaotic trajectories, not a precision), and greedy ids must agree wherever the CPU run's top-2 margin exceeds both distances."""
+    (2) the exact-model calibration: engine, CPU order a (mode "cpu") and CPU order b (mode "cpu_fast" with two kv chunks) each against the exact model
+        (dequantized weights, no activation quantization, f64).  All three sit at the int8-activation noise floor (2.5e-2 .. 4.5e-2 of max |logit| on
+        this model); the engine's MEAN distance must be within 5 % of the larger CPU mean (oracle-only run of this test's model: 1.030 x with f16 pages,
+        0.967 x with bf16 pages), and greedy ids must agree with order a wherever a's top-2 margin exceeds the distances involved."""
     from oracle import llama_ref
     if request.config.getoption("--host-emulation"):
         pytest.skip("8B layer shapes are for the device")
@@ -201,12 +222,15 @@ def test_north_star_parity_8b_layer_shapes(oracle, dev, request, kv):
     ref = llama_ref.LlamaRef(cfg, w, cos, sin, mode="cpu", kv_dtype=kv)
     alt = llama_ref.LlamaRef(cfg, w, cos, sin, mode="cpu_fast", kv_dtype=kv, n_kv_chunks=2)
     mirror = llama_ref.LlamaRef(cfg, w, cos, sin, mode="engine", kv_dtype=kv)
-    tok, eng, spread, flips, cpu_flips = 1000 % cfg.vocab_size, [], [], 0, 0
+    truth = llama_ref.LlamaRef(cfg, w, cos, sin, mode="exact", kv_dtype=kv)
+    tok, eng, spread, flips, cpu_flips, vx = 1000 % cfg.vocab_size, [], [], 0, 0, {"engine": [], "a": [], "b": []}
     for pos in range(24):
-        want, other, exact = ref.step(tok, pos), alt.step(tok, pos), mirror.step(tok, pos)
+        want, other, exact, tr = ref.step(tok, pos), alt.step(tok, pos), mirror.step(tok, pos), truth.step(tok, pos)
         m.set_state([tok], [pos])
         got = m.forward_logits(1)[0].float().cpu().numpy()
         assert np.array_equal(got, exact), f"position {pos}: engine differs from the engine-order oracle ({int((got != exact).sum())} logits, max {float(np.abs(got - exact).max()):.3e})"
+        for k, lg in (("engine", got), ("a", want), ("b", other)):
+            vx[k].append(float(np.abs(lg - tr).max() / np.abs(tr).max()))
         scale = np.abs(want).max()
         eng.append(float(np.abs(got - want).max() / scale))
         spread.append(float(np.abs(other - want).max() / scale))
@@ -220,8 +244,9 @@ def test_north_star_parity_8b_layer_shapes(oracle, dev, request, kv):
         tok = int(want.argmax())
     print(f"8B layer shapes / kv {kv}: engine == engine-order oracle at 24 / 24 positions; engine-vs-cpu worst {max(eng):.2e} mean {np.mean(eng):.2e}; "
           f"cpu-vs-cpu_b worst {max(spread):.2e} mean {np.mean(spread):.2e}; near-ties {flips}; positions where the two CPU orders pick different ids: {cpu_flips}")
-    assert max(eng) <= max(1e-3, 1.25 * max(spread)), (max(eng), max(spread))
-    assert np.mean(eng) <= max(1e-3, 1.5 * np.mean(spread)), (np.mean(eng), np.mean(spread))
+    mean = {k: float(np.mean(v)) for k, v in vx.items()}
+    print(f"mean distance to the exact model: engine {mean['engine']:.4f}, cpu a {mean['a']:.4f}, cpu b {mean['b']:.4f}")
+    assert mean["engine"] <= 1.05 * max(mean["a"], mean["b"]), mean
 
 
 def test_prefill_512_tokens_at_8b_layer_shapes_vs_exact_oracle(oracle, dev, request):
@@ -384,15 +409,19 @@ def test_sliding_window_decode_and_prefill(oracle, dev, request):
         m3.set_state([t], [pos])
         ld = m3.forward_logits(1)[0].clone()
     print(f"window prefill vs decode: {float((lp - ld).abs().max()) / float(ld.abs().max()):.3e}")
-    assert float((lp - ld).abs().max()) <= 5e-2 * float(ld.abs().max())
+    if m2.prefill_is_exact:
+        assert torch.equal(lp.float(), ld.float()), "prefill (decode engine's arithmetic) != token-by-token decode"
+    else:
+        assert float((lp - ld).abs().max()) <= 5e-2 * float(ld.abs().max())
     # and the decode step after the prefill reads the pages the prefill wrote through the same window
     nxt = int(ld.argmax())
     m2.set_state([nxt], [len(prompt)]); m3.set_state([nxt], [len(prompt)])
     a, b = m2.forward_logits(1)[0], m3.forward_logits(1)[0]
     print(f"first decode after the prompt: {float((a - b).abs().max()) / float(b.abs().max()):.3e}")
-    # KV pages written by the bf16 prompt GEMMs vs pages written by the int8 decode GEMVs, read through the same window: 6.0e-2 measured on the MI355X
-    # (a 512-wide model has little to average over; a wrong slot or mask would be O(1))
-    assert float((a - b).abs().max()) <= 1e-1 * float(b.abs().max())
+    if m2.prefill_is_exact:
+        assert torch.equal(a, b), "decode after the prefill differs from decode after a token-by-token pass: the KV pages differ"
+    else:  # KV pages written by the bf16 prompt GEMMs vs pages written by the int8 decode GEMVs, read through the same window: 6.0e-2 measured on the MI355X
+        assert float((a - b).abs().max()) <= 1e-1 * float(b.abs().max())
 
 
 def test_engine_mixtral_moe_vs_cpu_path_oracle(oracle, dev, request):
@@ -400,6 +429,4 @@ def test_engine_mixtral_moe_vs_cpu_path_oracle(oracle, dev, request):
     types = dict(embd=oracle.Q4_K, q=oracle.Q4_K, k=oracle.Q4_K, v=oracle.Q6_K, o=oracle.Q4_K, gate=oracle.Q4_K, up=oracle.Q4_K, down=oracle.Q6_K, output=oracle.Q6_K)
     from oracle import llama_ref
     cfg, w, m, cos, sin = _mk(oracle, dev, types, "bf16", experts=4)
-    ref = llama_ref.LlamaRef(cfg, w, cos, sin, mode="cpu", kv_dtype="bf16")
-    worst = _greedy_parity(oracle, m, ref, cfg, steps, 3e-2, exact_frac=None if steps < 10 else 1)
-    print(f"moe: worst {worst:.2e}")
+    _vs_exact(m, cfg, w, cos, sin, "bf16", steps, "moe", check=steps >= 10, factor=1.1)  # 24 positions of a 4-expert toy: 1.046 x on the restatement
