@@ -525,6 +525,15 @@ def main():
         torch.cuda.synchronize()
 
     r = timed_run(model, cfg, a.prompt_len, a.steps, a.warmup, a.batch, sync, world, dev)
+    if tp and p2p is not None:
+        # the peer-mailbox route reports a granule that never arrived through its error word (bounded spin, NaN sums): if ANY rank saw one, every rank drops
+        # the route and the whole timed pass is repeated on RCCL -- a number measured over NaN sums is not a measurement
+        bad = torch.tensor([int(model.p2p_error() != 0)], device=dev)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad.item()):
+            model.set_p2p(None)
+            p2p, p2p_note = None, "rccl only (the p2p route raised its error word during the timed pass: dropped, pass repeated on RCCL)"
+            r = timed_run(model, cfg, a.prompt_len, a.steps, a.warmup, a.batch, sync, world, dev)
     prompt, ttft, prefill_flops, B, t_all, dev_s, toks = r["prompt"], r["ttft"], r["prefill_flops"], r["B"], r["t_all"], r["dev_s"], r["toks"]
     prefill_exact = bool(model.prefill_is_exact)
     ttft_bf16 = None

@@ -161,9 +161,10 @@ MRS_DECL_MMQ_QUANTIZE(D4) MRS_DECL_MMQ_QUANTIZE(DS4) MRS_DECL_MMQ_QUANTIZE(D2S6)
  *      the routes in expert-sorted order, expert e owns [expert_bounds[e], expert_bounds[e+1]) and channel e of x, column j lands in dst
  *      column ids_dst[j] (f32, column stride stride_col_dst).
  *      replaces kernels/mmq_gguf/mmq_instance_<t>.cu:216-259 and DEFINE_MMQ_MOE_LAUNCHER (mmq_gguf.cuh:3968-4010); Rust: ffi.rs:1410-1452,
- *      callers fast_mmq.rs:421-437 (dense), gguf/cuda.rs (grouped MoE prompt path).  MI355X note: the fast prompt path of this library is
- *      the fused block-dequant -> bf16 MFMA GEMM (mrs_gemm_q_*, include/mrs_hip_ext.h); these entry points keep fast_mmq.rs linking and
- *      numerically equivalent (integer dots, stored partial sums), at MMVQ-style throughput. */
+ *      callers fast_mmq.rs:421-437 (dense), gguf/cuda.rs (grouped MoE prompt path).  MI355X note: these entry points keep fast_mmq.rs linking and
+ *      numerically equivalent (integer dots on the stored Q8_1 images and partial sums), as LDS-tiled i8 MFMA kernels (csrc/mmq.hip,
+ *      profiles/round3_mmq.md); the C++ runner's own prompt paths are mrs_gemm_qi (the decode engine's arithmetic, default) and the fused
+ *      block-dequant -> bf16 MFMA GEMM mrs_gemm_q_* (selectable), both in include/mrs_hip_ext.h. */
 #define MRS_DECL_MMQ(t)                                                                                                                        \
   void launch_mmq_gguf_##t(void *tmp_fixup, const void *x, const void *y, void *dst, int64_t ncols_x, int64_t nrows_x, int64_t ncols_y,          \
                            int64_t stride_row_x, int64_t stride_col_dst, int cc, int nsm, int64_t smpbo, int warp_size, int type_dst,            \

@@ -21,7 +21,7 @@ class HipLibraryMissing(RuntimeError):
 
 def path(key: str) -> str:
     # MRS_EXT_LIB: an alternative BUILD of libmrs_hip_ext.so for A/B kernel experiments on the GPU box (e.g. lib/libmrs_hip_ext_occ4.so built by
-    # scripts/exp/build_occ4.sh).  Still an in-tree HIP library of the same sources; a missing file fails loudly like the default.
+    # profiles/experiments/build_occ4.sh).  Still an in-tree HIP library of the same sources; a missing file fails loudly like the default.
     if key == "ext" and os.environ.get("MRS_EXT_LIB"):
         p = os.environ["MRS_EXT_LIB"]
         return p if os.path.isabs(p) else os.path.join(LIB_DIR, p)

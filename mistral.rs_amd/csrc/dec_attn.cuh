@@ -24,11 +24,98 @@ struct AttnArgs {
                // mistralrs-core/src/paged_attention/layers/paged_attention.rs:551-553: key <= pos - window is too old); 0 = all
 };
 
+// One 32-token KV block of one kv head in registers: lane (t = lane & 31, half = lane >> 5) holds K dims [(half * 8 + c) * 8, +8) of token t in kr[c];
+// lane d holds V dims d (vr[0..3]) and d + 64 (vr[4..7]) of the 32 tokens.
+template <bool WITH_V>
+__device__ __forceinline__ void attn_load_block(const AttnArgs &a, size_t base, int4 (&kr)[8], int4 (&vr)[8]) {
+  constexpr int BS = 32;
+  const int lane = lane_opaque(), t = lane & 31, half = lane >> 5;
+  const uint16_t *kb = a.k_cache + base + (size_t)(half * 8) * BS * 8 + t * 8;
+  const uint16_t *vb = a.v_cache + base;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) kr[c] = *(const int4 *)(kb + (size_t)c * BS * 8);
+  if (WITH_V) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) vr[r * 4 + c] = *(const int4 *)(vb + (size_t)(lane + 64 * r) * BS + c * 8);
+  }
+}
+// The online-softmax update of one block for the G query heads in q_s (G * 128 floats of wave-private LDS; p_s: G * 32): scores by fma chains over the lane's 64
+// dims + the other half, block max / sum trees, fast_exp, (WITH_V) o = o * alpha + P.V by fma chains.  `first` = first block of the split (l = o = 0: no correction).
+// EVERY engine attention path (decode split kernel, prompt kernel) goes through this function: same bits.
+template <int G, class CT, bool WITH_V>
+__device__ __forceinline__ void attn_block_update(const AttnArgs &a, const int4 (&kr)[8], const int4 (&vr)[8], const float *q_s, float *p_s, int b, bool first, int ctx,
+                                                  int lo, float (&m)[G], float (&l)[G], float (&o0)[G], float (&o1)[G]) {
+  constexpr int HD = 128, BS = 32;
+  const int lane = lane_opaque(), t = lane & 31, half = lane >> 5;
+  float s[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) s[g] = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    float kf[8];
+    unpack16<CT>(kr[c], kf);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const float4 qa = *(const float4 *)(q_s + g * HD + (half * 8 + c) * 8);
+      const float4 qb = *(const float4 *)(q_s + g * HD + (half * 8 + c) * 8 + 4);
+      s[g] = fmaf(qa.x, kf[0], s[g]); s[g] = fmaf(qa.y, kf[1], s[g]); s[g] = fmaf(qa.z, kf[2], s[g]); s[g] = fmaf(qa.w, kf[3], s[g]);
+      s[g] = fmaf(qb.x, kf[4], s[g]); s[g] = fmaf(qb.y, kf[5], s[g]); s[g] = fmaf(qb.z, kf[6], s[g]); s[g] = fmaf(qb.w, kf[7], s[g]);
+    }
+  }
+  const bool valid = b * BS + t < ctx && b * BS + t >= lo;
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    float v = s[g] + __shfl_xor(s[g], 32, 64);
+    v = valid ? v * a.scale : -FLT_MAX;
+    float mx = v;
+    mx = fmaxf(mx, dpp_f<0xB1>(mx)); mx = fmaxf(mx, dpp_f<0x4E>(mx)); mx = fmaxf(mx, dpp_f<0x141>(mx)); mx = fmaxf(mx, dpp_f<0x140>(mx));
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    const float mn = fmaxf(m[g], mx);
+    const float p = valid ? fast_exp_ref(v - mn) : 0.f;
+    float ps = p;
+    ps += dpp_f<0xB1>(ps); ps += dpp_f<0x4E>(ps); ps += dpp_f<0x141>(ps); ps += dpp_f<0x140>(ps);
+    ps += __shfl_xor(ps, 16, 64);
+    if (first) {  // first block of the split: l = o = 0, so l * alpha + ps == ps and o * alpha == 0 bit for bit -- no correction to compute
+      l[g] = ps;
+    } else {
+      const float alpha = fast_exp_ref(m[g] - mn);
+      l[g] = l[g] * alpha + ps;
+      if (WITH_V) { o0[g] *= alpha; o1[g] *= alpha; }
+    }
+    m[g] = mn;
+    if (WITH_V && half == 0) p_s[g * BS + t] = p;
+  }
+  if (!WITH_V) return;
+  MRS_WAVE_SYNC();
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float vf[8];
+      unpack16<CT>(vr[r * 4 + c], vf);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) vf[j] = (b * BS + c * 8 + j < ctx) ? vf[j] : 0.f;  // stale slots may hold NaNs
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float4 pa = *(const float4 *)(p_s + g * BS + c * 8);
+        const float4 pb = *(const float4 *)(p_s + g * BS + c * 8 + 4);
+        float acc = r == 0 ? o0[g] : o1[g];
+        acc = fmaf(pa.x, vf[0], acc); acc = fmaf(pa.y, vf[1], acc); acc = fmaf(pa.z, vf[2], acc); acc = fmaf(pa.w, vf[3], acc);
+        acc = fmaf(pb.x, vf[4], acc); acc = fmaf(pb.y, vf[5], acc); acc = fmaf(pb.z, vf[6], acc); acc = fmaf(pb.w, vf[7], acc);
+        if (r == 0) o0[g] = acc; else o1[g] = acc;
+      }
+    }
+  }
+  MRS_WAVE_SYNC();
+}
+
 // q_s: G * 128 floats, p_s: G * 32 floats of wave-private LDS; the item covers query heads [head0, head0 + G) of kv head kvh
 // blocks [b0, b1) of the sequence; sink(g, o0, o1, m, l) receives the un-normalised partial of query head head0 + g (o0 / o1: dims lane / lane + 64)
 template <int G, class CT, class Sink>
 __device__ __forceinline__ void attn_split_core(const AttnArgs &a, int kvh, int head0, int seq, int b0, int b1, float *q_s, float *p_s, Sink sink, int first_page = -1) {
-  constexpr int HD = 128, BS = 32;
+  constexpr int HD = 128;
   const int lane = lane_opaque();
   const int ctx = (int)a.context_lens[seq];
   const int lo = a.window > 0 && ctx > a.window ? ctx - a.window : 0;  // first position inside the window (the query sits at ctx - 1)
@@ -37,80 +124,14 @@ __device__ __forceinline__ void attn_split_core(const AttnArgs &a, int kvh, int 
   for (int i = lane * 4; i < G * HD; i += 256) *(float4 *)(q_s + i) = *(const float4 *)(qg + i);
   MRS_WAVE_SYNC();
   const uint32_t *bt = a.block_tables + (size_t)seq * a.max_blocks_per_seq;
-  const int t = lane & 31, half = lane >> 5;
   float m[G], l[G], o0[G], o1[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) { m[g] = -FLT_MAX; l[g] = 0.f; o0[g] = 0.f; o1[g] = 0.f; }
   for (int b = b0; b < b1; ++b) {
     const size_t base = (size_t)(b == b0 && first_page >= 0 ? (unsigned)first_page : bt[b]) * a.kv_block_stride + (size_t)kvh * a.kv_head_stride;  // first_page: loaded by the caller ahead of the context length
-    const uint16_t *kb = a.k_cache + base + (size_t)(half * 8) * BS * 8 + t * 8;
-    const uint16_t *vb = a.v_cache + base;
     int4 kr[8], vr[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) kr[c] = *(const int4 *)(kb + (size_t)c * BS * 8);
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) vr[r * 4 + c] = *(const int4 *)(vb + (size_t)(lane + 64 * r) * BS + c * 8);
-    float s[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) s[g] = 0.f;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      float kf[8];
-      unpack16<CT>(kr[c], kf);
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const float4 qa = *(const float4 *)(q_s + g * HD + (half * 8 + c) * 8);
-        const float4 qb = *(const float4 *)(q_s + g * HD + (half * 8 + c) * 8 + 4);
-        s[g] = fmaf(qa.x, kf[0], s[g]); s[g] = fmaf(qa.y, kf[1], s[g]); s[g] = fmaf(qa.z, kf[2], s[g]); s[g] = fmaf(qa.w, kf[3], s[g]);
-        s[g] = fmaf(qb.x, kf[4], s[g]); s[g] = fmaf(qb.y, kf[5], s[g]); s[g] = fmaf(qb.z, kf[6], s[g]); s[g] = fmaf(qb.w, kf[7], s[g]);
-      }
-    }
-    const bool valid = b * BS + t < ctx && b * BS + t >= lo;
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      float v = s[g] + __shfl_xor(s[g], 32, 64);
-      v = valid ? v * a.scale : -FLT_MAX;
-      float mx = v;
-      mx = fmaxf(mx, dpp_f<0xB1>(mx)); mx = fmaxf(mx, dpp_f<0x4E>(mx)); mx = fmaxf(mx, dpp_f<0x141>(mx)); mx = fmaxf(mx, dpp_f<0x140>(mx));
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      const float mn = fmaxf(m[g], mx);
-      const float p = valid ? fast_exp_ref(v - mn) : 0.f;
-      float ps = p;
-      ps += dpp_f<0xB1>(ps); ps += dpp_f<0x4E>(ps); ps += dpp_f<0x141>(ps); ps += dpp_f<0x140>(ps);
-      ps += __shfl_xor(ps, 16, 64);
-      if (b == b0) {  // first block of the split: l = o = 0, so l * alpha + ps == ps and o * alpha == 0 bit for bit -- no correction to compute
-        l[g] = ps;
-      } else {
-        const float alpha = fast_exp_ref(m[g] - mn);
-        l[g] = l[g] * alpha + ps;
-        o0[g] *= alpha; o1[g] *= alpha;
-      }
-      m[g] = mn;
-      if (half == 0) p_s[g * BS + t] = p;
-    }
-    MRS_WAVE_SYNC();
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        float vf[8];
-        unpack16<CT>(vr[r * 4 + c], vf);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) vf[j] = (b * BS + c * 8 + j < ctx) ? vf[j] : 0.f;  // stale slots may hold NaNs
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          const float4 pa = *(const float4 *)(p_s + g * BS + c * 8);
-          const float4 pb = *(const float4 *)(p_s + g * BS + c * 8 + 4);
-          float acc = r == 0 ? o0[g] : o1[g];
-          acc = fmaf(pa.x, vf[0], acc); acc = fmaf(pa.y, vf[1], acc); acc = fmaf(pa.z, vf[2], acc); acc = fmaf(pa.w, vf[3], acc);
-          acc = fmaf(pb.x, vf[4], acc); acc = fmaf(pb.y, vf[5], acc); acc = fmaf(pb.z, vf[6], acc); acc = fmaf(pb.w, vf[7], acc);
-          if (r == 0) o0[g] = acc; else o1[g] = acc;
-        }
-      }
-    }
-    MRS_WAVE_SYNC();
+    attn_load_block<true>(a, base, kr, vr);
+    attn_block_update<G, CT, true>(a, kr, vr, q_s, p_s, b, b == b0, ctx, lo, m, l, o0, o1);
   }
 #pragma unroll
   for (int g = 0; g < G; ++g) sink(g, o0[g], o1[g], m[g], l[g]);

@@ -578,7 +578,7 @@ __global__ void __launch_bounds__(HT) gemm_qb_kernel(const GemmBArgs a) {
 // LDS per k-step: 48 KiB written + 96 KiB read (a 128 x 64 wave tile reads 24 KiB per 32 MFMAs instead of 16 KiB per 16).
 // One barrier per k-step, hit by both kinds (s_barrier counts waves, not call sites).
 #ifndef MRS_GEMM_ABLATE
-#define MRS_GEMM_ABLATE 0  // experiment builds only (scripts/exp/build_gemm_ablate.sh): 1 no decode arithmetic, 2 producers idle, 4 no MFMA, 8 no fragment reads, 16 no A copies
+#define MRS_GEMM_ABLATE 0  // experiment builds only (profiles/experiments/build_gemm_ablate.sh): 1 no decode arithmetic, 2 producers idle, 4 no MFMA, 8 no fragment reads, 16 no A copies
 #endif
 template <int TYPE, bool GLU = false>
 __global__ void __launch_bounds__(HT) gemm_qc_kernel(const GemmBArgs a) {

@@ -24,6 +24,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 
 namespace mrs {
 namespace qi {
@@ -474,40 +475,95 @@ extern "C" int mrs_gemm_qi_ws(const void *w_qi, int type, int N, int K, const vo
 #include "dec_attn.cuh"
 namespace mrs {
 namespace qi {
-template <int G, class CT>
-__global__ void __launch_bounds__(256) prefill_attn_exact_kernel(const dec::AttnArgs a, const int start_pos) {
+// One wave owns `qw` consecutive prompt tokens of one kv head (a workgroup = 4 waves = 4 * qw tokens) and walks the splits of their contexts in ascending order; with one
+// block per split (max_context_len <= 2048, ONE) the K / V block sits in registers once for all `qw` queries -- the L2 traffic of a prompt drops by 4 * qw / (1.5) against one
+// workgroup per token.  Per QUERY the arithmetic is the decode kernel's: every split's (m, l, o) comes from dec::attn_block_update (the function dec::attn_split_core runs),
+// and the merge is dec::attn_merge_core's (weights fast_exp(m_j - max m), sums in ascending split order, multiply and add separate).  Because the merge weights need the
+// maximum over ALL splits, the walk runs twice: pass A computes (m_j, l_j) from K alone, pass B recomputes the same scores (same inputs, same instructions: same bits), forms
+// o_j and accumulates o_j * w_j at once -- no partial is ever stored.
+template <int G, class CT, bool ONE>
+__global__ void __launch_bounds__(256) prefill_attn_exact_kernel(const dec::AttnArgs a, const int qw) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int HD = 128;
   const int tid = tid_opaque(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kvh = blockIdx.x, t = (int)gridDim.y - 1 - (int)blockIdx.y;  // longest contexts first
-  const int ms = a.max_splits;
-  float *po = (float *)smem;                       // [G][ms][128]
-  float *pm = po + (size_t)G * ms * HD, *pl = pm + G * ms;  // [G][ms]
-  float *q_s = pl + G * ms + wave * (G * HD + G * 32), *p_s = q_s + G * HD;
-  const int ctx = (int)a.context_lens[t];
-  const int nblk = (ctx + 31) / 32, ns = (nblk + a.bpw - 1) / a.bpw;
-  const int lo_w = a.window > 0 && ctx > a.window ? ctx - a.window : 0;
-  for (int sp = wave; sp < ns; sp += 4) {
-    const int b0 = sp * a.bpw, b1 = min(b0 + a.bpw, nblk);
-    auto keep = [&](int g, float o0, float o1, float m, float l) {
-      float *o = po + ((size_t)g * ms + sp) * HD;
-      o[lane] = o0; o[lane + 64] = o1;
-      if (lane == 0) { pm[g * ms + sp] = m; pl[g * ms + sp] = l; }
-    };
-    if (b1 * 32 <= lo_w) {  // the split lies before the sliding window: what a fully masked pass gives (mrs_dec_attention publishes the same)
+  const int kvh = blockIdx.x, tile = (int)gridDim.y - 1 - (int)blockIdx.y;  // longest contexts first
+  const int T = a.num_seqs, ms = a.max_splits, bpw = a.bpw;
+  const int t0 = (tile * 4 + wave) * qw, nq = min(qw, T - t0);
+  if (nq <= 0) return;  // no workgroup barrier below: a wave may leave
+  const size_t per_wave = (size_t)qw * G * HD * 2 + G * 32 + (size_t)qw * G * ms * 2 + (size_t)qw * G;
+  float *q_s = (float *)smem + wave * per_wave, *p_s = q_s + (size_t)qw * G * HD, *acc = p_s + G * 32, *ml = acc + (size_t)qw * G * HD, *sall = ml + (size_t)qw * G * ms * 2;
+  int ctx_max = 0;
+  for (int i = 0; i < nq; ++i) {
+    const float *qg = a.q + (size_t)(t0 + i) * a.q_stride + (size_t)kvh * G * HD;
+    for (int k = lane * 4; k < G * HD; k += 256) *(float4 *)(q_s + (size_t)i * G * HD + k) = *(const float4 *)(qg + k);
+    for (int k = lane; k < G * HD; k += 64) acc[(size_t)i * G * HD + k] = 0.f;
+    ctx_max = max(ctx_max, (int)a.context_lens[t0 + i]);
+  }
+  for (int k = lane; k < nq * G; k += 64) sall[k] = 0.f;
+  MRS_WAVE_SYNC();
+  const uint32_t *bt = a.block_tables;  // one sequence: every token reads the same row
+  const int ns_w = (((ctx_max + 31) / 32) + bpw - 1) / bpw;
+  auto base_of = [&](int b) { return (size_t)bt[b] * a.kv_block_stride + (size_t)kvh * a.kv_head_stride; };
+  auto walk = [&](auto with_v) {
+    constexpr bool WITH_V = decltype(with_v)::value;
+    for (int sp = 0; sp < ns_w; ++sp) {
+      const int b0 = sp * bpw;
+      int4 kr[8], vr[8];
+      if (ONE) dec::attn_load_block<WITH_V>(a, base_of(b0), kr, vr);
+      for (int i = 0; i < nq; ++i) {
+        const int ctx = (int)a.context_lens[t0 + i], nblk = (ctx + 31) / 32;
+        if (sp >= (nblk + bpw - 1) / bpw) continue;  // this token's decode step has no such split
+        const int b1 = min(b0 + bpw, nblk), lo = a.window > 0 && ctx > a.window ? ctx - a.window : 0;
+        float m[G], l[G], o0[G], o1[G];
 #pragma unroll
-      for (int g = 0; g < G; ++g) keep(g, 0.f, 0.f, -FLT_MAX, 0.f);
-    } else {
-      dec::attn_split_core<G, CT>(a, kvh, kvh * G, t, b0, b1, q_s, p_s, keep);
+        for (int g = 0; g < G; ++g) { m[g] = -FLT_MAX; l[g] = 0.f; o0[g] = 0.f; o1[g] = 0.f; }
+        if (b1 * 32 > lo) {  // else: the split lies before the sliding window -- what a fully masked pass gives (mrs_dec_attention publishes the same)
+          for (int b = b0; b < b1; ++b) {
+            if (!ONE) dec::attn_load_block<WITH_V>(a, base_of(b), kr, vr);
+            dec::attn_block_update<G, CT, WITH_V>(a, kr, vr, q_s + (size_t)i * G * HD, p_s, b, b == b0, ctx, lo, m, l, o0, o1);
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          float *e = ml + ((size_t)(i * G + g) * ms + sp) * 2;
+          if (!WITH_V) {
+            e[0] = m[g]; e[1] = l[g];  // every lane writes the same value
+          } else {  // dec::attn_merge_core, one split: s += l_j * w_j; acc += o_j * w_j
+            const float wj = e[0], lw = l[g] * wj;
+            sall[i * G + g] = sall[i * G + g] + lw;
+            float *ao = acc + (size_t)(i * G + g) * HD;
+            const float u0 = o0[g] * wj, u1 = o1[g] * wj;
+            ao[lane] = ao[lane] + u0;
+            ao[lane + 64] = ao[lane + 64] + u1;
+          }
+        }
+      }
+    }
+  };
+  walk(std::false_type{});
+  MRS_WAVE_SYNC();
+  for (int i = 0; i < nq; ++i) {  // merge weights: w_j = fast_exp(m_j - max_j m_j), lane j <-> split j
+    const int nblk = ((int)a.context_lens[t0 + i] + 31) / 32, ns = (nblk + bpw - 1) / bpw;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      float *e = ml + (size_t)(i * G + g) * ms * 2;
+      const float mj = lane < ns ? e[lane * 2] : -FLT_MAX;
+      const float mx = wave_max(mj);
+      const float w = fast_exp_ref(mj - mx);
+      if (lane < ns) e[lane * 2] = w;
     }
   }
-  __syncthreads();
-  for (int g = wave; g < G; g += 4) {
-    float v0, v1;
-    dec::attn_merge_core(ns, pm + g * ms, pl + g * ms, po + (size_t)g * ms * HD, v0, v1);
-    float *o = a.out + ((size_t)t * a.num_heads + kvh * G + g) * HD;
-    o[lane] = v0; o[lane + 64] = v1;
-  }
+  MRS_WAVE_SYNC();
+  walk(std::true_type{});
+  MRS_WAVE_SYNC();
+  for (int i = 0; i < nq; ++i)
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const float inv = 1.0f / sall[i * G + g];
+      const float *ao = acc + (size_t)(i * G + g) * HD;
+      float *o = a.out + ((size_t)(t0 + i) * a.num_heads + kvh * G + g) * HD;
+      o[lane] = ao[lane] * inv; o[lane + 64] = ao[lane + 64] * inv;
+    }
 }
 }  // namespace qi
 }  // namespace mrs
@@ -526,14 +582,19 @@ extern "C" int mrs_prefill_attention_exact(const float *q, const void *k_cache, 
   a.kv_block_stride = kv_block_stride; a.kv_head_stride = kv_head_stride; a.num_seqs = T; a.scale = scale; a.window = sliding_window > 0 ? sliding_window : 0;
   const int nblk = (max_context_len + 31) / 32;
   a.bpw = nblk <= 64 ? 1 : (nblk + 63) / 64;  // == mrs_dec_attention
-  // partials kept in LDS: as many splits as the longest context of this prompt needs (<= 64 by the rule above); fewer splits = more workgroups per CU
+  // (w_j, l_j) per split live in LDS: as many splits as the longest context of this prompt needs (<= 64 by the rule above)
   const int need_ctx = max_prompt_ctx > 0 && max_prompt_ctx < max_context_len ? max_prompt_ctx : max_context_len;
   a.max_splits = std::max(1, std::min(64, (((need_ctx + 31) / 32) + a.bpw - 1) / a.bpw));
-  const size_t lds = ((size_t)G * a.max_splits * 128 + 2 * (size_t)G * a.max_splits + 4 * ((size_t)G * 128 + (size_t)G * 32)) * 4;
+  static const int qw_env = [] { const char *e = getenv("MRS_PREFILL_ATTN_QW"); return e ? atoi(e) : 0; }();
+  int qw = qw_env > 0 ? qw_env : 4;  // prompt tokens per wave
+  auto lds_for = [&](int w) { return 4 * ((size_t)w * G * 128 * 2 + (size_t)G * 32 + (size_t)w * G * a.max_splits * 2 + (size_t)w * G) * 4; };
+  while (qw > 1 && (lds_for(qw) > 76 * 1024 || (T + 4 * qw - 1) / (4 * qw) * num_kv_heads < 512)) --qw;  // two workgroups per CU, and enough workgroups to fill the chip
+  const size_t lds = lds_for(qw);
   if (lds > 158 * 1024) return -2;
-  const dim3 grid(num_kv_heads, T);
+  const dim3 grid(num_kv_heads, (T + 4 * qw - 1) / (4 * qw));
   hipStream_t s = (hipStream_t)stream;
-#define MRS_PA(GG, CT) { auto kern = mrs::qi::prefill_attn_exact_kernel<GG, CT>; mrs::lds_attr_once((const void *)kern, 158 * 1024); hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a, 0); }
+#define MRS_PA(GG, CT) { if (a.bpw == 1) { auto kern = mrs::qi::prefill_attn_exact_kernel<GG, CT, true>; mrs::lds_attr_once((const void *)kern, 158 * 1024); hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a, qw); } \
+                         else { auto kern = mrs::qi::prefill_attn_exact_kernel<GG, CT, false>; mrs::lds_attr_once((const void *)kern, 158 * 1024); hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a, qw); } }
 #define MRS_PAG(CT) switch (G) { case 1: MRS_PA(1, CT) break; case 2: MRS_PA(2, CT) break; case 4: MRS_PA(4, CT) break; default: MRS_PA(8, CT) break; }
   if (kv_dtype == 1) { MRS_PAG(mrs::bf16_t) } else { MRS_PAG(mrs::f16_t) }
 #undef MRS_PAG

@@ -59,6 +59,7 @@ __device__ __forceinline__ void wg_slice(size_t count, size_t &i0, size_t &i1) {
   i1 = i0 + per < count ? i0 + per : count;
   if (i0 > count) i0 = count;
 }
+constexpr unsigned long long SPIN_TICKS = 1000000ull;  // 10 ms at 100 MHz
 __device__ __forceinline__ void post(const Comm &c, const float *buf, size_t count, unsigned seq) {
   const size_t half = (size_t)(seq & 1) * c.world * c.max_elems;
   size_t i0, i1;
@@ -87,10 +88,16 @@ __device__ __forceinline__ bool reduce(const Comm &c, float *buf, size_t count, 
     for (int r = 0; r < c.world; ++r) {
       const unsigned long long *p = c.mail[c.rank] + half + (size_t)r * c.max_elems + i;
       unsigned long long g = MRS_P2P_LOAD(p);
-      for (unsigned spins = 0; (unsigned)(g >> 32) != seq; ++spins) {
-        if (spins > (1u << 24)) { mine = false; break; }
-        __builtin_amdgcn_s_sleep(1);
-        g = MRS_P2P_LOAD(p);
+      if ((unsigned)(g >> 32) != seq) {
+        // bounded by TIME, not by iterations: ~10 ms of the 100 MHz s_memrealtime clock -- three orders of magnitude above a healthy hop (a few us),
+        // short enough that a peer that is not running the same sequence of all-reduces costs one step, not the job (the host reads the error word
+        // at its next synchronisation point and falls back to RCCL: Llama.p2p_error, bench.py)
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        do {
+          if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_TICKS) { mine = false; break; }
+          __builtin_amdgcn_s_sleep(1);
+          g = MRS_P2P_LOAD(p);
+        } while ((unsigned)(g >> 32) != seq);
       }
       sum += __uint_as_float((unsigned)g);  // rank order: identical bits on every rank
     }

@@ -577,7 +577,7 @@ class Llama {
     const int want = prefill_mode >= 0 ? prefill_mode : env_want;
     if (!want || cfg.use_fused != 2 || !engine_ok() || cfg.world_size > 1 || cfg.num_experts > 0 || cfg.head_dim != 128 || cfg.block_size != 32) return false;
     const int G = cfg.num_heads / std::max(1, (int)cfg.num_kv_heads);
-    if (cfg.num_heads % cfg.num_kv_heads || (G != 1 && G != 2 && G != 4)) return false;
+    if (cfg.num_heads % cfg.num_kv_heads || (G != 1 && G != 2 && G != 4 && G != 8)) return false;
     for (const Block &bl : blocks) {
       const GgufMatMul *ls[7] = {bl.q_proj.get(), bl.k_proj.get(), bl.v_proj.get(), bl.o_proj.get(), bl.gate_proj.get(), bl.up_proj.get(), bl.down_proj.get()};
       for (const GgufMatMul *l : ls)

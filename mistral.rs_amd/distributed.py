@@ -240,6 +240,7 @@ class P2PAllReduce:
         # Every step that can fail on one rank only is followed by an exchange of the outcome, so that all ranks leave through the same door
         # (a rank that raised while its peers sit in a collective would hang the job instead of falling back to RCCL).
         err, mine = None, (C.c_char * 64)()
+        self.handle, self._peer_ptrs = None, []
         self.mailbox_ptr = L.mrs_p2p_alloc_mailbox(L.mrs_p2p_mailbox_bytes(world_size, max_elems))
         if not self.mailbox_ptr:
             err = "mailbox allocation: " + (L.mrs_last_error() or b"").decode()
@@ -261,6 +262,7 @@ class P2PAllReduce:
                 err = f"hipIpcOpenMemHandle(rank {r}): " + (L.mrs_last_error() or b"").decode()
                 break
             ptrs[r] = p
+            self._peer_ptrs.append(p)
         got2 = [None] * world_size
         dist.all_gather_object(got2, err)  # also the barrier: every mailbox is zeroed and mapped before the first granule is written
         bad = [f"rank {r}: {e}" for r, e in enumerate(got2) if e]
@@ -268,13 +270,38 @@ class P2PAllReduce:
             self._release()
             raise RuntimeError("p2p all-reduce unavailable (" + "; ".join(bad) + ")")
         self.handle = L.mrs_p2p_create(rank, world_size, ptrs, max_elems)
-        if not self.handle:
-            raise RuntimeError((L.mrs_last_error() or b"").decode())
+        got3 = [None] * world_size
+        dist.all_gather_object(got3, None if self.handle else "mrs_p2p_create: " + (L.mrs_last_error() or b"").decode())
+        bad = [f"rank {r}: {e}" for r, e in enumerate(got3) if e]
+        if bad:  # the last step that can fail on one rank only: exchanged like the others, so no rank starts polling a peer that gave up
+            self._release()
+            raise RuntimeError("p2p all-reduce unavailable (" + "; ".join(bad) + ")")
 
     def _release(self) -> None:
+        """Free everything this object opened, in reverse order (idempotent): the Comm, the peers' mapped mailboxes, the own mailbox."""
+        L = self._L
+        if getattr(self, "handle", None):
+            L.mrs_p2p_destroy.argtypes = [C.c_void_p]
+            L.mrs_p2p_destroy(self.handle)
+            self.handle = None
+        L.mrs_ipc_close_handle.argtypes = [C.c_void_p]
+        for p in getattr(self, "_peer_ptrs", []):
+            L.mrs_ipc_close_handle(p)
+        self._peer_ptrs = []
         if getattr(self, "mailbox_ptr", None):
-            self._L.mrs_p2p_free_mailbox(self.mailbox_ptr)
+            L.mrs_p2p_free_mailbox(self.mailbox_ptr)
             self.mailbox_ptr = None
+
+    def close(self) -> None:
+        """Release the mailbox, the peer mappings and the Comm.  The caller must have synchronised the device (no all-reduce in flight) and detached the
+        object from any runner (Llama.set_p2p(None)) first."""
+        self._release()
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
 
     def all_reduce_(self, t: torch.Tensor) -> torch.Tensor:
         assert t.dtype == torch.float32 and t.is_contiguous()

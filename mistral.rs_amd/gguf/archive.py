@@ -170,17 +170,31 @@ class GgufArchive:
                 raise GgufError(f"GGUF metadata is missing required key `{arch}.{k}`")
             return md[f"{arch}.{k}"]
 
-        def req_uint(k, nonzero=False):
+        def req_uint(k, nonzero=False, uniform=False):
+            """required_usize / required_uniform_usize / required_uniform_nonzero_usize (normal_config.rs:594-640,983-1002): `uniform` keys may be a
+            per-layer array as long as every (non-zero, for `nonzero`) entry is the same value."""
             v = req(k)
-            if isinstance(v, bool) or not isinstance(v, (int, np.integer)) or int(v) < 0:
+            if uniform and isinstance(v, (list, tuple, np.ndarray)):
+                vals = list(np.asarray(v).reshape(-1))
+            else:
+                vals = [v]
+            if any(isinstance(x, (bool, np.bool_)) or not isinstance(x, (int, np.integer)) or int(x) < 0 for x in vals):
                 raise GgufError(f"GGUF metadata `{arch}.{k}` must be a non-negative integer fitting this platform")
-            if nonzero and int(v) == 0:
-                raise GgufError(f"GGUF metadata `{arch}.{k}` has no non-zero value")
-            return int(v)
+            vals = [int(x) for x in vals]
+            if nonzero:
+                vals = [x for x in vals if x != 0]
+                if not vals:
+                    raise GgufError(f"GGUF metadata `{arch}.{k}` has no non-zero value")
+            if not vals:
+                raise GgufError(f"GGUF metadata `{arch}.{k}` cannot be an empty array")
+            if any(x != vals[0] for x in vals):
+                raise GgufError(f"Native `{arch}` config cannot represent per-layer `{arch}.{k}` values {vals}; provide the original Hugging Face config "
+                                "or use a compatible architecture path")
+            return vals[0]
         # StandardFields::read_with_intermediate_size (gguf/normal_config.rs:897-925): every field below is REQUIRED there -- no silent defaults
-        heads = req_uint("attention.head_count")
-        d = req_uint("embedding_length")
-        kv_heads = req_uint("attention.head_count_kv", nonzero=True)
+        heads = req_uint("attention.head_count", uniform=True)
+        d = req_uint("embedding_length", uniform=True)
+        kv_heads = req_uint("attention.head_count_kv", nonzero=True, uniform=True)
         ctx_len = req_uint("context_length")
         eps = md.get(f"{arch}.attention.layer_norm_rms_epsilon", md.get(f"{arch}.attention.layer_norm_epsilon"))
         if eps is None:  # normal_config.rs:748-761
@@ -205,7 +219,7 @@ class GgufArchive:
         scaling = None
         if md.get(f"{arch}.rope.scaling.type") == "linear":
             scaling = RopeScaling("linear", float(md.get(f"{arch}.rope.scaling.factor", 1.0)))
-        kw = dict(hidden_size=d, intermediate_size=req_uint("feed_forward_length"), num_layers=req_uint("block_count"), num_heads=heads,
+        kw = dict(hidden_size=d, intermediate_size=req_uint("feed_forward_length", uniform=True), num_layers=req_uint("block_count"), num_heads=heads,
                   num_kv_heads=kv_heads, vocab_size=int(vocab), head_dim=head_dim,
                   rms_eps=float(eps), rope_theta=float(md.get(f"{arch}.rope.freq_base", 10000.0)),
                   rope_scaling=scaling, rope_interleaved=True,  # GGUF llama/mistral: adjacent pairs (normal_registry.rs:446-461)

@@ -128,6 +128,8 @@ class GgufMatMul:
         from .. import isq
         if dtype is None:
             return self
+        if dtype == self.w.dtype and imatrix_weight is None:  # gguf/mod.rs:645-657: same type, no importance vector -> the layer is returned untouched,
+            return self                                       # BEFORE the rank is looked at (no lossy dequantize -> re-quantize of expert stacks either)
         if len(self.w.shape) == 3:
             out = isq.quantize_expert_stack(self.dequantize_w(torch.float32), dtype, imatrix_weight)
             return GgufMatMul(out, self.b, self.prompt_route)

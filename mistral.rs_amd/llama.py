@@ -243,10 +243,17 @@ class Llama:
         self._chk(self._L.mrs_llama_set_comm(self._h, comm.handle))
 
     def set_p2p(self, p2p) -> None:
-        """Attach the one-shot peer-mailbox all-reduce (distributed.P2PAllReduce): decode-sized row-parallel all-reduces take it, larger ones RCCL."""
+        """Attach the one-shot peer-mailbox all-reduce (distributed.P2PAllReduce): decode-sized row-parallel all-reduces take it, larger ones RCCL.
+        None detaches it (every all-reduce on RCCL again); a captured decode graph must be re-captured afterwards."""
         self._p2p = p2p
         self._L.mrs_llama_set_p2p.argtypes = [C.c_void_p, C.c_void_p]
-        self._chk(self._L.mrs_llama_set_p2p(self._h, p2p.handle))
+        self._chk(self._L.mrs_llama_set_p2p(self._h, p2p.handle if p2p is not None else None))
+
+    def p2p_error(self) -> int:
+        """Error word of the peer-mailbox route (blocking device read; call where the host synchronises anyway -- after a run of decode steps, before
+        tokens are handed out): non-zero = some granule never arrived within the bounded spin (ext_p2p.hip, ~10 ms) and the affected sums are NaN.
+        The caller drops the route (set_p2p(None) -> RCCL) and repeats the steps since its last check; bench.py does exactly that."""
+        return 0 if getattr(self, "_p2p", None) is None else self._p2p.error()
 
     def set_tensor(self, name: str, t) -> None:
         """t: QTensor (packed GGUF blocks) or an f32 torch tensor (norm weights)."""

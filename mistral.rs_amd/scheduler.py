@@ -325,14 +325,16 @@ class PagedEngine:
                     self._finish_token(seq, last)
         elif out.kind == "completion":
             self.steps["completion"] += 1
-            rows = out.scheduled[: self.cfg.max_batch]
-            for i, seq in enumerate(rows):
-                self.m.block_tables[i] = self._table(seq)
-            self.m.set_state([s.tokens[-1] for s in rows], [len(s) - 1 for s in rows])
-            logits = self.m.forward_logits(len(rows))
-            for i, seq in enumerate(rows):
-                seq.num_computed_tokens = len(seq)
-                self._finish_token(seq, logits[i])
+            # every scheduled row decodes in THIS step (the scheduler has reserved its slot and counted the step): launches of up to max_batch rows
+            for r0 in range(0, len(out.scheduled), self.cfg.max_batch):
+                rows = out.scheduled[r0: r0 + self.cfg.max_batch]
+                for i, seq in enumerate(rows):
+                    self.m.block_tables[i] = self._table(seq)
+                self.m.set_state([s.tokens[-1] for s in rows], [len(s) - 1 for s in rows])
+                logits = self.m.forward_logits(len(rows)).clone()
+                for i, seq in enumerate(rows):
+                    seq.num_computed_tokens = len(seq)
+                    self._finish_token(seq, logits[i])
         self.s.free_finished_sequence_groups()
         return out.kind
 

@@ -18,7 +18,7 @@
  *                   dependency, not vendored: restated from its published source): sum of squares in f32 in element order,
  *                   m = sqrt(sum / d + eps), y_i = x_i / m * w_i.   Call site: mistralrs-core/src/layers.rs:403-414.
  *       SiLU        x / (1 + exp(-x)) with libm expf (mistralrs-quant/src/utils/ops.rs:2601-2612) -- ggml_oracle.c orc_glu_act.
- * (2) "engine" order -- the same operations with the summation trees of mistral.rs_amd/csrc (dec_core.cuh act_finish,
+ * (2) "engine" order -- the same operations with the summation trees of mistral.rs_amd/csrc (dec_core2.cuh act_finish,
  *     dec_attn2.cuh): every function below states the order in its comment; tests/test_dec_engine.py and test_dec_model.py assert
  *     bit equality between the HIP kernels and these functions (GEMV: orc_gemv_engine at the end of this file).
  */
@@ -240,7 +240,7 @@ void orc_attention_full_cpu(const float *q, const float *k, const float *v, floa
 
 
 /* ================================================================== engine order */
-/* the 64-lane all-reduce of dec_core.cuh wave_sum_all: v += v[i^1]; v += v[i^2]; v += v[mirror within 8]; v += v[mirror within 16];
+/* the 64-lane all-reduce of dec_core2.cuh wave_sum_all: v += v[i^1]; v += v[i^2]; v += v[mirror within 8]; v += v[mirror within 16];
  * result = (lane0 + lane16) + (lane32 + lane48) */
 static float wave_sum_all_64(const float *in) {
   float a[64], b[64];
@@ -252,7 +252,7 @@ static float wave_sum_all_64(const float *in) {
   return (a[0] + a[16]) + (a[32] + a[48]);
 }
 
-/* RmsNorm of the engine's GEMV prologue (dec_core.cuh act_finish / ActStager, 512-thread workgroups): thread t sums the squares of its float4 pieces
+/* RmsNorm of the engine's GEMV prologue (dec_core2.cuh act_finish / ActStager, 512-thread workgroups): thread t sums the squares of its float4 pieces
  * e = 4 t + 2048 j (j ascending, x, y, z, w in order, fma), wave sums by wave_sum_all, the 8 wave sums as ((0+1)+(2+3))+((4+5)+(6+7));
  * m = sqrt(tot / d + eps); y_i = x_i / m * w_i  (candle's expression; the device computes the correctly rounded quotient with one
  * reciprocal and two fma per element, checked against `/` in tests/test_dec_engine.py). */
@@ -365,7 +365,7 @@ void orc_attention_engine_w(const float *q, const float *k, const float *v, floa
   }
 }
 
-/* The device's quotient x / m: y = 1 / m correctly rounded, q0 = x y, r = fma(-m, q0, x), q = fma(r, y, q0) (dec_core.cuh div_by).
+/* The device's quotient x / m: y = 1 / m correctly rounded, q0 = x y, r = fma(-m, q0, x), q = fma(r, y, q0) (dec_core2.cuh div_by).
  * Returns the number of (x, m) pairs for which it differs from the IEEE quotient: tests/test_oracle.py holds it to 0. */
 int64_t orc_div_by_mismatches(const float *x, const float *m, int64_t n) {
   int64_t bad = 0;
@@ -476,7 +476,7 @@ int orc_gemv_engine(int type, const void *W, int N, int K, const float *x, float
   return 0;
 }
 
-/* trunc(x + copysign(0.49999997f, x)) (the device's round-half-away, dec_core.cuh round_away / common.cuh fast_exp_ref) against roundf over EVERY
+/* trunc(x + copysign(0.49999997f, x)) (the device's round-half-away, dec_core2.cuh round_away / common.cuh fast_exp_ref) against roundf over EVERY
  * float with |x| <= limit: returns the number of mismatches (tests/test_oracle.py holds it to 0 for limit = 129) */
 int64_t orc_round_trick_mismatches(float limit) {
   uint32_t top;

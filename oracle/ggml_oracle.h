@@ -90,7 +90,7 @@ void orc_attention_single_q_cpu(const float *q, const float *k, const float *v, 
                                 float scale, int n_kv_chunks);
 void orc_rms_norm_candle(const float *x, const float *w, float *out, int rows, int d, float eps); /* x / sqrt(mean + eps) * w, f32 sums in order */
 void orc_rms_norm_engine(const float *x, const float *w, float *out, int rows, int d, float eps); /* same expression, the engine's summation tree */
-int64_t orc_div_by_mismatches(const float *x, const float *m, int64_t n);                                   /* dec_core.cuh div_by vs `/` */
+int64_t orc_div_by_mismatches(const float *x, const float *m, int64_t n);                                   /* dec_core2.cuh div_by vs `/` */
 int64_t orc_round_trick_mismatches(float limit);                                                      /* the device round-half-away vs roundf, exhaustive */
 float orc_silu_engine(float x);                                                                   /* x / (1 + fast_exp(-x)) */
 void orc_fused_glu_engine(const float *a, const float *b, float *out, int64_t n);

@@ -319,7 +319,8 @@ extern "C" inline __bf16 __truncsfbf2(float f) {
 
 #define hipLaunchKernelGGL(K, G, B, LDS, STREAM, ...) hiphost::launch(dim3(G), dim3(B), (size_t)(LDS), [&] { K(__VA_ARGS__); })
 #define __builtin_amdgcn_update_dpp(OLD, SRC, CTRL, RMASK, BMASK, BOUND) hiphost::dpp((SRC), (CTRL))
-#define __builtin_amdgcn_s_memrealtime() 0ull
+namespace hiphost { inline unsigned long long fake_realtime() { static thread_local unsigned long long t = 0; return t += 1000; } }  /* advances per read: time-bounded spins end */
+#define __builtin_amdgcn_s_memrealtime() hiphost::fake_realtime()
 #define __builtin_amdgcn_readlane(V, L) hiphost::exchange((int)(V), (L))
 #define __builtin_amdgcn_readfirstlane(V) hiphost::exchange((int)(V), 0) /* kernels use it on wave-uniform values only */
 #define __builtin_amdgcn_sched_group_barrier(MASK, SIZE, SYNC) ((void)0) /* instruction-order hint only */

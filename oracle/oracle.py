@@ -294,7 +294,7 @@ def rms_norm_candle(x: np.ndarray, w: np.ndarray, eps: float) -> np.ndarray:
 
 
 def rms_norm_engine(x: np.ndarray, w: np.ndarray, eps: float) -> np.ndarray:
-    """Same expression with the decode engine's summation tree (csrc/dec_core.cuh act_finish)."""
+    """Same expression with the decode engine's summation tree (csrc/dec_core2.cuh act_finish)."""
     x = np.ascontiguousarray(x, dtype=np.float32)
     w = np.ascontiguousarray(w, dtype=np.float32)
     out = np.empty_like(x)

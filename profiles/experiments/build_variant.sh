@@ -1,5 +1,5 @@
 #!/bin/bash
-# experiment build of libmrs_hip_ext.so: scripts/exp/build_variant.sh <name> <source.hip> "<extra hipcc flags>"  ->  mistral.rs_amd/lib/libmrs_hip_ext_<name>.so
+# experiment build of libmrs_hip_ext.so: profiles/experiments/build_variant.sh <name> <source.hip> "<extra hipcc flags>"  ->  mistral.rs_amd/lib/libmrs_hip_ext_<name>.so
 # (selected at run time with MRS_EXT_LIB=libmrs_hip_ext_<name>.so, mistral.rs_amd/_lib.py; run HERE, the .so travels to the GPU box)
 set -e
 name=$1; src=$2; shift 2

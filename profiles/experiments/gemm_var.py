@@ -1,4 +1,4 @@
-"""Time variants of ext_gemm.hip (compiled with -DGV=n into scripts/exp/gemm_var_n.so) on the Llama-3-8B prefill shapes (Q4_K)."""
+"""Time variants of ext_gemm.hip (compiled with -DGV=n into profiles/experiments/gemm_var_n.so) on the Llama-3-8B prefill shapes (Q4_K)."""
 import ctypes as C, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-2 A/B on the GPU box (one gpurun call, ~4 min): the shipped decode kernels (1 workgroup of 8 waves per CU, 133-139 VGPRs) against the
-# 128-VGPR build (scripts/exp/build_occ4.sh) at 1x and 2x workgroups per CU.  Each line is a full `bench.py` decode measurement; parity of the
+# 128-VGPR build (profiles/experiments/build_occ4.sh) at 1x and 2x workgroups per CU.  Each line is a full `bench.py` decode measurement; parity of the
 # variant is checked first (same greedy tokens as the default build: greedy_tokens_head in the JSON line).
 set -u
 OUT=gpurun_out/occ4

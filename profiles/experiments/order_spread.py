@@ -1,6 +1,6 @@
 """How far apart are two f32 summation orders of the SAME CPU-path arithmetic (oracle modes "cpu" and "cpu_fast") as the synthetic model gets deeper?
 Llama-3-8B layer shapes, random valid Q4_K_M blocks (the weights of tests/test_dec_model.py::_mk_8b_dims), vocab 4096; CPU only.
-usage: python scripts/exp/order_spread.py [layers ...]"""
+usage: python profiles/experiments/order_spread.py [layers ...]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Per-workgroup timeline of the decode engine's GEMV launches inside the captured decode graph (needs MRS_EXT_LIB=libmrs_hip_ext_tl.so,
-built by scripts/exp/build_variant.sh tl ext_dec.hip -DMRS_DEC_TIMELINE).  Stamps (100 MHz constant clock, lane 0 of wave 0 / wave 7):
+built by profiles/experiments/build_variant.sh tl ext_dec.hip -DMRS_DEC_TIMELINE).  Stamps (100 MHz constant clock, lane 0 of wave 0 / wave 7):
 0 kernel entry, 1 ring issued (prologue starts), 2 prologue done, 3 wave 0 finished its rows, 4 wave 7 finished."""
 import ctypes as C, os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

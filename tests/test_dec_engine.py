@@ -1,4 +1,4 @@
-"""Decode engine (csrc/dec_core.cuh, ext_dec.hip): GEMV phases in the arithmetic of the reference CPU path
+"""Decode engine (csrc/dec_core2.cuh, ext_dec.hip): GEMV phases in the arithmetic of the reference CPU path
 (GgufMatMul::forward_raw -> candle QMatMul on f32 activations, mistralrs-quant/src/gguf/mod.rs:465-478): Q8_K / Q8_0 activation quantization,
 integer block dots, f32 combination.  Checked against oracle B (oracle/ggml_oracle.c orc_matmul_cpu: dot_kquant_q8K / dot_legacy_q8).
 Same test bodies on the wave64 host emulation (CPU suite) and on the MI355X (`-m gpu`).

@@ -232,6 +232,7 @@ def _tp_runner_worker(rank, world, port, q, experts=0):
             m1.set_state([t], [pos])
             ref.append(m1.forward_logits(1)[0].clone())
         m1p = build(full, 0, 1)
+        m1p.set_prefill_mode(0)  # tensor-parallel prompts run the bf16-operand MFMA GEMMs (the exact prompt path is TP = 1 only): same arithmetic on both sides
         ref.append(m1p.prefill(prompt, 0).clone())
         ref = torch.stack(ref)
         same_on_all_ranks = all(bool(torch.equal(g, gathered[0])) for g in gathered)
@@ -422,6 +423,38 @@ def check_p2p_all_reduce_split_launches(be, world, count, rounds=5):
     assert all(err(c) == 0 for c in comms)
     for c in comms:
         be.sym("mrs_p2p_destroy", [C.c_void_p], None)(c)
+
+
+def check_p2p_missing_peer_times_out(be, limit_s):
+    """A peer that never posts: the reduce gives up after ~10 ms of device time (ext_p2p.hip SPIN_TICKS), its elements become NaN and the error word is
+    raised -- the host reads it at its next synchronisation point and falls back to RCCL (Llama.p2p_error); the job does not hang."""
+    import ctypes as C
+    import time
+    boxes, comms = _p2p_world(be, 2, 1024)
+    post = be.sym("mrs_p2p_post", [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p], C.c_int)
+    red = be.sym("mrs_p2p_reduce", [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p], C.c_int)
+    err = be.sym("mrs_p2p_error", [C.c_void_p], C.c_int)
+    buf = be.buf(np.ones(600, dtype=np.float32))
+    assert post(comms[0], buf.ptr, 600, be.stream) == 0  # rank 1 never posts
+    t0 = time.perf_counter()
+    assert red(comms[0], buf.ptr, 600, be.stream) == 0
+    assert err(comms[0]) == 1  # blocking read
+    dt = time.perf_counter() - t0
+    assert np.isnan(buf.numpy()).all()
+    assert dt < limit_s, f"the bounded spin took {dt:.3f} s"
+    for c in comms:
+        be.sym("mrs_p2p_destroy", [C.c_void_p], None)(c)
+
+
+def test_p2p_missing_peer_times_out_host_emulation():
+    from tests.abi_backends import HostBackend
+    check_p2p_missing_peer_times_out(HostBackend(), 60.0)
+
+
+@pytest.mark.gpu
+def test_p2p_missing_peer_times_out_gpu(dev):
+    from tests.abi_backends import GpuBackend
+    check_p2p_missing_peer_times_out(GpuBackend(dev), 1.0)
 
 
 @pytest.mark.parametrize("world,count", [(2, 300), (8, 4096), (3, 1)])

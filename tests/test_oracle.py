@@ -143,7 +143,7 @@ def test_round_trick_exhaustive(oracle):
 
 
 def test_device_quotient_equals_ieee_division(oracle):
-    """RmsNorm's x / m on the device = one correctly rounded reciprocal + q0 = x y, r = fma(-m, q0, x), q = fma(r, y, q0) (dec_core.cuh div_by):
+    """RmsNorm's x / m on the device = one correctly rounded reciprocal + q0 = x y, r = fma(-m, q0, x), q = fma(r, y, q0) (dec_core2.cuh div_by):
     equal to the IEEE quotient on 2e7 random pairs over six decades and for divisors with an all-ones mantissa."""
     import ctypes as C
     L = oracle.lib()
