@@ -41,6 +41,18 @@ void moe_router_topk_bf16(const void *logits, float *weights, uint32_t *ids, con
                           int n_experts, int top_k, int score_mode, int weight_mode, bool renormalize, bool clamp_logits, float clamp_min,
                           float clamp_max, float norm_min, float output_scale, int64_t stream);
 
+/* Sampling: top-k of one f32 logits row over a large vocabulary + the pieces of the full-softmax normaliser (Sampler::sample_topk_on_device, sampler.rs:1171-1260;
+ * top-p / min-p / the draw stay on the host).  The caller owns every buffer: block_values / block_indices [nrows][nblocks][k], block_maxes / block_sums
+ * [nrows][nblocks] (workspace, nblocks = ceil(ncols / chunk_size)), packed_out [nrows][2k + 2] = k values, k indices as f32, denom, max(x / T).
+ * Order: value descending, index ascending on ties; NaN and -inf are never selected, missing entries are (-inf, 0).  1 <= k <= 128, chunk_size <= 4096 (the
+ * reference's host wrapper passes 2048).  replaces mistralrs-core/src/cuda/sort.cu:1502-1823,2146-2206 ; ffi.rs:583-624 ; caller ops.rs:691-1000 */
+void topk_large_f32(const float *input, float *block_values, uint32_t *block_indices, float *block_maxes, float *block_sums, float *values_out,
+                    uint32_t *indices_out, float *softmax_info_out, int ncols, int k, int chunk_size, int nblocks, float inv_temperature, int64_t stream);
+void topk_large_f32_packed(const float *input, float *block_values, uint32_t *block_indices, float *block_maxes, float *block_sums, float *packed_out,
+                           int ncols, int k, int chunk_size, int nblocks, float inv_temperature, int64_t stream);
+void topk_large_f32_packed_batched(const float *input, const float *inv_temperatures, float *block_values, uint32_t *block_indices, float *block_maxes,
+                                   float *block_sums, float *packed_out, int nrows, int ncols, int k, int chunk_size, int nblocks, int64_t stream);
+
 #ifdef __cplusplus
 }
 #endif

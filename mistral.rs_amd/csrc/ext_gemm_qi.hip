@@ -490,7 +490,7 @@ __global__ void __launch_bounds__(256) prefill_attn_exact_kernel(const dec::Attn
   const int T = a.num_seqs, ms = a.max_splits, bpw = a.bpw;
   const int t0 = (tile * 4 + wave) * qw, nq = min(qw, T - t0);
   if (nq <= 0) return;  // no workgroup barrier below: a wave may leave
-  const size_t per_wave = (size_t)qw * G * HD * 2 + G * 32 + (size_t)qw * G * ms * 2 + (size_t)qw * G;
+  const size_t per_wave = (size_t)qw * G * HD * 2 + G * 32 + (size_t)qw * G * ms * 2 + (size_t)qw * G * 64;
   float *q_s = (float *)smem + wave * per_wave, *p_s = q_s + (size_t)qw * G * HD, *acc = p_s + G * 32, *ml = acc + (size_t)qw * G * HD, *sall = ml + (size_t)qw * G * ms * 2;
   int ctx_max = 0;
   for (int i = 0; i < nq; ++i) {
@@ -499,7 +499,7 @@ __global__ void __launch_bounds__(256) prefill_attn_exact_kernel(const dec::Attn
     for (int k = lane; k < G * HD; k += 64) acc[(size_t)i * G * HD + k] = 0.f;
     ctx_max = max(ctx_max, (int)a.context_lens[t0 + i]);
   }
-  for (int k = lane; k < nq * G; k += 64) sall[k] = 0.f;
+  for (int k = 0; k < nq * G; ++k) sall[k * 64 + lane] = 0.f;  // the running sum of l_j * w_j: one private copy per lane (wave-uniform value)
   MRS_WAVE_SYNC();
   const uint32_t *bt = a.block_tables;  // one sequence: every token reads the same row
   const int ns_w = (((ctx_max + 31) / 32) + bpw - 1) / bpw;
@@ -530,7 +530,7 @@ __global__ void __launch_bounds__(256) prefill_attn_exact_kernel(const dec::Attn
             e[0] = m[g]; e[1] = l[g];  // every lane writes the same value
           } else {  // dec::attn_merge_core, one split: s += l_j * w_j; acc += o_j * w_j
             const float wj = e[0], lw = l[g] * wj;
-            sall[i * G + g] = sall[i * G + g] + lw;
+            sall[(i * G + g) * 64 + lane] = sall[(i * G + g) * 64 + lane] + lw;
             float *ao = acc + (size_t)(i * G + g) * HD;
             const float u0 = o0[g] * wj, u1 = o1[g] * wj;
             ao[lane] = ao[lane] + u0;
@@ -559,7 +559,7 @@ __global__ void __launch_bounds__(256) prefill_attn_exact_kernel(const dec::Attn
   for (int i = 0; i < nq; ++i)
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      const float inv = 1.0f / sall[i * G + g];
+      const float inv = 1.0f / sall[(i * G + g) * 64 + lane];
       const float *ao = acc + (size_t)(i * G + g) * HD;
       float *o = a.out + ((size_t)(t0 + i) * a.num_heads + kvh * G + g) * HD;
       o[lane] = ao[lane] * inv; o[lane + 64] = ao[lane + 64] * inv;
@@ -587,7 +587,7 @@ extern "C" int mrs_prefill_attention_exact(const float *q, const void *k_cache, 
   a.max_splits = std::max(1, std::min(64, (((need_ctx + 31) / 32) + a.bpw - 1) / a.bpw));
   static const int qw_env = [] { const char *e = getenv("MRS_PREFILL_ATTN_QW"); return e ? atoi(e) : 0; }();
   int qw = qw_env > 0 ? qw_env : 4;  // prompt tokens per wave
-  auto lds_for = [&](int w) { return 4 * ((size_t)w * G * 128 * 2 + (size_t)G * 32 + (size_t)w * G * a.max_splits * 2 + (size_t)w * G) * 4; };
+  auto lds_for = [&](int w) { return 4 * ((size_t)w * G * 128 * 2 + (size_t)G * 32 + (size_t)w * G * a.max_splits * 2 + (size_t)w * G * 64) * 4; };
   while (qw > 1 && (lds_for(qw) > 76 * 1024 || (T + 4 * qw - 1) / (4 * qw) * num_kv_heads < 512)) --qw;  // two workgroups per CU, and enough workgroups to fill the chip
   const size_t lds = lds_for(qw);
   if (lds > 158 * 1024) return -2;

@@ -1,0 +1,298 @@
+// sampling.hip -- libmistralrscuda, sampling subset: top-k of one logits row over a 100k+ vocabulary + the pieces of the full-softmax normaliser the host
+// sampler needs (Sampler::sample_topk_on_device, mistralrs-core/src/sampler.rs:1171-1260: top-p / min-p / the multinomial draw stay on the host).
+//   topk_large_f32, topk_large_f32_packed, topk_large_f32_packed_batched      mistralrs-core/src/cuda/sort.cu:1502-1823,2146-2206 ; ffi.rs:583-624 ;
+//                                                                              caller ops.rs:691-828 (cuda_topk_logits_f32_packed)
+// Contract kept from the reference (the caller owns every buffer):
+//   stage 1, one workgroup per `chunk_size` logits: block_values / block_indices [chunk][k] = the chunk's k largest logits in (value descending, index
+//   ascending) order, NaN and -inf never selected, missing entries (-inf, 0); block_maxes[chunk] = top value * inv_temperature (-inf for an empty chunk);
+//   block_sums[chunk] = sum over the chunk of expf(x * inv_temperature - block_max) (NaN if the chunk holds one);
+//   stage 2, one workgroup per row: global max of block_maxes, denom = sum_b block_sums[b] * expf(block_maxes[b] - max), and the k best candidates in the
+//   same order; packed_out = [k values][k indices as f32][denom][max].
+// MI355X design (not the reference's k rounds of scan-the-chunk + two block barriers each):
+//   stage 1: a chunk lives in REGISTERS (<= 16 logits per thread), every wave extracts the top-k of its quarter on its own -- one 64-bit key per candidate
+//   (order-preserving float bits << 32 | ~index, so ONE max reduction per round settles value and tie), 6 xor-shuffles per round, no barrier -- then wave 0
+//   merges the four sorted lists by heads (one lane per list).  stage 2 is the same head merge over the nblocks sorted lists (a lane per list, lists beyond
+//   64 share lanes): k rounds of one wave-wide max instead of k scans of nblocks * k candidates.
+//   The f32 sums keep the reference's association (per-thread strided partials, 32-lane shuffle-down trees, warp sums through LDS) so that only expf's last
+//   ulp separates the normaliser from the CUDA build's.
+#include "common.cuh"
+#include <stdint.h>
+#include <algorithm>
+
+namespace mrs {
+namespace sampling {
+
+constexpr int NT = 256;       // threads per workgroup (the reference's block size: the strided partial sums depend on it)
+constexpr int MAXV = 16;      // logits per thread kept in registers: chunks up to 4096
+constexpr int MAX_K = 128;    // CUDA_TOPK_MAX_K (ops.rs:18)
+
+__device__ __forceinline__ unsigned long long key_of(float v, unsigned idx) {
+  // NaN and -inf are never candidates (sort.cu:1552: candidate == candidate && candidate > -INFINITY)
+  if (!(v == v) || v == -INFINITY) return 0ull;
+  const unsigned u = __float_as_uint(v + 0.0f);  // -0.0 -> +0.0: the reference's `>` sees them as equal (the lower index wins)
+  const unsigned o = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ((unsigned long long)o << 32) | (unsigned long long)(~idx);
+}
+// max over the wave, every lane gets it: DPP inside rows of 16 (xor 1, xor 2, half-row mirror, row mirror), then the four row results through v_readlane -- no LDS crossbar
+template <int CTRL> __device__ __forceinline__ unsigned long long dpp_u64(unsigned long long k) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)k, CTRL, 0xf, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(k >> 32), CTRL, 0xf, 0xf, false);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long k, int lane) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k, lane), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(k >> 32), lane);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k) {
+  unsigned long long o;
+  o = dpp_u64<0xB1>(k); k = o > k ? o : k;
+  o = dpp_u64<0x4E>(k); k = o > k ? o : k;
+  o = dpp_u64<0x141>(k); k = o > k ? o : k;
+  o = dpp_u64<0x140>(k); k = o > k ? o : k;
+  const unsigned long long r0 = readlane_u64(k, 0), r1 = readlane_u64(k, 16), r2 = readlane_u64(k, 32), r3 = readlane_u64(k, 48);
+  const unsigned long long a = r0 > r1 ? r0 : r1, b = r2 > r3 ? r2 : r3;
+  return a > b ? a : b;
+}
+// the reference's reductions, association for association (sort.cu:1470-1497): 32-lane shuffle-down trees, warp sums through shared memory, first warp again
+__device__ __forceinline__ float warp32_sum_down(float v) {
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) v += __shfl_down(v, off, 32);
+  return v;
+}
+__device__ __forceinline__ float block_sum_ref_order(float v, float *warp_sums /* [32] */) {
+  const int tid = threadIdx.x, warp_id = tid / 32, lane_id = tid % 32;
+  v = warp32_sum_down(v);
+  if (lane_id == 0) warp_sums[warp_id] = v;
+  __syncthreads();
+  v = tid < NT / 32 ? warp_sums[tid] : 0.0f;
+  if (tid < 64) v = warp32_sum_down(v);  // the whole first wave walks the tree (lanes 32..63 reduce zeros): lane 0 sees the reference's first-warp tree
+  __syncthreads();
+  return v;  // valid in thread 0
+}
+
+struct Stage1Args {
+  const float *input;
+  float *block_values;
+  uint32_t *block_indices;
+  float *block_maxes, *block_sums;
+  const float *inv_temperatures;  // batched: one per row
+  float inv_temperature;
+  int ncols, k, chunk_size, nblocks;
+};
+
+// merge `nl` lists sorted by key (descending) into the k best: lane l walks list l (l, l + 64, ... when nl > 64) by its head; `get(list, pos)` returns the key
+// (0 = exhausted), emit(ki, list, pos) receives the winners in order.  One wave.
+template <class Get, class Emit>
+__device__ __forceinline__ void head_merge(int nl, int k, int *heads /* LDS [nl] */, Get get, Emit emit) {
+  const int lane = threadIdx.x & 63;
+  for (int l = lane; l < nl; l += 64) heads[l] = 0;  // a lane only ever touches the heads of its own lists: no cross-lane traffic through LDS
+  for (int ki = 0; ki < k; ++ki) {
+    unsigned long long best = 0ull;
+    int bl = -1;
+    for (int l = lane; l < nl; l += 64) {
+      const int h = heads[l];
+      const unsigned long long key = h < k ? get(l, h) : 0ull;
+      if (key > best) { best = key; bl = l; }
+    }
+    const unsigned long long win = wave_max_u64(best);
+    // keys are unique (they carry the index), so exactly one lane holds the winner -- unless nothing is left
+    const bool mine = win != 0ull && best == win;
+    const unsigned long long m = __ballot(mine);
+    int wl = -1, wp = 0;
+    if (m) {
+      const int src = __ffsll((long long)m) - 1;
+      wl = __shfl(bl, src, 64);
+      wp = __shfl(mine ? heads[bl < 0 ? 0 : bl] : 0, src, 64);
+    }
+    if (mine) heads[bl] += 1;
+    emit(ki, wl, wp);
+  }
+}
+
+template <bool BATCHED>
+__global__ void __launch_bounds__(NT) topk_stage1_kernel(Stage1Args a) {
+  __shared__ unsigned long long s_keys[4][MAX_K];  // each wave's sorted candidates
+  __shared__ float s_vals[4][MAX_K];
+  __shared__ int s_heads[4];
+  __shared__ float s_warp_sums[32];
+  __shared__ float s_block_max;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t row = BATCHED ? blockIdx.y : 0;
+  const int chunk = blockIdx.x, k = a.k;
+  const float *input = a.input + row * (size_t)a.ncols;
+  float *bv = a.block_values + (row * a.nblocks + chunk) * (size_t)k;
+  uint32_t *bi = a.block_indices + (row * a.nblocks + chunk) * (size_t)k;
+  const float inv_t = BATCHED ? a.inv_temperatures[row] : a.inv_temperature;
+  const int start = chunk * a.chunk_size, end = min(start + a.chunk_size, a.ncols), width = max(0, end - start);
+  // the chunk in registers, in the reference's thread-strided assignment (local = tid + 256 j): needed as it is for the partial sums below
+  float v[MAXV];
+  unsigned long long keys[MAXV];
+#pragma unroll
+  for (int j = 0; j < MAXV; ++j) {
+    const int local = tid + j * NT;
+    v[j] = local < width ? input[start + local] : -INFINITY;
+    keys[j] = local < width ? key_of(v[j], (unsigned)(start + local)) : 0ull;
+  }
+  // ---- every wave: the k best of its 64 x MAXV logits, sorted.  A lane keeps its best unused key; only the round's winner rescans its registers.
+  int bj = 0;
+  auto local_best = [&]() {
+    unsigned long long b = 0ull;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j)
+      if (keys[j] > b) { b = keys[j]; bj = j; }
+    return b;
+  };
+  unsigned long long best = local_best();
+  for (int ki = 0; ki < k; ++ki) {
+    const unsigned long long win = wave_max_u64(best);
+    if (win != 0ull && best == win) {  // keys carry the index: exactly one lane
+      float val = 0.f;
+#pragma unroll
+      for (int j = 0; j < MAXV; ++j) { val = j == bj ? v[j] : val; keys[j] = j == bj ? 0ull : keys[j]; }
+      s_keys[wave][ki] = win;
+      s_vals[wave][ki] = val;  // the original bits (a -0.0 stays -0.0)
+      best = local_best();
+    } else if (win == 0ull && lane == 0) {
+      s_keys[wave][ki] = 0ull;
+      s_vals[wave][ki] = -INFINITY;
+    }
+  }
+  __syncthreads();
+  // ---- wave 0: merge the four lists
+  if (wave == 0) {
+    head_merge(4, k, s_heads, [&](int l, int h) { return s_keys[l][h]; },
+               [&](int ki, int wl, int wp) {
+                 if (lane == 0) {
+                   bv[ki] = wl >= 0 ? s_vals[wl][wp] : -INFINITY;
+                   bi[ki] = wl >= 0 ? ~(unsigned)(s_keys[wl][wp] & 0xffffffffull) : 0u;
+                   if (ki == 0) s_block_max = width > 0 ? (wl >= 0 ? s_vals[wl][wp] : -INFINITY) * inv_t : -INFINITY;
+                 }
+               });
+  }
+  __syncthreads();
+  // ---- the chunk's share of the softmax normaliser (sort.cu:1580-1597)
+  const float block_max = s_block_max;
+  float local_sum = 0.0f;
+#pragma unroll
+  for (int j = 0; j < MAXV; ++j) {
+    const int local = tid + j * NT;
+    if (local < width) {
+      const float c = v[j];
+      if (c != c) local_sum = NAN;
+      else if (block_max != -INFINITY) local_sum += expf(c * inv_t - block_max);
+    }
+  }
+  const float block_sum = block_sum_ref_order(local_sum, s_warp_sums);
+  if (tid == 0) {
+    a.block_maxes[row * a.nblocks + chunk] = block_max;
+    a.block_sums[row * a.nblocks + chunk] = block_sum;
+  }
+}
+
+struct Stage2Args {
+  const float *block_values;
+  const uint32_t *block_indices;
+  const float *block_maxes, *block_sums;
+  float *packed_out;      // [2k + 2] per row, or NULL
+  float *values_out;      // unpacked variant
+  uint32_t *indices_out;
+  float *softmax_info_out;
+  int nblocks, k, depth;
+};
+
+template <bool BATCHED>
+__global__ void __launch_bounds__(NT) topk_stage2_kernel(Stage2Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int *heads = (int *)smem;  // [nblocks]
+  __shared__ float s_warp_max[32], s_warp_sums[32];
+  __shared__ float s_global_max;
+  const int tid = threadIdx.x, lane = tid & 63, k = a.k, nb = a.nblocks;
+  const size_t row = BATCHED ? blockIdx.x : 0;
+  const float *bv = a.block_values + row * (size_t)nb * k;
+  const uint32_t *bi = a.block_indices + row * (size_t)nb * k;
+  const float *bm = a.block_maxes + row * (size_t)nb, *bs = a.block_sums + row * (size_t)nb;
+  float *packed = a.packed_out ? a.packed_out + row * (size_t)(2 * k + 2) : nullptr;
+  // global max (a max is association-free)
+  float gm = -INFINITY;
+  for (int b = tid; b < nb; b += NT) gm = fmaxf(gm, bm[b]);
+  gm = wave_max(gm);
+  if (lane == 0) s_warp_max[tid >> 6] = gm;
+  __syncthreads();
+  if (tid == 0) s_global_max = fmaxf(fmaxf(s_warp_max[0], s_warp_max[1]), fmaxf(s_warp_max[2], s_warp_max[3]));
+  __syncthreads();
+  const float global_max = s_global_max;
+  float local_denom = 0.0f;
+  if (global_max != -INFINITY)
+    for (int b = tid; b < nb; b += NT) local_denom += bs[b] * expf(bm[b] - global_max);
+  const float denom = block_sum_ref_order(local_denom, s_warp_sums);
+  if (tid == 0) {
+    if (packed) { packed[2 * k] = denom; packed[2 * k + 1] = global_max; }
+    else { a.softmax_info_out[0] = denom; a.softmax_info_out[1] = global_max; }
+  }
+  // the heads of every list, as keys, in LDS: `depth` entries per list (all k of them for vocabularies up to ~130k tokens); deeper entries are read from memory
+  unsigned long long *skeys = (unsigned long long *)(smem + (((size_t)nb * sizeof(int) + 7) & ~(size_t)7));
+  const int depth = a.depth;
+  for (int i = tid; i < nb * depth; i += NT) {
+    const int l = i / depth, h = i - l * depth;
+    skeys[i] = key_of(bv[(size_t)l * k + h], bi[(size_t)l * k + h]);
+  }
+  __syncthreads();
+  if (tid >= 64) return;
+  // winners are only RECORDED in the loop (list, position); values and indices are gathered afterwards by 64 lanes at once -- a load per round on the
+  // critical path would cost more than the round itself
+  __shared__ int s_win[MAX_K];
+  head_merge(nb, k, heads, [&](int l, int h) { return h < depth ? skeys[l * depth + h] : key_of(bv[(size_t)l * k + h], bi[(size_t)l * k + h]); },
+             [&](int ki, int wl, int wp) {
+               if (lane == 0) s_win[ki] = wl >= 0 ? wl * k + wp : -1;
+             });
+  MRS_WAVE_SYNC();
+  for (int ki = lane; ki < k; ki += 64) {
+    const int pos = s_win[ki];
+    const float val = pos >= 0 ? bv[pos] : -INFINITY;
+    const uint32_t idx = pos >= 0 ? bi[pos] : 0u;
+    if (packed) { packed[ki] = val; packed[k + ki] = (float)idx; }
+    else { a.values_out[ki] = val; a.indices_out[ki] = idx; }
+  }
+}
+
+static bool shape_ok(int ncols, int k, int chunk_size, int nblocks) {
+  return ncols > 0 && k >= 1 && k <= MAX_K && chunk_size >= 1 && chunk_size <= NT * MAXV && nblocks >= 1 && (long long)nblocks * chunk_size >= ncols;
+}
+static void run(const float *input, const float *inv_temperatures, float inv_temperature, float *block_values, uint32_t *block_indices, float *block_maxes,
+                float *block_sums, float *packed_out, float *values_out, uint32_t *indices_out, float *softmax_info_out, int nrows, int ncols, int k,
+                int chunk_size, int nblocks, bool batched, int64_t stream) {
+  if (!shape_ok(ncols, k, chunk_size, nblocks) || nrows < 1) return;  // the reference's host wrapper validates before it calls (ops.rs:699-731)
+  hipStream_t s = (hipStream_t)stream;
+  Stage1Args a1{input, block_values, block_indices, block_maxes, block_sums, inv_temperatures, inv_temperature, ncols, k, chunk_size, nblocks};
+  const size_t heads_bytes = ((size_t)nblocks * sizeof(int) + 7) & ~(size_t)7;
+  const int depth = (int)std::min<size_t>((size_t)k, (60 * 1024 - heads_bytes) / 8 / (size_t)nblocks);  // keys staged per list (60 KiB of LDS)
+  Stage2Args a2{block_values, block_indices, block_maxes, block_sums, packed_out, values_out, indices_out, softmax_info_out, nblocks, k, depth};
+  const size_t lds2 = heads_bytes + (size_t)nblocks * depth * 8;
+  if (batched) {
+    hipLaunchKernelGGL(topk_stage1_kernel<true>, dim3(nblocks, nrows), dim3(NT), 0, s, a1);
+    hipLaunchKernelGGL(topk_stage2_kernel<true>, dim3(nrows), dim3(NT), lds2, s, a2);
+  } else {
+    hipLaunchKernelGGL(topk_stage1_kernel<false>, dim3(nblocks), dim3(NT), 0, s, a1);
+    hipLaunchKernelGGL(topk_stage2_kernel<false>, dim3(1), dim3(NT), lds2, s, a2);
+  }
+}
+
+}  // namespace sampling
+}  // namespace mrs
+
+extern "C" void topk_large_f32(const float *input, float *block_values, uint32_t *block_indices, float *block_maxes, float *block_sums, float *values_out,
+                               uint32_t *indices_out, float *softmax_info_out, int ncols, int k, int chunk_size, int nblocks, float inv_temperature,
+                               int64_t stream) {
+  mrs::sampling::run(input, nullptr, inv_temperature, block_values, block_indices, block_maxes, block_sums, nullptr, values_out, indices_out, softmax_info_out, 1,
+                     ncols, k, chunk_size, nblocks, false, stream);
+}
+extern "C" void topk_large_f32_packed(const float *input, float *block_values, uint32_t *block_indices, float *block_maxes, float *block_sums, float *packed_out,
+                                      int ncols, int k, int chunk_size, int nblocks, float inv_temperature, int64_t stream) {
+  mrs::sampling::run(input, nullptr, inv_temperature, block_values, block_indices, block_maxes, block_sums, packed_out, nullptr, nullptr, nullptr, 1, ncols, k,
+                     chunk_size, nblocks, false, stream);
+}
+extern "C" void topk_large_f32_packed_batched(const float *input, const float *inv_temperatures, float *block_values, uint32_t *block_indices, float *block_maxes,
+                                              float *block_sums, float *packed_out, int nrows, int ncols, int k, int chunk_size, int nblocks, int64_t stream) {
+  mrs::sampling::run(input, inv_temperatures, 0.0f, block_values, block_indices, block_maxes, block_sums, packed_out, nullptr, nullptr, nullptr, nrows, ncols, k,
+                     chunk_size, nblocks, true, stream);
+}

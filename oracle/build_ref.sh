@@ -120,6 +120,18 @@ IMOE="$REF/mistralrs-quant/kernels/indexed_moe/indexed_moe.cu"
   echo 'static inline float max(float a, float b) { return fmaxf(a, b); }'
   awk '/^constexpr int MOE_ROUTER_SCORE_RAW/{p=1} /^void launch_moe_router_topk/{exit} p{if (held != "") print held; held=$0}' "$REF/mistralrs-core/src/cuda/sort.cu"
   cat "$HERE/ref_shim/router_driver.inc" ) | $CXX $FLAGS $FIB -o "$OUT/libref_router.so" -
+# sampling top-k over a large vocabulary (mistralrs-core/src/cuda/sort.cu): warp_reduce_max_with_idx (:925-940), the sum reductions (:1470-1497),
+# topk_large_stage1_f32 (:1502-1600) and topk_large_stage2_f32_packed (:1708-1823); launch sequence of :2165-2206 in topk_driver.inc
+grep -q '^__global__ void topk_large_stage1_f32($' "$REF/mistralrs-core/src/cuda/sort.cu" || { echo "build_ref.sh: topk_large_stage1_f32 moved"; exit 1; }
+( cat "$HERE/ref_shim/cuda_shim.h" "$HERE/ref_shim/fiber_shim.h"
+  S="$REF/mistralrs-core/src/cuda/sort.cu"
+  echo 'static inline int min(int a, int b) { return a < b ? a : b; }'
+  echo 'static inline int max(int a, int b) { return a > b ? a : b; }'
+  awk '/^__device__ __forceinline__ T warp_reduce_max_with_idx/{print "template <typename T>"; p=1} p{print} p&&/^}/{exit}' "$S"
+  awk '/^__device__ __forceinline__ float warp_reduce_sum_f32/{p=1} /^\/\/ Large-vocabulary top-k for token sampling/{exit} p{print}' "$S"
+  awk '/^__global__ void topk_large_stage1_f32\($/{print "template <bool BATCHED>"; p=1} /^__global__ void topk_large_stage2_f32\($/{exit} p{print}' "$S" | sed 's/extern __shared__ char smem\[\];/char *smem = shim_fiber::dyn_smem;/'
+  awk '/^__global__ void topk_large_stage2_f32_packed\($/{print "template <bool BATCHED>"; p=1} /^template <bool BATCHED, bool COMPUTE_SUMS>/{exit} p{print}' "$S" | sed 's/extern __shared__ char smem\[\];/char *smem = shim_fiber::dyn_smem;/'
+  cat "$HERE/ref_shim/topk_driver.inc" ) | $CXX $FLAGS $FIB -o "$OUT/libref_topk.so" -
 # fused_glu (mistralrs-quant/kernels/ops/ops.cu): activation enum + functions, scalar and vec4 kernels; f32 / f16 / bf16
 OPS="$REF/mistralrs-quant/kernels/ops/ops.cu"
 ( cat "$HERE/ref_shim/cuda_shim.h" "$HERE/ref_shim/fiber_shim.h"
@@ -145,4 +157,4 @@ MMQ_DIR="$REF/mistralrs-quant/kernels/mmq_gguf"
   awk '/^enum mmq_q8_1_ds_layout/{p=1} /^struct block_fp4_mmq/{exit} p{print}' "$MMQ_DIR/mmq_gguf.cuh"
   awk '/^#define CUDA_QUANTIZE_BLOCK_SIZE_MMQ/{p=1} /^template <mmq_q8_1_ds_layout ds_layout>$/{exit} p{print}' "$MMQ_DIR/mmq_quantize.cu"
   cat "$HERE/ref_shim/mmq_quantize_driver.inc" ) | $CXX $FLAGS $FIB -DSHIM_HALF_OPS -o "$OUT/libref_mmq_quantize.so" -
-echo "oracle/_ref: built libref_mmvq.so libref_affine.so libref_hqq.so libref_cache.so libref_pa.so libref_q8_1.so libref_rms.so libref_mmvq_kernel.so libref_glu.so libref_router.so libref_imoe.so libref_moe_decode.so libref_moe_grouped.so libref_gemv.so libref_half.so libref_mmq_quantize.so from $REF"
+echo "oracle/_ref: built libref_mmvq.so libref_affine.so libref_hqq.so libref_cache.so libref_pa.so libref_q8_1.so libref_rms.so libref_mmvq_kernel.so libref_glu.so libref_router.so libref_imoe.so libref_moe_decode.so libref_moe_grouped.so libref_gemv.so libref_half.so libref_mmq_quantize.so libref_topk.so from $REF"

@@ -186,6 +186,11 @@ namespace hiphost { static inline void wave_sync() { wave_barrier(linear_tid() /
 template <class T> static inline T __shfl_xor(T v, int mask, int = 64) { return hiphost::exchange(v, (hiphost::linear_tid() & 63) ^ mask); }
 template <class T> static inline T __shfl(T v, int src, int = 64) { return hiphost::exchange(v, src); }
 static inline unsigned long long __ballot(int pred) { return hiphost::ballot(pred != 0); }
+template <class T> static inline T __shfl_down(T v, int delta, int width = 64) {  /* a lane whose source falls outside its `width` segment keeps its own value */
+  const int lane = hiphost::linear_tid() & 63;
+  return hiphost::exchange(v, (lane % width) + delta < width ? lane + delta : lane);
+}
+static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 
 
 // ---------------------------------------------------------------------------------------------- matrix cores (gfx950 v_mfma_f32_32x32x16_bf16)

@@ -562,6 +562,98 @@ def moe_router_topk(logits: np.ndarray, top_k: int, score_mode: int = 1, weight_
 
 
 # ------------------------------------------------------------------------------------------------ MoE expert kernels (restatements)
+# ---------------------------------------------------------------- sampling: top-k over a large vocabulary (mistralrs-core/src/cuda/sort.cu:1502-1823)
+def _tree32_lane0(v: np.ndarray) -> np.float32:
+    """warp_reduce_sum_f32 (sort.cu:1470-1476) as lane 0 sees it: v += shfl_down(v, 16), 8, 4, 2, 1 over 32 lanes (a lane whose source is out of range adds itself)."""
+    v = np.asarray(v, dtype=np.float32).copy()
+    for off in (16, 8, 4, 2, 1):
+        sh = v.copy()
+        sh[: 32 - off] = v[off:]
+        v = (v + sh).astype(np.float32)
+    return v[0]
+
+
+def _block_sum_256(partials: np.ndarray) -> np.float32:
+    """block_reduce_sum_f32 (sort.cu:1478-1497) for a 256-thread block: 8 warp trees, then the tree of the 8 warp sums padded with zeros."""
+    ws = np.zeros(32, dtype=np.float32)
+    for w in range(8):
+        ws[w] = _tree32_lane0(partials[w * 32:(w + 1) * 32])
+    return _tree32_lane0(ws)
+
+
+def topk_large_packed(logits: np.ndarray, k: int, inv_temperature: float, chunk_size: int = 2048) -> dict:
+    """topk_large_stage1_f32 + topk_large_stage2_f32_packed (sort.cu:1502-1600, 1708-1823; host side ops.rs:691-828) for ONE f32 row, restated: the k largest
+    logits in (value descending, index ascending) order -- NaN and -inf are never selected, missing entries are (-inf, 0) --, per-chunk maxima / partial softmax sums
+    in the reference's f32 association (256 strided per-thread partials, 32-lane shuffle-down trees), denom and global max.  Returns the packed row
+    [k values][k indices as f32][denom][max] and the stage-1 workspace."""
+    x = np.ascontiguousarray(logits, dtype=np.float32).reshape(-1)
+    n = x.size
+    it = np.float32(inv_temperature)
+    nblocks = (n + chunk_size - 1) // chunk_size
+    bv = np.full((nblocks, k), -np.inf, dtype=np.float32)
+    bi = np.zeros((nblocks, k), dtype=np.uint32)
+    bm = np.empty(nblocks, dtype=np.float32)
+    bs = np.empty(nblocks, dtype=np.float32)
+
+    def best_k(vals, ids):
+        ok = ~np.isnan(vals) & (vals > -np.inf)
+        order = np.lexsort((ids[ok], -vals[ok].astype(np.float64)))[:k]  # value descending (-0.0 == +0.0), index ascending
+        return vals[ok][order], ids[ok][order]
+    with np.errstate(over="ignore", invalid="ignore"):
+        for c in range(nblocks):
+            lo, hi = c * chunk_size, min((c + 1) * chunk_size, n)
+            v, i = best_k(x[lo:hi], np.arange(lo, hi, dtype=np.uint32))
+            bv[c, : v.size], bi[c, : v.size] = v, i
+            bm[c] = bv[c, 0] * it if hi > lo else -np.inf
+            part = np.zeros(256, dtype=np.float32)
+            for t in range(256):
+                seg = x[lo + t:hi:256]
+                acc = np.float32(0)
+                for cnd in seg:
+                    if cnd != cnd:
+                        acc = np.float32(np.nan)
+                    elif bm[c] != -np.inf:
+                        acc = np.float32(acc + np.exp(np.float32(cnd * it - bm[c]), dtype=np.float32))
+                part[t] = acc
+            bs[c] = _block_sum_256(part)
+        gmax = np.float32(np.max(bm)) if nblocks else np.float32(-np.inf)
+        part = np.zeros(256, dtype=np.float32)
+        if gmax != -np.inf:
+            for b in range(nblocks):
+                part[b % 256] = np.float32(part[b % 256] + np.float32(bs[b] * np.exp(np.float32(bm[b] - gmax), dtype=np.float32)))
+        denom = _block_sum_256(part)
+    v, i = best_k(bv.reshape(-1), bi.reshape(-1))  # ties across chunks: lower candidate position = lower chunk = lower index
+    packed = np.empty(2 * k + 2, dtype=np.float32)
+    packed[:k], packed[k:2 * k] = -np.inf, 0.0
+    packed[: v.size], packed[k:k + i.size] = v, i.astype(np.float32)
+    packed[2 * k], packed[2 * k + 1] = denom, gmax
+    return {"packed": packed, "block_values": bv, "block_indices": bi, "block_maxes": bm, "block_sums": bs}
+
+
+def sample_topk_host(packed: np.ndarray, k: int, temperature: float, top_p: float = 1.0, min_p: float = 0.0):
+    """The host half of Sampler::sample_topk_on_device (sampler.rs:1189-1236): probabilities of the k candidates under the FULL softmax, then the top-p cut
+    (`top_p_cutoff` = top_p * sum of the kept probabilities, cumulative sum in candidate order) and the min-p cut (threshold = first probability * min_p).
+    Returns (token ids [k], reporting_probs [k], filtered probs [k]) -- the weights WeightedIndex draws from."""
+    vals, ids = packed[:k].astype(np.float32), packed[k:2 * k].astype(np.uint32)
+    denom, gmax = np.float32(packed[2 * k]), np.float32(packed[2 * k + 1])
+    inv_t = np.float32(1.0 / temperature)
+    with np.errstate(over="ignore", invalid="ignore"):
+        rep = (np.exp((vals * inv_t - gmax).astype(np.float32), dtype=np.float32) / denom).astype(np.float32)
+    probs = rep.copy()
+    if 0.0 < top_p < 1.0:
+        cutoff = np.float32(top_p) * np.float32(sum(np.float32(p) for p in probs))  # f32 running sum in candidate order (Iterator::sum::<f32>)
+        cum = np.float32(0)
+        for j in range(k):
+            if cum >= cutoff:
+                probs[j] = 0.0
+            else:
+                cum = np.float32(cum + probs[j])
+    if 0.0 < min_p < 1.0:
+        thr = np.float32(probs[0] * np.float32(min_p)) if k else np.float32(0)
+        probs[thr >= probs] = 0.0
+    return ids, rep, probs
+
+
 def _expert_rows(w: np.ndarray, e: int, n: int) -> np.ndarray:
     return w[e * n:(e + 1) * n]
 

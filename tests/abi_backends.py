@@ -33,6 +33,10 @@ class HostBackend:
     @classmethod
     def lib(cls):
         if cls._lib is None:
+            so = os.environ.get("MRS_HIPHOST_SO")  # a build of oracle/build_hip_host.sh elsewhere (HIPHOST_OUT=...): used as it is, never rebuilt
+            if so:
+                cls._lib = C.CDLL(so, mode=C.RTLD_GLOBAL if cls.global_symbols else C.RTLD_LOCAL)
+                return cls._lib
             so = os.path.join(ROOT, "oracle", "_hiphost", "libhiphost.so")
             srcs = [os.path.join(ROOT, "mistral.rs_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "mistral.rs_amd", "csrc")) if f.endswith((".cuh", ".hip"))]
             srcs += [os.path.join(ROOT, "oracle", "hip_host", "hip", "hip_runtime.h"), os.path.join(ROOT, "oracle", "build_hip_host.sh")]

@@ -47,13 +47,13 @@ def check_attention(O, be, heads, kvh, T, max_ctx, kv_dtype=1, window=0, start=0
         assert np.array_equal(res[t], one.numpy()[0]), (t, float(np.abs(res[t] - one.numpy()[0]).max()))
 
 
-@pytest.mark.parametrize("heads,kvh,T,max_ctx,kvd,window,start", [(4, 1, 40, 64, 1, 0, 0), (4, 2, 70, 128, 0, 0, 0), (2, 2, 33, 96, 1, 0, 20), (8, 2, 50, 4096, 1, 0, 0), (4, 1, 90, 128, 1, 40, 0)])
+@pytest.mark.parametrize("heads,kvh,T,max_ctx,kvd,window,start", [(4, 1, 40, 64, 1, 0, 0), (4, 2, 70, 128, 0, 0, 0), (2, 2, 33, 96, 1, 0, 20), (8, 2, 50, 4096, 1, 0, 0), (4, 1, 90, 128, 1, 40, 0), (8, 1, 37, 64, 1, 0, 0), (16, 2, 21, 4096, 0, 0, 5)])
 def test_prompt_attention_equals_decode_attention_host_emulation(oracle, heads, kvh, T, max_ctx, kvd, window, start):
     check_attention(oracle, HostBackend(), heads, kvh, T, max_ctx, kvd, window, start)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("heads,kvh,T,max_ctx,kvd,window,start", [(32, 8, 512, 1024, 1, 0, 0), (32, 8, 300, 4096, 1, 0, 100), (8, 4, 129, 160, 0, 0, 0), (32, 8, 700, 832, 1, 256, 0), (32, 32, 64, 512, 1, 0, 0)])
+@pytest.mark.parametrize("heads,kvh,T,max_ctx,kvd,window,start", [(32, 8, 512, 1024, 1, 0, 0), (32, 8, 300, 4096, 1, 0, 100), (8, 4, 129, 160, 0, 0, 0), (32, 8, 700, 832, 1, 256, 0), (32, 32, 64, 512, 1, 0, 0), (64, 8, 200, 2304, 1, 0, 0)])
 def test_prompt_attention_equals_decode_attention_gpu(oracle, dev, heads, kvh, T, max_ctx, kvd, window, start):
     check_attention(oracle, GpuBackend(dev), heads, kvh, T, max_ctx, kvd, window, start)
 
