@@ -210,7 +210,14 @@ def measured_traffic(model_name, quant="q4_k_m"):
             k = next(v for name, v in ks.items() if "dec_gemv_kernel<1, 2" in name.replace("(bool)1", "true").replace("(int)", ""))
         except (OSError, KeyError, ValueError, StopIteration):
             continue
-        return {"traffic": int(k["read_bytes_per_launch"] + k["write_bytes_per_launch"]), "traffic_source": rel}
+        out = {"traffic": int(k["read_bytes_per_launch"] + k["write_bytes_per_launch"]), "traffic_source": rel}
+        try:  # the same kernel's average duration INSIDE the captured decode graph (rocprofv3 kernel trace of this command; includes the launch boundary)
+            st = json.load(open(os.path.join(here, rel.replace("_hbm_traffic", "_kernel_stats"))))["kernels"]
+            kk = next(v for name, v in st.items() if "dec_gemv_kernel<1, 2" in name.replace("(bool)1", "true").replace("(int)", ""))
+            out["in_graph_us_per_launch"] = round(kk["avg_us"], 2)
+        except (OSError, KeyError, ValueError, StopIteration):
+            pass
+        return out
     return {"traffic": None}
 
 
@@ -647,6 +654,8 @@ def main():
                      "bytes_per_launch": int(kern_bytes), "us_per_launch": round(kern_s * 1e6, 2), **measured_traffic(name, a.quant)},
         "greedy_tokens_head": [int(t) for t in toks[a.warmup: a.warmup + 8]],
     }
+    if out["roofline"].get("in_graph_us_per_launch"):  # committed profile of this command: the kernel inside the decode graph, launch boundary included
+        out["roofline"]["in_graph_frac"] = round(kern_bytes / (out["roofline"]["in_graph_us_per_launch"] * 1e-6) / HBM_PEAK, 4)
     if ttft_bf16 is not None:
         out["prefill_bf16"] = {"tokens_per_sec": round(a.prompt_len / ttft_bf16, 1), "ttft_ms": round(1e3 * ttft_bf16, 2), "frac": round(prefill_flops / ttft_bf16 / MFMA_PEAK, 4),
                                "note": "same prompt through the selectable bf16-operand path (Llama.set_prefill_mode(0) / MRS_PREFILL_EXACT=0): faster, but its logits and KV pages are "

@@ -53,6 +53,14 @@ void topk_large_f32_packed(const float *input, float *block_values, uint32_t *bl
 void topk_large_f32_packed_batched(const float *input, const float *inv_temperatures, float *block_values, uint32_t *block_indices, float *block_maxes,
                                    float *block_sums, float *packed_out, int nrows, int ncols, int k, int chunk_size, int nblocks, int64_t stream);
 
+/* Greedy sampling: arg-max of f32 logits rows.  block_values / block_indices [nrows][nblocks] are workspace; packed_out [nrows][2] = (max logit, token id as f32),
+ * token_ids_out [nrows] (either may be NULL).  Lowest index on ties; a row holding a NaN reports token 0xffffffff and (NaN, NaN); a row of -inf reports token 0.
+ * replaces mistralrs-core/src/cuda/sort.cu:1825-1912,2071-2143,2207-2238 ; ffi.rs:643-665 ; callers ops.rs:1232-2050 (cuda_top1_logits_f32_*) */
+void top1_large_f32_packed(const float *input, float *block_values, uint32_t *block_indices, float *packed_out, uint32_t *token_ids_out, int ncols, int chunk_size,
+                           int nblocks, int64_t stream);
+void top1_large_f32_packed_batched(const float *input, float *block_values, uint32_t *block_indices, float *packed_out, uint32_t *token_ids_out, int nrows, int ncols,
+                                   int chunk_size, int nblocks, int64_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,5 +1,6 @@
 // sampling.hip -- libmistralrscuda, sampling subset: top-k of one logits row over a 100k+ vocabulary + the pieces of the full-softmax normaliser the host
 // sampler needs (Sampler::sample_topk_on_device, mistralrs-core/src/sampler.rs:1171-1260: top-p / min-p / the multinomial draw stay on the host).
+//   top1_large_f32_packed, top1_large_f32_packed_batched                     sort.cu:1825-1912,2071-2143,2207-2238 ; ffi.rs:643-665 ; caller ops.rs:1232-2000 (greedy)
 //   topk_large_f32, topk_large_f32_packed, topk_large_f32_packed_batched      mistralrs-core/src/cuda/sort.cu:1502-1823,2146-2206 ; ffi.rs:583-624 ;
 //                                                                              caller ops.rs:691-828 (cuda_topk_logits_f32_packed)
 // Contract kept from the reference (the caller owns every buffer):
@@ -277,6 +278,97 @@ static void run(const float *input, const float *inv_temperatures, float inv_tem
   }
 }
 
+// ---------------------------------------------------------------- greedy: top1_large_f32_packed[_batched] (sort.cu:1825-1912, 2071-2143, 2207-2238)
+// stage 1: per chunk the largest logit and its (lowest) index; a chunk that holds a NaN reports (NaN, 0); no finite or +inf value -> (-inf, 0).
+// stage 2: per row the best chunk (lowest position on ties); any NaN chunk -> token id UINT32_MAX and packed (NaN, NaN); nothing selectable -> token 0.
+struct Top1Args {
+  const float *input;
+  float *block_values;
+  uint32_t *block_indices;
+  float *packed_out;
+  uint32_t *token_ids_out;
+  int ncols, chunk_size, nblocks;
+};
+// block-wide (key, value) arg-max + NaN flag: returns in thread 0
+__device__ __forceinline__ void block_argmax(unsigned long long best, float val, bool nan, unsigned long long &okey, float &oval, bool &onan) {
+  __shared__ unsigned long long s_k[4];
+  __shared__ float s_v[4];
+  __shared__ int s_n[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned long long w = wave_max_u64(best);
+  const bool any_nan = __ballot(nan) != 0ull;
+  if (w != 0ull && best == w) { s_k[wave] = w; s_v[wave] = val; }  // keys carry the position: one lane
+  if (w == 0ull && lane == 0) { s_k[wave] = 0ull; s_v[wave] = -INFINITY; }
+  if (lane == 0) s_n[wave] = any_nan;
+  __syncthreads();
+  okey = 0ull; oval = -INFINITY; onan = false;
+  if (tid == 0) {
+    for (int i = 0; i < 4; ++i) {
+      if (s_k[i] > okey) { okey = s_k[i]; oval = s_v[i]; }
+      onan = onan || s_n[i] != 0;
+    }
+  }
+  __syncthreads();
+}
+template <bool BATCHED>
+__global__ void __launch_bounds__(NT) top1_stage1_kernel(Top1Args a) {
+  const int tid = threadIdx.x, chunk = blockIdx.x;
+  const size_t row = BATCHED ? blockIdx.y : 0;
+  const float *input = a.input + row * (size_t)a.ncols;
+  const int start = chunk * a.chunk_size, end = min(start + a.chunk_size, a.ncols);
+  unsigned long long best = 0ull;
+  float val = -INFINITY;
+  bool nan = false;
+  for (int idx = start + tid; idx < end; idx += NT) {
+    const float c = input[idx];
+    if (c != c) nan = true;
+    const unsigned long long key = key_of(c, (unsigned)idx);
+    if (key > best) { best = key; val = c; }
+  }
+  unsigned long long k; float v; bool n;
+  block_argmax(best, val, nan, k, v, n);
+  if (tid == 0) {
+    a.block_values[row * a.nblocks + chunk] = n ? NAN : v;
+    a.block_indices[row * a.nblocks + chunk] = n || k == 0ull ? 0u : ~(unsigned)(k & 0xffffffffull);
+  }
+}
+template <bool BATCHED>
+__global__ void __launch_bounds__(NT) top1_stage2_kernel(Top1Args a) {
+  const int tid = threadIdx.x;
+  const size_t row = BATCHED ? blockIdx.x : 0;
+  const float *bv = a.block_values + row * (size_t)a.nblocks;
+  const uint32_t *bi = a.block_indices + row * (size_t)a.nblocks;
+  unsigned long long best = 0ull;
+  float val = -INFINITY;
+  bool nan = false;
+  for (int pos = tid; pos < a.nblocks; pos += NT) {
+    const float c = bv[pos];
+    if (c != c) nan = true;
+    const unsigned long long key = key_of(c, (unsigned)pos);
+    if (key > best) { best = key; val = c; }
+  }
+  unsigned long long k; float v; bool n;
+  block_argmax(best, val, nan, k, v, n);
+  if (tid == 0) {
+    const uint32_t token = n ? 0xffffffffu : (k != 0ull ? bi[~(unsigned)(k & 0xffffffffull)] : 0u);
+    if (a.packed_out) { a.packed_out[row * 2] = n ? NAN : v; a.packed_out[row * 2 + 1] = n ? NAN : (float)token; }
+    if (a.token_ids_out) a.token_ids_out[row] = token;
+  }
+}
+static void run_top1(const float *input, float *block_values, uint32_t *block_indices, float *packed_out, uint32_t *token_ids_out, int nrows, int ncols, int chunk_size,
+                     int nblocks, bool batched, int64_t stream) {
+  if (ncols <= 0 || chunk_size <= 0 || nblocks <= 0 || nrows <= 0 || (long long)nblocks * chunk_size < ncols) return;
+  hipStream_t s = (hipStream_t)stream;
+  Top1Args a{input, block_values, block_indices, packed_out, token_ids_out, ncols, chunk_size, nblocks};
+  if (batched) {
+    hipLaunchKernelGGL(top1_stage1_kernel<true>, dim3(nblocks, nrows), dim3(NT), 0, s, a);
+    hipLaunchKernelGGL(top1_stage2_kernel<true>, dim3(nrows), dim3(NT), 0, s, a);
+  } else {
+    hipLaunchKernelGGL(top1_stage1_kernel<false>, dim3(nblocks), dim3(NT), 0, s, a);
+    hipLaunchKernelGGL(top1_stage2_kernel<false>, dim3(1), dim3(NT), 0, s, a);
+  }
+}
+
 }  // namespace sampling
 }  // namespace mrs
 
@@ -296,3 +388,12 @@ extern "C" void topk_large_f32_packed_batched(const float *input, const float *i
   mrs::sampling::run(input, inv_temperatures, 0.0f, block_values, block_indices, block_maxes, block_sums, packed_out, nullptr, nullptr, nullptr, nrows, ncols, k,
                      chunk_size, nblocks, true, stream);
 }
+extern "C" void top1_large_f32_packed(const float *input, float *block_values, uint32_t *block_indices, float *packed_out, uint32_t *token_ids_out, int ncols,
+                                      int chunk_size, int nblocks, int64_t stream) {
+  mrs::sampling::run_top1(input, block_values, block_indices, packed_out, token_ids_out, 1, ncols, chunk_size, nblocks, false, stream);
+}
+extern "C" void top1_large_f32_packed_batched(const float *input, float *block_values, uint32_t *block_indices, float *packed_out, uint32_t *token_ids_out, int nrows,
+                                              int ncols, int chunk_size, int nblocks, int64_t stream) {
+  mrs::sampling::run_top1(input, block_values, block_indices, packed_out, token_ids_out, nrows, ncols, chunk_size, nblocks, true, stream);
+}
+

@@ -131,6 +131,10 @@ grep -q '^__global__ void topk_large_stage1_f32($' "$REF/mistralrs-core/src/cuda
   awk '/^__device__ __forceinline__ float warp_reduce_sum_f32/{p=1} /^\/\/ Large-vocabulary top-k for token sampling/{exit} p{print}' "$S"
   awk '/^__global__ void topk_large_stage1_f32\($/{print "template <bool BATCHED>"; p=1} /^__global__ void topk_large_stage2_f32\($/{exit} p{print}' "$S" | sed 's/extern __shared__ char smem\[\];/char *smem = shim_fiber::dyn_smem;/'
   awk '/^__global__ void topk_large_stage2_f32_packed\($/{print "template <bool BATCHED>"; p=1} /^template <bool BATCHED, bool COMPUTE_SUMS>/{exit} p{print}' "$S" | sed 's/extern __shared__ char smem\[\];/char *smem = shim_fiber::dyn_smem;/'
+  # greedy: top1_large_stage1_f32 (:1825-1912) and top1_large_stage2_f32_packed (:2071-2143); __syncthreads_or is three block barriers around a flag
+  echo 'static int shim_or_flag; static inline int __syncthreads_or(int p) { __syncthreads(); if (p) shim_or_flag = 1; __syncthreads(); const int r = shim_or_flag; __syncthreads(); if (threadIdx.x == 0) shim_or_flag = 0; return r; }'
+  awk '/^__global__ void top1_large_stage1_f32\($/{print "template <bool BATCHED, bool COMPUTE_SUMS>"; p=1} /^__global__ void categorical_large_stage2_f32_packed\($/{exit} p{print}' "$S"
+  awk '/^top1_large_stage2_f32_packed\(/{print "template <bool BATCHED>"; print "__global__ void"; p=1} /^extern "C" void topk_large_f32\(/{exit} p{print}' "$S"
   cat "$HERE/ref_shim/topk_driver.inc" ) | $CXX $FLAGS $FIB -o "$OUT/libref_topk.so" -
 # fused_glu (mistralrs-quant/kernels/ops/ops.cu): activation enum + functions, scalar and vec4 kernels; f32 / f16 / bf16
 OPS="$REF/mistralrs-quant/kernels/ops/ops.cu"

@@ -630,6 +630,36 @@ def topk_large_packed(logits: np.ndarray, k: int, inv_temperature: float, chunk_
     return {"packed": packed, "block_values": bv, "block_indices": bi, "block_maxes": bm, "block_sums": bs}
 
 
+def top1_large_packed(logits: np.ndarray, chunk_size: int = 2048):
+    """top1_large_stage1_f32 + top1_large_stage2_f32_packed (sort.cu:1825-1912, 2071-2143) for ONE f32 row, restated: per chunk (max, lowest index) -- a chunk with a NaN
+    reports (NaN, 0), a chunk without a selectable value (-inf, 0) --, then the best chunk (lowest position on ties).  Returns (packed [2] = max, token as f32; token id;
+    block_values; block_indices): token 0xffffffff and packed (NaN, NaN) when the row holds a NaN, token 0 when nothing is selectable."""
+    x = np.ascontiguousarray(logits, dtype=np.float32).reshape(-1)
+    n = x.size
+    nblocks = (n + chunk_size - 1) // chunk_size
+    bv, bi = np.empty(nblocks, dtype=np.float32), np.zeros(nblocks, dtype=np.uint32)
+    for c in range(nblocks):
+        seg = x[c * chunk_size:(c + 1) * chunk_size]
+        if np.isnan(seg).any():
+            bv[c], bi[c] = np.nan, 0
+            continue
+        ok = seg > -np.inf
+        if not ok.any():
+            bv[c], bi[c] = -np.inf, 0
+            continue
+        m = seg[ok].max()
+        j = int(np.nonzero(ok & (seg == m))[0][0])  # `>` keeps the first of equal values (-0.0 == +0.0)
+        bv[c], bi[c] = seg[j], c * chunk_size + j
+    if np.isnan(bv).any():
+        return np.array([np.nan, np.nan], dtype=np.float32), np.uint32(0xFFFFFFFF), bv, bi
+    ok = bv > -np.inf
+    if not ok.any():
+        return np.array([-np.inf, 0.0], dtype=np.float32), np.uint32(0), bv, bi
+    m = bv[ok].max()
+    p = int(np.nonzero(ok & (bv == m))[0][0])
+    return np.array([bv[p], np.float32(bi[p])], dtype=np.float32), np.uint32(bi[p]), bv, bi
+
+
 def sample_topk_host(packed: np.ndarray, k: int, temperature: float, top_p: float = 1.0, min_p: float = 0.0):
     """The host half of Sampler::sample_topk_on_device (sampler.rs:1189-1236): probabilities of the k candidates under the FULL softmax, then the top-p cut
     (`top_p_cutoff` = top_p * sum of the kept probabilities, cumulative sum in candidate order) and the min-p cut (threshold = first probability * min_p).

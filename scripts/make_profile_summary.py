@@ -28,6 +28,14 @@ def main():
     with open(os.path.join(root, "profiles", f"{tag}_kernel_stats.md"), "w") as f:
         f.write(f"# {tag}: `rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline` (MI355X, per-kernel, mrs:: kernels)\n\n")
         f.write(table)
+    # per-kernel average durations of the same pass as JSON (bench.py reads the dominant kernel's IN-GRAPH time from it: inside a captured graph the start / end stamps
+    # of consecutive kernels touch, so these durations include the launch boundary that the HIP-event figure of bench.py's `roofline` does not)
+    stats = glob.glob(os.path.join(src, "kt", "**", "*kernel_stats.csv"), recursive=True)
+    if stats:
+        ks = {r["Name"]: {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "min_us": float(r["MinNs"]) / 1e3, "max_us": float(r["MaxNs"]) / 1e3}
+              for r in csv.DictReader(open(stats[0])) if "mrs::" in r["Name"]}
+        with open(os.path.join(root, "profiles", f"{tag}_kernel_stats.json"), "w") as f:
+            json.dump({"source": "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-extra (decode graph replays + the prompt)", "kernels": ks}, f, indent=1, sort_keys=True)
     fetch, write = counters(os.path.join(src, "fetch"), "FETCH_SIZE"), counters(os.path.join(src, "write"), "WRITE_SIZE")
     out = {}
     for k, v in fetch.items():

@@ -192,3 +192,71 @@ def test_sampled_generation_on_the_runner(oracle, dev):
     a = sampler.generate(m, prompt, 8, top_k=20, temperature=1.5, top_p=0.9, min_p=0.02, seed=5)
     b = sampler.generate(m, prompt, 8, top_k=20, temperature=1.5, top_p=0.9, min_p=0.02, seed=5)
     assert a == b and all(0 < p <= 1 for p in a[1]) and all(0 <= t < cfg.vocab_size for t in a[0])
+
+
+# ---------------------------------------------------------------- greedy: top1_large_f32_packed[_batched]
+TOP1 = [(5000, 2048, "normal", 0), (128256, 2048, "normal", 1), (4100, 2048, "ties", 2), (3000, 2048, "nan", 3), (3000, 512, "sparse", 5), (1, 2048, "normal", 6),
+        (2049, 2048, "ties", 7), (700, 100, "allinf", 8)]
+
+
+def _top1_rows(n, kind, seed, rows=3):
+    if kind == "allinf":
+        return np.full((rows, n), -np.inf, dtype=np.float32)
+    xs = np.stack([_logits(n, seed + 31 * r, kind if r != 1 else "normal") for r in range(rows)])
+    if kind == "ties":
+        xs[2, :] = np.float32(-0.0)
+        xs[2, n // 3] = np.float32(0.0)  # equal to the -0.0 before it: the first index wins
+    return xs
+
+
+@pytest.mark.parametrize("n,chunk,kind,seed", TOP1, ids=[f"n{c[0]}c{c[1]}{c[2]}" for c in TOP1])
+def test_top1_restatement_matches_reference_kernels(oracle, n, chunk, kind, seed):
+    lib = _ref()
+    xs = _top1_rows(n, kind, seed)
+    rows, nb = xs.shape[0], (n + chunk - 1) // chunk
+    bv, bi = np.zeros(rows * nb, np.float32), np.zeros(rows * nb, np.uint32)
+    packed, toks = np.zeros(rows * 2, np.float32), np.zeros(rows, np.uint32)
+    vp = lambda a: a.ctypes.data_as(VP)
+    assert lib.ref_top1_large_f32_packed_batched(vp(xs), vp(bv), vp(bi), vp(packed), vp(toks), rows, n, chunk, nb) == 0
+    for r in range(rows):
+        p, t, v, i = oracle.top1_large_packed(xs[r], chunk)
+        np.testing.assert_array_equal(p.view(np.uint32) if not np.isnan(p).any() else np.isnan(p), packed[2 * r:2 * r + 2].view(np.uint32) if not np.isnan(p).any() else np.isnan(packed[2 * r:2 * r + 2]))
+        assert int(t) == int(toks[r])
+        np.testing.assert_array_equal(np.isnan(v), np.isnan(bv[r * nb:(r + 1) * nb]))
+        np.testing.assert_array_equal(v[~np.isnan(v)].view(np.uint32), bv[r * nb:(r + 1) * nb][~np.isnan(v)].view(np.uint32))
+        np.testing.assert_array_equal(i, bi[r * nb:(r + 1) * nb])
+
+
+def check_top1_product(be, oracle, n, chunk, kind, seed):
+    xs = _top1_rows(n, kind, seed)
+    rows, nb = xs.shape[0], (n + chunk - 1) // chunk
+    xb = be.buf(xs)
+    bv, bi = be.buf(np.zeros(rows * nb, np.float32)), be.buf(np.zeros(rows * nb, np.uint32))
+    pk, tk = be.buf(np.zeros(rows * 2, np.float32)), be.buf(np.zeros(rows, np.uint32))
+    be.sym("top1_large_f32_packed_batched", [VP, VP, VP, VP, VP, I, I, I, I, LL])(xb.ptr, bv.ptr, bi.ptr, pk.ptr, tk.ptr, rows, n, chunk, nb, be.stream or 0)
+    got_p, got_t = pk.numpy().reshape(rows, 2), tk.numpy()
+    for r in range(rows):
+        p, t, v, i = oracle.top1_large_packed(xs[r], chunk)
+        assert int(got_t[r]) == int(t), (r, got_t[r], t)
+        if np.isnan(p).any():
+            assert np.isnan(got_p[r]).all()
+        else:
+            np.testing.assert_array_equal(got_p[r].view(np.uint32), p.view(np.uint32))
+    # single-row entry point, token ids only
+    t1 = be.buf(np.zeros(1, np.uint32))
+    x0 = be.buf(xs[0].copy())
+    be.sym("top1_large_f32_packed", [VP, VP, VP, VP, VP, I, I, I, LL])(x0.ptr, bv.ptr, bi.ptr, None, t1.ptr, n, chunk, nb, be.stream or 0)
+    assert int(t1.numpy()[0]) == int(oracle.top1_large_packed(xs[0], chunk)[1])
+
+
+@pytest.mark.parametrize("n,chunk,kind,seed", [c for c in TOP1 if c[0] <= 5000], ids=[f"n{c[0]}c{c[1]}{c[2]}" for c in TOP1 if c[0] <= 5000])
+def test_top1_host_emulation(oracle, n, chunk, kind, seed):
+    from tests.abi_backends import HostBackend
+    check_top1_product(HostBackend(), oracle, n, chunk, kind, seed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,chunk,kind,seed", TOP1, ids=[f"n{c[0]}c{c[1]}{c[2]}" for c in TOP1])
+def test_top1_gpu(oracle, dev, n, chunk, kind, seed):
+    from tests.abi_backends import GpuBackend
+    check_top1_product(GpuBackend(dev), oracle, n, chunk, kind, seed)
