@@ -237,7 +237,7 @@ def check_top1_product(be, oracle, n, chunk, kind, seed):
     got_p, got_t = pk.numpy().reshape(rows, 2), tk.numpy()
     for r in range(rows):
         p, t, v, i = oracle.top1_large_packed(xs[r], chunk)
-        assert int(got_t[r]) == int(t), (r, got_t[r], t)
+        assert int(got_t[r]) & 0xFFFFFFFF == int(t), (r, got_t[r], t)  # the device buffer comes back as int32
         if np.isnan(p).any():
             assert np.isnan(got_p[r]).all()
         else:
@@ -246,7 +246,7 @@ def check_top1_product(be, oracle, n, chunk, kind, seed):
     t1 = be.buf(np.zeros(1, np.uint32))
     x0 = be.buf(xs[0].copy())
     be.sym("top1_large_f32_packed", [VP, VP, VP, VP, VP, I, I, I, LL])(x0.ptr, bv.ptr, bi.ptr, None, t1.ptr, n, chunk, nb, be.stream or 0)
-    assert int(t1.numpy()[0]) == int(oracle.top1_large_packed(xs[0], chunk)[1])
+    assert int(t1.numpy()[0]) & 0xFFFFFFFF == int(oracle.top1_large_packed(xs[0], chunk)[1])
 
 
 @pytest.mark.parametrize("n,chunk,kind,seed", [c for c in TOP1 if c[0] <= 5000], ids=[f"n{c[0]}c{c[1]}{c[2]}" for c in TOP1 if c[0] <= 5000])
