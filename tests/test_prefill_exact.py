@@ -82,6 +82,14 @@ def test_prefill_equals_token_by_token_decode_and_engine_order_oracle(oracle, de
     for layer, (k1, k2, v1, v2) in enumerate(zip(m1.key_caches, m2.key_caches, m1.value_caches, m2.value_caches)):
         assert torch.equal(k1.view(torch.int16), k2.view(torch.int16)), f"layer {layer}: K pages written by prefill != pages written by decode"
         assert torch.equal(v1.view(torch.int16), v2.view(torch.int16)), f"layer {layer}: V pages written by prefill != pages written by decode"
+    # the same prompt in two chunks (second chunk at start_pos > 0 attends the pages of the first): same pages, same logits
+    _, _, m3, _, _ = _mk(oracle, dev, Q4KM(oracle), kv)
+    cut = n_prompt // 2 + 1
+    m3.prefill(prompt[:cut], 0)
+    lc = m3.prefill(prompt[cut:], cut).float().cpu().numpy()
+    assert np.array_equal(lc, lp), "two-chunk prefill differs from the one-pass prefill"
+    for layer, (k1, k3, v1, v3) in enumerate(zip(m1.key_caches, m3.key_caches, m1.value_caches, m3.value_caches)):
+        assert torch.equal(k1.view(torch.int16), k3.view(torch.int16)) and torch.equal(v1.view(torch.int16), v3.view(torch.int16)), f"layer {layer}: chunked prefill pages differ"
     tok = int(lp.argmax())
     for pos in range(n_prompt, n_prompt + n_more):
         want = ref.step(tok, pos)
