@@ -266,7 +266,8 @@ static void run(const float *input, const float *inv_temperatures, float inv_tem
   hipStream_t s = (hipStream_t)stream;
   Stage1Args a1{input, block_values, block_indices, block_maxes, block_sums, inv_temperatures, inv_temperature, ncols, k, chunk_size, nblocks};
   const size_t heads_bytes = ((size_t)nblocks * sizeof(int) + 7) & ~(size_t)7;
-  const int depth = (int)std::min<size_t>((size_t)k, (60 * 1024 - heads_bytes) / 8 / (size_t)nblocks);  // keys staged per list (60 KiB of LDS)
+  if (heads_bytes > 56 * 1024) return;  // > 14 k chunks (a 29 M-token vocabulary at the reference's chunk size): outside this kernel
+  const int depth = (int)std::min<size_t>((size_t)k, (60 * 1024 - heads_bytes) / 8 / (size_t)nblocks);  // keys staged per list (60 KiB of LDS in all; 0 = read from memory)
   Stage2Args a2{block_values, block_indices, block_maxes, block_sums, packed_out, values_out, indices_out, softmax_info_out, nblocks, k, depth};
   const size_t lds2 = heads_bytes + (size_t)nblocks * depth * 8;
   if (batched) {
