@@ -61,6 +61,13 @@ void top1_large_f32_packed(const float *input, float *block_values, uint32_t *bl
 void top1_large_f32_packed_batched(const float *input, float *block_values, uint32_t *block_indices, float *packed_out, uint32_t *token_ids_out, int nrows, int ncols,
                                    int chunk_size, int nblocks, int64_t stream);
 
+/* Sampler pre-processing: dst [n] = x [n] (f32), then for the n_tokens listed token ids (ids >= n ignored): penalties -- skipped where count <= 0;
+ * v -= count * frequency_penalty + presence_penalty; if repetition_penalty != 1: v = v > 0 ? v / rp : v * rp -- or additive biases.
+ * replaces mistralrs-core/src/cuda/sort.cu:8-110 ; ffi.rs:45-65 ; callers sampler.rs:1113-1169 */
+void apply_sparse_penalties_f32(const void *x, void *dst, const uint32_t *token_ids, const float *counts, int n, int n_tokens, float frequency_penalty,
+                                float presence_penalty, float repetition_penalty, int64_t stream);
+void apply_sparse_logits_bias_f32(const void *x, void *dst, const uint32_t *token_ids, const float *biases, int n, int n_tokens, int64_t stream);
+
 #ifdef __cplusplus
 }
 #endif

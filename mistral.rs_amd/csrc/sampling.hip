@@ -370,6 +370,36 @@ static void run_top1(const float *input, float *block_values, uint32_t *block_in
   }
 }
 
+// ---------------------------------------------------------------- logits pre-processing of the sampler (sort.cu:8-110; callers sampler.rs:1113-1169)
+// dst = x, then the listed tokens are updated in place: penalties (frequency / presence / repetition, counts from the context) or additive biases.
+__global__ void __launch_bounds__(NT) copy_f32_kernel(const float *__restrict__ x, float *__restrict__ dst, int n) {
+  const int i = (blockIdx.x * NT + threadIdx.x) * 4;
+  if (i + 3 < n && ((((uintptr_t)x | (uintptr_t)dst) & 15) == 0)) *(float4 *)(dst + i) = *(const float4 *)(x + i);
+  else
+    for (int j = i; j < n && j < i + 4; ++j) dst[j] = x[j];
+}
+__global__ void __launch_bounds__(NT) sparse_penalties_kernel(float *__restrict__ logits, const uint32_t *__restrict__ token_ids, const float *__restrict__ counts, int n,
+                                                              int n_tokens, float frequency_penalty, float presence_penalty, float repetition_penalty) {
+  const int idx = blockIdx.x * NT + threadIdx.x;
+  if (idx >= n_tokens) return;
+  const uint32_t token_id = token_ids[idx];
+  if (token_id >= (uint32_t)n) return;
+  const float count = counts[idx];
+  if (count <= 0.0f) return;
+  float value = logits[token_id];
+  value -= fmaf(count, frequency_penalty, presence_penalty);  // `count * f + p` as nvcc contracts it (one rounding); this build has -ffp-contract=off, hence explicit
+  if (repetition_penalty != 1.0f) value = value > 0.0f ? value / repetition_penalty : value * repetition_penalty;
+  logits[token_id] = value;
+}
+__global__ void __launch_bounds__(NT) sparse_bias_kernel(float *__restrict__ logits, const uint32_t *__restrict__ token_ids, const float *__restrict__ biases, int n,
+                                                         int n_tokens) {
+  const int idx = blockIdx.x * NT + threadIdx.x;
+  if (idx >= n_tokens) return;
+  const uint32_t token_id = token_ids[idx];
+  if (token_id >= (uint32_t)n) return;
+  logits[token_id] += biases[idx];  // token ids are unique in the caller's map (sampler.rs:1145-1160), as in the reference
+}
+
 }  // namespace sampling
 }  // namespace mrs
 
@@ -396,5 +426,23 @@ extern "C" void top1_large_f32_packed(const float *input, float *block_values, u
 extern "C" void top1_large_f32_packed_batched(const float *input, float *block_values, uint32_t *block_indices, float *packed_out, uint32_t *token_ids_out, int nrows,
                                               int ncols, int chunk_size, int nblocks, int64_t stream) {
   mrs::sampling::run_top1(input, block_values, block_indices, packed_out, token_ids_out, nrows, ncols, chunk_size, nblocks, true, stream);
+}
+extern "C" void apply_sparse_penalties_f32(const void *x, void *dst, const uint32_t *token_ids, const float *counts, const int n, const int n_tokens,
+                                           const float frequency_penalty, const float presence_penalty, const float repetition_penalty, int64_t stream) {
+  using namespace mrs::sampling;
+  if (n <= 0) return;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(copy_f32_kernel, dim3((n + NT * 4 - 1) / (NT * 4)), dim3(NT), 0, s, (const float *)x, (float *)dst, n);
+  if (n_tokens <= 0) return;
+  hipLaunchKernelGGL(sparse_penalties_kernel, dim3((n_tokens + NT - 1) / NT), dim3(NT), 0, s, (float *)dst, token_ids, counts, n, n_tokens, frequency_penalty,
+                     presence_penalty, repetition_penalty);
+}
+extern "C" void apply_sparse_logits_bias_f32(const void *x, void *dst, const uint32_t *token_ids, const float *biases, const int n, const int n_tokens, int64_t stream) {
+  using namespace mrs::sampling;
+  if (n <= 0) return;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(copy_f32_kernel, dim3((n + NT * 4 - 1) / (NT * 4)), dim3(NT), 0, s, (const float *)x, (float *)dst, n);
+  if (n_tokens <= 0) return;
+  hipLaunchKernelGGL(sparse_bias_kernel, dim3((n_tokens + NT - 1) / NT), dim3(NT), 0, s, (float *)dst, token_ids, biases, n, n_tokens);
 }
 

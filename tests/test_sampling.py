@@ -263,3 +263,46 @@ def test_top1_host_emulation(oracle, n, chunk, kind, seed):
 def test_top1_gpu(oracle, dev, n, chunk, kind, seed):
     from tests.abi_backends import GpuBackend
     check_top1_product(GpuBackend(dev), oracle, n, chunk, kind, seed)
+
+
+# ---------------------------------------------------------------- sampler pre-processing: apply_sparse_penalties_f32 / apply_sparse_logits_bias_f32 (sort.cu:8-110)
+def check_penalties_and_bias(be, n=5003, n_tokens=300, seed=0):
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal(n) * 4).astype(np.float32)
+    ids = rng.permutation(n + 50)[:n_tokens].astype(np.uint32)  # unique; some >= n (ignored)
+    counts = rng.integers(0, 5, n_tokens).astype(np.float32)    # zeros: skipped
+    biases = rng.standard_normal(n_tokens).astype(np.float32)
+    xb, ib, cb, bb = be.buf(x), be.buf(ids), be.buf(counts), be.buf(biases)
+    for fp, pp, rp in [(0.3, 0.1, 1.0), (0.0, 0.0, 1.3), (0.7, -0.2, 0.8)]:
+        dst = be.buf(np.zeros(n, np.float32))
+        be.sym("apply_sparse_penalties_f32", [VP, VP, VP, VP, I, I, F, F, F, LL])(xb.ptr, dst.ptr, ib.ptr, cb.ptr, n, n_tokens, fp, pp, rp, be.stream or 0)
+        want = x.copy()
+        for t, c in zip(ids, counts):
+            if t < n and c > 0:
+                v = np.float32(want[t] - np.float32(np.float64(c) * np.float64(np.float32(fp)) + np.float64(np.float32(pp))))  # count * f + p in one rounding (fma)
+                if np.float32(rp) != np.float32(1.0):
+                    v = np.float32(v / np.float32(rp)) if v > 0 else np.float32(v * np.float32(rp))
+                want[t] = v
+        np.testing.assert_array_equal(dst.numpy().view(np.uint32), want.view(np.uint32))
+    dst = be.buf(np.zeros(n, np.float32))
+    be.sym("apply_sparse_logits_bias_f32", [VP, VP, VP, VP, I, I, LL])(xb.ptr, dst.ptr, ib.ptr, bb.ptr, n, n_tokens, be.stream or 0)
+    want = x.copy()
+    for t, b in zip(ids, biases):
+        if t < n:
+            want[t] = np.float32(want[t] + b)
+    np.testing.assert_array_equal(dst.numpy().view(np.uint32), want.view(np.uint32))
+    # no listed tokens: a plain copy
+    dst = be.buf(np.zeros(n, np.float32))
+    be.sym("apply_sparse_logits_bias_f32", [VP, VP, VP, VP, I, I, LL])(xb.ptr, dst.ptr, ib.ptr, bb.ptr, n, 0, be.stream or 0)
+    np.testing.assert_array_equal(dst.numpy().view(np.uint32), x.view(np.uint32))
+
+
+def test_penalties_and_bias_host_emulation():
+    from tests.abi_backends import HostBackend
+    check_penalties_and_bias(HostBackend())
+
+
+@pytest.mark.gpu
+def test_penalties_and_bias_gpu(dev):
+    from tests.abi_backends import GpuBackend
+    check_penalties_and_bias(GpuBackend(dev), n=128256, n_tokens=4000, seed=1)
