@@ -11,8 +11,8 @@
 //   same order; packed_out = [k values][k indices as f32][denom][max].
 // MI355X design (not the reference's k rounds of scan-the-chunk + two block barriers each):
 //   stage 1: a chunk lives in REGISTERS (<= 16 logits per thread), every wave extracts the top-k of its quarter on its own -- one 64-bit key per candidate
-//   (order-preserving float bits << 32 | ~index, so ONE max reduction per round settles value and tie), 6 xor-shuffles per round, no barrier -- then wave 0
-//   merges the four sorted lists by heads (one lane per list).  stage 2 is the same head merge over the nblocks sorted lists (a lane per list, lists beyond
+//   (order-preserving float bits << 32 | ~index, so ONE max reduction per round settles value and tie; DPP + v_readlane, no LDS crossbar), each lane's keys
+//   sorted once so that its best is keys[0], no barrier -- then wave 0 merges the four sorted lists by heads (one lane per list).  stage 2 is the same head merge over the nblocks sorted lists (a lane per list, lists beyond
 //   64 share lanes): k rounds of one wave-wide max instead of k scans of nblocks * k candidates.
 //   The f32 sums keep the reference's association (per-thread strided partials, 32-lane shuffle-down trees, warp sums through LDS) so that only expf's last
 //   ulp separates the normaliser from the CUDA build's.
@@ -27,12 +27,21 @@ constexpr int NT = 256;       // threads per workgroup (the reference's block si
 constexpr int MAXV = 16;      // logits per thread kept in registers: chunks up to 4096
 constexpr int MAX_K = 128;    // CUDA_TOPK_MAX_K (ops.rs:18)
 
+// One 64-bit key per candidate: [63:32] the value's bits mapped to an order-preserving unsigned (with -0.0 == +0.0, as the reference's `>` sees them),
+// [31:1] ~index (so the LOWER index wins a tie; indices < 2^31), [0] "the value was -0.0" (to give back the original bits).  0 = not a candidate.
 __device__ __forceinline__ unsigned long long key_of(float v, unsigned idx) {
   // NaN and -inf are never candidates (sort.cu:1552: candidate == candidate && candidate > -INFINITY)
   if (!(v == v) || v == -INFINITY) return 0ull;
-  const unsigned u = __float_as_uint(v + 0.0f);  // -0.0 -> +0.0: the reference's `>` sees them as equal (the lower index wins)
+  const unsigned u = __float_as_uint(v + 0.0f);  // -0.0 -> +0.0
   const unsigned o = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-  return ((unsigned long long)o << 32) | (unsigned long long)(~idx);
+  const unsigned low = ((~idx) << 1) | (__float_as_uint(v) == 0x80000000u ? 1u : 0u);
+  return ((unsigned long long)o << 32) | (unsigned long long)low;
+}
+__device__ __forceinline__ unsigned idx_of(unsigned long long key) { return (~((unsigned)key >> 1)) & 0x7fffffffu; }
+__device__ __forceinline__ float val_of(unsigned long long key) {  // the candidate's original bits
+  const unsigned o = (unsigned)(key >> 32);
+  const unsigned u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+  return __uint_as_float(((unsigned)key & 1u) ? 0x80000000u : u);
 }
 // max over the wave, every lane gets it: DPP inside rows of 16 (xor 1, xor 2, half-row mirror, row mirror), then the four row results through v_readlane -- no LDS crossbar
 template <int CTRL> __device__ __forceinline__ unsigned long long dpp_u64(unsigned long long k) {
@@ -81,39 +90,41 @@ struct Stage1Args {
   int ncols, k, chunk_size, nblocks;
 };
 
-// merge `nl` lists sorted by key (descending) into the k best: lane l walks list l (l, l + 64, ... when nl > 64) by its head; `get(list, pos)` returns the key
-// (0 = exhausted), emit(ki, list, pos) receives the winners in order.  One wave.
-template <class Get, class Emit>
-__device__ __forceinline__ void head_merge(int nl, int k, int *heads /* LDS [nl] */, Get get, Emit emit) {
+// merge `nl` lists sorted by key (descending) into the k best: lane l walks list l (l, l + 64, ... when nl > 64) by its head and keeps the best of its heads in a
+// register; one wave-wide max per round, and only the WINNING lane does anything else (win(ki, list, pos), advance its head, refresh its best) -- no broadcast.
+// `get(list, pos)` returns the key (0 = exhausted); without a winner lane 0 calls win(ki, -1, 0).  One wave.
+template <class Get, class Win>
+__device__ __forceinline__ void head_merge(int nl, int k, int *heads /* LDS [nl] */, Get get, Win win) {
   const int lane = threadIdx.x & 63;
   for (int l = lane; l < nl; l += 64) heads[l] = 0;  // a lane only ever touches the heads of its own lists: no cross-lane traffic through LDS
-  for (int ki = 0; ki < k; ++ki) {
-    unsigned long long best = 0ull;
-    int bl = -1;
+  int bl = -1;
+  auto my_best = [&]() {
+    unsigned long long b = 0ull;
+    bl = -1;
     for (int l = lane; l < nl; l += 64) {
       const int h = heads[l];
       const unsigned long long key = h < k ? get(l, h) : 0ull;
-      if (key > best) { best = key; bl = l; }
+      if (key > b) { b = key; bl = l; }
     }
-    const unsigned long long win = wave_max_u64(best);
-    // keys are unique (they carry the index), so exactly one lane holds the winner -- unless nothing is left
-    const bool mine = win != 0ull && best == win;
-    const unsigned long long m = __ballot(mine);
-    int wl = -1, wp = 0;
-    if (m) {
-      const int src = __ffsll((long long)m) - 1;
-      wl = __shfl(bl, src, 64);
-      wp = __shfl(mine ? heads[bl < 0 ? 0 : bl] : 0, src, 64);
+    return b;
+  };
+  unsigned long long best = my_best();
+  for (int ki = 0; ki < k; ++ki) {
+    const unsigned long long w = wave_max_u64(best);
+    if (w != 0ull && best == w) {  // keys are unique (they carry the index): exactly one lane
+      const int pos = heads[bl];
+      win(ki, bl, pos);
+      heads[bl] = pos + 1;
+      best = my_best();
+    } else if (w == 0ull && lane == 0) {
+      win(ki, -1, 0);
     }
-    if (mine) heads[bl] += 1;
-    emit(ki, wl, wp);
   }
 }
 
 template <bool BATCHED>
 __global__ void __launch_bounds__(NT) topk_stage1_kernel(Stage1Args a) {
   __shared__ unsigned long long s_keys[4][MAX_K];  // each wave's sorted candidates
-  __shared__ float s_vals[4][MAX_K];
   __shared__ int s_heads[4];
   __shared__ float s_warp_sums[32];
   __shared__ float s_block_max;
@@ -134,40 +145,43 @@ __global__ void __launch_bounds__(NT) topk_stage1_kernel(Stage1Args a) {
     v[j] = local < width ? input[start + local] : -INFINITY;
     keys[j] = local < width ? key_of(v[j], (unsigned)(start + local)) : 0ull;
   }
-  // ---- every wave: the k best of its 64 x MAXV logits, sorted.  A lane keeps its best unused key; only the round's winner rescans its registers.
-  int bj = 0;
-  auto local_best = [&]() {
-    unsigned long long b = 0ull;
+  // ---- every wave: the k best of its 64 x MAXV logits, sorted.  Each lane first sorts ITS keys (descending, a bitonic network in registers), so that its
+  // best unused key is always keys[0]; the round's winner shifts its array down by one.  A round = one wave-wide 64-bit max + 2 * MAXV moves in one lane.
 #pragma unroll
-    for (int j = 0; j < MAXV; ++j)
-      if (keys[j] > b) { b = keys[j]; bj = j; }
-    return b;
-  };
-  unsigned long long best = local_best();
+  for (int size = 2; size <= MAXV; size <<= 1)
+#pragma unroll
+    for (int stride = size >> 1; stride > 0; stride >>= 1)
+#pragma unroll
+      for (int j = 0; j < MAXV; ++j) {
+        const int p = j ^ stride;
+        if (p > j) {
+          const bool desc = (j & size) == 0;  // direction of this bitonic block
+          const unsigned long long a = keys[j], b = keys[p];
+          const bool sw = desc ? a < b : a > b;
+          keys[j] = sw ? b : a;
+          keys[p] = sw ? a : b;
+        }
+      }
   for (int ki = 0; ki < k; ++ki) {
-    const unsigned long long win = wave_max_u64(best);
-    if (win != 0ull && best == win) {  // keys carry the index: exactly one lane
-      float val = 0.f;
-#pragma unroll
-      for (int j = 0; j < MAXV; ++j) { val = j == bj ? v[j] : val; keys[j] = j == bj ? 0ull : keys[j]; }
+    const unsigned long long win = wave_max_u64(keys[0]);
+    if (win != 0ull && keys[0] == win) {  // keys carry the index: exactly one lane
       s_keys[wave][ki] = win;
-      s_vals[wave][ki] = val;  // the original bits (a -0.0 stays -0.0)
-      best = local_best();
+#pragma unroll
+      for (int j = 0; j + 1 < MAXV; ++j) keys[j] = keys[j + 1];
+      keys[MAXV - 1] = 0ull;
     } else if (win == 0ull && lane == 0) {
       s_keys[wave][ki] = 0ull;
-      s_vals[wave][ki] = -INFINITY;
     }
   }
   __syncthreads();
   // ---- wave 0: merge the four lists
   if (wave == 0) {
     head_merge(4, k, s_heads, [&](int l, int h) { return s_keys[l][h]; },
-               [&](int ki, int wl, int wp) {
-                 if (lane == 0) {
-                   bv[ki] = wl >= 0 ? s_vals[wl][wp] : -INFINITY;
-                   bi[ki] = wl >= 0 ? ~(unsigned)(s_keys[wl][wp] & 0xffffffffull) : 0u;
-                   if (ki == 0) s_block_max = width > 0 ? (wl >= 0 ? s_vals[wl][wp] : -INFINITY) * inv_t : -INFINITY;
-                 }
+               [&](int ki, int wl, int wp) {  // the winning lane (or lane 0 when nothing is left)
+                 const unsigned long long key = wl >= 0 ? s_keys[wl][wp] : 0ull;
+                 bv[ki] = wl >= 0 ? val_of(key) : -INFINITY;
+                 bi[ki] = wl >= 0 ? idx_of(key) : 0u;
+                 if (ki == 0) s_block_max = width > 0 ? (wl >= 0 ? val_of(key) : -INFINITY) * inv_t : -INFINITY;
                });
   }
   __syncthreads();
@@ -243,9 +257,7 @@ __global__ void __launch_bounds__(NT) topk_stage2_kernel(Stage2Args a) {
   // critical path would cost more than the round itself
   __shared__ int s_win[MAX_K];
   head_merge(nb, k, heads, [&](int l, int h) { return h < depth ? skeys[l * depth + h] : key_of(bv[(size_t)l * k + h], bi[(size_t)l * k + h]); },
-             [&](int ki, int wl, int wp) {
-               if (lane == 0) s_win[ki] = wl >= 0 ? wl * k + wp : -1;
-             });
+             [&](int ki, int wl, int wp) { s_win[ki] = wl >= 0 ? wl * k + wp : -1; });
   MRS_WAVE_SYNC();
   for (int ki = lane; ki < k; ki += 64) {
     const int pos = s_win[ki];
@@ -330,7 +342,7 @@ __global__ void __launch_bounds__(NT) top1_stage1_kernel(Top1Args a) {
   block_argmax(best, val, nan, k, v, n);
   if (tid == 0) {
     a.block_values[row * a.nblocks + chunk] = n ? NAN : v;
-    a.block_indices[row * a.nblocks + chunk] = n || k == 0ull ? 0u : ~(unsigned)(k & 0xffffffffull);
+    a.block_indices[row * a.nblocks + chunk] = n || k == 0ull ? 0u : idx_of(k);
   }
 }
 template <bool BATCHED>
@@ -351,7 +363,7 @@ __global__ void __launch_bounds__(NT) top1_stage2_kernel(Top1Args a) {
   unsigned long long k; float v; bool n;
   block_argmax(best, val, nan, k, v, n);
   if (tid == 0) {
-    const uint32_t token = n ? 0xffffffffu : (k != 0ull ? bi[~(unsigned)(k & 0xffffffffull)] : 0u);
+    const uint32_t token = n ? 0xffffffffu : (k != 0ull ? bi[idx_of(k)] : 0u);
     if (a.packed_out) { a.packed_out[row * 2] = n ? NAN : v; a.packed_out[row * 2 + 1] = n ? NAN : (float)token; }
     if (a.token_ids_out) a.token_ids_out[row] = token;
   }
