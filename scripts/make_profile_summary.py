@@ -26,7 +26,7 @@ def main():
     table = subprocess.run([sys.executable, os.path.join(root, "scripts", "rocprof_summary.py"), kt, "--top", "40", "--match", "mrs::"],
                            capture_output=True, text=True, check=True).stdout
     with open(os.path.join(root, "profiles", f"{tag}_kernel_stats.md"), "w") as f:
-        f.write(f"# {tag}: `rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline` (MI355X, per-kernel, mrs:: kernels)\n\n")
+        f.write(f"# {tag}: `rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-extra` (MI355X, per-kernel, mrs:: kernels)\n\n")
         f.write(table)
     # per-kernel average durations of the same pass as JSON (bench.py reads the dominant kernel's IN-GRAPH time from it: inside a captured graph the start / end stamps
     # of consecutive kernels touch, so these durations include the launch boundary that the HIP-event figure of bench.py's `roofline` does not)
