@@ -369,14 +369,20 @@ def parity_leg(model, cfg, a, prefill_exact):
 
 def extra_config(kind, dev, steps=64, warmup=4, prompt_len=512):
     """A second BASELINE.json configuration on the same GPU, after the headline run (N = 1, default flags only): the same timed_run() on a freshly built model.
-    kind: "q8_0_isq" = configs[2] (Llama-3-8B, every linear quantized in situ from bf16 to Q8_0 on the GPU), "mixtral" = configs[4]'s model on ONE GPU
+    kind: "70b" = configs[3]'s model (Llama-3-70B Q4_K_M, 2048-token prompt) on ONE GPU (40 GB of weights); "q8_0_isq" = configs[2] (Llama-3-8B, every linear quantized in situ from bf16 to Q8_0 on the GPU), "mixtral" = configs[4]'s model on ONE GPU
     (Mixtral-8x7B-shaped Q4_K_M, 26 GB: fits one MI355X; the TP = 2 form is `bench.py --model mixtral --gpus 2`)."""
     import gc
     import torch
     from mistralrs_amd.llama import LlamaConfig
     t_build = time.perf_counter()
     max_ctx = (prompt_len + warmup + steps + 2 + 63) // 64 * 64
-    if kind == "mixtral":
+    if kind == "70b":
+        prompt_len = 2048
+        max_ctx = (prompt_len + warmup + steps + 2 + 63) // 64 * 64
+        cfg = LlamaConfig.llama3_70b(max_batch=1, max_context_len=max_ctx, max_position_embeddings=max(8192, max_ctx))
+        model = build_model(cfg, dev, seed=0, max_new_tokens=warmup + steps + 8, quant="q4_k_m", weights="gaussian")
+        name, wdesc = "Llama-3-70B GGUF Q4_K_M on ONE GPU (configs[3]'s model; its TP = 8 form is `bench.py --gpus 8`)", "N(0, 0.02^2) through the device ISQ quantizers"
+    elif kind == "mixtral":
         cfg = LlamaConfig.mixtral_8x7b(max_batch=1, max_context_len=max_ctx, max_position_embeddings=max(8192, max_ctx))
         model = build_model(cfg, dev, seed=0, max_new_tokens=warmup + steps + 8, quant="q4_k_m", weights="blocks")
         name, wdesc = "Mixtral-8x7B-shaped (8 experts, top-2) GGUF Q4_K_M, TP=1", "random valid block bytes (46.7 B parameters: the gaussian + quantize pass is skipped to bound the run)"
@@ -396,6 +402,14 @@ def extra_config(kind, dev, steps=64, warmup=4, prompt_len=512):
            "step_roofline_frac": round(step_bytes * (steps / r["t_all"]) / HBM_PEAK, 4), "prefill_tokens_per_sec": round(prompt_len / r["ttft"], 1),
            "ttft_ms": round(1e3 * r["ttft"], 2), "prefill_arithmetic": "decode engine's (exact)" if model.prefill_is_exact else "bf16-operand MFMA",
            "decode_path": model.decode_path, "build_s": round(t_build, 1)}
+    if kind == "70b" and model.prefill_is_exact:  # long prompt: also the selectable bf16-operand path (what a tensor-parallel run uses)
+        model.set_prefill_mode(0)
+        model.prefill(r["prompt"], 0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        int(model.prefill(r["prompt"], 0).argmax())
+        tb = time.perf_counter() - t0
+        out["prefill_bf16"] = {"tokens_per_sec": round(prompt_len / tb, 1), "ttft_ms": round(1e3 * tb, 2), "frac": round(r["prefill_flops"] / tb / MFMA_PEAK, 4)}
     del model
     gc.collect()
     torch.cuda.empty_cache()
@@ -684,7 +698,7 @@ def main():
         import gc
         gc.collect()
         torch.cuda.empty_cache()
-        for kind in ("q8_0_isq", "mixtral"):
+        for kind in ("q8_0_isq", "mixtral", "70b"):
             try:
                 out["extra_configs"][kind] = extra_config(kind, dev)
             except Exception as e:

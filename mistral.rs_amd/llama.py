@@ -253,7 +253,13 @@ class Llama:
         """Error word of the peer-mailbox route (blocking device read; call where the host synchronises anyway -- after a run of decode steps, before
         tokens are handed out): non-zero = some granule never arrived within the bounded spin (ext_p2p.hip, ~10 ms) and the affected sums are NaN.
         The caller drops the route (set_p2p(None) -> RCCL) and repeats the steps since its last check; bench.py does exactly that."""
-        return 0 if getattr(self, "_p2p", None) is None else self._p2p.error()
+        if getattr(self, "_p2p", None) is None:
+            return 0
+        self._L.mrs_llama_check_p2p.argtypes = [C.c_void_p]
+        e = int(self._L.mrs_llama_check_p2p(self._h))  # the C++ runner drops the route itself when the word is set
+        if e:
+            self._p2p = None
+        return e
 
     def set_tensor(self, name: str, t) -> None:
         """t: QTensor (packed GGUF blocks) or an f32 torch tensor (norm weights)."""
