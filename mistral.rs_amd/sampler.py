@@ -98,13 +98,13 @@ def sample(packed: np.ndarray, k: int, temperature: float, top_p: float, min_p: 
     return int(ids[j]), float(rep[j])
 
 
-def generate(model, prompt, max_new_tokens: int, top_k: int, temperature: float = 1.0, top_p: float = 1.0, min_p: float = 0.0, seed: int = 0, seq: int = 0):
+def generate(model, prompt, max_new_tokens: int, top_k: int, temperature: float = 1.0, top_p: float = 1.0, min_p: float = 0.0, seed: int = 0):
     """Sampled decoding on a `Llama` runner (the loop of `Sampler::sample` with top_k set, sampler.rs:1262-1290): prefill, then per token one decode step, the device
     top-k over the logits row, `2k + 2` floats to the host, the top-p / min-p cuts and the draw there.  top_k == 1 takes the best candidate without a draw
     (sample_cuda_top1_row).  Returns (tokens, reporting probabilities)."""
     rng = np.random.default_rng(seed)
     tk = TopK(model.cfg.vocab_size, top_k, model.device)
-    logits = model.prefill(list(prompt), 0, seq=seq).float().reshape(1, -1)
+    logits = model.prefill(list(prompt), 0).float().reshape(1, -1)  # sequence 0: the decode steps below run batch row 0
     toks, probs = [], []
     for i in range(max_new_tokens):
         packed = tk(logits.contiguous(), temperature).cpu().numpy()[0]
