@@ -45,8 +45,8 @@ __host__ __device__ constexpr int tmask_of(int type) { return type == T_Q4_K ? T
 
 template <int N> struct AuxV { float a[N], b[N]; };
 
-template <int NCOLS, int EPI, bool SPEC, int TMASK>
-__device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float *red, int *ctr) {
+template <int NCOLS, int EPI, int TMASK>
+__device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float *red) {
   const int tid0 = tid_opaque();
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6), lane = tid0 & 63;
   const int K = a.K;
@@ -84,19 +84,17 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
   const int mode = act_mode_for(jb.mat[0].type);
   constexpr int NCI = EPI == EPI_RESID2 ? 2 : NCOLS;  // columns of the activation image
 
-  // the activation prologue (dec_core2.cuh): a pre-quantized image is copied, an f32 vector is normalised / quantized on the ALL or the SPEC schedule
-  // (the registers of the two schedules are never live together: the struct is chosen at compile time)
-  using PreT = typename std::conditional<SPEC, SpecRegs, ActRegs<2>>::type;
-  PreT pre;
+  // the activation prologue (dec_core2.cuh): a pre-quantized image is copied, an f32 vector is normalised / quantized
+  ActRegs<MAXP> pre;
   const size_t img_bytes = act_bytes(K, NCI);
+  const bool from_img = a.x_img != nullptr;
+  const void *xsrc = from_img ? a.x_img : (const void *)a.x;
+  const unsigned xbytes = from_img ? (unsigned)img_bytes : (unsigned)K * 4u;
+  const float *nw_eff = from_img ? nullptr : a.norm_w;
   auto stage = [&](int st) {
-    if constexpr (SPEC) {
-      if (st == 0) pre = act_issue_spec(a.x, a.norm_w, K, wave); else act_finish_spec<NCI>(smem, pre, a.x, a.ldx, a.norm_w, a.eps, K, mode, wave);
-    } else {
-      if (a.x_img) { if (st == 0) pre = img_issue_all<2>(a.x_img, img_bytes); else img_finish_all<2>(smem, pre, a.x_img, img_bytes); }
-      else if (st == 0) pre = act_issue_all<2>(a.x, a.norm_w, K);
-      else act_finish_all<NCI, 2>(smem, red, pre, a.x, a.ldx, a.norm_w, a.eps, K, mode);
-    }
+    if (st == 0) pre = act_issue_all<MAXP>(xsrc, xbytes, nw_eff, K);
+    else if (from_img) img_finish_all<MAXP>(smem, pre, a.x_img, img_bytes);
+    else act_finish_all<NCI, MAXP>(smem, red, pre, a.x, a.ldx, a.norm_w, a.eps, K, mode);
   };
   const int lpr = 4 * g.LPC;             // lanes per row of a record group: row rr of the group = lanes [rr * lpr, (rr + 1) * lpr), owner lane = rr * lpr + owner_off(g)
   const int rr = lane / lpr;
@@ -121,7 +119,7 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
         }
       }
     };
-    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, NCOLS, SPEC>(jb, K, NCI, mode, smem, ctr, stage, auxf, epi); })
+    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, NCOLS>(jb, K, NCI, mode, smem, stage, auxf, epi); })
   } else if constexpr (EPI == EPI_RESID2) {
     // MoE down of the two experts of one token in one launch (the image has two columns = the two experts' activation vectors): a unit streams its rows of
     // expert sel[0] against column 0, then the same rows of expert sel[1] against column 1, and writes (out * resid_scale + w0 s0) * 1 + w1 s1 -- the two
@@ -143,7 +141,7 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
         a.out[row0 + rr] = h1 * 1.0f + sum[0] * w1;
       }
     };
-    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, 1, SPEC, true>(jb, K, NCI, mode, smem, ctr, stage, auxf, epi); })
+    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, 1, true>(jb, K, NCI, mode, smem, stage, auxf, epi); })
   } else if constexpr (EPI == EPI_GLU) {
     float gsave[NCOLS];  // the gate sums of the record group until the matching up rows arrive (same unit, same lanes)
 #pragma unroll
@@ -161,7 +159,7 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
           a.out[(size_t)slot * a.slot_out_stride + (size_t)c * a.out_stride + (row - slot * a.nrows[0])] = (a.activation == 0 ? silu_engine(gsave[c]) : glu_act(gsave[c], a.activation)) * sum[c];
       }
     };
-    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, NCOLS, SPEC>(jb, K, NCI, mode, smem, ctr, stage, auxf, epi); })
+    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, NCOLS>(jb, K, NCI, mode, smem, stage, auxf, epi); })
   } else {  // EPI_QKV: rows 2i, 2i + 1 of a tensor are a RoPE pair; a record group holds whole pairs (R >= 2) or a unit holds two record groups (R = 1)
     // positions and KV slots: a handful of scalars, loaded before anything else; the RoPE factors travel with the record (owner lanes of the pair's two rows)
     int posv[NCOLS], slotv[NCOLS];  // slots are block * block_size + offset of a cache that fits 32-bit indexing per layer (checked by the launcher)
@@ -228,21 +226,20 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
         }
       }
     };
-    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, NCOLS, SPEC>(jb, K, NCI, mode, smem, ctr, stage, auxf, epi); })
+    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, NCOLS>(jb, K, NCI, mode, smem, stage, auxf, epi); })
   }
 }
 
-template <int NCOLS, int EPI, bool SPEC, int TMASK = TM_ALL>
+template <int NCOLS, int EPI, int TMASK = TM_ALL>
 __global__ void __launch_bounds__(NT) dec_gemv_kernel(const GemvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ float red[8 * 8];  // RMSNorm partials: [column][wave]
-  __shared__ int ctr;           // the workgroup's unit counter
-  gemv_phase<NCOLS, EPI, SPEC, TMASK>(a, smem, red, &ctr);
+  gemv_phase<NCOLS, EPI, TMASK>(a, smem, red);
 }
 
 
 // launch one GEMV phase with NCOLS activation columns (ext_dec_gemv.hip, one definition per NCOLS)
-template <int NCOLS> int gemv_launch(int epi, bool spec, int tmask, int grid, size_t lds, const GemvArgs &a, hipStream_t s);
+template <int NCOLS> int gemv_launch(int epi, int tmask, int grid, size_t lds, const GemvArgs &a, hipStream_t s);
 
 }  // namespace dec
 }  // namespace mrs

@@ -26,7 +26,8 @@ namespace mrs {
 namespace dec {
 
 // ------------------------------------------------------------------------------------------------ repack GGUF blocks -> decode layout (dec_core2.cuh)
-// one thread per stored slot (record, a): source = superblock sb of row `row` of the row-major GGUF tensor, or zeros for a slot without one
+// one thread per (tile, lane): lane (r, p, c) of tile t of row group rg <- quarter c of superblock p * Cs + t of row 4 rg + r of the row-major GGUF tensor,
+// or zeros where there is none (rows past n, the short tail of the last chunks)
 __device__ __forceinline__ void st16(uint8_t *p, const uint8_t *b) { *(v4u *)p = *(const v4u *)b; }
 __device__ __forceinline__ void k4_scale_min(const uint8_t *sc12, uint8_t *sc, uint8_t *mn) {  // get_scale_min_k4 (marlin_gguf_affine_repack.cu:200-210)
 #pragma unroll
@@ -36,76 +37,67 @@ __device__ __forceinline__ void k4_scale_min(const uint8_t *sc12, uint8_t *sc, u
   }
 }
 template <int TYPE>
-__global__ void __launch_bounds__(256) repack_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, long long n, int K, long long nslots) {
+__global__ void __launch_bounds__(256) repack_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, long long n, int K, long long nlanes) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= nslots) return;
+  if (i >= nlanes) return;
   const Geo g = geo_for(K);
-  const long long rec = i / g.A;
-  const int a = (int)(i % g.A), A = g.A;
-  const long long rgi = rec / g.TPC;
-  const int ts = (int)(rec % g.TPC);
-  const int j = a % g.W, p = (a / g.W) & 3, r = a / (4 * g.W);
-  const long long row = rgi * g.R + r;
-  const int sbi = ts * g.W + j, sb = p * g.Cs + sbi;
-  const bool have = row < n && sbi < g.Cs && sb < g.S;
-  uint8_t *rb = dst + rec * rec_bytes(TYPE, g);
+  const long long tile = i >> 6;
+  const int L = (int)(i & 63), r = L >> 4, p = (L >> 2) & 3, c = L & 3, slot = L >> 2;
+  const long long rg = tile / g.Cs;
+  const int t = (int)(tile - rg * g.Cs);
+  const long long row = rg * g.R + r;
+  const int sb = p * g.Cs + t;
+  const bool have = row < n && sb < g.S;
+  uint8_t *tb = dst + (size_t)tile * tile_bytes(TYPE);
   alignas(16) uint8_t buf[16];
   if constexpr (TYPE == T_Q4_K || TYPE == T_Q5_K) {
-    constexpr int TS = TYPE == T_Q4_K ? 144 : 176, NP = TYPE == T_Q4_K ? 8 : 10;
+    constexpr int TS = TYPE == T_Q4_K ? 144 : 176;
+    constexpr unsigned HS = TYPE == T_Q4_K ? 2048u : 2560u, HD = TYPE == T_Q4_K ? 2304u : 2816u;
     const uint8_t *b = src + ((size_t)row * g.S + sb) * TS;
     const uint8_t *qs = b + (TYPE == T_Q5_K ? 48 : 16);
-    for (int pi = 0; pi < 8; ++pi) {
-      for (int k = 0; k < 16; ++k) buf[k] = have ? (uint8_t)(qs[pi * 16 + k] ^ (TYPE == T_Q4_K ? 0x80 : 0x00)) : 0;
-      st16(rb + ((size_t)pi * A + a) * 16, buf);
+    for (int h = 0; h < 2; ++h) {  // pieces 2c + h of the superblock's qs
+      for (int k = 0; k < 16; ++k) buf[k] = have ? (uint8_t)(qs[32 * c + 16 * h + k] ^ (TYPE == T_Q4_K ? 0x80 : 0x00)) : 0;
+      st16(tb + (size_t)h * 1024 + (size_t)L * 16, buf);
     }
     if constexpr (TYPE == T_Q5_K) {
       const uint8_t *qh = b + 16;
-      for (int half = 0; half < 2; ++half) {
-        for (int pi = 0; pi < 4; ++pi) {  // piece i = 4 half + pi: quarter c = i / 2, hp = i & 1: low nibbles = weights c*64 + hp*16 + e, high = + 32; fifth bits = qh[hp*16 + e] bits 2c, 2c+1
-          const int ii = 4 * half + pi, c = ii >> 1, hp = ii & 1;
-          uint32_t wv = 0;
-          if (have)
-            for (int k = 0; k < 4; ++k)
-              for (int jj = 0; jj < 4; ++jj) {
-                const uint32_t v = qh[hp * 16 + 4 * k + jj];
-                wv |= ((v >> (2 * c)) & 1u) << (8 * jj + k);
-                wv |= ((v >> (2 * c + 1)) & 1u) << (8 * jj + 4 + k);
-              }
-          *(uint32_t *)(buf + 4 * pi) = wv;
-        }
-        st16(rb + ((size_t)(8 + half) * A + a) * 16, buf);
+      for (int h = 0; h < 2; ++h) {  // piece 2c + h: low nibbles = weights 64 c + 16 h + e, high = + 32; fifth bits = qh[16 h + e] bits 2c, 2c + 1
+        uint32_t wv = 0;
+        if (have)
+          for (int k = 0; k < 4; ++k)
+            for (int jj = 0; jj < 4; ++jj) {
+              const uint32_t v = qh[h * 16 + 4 * k + jj];
+              wv |= ((v >> (2 * c)) & 1u) << (8 * jj + k);
+              wv |= ((v >> (2 * c + 1)) & 1u) << (8 * jj + 4 + k);
+            }
+        *(uint32_t *)(tb + 2048 + (size_t)L * 8 + 4 * h) = wv;
       }
     }
     uint8_t sc[8], mn[8];
     if (have) k4_scale_min(b + 4, sc, mn);
-    for (int k = 0; k < 8; ++k) { buf[k] = have ? sc[k] : 0; buf[8 + k] = have ? mn[k] : 0; }
-    st16(rb + ((size_t)NP * A + a) * 16, buf);
-    *(uint32_t *)(rb + (size_t)(NP + 1) * 16 * A + 4 * a) = have ? ((uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24)) : 0u;
+    *(uint32_t *)(tb + HS + (size_t)L * 4) = have ? ((uint32_t)sc[2 * c] | ((uint32_t)sc[2 * c + 1] << 8) | ((uint32_t)mn[2 * c] << 16) | ((uint32_t)mn[2 * c + 1] << 24)) : 0u;
+    if (c == 0) *(uint32_t *)(tb + HD + (size_t)slot * 4) = have ? ((uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24)) : 0u;
   } else if constexpr (TYPE == T_Q6_K) {
     const uint8_t *b = src + ((size_t)row * g.S + sb) * 210;
     const uint8_t *ql = b, *qh = b + 128;
     auto lo4 = [&](int e) { const int hh = e / 128, pos = e % 32, qt = (e % 128) / 32, ii = hh * 64 + pos + (qt % 2) * 32; return qt < 2 ? (ql[ii] & 15) : (ql[ii] >> 4); };
     auto hi2 = [&](int e) { const int hh = e / 128, pos = e % 32, qt = (e % 128) / 32; return (qh[hh * 32 + pos] >> (qt * 2)) & 3; };
-    for (int pi = 0; pi < 8; ++pi) {
-      for (int k = 0; k < 16; ++k) buf[k] = have ? (uint8_t)(lo4((2 * pi) * 16 + k) | (lo4((2 * pi + 1) * 16 + k) << 4)) : 0;
-      st16(rb + ((size_t)pi * A + a) * 16, buf);
+    for (int h = 0; h < 2; ++h) {  // runs 4c + 2h (low nibble), 4c + 2h + 1 (high nibble)
+      for (int k = 0; k < 16; ++k) buf[k] = have ? (uint8_t)(lo4((4 * c + 2 * h) * 16 + k) | (lo4((4 * c + 2 * h + 1) * 16 + k) << 4)) : 0;
+      st16(tb + (size_t)h * 1024 + (size_t)L * 16, buf);
     }
-    for (int gq = 0; gq < 4; ++gq) {
-      for (int k = 0; k < 16; ++k)
-        buf[k] = have ? (uint8_t)(hi2((4 * gq) * 16 + k) | (hi2((4 * gq + 1) * 16 + k) << 2) | (hi2((4 * gq + 2) * 16 + k) << 4) | (hi2((4 * gq + 3) * 16 + k) << 6)) : 0;
-      st16(rb + ((size_t)(8 + gq) * A + a) * 16, buf);
-    }
-    for (int k = 0; k < 16; ++k) buf[k] = have ? b[192 + k] : 0;
-    st16(rb + ((size_t)12 * A + a) * 16, buf);
-    *(uint16_t *)(rb + (size_t)208 * A + 2 * a) = have ? (uint16_t)(b[208] | (b[209] << 8)) : (uint16_t)0;
-  } else {  // Q8_0: superblock = blocks 8 sb .. 8 sb + 7 of the row
-    const uint8_t *b = src + ((size_t)row * (K / 32) + (size_t)sb * 8) * 34;
-    for (int pi = 0; pi < 16; ++pi) {
+    for (int k = 0; k < 16; ++k)
+      buf[k] = have ? (uint8_t)(hi2((4 * c) * 16 + k) | (hi2((4 * c + 1) * 16 + k) << 2) | (hi2((4 * c + 2) * 16 + k) << 4) | (hi2((4 * c + 3) * 16 + k) << 6)) : 0;
+    st16(tb + 2048 + (size_t)L * 16, buf);
+    *(uint32_t *)(tb + 3072 + (size_t)L * 4) = have ? ((uint32_t)b[192 + 4 * c] | ((uint32_t)b[193 + 4 * c] << 8) | ((uint32_t)b[194 + 4 * c] << 16) | ((uint32_t)b[195 + 4 * c] << 24)) : 0u;
+    if (c == 0) *(uint16_t *)(tb + 3328 + (size_t)slot * 2) = have ? (uint16_t)(b[208] | (b[209] << 8)) : (uint16_t)0;
+  } else {  // Q8_0: superblock = blocks 8 sb .. 8 sb + 7 of the row; quarter c = blocks 2c, 2c + 1
+    const uint8_t *b = src + ((size_t)row * (K / 32) + (size_t)sb * 8 + 2 * c) * 34;
+    for (int pi = 0; pi < 4; ++pi) {
       for (int k = 0; k < 16; ++k) buf[k] = have ? b[(pi >> 1) * 34 + 2 + (pi & 1) * 16 + k] : 0;
-      st16(rb + ((size_t)pi * A + a) * 16, buf);
+      st16(tb + (size_t)pi * 1024 + (size_t)L * 16, buf);
     }
-    for (int k = 0; k < 8; ++k) { buf[2 * k] = have ? b[k * 34] : 0; buf[2 * k + 1] = have ? b[k * 34 + 1] : 0; }
-    st16(rb + ((size_t)16 * A + a) * 16, buf);
+    *(uint32_t *)(tb + 4096 + (size_t)L * 4) = have ? ((uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[34] << 16) | ((uint32_t)b[35] << 24)) : 0u;
   }
 }
 
@@ -119,8 +111,8 @@ static bool make_mat(Mat &m, const void *planes, int type, long long n, long lon
 
 
 // ------------------------------------------------------------------------------------------------ decode attention, split + last-arriver merge
-// Round 3.  Grid (kv heads, sequences, ceil(max splits / 4)), 4 waves = 4 splits per workgroup, no barrier in the split phase (as
-// decode_attn_wave_kernel).  TICKET variant: instead of a second launch for the merge (4.9 us + a kernel boundary per layer), every workgroup publishes its
+// Grid (kv heads, sequences, splits), G waves per workgroup = the G query heads of ONE split (round 5; rounds 3-4: 4 splits per workgroup, all G heads per
+// wave), no barrier in the split phase.  TICKET variant: instead of a second launch for the merge (4.9 us + a kernel boundary per layer), every workgroup publishes its
 // partials write-through at agent scope, drains its stores and takes a ticket on the (sequence, kv head) counter; the workgroup that draws the
 // last ticket merges all G heads of the kv head: wave w = query heads 2w, 2w + 1 (256 output values = ONE Q8_K superblock of the attention
 // vector), lane = 4 consecutive dims, sequential over the splits (attn_merge_core's order).  It writes the f32 result and -- what o_proj's
@@ -185,26 +177,29 @@ __device__ __forceinline__ void attn2_merge(const Attn2Args &a, int kvh, int seq
   }
 }
 
-// TICKET: one launch (the last workgroup of a (sequence, kv head) merges); else the split phase only and dec_attn2_merge_kernel follows
+// TICKET: one launch (the last workgroup of a (sequence, kv head) merges); else the split phase only and dec_attn2_merge_kernel follows.
+// Round 5 geometry: grid (kv heads, sequences, splits), G waves per workgroup: wave g = query head head0 + g of ONE split (round 4: 4 splits per workgroup, every wave
+// all G heads: 56 workgroups of 329 VGPRs at a 512-token context).  The per-head arithmetic is the same function (attn_split_core<1>): same bits; the G waves read the
+// same 16 KB of K / V (L1 / L2 hits), every wave's serial chain is 1 / G as long, and a 512-token context fills 8 x 24 = 192 CUs.
 template <int G, class CT, bool TICKET>
-__global__ void __launch_bounds__(256) dec_attn2_kernel(const Attn2Args a) {
+__global__ void __launch_bounds__(64 * G) dec_attn2_kernel(const Attn2Args a) {
   constexpr int HD = 128;
-  __shared__ __attribute__((aligned(16))) float q_s[4][G * HD + G * 32];
+  __shared__ __attribute__((aligned(16))) float q_s[G][HD + 32];
   __shared__ int last_s;
   const AttnArgs &t = a.t;
   const int tid = tid_opaque(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kvh = blockIdx.x, seq = blockIdx.y;
-  const int split = blockIdx.z * 4 + wave, head0 = kvh * G;
+  const int split = blockIdx.z, head0 = kvh * G;
   // the first page index of the split does not depend on the context length: both scalar loads leave together (they used to be a chain)
   const unsigned blk_first = t.block_tables[(size_t)seq * t.max_blocks_per_seq + min(split * t.bpw, t.max_blocks_per_seq - 1)];
   const int nblk = ((int)t.context_lens[seq] + 31) / 32;
-  const int ns = (nblk + t.bpw - 1) / t.bpw, nwg = (ns + 3) / 4;
-  if ((int)blockIdx.z >= nwg) return;  // workgroup-uniform: no split of this sequence lands here
-  if (split < ns) {
+  const int ns = (nblk + t.bpw - 1) / t.bpw;
+  if (split >= ns) return;  // workgroup-uniform: no split of this sequence lands here
+  {
     const int b0 = split * t.bpw, b1 = min(b0 + t.bpw, nblk);
     const int ctx_w = (int)t.context_lens[seq], lo_w = t.window > 0 && ctx_w > t.window ? ctx_w - t.window : 0;
-    auto publish = [&](int g, float o0, float o1, float m, float l) {
-      const size_t pi = ((size_t)seq * t.num_heads + head0 + g) * t.max_splits + split;
+    auto publish = [&](int, float o0, float o1, float m, float l) {
+      const size_t pi = ((size_t)seq * t.num_heads + head0 + wave) * t.max_splits + split;
       if constexpr (TICKET) {
         __hip_atomic_store(t.part_o + pi * HD + lane, o0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(t.part_o + pi * HD + lane + 64, o1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -219,17 +214,16 @@ __global__ void __launch_bounds__(256) dec_attn2_kernel(const Attn2Args a) {
       }
     };
     if (b1 * 32 <= lo_w) {  // every block of the split lies before the sliding window: the partial a fully masked pass would give, without reading K / V
-#pragma unroll
-      for (int g = 0; g < G; ++g) publish(g, 0.f, 0.f, -FLT_MAX, 0.f);
+      publish(0, 0.f, 0.f, -FLT_MAX, 0.f);
     } else {
-      attn_split_core<G, CT>(t, kvh, head0, seq, b0, b1, q_s[wave], q_s[wave] + G * HD, publish, (int)blk_first);
+      attn_split_core<1, CT>(t, kvh, head0 + wave, seq, b0, b1, q_s[wave], q_s[wave] + HD, publish, (int)blk_first);
     }
   }
   if constexpr (TICKET) {
     MRS_WAIT_VMCNT0();  // this wave's partials have left the CU
     __syncthreads();
     unsigned *tk = a.ticket + (size_t)seq * t.num_kv_heads + kvh;
-    if (tid == 0) last_s = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nwg - 1);  // release our partials, acquire the others' (advisor, round 3)
+    if (tid == 0) last_s = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(ns - 1);  // release our partials, acquire the others' (advisor, round 3)
     __syncthreads();
     if (!last_s) return;
     if (tid == 0) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every other workgroup of this (seq, kv head) has already drawn
@@ -282,21 +276,12 @@ template <int EPI> struct Launch {
     if (grid < 1) return -1;
     size_t lds = (act_bytes(a.K, NCI) + 15) & ~(size_t)15;
     if (lds > 158 * 1024) return -2;
-    // SPEC when a workgroup's weight requests keep its memory pipe busy for microseconds and there is a prologue worth hiding
-    bool spec = !a.x_img && total_bytes / (size_t)grid > 96 * 1024;
-    { static const int force = [] { const char *e = getenv("MRS_DEC_SPEC"); return e ? atoi(e) : -1; }(); if (force >= 0 && !a.x_img) spec = force != 0; }
-    // ring depth (Job::ring), measured per phase on the MI355X at Llama-3-8B shapes (profiles/round4_decode.md): gate / up (56 records per workgroup) and the
-    // small launches want ONE record ahead (the compute phase of these launches is issue-bound and starts at the prologue's barrier: requests queued behind it
-    // only delay the first record); down_proj (SPEC schedule, 16 records per workgroup of 8-12 KiB) and long streams (lm_head: hundreds of records per
-    // workgroup) keep the full ring
-    { static const int force = [] { const char *e = getenv("MRS_DEC_RING"); return e ? atoi(e) : 0; }();
-      const size_t per_wg = total_bytes / (size_t)grid;
-      const bool deep = per_wg > 768 * 1024 || (spec && NCOLS == 1 && (EPI == EPI_RESID || EPI == EPI_STORE || EPI == EPI_RESID2));
-      a.ring = force > 0 ? force : (deep ? 8 : 1); }
-    if (NCOLS > 1 || EPI == EPI_QKV) spec = false;  // the SPEC schedule is built for one column; the QKV launch is small
+    // ring depth (Job::ring): 0 = the format's full register ring (dec_core2.cuh Tile<>::NS); MRS_DEC_RING overrides (measurements)
+    { static const int force = [] { const char *e = getenv("MRS_DEC_RING"); return e ? atoi(e) : 0; }(); a.ring = force > 0 ? force : 0; }
+    (void)total_bytes;
     int tmask = 0;
     for (int i = 0; i < (EPI == EPI_QKV ? 3 : 1); ++i) tmask |= tmask_of(a.m[i].type);
-    return gemv_launch<NCOLS>(EPI, spec, tmask, grid, lds, a, s);
+    return gemv_launch<NCOLS>(EPI, tmask, grid, lds, a, s);
   }
   // activation columns [c0, ...) of a batched launch: every per-column pointer moves
   static GemvArgs shift_cols(GemvArgs a, int c0) {
@@ -340,7 +325,7 @@ extern "C" size_t mrs_dec_repack_bytes(int type, long long n, long long k) {
 extern "C" int mrs_dec_repack(const void *gguf_blocks, int type, long long n, long long k, void *planes, void *stream) {
   if (!mrs_dec_repack_bytes(type, n, k) || !gguf_blocks || !planes) return -1;
   const Geo g = geo_for((int)k);
-  const long long nslots = ((n + g.R - 1) / g.R) * g.TPC * g.A;
+  const long long nslots = ((n + g.R - 1) / g.R) * g.TPC * 64;  // one thread per lane of every tile
   const dim3 grid((unsigned)((nslots + 255) / 256));
   hipStream_t s = (hipStream_t)stream;
   switch (type) {
@@ -469,7 +454,7 @@ extern "C" int mrs_dec_attention(float *out_f32, void *img_out, unsigned *ticket
   t.max_splits = mrs_decode_attention_max_splits(max_context_len);  // stride of the partials, as in the two-launch route
   a.ticket = ticket; a.img = with_img ? (uint8_t *)img_out : nullptr;
   const int nsplit = (nblk + t.bpw - 1) / t.bpw;
-  const dim3 grid(num_kv_heads, num_seqs, (nsplit + 3) / 4);
+  const dim3 grid(num_kv_heads, num_seqs, nsplit);
   hipStream_t s = (hipStream_t)stream;
   // MRS_DEC_ATTN_TICKET (default 1): the merge inside the split launch (last arriver); 0 = a second launch for the merge.  Measured on the MI355X
   // (profiles/round3_decode.md): the hand-off (write-through partials, drain, device-scope ticket, sc1 loads) costs about what the second launch and its
@@ -478,9 +463,9 @@ extern "C" int mrs_dec_attention(float *out_f32, void *img_out, unsigned *ticket
   const dim3 mgrid(num_kv_heads, num_seqs);
 #define MRS_A2(GG, CT)                                                                                                   \
   do {                                                                                                                   \
-    if (one_launch) hipLaunchKernelGGL((dec_attn2_kernel<GG, CT, true>), grid, dim3(256), 0, s, a);                      \
+    if (one_launch) hipLaunchKernelGGL((dec_attn2_kernel<GG, CT, true>), grid, dim3(64 * GG), 0, s, a);                      \
     else {                                                                                                               \
-      hipLaunchKernelGGL((dec_attn2_kernel<GG, CT, false>), grid, dim3(256), 0, s, a);                                   \
+      hipLaunchKernelGGL((dec_attn2_kernel<GG, CT, false>), grid, dim3(64 * GG), 0, s, a);                                   \
       hipLaunchKernelGGL((dec_attn2_merge_kernel<GG>), mgrid, dim3(64 * ((GG + 1) / 2)), 0, s, a);                       \
     }                                                                                                                    \
   } while (0)
@@ -491,3 +476,12 @@ extern "C" int mrs_dec_attention(float *out_f32, void *img_out, unsigned *ticket
   return with_img ? 1 : 0;
 }
 
+
+// ---- the plain launcher of the GEMV core (tests/test_dec2_core.py, scripts/bench_dec.py): out [b][ld_out] = W . (RmsNorm(x) or x), nothing else
+extern "C" size_t mrs_dec2_repack_bytes(int type, long long n, long long k) { return mrs_dec_repack_bytes(type, n, k); }
+extern "C" int mrs_dec2_repack(const void *gguf_blocks, int type, long long n, long long k, void *planes, void *stream) { return mrs_dec_repack(gguf_blocks, type, n, k, planes, stream); }
+extern "C" void mrs_dec2_timeline(void *buf) { g_tl_buf = (unsigned long long *)buf; }
+extern "C" int mrs_dec2_gemv(const mrs_dec_mat_c *w, const float *x, int ldx, const float *norm_w, float eps, float *out, int ld_out, int b, void *stream) {
+  if (!w) return -1;
+  return mrs_dec_proj(w, (int)w->n, nullptr, x, ldx, norm_w, eps, out, ld_out, 0, 1.0f, nullptr, b, stream);
+}

@@ -120,14 +120,14 @@ __global__ void __launch_bounds__(NT) qi_quantize_kernel(const QuantArgs a) {
     __syncthreads();  // the same threads read back what they wrote (tid * 4 + j * 2048), the barrier orders the other waves' view of nothing: cheap insurance
     xr = dst;
   }
-  const ActRegs<2> pre = act_issue_all<2>(xr, a.norm_w, K);
-  act_finish_all<1, 2>(smem, red, pre, xr, K, a.norm_w, a.eps, K, ACT_Q8K);
+  const ActRegs<MAXP> pre = act_issue_all<MAXP>(xr, (unsigned)K * 4u, a.norm_w, K);
+  act_finish_all<1, MAXP>(smem, red, pre, xr, K, a.norm_w, a.eps, K, ACT_Q8K);
   __syncthreads();
   const Act act = act_view(smem, K, 1, ACT_Q8K);
   // thread -> (superblock, group of 8 elements): 32 groups per superblock
   for (int gi = tid; gi < S * 32; gi += NT) {
     const int sb = gi >> 5, g8 = gi & 31;
-    const int8_t *q = (const int8_t *)(act.q + (size_t)sb * ACT_QS + g8 * 8);
+    const int8_t *q = (const int8_t *)(act.q + act.qoff(sb) + g8 * 8);
     h8 o;
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) o[jj] = (_Float16)(float)q[perm8(jj)];

@@ -312,6 +312,14 @@ static inline short hiphost_raw_buffer_load_b16(__amdgpu_buffer_rsrc_t r, unsign
   return v;
 }
 #define __builtin_amdgcn_raw_buffer_load_b32(R, VOFF, SOFF, AUX) hiphost_raw_buffer_load_b32((R), (VOFF), (SOFF))
+typedef unsigned hiphost_v2u __attribute__((ext_vector_type(2)));
+static inline hiphost_v2u hiphost_raw_buffer_load_b64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  hiphost_v2u v = {0, 0};
+  const unsigned long long o = (unsigned long long)voff + soff;
+  if (o + 8 <= r.bytes) memcpy(&v, r.base + o, 8);
+  return v;
+}
+#define __builtin_amdgcn_raw_buffer_load_b64(R, VOFF, SOFF, AUX) hiphost_raw_buffer_load_b64((R), (VOFF), (SOFF))
 #define __builtin_amdgcn_raw_buffer_load_b16(R, VOFF, SOFF, AUX) hiphost_raw_buffer_load_b16((R), (VOFF), (SOFF))
 // f32 -> bf16 (RNE) for `__builtin_convertvector(float2, __bf16 x 2)`: x86 lowers it to this runtime call
 extern "C" inline __bf16 __truncsfbf2(float f) {

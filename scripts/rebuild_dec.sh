@@ -10,7 +10,7 @@ F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -ffp-contract=of
 pids=""
 if [ -z "$ONLY" ]; then
 for nc in 1 2 3 4 5 6 7 8; do /opt/rocm/bin/hipcc $F -DMRS_DEC_NC=$nc -c csrc/ext_dec_gemv.hip -o csrc/build/ext_dec_gemv_nc$nc.o & pids="$pids $!"; done
-for f in ext_dec ext_dec2 ext_gemm_qi ext_prefetch; do /opt/rocm/bin/hipcc $F -c csrc/$f.hip -o csrc/build/$f.o & pids="$pids $!"; done
+for f in ext_dec ext_gemm_qi ext_prefetch; do /opt/rocm/bin/hipcc $F -c csrc/$f.hip -o csrc/build/$f.o & pids="$pids $!"; done
 else
 for f in $ONLY; do /opt/rocm/bin/hipcc $F -c csrc/$f.hip -o csrc/build/$f.o & pids="$pids $!"; done
 fi

@@ -255,7 +255,8 @@ def check_attention(O, be, heads, kvh, ctxs, max_ctx, kv_dtype=1, n_out=24, wind
     ticket = be.buf(np.zeros(b * kvh, np.uint32))
     scale = np.float32(1.0 / np.sqrt(np.float32(hd)))
     nimg = be.sym("mrs_dec_act_image_bytes", [C.c_int, C.c_int], C.c_size_t)(nq, b)
-    assert nimg == b * (nq // 256) * (272 + 48 + 80)  # per superblock: 256 int8 at a stride of 272, scales (48 covers the Q8_0 mode), 16 sums at a stride of 80
+    S_ = nq // 256
+    assert nimg == b * (4 * (((S_ + 3) // 4) * 256 + 16) + S_ * (48 + 80))  # per column: 4 chunks of quants (16-byte skew each), scales (48 covers the Q8_0 mode), 16 sums at a stride of 80 per superblock
     img, got = be.buf(np.zeros(nimg, np.uint8)), be.buf(np.full((b, nq), np.nan, np.float32))
     fn = be.sym("mrs_dec_attention", ATTN2, C.c_int)
     even = (heads // kvh) % 2 == 0
