@@ -549,10 +549,7 @@ def main():
     if tp and p2p is not None:
         # the peer-mailbox route reports a granule that never arrived through its error word (bounded spin, NaN sums): if ANY rank saw one, every rank drops
         # the route and the whole timed pass is repeated on RCCL -- a number measured over NaN sums is not a measurement
-        bad = torch.tensor([int(model.p2p_error() != 0)], device=dev)
-        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
-        if int(bad.item()):
-            model.set_p2p(None)
+        if model.p2p_sync_error():  # MAX over the ranks, every rank detaches in the same step (mrs_hip_ext.h: mrs_llama_check_p2p)
             p2p, p2p_note = None, "rccl only (the p2p route raised its error word during the timed pass: dropped, pass repeated on RCCL)"
             r = timed_run(model, cfg, a.prompt_len, a.steps, a.warmup, a.batch, sync, world, dev)
     prompt, ttft, prefill_flops, B, t_all, dev_s, toks = r["prompt"], r["ttft"], r["prefill_flops"], r["B"], r["t_all"], r["dev_s"], r["toks"]

@@ -234,7 +234,7 @@ int mrs_l3_prefetch(const void *p, size_t bytes, int workgroups, void *sink, voi
 int mrs_mfma_f16_int_probe(const void *a, const void *b, float *out, int ksteps, void *stream);
 /* decode-layout copy (mrs_dec_repack output, caller-owned) of a linear tensor already registered with mrs_llama_set_tensor */
 int mrs_llama_set_dec_tensor(void *model, const char *name, const void *planes);
-int mrs_llama_check_p2p(void *model); /* blocking read of the p2p error word; non-zero: the route has been dropped (RCCL from now on), re-capture graphs and repeat the steps since the last check */
+int mrs_llama_check_p2p(void *model); /* blocking read of THIS rank's p2p error word (the route is NOT changed).  MANDATORY host protocol: reduce the word with MAX over the tensor-parallel ranks; when the maximum is non-zero EVERY rank calls mrs_llama_set_p2p(model, NULL) in the same step, re-captures its graphs and repeats the steps since the last check -- a route dropped on one rank only pairs RCCL calls of different steps */
 int mrs_llama_set_mode(void *model, int use_fused); /* switch the decode path (values of mrs_llama_config.use_fused) */
 void *mrs_llama_create(const mrs_llama_config *cfg);
 void mrs_llama_destroy(void *model);

@@ -116,25 +116,27 @@ __device__ __forceinline__ int quad_sum(int v) { v += dppi<0xB1>(v); v += dppi<0
 // a producer kernel leaves in global memory).  ncols columns of K values:
 //   q  [ncols][4][CQ]   int8: chunk p of a column at p * CQ, CQ = Cs * 256 + 16; superblock p * Cs + t at t * 256 inside its chunk, element order
 //                       (a tile's lanes read (chunk p, quarter c) at p * CQ + c * 64 + const: 16 bank groups for the 16 pairs)
-//   d  [ncols][S][DW]   f32: Q8_K mode DW = 1: d of the superblock;  Q8_0 mode DW = 12: f32(f16(d)) of the 8 blocks (4 pad floats)
-//   bs [ncols][S][20]   int32 sums of the 16 runs of 16 (Q8_K mode; 4 pad ints)
+//   d  [ncols][Sp][DW]  f32: Q8_K mode DW = 1: d of the superblock;  Q8_0 mode DW = 12: f32(f16(d)) of the 8 blocks (4 pad floats);  Sp = 4 Cs >= S slots (a tile's
+//                       dead slots -- superblock index >= S -- read inside the image and are discarded)
+//   bs [ncols][Sp][20]  int32 sums of the 16 runs of 16 (Q8_K mode; 4 pad ints)
 constexpr int ACT_BS = 20;
 __host__ __device__ inline int act_dw(int mode) { return mode == ACT_Q80 ? 12 : 1; }
 __host__ __device__ inline int act_cq(int K) { return ((K / 256 + 3) / 4) * 256 + 16; }                                                   // bytes of one chunk of one column
-__host__ __device__ inline size_t act_bytes(int K, int ncols) { return (size_t)ncols * ((size_t)4 * act_cq(K) + (size_t)(K / 256) * (48 + ACT_BS * 4)); }  // both modes fit
+__host__ __device__ inline int act_sp(int K) { return 4 * ((K / 256 + 3) / 4); }  // superblock slots of a row in the d / bs regions: the 4 x Cs slots of a row group's tiles (>= S)
+__host__ __device__ inline size_t act_bytes(int K, int ncols) { return (size_t)ncols * ((size_t)4 * act_cq(K) + (size_t)act_sp(K) * (48 + ACT_BS * 4)); }  // both modes fit
 struct Act {
   const char *q;
   const float *d;
   const int *bs;
-  int K, S, dw, Cs, CQ;
+  int K, S, dw, Cs, CQ, Sp;
   // byte offset of superblock sb's quants inside its column
   __device__ __forceinline__ int qoff(int sb) const { const int p = sb / Cs; return p * CQ + (sb - p * Cs) * 256; }
   __device__ __forceinline__ size_t qcol(int c) const { return (size_t)c * 4 * CQ; }
 };
 __device__ __forceinline__ Act act_view(char *smem, int K, int ncols, int mode) {
-  const int S = K / 256, dw = act_dw(mode), CQ = act_cq(K);
+  const int S = K / 256, dw = act_dw(mode), CQ = act_cq(K), Sp = act_sp(K);
   char *d = smem + (size_t)ncols * 4 * CQ;
-  return Act{smem, (const float *)d, (const int *)(d + (size_t)ncols * S * dw * 4), K, S, dw, (S + 3) / 4, CQ};
+  return Act{smem, (const float *)d, (const int *)(d + (size_t)ncols * Sp * dw * 4), K, S, dw, (S + 3) / 4, CQ, Sp};
 }
 
 // quantize N superblocks at once: lane l holds elements 4 l .. 4 l + 3 of each (v[n], superblock sb[n], live[n] wave-uniform) -> column c of the image.
@@ -143,10 +145,10 @@ __device__ __forceinline__ Act act_view(char *smem, int K, int ncols, int mode) 
 // element of largest magnitude wins) and quantize_row_q8_0 (d = amax / 127, q = round(x / d), d kept as f16) -- oracle/ggml_oracle.c.
 template <int N>
 __device__ __forceinline__ void quantize_multi(const float4 (&v)[N], const int (&sb)[N], const bool (&live)[N], int c, int mode, char *img, int K, int ncols) {
-  const int lane = lane_opaque(), S = K / 256, dw = act_dw(mode), Cs = (S + 3) / 4, CQ = act_cq(K);
+  const int lane = lane_opaque(), S = K / 256, dw = act_dw(mode), Cs = (S + 3) / 4, CQ = act_cq(K), Sp = act_sp(K);
   char *q0p = img + (size_t)c * 4 * CQ;
-  float *d0p = (float *)(img + (size_t)ncols * 4 * CQ) + (size_t)c * S * dw;
-  int *b0p = (int *)(img + (size_t)ncols * 4 * CQ + (size_t)ncols * S * dw * 4) + (size_t)c * S * ACT_BS;
+  float *d0p = (float *)(img + (size_t)ncols * 4 * CQ) + (size_t)c * Sp * dw;
+  int *b0p = (int *)(img + (size_t)ncols * 4 * CQ + (size_t)ncols * Sp * dw * 4) + (size_t)c * Sp * ACT_BS;
   int qo[N];
 #pragma unroll
   for (int n = 0; n < N; ++n) { const int sbn = live[n] ? sb[n] : 0, p = sbn / Cs; qo[n] = p * CQ + (sbn - p * Cs) * 256; }
@@ -290,7 +292,103 @@ __device__ __forceinline__ void act_finish_all(char *img, float *red, const ActR
     }
   }
 }
+// ---- the same prologue on PW = 4 waves ("prologue waves"), without a workgroup barrier: while they run it, the other waves of the workgroup request weights
+// (stream(): a wave is blocked on the issue of its ring for microseconds -- the memory system accepts requests at HBM rate -- so a wave cannot do both).
+constexpr int PW = 4;
+// SPEC: waves 0 .. PW-1 only.  Registers: the whole row for the sum of squares (16 pieces per lane and batch) + the wave's own superblocks (<= 16).
+constexpr int SPEC_OWN = 16;
+struct SpecRegs { v4u xa[16]; v4u xo[SPEC_OWN]; v4u wo[SPEC_OWN]; };
+__device__ __forceinline__ SpecRegs act_issue_spec(const float *x, const float *nw, int K, int wave) {
+  SpecRegs p;
+  const int lane = lane_opaque(), S = K / 256;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)x, (short)0, K * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)(nw ? nw : x), (short)0, nw ? K * 4 : 0, 0x00020000);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {  // virtual thread v * 64 + lane, piece jj: element (v * 64 + lane) * 4 + 2048 jj;  i = 8 jj + v  (first 4096 values)
+    p.xa[i] = v4u{0u, 0u, 0u, 0u};
+    if (nw && (i >> 3) * 2048 < K) p.xa[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (unsigned)(((i & 7) * 64 + lane) * 16 + (i >> 3) * 8192), 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < SPEC_OWN; ++i) {
+    p.xo[i] = v4u{0u, 0u, 0u, 0u}; p.wo[i] = v4u{0u, 0u, 0u, 0u};
+    const int sb = wave + i * PW;
+    if (sb < S) {  // wave-uniform
+      p.xo[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (unsigned)(sb * 1024 + lane * 16), 0, 0);
+      if (nw) p.wo[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, (unsigned)(sb * 1024 + lane * 16), 0, 0);
+    }
+  }
+  return p;
+}
+template <int NCOLS>
+__device__ __forceinline__ void act_finish_spec(char *img, const SpecRegs &pre, const float *__restrict__ x, int ldx, const float *__restrict__ nw, float eps, int K, int mode, int wave) {
+  const int lane = lane_opaque(), S = K / 256;
+#pragma unroll
+  for (int c = 0; c < NCOLS; ++c) {
+    const float *xr = x + (size_t)c * ldx;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)xr, (short)0, K * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)(nw ? nw : xr), (short)0, nw ? K * 4 : 0, 0x00020000);
+    float nm = 1.0f, inv = 1.0f;
+    if (nw) {
+      float ss[8];
+#pragma unroll
+      for (int v = 0; v < 8; ++v) ss[v] = 0.f;
+      for (int j0 = 0; j0 * 2048 < K; j0 += 2) {  // two pieces (16 loads) per batch
+        v4u f[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          if (c == 0 && j0 == 0) f[i] = pre.xa[i];
+          else { f[i] = v4u{0u, 0u, 0u, 0u}; if ((j0 + (i >> 3)) * 2048 < K) f[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (unsigned)(((i & 7) * 64 + lane) * 16 + (j0 + (i >> 3)) * 8192), 0, 0); }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const float4 g = as_f4(f[i]); float &s1 = ss[i & 7]; s1 = fmaf(g.x, g.x, s1); s1 = fmaf(g.y, g.y, s1); s1 = fmaf(g.z, g.z, s1); s1 = fmaf(g.w, g.w, s1); }
+      }
+      float ws[8];
+#pragma unroll
+      for (int v = 0; v < 8; ++v) ws[v] = wave_sum_all(ss[v]);
+      const float tot = ((ws[0] + ws[1]) + (ws[2] + ws[3])) + ((ws[4] + ws[5]) + (ws[6] + ws[7]));
+      nm = sqrtf(tot / (float)K + eps);
+      inv = 1.0f / nm;
+    }
+    // own superblocks wave + i PW, four per quantizer call
+#pragma unroll
+    for (int i0 = 0; i0 < SPEC_OWN; i0 += 4) {
+      if (wave + i0 * PW < S) {  // wave-uniform
+        float4 v[4]; int sb[4]; bool live[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int i = i0 + k;
+          sb[k] = wave + i * PW; live[k] = sb[k] < S;
+          v4u xr4 = pre.xo[i], wr4 = pre.wo[i];
+          if (c != 0) {
+            xr4 = v4u{0u, 0u, 0u, 0u};
+            if (live[k]) xr4 = __builtin_amdgcn_raw_buffer_load_b128(rx, (unsigned)(sb[k] * 1024 + lane * 16), 0, 0);
+          }
+          v[k] = nw ? norm4(as_f4(xr4), as_f4(wr4), nm, inv) : as_f4(xr4);
+        }
+        quantize_multi<4>(v, sb, live, c, mode, img, K, NCOLS);
+      }
+    }
+    for (int sbx = wave + SPEC_OWN * PW; sbx < S; sbx += PW) {  // rows beyond 16384 values
+      const float4 xv = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rx, (unsigned)(sbx * 1024 + lane * 16), 0, 0));
+      const float4 w4 = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rw, (unsigned)(sbx * 1024 + lane * 16), 0, 0));
+      quantize_sb(nw ? norm4(xv, w4, nm, inv) : xv, sbx, c, mode, img, K, NCOLS);
+    }
+  }
+}
+
 // a pre-quantized image (act_bytes(K, ncols) bytes, 16-byte aligned, written by a producer kernel; requested by act_issue_all) -> LDS: the 16-byte pieces at tid * 16 + j * 8192
+// the same copy by the PW prologue waves only (256 threads): eight 16-byte pieces in flight per thread
+__device__ __forceinline__ void img_copy_spec(char *smem, const void *img, size_t bytes) {
+  const int tid = tid_opaque();  // < PW * 64
+  const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc((void *)img, (short)0, (int)bytes, 0x00020000);
+  for (size_t o0 = 0; o0 < bytes; o0 += (size_t)8 * PW * 1024) {
+    v4u r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = __builtin_amdgcn_raw_buffer_load_b128(ri, (unsigned)(o0 + (size_t)j * PW * 1024 + (size_t)tid * 16), 0, 0);  // past the end: zeros
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const size_t o = o0 + (size_t)j * PW * 1024 + (size_t)tid * 16; if (o < bytes) *(v4u *)(smem + o) = r[j]; }
+  }
+}
 template <int NP> __device__ __forceinline__ void img_finish_all(char *smem, const ActRegs<NP> &pre, const void *img, size_t bytes) {
   const int tid = tid_opaque();
 #pragma unroll
@@ -323,8 +421,8 @@ __device__ __forceinline__ int sbyte_of(unsigned w, int i) { return (int)(int8_t
 
 // operands of one (superblock, column) in LDS, for the lane's quarter c: the 64 int8 of the quarter, its four per-16 sums, the scale(s)
 struct ActQ { int4 a0, a1, a2, a3; };
-__device__ __forceinline__ ActQ act_quarter(const Act &act, int col, int qo, int c) {
-  const char *qc = act.q + act.qcol(col) + qo + c * 64;
+__device__ __forceinline__ ActQ act_quarter(const Act &act, int col, int qo, int) {  // qo: byte offset of the lane's quarter inside the column
+  const char *qc = act.q + act.qcol(col) + qo;
   return ActQ{*(const int4 *)(qc), *(const int4 *)(qc + 16), *(const int4 *)(qc + 32), *(const int4 *)(qc + 48)};
 }
 
@@ -351,12 +449,12 @@ template <> struct Tile<T_Q4_K> {
 #pragma unroll
     for (int k = 0; k < NCOLS; ++k) {
       const ActQ a = act_quarter(act, col0 + k, qo, c);
-      const int4 b = *(const int4 *)(act.bs + ((size_t)(col0 + k) * act.S + sb) * ACT_BS + 4 * c);  // runs 4c .. 4c+3
+      const int4 b = *(const int4 *)(act.bs + ((size_t)(col0 + k) * act.Sp + sb) * ACT_BS + 4 * c);  // runs 4c .. 4c+3
       const int bsa = b.x + b.y, bsb = b.z + b.w;                                                      // sub-blocks 2c, 2c+1
       const int dlo = dot16(lo1, a.a1, dot16(lo0, a.a0, 0)), dhi = dot16(hi1, a.a3, dot16(hi0, a.a2, 0));
       const int isum16 = quad_sum(__mul24(sca16, dlo) + __mul24(scb, dhi + (bsb << 7)));  // 16 sum q a = sum 16 (q - 8) a + 128 sum a
       const int msum = quad_sum(__mul24(ma, bsa) + __mul24(mb, bsb));
-      const float yd = act.d[((size_t)(col0 + k) * act.S + sb) * act.dw];
+      const float yd = act.d[((size_t)(col0 + k) * act.Sp + sb) * act.dw];
       T[k] = fmaf(d * yd, (float)isum16 * 0.0625f, -((dmin * yd) * (float)msum));
     }
   }
@@ -390,12 +488,12 @@ template <> struct Tile<T_Q5_K> {
 #pragma unroll
     for (int k = 0; k < NCOLS; ++k) {
       const ActQ a = act_quarter(act, col0 + k, qo, c);
-      const int4 b = *(const int4 *)(act.bs + ((size_t)(col0 + k) * act.S + sb) * ACT_BS + 4 * c);
+      const int4 b = *(const int4 *)(act.bs + ((size_t)(col0 + k) * act.Sp + sb) * ACT_BS + 4 * c);
       const int bsa = b.x + b.y, bsb = b.z + b.w;
       const int dlo = dot16(lo1, a.a1, dot16(lo0, a.a0, 0)), dhi = dot16(hi1, a.a3, dot16(hi0, a.a2, 0));
       const int isum = quad_sum(__mul24(sca, dlo) + __mul24(scb, dhi));
       const int msum = quad_sum(__mul24(ma, bsa) + __mul24(mb, bsb));
-      const float yd = act.d[((size_t)(col0 + k) * act.S + sb) * act.dw];
+      const float yd = act.d[((size_t)(col0 + k) * act.Sp + sb) * act.dw];
       T[k] = fmaf(d * yd, (float)isum, -((dmin * yd) * (float)msum));
     }
   }
@@ -427,12 +525,12 @@ template <> struct Tile<T_Q6_K> {
 #pragma unroll
     for (int k = 0; k < NCOLS; ++k) {
       const ActQ a = act_quarter(act, col0 + k, qo, c);
-      const int4 b = *(const int4 *)(act.bs + ((size_t)(col0 + k) * act.S + sb) * ACT_BS + 4 * c);
+      const int4 b = *(const int4 *)(act.bs + ((size_t)(col0 + k) * act.Sp + sb) * ACT_BS + 4 * c);
       // sum sc <q - 32, u> = sum sc (<q, u> - 32 sum u), all integer
       int iq = __mul24(s0, dot16(q0, a.a0, 0) - 32 * b.x) + __mul24(s1, dot16(q1, a.a1, 0) - 32 * b.y);
       iq += __mul24(s2, dot16(q2, a.a2, 0) - 32 * b.z) + __mul24(s3, dot16(q3, a.a3, 0) - 32 * b.w);
       const int isum = quad_sum(iq);
-      const float yd = act.d[((size_t)(col0 + k) * act.S + sb) * act.dw];
+      const float yd = act.d[((size_t)(col0 + k) * act.Sp + sb) * act.dw];
       T[k] = (d * yd) * (float)isum;
     }
   }
@@ -457,7 +555,7 @@ template <> struct Tile<T_Q8_0> {
 #pragma unroll
     for (int k = 0; k < NCOLS; ++k) {
       const ActQ a = act_quarter(act, col0 + k, qo, c);
-      const float2 dx = *(const float2 *)(act.d + ((size_t)(col0 + k) * act.S + sb) * act.dw + 2 * c);
+      const float2 dx = *(const float2 *)(act.d + ((size_t)(col0 + k) * act.Sp + sb) * act.dw + 2 * c);
       const int isa = dot16(w.q1, a.a1, dot16(w.q0, a.a0, 0)), isb = dot16(w.q3, a.a3, dot16(w.q2, a.a2, 0));
       const float pa = (float)isa * dwa * dx.x, pb = (float)isb * dwb * dx.y;
       float r = pa + pb;  // quarter 0: t = p0; t = t + p1
@@ -493,11 +591,18 @@ template <int TYPE, int NCOLS, int C0> struct TermCols {
 
 // ------------------------------------------------------------------------------------------------ the streaming core
 // A workgroup owns the UNITS [u0, u1) of a launch; unit u = rgpu consecutive record groups (a record group = 4 consecutive rows = Cs tiles) of each of the launch's
-// nseg tensors (gate and up rows of the same index travel together).  Wave w takes units u0 + w, u0 + w + NW, ...; it keeps up to NS tiles requested ahead of the one it
-// is computing (the whole ring is requested before the activation prologue).  epi(seg, row0, nvalid, rgl, sums, aux) is called once per finished record group; inside a
-// unit: segment 0 before segment 1, record groups ascending; the call is lane-parallel: every lane of row rr = lane / 16 of the group's chunk-3 quad (lanes 16 rr + 12 ..
-// + 15) holds that row's sum, lane 16 rr + 12 is the row's owner, nvalid rows exist.  aux(unit, seg, rgl) runs when the group's LAST tile is REQUESTED (operands of the
-// epilogue -- residual values, RoPE factors -- travel with the weights instead of costing a dependent load after the row sum); its result comes back to epi.
+// nseg tensors (gate and up rows of the same index travel together).  Waves take units from a counter in LDS (the streaming waves their first one statically); a
+// wave keeps NS tiles requested ahead of the one it is computing.  epi(seg, row0, nvalid, rgl, sums, aux) is called once per finished record group; inside a
+// unit: segment 0 before segment 1, record groups ascending; the call is lane-parallel: every lane of the chunk-3 quad of row rr = lane / 16 of the group (lanes
+// 16 rr + 12 .. + 15) holds that row's sum, lane 16 rr + 12 is the row's owner, nvalid rows exist.  aux(row0) runs with every REQUEST of the group's tiles (operands
+// of the epilogue -- residual values, RoPE factors -- travel with the weights instead of costing a dependent load after the row sum); the copy that came with the last
+// tile comes back to epi.
+//
+// Schedule (measured on the MI355X, profiles/round5_decode.md): the memory system accepts a CU's requests at HBM rate, so a wave that requests a deep ring is BLOCKED
+// in its issue for microseconds and cannot run the activation prologue meanwhile; and nothing can be multiplied before the prologue is done.  Hence two roles:
+//   waves PW .. 7 ("streaming"): first unit static, request the ring at once; wait at the barrier; compute.
+//   waves 0 .. PW-1 ("prologue"): request the activation row, run the prologue (RMSNorm + quantization, no workgroup barrier inside), barrier; then take units
+//   from the counter like everybody else (they start late and simply end up with fewer).
 struct Job {
   Mat mat[2];
   int nseg, rgpu;
@@ -513,15 +618,17 @@ struct Job {
 #define MRS_TL2(jb, i) do { if ((jb).tl && (tid_opaque() & 63) == 0) (jb).tl[((size_t)blockIdx.x * NW + (tid_opaque() >> 6)) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 // the lane of a record group's row rr that owns the row sum in the epilogue (and loads the row's epilogue operands): 16 rr + owner_off
 __host__ __device__ inline int owner_off(const Geo &) { return 12; }
-struct RecMeta { int unit, seg, rgl, ts; };  // unit < 0: nothing was requested into the slot
+// what a ring slot remembers of its tile (scalars): ts | seg << 24, or -1 for "nothing live was requested"; the first row of its record group in the launch's row
+// numbering (slot * rows-per-slot + local row); the number of rows of the group that exist
+struct RecMeta { int ts_seg, row0, nvalid; };
 struct NoAux {};
 
 // SEGCOL (NCOLS must be 1): segment s multiplies by activation column s of a 2-column image (MoE down: two experts' rows against their own activations)
 template <int TYPE, int NCOLS, bool SEGCOL = false, class Stage, class AuxF, class Epi>
-__device__ __forceinline__ void stream(const Job &jb, int K, int ncols_img, int mode, char *smem, Stage stage, AuxF auxf, Epi epi) {
+__device__ __forceinline__ void stream(const Job &jb, int K, int ncols_img, int mode, char *smem, int *ctr, Stage stage, AuxF auxf, Epi epi) {
   using TL = Tile<TYPE>;
-  using AuxT = decltype(auxf(0, 0, 0));
-  constexpr int NS = TL::NS;
+  using AuxT = decltype(auxf(0));
+  constexpr int NS = NCOLS <= 2 ? TL::NS : (TL::NS > 4 ? 4 : TL::NS);  // wide batches: the arithmetic per tile is NCOLS times longer, a shorter ring covers the same time
   const int tid = tid_opaque(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const Geo g = geo_for(K);
   const int Cs = g.Cs;
@@ -533,12 +640,10 @@ __device__ __forceinline__ void stream(const Job &jb, int K, int ncols_img, int 
   typename TL::Raw ring[NS];
   RecMeta meta[NS];
   AuxT auxv[NS];
-  // the wave's request cursor: (unit, segment, record group, tile) -- all wave-uniform
-  int lunit = jb.u0 + wave, lseg = 0, lrgl = 0, lts = 0;
   // expert ids of the launch's slots (MoE), read ONCE, before the first store of the kernel, as scalars: a load of sel[] inside the request loop is a VMEM load
   // (the compiler cannot prove that the epilogue's stores leave it alone), and waiting for it is `s_waitcnt vmcnt(0)` -- it would drain the whole ring at every request
-  // (it did, in rounds 3-4: one tile in flight per wave whatever the ring depth)
-  // (eight 8-bit ids packed into one 64-bit scalar: an array would be indexed in scratch memory, i.e. through vmcnt again; the launchers refuse > 256 experts)
+  // (it did, in rounds 3-4: one tile in flight per wave whatever the ring depth).  Eight 8-bit ids in one 64-bit scalar: an array would be indexed in scratch memory,
+  // i.e. through vmcnt again; the launchers refuse > 256 experts.
   unsigned long long selp = 0ull;
   const bool moe = jb.sel != nullptr;
   if (moe) {
@@ -547,46 +652,81 @@ __device__ __forceinline__ void stream(const Job &jb, int K, int ncols_img, int 
     for (int i = 0; i < 8; ++i) if (i < nsl) selp |= (unsigned long long)(unsigned)(__builtin_amdgcn_readfirstlane(jb.sel[i]) & 0xff) << (8 * i);
   }
   auto sel_at = [&](int i) { return (int)((selp >> (8 * (i & 7))) & 0xffull); };
+  // the wave's request cursor (all wave-uniform): the unit, the segment, tiles left in the segment, the byte offset of the next tile (tiles of a segment of a unit
+  // are consecutive in memory), the group's first row and the tile index inside the group
+  const bool late = wave < PW;
+  const int tps = jb.rgpu * Cs;  // tiles per segment of a unit
+  int lunit = -1, lseg = 0, lleft = 0, lts = 0, lrow0 = 0, lslot_row0 = 0;
+  unsigned ltoff = 0, lubase[2] = {0u, 0u};
+  auto open_unit = [&](int u) {  // wave-uniform; u may be past the end (the cursor then stays dead)
+    lunit = u; lseg = 0; lts = 0; lleft = tps;
+    if (u < jb.u1) {
+      int local = u * jb.rgpu, e0 = 0, e1 = 0, sl = 0;
+      if (moe) {
+        if (jb.sel_mode == 2) { e0 = sel_at(0); e1 = sel_at(1); }
+        else { sl = u / jb.upe; e0 = e1 = sel_at(sl); local -= sl * jb.upe * jb.rgpu; }
+      }
+      lubase[0] = (unsigned)(e0 * jb.ergs + local) * (unsigned)Cs * tileb;
+      lubase[1] = (unsigned)(e1 * jb.ergs + local) * (unsigned)Cs * tileb;
+      lrow0 = u * jb.rgpu * g.R;
+      lslot_row0 = sl * (jb.upe * jb.rgpu * g.R);
+      ltoff = lubase[0];
+    }
+  };
   // Every request below is UNCONDITIONAL (a wave past its last tile asks for an out-of-range offset: zeros, no traffic) and every tile asks for the same number of
   // loads: hipcc's s_waitcnt insertion merges the counter state of control-flow paths conservatively, so ONE conditional load between a tile's request and its use
   // makes the wait for that tile stricter by one, and a conditional request of a whole tile (rounds 3-4) collapses every wait to vmcnt(0) -- the ring then holds one
   // tile in flight whatever its depth.  With straight-line requests the waits come out exact: vmcnt((NS - 1) x loads per tile).
   constexpr unsigned DEAD = 0xF0000000u;  // beyond every tensor (make_mat refuses tensors of 0xF0000000 bytes and more); + the tile's plane offsets: no wrap
   auto issue = [&](typename TL::Raw &slot, RecMeta &m, AuxT &ax) {
-    const bool livel = lunit < jb.u1;
-    m = RecMeta{livel ? lunit : -1, lseg, lrgl, lts};
-    const int un = livel ? lunit : jb.u0;  // a unit that exists: the (unused) epilogue operands of a dead request come from valid addresses
-    int local = un * jb.rgpu + lrgl, expert = 0;
-    if (moe) {
-      if (jb.sel_mode == 2) expert = sel_at(lseg);
-      else { const int sl = un / jb.upe; expert = sel_at(sl); local -= sl * jb.upe * jb.rgpu; }
-    }
-    const unsigned tile = ((unsigned)(expert * jb.ergs + local) * (unsigned)Cs + (unsigned)lts) * tileb;
-    slot = TL::load(lseg == 0 ? rs0 : rs1, livel ? tile : DEAD, lane);
-    ax = auxf(un, lseg, lrgl);  // operands of the group's epilogue travel with every tile of the group (the last tile's copy is the one used)
-    if (livel && ++lts == Cs) {
-      lts = 0;
-      if (++lrgl == jb.rgpu) {
-        lrgl = 0;
-        if (++lseg == jb.nseg) { lseg = 0; lunit += NW; }
+    const bool livel = lunit >= 0 && lunit < jb.u1;
+    const int lrow = lrow0 - lslot_row0;  // local row inside the expert slot
+    m = RecMeta{livel ? (lts | (lseg << 24)) : -1, lrow0, min(g.R, jb.nrows - lrow)};
+    slot = TL::load(lseg == 0 ? rs0 : rs1, livel ? ltoff : DEAD, lane);
+    ax = auxf(livel ? lrow0 : 0);
+    if (livel) {  // scalar bookkeeping only: no memory instruction under this branch
+      ltoff += tileb;
+      if (++lts == Cs) { lts = 0; lrow0 += g.R; }
+      if (--lleft == 0) {
+        if (lseg + 1 < jb.nseg) { lseg = 1; lleft = tps; ltoff = lubase[1]; lrow0 -= jb.rgpu * g.R; }
+        else {  // next unit from the workgroup's counter (LDS atomic: lgkmcnt, not vmcnt)
+          int nu = 0;
+          if (lane == 0) nu = atomicAdd(ctr, 1);
+          open_unit(__builtin_amdgcn_readfirstlane(nu));
+        }
       }
     }
   };
 #pragma unroll
-  for (int i = 0; i < NS; ++i) meta[i] = RecMeta{-1, 0, 0, 0};
-  // A CU has one in-order memory pipe: what the prologue needs from memory is requested (stage 0), by every wave, BEFORE any wave of the workgroup requests
-  // weights -- the first barrier sits in between; then the whole ring, then the prologue's arithmetic while the ring streams in.
-  stage(0);
-  MRS_TL2(jb, 0);
-  __syncthreads();
+  for (int i = 0; i < NS; ++i) meta[i] = RecMeta{-1, 0, 0};
+  if (late) {
+    stage(0);  // the activation row -> registers
+    MRS_TL2(jb, 0);
+    if (tid == 0) *ctr = jb.u0 + (NW - PW);
+    __syncthreads();
+    stage(1);  // prologue arithmetic while the other waves request weights
+    MRS_TL2(jb, 2);
+    __syncthreads();
+    MRS_TL2(jb, 3);
+    int nu = 0;
+    if (lane == 0) nu = atomicAdd(ctr, 1);
+    open_unit(__builtin_amdgcn_readfirstlane(nu));
 #pragma unroll
-  for (int i = 0; i < NS; ++i) issue(ring[i], meta[i], auxv[i]);
-  MRS_TL2(jb, 1);
-  stage(1);  // squares, (barrier), quantize
-  MRS_TL2(jb, 2);
-  __syncthreads();
-  MRS_TL2(jb, 3);
+    for (int i = 0; i < NS; ++i) issue(ring[i], meta[i], auxv[i]);
+  } else {
+    MRS_TL2(jb, 0);
+    __syncthreads();
+    open_unit(jb.u0 + wave - PW);
+#pragma unroll
+    for (int i = 0; i < NS; ++i) issue(ring[i], meta[i], auxv[i]);
+    MRS_TL2(jb, 1);
+    __syncthreads();
+    MRS_TL2(jb, 3);
+  }
   const Act act = act_view(smem, K, ncols_img, mode);
+  // per-lane constants of the LDS operands: chunk p, quarter c
+  const int pCs = p * Cs;
+  const int qo_lane = p * act.CQ + c * 64;
   float acc[NCOLS];
 #pragma unroll
   for (int k = 0; k < NCOLS; ++k) acc[k] = 0.0f;
@@ -596,11 +736,12 @@ __device__ __forceinline__ void stream(const Job &jb, int K, int ncols_img, int 
   do {
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
-      if (meta[i].unit >= 0) {  // wave-uniform
-        const int ts = meta[i].ts, sb = p * Cs + ts;
+      if (meta[i].ts_seg >= 0) {  // wave-uniform
+        const int ts = meta[i].ts_seg & 0xffffff, seg = meta[i].ts_seg >> 24;
+        const int sb = pCs + ts;
         const bool live = sb < g.S;  // a chunk of the last quarter may be short (or empty): its slots are zeros in memory and take no part in the sum
         float T[NCOLS];
-        TermCols<TYPE, NCOLS, 0>::run(ring[i], live ? sb : 0, live ? p * act.CQ + ts * 256 : 0, c, act, SEGCOL ? meta[i].seg : 0, T);
+        TermCols<TYPE, NCOLS, 0>::run(ring[i], sb, qo_lane + ts * 256, c, act, SEGCOL ? seg : 0, T);
 #pragma unroll
         for (int k = 0; k < NCOLS; ++k) acc[k] = ts == 0 ? (live ? T[k] : 0.0f) : (live ? acc[k] + T[k] : acc[k]);  // c_p: left to right inside the chunk
         if (ts == Cs - 1) {
@@ -612,14 +753,12 @@ __device__ __forceinline__ void stream(const Job &jb, int K, int ncols_img, int 
             u = dppf<0x124>(u) + acc[k];
             tot[k] = dppf<0x124>(u) + acc[k];
           }
-          const int urow = (meta[i].unit * jb.rgpu + meta[i].rgl) * g.R;               // first row of the group in the launch's numbering (slot * rows-per-slot + local row)
-          const int lrow = urow - (meta[i].unit / jb.upe) * (jb.upe * jb.rgpu * g.R);  // local row inside the expert slot
-          epi(meta[i].seg, urow, min(g.R, jb.nrows - lrow), meta[i].rgl, tot, auxv[i]);
+          epi(seg, meta[i].row0, meta[i].nvalid, (meta[i].row0 / g.R) % jb.rgpu, tot, auxv[i]);
         }
       }
       issue(ring[i], meta[i], auxv[i]);
     }
-  } while (meta[0].unit >= 0);  // requests go out in order: slot 0 holds the oldest one
+  } while (meta[0].ts_seg >= 0);  // requests go out in order: slot 0 holds the oldest one
   MRS_TL2(jb, 14);
 }
 

@@ -46,7 +46,7 @@ __host__ __device__ constexpr int tmask_of(int type) { return type == T_Q4_K ? T
 template <int N> struct AuxV { float a[N], b[N]; };
 
 template <int NCOLS, int EPI, int TMASK>
-__device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float *red) {
+__device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, int *ctr) {
   const int tid0 = tid_opaque();
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6), lane = tid0 & 63;
   const int K = a.K;
@@ -84,32 +84,37 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
   const int mode = act_mode_for(jb.mat[0].type);
   constexpr int NCI = EPI == EPI_RESID2 ? 2 : NCOLS;  // columns of the activation image
 
-  // the activation prologue (dec_core2.cuh): a pre-quantized image is copied, an f32 vector is normalised / quantized
-  ActRegs<MAXP> pre;
+  // the activation prologue (dec_core2.cuh), run by the PW prologue waves of stream(): a pre-quantized image is copied, an f32 vector is normalised / quantized
+  SpecRegs pre;  // ONE producer (act_issue_spec): a register struct assigned from two different calls under a run-time branch is demoted to scratch memory by hipcc
   const size_t img_bytes = act_bytes(K, NCI);
   const bool from_img = a.x_img != nullptr;
-  const void *xsrc = from_img ? a.x_img : (const void *)a.x;
-  const unsigned xbytes = from_img ? (unsigned)img_bytes : (unsigned)K * 4u;
-  const float *nw_eff = from_img ? nullptr : a.norm_w;
   auto stage = [&](int st) {
-    if (st == 0) pre = act_issue_all<MAXP>(xsrc, xbytes, nw_eff, K);
-    else if (from_img) img_finish_all<MAXP>(smem, pre, a.x_img, img_bytes);
-    else act_finish_all<NCI, MAXP>(smem, red, pre, a.x, a.ldx, a.norm_w, a.eps, K, mode);
+    if (from_img) { if (st == 1) img_copy_spec(smem, a.x_img, img_bytes); }
+    else if (st == 0) pre = act_issue_spec(a.x, a.norm_w, K, wave);
+    else act_finish_spec<NCI>(smem, pre, a.x, a.ldx, a.norm_w, a.eps, K, mode, wave);
   };
+  constexpr bool AUX_RING = NCOLS <= 2;  // epilogue operands travel with the tiles (latency-bound small batches) or are loaded by the epilogue
   const int lpr = 4 * g.LPC;             // lanes per row of a record group: row rr of the group = lanes [rr * lpr, (rr + 1) * lpr), owner lane = rr * lpr + owner_off(g)
   const int rr = lane / lpr;
   const bool own = (lane & (lpr - 1)) == owner_off(g);
   if constexpr (EPI == EPI_STORE || EPI == EPI_RESID) {
     const float ascale = a.acc_scale ? *a.acc_scale : 1.0f;
-    // residual values travel with the record (requested behind its weights): the owner lane of a row loads the row's old value
-    auto auxf = [&](int unit, int, int rgl) {
+    // residual values travel with the tiles of their record group (requested behind the weights; batch 1 and 2: AUX_RING), or are loaded by the epilogue (wider
+    // batches: the ring of operands would cost NS x 2 x NCOLS registers).  Unconditional loads from clamped addresses: a lane-conditional load is a branch around a
+    // VMEM instruction, and every such branch makes the tile waits of dec_core2.cuh stream() one load stricter.
+    auto load_aux = [&](int row) {
       AuxV<NCOLS> v;
-      const int row = (unit * jb.rgpu + rgl) * g.R + rr;
+      const int rc = min(row, jb.nrows - 1);
 #pragma unroll
-      for (int c = 0; c < NCOLS; ++c) { v.a[c] = 0.f; v.b[c] = 0.f; if (EPI == EPI_RESID && own && row < jb.nrows) v.a[c] = a.out[(size_t)c * a.out_stride + row]; }
+      for (int c = 0; c < NCOLS; ++c) { v.a[c] = 0.f; v.b[c] = 0.f; if constexpr (EPI == EPI_RESID) v.a[c] = a.out[(size_t)c * a.out_stride + rc]; }
       return v;
     };
-    auto epi = [&](int, int row0, int nvalid, int, const float(&sum)[NCOLS], const AuxV<NCOLS> &ax) {
+    auto auxf = [&](int row0) {
+      if constexpr (AUX_RING) return load_aux(row0 + rr); else return NoAux{};
+    };
+    auto epi = [&](int, int row0, int nvalid, int, const float(&sum)[NCOLS], const auto &axr) {
+      AuxV<NCOLS> ax;
+      if constexpr (AUX_RING) ax = axr; else ax = load_aux(row0 + rr);
       if (own && rr < nvalid) {
 #pragma unroll
         for (int c = 0; c < NCOLS; ++c) {
@@ -119,7 +124,7 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
         }
       }
     };
-    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, NCOLS>(jb, K, NCI, mode, smem, stage, auxf, epi); })
+    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, NCOLS>(jb, K, NCI, mode, smem, ctr, stage, auxf, epi); })
   } else if constexpr (EPI == EPI_RESID2) {
     // MoE down of the two experts of one token in one launch (the image has two columns = the two experts' activation vectors): a unit streams its rows of
     // expert sel[0] against column 0, then the same rows of expert sel[1] against column 1, and writes (out * resid_scale + w0 s0) * 1 + w1 s1 -- the two
@@ -127,10 +132,10 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
     static_assert(EPI != EPI_RESID2 || NCOLS == 1, "one accumulator column; the image has two");
     const float w0 = a.acc_scale[0], w1 = a.acc_scale[1];
     float s0save = 0.0f;  // the first expert's sums of the record group
-    auto auxf = [&](int unit, int seg, int rgl) {
+    auto auxf = [&](int row0) {
       AuxV<1> v; v.a[0] = 0.f; v.b[0] = 0.f;
-      const int row = (unit * jb.rgpu + rgl) * g.R + rr;
-      if (seg == 1 && own && row < jb.nrows) v.a[0] = a.out[row];
+      const int row = row0 + rr;
+      v.a[0] = a.out[min(row, jb.nrows - 1)];  // unconditional (dec_core2.cuh stream(): every request of a tile is straight-line code); used by segment 1's epilogue
       return v;
     };
     auto epi = [&](int seg, int row0, int nvalid, int, const float(&sum)[1], const AuxV<1> &ax) {
@@ -141,12 +146,12 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
         a.out[row0 + rr] = h1 * 1.0f + sum[0] * w1;
       }
     };
-    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, 1, true>(jb, K, NCI, mode, smem, stage, auxf, epi); })
+    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, 1, true>(jb, K, NCI, mode, smem, ctr, stage, auxf, epi); })
   } else if constexpr (EPI == EPI_GLU) {
     float gsave[NCOLS];  // the gate sums of the record group until the matching up rows arrive (same unit, same lanes)
 #pragma unroll
     for (int c = 0; c < NCOLS; ++c) gsave[c] = 0.0f;
-    auto auxf = [](int, int, int) { return NoAux{}; };
+    auto auxf = [](int) { return NoAux{}; };
     auto epi = [&](int seg, int row0, int nvalid, int, const float(&sum)[NCOLS], const NoAux &) {
       if (seg == 0) {
 #pragma unroll
@@ -159,28 +164,34 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
           a.out[(size_t)slot * a.slot_out_stride + (size_t)c * a.out_stride + (row - slot * a.nrows[0])] = (a.activation == 0 ? silu_engine(gsave[c]) : glu_act(gsave[c], a.activation)) * sum[c];
       }
     };
-    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, NCOLS>(jb, K, NCI, mode, smem, stage, auxf, epi); })
+    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, NCOLS>(jb, K, NCI, mode, smem, ctr, stage, auxf, epi); })
   } else {  // EPI_QKV: rows 2i, 2i + 1 of a tensor are a RoPE pair; a record group holds whole pairs (R >= 2) or a unit holds two record groups (R = 1)
     // positions and KV slots: a handful of scalars, loaded before anything else; the RoPE factors travel with the record (owner lanes of the pair's two rows)
     int posv[NCOLS], slotv[NCOLS];  // slots are block * block_size + offset of a cache that fits 32-bit indexing per layer (checked by the launcher)
 #pragma unroll
     for (int c = 0; c < NCOLS; ++c) { posv[c] = a.positions[c]; slotv[c] = mi == 0 ? 0 : (int)a.slot_mapping[c]; }
-    auto auxf = [&](int unit, int, int rgl) {
+    auto load_aux = [&](int row) {  // RoPE factors of the row's pair for every column; identity for v and unrotated dims (x*1 - y*0 = x exactly).  Unconditional loads.
       AuxV<NCOLS> v;
-      const int row = (unit * jb.rgpu + rgl) * g.R + rr;
       const int pair_i = (int)((unsigned)row % (unsigned)a.head_dim) >> 1;
-      const bool rot = mi < 2 && pair_i < a.rot_pairs && own && row < jb.nrows;
+      const bool rot = mi < 2 && pair_i < a.rot_pairs;
+      const int pi = min(pair_i, a.rot_pairs - 1);
 #pragma unroll
       for (int c = 0; c < NCOLS; ++c) {
-        v.a[c] = 1.0f; v.b[c] = 0.0f;  // identity rotation for v and unrotated dims (x*1 - y*0 = x exactly)
-        if (rot) { const size_t ti = (size_t)posv[c] * a.rot_pairs + pair_i; v.a[c] = a.cos_t[ti]; v.b[c] = a.sin_t[ti]; }
+        const size_t ti = (size_t)posv[c] * a.rot_pairs + pi;
+        const float cs = a.cos_t[ti], sn = a.sin_t[ti];
+        v.a[c] = rot ? cs : 1.0f; v.b[c] = rot ? sn : 0.0f;
       }
       return v;
+    };
+    auto auxf = [&](int row0) {
+      if constexpr (AUX_RING) return load_aux(row0 + rr); else return NoAux{};
     };
     float prev[NCOLS];  // R = 1: the even row's sum waits for the odd row's record group
 #pragma unroll
     for (int c = 0; c < NCOLS; ++c) prev[c] = 0.0f;
-    auto epi = [&](int, int row0, int nvalid, int rgl, const float(&sum)[NCOLS], const AuxV<NCOLS> &ax) {  // rows are local rows of tensor mi
+    auto epi = [&](int, int row0, int nvalid, int rgl, const float(&sum)[NCOLS], const auto &axr) {  // rows are local rows of tensor mi
+      AuxV<NCOLS> ax;
+      if constexpr (AUX_RING) ax = axr; else ax = load_aux(row0 + rr);
       const bool single = g.R == 1;
       if (single && (rgl & 1) == 0) {
 #pragma unroll
@@ -226,15 +237,15 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
         }
       }
     };
-    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, NCOLS>(jb, K, NCI, mode, smem, stage, auxf, epi); })
+    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, NCOLS>(jb, K, NCI, mode, smem, ctr, stage, auxf, epi); })
   }
 }
 
 template <int NCOLS, int EPI, int TMASK = TM_ALL>
 __global__ void __launch_bounds__(NT) dec_gemv_kernel(const GemvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ float red[8 * 8];  // RMSNorm partials: [column][wave]
-  gemv_phase<NCOLS, EPI, TMASK>(a, smem, red);
+  __shared__ int ctr;  // the workgroup's unit counter
+  gemv_phase<NCOLS, EPI, TMASK>(a, smem, &ctr);
 }
 
 

@@ -59,7 +59,8 @@ __device__ __forceinline__ void wg_slice(size_t count, size_t &i0, size_t &i1) {
   i1 = i0 + per < count ? i0 + per : count;
   if (i0 > count) i0 = count;
 }
-constexpr unsigned long long SPIN_TICKS = 1000000ull;  // 10 ms at 100 MHz
+constexpr unsigned long long SPIN_TICKS = 200000000ull;  // 2 s at 100 MHz: tensor-parallel ranks are separate PROCESSES -- lazy module loads, graph capture of 80 layers or a GC pause skew them
+                                                         // by far more than a hop (10 ms made a late but healthy peer look dead)
 __device__ __forceinline__ void post(const Comm &c, const float *buf, size_t count, unsigned seq) {
   const size_t half = (size_t)(seq & 1) * c.world * c.max_elems;
   size_t i0, i1;
@@ -81,23 +82,26 @@ __device__ __forceinline__ bool reduce(const Comm &c, float *buf, size_t count, 
   const size_t half = (size_t)(seq & 1) * c.world * c.max_elems;
   size_t i0, i1;
   wg_slice(count, i0, i1);
-  bool ok = true;
+  // state[1] != 0: a granule has timed out before (in this call or an earlier one, in any workgroup): nobody waits again -- every remaining element becomes NaN at
+  // once and later calls return immediately until the host clears or drops the route (a dead peer used to cost the full bound per element)
+  bool ok = *(volatile unsigned *)(c.state + 1) == 0u;
   for (size_t i = i0 + threadIdx.x; i < i1; i += NT) {
     float sum = 0.f;
-    bool mine = true;
-    for (int r = 0; r < c.world; ++r) {
+    bool mine = ok;
+    for (int r = 0; mine && r < c.world; ++r) {
       const unsigned long long *p = c.mail[c.rank] + half + (size_t)r * c.max_elems + i;
       unsigned long long g = MRS_P2P_LOAD(p);
       if ((unsigned)(g >> 32) != seq) {
-        // bounded by TIME, not by iterations: ~10 ms of the 100 MHz s_memrealtime clock -- three orders of magnitude above a healthy hop (a few us),
-        // short enough that a peer that is not running the same sequence of all-reduces costs one step, not the job (the host reads the error word
-        // at its next synchronisation point and falls back to RCCL: Llama.p2p_error, bench.py)
+        // bounded by TIME, not by iterations: the 100 MHz s_memrealtime clock.  The host reads the error word at its next synchronisation point, reduces it (MAX)
+        // over the ranks and drops the route on ALL of them in the same step (Llama.p2p_error, bench.py)
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        unsigned spins = 0;
         do {
-          if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_TICKS) { mine = false; break; }
+          if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_TICKS || ((++spins & 63u) == 0u && *(volatile unsigned *)(c.state + 1) != 0u)) { mine = false; break; }
           __builtin_amdgcn_s_sleep(1);
           g = MRS_P2P_LOAD(p);
         } while ((unsigned)(g >> 32) != seq);
+        if (!mine) *(volatile unsigned *)(c.state + 1) = 1u;  // tell the other threads / workgroups now, not at the end of the call
       }
       sum += __uint_as_float((unsigned)g);  // rank order: identical bits on every rank
     }

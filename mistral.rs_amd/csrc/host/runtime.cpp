@@ -976,12 +976,11 @@ extern "C" int mrs_llama_set_prefill_mode(void *m, int exact) { ((Llama *)m)->pr
 extern "C" int mrs_llama_set_comm(void *m, void *comm) { ((Llama *)m)->comm = comm; return 0; }
 extern "C" int mrs_llama_set_p2p(void *m, void *p2p) { ((Llama *)m)->p2p = p2p; return 0; }
 // Error word of the peer-mailbox route (blocking device read: call where the host synchronises anyway).  Non-zero = a granule never arrived within the bounded spin and the
-// affected sums are NaN: the runner DROPS the route (every later all-reduce goes to RCCL; a captured decode graph must be re-captured) and reports it, the caller repeats
-// the steps since its last check.
+// affected sums are NaN.  The word is PER RANK and the route must change on EVERY rank in the same step (a rank on RCCL next to a rank on p2p pairs collectives of
+// different steps): this call only READS -- the host reduces the word (MAX) over the tensor-parallel ranks, and when the maximum is non-zero every rank calls
+// mrs_llama_set_p2p(model, NULL), re-captures its decode graph and repeats the steps since its last check (Llama.p2p_sync_error does exactly this).
 extern "C" int mrs_llama_check_p2p(void *m) {
   Llama *l = (Llama *)m;
   if (!l->p2p) return 0;
-  const int e = mrs_p2p_error(l->p2p);
-  if (e) l->p2p = nullptr;
-  return e;
+  return mrs_p2p_error(l->p2p);
 }

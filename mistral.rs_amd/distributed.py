@@ -297,11 +297,8 @@ class P2PAllReduce:
         object from any runner (Llama.set_p2p(None)) first."""
         self._release()
 
-    def __del__(self):
-        try:
-            self._release()
-        except Exception:
-            pass
+    # no __del__: freeing the mailbox needs a device synchronisation and a rank barrier first (peers post into it through their IPC mapping, a captured graph holds
+    # its address by value) -- only close() releases, after the caller has done both (ADVICE round 4)
 
     def all_reduce_(self, t: torch.Tensor) -> torch.Tensor:
         assert t.dtype == torch.float32 and t.is_contiguous()

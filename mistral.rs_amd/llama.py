@@ -250,16 +250,33 @@ class Llama:
         self._chk(self._L.mrs_llama_set_p2p(self._h, p2p.handle if p2p is not None else None))
 
     def p2p_error(self) -> int:
-        """Error word of the peer-mailbox route (blocking device read; call where the host synchronises anyway -- after a run of decode steps, before
-        tokens are handed out): non-zero = some granule never arrived within the bounded spin (ext_p2p.hip, ~10 ms) and the affected sums are NaN.
-        The caller drops the route (set_p2p(None) -> RCCL) and repeats the steps since its last check; bench.py does exactly that."""
+        """THIS rank's error word of the peer-mailbox route (blocking device read; call where the host synchronises anyway -- after a run of decode steps, before
+        tokens are handed out): non-zero = some granule never arrived within the bounded spin (ext_p2p.hip) and the affected sums are NaN.  Read only: the word is
+        per rank and the route must be dropped on EVERY rank in the same step -- use `p2p_sync_error()` unless you reduce the word over the ranks yourself."""
         if getattr(self, "_p2p", None) is None:
             return 0
         self._L.mrs_llama_check_p2p.argtypes = [C.c_void_p]
-        e = int(self._L.mrs_llama_check_p2p(self._h))  # the C++ runner drops the route itself when the word is set
-        if e:
-            self._p2p = None
-        return e
+        return int(self._L.mrs_llama_check_p2p(self._h))
+
+    def p2p_sync_error(self, group=None) -> bool:
+        """The mandatory protocol around the error word (include/mrs_hip_ext.h, mrs_llama_check_p2p): MAX-reduce it over the tensor-parallel ranks; if any rank saw
+        a time-out, EVERY rank detaches the route in this same call (RCCL from now on).  Returns True when the route was dropped: the caller re-captures its decode
+        graph and repeats the steps since its last check.  The P2PAllReduce object stays alive (peers may still hold its mailbox mapped) until its close()."""
+        if getattr(self, "_p2p", None) is None:
+            return False
+        import torch
+        import torch.distributed as dist
+        bad = torch.tensor([int(self.p2p_error() != 0)], device=self.dev if hasattr(self, "dev") else "cuda")
+        if dist.is_available() and dist.is_initialized():
+            if bad.device.type == "cpu" or dist.get_backend(group) == "gloo":
+                bad = bad.cpu()
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
+        if int(bad.item()):
+            keep = self._p2p
+            self.set_p2p(None)
+            self._p2p_dropped = keep  # not freed here: close() after every rank has detached and re-captured
+            return True
+        return False
 
     def set_tensor(self, name: str, t) -> None:
         """t: QTensor (packed GGUF blocks) or an f32 torch tensor (norm weights)."""

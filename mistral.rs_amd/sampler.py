@@ -63,6 +63,38 @@ class TopK:
         return self.packed[:rows]
 
 
+class Top1:
+    """Greedy rows: `top1_large_f32_packed[_batched]` (cuda_top1_logits_f32_*, ops.rs:1232-2050) -- packed [rows][2] = (max logit, token id as f32); no temperature."""
+
+    def __init__(self, vocab: int, device, max_rows: int = 1):
+        if vocab <= 0:
+            raise ValueError("top-1: empty logits")
+        self.vocab, self.max_rows, self.device = vocab, max_rows, device
+        self.nblocks = (vocab + CHUNK_SIZE - 1) // CHUNK_SIZE
+        self.block_values = torch.empty(max_rows, self.nblocks, dtype=torch.float32, device=device)
+        self.block_indices = torch.empty(max_rows, self.nblocks, dtype=torch.int32, device=device)
+        self.packed = torch.empty(max_rows, 2, dtype=torch.float32, device=device)
+        vp, i, ll = C.c_void_p, C.c_int, C.c_int64
+        self._many = _lib.sym("core", "top1_large_f32_packed_batched", [vp, vp, vp, vp, vp, i, i, i, i, ll])
+
+    def __call__(self, logits: torch.Tensor) -> torch.Tensor:
+        x = logits.reshape(-1, self.vocab)
+        rows = x.shape[0]
+        if x.dtype != torch.float32 or not x.is_contiguous() or rows > self.max_rows:
+            raise ValueError("top-1: logits must be contiguous f32 with at most max_rows rows")
+        self._many(x.data_ptr(), self.block_values.data_ptr(), self.block_indices.data_ptr(), self.packed.data_ptr(), None, rows, self.vocab, CHUNK_SIZE, self.nblocks,
+                   torch.cuda.current_stream().cuda_stream)
+        return self.packed[:rows]
+
+
+def top1_token(packed2) -> int:
+    """Sampler::cuda_top1_token (sampler.rs:1284-1297): the packed pair must be finite and hold a non-negative integer"""
+    mx, ix = float(packed2[0]), float(packed2[1])
+    if not (np.isfinite(mx) and np.isfinite(ix)) or ix < 0 or ix != np.floor(ix):
+        raise ValueError(f"invalid CUDA top-1 output: max_logit={mx} argmax={ix}")
+    return int(ix)
+
+
 def filtered_probs(packed: np.ndarray, k: int, temperature: float, top_p: float = 1.0, min_p: float = 0.0):
     """sampler.rs:1189-1236 for one packed row: (token ids [k], reporting probabilities [k], weights after the top-p and min-p cuts [k]); f32 like the reference."""
     vals, ids = packed[:k].astype(np.float32), packed[k:2 * k].astype(np.uint32)
@@ -91,27 +123,33 @@ def filtered_probs(packed: np.ndarray, k: int, temperature: float, top_p: float 
 def sample(packed: np.ndarray, k: int, temperature: float, top_p: float, min_p: float, rng: np.random.Generator):
     """One draw: (token id, its reporting probability).  Raises like the reference when every weight is zero."""
     ids, rep, probs = filtered_probs(packed, k, temperature, top_p, min_p)
-    w = np.where(np.isfinite(probs) & (probs > 0), probs, 0).astype(np.float64)
-    if w.sum() == 0.0:
-        raise ValueError("All sampling probabilities are zero after top-k filtering.")
+    # WeightedIndex::new (sampler.rs:1238-1258) refuses NaN / infinite / negative weights and an all-zero set; nothing is silently zeroed
+    if float(np.where(np.isfinite(probs) & (probs > 0), probs, 0).astype(np.float64).sum()) == 0.0:
+        raise ValueError("All sampling probabilities are zero after CUDA top-k filtering.")
+    if not np.all(np.isfinite(probs)) or np.any(probs < 0):
+        raise ValueError("Failed to construct CUDA top-k multinomial sampler: invalid weight")
+    w = probs.astype(np.float64)
     j = int(rng.choice(k, p=w / w.sum()))
     return int(ids[j]), float(rep[j])
 
 
 def generate(model, prompt, max_new_tokens: int, top_k: int, temperature: float = 1.0, top_p: float = 1.0, min_p: float = 0.0, seed: int = 0):
     """Sampled decoding on a `Llama` runner (the loop of `Sampler::sample` with top_k set, sampler.rs:1262-1290): prefill, then per token one decode step, the device
-    top-k over the logits row, `2k + 2` floats to the host, the top-p / min-p cuts and the draw there.  top_k == 1 takes the best candidate without a draw
+    top-k over the logits row, `2k + 2` floats to the host, the top-p / min-p cuts and the draw there.  top_k == 1 takes the arg-max through the top-1 kernels, no temperature, probability 1
     (sample_cuda_top1_row).  Returns (tokens, reporting probabilities)."""
     rng = np.random.default_rng(seed)
-    tk = TopK(model.cfg.vocab_size, top_k, model.device)
+    k = min(int(top_k), int(model.cfg.vocab_size))
+    t1 = Top1(model.cfg.vocab_size, model.device) if k == 1 else None
+    tk = None if k == 1 else TopK(model.cfg.vocab_size, top_k, model.device)
     logits = model.prefill(list(prompt), 0).float().reshape(1, -1)  # sequence 0: the decode steps below run batch row 0
     toks, probs = [], []
     for i in range(max_new_tokens):
-        packed = tk(logits.contiguous(), temperature).cpu().numpy()[0]
-        if tk.k == 1:
-            ids, rep, _ = filtered_probs(packed, 1, temperature)
-            tok, p = int(ids[0]), float(rep[0])
+        if hasattr(model, "p2p_sync_error") and model.p2p_sync_error():  # tensor parallel: a timed-out peer-mailbox sum is NaN -- never hand out a token from it
+            raise RuntimeError("p2p all-reduce timed out: the route has been dropped on every rank (RCCL from now on); re-run the request")
+        if k == 1:  # sample_cuda_top1_row (sampler.rs:767-781): the arg-max, no temperature, logprob 0 (probability 1)
+            tok, p = top1_token(t1(logits.contiguous()).cpu().numpy()[0]), 1.0
         else:
+            packed = tk(logits.contiguous(), temperature).cpu().numpy()[0]
             tok, p = sample(packed, tk.k, temperature, top_p, min_p, rng)
         toks.append(tok)
         probs.append(p)

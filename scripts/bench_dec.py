@@ -134,7 +134,7 @@ def main():
             tl = torch.zeros(256 * 8 * 16, dtype=torch.int64, device=dev)
             stc = torch.cuda.current_stream().cuda_stream
             for i, inst in enumerate(insts[:6]):
-                L.mrs_dec_timeline(tl.data_ptr() if i == 5 else None, 1)
+                L.mrs_dec_timeline(tl.data_ptr() if i == len(insts[:6]) - 1 else None, 1)
                 assert inst[1](stc) == 0
                 torch.cuda.synchronize()
             L.mrs_dec_timeline(None, 0)
@@ -147,8 +147,7 @@ def main():
                 v = rel[:, sel, i][t[:, sel, i] > 0]
                 return (round(float(np.median(v)), 2), round(float(v.max()), 2)) if v.size else None
             for nm, sel in (("waves 0-3", slice(0, 4)), ("waves 4-7", slice(4, 8))):
-                print(name, nm, "(median, max us): entry", med(sel, 0), "issued", med(sel, 1), "prologue", med(sel, 2), "barrier", med(sel, 3), "rec1", med(sel, 4), "rec2", med(sel, 5),
-                      "rec3", med(sel, 6), "rec4", med(sel, 7), "end", med(sel, 14), flush=True)
+                print(name, nm, "(median, max us): entry", med(sel, 0), "ring issued", med(sel, 1), "prologue done", med(sel, 2), "barrier", med(sel, 3), "end", med(sel, 14), flush=True)
             del insts
             torch.cuda.empty_cache()
             continue

@@ -256,7 +256,7 @@ def check_attention(O, be, heads, kvh, ctxs, max_ctx, kv_dtype=1, n_out=24, wind
     scale = np.float32(1.0 / np.sqrt(np.float32(hd)))
     nimg = be.sym("mrs_dec_act_image_bytes", [C.c_int, C.c_int], C.c_size_t)(nq, b)
     S_ = nq // 256
-    assert nimg == b * (4 * (((S_ + 3) // 4) * 256 + 16) + S_ * (48 + 80))  # per column: 4 chunks of quants (16-byte skew each), scales (48 covers the Q8_0 mode), 16 sums at a stride of 80 per superblock
+    assert nimg == b * (4 * (((S_ + 3) // 4) * 256 + 16) + 4 * ((S_ + 3) // 4) * (48 + 80))  # per column: 4 chunks of quants (16-byte skew each); scales (48 covers the Q8_0 mode) and 16 sums at a stride of 80 for the 4 * ceil(S / 4) superblock slots of a row group's tiles
     img, got = be.buf(np.zeros(nimg, np.uint8)), be.buf(np.full((b, nq), np.nan, np.float32))
     fn = be.sym("mrs_dec_attention", ATTN2, C.c_int)
     even = (heads // kvh) % 2 == 0

@@ -191,7 +191,7 @@ def test_sampled_generation_on_the_runner(oracle, dev):
         m.set_state([greedy[-1]], [len(prompt) + i])
         lg = m.forward_logits(1)[0]
     toks, probs = sampler.generate(m, prompt, 6, top_k=1)
-    assert toks == greedy and all(0 < p <= 1 for p in probs)
+    assert toks == greedy and all(p == 1.0 for p in probs)  # sample_cuda_top1_row: logprob 0
     a = sampler.generate(m, prompt, 8, top_k=20, temperature=1.5, top_p=0.9, min_p=0.02, seed=5)
     b = sampler.generate(m, prompt, 8, top_k=20, temperature=1.5, top_p=0.9, min_p=0.02, seed=5)
     assert a == b and all(0 < p <= 1 for p in a[1]) and all(0 <= t < cfg.vocab_size for t in a[0])
