@@ -29,6 +29,7 @@
 #pragma once
 #include "gguf_blocks.cuh"
 #include <type_traits>
+#include <utility>
 
 #ifndef MRS_WAVE_SYNC
 #define MRS_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
@@ -239,21 +240,21 @@ template <int NP> __device__ __forceinline__ ActRegs<NP> act_issue_all(const voi
   for (int j = 0; j < NP; ++j) { p.wv[j] = v4u{0u, 0u, 0u, 0u}; if (nw && j < nv) p.wv[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, off + (unsigned)j * 8192u, 0, 0); }
   return p;
 }
-// `red`: NCOLS * 8 floats of LDS.  No trailing barrier (the caller's barrier publishes the image).
+// `red`: NCOLS * 8 floats of LDS.  Two halves so that the caller can request weights between them (stream()):
+//   act_sumsq_all     squares, wave sums -> red, ONE workgroup barrier (none when there is no norm weight)
+//   act_quantize_all  norm factors from red (per column, read back from LDS: an array of factors indexed by a column loop that hipcc does not unroll -- 7 - 8
+//                     columns -- would live in scratch memory), normalise + quantize the wave's superblocks into the image.  No trailing barrier (the caller's
+//                     barrier publishes the image).
 template <int NCOLS, int NP>
-__device__ __forceinline__ void act_finish_all(char *img, float *red, const ActRegs<NP> &pre, const float *__restrict__ x, int ldx, const float *__restrict__ nw, float eps, int K, int mode) {
+__device__ __forceinline__ void act_sumsq_all(float *red, const ActRegs<NP> &pre, const float *__restrict__ x, int ldx, const float *__restrict__ nw, int K) {
   const int tid = tid_opaque(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nv = wave < 8 ? (K + 2047) / 2048 : 0;  // waves 8 .. 15 of a 1024-thread workgroup only pass the barrier
-  float nm[NCOLS], inv[NCOLS];
-#pragma unroll
-  for (int c = 0; c < NCOLS; ++c) { nm[c] = 1.0f; inv[c] = 1.0f; }
   auto ldx4 = [&](int c, int j) -> float4 { const int e = tid * 4 + j * 2048; return e < K ? *(const float4 *)(x + (size_t)c * ldx + e) : make_float4(0.f, 0.f, 0.f, 0.f); };
-  auto ldw4 = [&](int j) -> float4 { const int e = tid * 4 + j * 2048; return e < K ? *(const float4 *)(nw + e) : make_float4(0.f, 0.f, 0.f, 0.f); };
   if (nw) {
 #pragma unroll
     for (int c = 0; c < NCOLS; ++c) {
       float ss = 0.f;
-      auto sq = [&](float4 f) { ss = fmaf(f.x, f.x, ss); ss = fmaf(f.y, f.y, ss); ss = fmaf(f.z, f.z, ss); ss = fmaf(f.w, f.w, ss); };
+      auto sq = [&](float4 v) { ss = fmaf(v.x, v.x, ss); ss = fmaf(v.y, v.y, ss); ss = fmaf(v.z, v.z, ss); ss = fmaf(v.w, v.w, ss); };
 #pragma unroll
       for (int j = 0; j < NP; ++j) if (j < nv) sq(c == 0 ? as_f4(pre.xv[j]) : ldx4(c, j));
       for (int j = NP; j < nv; ++j) sq(ldx4(c, j));
@@ -261,16 +262,23 @@ __device__ __forceinline__ void act_finish_all(char *img, float *red, const ActR
       if (lane == 0 && wave < 8) red[c * 8 + wave] = ss;
     }
     __syncthreads();
-#pragma unroll
-    for (int c = 0; c < NCOLS; ++c) {
-      const float *r = red + c * 8;
-      const float tot = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-      nm[c] = sqrtf(tot / (float)K + eps);
-      inv[c] = 1.0f / nm[c];
-    }
   }
+}
+template <int NCOLS, int NP>
+__device__ __forceinline__ void act_quantize_all(char *img, const float *red, const ActRegs<NP> &pre, const float *__restrict__ x, int ldx, const float *__restrict__ nw, float eps, int K, int mode) {
+  const int tid = tid_opaque(), wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nv = wave < 8 ? (K + 2047) / 2048 : 0;
+  auto ldx4 = [&](int c, int j) -> float4 { const int e = tid * 4 + j * 2048; return e < K ? *(const float4 *)(x + (size_t)c * ldx + e) : make_float4(0.f, 0.f, 0.f, 0.f); };
+  auto ldw4 = [&](int j) -> float4 { const int e = tid * 4 + j * 2048; return e < K ? *(const float4 *)(nw + e) : make_float4(0.f, 0.f, 0.f, 0.f); };
 #pragma unroll
   for (int c = 0; c < NCOLS; ++c) {
+    float nm = 1.0f, inv = 1.0f;
+    if (nw) {
+      const float *r = red + c * 8;
+      const float tot = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+      nm = sqrtf(tot / (float)K + eps);
+      inv = 1.0f / nm;
+    }
     // the wave's 256 values at 2048 j + 256 wave = superblock wave + 8 j; two superblocks per quantizer call
 #pragma unroll
     for (int j0 = 0; j0 < NP; j0 += 2) {
@@ -281,114 +289,23 @@ __device__ __forceinline__ void act_finish_all(char *img, float *red, const ActR
           const int j = j0 + i;
           sb[i] = wave + 8 * j; live[i] = j < nv && sb[i] * 256 < K;
           const float4 xv = c == 0 ? as_f4(pre.xv[j]) : (live[i] ? ldx4(c, j) : make_float4(0.f, 0.f, 0.f, 0.f));
-          v[i] = nw ? norm4(xv, as_f4(pre.wv[j]), nm[c], inv[c]) : xv;
+          v[i] = nw ? norm4(xv, as_f4(pre.wv[j]), nm, inv) : xv;
         }
         quantize_multi<2>(v, sb, live, c, mode, img, K, NCOLS);
       }
     }
     for (int j = NP; j < nv; ++j) {
       const int sb = wave + 8 * j;
-      if (sb * 256 < K) quantize_sb(nw ? norm4(ldx4(c, j), ldw4(j), nm[c], inv[c]) : ldx4(c, j), sb, c, mode, img, K, NCOLS);
+      if (sb * 256 < K) quantize_sb(nw ? norm4(ldx4(c, j), ldw4(j), nm, inv) : ldx4(c, j), sb, c, mode, img, K, NCOLS);
     }
   }
 }
-// ---- the same prologue on PW = 4 waves ("prologue waves"), without a workgroup barrier: while they run it, the other waves of the workgroup request weights
-// (stream(): a wave is blocked on the issue of its ring for microseconds -- the memory system accepts requests at HBM rate -- so a wave cannot do both).
-constexpr int PW = 4;
-// SPEC: waves 0 .. PW-1 only.  Registers: the whole row for the sum of squares (16 pieces per lane and batch) + the wave's own superblocks (<= 16).
-constexpr int SPEC_OWN = 16;
-struct SpecRegs { v4u xa[16]; v4u xo[SPEC_OWN]; v4u wo[SPEC_OWN]; };
-__device__ __forceinline__ SpecRegs act_issue_spec(const float *x, const float *nw, int K, int wave) {
-  SpecRegs p;
-  const int lane = lane_opaque(), S = K / 256;
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)x, (short)0, K * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)(nw ? nw : x), (short)0, nw ? K * 4 : 0, 0x00020000);
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {  // virtual thread v * 64 + lane, piece jj: element (v * 64 + lane) * 4 + 2048 jj;  i = 8 jj + v  (first 4096 values)
-    p.xa[i] = v4u{0u, 0u, 0u, 0u};
-    if (nw && (i >> 3) * 2048 < K) p.xa[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (unsigned)(((i & 7) * 64 + lane) * 16 + (i >> 3) * 8192), 0, 0);
-  }
-#pragma unroll
-  for (int i = 0; i < SPEC_OWN; ++i) {
-    p.xo[i] = v4u{0u, 0u, 0u, 0u}; p.wo[i] = v4u{0u, 0u, 0u, 0u};
-    const int sb = wave + i * PW;
-    if (sb < S) {  // wave-uniform
-      p.xo[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (unsigned)(sb * 1024 + lane * 16), 0, 0);
-      if (nw) p.wo[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, (unsigned)(sb * 1024 + lane * 16), 0, 0);
-    }
-  }
-  return p;
+template <int NCOLS, int NP>
+__device__ __forceinline__ void act_finish_all(char *img, float *red, const ActRegs<NP> &pre, const float *__restrict__ x, int ldx, const float *__restrict__ nw, float eps, int K, int mode) {
+  act_sumsq_all<NCOLS, NP>(red, pre, x, ldx, nw, K);
+  act_quantize_all<NCOLS, NP>(img, red, pre, x, ldx, nw, eps, K, mode);
 }
-template <int NCOLS>
-__device__ __forceinline__ void act_finish_spec(char *img, const SpecRegs &pre, const float *__restrict__ x, int ldx, const float *__restrict__ nw, float eps, int K, int mode, int wave) {
-  const int lane = lane_opaque(), S = K / 256;
-#pragma unroll
-  for (int c = 0; c < NCOLS; ++c) {
-    const float *xr = x + (size_t)c * ldx;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)xr, (short)0, K * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)(nw ? nw : xr), (short)0, nw ? K * 4 : 0, 0x00020000);
-    float nm = 1.0f, inv = 1.0f;
-    if (nw) {
-      float ss[8];
-#pragma unroll
-      for (int v = 0; v < 8; ++v) ss[v] = 0.f;
-      for (int j0 = 0; j0 * 2048 < K; j0 += 2) {  // two pieces (16 loads) per batch
-        v4u f[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          if (c == 0 && j0 == 0) f[i] = pre.xa[i];
-          else { f[i] = v4u{0u, 0u, 0u, 0u}; if ((j0 + (i >> 3)) * 2048 < K) f[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (unsigned)(((i & 7) * 64 + lane) * 16 + (j0 + (i >> 3)) * 8192), 0, 0); }
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { const float4 g = as_f4(f[i]); float &s1 = ss[i & 7]; s1 = fmaf(g.x, g.x, s1); s1 = fmaf(g.y, g.y, s1); s1 = fmaf(g.z, g.z, s1); s1 = fmaf(g.w, g.w, s1); }
-      }
-      float ws[8];
-#pragma unroll
-      for (int v = 0; v < 8; ++v) ws[v] = wave_sum_all(ss[v]);
-      const float tot = ((ws[0] + ws[1]) + (ws[2] + ws[3])) + ((ws[4] + ws[5]) + (ws[6] + ws[7]));
-      nm = sqrtf(tot / (float)K + eps);
-      inv = 1.0f / nm;
-    }
-    // own superblocks wave + i PW, four per quantizer call
-#pragma unroll
-    for (int i0 = 0; i0 < SPEC_OWN; i0 += 4) {
-      if (wave + i0 * PW < S) {  // wave-uniform
-        float4 v[4]; int sb[4]; bool live[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int i = i0 + k;
-          sb[k] = wave + i * PW; live[k] = sb[k] < S;
-          v4u xr4 = pre.xo[i], wr4 = pre.wo[i];
-          if (c != 0) {
-            xr4 = v4u{0u, 0u, 0u, 0u};
-            if (live[k]) xr4 = __builtin_amdgcn_raw_buffer_load_b128(rx, (unsigned)(sb[k] * 1024 + lane * 16), 0, 0);
-          }
-          v[k] = nw ? norm4(as_f4(xr4), as_f4(wr4), nm, inv) : as_f4(xr4);
-        }
-        quantize_multi<4>(v, sb, live, c, mode, img, K, NCOLS);
-      }
-    }
-    for (int sbx = wave + SPEC_OWN * PW; sbx < S; sbx += PW) {  // rows beyond 16384 values
-      const float4 xv = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rx, (unsigned)(sbx * 1024 + lane * 16), 0, 0));
-      const float4 w4 = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rw, (unsigned)(sbx * 1024 + lane * 16), 0, 0));
-      quantize_sb(nw ? norm4(xv, w4, nm, inv) : xv, sbx, c, mode, img, K, NCOLS);
-    }
-  }
-}
-
 // a pre-quantized image (act_bytes(K, ncols) bytes, 16-byte aligned, written by a producer kernel; requested by act_issue_all) -> LDS: the 16-byte pieces at tid * 16 + j * 8192
-// the same copy by the PW prologue waves only (256 threads): eight 16-byte pieces in flight per thread
-__device__ __forceinline__ void img_copy_spec(char *smem, const void *img, size_t bytes) {
-  const int tid = tid_opaque();  // < PW * 64
-  const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc((void *)img, (short)0, (int)bytes, 0x00020000);
-  for (size_t o0 = 0; o0 < bytes; o0 += (size_t)8 * PW * 1024) {
-    v4u r[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = __builtin_amdgcn_raw_buffer_load_b128(ri, (unsigned)(o0 + (size_t)j * PW * 1024 + (size_t)tid * 16), 0, 0);  // past the end: zeros
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { const size_t o = o0 + (size_t)j * PW * 1024 + (size_t)tid * 16; if (o < bytes) *(v4u *)(smem + o) = r[j]; }
-  }
-}
 template <int NP> __device__ __forceinline__ void img_finish_all(char *smem, const ActRegs<NP> &pre, const void *img, size_t bytes) {
   const int tid = tid_opaque();
 #pragma unroll
@@ -407,13 +324,13 @@ __device__ __forceinline__ int byte_of(unsigned w, int i) { return (int)((w >> (
 __device__ __forceinline__ int sbyte_of(unsigned w, int i) { return (int)(int8_t)((w >> (8 * i)) & 0xffu); }
 
 #ifndef MRS_DEC2_NS_Q4K
-#define MRS_DEC2_NS_Q4K 8
+#define MRS_DEC2_NS_Q4K 4
 #endif
 #ifndef MRS_DEC2_NS_Q5K
-#define MRS_DEC2_NS_Q5K 6
+#define MRS_DEC2_NS_Q5K 4
 #endif
 #ifndef MRS_DEC2_NS_Q6K
-#define MRS_DEC2_NS_Q6K 6
+#define MRS_DEC2_NS_Q6K 4
 #endif
 #ifndef MRS_DEC2_NS_Q80
 #define MRS_DEC2_NS_Q80 4
@@ -591,18 +508,21 @@ template <int TYPE, int NCOLS, int C0> struct TermCols {
 
 // ------------------------------------------------------------------------------------------------ the streaming core
 // A workgroup owns the UNITS [u0, u1) of a launch; unit u = rgpu consecutive record groups (a record group = 4 consecutive rows = Cs tiles) of each of the launch's
-// nseg tensors (gate and up rows of the same index travel together).  Waves take units from a counter in LDS (the streaming waves their first one statically); a
-// wave keeps NS tiles requested ahead of the one it is computing.  epi(seg, row0, nvalid, rgl, sums, aux) is called once per finished record group; inside a
-// unit: segment 0 before segment 1, record groups ascending; the call is lane-parallel: every lane of the chunk-3 quad of row rr = lane / 16 of the group (lanes
-// 16 rr + 12 .. + 15) holds that row's sum, lane 16 rr + 12 is the row's owner, nvalid rows exist.  aux(row0) runs with every REQUEST of the group's tiles (operands
-// of the epilogue -- residual values, RoPE factors -- travel with the weights instead of costing a dependent load after the row sum); the copy that came with the last
-// tile comes back to epi.
+// nseg tensors (gate and up rows of the same index travel together).  Wave w takes units u0 + w, u0 + w + NW, ...: T tiles, known up front; it keeps NS tiles
+// requested ahead of the one it is computing.  epi(seg, row0, nvalid, rgl, sums, aux) is called once per finished record group; inside a unit: segment 0 before
+// segment 1, record groups ascending; the call is lane-parallel: every lane of the chunk-3 quad of row rr = lane / 16 of the group (lanes 16 rr + 12 .. + 15) holds
+// that row's sum, lane 16 rr + 12 is the row's owner, nvalid rows exist.  aux(row0) runs with every REQUEST of the group's tiles (operands of the epilogue --
+// residual values, RoPE factors -- travel with the weights instead of costing a dependent load after the row sum); the copy that came with the last tile comes back to epi.
 //
-// Schedule (measured on the MI355X, profiles/round5_decode.md): the memory system accepts a CU's requests at HBM rate, so a wave that requests a deep ring is BLOCKED
-// in its issue for microseconds and cannot run the activation prologue meanwhile; and nothing can be multiplied before the prologue is done.  Hence two roles:
-//   waves PW .. 7 ("streaming"): first unit static, request the ring at once; wait at the barrier; compute.
-//   waves 0 .. PW-1 ("prologue"): request the activation row, run the prologue (RMSNorm + quantization, no workgroup barrier inside), barrier; then take units
-//   from the counter like everybody else (they start late and simply end up with fewer).
+// What the MI355X measurements of round 5 say (profiles/round5_decode.md, profiles/experiments/stream_probe.hip):
+//   * a launch that only streams (no prologue, trivial arithmetic) needs 3.0 / 3.8 / 7.5 / 12.2 / 66 us for 9 / 14 / 40 / 66 / 430 MB, boundary included, and FOUR
+//     1-KiB loads in flight per wave with 8 waves per CU reach that; deeper rings are slower on the short launches (the memory system accepts a CU's requests at its HBM
+//     share: a wave that requests more is blocked in the issue and cannot do anything else);
+//   * an out-of-range ("dead") buffer load still costs its 16 cycles in the CU's one texture addresser: a pass of dead requests of 8 waves is ~0.5 us;
+//   * nothing can be multiplied before the activation prologue is done, and the prologue's workgroup barrier waits for the SLOWEST wave's blocked issue.
+// Hence: (1) the activation row is requested first, ONE tile per wave next, the sum of squares and its barrier run while those fly, then the rest of the ring, then
+// the quantization and the publishing barrier; (2) the ring is NS = 4 tiles; (3) no dead requests in the common case: passes whose NS re-requests are all live run in
+// a loop, the last tiles are computed by straight-line tails that request nothing (or only the r < NS live ones that are left + NS - r dead).
 struct Job {
   Mat mat[2];
   int nseg, rgpu;
@@ -624,16 +544,27 @@ struct RecMeta { int ts_seg, row0, nvalid; };
 struct NoAux {};
 
 // SEGCOL (NCOLS must be 1): segment s multiplies by activation column s of a 2-column image (MoE down: two experts' rows against their own activations)
+// stage(0): request the activation row / image;  stage(1): sum of squares + its barrier (nothing for an image);  stage(2): normalise + quantize / copy into LDS
 template <int TYPE, int NCOLS, bool SEGCOL = false, class Stage, class AuxF, class Epi>
-__device__ __forceinline__ void stream(const Job &jb, int K, int ncols_img, int mode, char *smem, int *ctr, Stage stage, AuxF auxf, Epi epi) {
+__device__ __forceinline__ void stream(const Job &jb, int K, int ncols_img, int mode, char *smem, Stage stage, AuxF auxf, Epi epi) {
   using TL = Tile<TYPE>;
   using AuxT = decltype(auxf(0));
-  constexpr int NS = NCOLS <= 2 ? TL::NS : (TL::NS > 4 ? 4 : TL::NS);  // wide batches: the arithmetic per tile is NCOLS times longer, a shorter ring covers the same time
+  constexpr int NS = TL::NS;
   const int tid = tid_opaque(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const Geo g = geo_for(K);
   const int Cs = g.Cs;
   constexpr unsigned tileb = tile_bytes(TYPE);
   const int p = (lane >> 2) & 3, c = lane & 3;
+  // the wave's share: units u0 + wave, + NW, ...
+  const int nun = jb.u1 - jb.u0 - wave;
+  const int myunits = nun > 0 ? (nun + NW - 1) / NW : 0;
+  const int tps = jb.rgpu * Cs;  // tiles per segment of a unit
+  const int T = myunits * jb.nseg * tps;
+  if (T == 0) {  // a wave without tiles (small launches): its share of the prologue and the barriers, no requests at all
+    stage(0); stage(1); stage(2);
+    __syncthreads();
+    return;
+  }
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void *)jb.mat[0].base, (short)0, (int)jb.mat[0].bytes, 0x00020000);
   const bool two = jb.nseg > 1;
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void *)(two ? jb.mat[1].base : jb.mat[0].base), (short)0, (int)(two ? jb.mat[1].bytes : jb.mat[0].bytes), 0x00020000);
@@ -654,10 +585,8 @@ __device__ __forceinline__ void stream(const Job &jb, int K, int ncols_img, int 
   auto sel_at = [&](int i) { return (int)((selp >> (8 * (i & 7))) & 0xffull); };
   // the wave's request cursor (all wave-uniform): the unit, the segment, tiles left in the segment, the byte offset of the next tile (tiles of a segment of a unit
   // are consecutive in memory), the group's first row and the tile index inside the group
-  const bool late = wave < PW;
-  const int tps = jb.rgpu * Cs;  // tiles per segment of a unit
-  int lunit = -1, lseg = 0, lleft = 0, lts = 0, lrow0 = 0, lslot_row0 = 0;
-  unsigned ltoff = 0, lubase[2] = {0u, 0u};
+  int lunit = 0, lseg = 0, lleft = 0, lts = 0, lrow0 = 0, lslot_row0 = 0;
+  unsigned ltoff = 0, lubase1 = 0;
   auto open_unit = [&](int u) {  // wave-uniform; u may be past the end (the cursor then stays dead)
     lunit = u; lseg = 0; lts = 0; lleft = tps;
     if (u < jb.u1) {
@@ -666,20 +595,19 @@ __device__ __forceinline__ void stream(const Job &jb, int K, int ncols_img, int 
         if (jb.sel_mode == 2) { e0 = sel_at(0); e1 = sel_at(1); }
         else { sl = u / jb.upe; e0 = e1 = sel_at(sl); local -= sl * jb.upe * jb.rgpu; }
       }
-      lubase[0] = (unsigned)(e0 * jb.ergs + local) * (unsigned)Cs * tileb;
-      lubase[1] = (unsigned)(e1 * jb.ergs + local) * (unsigned)Cs * tileb;
+      ltoff = (unsigned)(e0 * jb.ergs + local) * (unsigned)Cs * tileb;
+      lubase1 = (unsigned)(e1 * jb.ergs + local) * (unsigned)Cs * tileb;
       lrow0 = u * jb.rgpu * g.R;
       lslot_row0 = sl * (jb.upe * jb.rgpu * g.R);
-      ltoff = lubase[0];
     }
   };
-  // Every request below is UNCONDITIONAL (a wave past its last tile asks for an out-of-range offset: zeros, no traffic) and every tile asks for the same number of
+  // Every request is UNCONDITIONAL (a cursor past its last tile asks for an out-of-range offset: zeros, no traffic) and every tile asks for the same number of
   // loads: hipcc's s_waitcnt insertion merges the counter state of control-flow paths conservatively, so ONE conditional load between a tile's request and its use
   // makes the wait for that tile stricter by one, and a conditional request of a whole tile (rounds 3-4) collapses every wait to vmcnt(0) -- the ring then holds one
   // tile in flight whatever its depth.  With straight-line requests the waits come out exact: vmcnt((NS - 1) x loads per tile).
   constexpr unsigned DEAD = 0xF0000000u;  // beyond every tensor (make_mat refuses tensors of 0xF0000000 bytes and more); + the tile's plane offsets: no wrap
   auto issue = [&](typename TL::Raw &slot, RecMeta &m, AuxT &ax) {
-    const bool livel = lunit >= 0 && lunit < jb.u1;
+    const bool livel = lunit < jb.u1;
     const int lrow = lrow0 - lslot_row0;  // local row inside the expert slot
     m = RecMeta{livel ? (lts | (lseg << 24)) : -1, lrow0, min(g.R, jb.nrows - lrow)};
     slot = TL::load(lseg == 0 ? rs0 : rs1, livel ? ltoff : DEAD, lane);
@@ -688,41 +616,23 @@ __device__ __forceinline__ void stream(const Job &jb, int K, int ncols_img, int 
       ltoff += tileb;
       if (++lts == Cs) { lts = 0; lrow0 += g.R; }
       if (--lleft == 0) {
-        if (lseg + 1 < jb.nseg) { lseg = 1; lleft = tps; ltoff = lubase[1]; lrow0 -= jb.rgpu * g.R; }
-        else {  // next unit from the workgroup's counter (LDS atomic: lgkmcnt, not vmcnt)
-          int nu = 0;
-          if (lane == 0) nu = atomicAdd(ctr, 1);
-          open_unit(__builtin_amdgcn_readfirstlane(nu));
-        }
+        if (lseg + 1 < jb.nseg) { lseg = 1; lleft = tps; ltoff = lubase1; lrow0 -= jb.rgpu * g.R; }
+        else open_unit(lunit + NW);
       }
     }
   };
+  open_unit(jb.u0 + wave);
+  stage(0);  // the activation row (or its image) -> registers: requested before any weights
+  MRS_TL2(jb, 0);
+  issue(ring[0], meta[0], auxv[0]);
+  stage(1);  // squares, wave sums, the prologue's workgroup barrier -- while the first tile of every wave is in flight
+  MRS_TL2(jb, 1);
 #pragma unroll
-  for (int i = 0; i < NS; ++i) meta[i] = RecMeta{-1, 0, 0};
-  if (late) {
-    stage(0);  // the activation row -> registers
-    MRS_TL2(jb, 0);
-    if (tid == 0) *ctr = jb.u0 + (NW - PW);
-    __syncthreads();
-    stage(1);  // prologue arithmetic while the other waves request weights
-    MRS_TL2(jb, 2);
-    __syncthreads();
-    MRS_TL2(jb, 3);
-    int nu = 0;
-    if (lane == 0) nu = atomicAdd(ctr, 1);
-    open_unit(__builtin_amdgcn_readfirstlane(nu));
-#pragma unroll
-    for (int i = 0; i < NS; ++i) issue(ring[i], meta[i], auxv[i]);
-  } else {
-    MRS_TL2(jb, 0);
-    __syncthreads();
-    open_unit(jb.u0 + wave - PW);
-#pragma unroll
-    for (int i = 0; i < NS; ++i) issue(ring[i], meta[i], auxv[i]);
-    MRS_TL2(jb, 1);
-    __syncthreads();
-    MRS_TL2(jb, 3);
-  }
+  for (int i = 1; i < NS; ++i) issue(ring[i], meta[i], auxv[i]);
+  stage(2);  // normalise + quantize (or copy the image) into LDS
+  MRS_TL2(jb, 2);
+  __syncthreads();
+  MRS_TL2(jb, 3);
   const Act act = act_view(smem, K, ncols_img, mode);
   // per-lane constants of the LDS operands: chunk p, quarter c
   const int pCs = p * Cs;
@@ -730,35 +640,43 @@ __device__ __forceinline__ void stream(const Job &jb, int K, int ncols_img, int 
   float acc[NCOLS];
 #pragma unroll
   for (int k = 0; k < NCOLS; ++k) acc[k] = 0.0f;
-  // ONE loop exit, at the latch: hipcc funnels every exit of a loop through the latch block, and the counter state merged there (a path that has just re-requested
-  // slot k against the path that re-requested all of them) made the header's first wait vmcnt(0) -- a full drain of the ring once per pass.  A slot without a
-  // tile skips its arithmetic but still makes its (out-of-range) requests: between the first dead slot and the end of the pass, at most 2 NS - 1 tiles' worth.
-  do {
+  auto compute = [&](int i) {  // the tile in slot i: T_sb of the lane's superblock, the chunk sum, the group's epilogue after its last tile
+    const int ts = meta[i].ts_seg & 0xffffff, seg = meta[i].ts_seg >> 24;
+    const int sb = pCs + ts;
+    const bool live = sb < g.S;  // a chunk of the last quarter may be short (or empty): its slots are zeros in memory and take no part in the sum
+    float Tm[NCOLS];
+    TermCols<TYPE, NCOLS, 0>::run(ring[i], sb, qo_lane + ts * 256, c, act, SEGCOL ? seg : 0, Tm);
 #pragma unroll
-    for (int i = 0; i < NS; ++i) {
-      if (meta[i].ts_seg >= 0) {  // wave-uniform
-        const int ts = meta[i].ts_seg & 0xffffff, seg = meta[i].ts_seg >> 24;
-        const int sb = pCs + ts;
-        const bool live = sb < g.S;  // a chunk of the last quarter may be short (or empty): its slots are zeros in memory and take no part in the sum
-        float T[NCOLS];
-        TermCols<TYPE, NCOLS, 0>::run(ring[i], sb, qo_lane + ts * 256, c, act, SEGCOL ? seg : 0, T);
+    for (int k = 0; k < NCOLS; ++k) acc[k] = ts == 0 ? (live ? Tm[k] : 0.0f) : (live ? acc[k] + Tm[k] : acc[k]);  // c_p: left to right inside the chunk
+    if (ts == Cs - 1) {
+      // the four chunk sums sit in the four quads of the row's 16 lanes (a DPP row); three row_ror:4 steps leave ((c0 + c1) + c2) + c3 in the chunk-3 quad
+      float tot[NCOLS];
 #pragma unroll
-        for (int k = 0; k < NCOLS; ++k) acc[k] = ts == 0 ? (live ? T[k] : 0.0f) : (live ? acc[k] + T[k] : acc[k]);  // c_p: left to right inside the chunk
-        if (ts == Cs - 1) {
-          // the four chunk sums sit in the four quads of the row's 16 lanes (a DPP row); three row_ror:4 steps leave ((c0 + c1) + c2) + c3 in the chunk-3 quad
-          float tot[NCOLS];
-#pragma unroll
-          for (int k = 0; k < NCOLS; ++k) {
-            float u = dppf<0x124>(acc[k]) + acc[k];
-            u = dppf<0x124>(u) + acc[k];
-            tot[k] = dppf<0x124>(u) + acc[k];
-          }
-          epi(seg, meta[i].row0, meta[i].nvalid, (meta[i].row0 / g.R) % jb.rgpu, tot, auxv[i]);
-        }
+      for (int k = 0; k < NCOLS; ++k) {
+        float u = dppf<0x124>(acc[k]) + acc[k];
+        u = dppf<0x124>(u) + acc[k];
+        tot[k] = dppf<0x124>(u) + acc[k];
       }
-      issue(ring[i], meta[i], auxv[i]);
+      epi(seg, meta[i].row0, meta[i].nvalid, (meta[i].row0 / g.R) % jb.rgpu, tot, auxv[i]);
     }
-  } while (meta[0].ts_seg >= 0);  // requests go out in order: slot 0 holds the oldest one
+  };
+  // passes whose NS re-requests are all live (one loop exit, at the latch: every exit of a loop is funnelled through the latch block by hipcc, and counter states
+  // merged there would make the header's first wait a full drain)
+  const int rest = T > NS ? T - NS : 0;  // tiles not yet requested
+  const int full = rest / NS;
+  for (int ps = 0; ps < full; ++ps) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) { compute(i); issue(ring[i], meta[i], auxv[i]); }
+  }
+  if (rest - full * NS > 0) {  // r = 1 .. NS - 1 live requests left: one more pass (its last NS - r requests are dead), then the tail
+#pragma unroll
+    for (int i = 0; i < NS; ++i) { compute(i); issue(ring[i], meta[i], auxv[i]); }
+#pragma unroll
+    for (int i = 0; i < NS; ++i) if (meta[i].ts_seg >= 0) compute(i);
+  } else {  // nothing left to request (the common case: tiles per wave are a multiple of NS for K = 4096 / 8192 shapes): the NS tiles in flight, no dead requests
+#pragma unroll
+    for (int i = 0; i < NS; ++i) if (meta[i].ts_seg >= 0) compute(i);
+  }
   MRS_TL2(jb, 14);
 }
 

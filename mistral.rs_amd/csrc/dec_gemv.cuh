@@ -46,7 +46,7 @@ __host__ __device__ constexpr int tmask_of(int type) { return type == T_Q4_K ? T
 template <int N> struct AuxV { float a[N], b[N]; };
 
 template <int NCOLS, int EPI, int TMASK>
-__device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, int *ctr) {
+__device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float *red) {
   const int tid0 = tid_opaque();
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6), lane = tid0 & 63;
   const int K = a.K;
@@ -84,14 +84,19 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, int *c
   const int mode = act_mode_for(jb.mat[0].type);
   constexpr int NCI = EPI == EPI_RESID2 ? 2 : NCOLS;  // columns of the activation image
 
-  // the activation prologue (dec_core2.cuh), run by the PW prologue waves of stream(): a pre-quantized image is copied, an f32 vector is normalised / quantized
-  SpecRegs pre;  // ONE producer (act_issue_spec): a register struct assigned from two different calls under a run-time branch is demoted to scratch memory by hipcc
+  // the activation prologue (dec_core2.cuh): a pre-quantized image is copied, an f32 vector is normalised / quantized.  ONE producer of the register set for both
+  // cases (act_issue_all): a struct assigned from two different calls under a run-time branch is demoted to scratch memory by hipcc.
+  ActRegs<MAXP> pre;
   const size_t img_bytes = act_bytes(K, NCI);
   const bool from_img = a.x_img != nullptr;
+  const void *xsrc = from_img ? a.x_img : (const void *)a.x;
+  const unsigned xbytes = from_img ? (unsigned)img_bytes : (unsigned)K * 4u;
+  const float *nw_eff = from_img ? nullptr : a.norm_w;
   auto stage = [&](int st) {
-    if (from_img) { if (st == 1) img_copy_spec(smem, a.x_img, img_bytes); }
-    else if (st == 0) pre = act_issue_spec(a.x, a.norm_w, K, wave);
-    else act_finish_spec<NCI>(smem, pre, a.x, a.ldx, a.norm_w, a.eps, K, mode, wave);
+    if (st == 0) pre = act_issue_all<MAXP>(xsrc, xbytes, nw_eff, K);
+    else if (st == 1) act_sumsq_all<NCI, MAXP>(red, pre, a.x, a.ldx, nw_eff, K);  // (an image has no norm weight: no barrier, factors 1)
+    else if (from_img) img_finish_all<MAXP>(smem, pre, a.x_img, img_bytes);
+    else act_quantize_all<NCI, MAXP>(smem, red, pre, a.x, a.ldx, a.norm_w, a.eps, K, mode);
   };
   constexpr bool AUX_RING = NCOLS <= 2;  // epilogue operands travel with the tiles (latency-bound small batches) or are loaded by the epilogue
   const int lpr = 4 * g.LPC;             // lanes per row of a record group: row rr of the group = lanes [rr * lpr, (rr + 1) * lpr), owner lane = rr * lpr + owner_off(g)
@@ -124,7 +129,7 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, int *c
         }
       }
     };
-    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, NCOLS>(jb, K, NCI, mode, smem, ctr, stage, auxf, epi); })
+    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, NCOLS>(jb, K, NCI, mode, smem, stage, auxf, epi); })
   } else if constexpr (EPI == EPI_RESID2) {
     // MoE down of the two experts of one token in one launch (the image has two columns = the two experts' activation vectors): a unit streams its rows of
     // expert sel[0] against column 0, then the same rows of expert sel[1] against column 1, and writes (out * resid_scale + w0 s0) * 1 + w1 s1 -- the two
@@ -146,7 +151,7 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, int *c
         a.out[row0 + rr] = h1 * 1.0f + sum[0] * w1;
       }
     };
-    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, 1, true>(jb, K, NCI, mode, smem, ctr, stage, auxf, epi); })
+    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, 1, true>(jb, K, NCI, mode, smem, stage, auxf, epi); })
   } else if constexpr (EPI == EPI_GLU) {
     float gsave[NCOLS];  // the gate sums of the record group until the matching up rows arrive (same unit, same lanes)
 #pragma unroll
@@ -164,7 +169,7 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, int *c
           a.out[(size_t)slot * a.slot_out_stride + (size_t)c * a.out_stride + (row - slot * a.nrows[0])] = (a.activation == 0 ? silu_engine(gsave[c]) : glu_act(gsave[c], a.activation)) * sum[c];
       }
     };
-    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, NCOLS>(jb, K, NCI, mode, smem, ctr, stage, auxf, epi); })
+    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, NCOLS>(jb, K, NCI, mode, smem, stage, auxf, epi); })
   } else {  // EPI_QKV: rows 2i, 2i + 1 of a tensor are a RoPE pair; a record group holds whole pairs (R >= 2) or a unit holds two record groups (R = 1)
     // positions and KV slots: a handful of scalars, loaded before anything else; the RoPE factors travel with the record (owner lanes of the pair's two rows)
     int posv[NCOLS], slotv[NCOLS];  // slots are block * block_size + offset of a cache that fits 32-bit indexing per layer (checked by the launcher)
@@ -237,15 +242,15 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, int *c
         }
       }
     };
-    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, NCOLS>(jb, K, NCI, mode, smem, ctr, stage, auxf, epi); })
+    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, NCOLS>(jb, K, NCI, mode, smem, stage, auxf, epi); })
   }
 }
 
 template <int NCOLS, int EPI, int TMASK = TM_ALL>
 __global__ void __launch_bounds__(NT) dec_gemv_kernel(const GemvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ int ctr;  // the workgroup's unit counter
-  gemv_phase<NCOLS, EPI, TMASK>(a, smem, &ctr);
+  __shared__ float red[8 * 8];  // RMSNorm partials: [column][wave]
+  gemv_phase<NCOLS, EPI, TMASK>(a, smem, red);
 }
 
 
