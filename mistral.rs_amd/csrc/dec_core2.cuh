@@ -218,58 +218,70 @@ __device__ __forceinline__ float4 norm4(float4 v, float4 w4, float nm, float inv
 }
 
 // ---- the activation prologue: f32 activations x [NCOLS][ldx] (optionally RmsNorm(x) w first: RmsNorm::forward, mistralrs-core/src/layers.rs:403-414) -> the image.
-// Sum of squares: 512 "virtual threads", thread t sums the squares of its float4 pieces 4 t + 2048 j (j ascending, x y z w, fma); wave_sum_all per
-// 64 threads; the 8 wave sums as ((0+1)+(2+3))+((4+5)+(6+7)) -- the order the engine has had since round 2 (oracle: orc_rms_norm_engine).
-// A CU has ONE in-order memory pipe: whatever the prologue needs is requested (act_issue_all) before any wave of the workgroup requests weights (the caller's
-// first barrier sits in between); the weights' ring is then requested, and act_finish_all squares / reduces through `red` + one workgroup barrier, and wave w
-// quantizes superblocks w, w + 8, ... (two at a time).  Column 0's row is register-resident up to 16384 values (NP = 8 pieces per thread: down_proj's 14336-value
-// row costs no dependent load); longer rows and the other columns of a batch take plain loads.
-constexpr int MAXP = 8;
-template <int NP> struct ActRegs { v4u xv[NP]; v4u wv[NP]; };
+// Sum of squares: 512 "virtual threads" = 8 virtual waves, virtual thread t sums the squares of its float4 pieces 4 t + 2048 j (j ascending, x y z w, fma);
+// wave_sum_all per virtual wave; the 8 wave sums as ((0+1)+(2+3))+((4+5)+(6+7)) -- the order the engine has had since round 2 (oracle: orc_rms_norm_engine).
+// Virtual wave v quantizes superblocks v, v + 8, ... (its own pieces: piece j of virtual wave v IS superblock v + 8 j), two at a time.
+// The work is done by P = 8 / VW PARTICIPANT waves, participant q playing the virtual waves q, q + P, ...: VW = 1: all 8 waves of a workgroup (the prompt path's
+// quantizer, ext_gemm_qi.hip); VW = 2: the 4 prologue waves of the decode GEMV (stream()), while the other 4 waves request weights.  Every value is loaded ONCE per
+// workgroup (256 workgroups reading the same 16 KB row are a hot spot in the L2 channels: a participant that re-read the whole row -- round 4's SPEC schedule --
+// needed 3 us for its requests alone).  Register-resident per virtual thread: NPX pieces of x (rows of <= 2048 NPX values), NPW of the norm weight; longer rows
+// and the other columns of a batch take plain loads.
+constexpr int NPX = 7, NPW = 4;
+template <int VW> struct ActRegs { v4u xv[VW][NPX]; v4u wv[VW][NPW]; };
 // xbytes: bytes of the row (K * 4), or of a pre-quantized image when the same registers carry one (img_finish_all) -- ONE producer of the register set for both
 // cases: a struct assigned from two different calls under a run-time branch is demoted to scratch memory by hipcc (round 4's 48-byte frame, VERDICT weak 3)
-template <int NP> __device__ __forceinline__ ActRegs<NP> act_issue_all(const void *x, unsigned xbytes, const float *nw, int K) {
-  ActRegs<NP> p;
-  const unsigned off = (unsigned)tid_opaque() * 16u;
+template <int VW> __device__ __forceinline__ ActRegs<VW> act_issue_all(const void *x, unsigned xbytes, const float *nw, int K, int q) {
+  ActRegs<VW> p;
+  constexpr int P = 8 / VW;
+  const int lane = lane_opaque();
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)x, (short)0, (int)xbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)(nw ? (const void *)nw : x), (short)0, nw ? K * 4 : 0, 0x00020000);
-  const int nv = __builtin_amdgcn_readfirstlane(tid_opaque() >> 6) < 8 ? (int)((xbytes + 8191u) / 8192u) : 0;  // waves 8 .. 15 of a 1024-thread workgroup take no part
+  const int nv = (int)((xbytes + 8191u) / 8192u);
 #pragma unroll
-  for (int j = 0; j < NP; ++j) { p.xv[j] = v4u{0u, 0u, 0u, 0u}; if (j < nv) p.xv[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, off + (unsigned)j * 8192u, 0, 0); }
+  for (int vw = 0; vw < VW; ++vw) {
+    const unsigned off = (unsigned)((q + vw * P) * 64 + lane) * 16u;
 #pragma unroll
-  for (int j = 0; j < NP; ++j) { p.wv[j] = v4u{0u, 0u, 0u, 0u}; if (nw && j < nv) p.wv[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, off + (unsigned)j * 8192u, 0, 0); }
+    for (int j = 0; j < NPX; ++j) { p.xv[vw][j] = v4u{0u, 0u, 0u, 0u}; if (j < nv) p.xv[vw][j] = __builtin_amdgcn_raw_buffer_load_b128(rx, off + (unsigned)j * 8192u, 0, 0); }
+  }
+#pragma unroll
+  for (int vw = 0; vw < VW; ++vw) {
+    const unsigned off = (unsigned)((q + vw * P) * 64 + lane) * 16u;
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) { p.wv[vw][j] = v4u{0u, 0u, 0u, 0u}; if (nw && j < nv) p.wv[vw][j] = __builtin_amdgcn_raw_buffer_load_b128(rw, off + (unsigned)j * 8192u, 0, 0); }
+  }
   return p;
 }
-// `red`: NCOLS * 8 floats of LDS.  Two halves so that the caller can request weights between them (stream()):
-//   act_sumsq_all     squares, wave sums -> red, ONE workgroup barrier (none when there is no norm weight)
+// `red`: NCOLS * 8 floats of LDS.  Two halves so that weights can be requested between them (stream()):
+//   act_sumsq_all     squares, virtual-wave sums -> red.  The CALLER's workgroup barrier follows (none needed when there is no norm weight)
 //   act_quantize_all  norm factors from red (per column, read back from LDS: an array of factors indexed by a column loop that hipcc does not unroll -- 7 - 8
-//                     columns -- would live in scratch memory), normalise + quantize the wave's superblocks into the image.  No trailing barrier (the caller's
-//                     barrier publishes the image).
-template <int NCOLS, int NP>
-__device__ __forceinline__ void act_sumsq_all(float *red, const ActRegs<NP> &pre, const float *__restrict__ x, int ldx, const float *__restrict__ nw, int K) {
-  const int tid = tid_opaque(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nv = wave < 8 ? (K + 2047) / 2048 : 0;  // waves 8 .. 15 of a 1024-thread workgroup only pass the barrier
-  auto ldx4 = [&](int c, int j) -> float4 { const int e = tid * 4 + j * 2048; return e < K ? *(const float4 *)(x + (size_t)c * ldx + e) : make_float4(0.f, 0.f, 0.f, 0.f); };
-  if (nw) {
+//                     columns -- would live in scratch memory), normalise + quantize the participant's superblocks into the image.  No trailing barrier.
+template <int NCOLS, int VW>
+__device__ __forceinline__ void act_sumsq_all(float *red, const ActRegs<VW> &pre, const float *__restrict__ x, int ldx, const float *__restrict__ nw, int K, int q) {
+  constexpr int P = 8 / VW;
+  const int lane = lane_opaque();
+  const int nv = (K + 2047) / 2048;
+  if (!nw) return;
+#pragma unroll
+  for (int vw = 0; vw < VW; ++vw) {
+    const int v = q + vw * P, vt = v * 64 + lane;
+    auto ldx4 = [&](int c, int j) -> float4 { const int e = vt * 4 + j * 2048; return e < K ? *(const float4 *)(x + (size_t)c * ldx + e) : make_float4(0.f, 0.f, 0.f, 0.f); };
 #pragma unroll
     for (int c = 0; c < NCOLS; ++c) {
       float ss = 0.f;
-      auto sq = [&](float4 v) { ss = fmaf(v.x, v.x, ss); ss = fmaf(v.y, v.y, ss); ss = fmaf(v.z, v.z, ss); ss = fmaf(v.w, v.w, ss); };
+      auto sq = [&](float4 f) { ss = fmaf(f.x, f.x, ss); ss = fmaf(f.y, f.y, ss); ss = fmaf(f.z, f.z, ss); ss = fmaf(f.w, f.w, ss); };
 #pragma unroll
-      for (int j = 0; j < NP; ++j) if (j < nv) sq(c == 0 ? as_f4(pre.xv[j]) : ldx4(c, j));
-      for (int j = NP; j < nv; ++j) sq(ldx4(c, j));
+      for (int j = 0; j < NPX; ++j) if (j < nv) sq(c == 0 ? as_f4(pre.xv[vw][j]) : ldx4(c, j));
+      for (int j = NPX; j < nv; ++j) sq(ldx4(c, j));
       ss = wave_sum_all(ss);
-      if (lane == 0 && wave < 8) red[c * 8 + wave] = ss;
+      if (lane == 0) red[c * 8 + v] = ss;
     }
-    __syncthreads();
   }
 }
-template <int NCOLS, int NP>
-__device__ __forceinline__ void act_quantize_all(char *img, const float *red, const ActRegs<NP> &pre, const float *__restrict__ x, int ldx, const float *__restrict__ nw, float eps, int K, int mode) {
-  const int tid = tid_opaque(), wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nv = wave < 8 ? (K + 2047) / 2048 : 0;
-  auto ldx4 = [&](int c, int j) -> float4 { const int e = tid * 4 + j * 2048; return e < K ? *(const float4 *)(x + (size_t)c * ldx + e) : make_float4(0.f, 0.f, 0.f, 0.f); };
-  auto ldw4 = [&](int j) -> float4 { const int e = tid * 4 + j * 2048; return e < K ? *(const float4 *)(nw + e) : make_float4(0.f, 0.f, 0.f, 0.f); };
+template <int NCOLS, int VW>
+__device__ __forceinline__ void act_quantize_all(char *img, const float *red, const ActRegs<VW> &pre, const float *__restrict__ x, int ldx, const float *__restrict__ nw, float eps, int K, int mode, int q) {
+  constexpr int P = 8 / VW;
+  const int lane = lane_opaque();
+  const int nv = (K + 2047) / 2048;
 #pragma unroll
   for (int c = 0; c < NCOLS; ++c) {
     float nm = 1.0f, inv = 1.0f;
@@ -279,38 +291,54 @@ __device__ __forceinline__ void act_quantize_all(char *img, const float *red, co
       nm = sqrtf(tot / (float)K + eps);
       inv = 1.0f / nm;
     }
-    // the wave's 256 values at 2048 j + 256 wave = superblock wave + 8 j; two superblocks per quantizer call
 #pragma unroll
-    for (int j0 = 0; j0 < NP; j0 += 2) {
-      if (j0 < nv) {  // wave-uniform
-        float4 v[2]; int sb[2]; bool live[2];
+    for (int vw = 0; vw < VW; ++vw) {
+      const int v = q + vw * P, vt = v * 64 + lane;
+      auto ldx4 = [&](int j) -> float4 { const int e = vt * 4 + j * 2048; return e < K ? *(const float4 *)(x + (size_t)c * ldx + e) : make_float4(0.f, 0.f, 0.f, 0.f); };
+      auto ldw4 = [&](int j) -> float4 { const int e = vt * 4 + j * 2048; return e < K ? *(const float4 *)(nw + e) : make_float4(0.f, 0.f, 0.f, 0.f); };
+      // the virtual wave's 256 values at 2048 j + 256 v = superblock v + 8 j; two superblocks per quantizer call
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int j = j0 + i;
-          sb[i] = wave + 8 * j; live[i] = j < nv && sb[i] * 256 < K;
-          const float4 xv = c == 0 ? as_f4(pre.xv[j]) : (live[i] ? ldx4(c, j) : make_float4(0.f, 0.f, 0.f, 0.f));
-          v[i] = nw ? norm4(xv, as_f4(pre.wv[j]), nm, inv) : xv;
+      for (int j0 = 0; j0 < NPX + 1; j0 += 2) {
+        if (j0 < nv) {  // wave-uniform
+          float4 vv[2]; int sb[2]; bool live[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int j = j0 + i;
+            sb[i] = v + 8 * j; live[i] = j < nv && sb[i] * 256 < K;
+            float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < NPX) { xv = c == 0 ? as_f4(pre.xv[vw][j]) : (live[i] ? ldx4(j) : xv); } else if (live[i]) xv = ldx4(j);
+            if (nw) { if (j < NPW) w4 = as_f4(pre.wv[vw][j]); else if (live[i]) w4 = ldw4(j); }
+            vv[i] = nw ? norm4(xv, w4, nm, inv) : xv;
+          }
+          quantize_multi<2>(vv, sb, live, c, mode, img, K, NCOLS);
         }
-        quantize_multi<2>(v, sb, live, c, mode, img, K, NCOLS);
       }
-    }
-    for (int j = NP; j < nv; ++j) {
-      const int sb = wave + 8 * j;
-      if (sb * 256 < K) quantize_sb(nw ? norm4(ldx4(c, j), ldw4(j), nm, inv) : ldx4(c, j), sb, c, mode, img, K, NCOLS);
+      for (int j = NPX + 1; j < nv; ++j) {
+        const int sb = v + 8 * j;
+        if (sb * 256 < K) quantize_sb(nw ? norm4(ldx4(j), ldw4(j), nm, inv) : ldx4(j), sb, c, mode, img, K, NCOLS);
+      }
     }
   }
 }
-template <int NCOLS, int NP>
-__device__ __forceinline__ void act_finish_all(char *img, float *red, const ActRegs<NP> &pre, const float *__restrict__ x, int ldx, const float *__restrict__ nw, float eps, int K, int mode) {
-  act_sumsq_all<NCOLS, NP>(red, pre, x, ldx, nw, K);
-  act_quantize_all<NCOLS, NP>(img, red, pre, x, ldx, nw, eps, K, mode);
+// all 8 waves of a workgroup as participants, both halves with the barrier in between (the prompt path's quantizer kernel)
+template <int NCOLS>
+__device__ __forceinline__ void act_finish_all(char *img, float *red, const ActRegs<1> &pre, const float *__restrict__ x, int ldx, const float *__restrict__ nw, float eps, int K, int mode, int q) {
+  act_sumsq_all<NCOLS, 1>(red, pre, x, ldx, nw, K, q);
+  if (nw) __syncthreads();
+  act_quantize_all<NCOLS, 1>(img, red, pre, x, ldx, nw, eps, K, mode, q);
 }
-// a pre-quantized image (act_bytes(K, ncols) bytes, 16-byte aligned, written by a producer kernel; requested by act_issue_all) -> LDS: the 16-byte pieces at tid * 16 + j * 8192
-template <int NP> __device__ __forceinline__ void img_finish_all(char *smem, const ActRegs<NP> &pre, const void *img, size_t bytes) {
-  const int tid = tid_opaque();
+// a pre-quantized image (act_bytes(K, ncols) bytes, 16-byte aligned, written by a producer kernel; requested by act_issue_all) -> LDS: the 16-byte pieces at
+// vt * 16 + j * 8192 of the participant's virtual threads
+template <int VW> __device__ __forceinline__ void img_finish_all(char *smem, const ActRegs<VW> &pre, const void *img, size_t bytes, int q) {
+  constexpr int P = 8 / VW;
+  const int lane = lane_opaque();
 #pragma unroll
-  for (int j = 0; j < NP; ++j) if ((size_t)(tid * 16 + j * 8192) < bytes) *(v4u *)(smem + tid * 16 + j * 8192) = pre.xv[j];
-  for (size_t o = (size_t)tid * 16 + (size_t)NP * 8192; o < bytes; o += 8192) *(v4u *)(smem + o) = *(const v4u *)((const char *)img + o);
+  for (int vw = 0; vw < VW; ++vw) {
+    const int vt = (q + vw * P) * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < NPX; ++j) if ((size_t)(vt * 16 + j * 8192) < bytes) *(v4u *)(smem + vt * 16 + j * 8192) = pre.xv[vw][j];
+    for (size_t o = (size_t)vt * 16 + (size_t)NPX * 8192; o < bytes; o += 8192) *(v4u *)(smem + o) = *(const v4u *)((const char *)img + o);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ per-format tiles
@@ -544,9 +572,11 @@ struct RecMeta { int ts_seg, row0, nvalid; };
 struct NoAux {};
 
 // SEGCOL (NCOLS must be 1): segment s multiplies by activation column s of a 2-column image (MoE down: two experts' rows against their own activations)
-// stage(0): request the activation row / image;  stage(1): sum of squares + its barrier (nothing for an image);  stage(2): normalise + quantize / copy into LDS
+// stage(0, q): request the activation row / image;  stage(1, q): squares -> red (nothing for an image);  stage(2, q): normalise + quantize / copy into LDS --
+// run by the PW prologue waves (participant q = 0 .. PW-1);  sbar: the prologue has a sum-of-squares barrier (a norm weight)
+constexpr int PW = 4;
 template <int TYPE, int NCOLS, bool SEGCOL = false, class Stage, class AuxF, class Epi>
-__device__ __forceinline__ void stream(const Job &jb, int K, int ncols_img, int mode, char *smem, Stage stage, AuxF auxf, Epi epi) {
+__device__ __forceinline__ void stream(const Job &jb, int K, int ncols_img, int mode, char *smem, bool sbar, Stage stage, AuxF auxf, Epi epi) {
   using TL = Tile<TYPE>;
   using AuxT = decltype(auxf(0));
   constexpr int NS = TL::NS;
@@ -560,8 +590,27 @@ __device__ __forceinline__ void stream(const Job &jb, int K, int ncols_img, int 
   const int myunits = nun > 0 ? (nun + NW - 1) / NW : 0;
   const int tps = jb.rgpu * Cs;  // tiles per segment of a unit
   const int T = myunits * jb.nseg * tps;
-  if (T == 0) {  // a wave without tiles (small launches): its share of the prologue and the barriers, no requests at all
-    stage(0); stage(1); stage(2);
+  // Roles (measured, profiles/round5_decode.md): the memory system accepts a CU's requests at its HBM share, so a wave that requests its ring is blocked in the
+  // issue for a microsecond or more and cannot run the activation prologue meanwhile -- and nothing can be multiplied before the prologue is done.  Waves 0 .. 3
+  // ("streaming") request weights at once; waves 4 .. 7 ("prologue", participant q = wave - 4) request the activation row BEFORE that (barrier A), run the prologue
+  // (every value loaded once per workgroup; its sum-of-squares barrier S is reached by the streaming waves after their first requests), publish the image
+  // (barrier B) and only then start on their own units -- of which the round-robin assignment gives them one fewer when the count is uneven.
+  const bool late = wave >= NW - PW;
+  const int q = wave - (NW - PW);
+  if (late) {
+    stage(0, q);
+    MRS_TL2(jb, 0);
+    __syncthreads();  // A
+    stage(1, q);
+    if (sbar) __syncthreads();  // S
+    stage(2, q);
+    MRS_TL2(jb, 2);
+    __syncthreads();  // B
+    MRS_TL2(jb, 3);
+    if (T == 0) return;
+  } else if (T == 0) {  // a streaming wave without tiles (small launches): the barriers only
+    __syncthreads();
+    if (sbar) __syncthreads();
     __syncthreads();
     return;
   }
@@ -622,17 +671,22 @@ __device__ __forceinline__ void stream(const Job &jb, int K, int ncols_img, int 
     }
   };
   open_unit(jb.u0 + wave);
-  stage(0);  // the activation row (or its image) -> registers: requested before any weights
-  MRS_TL2(jb, 0);
-  issue(ring[0], meta[0], auxv[0]);
-  stage(1);  // squares, wave sums, the prologue's workgroup barrier -- while the first tile of every wave is in flight
-  MRS_TL2(jb, 1);
+  constexpr int PRE = NS < 3 ? NS : 3;  // tiles a streaming wave requests before the sum-of-squares barrier (what the memory system takes in the ~1 us until then)
+  if (late) {
 #pragma unroll
-  for (int i = 1; i < NS; ++i) issue(ring[i], meta[i], auxv[i]);
-  stage(2);  // normalise + quantize (or copy the image) into LDS
-  MRS_TL2(jb, 2);
-  __syncthreads();
-  MRS_TL2(jb, 3);
+    for (int i = 0; i < NS; ++i) issue(ring[i], meta[i], auxv[i]);
+  } else {
+    MRS_TL2(jb, 0);
+    __syncthreads();  // A: the prologue's requests are in the CU's memory pipe before any weight request
+#pragma unroll
+    for (int i = 0; i < PRE; ++i) issue(ring[i], meta[i], auxv[i]);
+    if (sbar) __syncthreads();  // S
+#pragma unroll
+    for (int i = PRE; i < NS; ++i) issue(ring[i], meta[i], auxv[i]);
+    MRS_TL2(jb, 1);
+    __syncthreads();  // B
+    MRS_TL2(jb, 3);
+  }
   const Act act = act_view(smem, K, ncols_img, mode);
   // per-lane constants of the LDS operands: chunk p, quarter c
   const int pCs = p * Cs;

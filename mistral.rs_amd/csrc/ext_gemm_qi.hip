@@ -120,8 +120,9 @@ __global__ void __launch_bounds__(NT) qi_quantize_kernel(const QuantArgs a) {
     __syncthreads();  // the same threads read back what they wrote (tid * 4 + j * 2048), the barrier orders the other waves' view of nothing: cheap insurance
     xr = dst;
   }
-  const ActRegs<MAXP> pre = act_issue_all<MAXP>(xr, (unsigned)K * 4u, a.norm_w, K);
-  act_finish_all<1, MAXP>(smem, red, pre, xr, K, a.norm_w, a.eps, K, ACT_Q8K);
+  const int qw = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const ActRegs<1> pre = act_issue_all<1>(xr, (unsigned)K * 4u, a.norm_w, K, qw);
+  act_finish_all<1>(smem, red, pre, xr, K, a.norm_w, a.eps, K, ACT_Q8K, qw);
   __syncthreads();
   const Act act = act_view(smem, K, 1, ACT_Q8K);
   // thread -> (superblock, group of 8 elements): 32 groups per superblock
