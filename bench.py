@@ -333,6 +333,10 @@ def parity_leg(model, cfg, a, prefill_exact):
             cpu_toks.append(tc)
     n_cmp = len(cpu_toks)
     rnd = lambda v: [round(x, 6) for x in v]
+    try:
+        flip = first_flip_leg(model, cfg, runs["cpu"].w)
+    except Exception as e:  # reported extra
+        flip = {"error": repr(e)}
     out = {
         "greedy_match": gpu_toks[:n_cmp] == cpu_toks and n_cmp == D + 1,  # vs CPU order a (the reference's own summation orders), free-running after the shared prompt
         "greedy_match_engine_order_restatement": bool(all(ident)),  # identical logits => identical ids: the engine vs the CPU evaluation of the same arithmetic in its order
@@ -359,12 +363,55 @@ def parity_leg(model, cfg, a, prefill_exact):
             "argmax_agree_with_cpu_order_a": {"engine": int(sum(x == y for x, y in zip(ids(gl), ids(cl["cpu"])))), "cpu_order_b": int(sum(x == y for x, y in zip(ids(cl["cpu_b"]), ids(cl["cpu"])))),
                                               "of": len(gl)},
             "argmax_flips": flips[:4],
+            "first_flip": flip, "first_position_vs_cpu_order_a": flip.get("first_position_vs_cpu_order_a"), "positions_before_first_flip": flip.get("positions_before_first_flip"),
             "greedy_free_running": {"tokens_compared": n_cmp, "first_difference": next((i for i, (x, y) in enumerate(zip(gpu_toks, cpu_toks)) if x != y), None)},
             "note": "cpu order a = ggml generic 8-lane GEMV order + candle in-order rms sum + full.rs (prompt) / single_q.rs (decode, 1 kv chunk) attention; b = one f32 term per "
                     "superblock + 2 kv chunks. Orders that differ ONLY in f32 summation agree to ~1e-6 until a rounding difference moves one int8 activation quant across a "
                     "rounding step, then sit at the int8 noise floor of this random-weight model (profiles/round3_parity.md); the engine's arithmetic is pinned by the bit-identical "
                     "restatement, its validity as a sample of the reference arithmetic by vs_exact."}}
     return base, out
+
+
+def first_flip_leg(model, cfg, ref_w, positions=6):
+    """the one parity measurement that was still inferred from 2-layer models.  On THIS (32-layer) model:
+      * `first_position_vs_cpu_order_a`: a 1-token prompt -- no int8 activation quant can have moved yet between two f32 summation orders except through f32 rounding
+        itself -- on the engine and on LlamaRef(mode="cpu") (the reference's own orders): max |logit difference| / max |logit|;
+      * `positions_before_first_flip`: the oracle in the ENGINE's order (which the HIP engine equals bit for bit, checked above) and in CPU order a decode the same
+        tokens (teacher-forced on order a's greedy ids); every linear's int8 activation quants are compared, position by position: how many positions (and, inside the
+        first differing position, how many linears) pass before ONE quant differs, and how many of the quants differ there."""
+    import numpy as np
+    from mistralrs_amd.llama import rope_tables
+    from oracle import llama_ref
+    cos, sin = rope_tables(cfg)
+    nblk = (cfg.max_context_len + 31) // 32
+    ra = llama_ref.LlamaRef(cfg, ref_w, cos, sin, kv_dtype="bf16", mode="cpu")
+    re = llama_ref.LlamaRef(cfg, ref_w, cos, sin, kv_dtype="bf16", mode="engine", attn_bpw=1 if nblk <= 64 else (nblk + 63) // 64)
+    tok = 1000 % cfg.vocab_size
+    g0 = model.prefill([tok], 0).float().cpu().numpy().reshape(-1)
+    out = {}
+    first = None
+    for pos in range(positions):
+        ra.trace, re.trace = [], []
+        la = np.asarray(ra.step(tok, pos), dtype=np.float32)
+        le = np.asarray(re.step(tok, pos), dtype=np.float32)
+        if pos == 0:
+            out["first_position_vs_cpu_order_a"] = float(np.abs(g0 - la).max() / np.abs(la).max())
+            out["first_position_engine_equals_engine_order_restatement"] = bool(np.array_equal(g0, le))
+        if first is None:
+            for li, ((na, qa), (ne, qe)) in enumerate(zip(ra.trace, re.trace)):
+                nd = int((qa != qe).sum())
+                if nd:
+                    first = {"position": pos, "linears_before_it_in_that_position": li, "of_linears_per_position": len(ra.trace), "tensor": na,
+                             "quants_differing": nd, "of_quants": int(qa.size), "largest_quant_step": int(np.abs(qa.astype(np.int16) - qe.astype(np.int16)).max())}
+                    break
+        out.setdefault("per_position_vs_cpu_order_a", []).append(round(float(np.abs(le - la).max() / np.abs(la).max()), 9))
+        tok = int(la.argmax())
+    ra.trace = re.trace = None
+    out["positions_before_first_flip"] = positions if first is None else first["position"]
+    out["first_flip"] = first
+    out["what"] = ("engine-order restatement vs CPU order a on the bench model, teacher-forced on order a's ids from a 1-token prompt; per_position = max |logit difference| "
+                   "/ max |logit| (engine order vs order a); a flip = one int8 activation quant of one linear differing between the two orders")
+    return out
 
 
 def extra_config(kind, dev, steps=64, warmup=4, prompt_len=512):

@@ -296,13 +296,14 @@ __device__ __forceinline__ void act_quantize_all(char *img, const float *red, co
       const int v = q + vw * P, vt = v * 64 + lane;
       auto ldx4 = [&](int j) -> float4 { const int e = vt * 4 + j * 2048; return e < K ? *(const float4 *)(x + (size_t)c * ldx + e) : make_float4(0.f, 0.f, 0.f, 0.f); };
       auto ldw4 = [&](int j) -> float4 { const int e = vt * 4 + j * 2048; return e < K ? *(const float4 *)(nw + e) : make_float4(0.f, 0.f, 0.f, 0.f); };
-      // the virtual wave's 256 values at 2048 j + 256 v = superblock v + 8 j; two superblocks per quantizer call
+      // the virtual wave's 256 values at 2048 j + 256 v = superblock v + 8 j; FOUR superblocks per quantizer call (four interleaved reduction chains: a call is a
+      // ~150-instruction dependent chain per superblock, ~0.4 us for two -- down_proj's 7 superblocks per wave were 4 calls of two)
 #pragma unroll
-      for (int j0 = 0; j0 < NPX + 1; j0 += 2) {
+      for (int j0 = 0; j0 < NPX + 1; j0 += 4) {
         if (j0 < nv) {  // wave-uniform
-          float4 vv[2]; int sb[2]; bool live[2];
+          float4 vv[4]; int sb[4]; bool live[4];
 #pragma unroll
-          for (int i = 0; i < 2; ++i) {
+          for (int i = 0; i < 4; ++i) {
             const int j = j0 + i;
             sb[i] = v + 8 * j; live[i] = j < nv && sb[i] * 256 < K;
             float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), w4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -310,7 +311,11 @@ __device__ __forceinline__ void act_quantize_all(char *img, const float *red, co
             if (nw) { if (j < NPW) w4 = as_f4(pre.wv[vw][j]); else if (live[i]) w4 = ldw4(j); }
             vv[i] = nw ? norm4(xv, w4, nm, inv) : xv;
           }
-          quantize_multi<2>(vv, sb, live, c, mode, img, K, NCOLS);
+          if (j0 + 2 < nv) quantize_multi<4>(vv, sb, live, c, mode, img, K, NCOLS);
+          else {  // one or two live: the two-chain body
+            const float4 v2[2] = {vv[0], vv[1]}; const int s2[2] = {sb[0], sb[1]}; const bool l2[2] = {live[0], live[1]};
+            quantize_multi<2>(v2, s2, l2, c, mode, img, K, NCOLS);
+          }
         }
       }
       for (int j = NPX + 1; j < nv; ++j) {
@@ -573,10 +578,9 @@ struct NoAux {};
 
 // SEGCOL (NCOLS must be 1): segment s multiplies by activation column s of a 2-column image (MoE down: two experts' rows against their own activations)
 // stage(0, q): request the activation row / image;  stage(1, q): squares -> red (nothing for an image);  stage(2, q): normalise + quantize / copy into LDS --
-// run by the PW prologue waves (participant q = 0 .. PW-1);  sbar: the prologue has a sum-of-squares barrier (a norm weight)
-constexpr int PW = 4;
+// every wave is participant q = wave of the prologue (one virtual wave each);  sbar: the prologue has a sum-of-squares barrier (a norm weight)
 template <int TYPE, int NCOLS, bool SEGCOL = false, class Stage, class AuxF, class Epi>
-__device__ __forceinline__ void stream(const Job &jb, int K, int ncols_img, int mode, char *smem, bool sbar, Stage stage, AuxF auxf, Epi epi) {
+__device__ __forceinline__ void stream(const Job &jb, int K, int ncols_img, int mode, char *smem, int *ctr, bool sbar, Stage stage, AuxF auxf, Epi epi) {
   using TL = Tile<TYPE>;
   using AuxT = decltype(auxf(0));
   constexpr int NS = TL::NS;
@@ -590,28 +594,19 @@ __device__ __forceinline__ void stream(const Job &jb, int K, int ncols_img, int 
   const int myunits = nun > 0 ? (nun + NW - 1) / NW : 0;
   const int tps = jb.rgpu * Cs;  // tiles per segment of a unit
   const int T = myunits * jb.nseg * tps;
-  // Roles (measured, profiles/round5_decode.md): the memory system accepts a CU's requests at its HBM share, so a wave that requests its ring is blocked in the
-  // issue for a microsecond or more and cannot run the activation prologue meanwhile -- and nothing can be multiplied before the prologue is done.  Waves 0 .. 3
-  // ("streaming") request weights at once; waves 4 .. 7 ("prologue", participant q = wave - 4) request the activation row BEFORE that (barrier A), run the prologue
-  // (every value loaded once per workgroup; its sum-of-squares barrier S is reached by the streaming waves after their first requests), publish the image
-  // (barrier B) and only then start on their own units -- of which the round-robin assignment gives them one fewer when the count is uneven.
-  const bool late = wave >= NW - PW;
-  const int q = wave - (NW - PW);
-  if (late) {
-    stage(0, q);
-    MRS_TL2(jb, 0);
+  // Units are handed out by a counter in LDS when a unit is a whole number of ring passes (every K = 4096 / 8192 shape): the waves of a workgroup do not run at the
+  // same pace (the second wave of a SIMD loses the issue arbitration to the first: lm_head's waves 4 .. 7 finished 9 us after waves 0 .. 3 with equal static shares),
+  // and a wave that is ahead simply takes the next unit.  Otherwise (down_proj at K = 14336: 14 tiles per unit, one unit per wave) the share is static.
+  const int tpu = jb.nseg * tps;
+  const bool dyn = tpu % TL::NS == 0;
+  if (tid == 0) *ctr = jb.u0 + NW;  // published by barrier A
+  if (jb.u0 + wave >= jb.u1) {  // a wave without tiles (small launches): its share of the prologue and the barriers, no requests at all
+    stage(0, wave);
     __syncthreads();  // A
-    stage(1, q);
+    stage(1, wave);
     if (sbar) __syncthreads();  // S
-    stage(2, q);
-    MRS_TL2(jb, 2);
+    stage(2, wave);
     __syncthreads();  // B
-    MRS_TL2(jb, 3);
-    if (T == 0) return;
-  } else if (T == 0) {  // a streaming wave without tiles (small launches): the barriers only
-    __syncthreads();
-    if (sbar) __syncthreads();
-    __syncthreads();
     return;
   }
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void *)jb.mat[0].base, (short)0, (int)jb.mat[0].bytes, 0x00020000);
@@ -666,27 +661,28 @@ __device__ __forceinline__ void stream(const Job &jb, int K, int ncols_img, int 
       if (++lts == Cs) { lts = 0; lrow0 += g.R; }
       if (--lleft == 0) {
         if (lseg + 1 < jb.nseg) { lseg = 1; lleft = tps; ltoff = lubase1; lrow0 -= jb.rgpu * g.R; }
-        else open_unit(lunit + NW);
+        else if (dyn) {  // next unit from the workgroup's counter (LDS atomic: lgkmcnt, not vmcnt)
+          int nu = 0;
+          if (lane == 0) nu = atomicAdd(ctr, 1);
+          open_unit(__builtin_amdgcn_readfirstlane(nu));
+        } else open_unit(lunit + NW);
       }
     }
   };
   open_unit(jb.u0 + wave);
-  constexpr int PRE = NS < 3 ? NS : 3;  // tiles a streaming wave requests before the sum-of-squares barrier (what the memory system takes in the ~1 us until then)
-  if (late) {
+  stage(0, wave);  // the activation row (or its image) -> registers: requested before any weights
+  MRS_TL2(jb, 0);
+  __syncthreads();  // A (publishes the unit counter)
+  issue(ring[0], meta[0], auxv[0]);
+  stage(1, wave);  // squares, wave sums -- while the first tile of every wave is in flight
+  if (sbar) __syncthreads();  // S
+  MRS_TL2(jb, 1);
 #pragma unroll
-    for (int i = 0; i < NS; ++i) issue(ring[i], meta[i], auxv[i]);
-  } else {
-    MRS_TL2(jb, 0);
-    __syncthreads();  // A: the prologue's requests are in the CU's memory pipe before any weight request
-#pragma unroll
-    for (int i = 0; i < PRE; ++i) issue(ring[i], meta[i], auxv[i]);
-    if (sbar) __syncthreads();  // S
-#pragma unroll
-    for (int i = PRE; i < NS; ++i) issue(ring[i], meta[i], auxv[i]);
-    MRS_TL2(jb, 1);
-    __syncthreads();  // B
-    MRS_TL2(jb, 3);
-  }
+  for (int i = 1; i < NS; ++i) issue(ring[i], meta[i], auxv[i]);
+  stage(2, wave);  // normalise + quantize (or copy the image) into LDS
+  MRS_TL2(jb, 2);
+  __syncthreads();  // B
+  MRS_TL2(jb, 3);
   const Act act = act_view(smem, K, ncols_img, mode);
   // per-lane constants of the LDS operands: chunk p, quarter c
   const int pCs = p * Cs;
@@ -714,20 +710,28 @@ __device__ __forceinline__ void stream(const Job &jb, int K, int ncols_img, int 
       epi(seg, meta[i].row0, meta[i].nvalid, (meta[i].row0 / g.R) % jb.rgpu, tot, auxv[i]);
     }
   };
-  // passes whose NS re-requests are all live (one loop exit, at the latch: every exit of a loop is funnelled through the latch block by hipcc, and counter states
-  // merged there would make the header's first wait a full drain)
-  const int rest = T > NS ? T - NS : 0;  // tiles not yet requested
-  const int full = rest / NS;
-  for (int ps = 0; ps < full; ++ps) {
+  if (dyn) {
+    // a pass = NS tiles of ONE unit: its re-requests are all live or there is nothing left -- no dead requests, whatever the number of units the wave ends up with.
+    // (One loop exit, at the latch: every exit of a loop is funnelled through the latch block by hipcc, and counter states merged there would make the header's
+    // first wait a full drain.)
+    while (lunit < jb.u1) {
 #pragma unroll
-    for (int i = 0; i < NS; ++i) { compute(i); issue(ring[i], meta[i], auxv[i]); }
-  }
-  if (rest - full * NS > 0) {  // r = 1 .. NS - 1 live requests left: one more pass (its last NS - r requests are dead), then the tail
+      for (int i = 0; i < NS; ++i) { compute(i); issue(ring[i], meta[i], auxv[i]); }
+    }
 #pragma unroll
-    for (int i = 0; i < NS; ++i) { compute(i); issue(ring[i], meta[i], auxv[i]); }
+    for (int i = 0; i < NS; ++i) compute(i);  // the NS tiles in flight
+  } else {
+    // static share: passes whose NS re-requests are all live, then straight-line tails
+    const int rest = T > NS ? T - NS : 0;  // tiles not yet requested
+    const int full = rest / NS;
+    for (int ps = 0; ps < full; ++ps) {
 #pragma unroll
-    for (int i = 0; i < NS; ++i) if (meta[i].ts_seg >= 0) compute(i);
-  } else {  // nothing left to request (the common case: tiles per wave are a multiple of NS for K = 4096 / 8192 shapes): the NS tiles in flight, no dead requests
+      for (int i = 0; i < NS; ++i) { compute(i); issue(ring[i], meta[i], auxv[i]); }
+    }
+    if (rest - full * NS > 0) {  // r = 1 .. NS - 1 live requests left: one more pass (its last NS - r requests are dead), then the tail
+#pragma unroll
+      for (int i = 0; i < NS; ++i) { compute(i); issue(ring[i], meta[i], auxv[i]); }
+    }
 #pragma unroll
     for (int i = 0; i < NS; ++i) if (meta[i].ts_seg >= 0) compute(i);
   }

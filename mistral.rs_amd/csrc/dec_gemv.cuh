@@ -46,7 +46,7 @@ __host__ __device__ constexpr int tmask_of(int type) { return type == T_Q4_K ? T
 template <int N> struct AuxV { float a[N], b[N]; };
 
 template <int NCOLS, int EPI, int TMASK>
-__device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float *red) {
+__device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float *red, int *ctr) {
   const int tid0 = tid_opaque();
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6), lane = tid0 & 63;
   const int K = a.K;
@@ -84,20 +84,20 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
   const int mode = act_mode_for(jb.mat[0].type);
   constexpr int NCI = EPI == EPI_RESID2 ? 2 : NCOLS;  // columns of the activation image
 
-  // the activation prologue (dec_core2.cuh), run by the 4 prologue waves of stream() (2 virtual waves each): a pre-quantized image is copied, an f32 vector is
+  // the activation prologue (dec_core2.cuh), every wave is a participant (one virtual wave each): a pre-quantized image is copied, an f32 vector is
   // normalised / quantized.  ONE producer of the register set for both cases (act_issue_all): a struct assigned from two different calls under a run-time branch is
   // demoted to scratch memory by hipcc.
-  ActRegs<2> pre;
+  ActRegs<1> pre;
   const size_t img_bytes = act_bytes(K, NCI);
   const bool from_img = a.x_img != nullptr;
   const void *xsrc = from_img ? a.x_img : (const void *)a.x;
   const unsigned xbytes = from_img ? (unsigned)img_bytes : (unsigned)K * 4u;
   const float *nw_eff = from_img ? nullptr : a.norm_w;
   auto stage = [&](int st, int q) {
-    if (st == 0) pre = act_issue_all<2>(xsrc, xbytes, nw_eff, K, q);
-    else if (st == 1) act_sumsq_all<NCI, 2>(red, pre, a.x, a.ldx, nw_eff, K, q);  // (an image has no norm weight: nothing to do)
-    else if (from_img) img_finish_all<2>(smem, pre, a.x_img, img_bytes, q);
-    else act_quantize_all<NCI, 2>(smem, red, pre, a.x, a.ldx, a.norm_w, a.eps, K, mode, q);
+    if (st == 0) pre = act_issue_all<1>(xsrc, xbytes, nw_eff, K, q);
+    else if (st == 1) act_sumsq_all<NCI, 1>(red, pre, a.x, a.ldx, nw_eff, K, q);  // (an image has no norm weight: nothing to do)
+    else if (from_img) img_finish_all<1>(smem, pre, a.x_img, img_bytes, q);
+    else act_quantize_all<NCI, 1>(smem, red, pre, a.x, a.ldx, a.norm_w, a.eps, K, mode, q);
   };
   const bool sbar = nw_eff != nullptr;
   constexpr bool AUX_RING = NCOLS <= 2;  // epilogue operands travel with the tiles (latency-bound small batches) or are loaded by the epilogue
@@ -131,7 +131,7 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
         }
       }
     };
-    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, NCOLS>(jb, K, NCI, mode, smem, sbar, stage, auxf, epi); })
+    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, NCOLS>(jb, K, NCI, mode, smem, ctr, sbar, stage, auxf, epi); })
   } else if constexpr (EPI == EPI_RESID2) {
     // MoE down of the two experts of one token in one launch (the image has two columns = the two experts' activation vectors): a unit streams its rows of
     // expert sel[0] against column 0, then the same rows of expert sel[1] against column 1, and writes (out * resid_scale + w0 s0) * 1 + w1 s1 -- the two
@@ -153,7 +153,7 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
         a.out[row0 + rr] = h1 * 1.0f + sum[0] * w1;
       }
     };
-    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, 1, true>(jb, K, NCI, mode, smem, sbar, stage, auxf, epi); })
+    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, 1, true>(jb, K, NCI, mode, smem, ctr, sbar, stage, auxf, epi); })
   } else if constexpr (EPI == EPI_GLU) {
     float gsave[NCOLS];  // the gate sums of the record group until the matching up rows arrive (same unit, same lanes)
 #pragma unroll
@@ -171,7 +171,7 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
           a.out[(size_t)slot * a.slot_out_stride + (size_t)c * a.out_stride + (row - slot * a.nrows[0])] = (a.activation == 0 ? silu_engine(gsave[c]) : glu_act(gsave[c], a.activation)) * sum[c];
       }
     };
-    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, NCOLS>(jb, K, NCI, mode, smem, sbar, stage, auxf, epi); })
+    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, NCOLS>(jb, K, NCI, mode, smem, ctr, sbar, stage, auxf, epi); })
   } else {  // EPI_QKV: rows 2i, 2i + 1 of a tensor are a RoPE pair; a record group holds whole pairs (R >= 2) or a unit holds two record groups (R = 1)
     // positions and KV slots: a handful of scalars, loaded before anything else; the RoPE factors travel with the record (owner lanes of the pair's two rows)
     int posv[NCOLS], slotv[NCOLS];  // slots are block * block_size + offset of a cache that fits 32-bit indexing per layer (checked by the launcher)
@@ -244,7 +244,7 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
         }
       }
     };
-    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, NCOLS>(jb, K, NCI, mode, smem, sbar, stage, auxf, epi); })
+    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, NCOLS>(jb, K, NCI, mode, smem, ctr, sbar, stage, auxf, epi); })
   }
 }
 
@@ -252,7 +252,8 @@ template <int NCOLS, int EPI, int TMASK = TM_ALL>
 __global__ void __launch_bounds__(NT) dec_gemv_kernel(const GemvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ float red[8 * 8];  // RMSNorm partials: [column][wave]
-  gemv_phase<NCOLS, EPI, TMASK>(a, smem, red);
+  __shared__ int ctr;           // the workgroup's unit counter
+  gemv_phase<NCOLS, EPI, TMASK>(a, smem, red, &ctr);
 }
 
 

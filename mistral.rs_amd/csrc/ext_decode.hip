@@ -410,17 +410,38 @@ __device__ __forceinline__ unsigned long long pack_max(float v, int idx) {
   return ((unsigned long long)u << 32) | (unsigned)(0x7fffffff - idx);  // ties -> smaller index
 }
 
+// round 5: 16-byte loads, one contiguous slice per workgroup (the round-4 kernel walked the row with 4-byte strided loads from 128 workgroups: 8 us for 513 KB);
+// same packed key, same winner (largest value, lowest index), still one atomicMax per wave
 __global__ void __launch_bounds__(256) argmax_partial_kernel(const SampleArgs a) {
   const int c = blockIdx.y;
   const float *l = a.logits + (size_t)c * a.vocab;
+  const int n4 = a.vocab >> 2;
+  const int per = (n4 + gridDim.x - 1) / gridDim.x, i0 = blockIdx.x * per, i1 = min(i0 + per, n4);
   unsigned long long best = 0;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < a.vocab; i += gridDim.x * 256) {
-    const unsigned long long p = pack_max(l[i], i);
-    best = p > best ? p : best;
+  if ((((size_t)l) & 15) == 0) {
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+      const float4 v = *(const float4 *)(l + 4 * (size_t)i);
+      unsigned long long p = pack_max(v.x, 4 * i);
+      best = p > best ? p : best;
+      p = pack_max(v.y, 4 * i + 1); best = p > best ? p : best;
+      p = pack_max(v.z, 4 * i + 2); best = p > best ? p : best;
+      p = pack_max(v.w, 4 * i + 3); best = p > best ? p : best;
+    }
+  } else {
+    for (int i = 4 * i0 + threadIdx.x; i < 4 * i1; i += 256) { const unsigned long long p = pack_max(l[i], i); best = p > best ? p : best; }
   }
+  if (blockIdx.x == gridDim.x - 1)
+    for (int i = 4 * n4 + threadIdx.x; i < a.vocab; i += 256) { const unsigned long long p = pack_max(l[i], i); best = p > best ? p : best; }
 #pragma unroll
   for (int m = 32; m > 0; m >>= 1) { const unsigned long long o = __shfl_xor(best, m, 64); best = o > best ? o : best; }
-  if ((threadIdx.x & 63) == 0) atomicMax(a.scratch + c, best);
+  __shared__ unsigned long long wbest[4];
+  if ((threadIdx.x & 63) == 0) wbest[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {  // one atomic per workgroup (~12 ns each on one address)
+    unsigned long long b2 = wbest[0];
+    for (int w = 1; w < 4; ++w) b2 = wbest[w] > b2 ? wbest[w] : b2;
+    atomicMax(a.scratch + c, b2);
+  }
 }
 
 __global__ void __launch_bounds__(64) sample_advance_kernel(const SampleArgs a) {
@@ -672,7 +693,7 @@ extern "C" int mrs_sample_greedy_advance(const float *logits, int vocab, int b, 
   if (b <= 0 || b > 64) return -1;
   SampleArgs a{logits, vocab, b, next_ids, tokens_out, tokens_out_stride, step_counter, positions, context_lens, slot_mapping,
                block_tables, max_blocks, block_size, (unsigned long long *)scratch};
-  int gx = (vocab + 255) / 256; if (gx > 128) gx = 128;
+  int gx = (vocab + 2047) / 2048; if (gx > 256) gx = 256; if (gx < 1) gx = 1;  // two float4 per thread
   hipLaunchKernelGGL(argmax_partial_kernel, dim3(gx, b), dim3(256), 0, (hipStream_t)stream, a);
   hipLaunchKernelGGL(sample_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
   return 0;

@@ -44,11 +44,19 @@ class LlamaRef:
         self.attn_bpw, self.n_kv_chunks = attn_bpw, n_kv_chunks
         self.k = [[] for _ in range(cfg.num_layers)]
         self.v = [[] for _ in range(cfg.num_layers)]
+        self.trace = None  # a list: every linear() appends (tensor name, the int8 activation quants its matvec multiplies by) -- bench.py's first-flip measurement
 
     def linear(self, name: str, x: np.ndarray) -> np.ndarray:
         t, packed = self.w[name]
         n = packed.shape[0]
         k = x.shape[-1]
+        if self.trace is not None and self.mode in ("cpu", "cpu_fast", "engine"):
+            xq = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, k)
+            if t == O.Q8_0:  # Q8_0 weights take Q8_0 activation blocks (34 B: f16 d + 32 int8)
+                img = O.quantize(O.Q8_0, xq).reshape(xq.shape[0], -1, 34)[:, :, 2:]
+            else:            # K-quants take Q8_K (292 B: f32 d + 256 int8 + 16 int16 sums)
+                img = O.quantize_q8_K(xq).reshape(xq.shape[0], -1, 292)[:, :, 4:260]
+            self.trace.append((name, img.copy()))
         if self.mode == "q8_1":
             return O.matmul_q8_1(t, packed, n, k, O.quantize_q8_1(x.reshape(-1, k)))
         if self.mode == "cpu":
