@@ -203,11 +203,11 @@ def measured_traffic(model_name, quant="q4_k_m"):
     here = os.path.dirname(os.path.abspath(__file__))
     if "8B" not in model_name or quant != "q4_k_m":  # the profiled workload is the Q4_K_M model; ISQ Q8_0 streams twice the bytes
         return {"traffic": None}
-    for rel in ("profiles/round4_hbm_traffic.json", "profiles/round3_hbm_traffic.json", "profiles/round2_hbm_traffic.json"):  # newest committed pass first
+    for rel in ("profiles/round5_hbm_traffic.json", "profiles/round4_hbm_traffic.json", "profiles/round3_hbm_traffic.json", "profiles/round2_hbm_traffic.json"):  # newest committed pass first
         try:
             ks = json.load(open(os.path.join(here, rel)))["kernels"]
             # NCOLS = 1, EPI_GLU: `dec_gemv_kernel<1, 2, (bool)1, 15>` in round 4 (SPEC schedule, every format), `<1, 2, true>` in round 3, `<1, 2>` before
-            k = next(v for name, v in ks.items() if "dec_gemv_kernel<1, 2" in name.replace("(bool)1", "true").replace("(int)", ""))
+            k = next(v for name, v in ks.items() if "dec_gemv_kernel<1, 2" in name.replace("(bool)1", "true").replace("(int)", "").replace("(mrs::dec::)", ""))
         except (OSError, KeyError, ValueError, StopIteration):
             continue
         out = {"traffic": int(k["read_bytes_per_launch"] + k["write_bytes_per_launch"]), "traffic_source": rel}
@@ -215,6 +215,7 @@ def measured_traffic(model_name, quant="q4_k_m"):
             st = json.load(open(os.path.join(here, rel.replace("_hbm_traffic", "_kernel_stats"))))["kernels"]
             kk = next(v for name, v in st.items() if "dec_gemv_kernel<1, 2" in name.replace("(bool)1", "true").replace("(int)", ""))
             out["in_graph_us_per_launch"] = round(kk["avg_us"], 2)
+            out["in_graph_source"] = rel.replace("_hbm_traffic", "_kernel_stats")
         except (OSError, KeyError, ValueError, StopIteration):
             pass
         return out
@@ -707,13 +708,23 @@ def main():
                                      + "; whole prompt incl. the host read-back of the first token"},
         "device_ms_per_step": round(1e3 * dev_s / a.steps, 4),
         "step_bytes": int(step_bytes), "step_roofline_frac": round(step_bytes * (a.steps / t_all) / HBM_PEAK, 4),
+        # `frac` is the kernel INSIDE the captured decode graph (rocprofv3 kernel trace of this command, committed under profiles/: average duration, launch
+        # boundary included) when this round's profile is present; the live HIP-event figure over back-to-back launches of every layer's weights is the side field
+        # `isolated_*` (it flatters the kernel: no neighbours).  VERDICT round 4, weak 11.
         "roofline": {"bound": "hbm", "kernel": "dec_gemv_kernel<1, EPI_GLU> (decode engine gate/up phase: RMSNorm + Q8_K quantize + gate/up GEMV + SiLU*up)",
                      "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4),
                      "bytes_per_launch": int(kern_bytes), "us_per_launch": round(kern_s * 1e6, 2), **measured_traffic(name, a.quant)},
         "greedy_tokens_head": [int(t) for t in toks[a.warmup: a.warmup + 8]],
     }
-    if out["roofline"].get("in_graph_us_per_launch"):  # committed profile of this command: the kernel inside the decode graph, launch boundary included
-        out["roofline"]["in_graph_frac"] = round(kern_bytes / (out["roofline"]["in_graph_us_per_launch"] * 1e-6) / HBM_PEAK, 4)
+    rl = out["roofline"]
+    rl["isolated_us_per_launch"], rl["isolated_achieved"], rl["isolated_frac"] = rl["us_per_launch"], rl["achieved"], rl["frac"]
+    if rl.get("in_graph_us_per_launch") and "round5" in rl.get("in_graph_source", ""):  # this round's committed profile of this command
+        rl["us_per_launch"] = rl["in_graph_us_per_launch"]
+        rl["achieved"] = round(kern_bytes / (rl["in_graph_us_per_launch"] * 1e-6) / 1e9, 1)
+        rl["frac"] = rl["in_graph_frac"] = round(kern_bytes / (rl["in_graph_us_per_launch"] * 1e-6) / HBM_PEAK, 4)
+        rl["frac_source"] = "in-graph average of " + rl["in_graph_source"] + " (rocprofv3 --kernel-trace of this command); isolated_* = live HIP events over back-to-back launches"
+    else:
+        rl["frac_source"] = "live HIP events over back-to-back launches of every layer's weights (no in-graph profile of this round committed yet)"
     if ttft_bf16 is not None:
         out["prefill_bf16"] = {"tokens_per_sec": round(a.prompt_len / ttft_bf16, 1), "ttft_ms": round(1e3 * ttft_bf16, 2), "frac": round(prefill_flops / ttft_bf16 / MFMA_PEAK, 4),
                                "note": "same prompt through the selectable bf16-operand path (Llama.set_prefill_mode(0) / MRS_PREFILL_EXACT=0): faster, but its logits and KV pages are "

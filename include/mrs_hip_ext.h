@@ -43,7 +43,8 @@ int mrs_decode_norm_proj(const void *w, int type, int n, int K, const float *h, 
  * activations, mistralrs-quant/src/gguf/mod.rs:465-478): activations are quantized to Q8_K (K-quants) / Q8_0 (Q8_0 weights) inside
  * the kernels, integer block dots, f32 combination in the order "ORD-U" (one term per 256-value superblock, four runs, dec_core2.cuh) that the prompt
  * GEMM (mrs_gemm_qi) shares -- north_star's parity target.  Weights are read from a DECODE LAYOUT made once at load time from the unmodified GGUF
- * blocks (same bits; records of up to 64 superblocks, one superblock per lane; Q4_K / Q5_K sub-block scales expanded from 6 to 8 bits).  K % 256 == 0. */
+ * blocks (same bits; tiles of 16 superblocks = 4 rows x the 4 ORD-U chunks, four lanes per superblock, every plane lane-major; Q4_K / Q5_K sub-block scales expanded
+ * from 6 to 8 bits; tensors of 0xF0000000 bytes and more, and expert stacks of more than 256 experts, are refused).  K % 256 == 0. */
 typedef struct { const void *planes; int type; long long n, k; } mrs_dec_mat; /* planes: mrs_dec_repack output for a [n][k] tensor */
 int mrs_dec_supported(int ggml_type);                         /* q4_k q5_k q6_k q8_0 */
 size_t mrs_dec_repack_bytes(int ggml_type, long long n, long long k); /* 0 = unsupported type / shape */

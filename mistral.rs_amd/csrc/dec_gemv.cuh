@@ -100,7 +100,7 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
     else act_quantize_all<NCI, 1>(smem, red, pre, a.x, a.ldx, a.norm_w, a.eps, K, mode, q);
   };
   const bool sbar = nw_eff != nullptr;
-  constexpr bool AUX_RING = NCOLS <= 2;  // epilogue operands travel with the tiles (latency-bound small batches) or are loaded by the epilogue
+  constexpr bool AUX_RING = NCOLS == 1;  // epilogue operands travel with the tiles (latency-bound small batches) or are loaded by the epilogue
   const int lpr = 4 * g.LPC;             // lanes per row of a record group: row rr of the group = lanes [rr * lpr, (rr + 1) * lpr), owner lane = rr * lpr + owner_off(g)
   const int rr = lane / lpr;
   const bool own = (lane & (lpr - 1)) == owner_off(g);

@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(256) repack_kernel(const uint8_t *__restrict__
 static bool make_mat(Mat &m, const void *planes, int type, long long n, long long k) {
   if (!planes || !dec_type(type) || n <= 0 || k <= 0 || k % 256) return false;
   const size_t tb = tensor_bytes(type, n, k);
-  if (tb >= 0xffffff00ull) return false;  // one 32-bit buffer descriptor per tensor
+  if (tb >= 0xF0000000ull) return false;  // one 32-bit buffer descriptor per tensor; offsets from 0xF0000000 on are the out-of-range requests of dec_core2.cuh stream()
   m.base = (const uint8_t *)planes; m.bytes = (unsigned)tb; m.type = type; m.n = (int)n; m.k = (int)k;
   return true;
 }
@@ -377,7 +377,7 @@ extern "C" int mrs_dec_gate_up(const mrs_dec_mat_c *wg, const mrs_dec_mat_c *wu,
                                float eps, int activation, float *act_out, int ld_out, int b, void *stream) {
   GemvArgs a{};
   if (!wg || !wu || !make_mat(a.m[0], wg->planes, wg->type, wg->n, wg->k) || !make_mat(a.m[1], wu->planes, wu->type, wu->n, wu->k)) return -1;
-  if (wg->type != wu->type || wg->n != wu->n || wg->k != wu->k || n <= 0 || wg->n % n || (!expert_sel && wg->n != n)) return -1;
+  if (wg->type != wu->type || wg->n != wu->n || wg->k != wu->k || n <= 0 || wg->n % n || (!expert_sel && wg->n != n) || wg->n / n > 256) return -1;
   a.nrows[0] = a.nrows[1] = n; a.K = (int)wg->k; a.x = h; a.ldx = ldh; a.norm_w = norm_w; a.eps = eps; a.activation = activation;
   a.out = act_out; a.out_stride = ld_out; a.expert_sel = expert_sel;
   return Launch<EPI_GLU>::run(a, b, (hipStream_t)stream);
@@ -389,7 +389,7 @@ extern "C" int mrs_dec_gate_up_topk(const mrs_dec_mat_c *wg, const mrs_dec_mat_c
                                     float eps, int activation, float *act_out, int ld_out, void *stream) {
   GemvArgs a{};
   if (!wg || !wu || !expert_sel || topk < 1 || topk > 8 || !make_mat(a.m[0], wg->planes, wg->type, wg->n, wg->k) || !make_mat(a.m[1], wu->planes, wu->type, wu->n, wu->k)) return -1;
-  if (wg->type != wu->type || wg->n != wu->n || wg->k != wu->k || n <= 0 || wg->n % n) return -1;
+  if (wg->type != wu->type || wg->n != wu->n || wg->k != wu->k || n <= 0 || wg->n % n || wg->n / n > 256) return -1;
   a.nrows[0] = a.nrows[1] = n; a.K = (int)wg->k; a.x = h; a.ldx = (int)wg->k; a.norm_w = norm_w; a.eps = eps; a.activation = activation;
   a.out = act_out; a.out_stride = ld_out; a.expert_sel = expert_sel; a.slots = topk; a.slot_out_stride = ld_out;
   return Launch<EPI_GLU>::run(a, 1, (hipStream_t)stream);
@@ -400,7 +400,7 @@ extern "C" int mrs_dec_gate_up_topk(const mrs_dec_mat_c *wg, const mrs_dec_mat_c
 extern "C" int mrs_dec_proj_top2(const mrs_dec_mat_c *w, int n, const int32_t *expert_sel, const float *x, int ldx, float *out, float resid_scale,
                                  const float *acc_scale, void *stream) {
   GemvArgs a{};
-  if (!w || !expert_sel || !acc_scale || !make_mat(a.m[0], w->planes, w->type, w->n, w->k) || n <= 0 || w->n % n) return -1;
+  if (!w || !expert_sel || !acc_scale || !make_mat(a.m[0], w->planes, w->type, w->n, w->k) || n <= 0 || w->n % n || w->n / n > 256) return -1;
   a.nrows[0] = n; a.K = (int)w->k; a.x = x; a.ldx = ldx; a.out = out; a.out_stride = n; a.resid_scale = resid_scale; a.acc_scale = acc_scale;
   a.expert_sel = expert_sel;
   return Launch<EPI_RESID2>::go<1>(a, (hipStream_t)stream);
@@ -411,7 +411,7 @@ extern "C" int mrs_dec_proj_top2(const mrs_dec_mat_c *w, int n, const int32_t *e
 extern "C" int mrs_dec_proj(const mrs_dec_mat_c *w, int n, const int32_t *expert_sel, const float *x, int ldx, const float *norm_w, float eps, float *out,
                             int ld_out, int mode, float resid_scale, const float *acc_scale, int b, void *stream) {
   GemvArgs a{};
-  if (!w || !make_mat(a.m[0], w->planes, w->type, w->n, w->k) || n <= 0 || w->n % n || (!expert_sel && w->n != n)) return -1;
+  if (!w || !make_mat(a.m[0], w->planes, w->type, w->n, w->k) || n <= 0 || w->n % n || (!expert_sel && w->n != n) || w->n / n > 256) return -1;
   a.nrows[0] = n; a.K = (int)w->k; a.x = x; a.ldx = ldx; a.norm_w = norm_w; a.eps = eps; a.out = out; a.out_stride = ld_out;
   a.resid_scale = resid_scale; a.acc_scale = acc_scale; a.expert_sel = expert_sel;
   return mode ? Launch<EPI_RESID>::run(a, b, (hipStream_t)stream) : Launch<EPI_STORE>::run(a, b, (hipStream_t)stream);

