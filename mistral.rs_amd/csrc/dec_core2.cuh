@@ -579,11 +579,14 @@ struct NoAux {};
 // SEGCOL (NCOLS must be 1): segment s multiplies by activation column s of a 2-column image (MoE down: two experts' rows against their own activations)
 // stage(0, q): request the activation row / image;  stage(1, q): squares -> red (nothing for an image);  stage(2, q): normalise + quantize / copy into LDS --
 // every wave is participant q = wave of the prologue (one virtual wave each);  sbar: the prologue has a sum-of-squares barrier (a norm weight)
-template <int TYPE, int NCOLS, bool SEGCOL = false, class Stage, class AuxF, class Epi>
+// RING2: a ring of 2 tiles instead of the format's NS (4): launches in which all 8 waves of a workgroup stream (>= 8 units per workgroup) want ~37 KB per CU in
+// flight -- with 4 tiles per wave the waves are blocked in the issue of the 3 tiles behind the sum-of-squares barrier for ~1.7 us before they can quantize
+// (gate + up 16.6 -> 16.0 us); launches with 4 streaming waves (down_proj, o_proj) want the 4 (down_proj 12.8 vs 15.1 us with 2): profiles/round5_decode.md
+template <int TYPE, int NCOLS, bool SEGCOL = false, bool RING2 = false, class Stage, class AuxF, class Epi>
 __device__ __forceinline__ void stream(const Job &jb, int K, int ncols_img, int mode, char *smem, int *ctr, bool sbar, Stage stage, AuxF auxf, Epi epi) {
   using TL = Tile<TYPE>;
   using AuxT = decltype(auxf(0));
-  constexpr int NS = TL::NS;
+  constexpr int NS = (NCOLS <= 4 && !RING2) ? TL::NS : (TL::NS > 2 ? 2 : TL::NS);  // wide batches: a tile's arithmetic is NCOLS times longer, a short ring covers the same time (and fits the registers)
   const int tid = tid_opaque(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const Geo g = geo_for(K);
   const int Cs = g.Cs;
@@ -598,7 +601,7 @@ __device__ __forceinline__ void stream(const Job &jb, int K, int ncols_img, int 
   // same pace (the second wave of a SIMD loses the issue arbitration to the first: lm_head's waves 4 .. 7 finished 9 us after waves 0 .. 3 with equal static shares),
   // and a wave that is ahead simply takes the next unit.  Otherwise (down_proj at K = 14336: 14 tiles per unit, one unit per wave) the share is static.
   const int tpu = jb.nseg * tps;
-  const bool dyn = tpu % TL::NS == 0;
+  const bool dyn = tpu % NS == 0;
   if (tid == 0) *ctr = jb.u0 + NW;  // published by barrier A
   if (jb.u0 + wave >= jb.u1) {  // a wave without tiles (small launches): its share of the prologue and the barriers, no requests at all
     stage(0, wave);

@@ -45,7 +45,7 @@ __host__ __device__ constexpr int tmask_of(int type) { return type == T_Q4_K ? T
 
 template <int N> struct AuxV { float a[N], b[N]; };
 
-template <int NCOLS, int EPI, int TMASK>
+template <int NCOLS, int EPI, int TMASK, bool RING2>
 __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float *red, int *ctr) {
   const int tid0 = tid_opaque();
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6), lane = tid0 & 63;
@@ -131,7 +131,7 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
         }
       }
     };
-    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, NCOLS>(jb, K, NCI, mode, smem, ctr, sbar, stage, auxf, epi); })
+    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, NCOLS, false, RING2>(jb, K, NCI, mode, smem, ctr, sbar, stage, auxf, epi); })
   } else if constexpr (EPI == EPI_RESID2) {
     // MoE down of the two experts of one token in one launch (the image has two columns = the two experts' activation vectors): a unit streams its rows of
     // expert sel[0] against column 0, then the same rows of expert sel[1] against column 1, and writes (out * resid_scale + w0 s0) * 1 + w1 s1 -- the two
@@ -153,7 +153,7 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
         a.out[row0 + rr] = h1 * 1.0f + sum[0] * w1;
       }
     };
-    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, 1, true>(jb, K, NCI, mode, smem, ctr, sbar, stage, auxf, epi); })
+    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, 1, true, RING2>(jb, K, NCI, mode, smem, ctr, sbar, stage, auxf, epi); })
   } else if constexpr (EPI == EPI_GLU) {
     float gsave[NCOLS];  // the gate sums of the record group until the matching up rows arrive (same unit, same lanes)
 #pragma unroll
@@ -171,7 +171,7 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
           a.out[(size_t)slot * a.slot_out_stride + (size_t)c * a.out_stride + (row - slot * a.nrows[0])] = (a.activation == 0 ? silu_engine(gsave[c]) : glu_act(gsave[c], a.activation)) * sum[c];
       }
     };
-    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, NCOLS>(jb, K, NCI, mode, smem, ctr, sbar, stage, auxf, epi); })
+    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, NCOLS, false, RING2>(jb, K, NCI, mode, smem, ctr, sbar, stage, auxf, epi); })
   } else {  // EPI_QKV: rows 2i, 2i + 1 of a tensor are a RoPE pair; a record group holds whole pairs (R >= 2) or a unit holds two record groups (R = 1)
     // positions and KV slots: a handful of scalars, loaded before anything else; the RoPE factors travel with the record (owner lanes of the pair's two rows)
     int posv[NCOLS], slotv[NCOLS];  // slots are block * block_size + offset of a cache that fits 32-bit indexing per layer (checked by the launcher)
@@ -244,21 +244,21 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
         }
       }
     };
-    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, NCOLS>(jb, K, NCI, mode, smem, ctr, sbar, stage, auxf, epi); })
+    MRS_DEC_TYPE_SWITCH(jb.mat[0].type, { stream<TT, NCOLS, false, RING2>(jb, K, NCI, mode, smem, ctr, sbar, stage, auxf, epi); })
   }
 }
 
-template <int NCOLS, int EPI, int TMASK = TM_ALL>
+template <int NCOLS, int EPI, int TMASK = TM_ALL, bool RING2 = false>
 __global__ void __launch_bounds__(NT) dec_gemv_kernel(const GemvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ float red[8 * 8];  // RMSNorm partials: [column][wave]
   __shared__ int ctr;           // the workgroup's unit counter
-  gemv_phase<NCOLS, EPI, TMASK>(a, smem, red, &ctr);
+  gemv_phase<NCOLS, EPI, TMASK, RING2>(a, smem, red, &ctr);
 }
 
 
 // launch one GEMV phase with NCOLS activation columns (ext_dec_gemv.hip, one definition per NCOLS)
-template <int NCOLS> int gemv_launch(int epi, int tmask, int grid, size_t lds, const GemvArgs &a, hipStream_t s);
+template <int NCOLS> int gemv_launch(int epi, int tmask, bool ring2, int grid, size_t lds, const GemvArgs &a, hipStream_t s);
 
 }  // namespace dec
 }  // namespace mrs

@@ -281,7 +281,12 @@ template <int EPI> struct Launch {
     (void)total_bytes;
     int tmask = 0;
     for (int i = 0; i < (EPI == EPI_QKV ? 3 : 1); ++i) tmask |= tmask_of(a.m[i].type);
-    return gemv_launch<NCOLS>(EPI, tmask, grid, lds, a, s);
+    // ring depth: 2 tiles per wave when every wave of a workgroup streams (>= 8 units per workgroup), the format's 4 otherwise (dec_core2.cuh stream() RING2)
+    int total_units = 0;
+    for (int i = 0; i < (EPI == EPI_QKV ? 3 : 1); ++i) total_units += a.units[i];
+    static const int force_ring2 = [] { const char *e = getenv("MRS_DEC_RING2"); return e ? atoi(e) : -1; }();
+    const bool ring2 = force_ring2 >= 0 ? force_ring2 != 0 : total_units >= 8 * grid;
+    return gemv_launch<NCOLS>(EPI, tmask, ring2, grid, lds, a, s);
   }
   // activation columns [c0, ...) of a batched launch: every per-column pointer moves
   static GemvArgs shift_cols(GemvArgs a, int c0) {

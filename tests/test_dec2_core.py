@@ -66,3 +66,25 @@ def test_gemv_host_emulation(oracle, tname, n, k, b, norm):
                                                      ("Q6_K", 32064, 4096, 1, 1), ("Q8_0", 4096, 4096, 2, 1), ("Q5_K", 2048, 4096, 1, 0), ("Q4_K", 1024, 8192, 4, 1)])
 def test_gemv_gpu(oracle, dev, tname, n, k, b, norm):
     check(oracle, GpuBackend(dev), tname, n, k, b, norm, seed=n + k)
+
+
+def test_ring2_variant_host_emulation():
+    """The 2-tile ring (dec_core2.cuh stream() RING2: chosen at launch when a workgroup has >= 8 units, i.e. never at the row counts a CPU test can afford) forced through
+    MRS_DEC_RING2=1 in a child process (the launcher reads the variable once per process): a slice of the cases above, bit for bit."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, MRS_DEC_RING2="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", os.path.join(root, "tests", "test_dec2_core.py"), "-m", "not gpu",
+                        "-k", "test_gemv_host_emulation and (4096 or 14336 or 512)"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_ring_variants_gpu(oracle, dev):
+    """Both ring depths on the device at shapes on either side of the launcher's rule (8 units per workgroup): gate / up sized (ring 2 by rule), down sized (ring 4)."""
+    check(oracle, GpuBackend(dev), "Q4_K", 14336, 4096, 1, 1, seed=5)   # 3584 units: 14 per workgroup -> ring 2
+    check(oracle, GpuBackend(dev), "Q4_K", 4096, 14336, 1, 0, seed=6)   # 1024 units: 4 per workgroup -> ring 4
+    check(oracle, GpuBackend(dev), "Q6_K", 16384, 4096, 2, 1, seed=7)   # 16 per workgroup, two columns
