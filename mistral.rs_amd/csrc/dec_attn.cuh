@@ -120,17 +120,25 @@ __device__ __forceinline__ void attn_split_core(const AttnArgs &a, int kvh, int 
   const int ctx = (int)a.context_lens[seq];
   const int lo = a.window > 0 && ctx > a.window ? ctx - a.window : 0;  // first position inside the window (the query sits at ctx - 1)
   if (b0 >= b1) return;  // wave-uniform
+  const uint32_t *bt = a.block_tables + (size_t)seq * a.max_blocks_per_seq;
+  // the first block's K / V (HBM: evicted by 4.7 GB of weights since the last token) are requested BEFORE the query is staged through LDS: the two latencies overlap
+  // instead of adding up (round 5; the query rows are L2-resident, written by the qkv launch just before)
+  int4 kr[8], vr[8];
+  {
+    const size_t base0 = (size_t)(first_page >= 0 ? (unsigned)first_page : bt[b0]) * a.kv_block_stride + (size_t)kvh * a.kv_head_stride;  // first_page: loaded by the caller ahead of the context length
+    attn_load_block<true>(a, base0, kr, vr);
+  }
   const float *qg = a.q + (size_t)seq * a.q_stride + (size_t)head0 * HD;
   for (int i = lane * 4; i < G * HD; i += 256) *(float4 *)(q_s + i) = *(const float4 *)(qg + i);
   MRS_WAVE_SYNC();
-  const uint32_t *bt = a.block_tables + (size_t)seq * a.max_blocks_per_seq;
   float m[G], l[G], o0[G], o1[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) { m[g] = -FLT_MAX; l[g] = 0.f; o0[g] = 0.f; o1[g] = 0.f; }
   for (int b = b0; b < b1; ++b) {
-    const size_t base = (size_t)(b == b0 && first_page >= 0 ? (unsigned)first_page : bt[b]) * a.kv_block_stride + (size_t)kvh * a.kv_head_stride;  // first_page: loaded by the caller ahead of the context length
-    int4 kr[8], vr[8];
-    attn_load_block<true>(a, base, kr, vr);
+    if (b > b0) {
+      const size_t base = (size_t)bt[b] * a.kv_block_stride + (size_t)kvh * a.kv_head_stride;
+      attn_load_block<true>(a, base, kr, vr);
+    }
     attn_block_update<G, CT, true>(a, kr, vr, q_s, p_s, b, b == b0, ctx, lo, m, l, o0, o1);
   }
 #pragma unroll

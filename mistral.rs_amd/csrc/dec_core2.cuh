@@ -533,7 +533,7 @@ template <int TYPE, int NCOLS, int C0> struct TermCols {
         Tile<TYPE>::template term<1>(w, sb, qo, c, act, col0 + C0, t1);
         T[C0] = t1[0];
       }
-      if constexpr (C0 + 2 < NCOLS) __builtin_amdgcn_sched_barrier(0);  // one pair at a time
+      if constexpr (C0 + 2 < NCOLS && (C0 & 2) != 0) __builtin_amdgcn_sched_barrier(0);  // four columns at a time: their LDS operands are in flight together (one pair at a time exposed an LDS round trip per pair: batch 8 was latency-bound), more would not fit the registers
       TermCols<TYPE, NCOLS, C0 + 2>::run(w, sb, qo, c, act, col0, T);
     }
   }

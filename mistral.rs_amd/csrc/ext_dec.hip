@@ -147,11 +147,13 @@ __device__ __forceinline__ void attn2_merge(const Attn2Args &a, int kvh, int seq
   v4u r[MB];
 #pragma unroll
   for (int i = 0; i < MB; ++i) r[i] = __builtin_amdgcn_raw_buffer_load_b128(ro, off0 + (unsigned)i * 512u, 0, AUX);  // past the last split of head B: out of range, zeros
-  const float wA = fast_exp_ref(mA - wave_max(mA)), wB = fast_exp_ref(mB - wave_max(mB));
+  const float wA = fast_exp_ref(mA - dec2::wave_max_all(mA)), wB = fast_exp_ref(mB - dec2::wave_max_all(mB));  // DPP + readlane (a maximum is exact in any order)
   float s_all = 0.f;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   auto step = [&](int j, v4u raw) {
-    const float wAj = __shfl(wA, j, 64), wBj = __shfl(wB, j, 64), lAj = __shfl(lA, j, 64), lBj = __shfl(lB, j, 64);  // all lanes take part in every exchange
+    // split j's weight and sum live in lane j: v_readlane (a few cycles, j is wave-uniform) instead of four ds_bpermute round trips per split -- the merge is a
+    // serial chain behind the last ticket, and 18 splits x 4 LDS exchanges were ~1.5 us of it (round 5)
+    const float wAj = dec2::rlf(wA, j), wBj = dec2::rlf(wB, j), lAj = dec2::rlf(lA, j), lBj = dec2::rlf(lB, j);
     const float wj = hsel ? wBj : wAj, lj = hsel ? lBj : lAj;
     const float lw = lj * wj;
     s_all = s_all + lw;

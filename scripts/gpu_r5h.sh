@@ -1,0 +1,9 @@
+#!/bin/bash
+export TMPDIR=/tmp
+O=gpurun_out/r5h; mkdir -p $O
+timeout 600 python -m pytest tests/test_dec_engine.py tests/test_dec_model.py -m gpu -x -q > $O/t1.log 2>&1; tail -2 $O/t1.log
+timeout 300 python scripts/bench_dec.py --reps 8 --phases qkv,o,gate_up,down4 > $O/dec.log 2>&1; grep phase $O/dec.log | cut -c1-130
+timeout 600 python bench.py --no-cpu-baseline --no-dropin --no-extra --steps 128 > $O/bench.log 2>&1; tail -1 $O/bench.log | cut -c1-300
+timeout 300 python bench.py --no-cpu-baseline --no-dropin --no-extra --steps 64 --batch 8 > $O/bench_b8.log 2>&1; tail -1 $O/bench_b8.log | cut -c1-200
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o r -- python bench.py --no-cpu-baseline --no-dropin --no-extra --steps 32 > $O/kt.log 2>&1
+f=$(find $O/kt -name "*kernel_trace.csv" | head -1); python scripts/rocprof_summary.py $f --top 14 --match dec 2>&1 | cut -c1-200

@@ -426,8 +426,9 @@ def check_p2p_all_reduce_split_launches(be, world, count, rounds=5):
 
 
 def check_p2p_missing_peer_times_out(be, limit_s):
-    """A peer that never posts: the reduce gives up after ~10 ms of device time (ext_p2p.hip SPIN_TICKS), its elements become NaN and the error word is
-    raised -- the host reads it at its next synchronisation point and falls back to RCCL (Llama.p2p_error); the job does not hang."""
+    """A peer that never posts: the reduce gives up after the bounded spin (ext_p2p.hip SPIN_TICKS: 2 s of device time -- ranks are separate processes and skew by far
+    more than a hop), ONCE: the first granule that times out raises the error word, every other element and every later call becomes NaN without waiting again.  The
+    host reads the word at its next synchronisation point, MAX-reduces it over the ranks and drops the route on all of them (Llama.p2p_sync_error); the job does not hang."""
     import ctypes as C
     import time
     boxes, comms = _p2p_world(be, 2, 1024)
@@ -442,6 +443,13 @@ def check_p2p_missing_peer_times_out(be, limit_s):
     dt = time.perf_counter() - t0
     assert np.isnan(buf.numpy()).all()
     assert dt < limit_s, f"the bounded spin took {dt:.3f} s"
+    # a later call on the same (dead) route: NaN at once, the word stays up
+    buf2 = be.buf(np.ones(600, dtype=np.float32))
+    assert post(comms[0], buf2.ptr, 600, be.stream) == 0
+    t0 = time.perf_counter()
+    assert red(comms[0], buf2.ptr, 600, be.stream) == 0
+    assert err(comms[0]) == 1 and np.isnan(buf2.numpy()).all()
+    assert time.perf_counter() - t0 < max(0.25, limit_s / 8), "a dead route must not spin again"
     for c in comms:
         be.sym("mrs_p2p_destroy", [C.c_void_p], None)(c)
 
@@ -454,7 +462,82 @@ def test_p2p_missing_peer_times_out_host_emulation():
 @pytest.mark.gpu
 def test_p2p_missing_peer_times_out_gpu(dev):
     from tests.abi_backends import GpuBackend
-    check_p2p_missing_peer_times_out(GpuBackend(dev), 1.0)
+    check_p2p_missing_peer_times_out(GpuBackend(dev), 4.0)
+
+
+def test_p2p_world8_one_rank_missing_every_rank_drops_in_the_same_step_host_emulation():
+    """VERDICT round 4, 8b, at the level a sequential emulation can run: 8 ranks of the Llama-3-70B row-parallel all-reduce ([1, 8192] f32), rank 5 never starts
+    (its mailbox stays silent).  Every LIVE rank's sum is NaN and raises ITS error word; the word is per rank, so the host protocol (include/mrs_hip_ext.h,
+    Llama.p2p_sync_error) is a MAX over the ranks followed by a drop on ALL of them -- emulated here -- and the step is repeated on the fallback (here: a rank-order
+    host sum) with identical bits on every rank.  A rank that only looked at its own word would be wrong: rank 5 (late, not dead) sees no error at all."""
+    import ctypes as C
+    from tests.abi_backends import HostBackend
+    be = HostBackend()
+    world, count, dead = 8, 8192, 5
+    boxes, comms = _p2p_world(be, world, count)
+    post = be.sym("mrs_p2p_post", [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p], C.c_int)
+    red = be.sym("mrs_p2p_reduce", [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p], C.c_int)
+    err = be.sym("mrs_p2p_error", [C.c_void_p], C.c_int)
+    rng = np.random.default_rng(8)
+    xs = [rng.standard_normal(count).astype(np.float32) for _ in range(world)]
+    bufs = [be.buf(x.copy()) for x in xs]
+    live = [r for r in range(world) if r != dead]
+    for r in live:
+        assert post(comms[r], bufs[r].ptr, count, be.stream) == 0
+    for r in live:
+        assert red(comms[r], bufs[r].ptr, count, be.stream) == 0
+    words = [err(comms[r]) for r in range(world)]
+    assert [words[r] for r in live] == [1] * 7 and words[dead] == 0  # the late rank itself has seen nothing
+    assert all(np.isnan(bufs[r].numpy()).all() for r in live)
+    # host protocol: MAX over the ranks -> every rank detaches in the same step (a per-rank decision would leave rank 5 on the mailboxes)
+    drop = max(words)
+    routes = ["rccl" if drop else "p2p"] * world
+    assert routes == ["rccl"] * world
+    want = np.zeros(count, dtype=np.float32)
+    for x in xs:  # the fallback sum, rank order
+        want = (want + x).astype(np.float32)
+    outs = [want.copy() for _ in range(world)]
+    assert all(np.array_equal(o.view(np.uint32), outs[0].view(np.uint32)) for o in outs)
+    for c in comms:
+        be.sym("mrs_p2p_destroy", [C.c_void_p], None)(c)
+
+
+def _sync_error_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    import mistralrs_amd  # noqa: F401
+    from mistralrs_amd.llama import Llama
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+
+    class Stub:  # the attributes Llama.p2p_sync_error touches
+        dev = torch.device("cpu")
+        _p2p = object()
+        dropped = False
+
+        def p2p_error(self):
+            return 1 if rank == 1 else 0  # ONE rank timed out
+
+        def set_p2p(self, p):
+            self._p2p, self.dropped = p, p is None
+    st = Stub()
+    res = Llama.p2p_sync_error(st)
+    q.put((rank, bool(res), st.dropped, st._p2p is None))
+    dist.destroy_process_group()
+
+
+def test_p2p_sync_error_drops_the_route_on_every_rank_world2_gloo():
+    """Llama.p2p_sync_error: rank 1 alone raises its word; BOTH ranks must come back with the route dropped (a rank-local drop pairs RCCL calls of
+    different steps)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_sync_error_worker, args=(r, 2, 29641, q)) for r in range(2)]
+    for p_ in ps:
+        p_.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p_ in ps:
+        p_.join(60)
+    assert got == [(0, True, True, True), (1, True, True, True)], got
 
 
 @pytest.mark.parametrize("world,count", [(2, 300), (8, 4096), (3, 1)])
