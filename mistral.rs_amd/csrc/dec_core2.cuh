@@ -349,10 +349,13 @@ template <int VW> __device__ __forceinline__ void img_finish_all(char *smem, con
 // ------------------------------------------------------------------------------------------------ per-format tiles
 // Raw = the registers a lane holds for its QUARTER of a superblock (filled by buffer loads); term() turns the quad's four quarters into T_sb for NCOLS columns
 // (every lane of the quad ends up with the same T).  Tile layouts (byte offsets inside a tile, L = lane, s = L >> 2 = superblock slot (r * 4 + p)):
-__device__ __forceinline__ v4u ldb128(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 2); }  // aux 2 = nt: read once per token
-__device__ __forceinline__ v2u ldb64(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 2); }
-__device__ __forceinline__ unsigned ldb32(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 2); }
-__device__ __forceinline__ unsigned ldb16(__amdgpu_buffer_rsrc_t r, unsigned off) { return (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 2); }
+#ifndef MRS_DEC2_LD_AUX
+#define MRS_DEC2_LD_AUX 2  // nt: read once per token (6.8 vs 6.0 TB/s on a 430 MB stream, profiles/round5_decode.md section 2); 0 = default policy (experiments)
+#endif
+__device__ __forceinline__ v4u ldb128(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, MRS_DEC2_LD_AUX); }
+__device__ __forceinline__ v2u ldb64(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, MRS_DEC2_LD_AUX); }
+__device__ __forceinline__ unsigned ldb32(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, MRS_DEC2_LD_AUX); }
+__device__ __forceinline__ unsigned ldb16(__amdgpu_buffer_rsrc_t r, unsigned off) { return (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, off, 0, MRS_DEC2_LD_AUX); }
 __device__ __forceinline__ int byte_of(unsigned w, int i) { return (int)((w >> (8 * i)) & 0xffu); }
 __device__ __forceinline__ int sbyte_of(unsigned w, int i) { return (int)(int8_t)((w >> (8 * i)) & 0xffu); }
 
@@ -680,9 +683,18 @@ __device__ __forceinline__ void stream(const Job &jb, int K, int ncols_img, int 
   stage(1, wave);  // squares, wave sums -- while the first tile of every wave is in flight
   if (sbar) __syncthreads();  // S
   MRS_TL2(jb, 1);
+  // short launches (qkv, o_proj: a wave has at most two passes of tiles) publish the image BEFORE the rest of the ring is requested: the wave would sit ~1 us in the
+  // blocked issue of those requests first, and everybody's barrier B with it; long launches keep the order that keeps the memory pipe busy through the prologue
+  const bool image_first = T <= 2 * NS;
+  if (!image_first) {
 #pragma unroll
-  for (int i = 1; i < NS; ++i) issue(ring[i], meta[i], auxv[i]);
+    for (int i = 1; i < NS; ++i) issue(ring[i], meta[i], auxv[i]);
+  }
   stage(2, wave);  // normalise + quantize (or copy the image) into LDS
+  if (image_first) {
+#pragma unroll
+    for (int i = 1; i < NS; ++i) issue(ring[i], meta[i], auxv[i]);
+  }
   MRS_TL2(jb, 2);
   __syncthreads();  // B
   MRS_TL2(jb, 3);

@@ -196,32 +196,6 @@ class Llama {
   Workspace ws{};
   bool have_bufs = false;
   int attn2 = [] { const char *e = getenv("MRS_DEC_ATTN2"); return e ? atoi(e) : 1; }();  // decode engine attention: 1 = split kernel with the last-arriver merge + Q8_K image for o_proj (round 3, one launch), 0 = split + merge launches
-  // Weight prefetch on a side stream (round 5, profiles/round5_decode.md section 6): a decode step is a dependency chain whose fixed costs (launch boundary, entry,
-  // the quantization prologue, attention's latency chain) leave HBM idle for about half of it, and the WEIGHTS of the following launches depend on nothing.  While launch
-  // k runs, a 256-workgroup side kernel (mrs_l3_prefetch: loads that are thrown away) pulls the tensors of launch k + 1 through the 256 MiB Infinity Cache; the decode
-  // kernels then stream from the cache.  Fork / join through events, so a captured step graph holds the side kernels as parallel branches.  MRS_DEC_PREFETCH=0 disables.
-  mutable hipStream_t pf_side = nullptr;
-  mutable std::vector<hipEvent_t> pf_ev;
-  mutable size_t pf_next = 0;
-  int prefetch_on = [] { const char *e = getenv("MRS_DEC_PREFETCH"); return e ? atoi(e) : 0; }();
-  void pf_fork(hipStream_t s, std::initializer_list<const mrs_dec_mat *> mats) const {
-    if (!prefetch_on) return;
-    if (!pf_side && hipStreamCreateWithFlags(&pf_side, hipStreamNonBlocking) != hipSuccess) { const_cast<Llama *>(this)->prefetch_on = 0; return; }
-    if (pf_next >= pf_ev.size()) { hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return; pf_ev.push_back(e); }
-    hipEvent_t e = pf_ev[pf_next++];
-    hipEventRecord(e, s);
-    hipStreamWaitEvent(pf_side, e, 0);
-    for (const mrs_dec_mat *m : mats)
-      if (m && m->planes) mrs_l3_prefetch(m->planes, mrs_dec_repack_bytes(m->type, m->n, m->k), 256, nullptr, pf_side);
-  }
-  void pf_join(hipStream_t s) const {
-    if (!prefetch_on || !pf_side) return;
-    if (pf_next >= pf_ev.size()) { hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return; pf_ev.push_back(e); }
-    hipEvent_t e = pf_ev[pf_next++];
-    hipEventRecord(e, pf_side);
-    hipStreamWaitEvent(s, e, 0);
-    pf_next = 0;  // the next step (or capture) reuses the events in the same order
-  }
   void *comm = nullptr;  // RCCL communicator (ext_comm.hip) when cfg.world_size > 1
   void *p2p = nullptr;   // one-shot peer-mailbox all-reduce (ext_p2p.hip) for decode-sized messages
 
@@ -458,15 +432,11 @@ class Llama {
     const int bs = cfg.block_size, kvh = cfg.num_kv_heads;
     const int eff_max = std::min(cfg.max_blocks_per_seq * bs, cfg.max_context_len);
     if (wte->embedding_forward_raw(bufs.input_ids, b, ws.h, s)) return -1;
-    const bool pf = prefetch_on && cfg.num_experts == 0;
-    for (size_t li = 0; li < blocks.size(); ++li) {
-      const Block &bl = blocks[li];
-      if (pf) pf_fork(s, {&bl.dout});  // while qkv runs: o_proj's weights (qkv's own were pulled in behind down_proj of the layer before)
+    for (const Block &bl : blocks) {
       // rotate-half RoPE: the caller registered q / k decode planes in pair order (mrs_dec_qkv_neox; llama.py permutes the rows before the repack)
       if ((cfg.rope_interleaved ? mrs_dec_qkv : mrs_dec_qkv_neox)(&bl.dq, &bl.dk, &bl.dv, ws.h, d, bl.input_layernorm, cfg.rms_eps, ws.q, bl.key_cache, bl.value_cache,
                                                                   bufs.slot_mapping, bufs.positions, bufs.cos_table, bufs.sin_table, hd, cfg.rot_dim / 2, kvh, bs, kvd, b, s))
         return fail("mrs_dec_qkv refused the layer");
-      if (pf) pf_fork(s, {&bl.dgate, &bl.dup});  // while attention and o_proj run: gate / up (66 MB)
       if (attn2) {
         // one launch: splits + last-arriver merge; even GQA groups hand o_proj the Q8_K image of the result (Q8_0 weights take Q8_0 activations: f32 result)
         const bool want_img = bl.dout.type != 8 && (cfg.num_heads / kvh) % 2 == 0 && mrs_dec_act_image_bytes(nq, b) <= mrs_dec_proj_img_max_bytes();
@@ -515,13 +485,10 @@ class Llama {
         if (all_reduce(ws.h, (size_t)b * d, s)) return fail("moe all-reduce failed: %s", g_last_error.c_str());
         continue;
       }
-      if (pf) pf_fork(s, {&bl.ddown});  // while gate / up runs: down_proj
       if (mrs_dec_gate_up(&bl.dgate, &bl.dup, ff, nullptr, ws.h, d, bl.post_attention_layernorm, cfg.rms_eps, 0, ws.act, ff, b, s)) return fail("mrs_dec_gate_up refused");
-      if (pf && li + 1 < blocks.size()) pf_fork(s, {&blocks[li + 1].dq, &blocks[li + 1].dk, &blocks[li + 1].dv});  // while down_proj runs: the next layer's q / k / v
       if (mrs_dec_proj(&bl.ddown, d, nullptr, ws.act, ff, nullptr, 0.f, ws.h, d, 1, rs, nullptr, b, s) || all_reduce(ws.h, (size_t)b * d, s))
         return fail("down_proj failed: %s", g_last_error.c_str());
     }
-    if (pf) pf_join(s);
     if (mrs_dec_proj(&dlm_head, cfg.vocab_size, nullptr, ws.h, d, ln_f, cfg.rms_eps, bufs.logits, cfg.vocab_size, 0, 1.0f, nullptr, b, s)) return fail("lm_head refused");
     return 0;
   }

@@ -358,15 +358,6 @@ static inline hipError_t hipIpcOpenMemHandle(void **p, hipIpcMemHandle_t h, unsi
 static inline hipError_t hipIpcCloseMemHandle(void *) { return hipSuccess; }
 static inline hipError_t hipMemcpy(void *d, const void *s_, size_t n, int) { memcpy(d, s_, n); return hipSuccess; }
 static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
-/* side streams / events of the runner's weight prefetch: everything runs synchronously here */
-typedef void *hipEvent_t;
-enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
-static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s_, unsigned) { *s_ = (hipStream_t)0; return hipSuccess; }
-static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
-static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = (hipEvent_t)0; return hipSuccess; }
-static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
-static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
-static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipDeviceGetAttribute(int *v, int, int) { *v = 4; return hipSuccess; }  /* the emulated "chip": 4 CUs (persistent step: 4 workgroups) */
 #define MRS_WAVE_SYNC() hiphost::wave_sync()                           /* product code: a compiler-level wave barrier (lockstep lanes) */
 #define __builtin_amdgcn_sdot4(A, B, C, CLAMP) hiphost_sdot4((A), (B), (C))
