@@ -683,18 +683,11 @@ __device__ __forceinline__ void stream(const Job &jb, int K, int ncols_img, int 
   stage(1, wave);  // squares, wave sums -- while the first tile of every wave is in flight
   if (sbar) __syncthreads();  // S
   MRS_TL2(jb, 1);
-  // short launches (qkv, o_proj: a wave has at most two passes of tiles) publish the image BEFORE the rest of the ring is requested: the wave would sit ~1 us in the
-  // blocked issue of those requests first, and everybody's barrier B with it; long launches keep the order that keeps the memory pipe busy through the prologue
-  const bool image_first = T <= 2 * NS;
-  if (!image_first) {
+  // (publishing the image BEFORE the rest of the ring is requested -- tried for the short launches, round 5 -- made qkv 0.9 us slower in the graph: the requests that
+  // would have overlapped the quantization arithmetic then queue behind it)
 #pragma unroll
-    for (int i = 1; i < NS; ++i) issue(ring[i], meta[i], auxv[i]);
-  }
+  for (int i = 1; i < NS; ++i) issue(ring[i], meta[i], auxv[i]);
   stage(2, wave);  // normalise + quantize (or copy the image) into LDS
-  if (image_first) {
-#pragma unroll
-    for (int i = 1; i < NS; ++i) issue(ring[i], meta[i], auxv[i]);
-  }
   MRS_TL2(jb, 2);
   __syncthreads();  // B
   MRS_TL2(jb, 3);

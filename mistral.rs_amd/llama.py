@@ -266,7 +266,7 @@ class Llama:
             return False
         import torch
         import torch.distributed as dist
-        bad = torch.tensor([int(self.p2p_error() != 0)], device=self.dev if hasattr(self, "dev") else "cuda")
+        bad = torch.tensor([int(self.p2p_error() != 0)], device=getattr(self, "device", None) or getattr(self, "dev", "cuda"))
         if dist.is_available() and dist.is_initialized():
             if bad.device.type == "cpu" or dist.get_backend(group) == "gloo":
                 bad = bad.cpu()

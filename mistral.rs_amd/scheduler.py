@@ -304,6 +304,13 @@ class PagedEngine:
         if len(seq.generated) >= seq.max_new_tokens or len(seq.tokens) >= self.cfg.max_context_len:
             seq.state = DONE
 
+    def _p2p_guard(self) -> None:
+        """Tensor parallel: before tokens are handed out, the per-rank error word of the peer-mailbox all-reduce is MAX-reduced over the ranks (Llama.p2p_sync_error);
+        a timed-out sum is NaN, so the step is not usable -- the route has been dropped on every rank, the caller re-runs the request on RCCL."""
+        f = getattr(self.m, "p2p_sync_error", None)
+        if f is not None and f():
+            raise RuntimeError("p2p all-reduce timed out during this step: the route has been dropped on every rank (RCCL from now on); re-schedule the step")
+
     def step(self) -> str:
         out = self.s.schedule()
         self.steps["preemptions"] += len(out.preempted)
@@ -319,6 +326,7 @@ class PagedEngine:
                     self.m.block_tables[: len(ids)] = table
                     self.m.set_state(ids, list(range(i, i + len(ids))))
                     last = self.m.forward_logits(len(ids))[len(ids) - 1]
+                self._p2p_guard()
                 seq.num_computed_tokens = b
                 if b == len(seq):  # the prompt's last token produced the first new token (llama.rs:514-517: logits of the last position only)
                     seq.state = RUNNING_COMPLETION
@@ -332,6 +340,7 @@ class PagedEngine:
                     self.m.block_tables[i] = self._table(seq)
                 self.m.set_state([s.tokens[-1] for s in rows], [len(s) - 1 for s in rows])
                 logits = self.m.forward_logits(len(rows)).clone()
+                self._p2p_guard()
                 for i, seq in enumerate(rows):
                     seq.num_computed_tokens = len(seq)
                     self._finish_token(seq, logits[i])
