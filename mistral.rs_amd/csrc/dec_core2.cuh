@@ -564,7 +564,6 @@ struct Job {
   int nseg, rgpu;
   int nrows;            // rows per tensor (per expert slot) that take part
   int u0, u1;           // this workgroup's units
-  int ring;             // unused (the ring depth is the format's NS: a run-time depth would put a branch around every request)
   const int32_t *sel;   // stacked experts [E * rows][K]: device array of expert ids per slot, or nullptr (dense)
   int sel_mode;         // 1: slot = unit / upe (all top-k experts of a token in one launch; upe = every unit when there is one slot);  2: slot = segment
   int upe;              // units per expert slot

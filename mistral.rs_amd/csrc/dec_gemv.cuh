@@ -26,7 +26,6 @@ struct GemvArgs {
   int slots, slot_out_stride; // GLU with several experts of ONE token in a launch (MoE top-k): row r of the launch -> slot r / nrows[0], output out + slot * slot_out_stride
   const void *x_img;          // activations already quantized by the producer (dec_attn2_kernel): the LDS image of NCOLS columns, byte for byte
   int units[3], rgpu;         // units of the launch (per tensor for QKV) and record groups per unit
-  int ring;                   // ring depth of the launch (Job::ring)
   unsigned long long *tl;
 };
 
@@ -68,7 +67,7 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
   const int nwg = wge - wgb, wi = bx - wgb;
   Job jb{};
   jb.nseg = (EPI == EPI_GLU || EPI == EPI_RESID2) ? 2 : 1;
-  jb.rgpu = a.rgpu; jb.ring = a.ring;
+  jb.rgpu = a.rgpu;
   jb.mat[0].base = mi == 0 ? b0 : (mi == 1 ? b1 : b2);
   jb.mat[0].bytes = mi == 0 ? by0 : (mi == 1 ? by1 : by2);
   jb.mat[0].type = mi == 0 ? ty0 : (mi == 1 ? ty1 : ty2);

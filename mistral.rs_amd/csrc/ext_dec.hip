@@ -250,7 +250,6 @@ template <int EPI> struct Launch {
     a.tl = g_tl_buf;
     a.rgpu = EPI == EPI_QKV && g.R < 2 ? 2 : 1;
     const int upr = g.R * a.rgpu;  // rows per unit
-    size_t total_bytes = 0;
     int grid = 0;
     if (EPI == EPI_QKV) {
       // workgroups per tensor in proportion to its bytes (a workgroup streams one tensor), at least one each
@@ -260,7 +259,6 @@ template <int EPI> struct Launch {
         a.units[i] = a.nrows[i] / upr;
         bytes[i] = (double)a.units[i] * a.rgpu * g.TPC * (double)rec_bytes(a.m[i].type, g); tot += bytes[i]; want += a.units[i];
       }
-      total_bytes = (size_t)tot;
       const int G = want < 256 ? want : 256;
       int wgs[3], used = 0;
       for (int i = 0; i < 3; ++i) { wgs[i] = std::max(1, std::min(a.units[i], (int)(G * bytes[i] / tot + 0.5))); used += wgs[i]; }
@@ -273,14 +271,10 @@ template <int EPI> struct Launch {
       const int upe = (a.nrows[0] + upr - 1) / upr;
       a.units[0] = upe * slots;
       grid = a.units[0] < 256 ? a.units[0] : 256;
-      total_bytes = (size_t)a.units[0] * (EPI == EPI_GLU || EPI == EPI_RESID2 ? 2 : 1) * g.TPC * rec_bytes(a.m[0].type, g);
     }
     if (grid < 1) return -1;
     size_t lds = (act_bytes(a.K, NCI) + 15) & ~(size_t)15;
     if (lds > 158 * 1024) return -2;
-    // ring depth (Job::ring): 0 = the format's full register ring (dec_core2.cuh Tile<>::NS); MRS_DEC_RING overrides (measurements)
-    { static const int force = [] { const char *e = getenv("MRS_DEC_RING"); return e ? atoi(e) : 0; }(); a.ring = force > 0 ? force : 0; }
-    (void)total_bytes;
     int tmask = 0;
     for (int i = 0; i < (EPI == EPI_QKV ? 3 : 1); ++i) tmask |= tmask_of(a.m[i].type);
     // ring depth: 2 tiles per wave when every wave of a workgroup streams (>= 8 units per workgroup), the format's 4 otherwise (dec_core2.cuh stream() RING2)
