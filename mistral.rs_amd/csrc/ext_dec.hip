@@ -225,7 +225,15 @@ __global__ void __launch_bounds__(64 * G) dec_attn2_kernel(const Attn2Args a) {
     MRS_WAIT_VMCNT0();  // this wave's partials have left the CU
     __syncthreads();
     unsigned *tk = a.ticket + (size_t)seq * t.num_kv_heads + kvh;
-    if (tid == 0) last_s = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(ns - 1);  // release our partials, acquire the others' (advisor, round 3)
+    // The ticket's ordering is a build-time choice (MRS_DEC_ATTN_TICKET_ORDER, default __ATOMIC_RELAXED since round 5).  The hand-off is the guide's R1 form
+    // (MI355X_MICROARCH.md, "Valid forms": sc1 write-through payload stores -> drained vmcnt(0) -> agent-scope flag; consumer: returned atomic -> sc1 loads, which never
+    // read the CU's L1): the payload is already in memory when the ticket is drawn, and the merge reads it past L1.  An ACQ_REL ticket (rounds 3-4) adds
+    // `buffer_wbl2 sc1` + `buffer_inv sc1` around the atomic in EVERY workgroup -- ~1.7 us each by the guide's price list, on the serial chain of the last arriver --
+    // and orders nothing this protocol relies on (no dirty lines to write back, no L1-served load to invalidate for).
+#ifndef MRS_DEC_ATTN_TICKET_ORDER
+#define MRS_DEC_ATTN_TICKET_ORDER __ATOMIC_RELAXED
+#endif
+    if (tid == 0) last_s = __hip_atomic_fetch_add(tk, 1u, MRS_DEC_ATTN_TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(ns - 1);
     __syncthreads();
     if (!last_s) return;
     if (tid == 0) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every other workgroup of this (seq, kv head) has already drawn

@@ -23,6 +23,10 @@ class _HostBuf:
     def fill(self, v):
         self.a[...] = v
 
+    def write(self, a):
+        """in-place upload: same address, new contents"""
+        self.a[...] = np.asarray(a).reshape(self.a.shape)
+
 
 class HostBackend:
     name = "host-emulation"
@@ -72,6 +76,11 @@ class _GpuBuf:
 
     def fill(self, v):
         self.t.fill_(v)
+
+    def write(self, a):
+        """in-place upload: same address, new contents"""
+        import torch
+        self.t.copy_(torch.from_numpy(np.ascontiguousarray(a)).reshape(self.t.shape).to(self.t.dtype))
 
 
 class GpuBackend:

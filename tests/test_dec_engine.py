@@ -306,6 +306,50 @@ def test_fused_attention_gpu(oracle, dev, heads, kvh, ctxs, max_ctx, kvd):
     check_attention(oracle, GpuBackend(dev), heads, kvh, ctxs, max_ctx, kvd, n_out=256)
 
 
+def check_attention_handoff_reuse(O, be, iters, heads=32, kvh=8, ctx=700, max_ctx=832):
+    """The split -> last-arriver hand-off inside mrs_dec_attention under the conditions that expose a stale read: the SAME partial buffers, ticket, image and output for
+    `iters` consecutive calls, a NEW query (hence new partials at the same addresses) every call, the merging workgroup's caches warm from the call before.  Every call
+    must equal the engine-order restatement bit for bit (the ticket is a relaxed agent-scope atomic since round 5: sc1 payload -> drained -> flag, sc1 loads in the merge)."""
+    hd, bs = 128, 32
+    nq = heads * hd
+    rng = np.random.default_rng(99)
+    mbs = (max_ctx + bs - 1) // bs
+    nblocks = mbs + 1
+    kc_np = O.to_bf16_bits((rng.standard_normal((nblocks, kvh, hd // 8, bs, 8)) * 0.7).astype(np.float32))
+    vc_np = O.to_bf16_bits(rng.standard_normal((nblocks, kvh, hd, bs)).astype(np.float32))
+    bt_np = rng.permutation(nblocks - 1)[:mbs].reshape(1, mbs).astype(np.uint32) + 1
+    kc, vc, bt = be.buf(kc_np), be.buf(vc_np), be.buf(bt_np)
+    cl = be.buf(np.asarray([ctx], dtype=np.uint32))
+    splits = be.sym("mrs_decode_attention_max_splits", [C.c_int], C.c_int)(max_ctx)
+    po, pm, pl = be.buf(np.zeros((1, heads, splits, hd), np.float32)), be.buf(np.zeros((1, heads, splits), np.float32)), be.buf(np.zeros((1, heads, splits), np.float32))
+    ticket = be.buf(np.zeros(kvh, np.uint32))
+    nimg = be.sym("mrs_dec_act_image_bytes", [C.c_int, C.c_int], C.c_size_t)(nq, 1)
+    img, got = be.buf(np.zeros(nimg, np.uint8)), be.buf(np.full((1, nq), np.nan, np.float32))
+    fn = be.sym("mrs_dec_attention", ATTN2, C.c_int)
+    scale = np.float32(1.0 / np.sqrt(np.float32(hd)))
+    k, v = _gather_kv(kc_np, vc_np, bt_np[0], ctx, O.from_bf16_bits)
+    q = be.buf(np.zeros((1, nq), np.float32))
+    for it in range(iters):
+        q_np = (rng.standard_normal((1, nq)) * (0.5 + 0.1 * (it % 5))).astype(np.float32)
+        q.write(q_np)
+        rc = fn(got.ptr, img.ptr, ticket.ptr, po.ptr, pm.ptr, pl.ptr, q.ptr, kc.ptr, vc.ptr, kvh, scale, bt.ptr, cl.ptr, bs, max_ctx, 1, heads, hd, mbs, nq, kvh * hd * bs,
+                hd * bs, 1, 0, be.stream)
+        assert rc == 1
+        res = got.numpy()
+        eng = O.attention_engine(q_np[0].reshape(heads, hd), k, v, scale, 1, 0)
+        assert np.array_equal(res[0].reshape(heads, hd), eng), ("stale hand-off?", it, float(np.abs(res[0].reshape(heads, hd) - eng).max()))
+        assert not ticket.numpy().any()
+
+
+def test_attention_handoff_reuse_host_emulation(oracle):
+    check_attention_handoff_reuse(oracle, HostBackend(), 3, heads=8, kvh=2, ctx=200, max_ctx=224)
+
+
+@pytest.mark.gpu
+def test_attention_handoff_reuse_gpu(oracle, dev):
+    check_attention_handoff_reuse(oracle, GpuBackend(dev), 80)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("heads,kvh,ctxs,max_ctx,kvd", [(32, 8, [4000, 70], 4096, 1), (32, 32, [300], 512, 1), (8, 1, [2047], 2048, 0), (32, 8, [768] * 8, 1024, 1)])
 def test_attention_more_shapes_gpu(oracle, dev, heads, kvh, ctxs, max_ctx, kvd):
