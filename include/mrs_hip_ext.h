@@ -84,6 +84,15 @@ int mrs_dec_attention(float *out_f32, void *img_out, unsigned *ticket, float *pa
 size_t mrs_dec_proj_img_max_bytes(void); /* largest activation image mrs_dec_proj_img takes (the LDS budget) */
 /* GEMV on a pre-quantized activation image (K-quant weights only) */
 int mrs_dec_proj_img(const mrs_dec_mat *w, int n, const void *x_img, float *out, int ld_out, int mode, float resid_scale, int b, void *stream);
+/* Batched decode (b = 2..8): the activation image built ONCE per phase instead of by each of the 256 GEMV workgroups.  mrs_dec_act_image: x [b][ldx] f32
+ * (-> RmsNorm when norm_w) -> img_out (16-byte aligned, mrs_dec_act_image_bytes(k, b) bytes: one image per column group that fits LDS) for weights of type
+ * `weight_type` (K-quants: Q8_K quantization, Q8_0: Q8_0 -- BlockQ8K::from_float / quantize_row_q8_0 as in the GEMV prologue, same bytes); the *_img entry
+ * points are mrs_dec_qkv / mrs_dec_qkv_neox (neox != 0) / mrs_dec_gate_up (dense) / mrs_dec_proj on such an image: bit-identical results. */
+int mrs_dec_act_image(const float *x, int ldx, const float *norm_w, float eps, int k, int weight_type, int b, void *img_out, void *stream);
+int mrs_dec_qkv_img(const mrs_dec_mat *wq, const mrs_dec_mat *wk, const mrs_dec_mat *wv, const void *x_img, float *q_out, void *k_cache, void *v_cache,
+                    const int64_t *slot_mapping, const int32_t *positions, const float *cos_t, const float *sin_t, int head_dim, int rot_pairs,
+                    int num_kv_heads, int block_size, int kv_dtype, int b, int neox, void *stream);
+int mrs_dec_gate_up_img(const mrs_dec_mat *wg, const mrs_dec_mat *wu, int n, const void *x_img, int activation, float *act_out, int ld_out, int b, void *stream);
 /* Fused HQQ dequant-GEMV for decode (ext_hqq_gemv.hip): out [b][ldo] = x [b][ldx] . W^T (+ bias) straight from the packed 4-bit / 8-bit HQQ tensor (group 64, axis 0),
  * b <= 8; dtype 0 = f32, 1 = f16, 2 = bf16 for x / scale / zero / bias / out.  Role: HqqLayer::forward_raw (hqq/mod.rs:1092-1100,1163-1171) without materialising
  * dequantize_w(); the dequantized values are bit-identical to dequantize_{4,8}bit_u8_kernel_*.  -1 = outside the fused kernel (keep dequantize + dense matmul). */

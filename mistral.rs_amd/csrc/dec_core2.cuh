@@ -278,7 +278,8 @@ __device__ __forceinline__ void act_sumsq_all(float *red, const ActRegs<VW> &pre
   }
 }
 template <int NCOLS, int VW>
-__device__ __forceinline__ void act_quantize_all(char *img, const float *red, const ActRegs<VW> &pre, const float *__restrict__ x, int ldx, const float *__restrict__ nw, float eps, int K, int mode, int q) {
+__device__ __forceinline__ void act_quantize_all(char *img, const float *red, const ActRegs<VW> &pre, const float *__restrict__ x, int ldx, const float *__restrict__ nw, float eps, int K, int mode, int q,
+                                                 int c0 = 0, int ncols_img = NCOLS) {  // column c of x -> column c0 + c of an image of ncols_img columns (dec_act_image_kernel: one workgroup per column)
   constexpr int P = 8 / VW;
   const int lane = lane_opaque();
   const int nv = (K + 2047) / 2048;
@@ -311,16 +312,16 @@ __device__ __forceinline__ void act_quantize_all(char *img, const float *red, co
             if (nw) { if (j < NPW) w4 = as_f4(pre.wv[vw][j]); else if (live[i]) w4 = ldw4(j); }
             vv[i] = nw ? norm4(xv, w4, nm, inv) : xv;
           }
-          if (j0 + 2 < nv) quantize_multi<4>(vv, sb, live, c, mode, img, K, NCOLS);
+          if (j0 + 2 < nv) quantize_multi<4>(vv, sb, live, c0 + c, mode, img, K, ncols_img);
           else {  // one or two live: the two-chain body
             const float4 v2[2] = {vv[0], vv[1]}; const int s2[2] = {sb[0], sb[1]}; const bool l2[2] = {live[0], live[1]};
-            quantize_multi<2>(v2, s2, l2, c, mode, img, K, NCOLS);
+            quantize_multi<2>(v2, s2, l2, c0 + c, mode, img, K, ncols_img);
           }
         }
       }
       for (int j = NPX + 1; j < nv; ++j) {
         const int sb = v + 8 * j;
-        if (sb * 256 < K) quantize_sb(nw ? norm4(ldx4(j), ldw4(j), nm, inv) : ldx4(j), sb, c, mode, img, K, NCOLS);
+        if (sb * 256 < K) quantize_sb(nw ? norm4(ldx4(j), ldw4(j), nm, inv) : ldx4(j), sb, c0 + c, mode, img, K, ncols_img);
       }
     }
   }

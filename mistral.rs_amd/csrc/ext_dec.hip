@@ -249,6 +249,34 @@ __global__ void __launch_bounds__(64 * ((G + 1) / 2)) dec_attn2_merge_kernel(con
 }
 
 
+// ------------------------------------------------------------------------------------------------ the activation image as its own launch (batched decode)
+// A GEMV workgroup builds the image of ALL activation columns before it streams: at 8 columns that is 16 (K = 4096) to 28 (K = 14336, 4 columns per launch)
+// superblocks per wave, 256 times over -- 17-25 us of a 40-60 us launch (rocprofv3, round 5).  dec_act_image_kernel builds it ONCE, one workgroup per column
+// with the GEMV prologue's own functions (same virtual waves, same bytes), in column groups that each fit LDS (Launch::run's halving); the GEMV then copies its
+// group's image (GemvArgs::x_img, like o_proj after mrs_dec_attention).
+struct ActImgArgs {
+  const float *x; int ldx; const float *norm_w; float eps; int K, mode;
+  char *img;
+  int gc0[8], gn[8];  // per column: first column and size of its group (the group's image starts at act_bytes(K, gc0))
+};
+__global__ void __launch_bounds__(NT) dec_act_image_kernel(const ActImgArgs a) {
+  __shared__ float red[8];
+  const int tid = tid_opaque(), wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = (int)blockIdx.x;
+  const float *x = a.x + (size_t)c * a.ldx;
+  const ActRegs<1> pre = act_issue_all<1>(x, (unsigned)a.K * 4u, a.norm_w, a.K, wave);
+  act_sumsq_all<1, 1>(red, pre, x, a.ldx, a.norm_w, a.K, wave);
+  if (a.norm_w) __syncthreads();
+  const int c0 = a.gc0[c], n = a.gn[c];
+  act_quantize_all<1, 1>(a.img + act_bytes(a.K, c0), red, pre, x, a.ldx, a.norm_w, a.eps, a.K, a.mode, wave, c - c0, n);
+}
+// the column groups of a batch of b columns of K values: halved until a group's image fits LDS (the same recursion as Launch::run)
+constexpr size_t LDS_IMG_MAX = (size_t)158 * 1024;
+static void col_groups(int K, int c0, int b, int *gc0, int *gn) {
+  if (b > 1 && act_bytes(K, b) > LDS_IMG_MAX) { col_groups(K, c0, b / 2, gc0, gn); col_groups(K, c0 + b / 2, b - b / 2, gc0, gn); return; }
+  for (int c = c0; c < c0 + b; ++c) { gc0[c] = c0; gn[c] = b; }
+}
+
 // ------------------------------------------------------------------------------------------------ launch
 static unsigned long long *g_tl_buf = nullptr;
 template <int EPI> struct Launch {
@@ -282,7 +310,7 @@ template <int EPI> struct Launch {
     }
     if (grid < 1) return -1;
     size_t lds = (act_bytes(a.K, NCI) + 15) & ~(size_t)15;
-    if (lds > 158 * 1024) return -2;
+    if (lds > LDS_IMG_MAX) return -2;
     int tmask = 0;
     for (int i = 0; i < (EPI == EPI_QKV ? 3 : 1); ++i) tmask |= tmask_of(a.m[i].type);
     // ring depth: 2 tiles per wave when every wave of a workgroup streams (>= 8 units per workgroup), the format's 4 otherwise (dec_core2.cuh stream() RING2)
@@ -299,12 +327,13 @@ template <int EPI> struct Launch {
     if (a.q_out) a.q_out += (size_t)c0 * a.nrows[0];
     if (a.positions) a.positions += c0;
     if (a.slot_mapping) a.slot_mapping += c0;
+    if (a.x_img) a.x_img = (const char *)a.x_img + act_bytes(a.K, c0);  // (mrs_dec_act_image writes one image per column group: col_groups)
     return a;
   }
   static int run(const GemvArgs &a, int b, hipStream_t s) {
     // the activation image of all columns must fit LDS (1.39 K bytes per column): wider batches run as column groups, each a launch of its own
     // (Llama-3-70B down_proj, K = 28672: 4 columns per launch)
-    if (b > 1 && !a.x_img && act_bytes(a.K, b) > 158 * 1024) {
+    if (b > 1 && act_bytes(a.K, b) > LDS_IMG_MAX) {
       const int half = b / 2;
       const int rc = run(a, half, s);
       return rc ? rc : run(shift_cols(a, half), b - half, s);
@@ -349,9 +378,11 @@ extern "C" int mrs_dec_repack(const void *gguf_blocks, int type, long long n, lo
 // k / v into the paged cache (kv_dtype 1 = bf16, 0 = f16).  All three tensors must share the activation format (K-quants or Q8_0).
 static int dec_qkv_impl(const mrs_dec_mat_c *wq, const mrs_dec_mat_c *wk, const mrs_dec_mat_c *wv, const float *h, int ldh, const float *norm_w, float eps,
                         float *q_out, void *k_cache, void *v_cache, const int64_t *slot_mapping, const int32_t *positions, const float *cos_t,
-                        const float *sin_t, int head_dim, int rot_pairs, int num_kv_heads, int block_size, int kv_dtype, int b, int neox, void *stream) {
+                        const float *sin_t, int head_dim, int rot_pairs, int num_kv_heads, int block_size, int kv_dtype, int b, int neox, void *stream,
+                        const void *x_img = nullptr) {
   GemvArgs a{};
   a.neox = neox;
+  a.x_img = x_img;
   if (neox && rot_pairs * 2 != head_dim) return -1;  // pair order (i, i + head_dim / 2) is the rotate-half pairing only when every dim rotates
   if (!wq || !wk || !wv || !make_mat(a.m[0], wq->planes, wq->type, wq->n, wq->k) || !make_mat(a.m[1], wk->planes, wk->type, wk->n, wk->k) ||
       !make_mat(a.m[2], wv->planes, wv->type, wv->n, wv->k)) return -1;
@@ -434,7 +465,35 @@ extern "C" int mrs_dec_proj_img(const mrs_dec_mat_c *w, int n, const void *x_img
   return mode ? Launch<EPI_RESID>::run(a, b, (hipStream_t)stream) : Launch<EPI_STORE>::run(a, b, (hipStream_t)stream);
 }
 extern "C" size_t mrs_dec_act_image_bytes(int k, int b) { return act_bytes(k, b); }
-extern "C" size_t mrs_dec_proj_img_max_bytes(void) { return (size_t)158 * 1024; }
+extern "C" size_t mrs_dec_proj_img_max_bytes(void) { return LDS_IMG_MAX; }
+
+// The activation image of a batch, built once: x [b][ldx] f32 (-> RmsNorm when norm_w) -> the images of the column groups, act_bytes(k, b) bytes in all, for the
+// *_img entry points of a weight of type `weight_type` (K-quants: Q8_K quantization, Q8_0: Q8_0).  One workgroup per column; b <= 8.
+extern "C" int mrs_dec_act_image(const float *x, int ldx, const float *norm_w, float eps, int k, int weight_type, int b, void *img_out, void *stream) {
+  if (!x || !img_out || b < 1 || b > 8 || k <= 0 || k % 256 || !dec_type(weight_type) || ((uintptr_t)img_out & 15)) return -1;
+  ActImgArgs a{};
+  a.x = x; a.ldx = ldx; a.norm_w = norm_w; a.eps = eps; a.K = k; a.mode = act_mode_for(weight_type); a.img = (char *)img_out;
+  col_groups(k, 0, b, a.gc0, a.gn);
+  hipLaunchKernelGGL(dec_act_image_kernel, dim3(b), dim3(NT), 0, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+// mrs_dec_qkv / mrs_dec_qkv_neox (neox != 0) on an image of RmsNorm(h) made by mrs_dec_act_image for these weights
+extern "C" int mrs_dec_qkv_img(const mrs_dec_mat_c *wq, const mrs_dec_mat_c *wk, const mrs_dec_mat_c *wv, const void *x_img, float *q_out, void *k_cache, void *v_cache,
+                               const int64_t *slot_mapping, const int32_t *positions, const float *cos_t, const float *sin_t, int head_dim, int rot_pairs,
+                               int num_kv_heads, int block_size, int kv_dtype, int b, int neox, void *stream) {
+  if (!x_img) return -1;
+  return dec_qkv_impl(wq, wk, wv, nullptr, 0, nullptr, 0.f, q_out, k_cache, v_cache, slot_mapping, positions, cos_t, sin_t, head_dim, rot_pairs, num_kv_heads, block_size,
+                      kv_dtype, b, neox, stream, x_img);
+}
+// mrs_dec_gate_up (dense) on an image of RmsNorm(h)
+extern "C" int mrs_dec_gate_up_img(const mrs_dec_mat_c *wg, const mrs_dec_mat_c *wu, int n, const void *x_img, int activation, float *act_out, int ld_out, int b,
+                                   void *stream) {
+  GemvArgs a{};
+  if (!x_img || !wg || !wu || !make_mat(a.m[0], wg->planes, wg->type, wg->n, wg->k) || !make_mat(a.m[1], wu->planes, wu->type, wu->n, wu->k)) return -1;
+  if (wg->type != wu->type || wg->n != wu->n || wg->k != wu->k || n <= 0 || wg->n != n) return -1;
+  a.nrows[0] = a.nrows[1] = n; a.K = (int)wg->k; a.x_img = x_img; a.activation = activation; a.out = act_out; a.out_stride = ld_out;
+  return Launch<EPI_GLU>::run(a, b, (hipStream_t)stream);
+}
 
 // Decode attention of the engine, one launch (dec_attn2_kernel).  out_f32 [b][num_heads * 128] (may be NULL when an image is written);
 // img_out: Q8_K activation image for mrs_dec_proj_img (written when the GQA group is even; may be NULL); ticket: [b * num_kv_heads] u32, zero

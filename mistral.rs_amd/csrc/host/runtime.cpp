@@ -182,6 +182,7 @@ struct Workspace {  // carve-up of the caller's scratch
   float *moe_act;           // decode engine: [top_k][intermediate] f32 activations of the selected experts
   void *attn_img;           // decode engine: Q8_K activation image of the attention result (mrs_dec_attention / mrs_dec_attention_q8k -> mrs_dec_proj_img)
   unsigned *attn_ticket;    // decode engine: [max_batch][kv heads] arrival counters of mrs_dec_attention (zero at rest)
+  void *act_img;            // decode engine, batched steps: the activation image of a phase, built once (mrs_dec_act_image -> mrs_dec_*_img); hidden or ffn width, <= 8 columns
 };
 
 class Llama {
@@ -225,6 +226,7 @@ class Llama {
     t += align(B * c.num_heads * parts * c.head_dim * 4) + 2 * align(B * c.num_heads * parts * 4);
     t += align(B * 8);
     t += align(mrs_dec_act_image_bytes((int)nq, (int)B)) + align(B * (size_t)c.num_kv_heads * 4);
+    t += align(mrs_dec_act_image_bytes(std::max((int)d, (int)c.intermediate_size), (int)std::min<size_t>(B, 8)));  // act_img
     if (c.num_experts > 0) {
       const size_t k = std::max(1, (int)c.num_experts_per_tok);
       t += align(B * k * 4) * 2 + align(k * (pad_to(c.intermediate_size, MATRIX_ROW_PADDING) / 32) * 36);
@@ -253,6 +255,7 @@ class Llama {
     ws.sample_scratch = take(B * 8);
     ws.attn_img = take(mrs_dec_act_image_bytes((int)nq, (int)B));
     ws.attn_ticket = (unsigned *)take(B * (size_t)cfg.num_kv_heads * 4);
+    ws.act_img = take(mrs_dec_act_image_bytes(std::max((int)d, (int)cfg.intermediate_size), (int)std::min<size_t>(B, 8)));
     if (cfg.num_experts > 0) {
       const size_t k = std::max(1, (int)cfg.num_experts_per_tok);
       ws.moe_ids = (int32_t *)take(B * k * 4); ws.moe_w = (float *)take(B * k * 4);
@@ -432,9 +435,19 @@ class Llama {
     const int bs = cfg.block_size, kvh = cfg.num_kv_heads;
     const int eff_max = std::min(cfg.max_blocks_per_seq * bs, cfg.max_context_len);
     if (wte->embedding_forward_raw(bufs.input_ids, b, ws.h, s)) return -1;
+    // Batched steps: every GEMV workgroup would normalise + quantize all b activation columns itself (256 times the same work, 17-25 us of a 40-60 us launch at
+    // b = 8); from MRS_DEC_IMG_MIN_B columns on the image of a phase is built once by mrs_dec_act_image (b workgroups) and the GEMVs copy it -- same bytes.
+    static const int img_min_b = [] { const char *e = getenv("MRS_DEC_IMG_MIN_B"); return e ? atoi(e) : 2; }();
+    const bool imgb = b >= img_min_b && b >= 2 && b <= 8;
+    auto image = [&](const float *x, int ldx, const float *nw, int k, int wtype) { return mrs_dec_act_image(x, ldx, nw, cfg.rms_eps, k, wtype, b, ws.act_img, s); };
     for (const Block &bl : blocks) {
       // rotate-half RoPE: the caller registered q / k decode planes in pair order (mrs_dec_qkv_neox; llama.py permutes the rows before the repack)
-      if ((cfg.rope_interleaved ? mrs_dec_qkv : mrs_dec_qkv_neox)(&bl.dq, &bl.dk, &bl.dv, ws.h, d, bl.input_layernorm, cfg.rms_eps, ws.q, bl.key_cache, bl.value_cache,
+      if (imgb) {
+        if (image(ws.h, d, bl.input_layernorm, d, bl.dq.type) ||
+            mrs_dec_qkv_img(&bl.dq, &bl.dk, &bl.dv, ws.act_img, ws.q, bl.key_cache, bl.value_cache, bufs.slot_mapping, bufs.positions, bufs.cos_table, bufs.sin_table, hd,
+                            cfg.rot_dim / 2, kvh, bs, kvd, b, cfg.rope_interleaved ? 0 : 1, s))
+          return fail("mrs_dec_qkv_img refused the layer");
+      } else if ((cfg.rope_interleaved ? mrs_dec_qkv : mrs_dec_qkv_neox)(&bl.dq, &bl.dk, &bl.dv, ws.h, d, bl.input_layernorm, cfg.rms_eps, ws.q, bl.key_cache, bl.value_cache,
                                                                   bufs.slot_mapping, bufs.positions, bufs.cos_table, bufs.sin_table, hd, cfg.rot_dim / 2, kvh, bs, kvd, b, s))
         return fail("mrs_dec_qkv refused the layer");
       if (attn2) {
@@ -485,11 +498,17 @@ class Llama {
         if (all_reduce(ws.h, (size_t)b * d, s)) return fail("moe all-reduce failed: %s", g_last_error.c_str());
         continue;
       }
-      if (mrs_dec_gate_up(&bl.dgate, &bl.dup, ff, nullptr, ws.h, d, bl.post_attention_layernorm, cfg.rms_eps, 0, ws.act, ff, b, s)) return fail("mrs_dec_gate_up refused");
-      if (mrs_dec_proj(&bl.ddown, d, nullptr, ws.act, ff, nullptr, 0.f, ws.h, d, 1, rs, nullptr, b, s) || all_reduce(ws.h, (size_t)b * d, s))
-        return fail("down_proj failed: %s", g_last_error.c_str());
+      if (imgb) {
+        if (image(ws.h, d, bl.post_attention_layernorm, d, bl.dgate.type) || mrs_dec_gate_up_img(&bl.dgate, &bl.dup, ff, ws.act_img, 0, ws.act, ff, b, s))
+          return fail("mrs_dec_gate_up_img refused");
+      } else if (mrs_dec_gate_up(&bl.dgate, &bl.dup, ff, nullptr, ws.h, d, bl.post_attention_layernorm, cfg.rms_eps, 0, ws.act, ff, b, s)) return fail("mrs_dec_gate_up refused");
+      const int drc = imgb && bl.ddown.type != Q8_0 ? (image(ws.act, ff, nullptr, ff, bl.ddown.type) || mrs_dec_proj_img(&bl.ddown, d, ws.act_img, ws.h, d, 1, rs, b, s))
+                                                    : mrs_dec_proj(&bl.ddown, d, nullptr, ws.act, ff, nullptr, 0.f, ws.h, d, 1, rs, nullptr, b, s);
+      if (drc || all_reduce(ws.h, (size_t)b * d, s)) return fail("down_proj failed: %s", g_last_error.c_str());
     }
-    if (mrs_dec_proj(&dlm_head, cfg.vocab_size, nullptr, ws.h, d, ln_f, cfg.rms_eps, bufs.logits, cfg.vocab_size, 0, 1.0f, nullptr, b, s)) return fail("lm_head refused");
+    const int lrc = imgb && dlm_head.type != Q8_0 ? (image(ws.h, d, ln_f, d, dlm_head.type) || mrs_dec_proj_img(&dlm_head, cfg.vocab_size, ws.act_img, bufs.logits, cfg.vocab_size, 0, 1.0f, b, s))
+                                                  : mrs_dec_proj(&dlm_head, cfg.vocab_size, nullptr, ws.h, d, ln_f, cfg.rms_eps, bufs.logits, cfg.vocab_size, 0, 1.0f, nullptr, b, s);
+    if (lrc) return fail("lm_head refused");
     return 0;
   }
 

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--v2", action="store_true", help="time the round-4 core's plain launcher (mrs_dec2_gemv) on one tensor of each phase's bytes")
     ap.add_argument("--timeline", action="store_true", help="instead of timing: one cold launch per phase with the s_memrealtime stamps of dec_core2.cuh (MRS_TL2), medians per wave group")
     ap.add_argument("--hot", action="store_true", help="two rotating buffers per phase, replayed 8 x inside the graph: the weights stay in the 256 MiB Infinity Cache")
+    ap.add_argument("--img", action="store_true", help="batched steps: the GEMV phases on an activation image built ONCE by mrs_dec_act_image (not timed here), as the runner does for b >= 2")
     a = ap.parse_args()
     import torch
     import mistralrs_amd  # noqa: F401
@@ -69,11 +70,29 @@ def main():
         return sum(w.data.numel() for w in ws)
 
     phases = {}
+    L.mrs_dec_act_image_bytes.restype = C.c_size_t
+    L.mrs_dec_act_image_bytes.argtypes = [C.c_int, C.c_int]
+    L.mrs_dec_act_image.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.mrs_dec_qkv_img.argtypes = [MP, MP, MP] + [C.c_void_p] * 8 + [C.c_int] * 7 + [C.c_void_p]
+    L.mrs_dec_gate_up_img.argtypes = [MP, MP, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.mrs_dec_proj_img.argtypes = [MP, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]
+
+    def image(x, ldx, norm, k, dt):
+        im = torch.empty(L.mrs_dec_act_image_bytes(k, b), dtype=torch.uint8, device=dev)
+        assert L.mrs_dec_act_image(x.data_ptr(), ldx, nw.data_ptr() if norm else None, 1e-5, k, dt.id, b, im.data_ptr(), st) == 0
+        torch.cuda.synchronize()
+        return im
+    img_h = image(h, d, True, d, Q4) if a.img else None
+    img_act = image(act, ff, False, ff, Q4) if a.img else None
+    img_attn = image(attn, nq, False, nq, Q4) if a.img else None
 
     def ph_qkv(i):
         ws = (make(Q4, nq, d, 3 * i), make(Q4, nkv, d, 3 * i + 1), make(Q6, nkv, d, 3 * i + 2))
         new = lambda st: L.mrs_dec_qkv(C.byref(ws[0][2]), C.byref(ws[1][2]), C.byref(ws[2][2]), h.data_ptr(), d, nw.data_ptr(), 1e-5, q_out.data_ptr(), kc.data_ptr(), vc.data_ptr(),
                                     slots.data_ptr(), pos.data_ptr(), cos.data_ptr(), sin.data_ptr(), hd, hd // 2, 8, 32, 1, b, st)
+        if a.img:
+            new = lambda st: L.mrs_dec_qkv_img(C.byref(ws[0][2]), C.byref(ws[1][2]), C.byref(ws[2][2]), img_h.data_ptr(), q_out.data_ptr(), kc.data_ptr(), vc.data_ptr(),
+                                               slots.data_ptr(), pos.data_ptr(), cos.data_ptr(), sin.data_ptr(), hd, hd // 2, 8, 32, 1, b, 0, st)
         old = lambda st: L.mrs_decode_qkv(ws[0][0].data.data_ptr(), ws[1][0].data.data_ptr(), ws[2][0].data.data_ptr(), 12, 12, 14, nq, nkv, nkv, d, h.data_ptr(), nw.data_ptr(), 1e-5,
                                        q_out.data_ptr(), kc.data_ptr(), vc.data_ptr(), slots.data_ptr(), pos.data_ptr(), cos.data_ptr(), sin.data_ptr(), hd, hd // 2, 8, 32, b, st)
         return ws, new, old, nbytes(*[w[0] for w in ws])
@@ -82,6 +101,9 @@ def main():
         def f(i):
             ws = (make(dt, n, k, 100 + i),)
             new = lambda st: L.mrs_dec_proj(C.byref(ws[0][2]), n, None, x.data_ptr(), ldx, None, 0.0, h.data_ptr(), d, 1, 1.0, None, b, st)
+            if a.img:
+                im = img_act if k == ff else img_attn
+                new = lambda st: L.mrs_dec_proj_img(C.byref(ws[0][2]), n, im.data_ptr(), h.data_ptr(), d, 1, 1.0, b, st)
             old = lambda st: L.mrs_decode_proj(ws[0][0].data.data_ptr(), dt.id, n, k, ybuf.data_ptr(), stride, h.data_ptr(), d, 1, b, st)
             return ws, new, old, nbytes(ws[0][0])
         return f
@@ -89,12 +111,16 @@ def main():
     def ph_gate_up(i):
         ws = (make(Q4, ff, d, 200 + 2 * i), make(Q4, ff, d, 201 + 2 * i))
         new = lambda st: L.mrs_dec_gate_up(C.byref(ws[0][2]), C.byref(ws[1][2]), ff, None, h.data_ptr(), d, nw.data_ptr(), 1e-5, 0, act.data_ptr(), ff, b, st)
+        if a.img:
+            new = lambda st: L.mrs_dec_gate_up_img(C.byref(ws[0][2]), C.byref(ws[1][2]), ff, img_h.data_ptr(), 0, act.data_ptr(), ff, b, st)
         old = lambda st: L.mrs_decode_gate_up(ws[0][0].data.data_ptr(), ws[1][0].data.data_ptr(), 12, ff, d, h.data_ptr(), nw.data_ptr(), 1e-5, 0, yb.data_ptr(), 14336 // 32, b, st)
         return ws, new, old, nbytes(ws[0][0], ws[1][0])
 
     def ph_lm(i):
         ws = (make(Q6, 128256, d, 300 + i),)
         new = lambda st: L.mrs_dec_proj(C.byref(ws[0][2]), 128256, None, h.data_ptr(), d, nw.data_ptr(), 1e-5, logits.data_ptr(), 128256, 0, 1.0, None, b, st)
+        if a.img:
+            new = lambda st: L.mrs_dec_proj_img(C.byref(ws[0][2]), 128256, img_h.data_ptr(), logits.data_ptr(), 128256, 0, 1.0, b, st)
         old = lambda st: L.mrs_decode_norm_proj(ws[0][0].data.data_ptr(), 14, 128256, d, h.data_ptr(), nw.data_ptr(), 1e-5, logits.data_ptr(), 128256, b, st)
         return ws, new, old, nbytes(ws[0][0])
 

@@ -215,6 +215,119 @@ def test_qkv_gpu(oracle, dev, tq, tv, heads, kvh, hd, k, b, kvd):
     check_qkv(oracle, GpuBackend(dev), tq, tv, heads, kvh, hd, k, b, kvd)
 
 
+ACT_IMG = [C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+PROJ_IMG_ = [C.POINTER(Mat), C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]
+GLU_IMG = [C.POINTER(Mat), C.POINTER(Mat), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+QKV_IMG = [C.POINTER(Mat)] * 3 + [C.c_void_p] * 8 + [C.c_int] * 7 + [C.c_void_p]
+
+
+def _act_image(be, t, x, nw, k, b):
+    """mrs_dec_act_image: the batch's activation image built once (one workgroup per column, column groups that fit LDS)"""
+    nbytes = be.sym("mrs_dec_act_image_bytes", [C.c_int, C.c_int], C.c_size_t)(k, b)
+    img = be.buf(np.full(nbytes, 0xA5, np.uint8))  # dead slots of the image keep this fill: whatever they hold must not reach a result
+    assert be.sym("mrs_dec_act_image", ACT_IMG, C.c_int)(x.ptr, k, nw.ptr if nw is not None else None, 1e-5, k, t, b, img.ptr, be.stream) == 0
+    return img
+
+
+def check_image_proj(O, be, tname, n, k, b, norm):
+    """mrs_dec_proj (every GEMV workgroup quantizes the b columns itself) against mrs_dec_act_image + mrs_dec_proj_img: the same bits (batched decode of the runner)"""
+    t = getattr(O, tname)
+    packed = _weights(O, t, n, k, 31)
+    keep, m = repack(be, O, t, packed, n, k)
+    rng = np.random.default_rng(32)
+    x = rng.standard_normal((b, k)).astype(np.float32)
+    x[b - 1, :256] = 0.0
+    nw = (1.0 + 0.1 * rng.standard_normal(k)).astype(np.float32)
+    base = rng.standard_normal((b, n)).astype(np.float32)
+    xb, nb = be.buf(x), (be.buf(nw) if norm else None)
+    o1, o2 = be.buf(base.copy()), be.buf(base.copy())
+    assert be.sym("mrs_dec_proj", PROJ, C.c_int)(C.byref(m), n, None, xb.ptr, k, nb.ptr if norm else None, 1e-5, o1.ptr, n, 1, 0.5, None, b, be.stream) == 0
+    img = _act_image(be, t, xb, nb, k, b)
+    assert be.sym("mrs_dec_proj_img", PROJ_IMG_, C.c_int)(C.byref(m), n, img.ptr, o2.ptr, n, 1, 0.5, b, be.stream) == 0
+    a1, a2 = o1.numpy(), o2.numpy()
+    assert np.array_equal(a1, a2), (tname, n, k, b, norm, float(np.abs(a1 - a2).max()))
+    xe = O.rms_norm_engine(x, nw, 1e-5) if norm else x
+    eng = base * np.float32(0.5) + np.concatenate([O.gemv_engine(t, packed, n, k, r) for r in xe], axis=0) * np.float32(1.0)
+    assert np.array_equal(a2, eng), (tname, n, k, b, norm, "engine-order oracle")
+
+
+def check_image_gate_up(O, be, tname, n, k, b):
+    t = getattr(O, tname)
+    pg, pu = _weights(O, t, n, k, 41), _weights(O, t, n, k, 42)
+    kg, mg = repack(be, O, t, pg, n, k)
+    ku, mu = repack(be, O, t, pu, n, k)
+    rng = np.random.default_rng(43)
+    x = rng.standard_normal((b, k)).astype(np.float32)
+    nw = (1.0 + 0.1 * rng.standard_normal(k)).astype(np.float32)
+    xb, nb = be.buf(x), be.buf(nw)
+    o1, o2 = be.buf(np.zeros((b, n), np.float32)), be.buf(np.zeros((b, n), np.float32))
+    assert be.sym("mrs_dec_gate_up", GLU, C.c_int)(C.byref(mg), C.byref(mu), n, None, xb.ptr, k, nb.ptr, 1e-5, 0, o1.ptr, n, b, be.stream) == 0
+    img = _act_image(be, t, xb, nb, k, b)
+    assert be.sym("mrs_dec_gate_up_img", GLU_IMG, C.c_int)(C.byref(mg), C.byref(mu), n, img.ptr, 0, o2.ptr, n, b, be.stream) == 0
+    a1, a2 = o1.numpy(), o2.numpy()
+    assert np.array_equal(a1, a2) and np.isfinite(a2).all(), (tname, n, k, b, float(np.abs(a1 - a2).max()))
+
+
+def check_image_qkv(O, be, tq, tv, heads, kvh, k, b, neox):
+    hd, bs = 128, 32
+    nq, nkv = heads * hd, kvh * hd
+    pq, pk, pv = _weights(O, getattr(O, tq), nq, k, 51), _weights(O, getattr(O, tq), nkv, k, 52), _weights(O, getattr(O, tv), nkv, k, 53)
+    kq, mq = repack(be, O, getattr(O, tq), pq, nq, k)
+    kk, mk = repack(be, O, getattr(O, tq), pk, nkv, k)
+    kv, mv = repack(be, O, getattr(O, tv), pv, nkv, k)
+    rng = np.random.default_rng(54)
+    x = rng.standard_normal((b, k)).astype(np.float32)
+    nw = (1.0 + 0.05 * rng.standard_normal(k)).astype(np.float32)
+    inv = 1.0 / (10000.0 ** (np.arange(0, hd, 2, dtype=np.float32) / hd))
+    fr = np.arange(64, dtype=np.float32)[:, None] * inv[None, :]
+    pos = np.array([5 + 7 * i for i in range(b)], dtype=np.int32)
+    slots = np.array([(2 * i) * bs + int(pos[i]) % bs for i in range(b)], dtype=np.int64)
+    xb, nb, sb, pb, cb, snb = be.buf(x), be.buf(nw), be.buf(slots), be.buf(pos), be.buf(np.cos(fr).astype(np.float32)), be.buf(np.sin(fr).astype(np.float32))
+    res = []
+    for use_img in (False, True):
+        kc, vc = be.buf(np.zeros((2 * b, kvh, hd // 8, bs, 8), dtype=np.uint16)), be.buf(np.zeros((2 * b, kvh, hd, bs), dtype=np.uint16))
+        qb = be.buf(np.zeros((b, nq), dtype=np.float32))
+        if use_img:
+            img = _act_image(be, getattr(O, tq), xb, nb, k, b)
+            assert be.sym("mrs_dec_qkv_img", QKV_IMG, C.c_int)(C.byref(mq), C.byref(mk), C.byref(mv), img.ptr, qb.ptr, kc.ptr, vc.ptr, sb.ptr, pb.ptr, cb.ptr, snb.ptr, hd,
+                                                                hd // 2, kvh, bs, 1, b, neox, be.stream) == 0
+        else:
+            assert be.sym("mrs_dec_qkv_neox" if neox else "mrs_dec_qkv", QKV, C.c_int)(C.byref(mq), C.byref(mk), C.byref(mv), xb.ptr, k, nb.ptr, 1e-5, qb.ptr, kc.ptr, vc.ptr,
+                                                                                      sb.ptr, pb.ptr, cb.ptr, snb.ptr, hd, hd // 2, kvh, bs, 1, b, be.stream) == 0
+        res.append((qb.numpy(), kc.numpy(), vc.numpy()))
+    for a1, a2 in zip(*res):
+        assert np.array_equal(a1, a2)
+    assert np.count_nonzero(res[1][0]) > 0 and np.count_nonzero(res[1][1]) > 0
+
+
+@pytest.mark.parametrize("tname,n,k,b,norm", [("Q4_K", 24, 1024, 3, True), ("Q6_K", 16, 512, 8, False), ("Q4_K", 8, 14336, 8, False), ("Q5_K", 12, 768, 5, True)])
+def test_image_proj_host_emulation(oracle, tname, n, k, b, norm):
+    check_image_proj(oracle, HostBackend(), tname, n, k, b, norm)  # (k = 14336, b = 8: two column groups of four)
+
+
+def test_image_gate_up_qkv_host_emulation(oracle):
+    check_image_gate_up(oracle, HostBackend(), "Q4_K", 32, 512, 4)
+    check_image_gate_up(oracle, HostBackend(), "Q8_0", 16, 512, 2)
+    check_image_qkv(oracle, HostBackend(), "Q4_K", "Q6_K", 2, 1, 512, 3, 0)
+    check_image_qkv(oracle, HostBackend(), "Q4_K", "Q4_K", 2, 2, 256, 2, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tname,n,k,b,norm", [("Q4_K", 4096, 14336, 8, False), ("Q6_K", 4096, 14336, 5, False), ("Q4_K", 2048, 4096, 8, True), ("Q6_K", 512, 28672, 8, False),
+                                              ("Q4_K", 1000, 4096, 2, True)])
+def test_image_proj_gpu(oracle, dev, tname, n, k, b, norm):
+    check_image_proj(oracle, GpuBackend(dev), tname, n, k, b, norm)
+
+
+@pytest.mark.gpu
+def test_image_gate_up_qkv_gpu(oracle, dev):
+    be = GpuBackend(dev)
+    check_image_gate_up(oracle, be, "Q4_K", 14336, 4096, 8)
+    check_image_gate_up(oracle, be, "Q8_0", 2048, 4096, 3)
+    check_image_qkv(oracle, be, "Q4_K", "Q6_K", 32, 8, 4096, 8, 0)
+    check_image_qkv(oracle, be, "Q4_K", "Q4_K", 32, 8, 4096, 4, 1)
+
+
 ATTN_F32 = [C.c_void_p] * 7 + [C.c_int, C.c_float, C.c_void_p, C.c_void_p] + [C.c_int] * 10 + [C.c_void_p]
 ATTN_Q8K = [C.c_void_p] * 5 + [C.c_int, C.c_float, C.c_void_p, C.c_void_p] + [C.c_int] * 10 + [C.c_void_p]
 PROJ_IMG = [C.POINTER(Mat), C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]

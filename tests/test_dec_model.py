@@ -349,6 +349,30 @@ def test_engine_graph_loop_batch_and_chunked_prefill(oracle, dev, request):
         assert torch.equal(both[0], alone), f"batched != single at position {pos}"
 
 
+@pytest.mark.parametrize("mix", ["q4km", "q8"])
+def test_engine_batched_steps_build_the_activation_image_once(oracle, dev, request, mix):
+    """Batched decode steps (b >= 2: mrs_dec_act_image + the *_img entry points, one image per phase instead of one per GEMV workgroup) give every sequence the
+    logits it gets alone (b = 1: the image is built inside the GEMV), bit for bit."""
+    import torch
+    types = {"q4km": Q4KM, "q8": Q8}[mix](oracle)
+    cfg, w, m, cos, sin = _mk(oracle, dev, types, "bf16", max_batch=4)
+    _, _, m1, _, _ = _mk(oracle, dev, types, "bf16", max_batch=4)
+    npos = 3
+    toks = [[(17 * s + 5 * p + 3) % cfg.vocab_size for p in range(npos)] for s in range(4)]
+    alone = []
+    for s in range(4):  # m1's sequence 0 plays sequence s from position 0 (its pages are overwritten)
+        alone.append([])
+        for p in range(npos):
+            m1.set_state([toks[s][p]], [p])
+            alone[s].append(m1.forward_logits(1)[0].clone())
+    for b in (4, 3, 2):
+        for pos in range(npos):
+            m.set_state([toks[s][pos] for s in range(b)], [pos] * b)
+            both = m.forward_logits(b)
+            for s in range(b):
+                assert torch.equal(both[s], alone[s][pos]), f"b = {b}: sequence {s} at position {pos} differs from its single-sequence step"
+
+
 def test_short_prompt_in_long_context_and_replay_guard(oracle, dev, request):
     """(advisor, round 1) a prompt of <= 16 tokens must prefill when max_context_len > 512 (the v1 / v2 rule of the fallback attention used to refuse
     before the MFMA flash kernel was even tried), and a captured decode graph must not be replayed past max_new_tokens / max_context_len."""
