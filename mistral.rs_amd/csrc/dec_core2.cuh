@@ -715,7 +715,7 @@ __device__ __forceinline__ void stream(const Job &jb, int K, int ncols_img, int 
         u = dppf<0x124>(u) + acc[k];
         tot[k] = dppf<0x124>(u) + acc[k];
       }
-      epi(seg, meta[i].row0, meta[i].nvalid, (meta[i].row0 / g.R) % jb.rgpu, tot, auxv[i]);
+      epi(seg, meta[i].row0, meta[i].nvalid, (meta[i].row0 / g.R) & (jb.rgpu - 1), tot, auxv[i]);  // rgpu is 1 or 2
     }
   };
   if (dyn) {

@@ -19,6 +19,8 @@ struct GemvArgs {
   int activation;
   float *q_out; void *k_cache, *v_cache; const int64_t *slot_mapping; const int32_t *positions; const float *cos_t, *sin_t;
   int head_dim, rot_pairs, num_kv_heads, block_size, cache_x, kv_f16;
+  int hd_shift, bs_shift, x_shift;  // log2 of head_dim / block_size / cache_x (the launcher refuses other values): the epilogue's index arithmetic is shifts and masks --
+                                    // with run-time divisors it was ~10 integer divisions per column and row pair (~40 VALU each), 10 us of the batch-8 qkv launch
   int neox;       // EPI_QKV: rows of q / k are stored in PAIR order (original rows i, i + head_dim / 2 of a head adjacent): rotate-half RoPE; results go back to i, i + head_dim / 2
   int wg0[4];     // EPI_QKV: first workgroup of q, k, v and the total (a workgroup streams ONE tensor: the three may have different formats)
   const int32_t *expert_sel;  // stacked experts [E * nrows][K]: rows of expert e start at e * nrows (nullptr = dense)
@@ -26,6 +28,9 @@ struct GemvArgs {
   int slots, slot_out_stride; // GLU with several experts of ONE token in a launch (MoE top-k): row r of the launch -> slot r / nrows[0], output out + slot * slot_out_stride
   const void *x_img;          // activations already quantized by the producer (dec_attn2_kernel): the LDS image of NCOLS columns, byte for byte
   int units[3], rgpu;         // units of the launch (per tensor for QKV) and record groups per unit
+  int ubase[3], urem[3], upe; // a tensor's units over its workgroups: workgroup wi takes ubase + (wi < urem) units from wi * ubase + min(wi, urem) (computed by the launcher:
+                              // the kernel used to open with two 64-bit and one 32-bit integer division -- ~300 scalar instructions ahead of the first request of every
+                              // launch); upe = units per expert slot
   unsigned long long *tl;
 };
 
@@ -54,6 +59,7 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
   // selected: a select between kernel-argument ADDRESSES makes hipcc copy the whole argument block to scratch memory and index it there.
   const int w1 = a.wg0[1], w2 = a.wg0[2], w3 = a.wg0[3];
   const int un0 = a.units[0], un1 = a.units[1], un2 = a.units[2];
+  const int ub0 = a.ubase[0], ub1 = a.ubase[1], ub2 = a.ubase[2], ur0 = a.urem[0], ur1 = a.urem[1], ur2 = a.urem[2];
   const int nr0 = a.nrows[0], nr1 = a.nrows[1], nr2 = a.nrows[2];
   const uint8_t *b0 = a.m[0].base, *b1 = a.m[1].base, *b2 = a.m[2].base;
   const unsigned by0 = a.m[0].bytes, by1 = a.m[1].bytes, by2 = a.m[2].bytes;
@@ -64,7 +70,9 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
   const int wgb = EPI == EPI_QKV ? (mi == 0 ? 0 : (mi == 1 ? w1 : w2)) : 0;
   const int wge = EPI == EPI_QKV ? (mi == 0 ? w1 : (mi == 1 ? w2 : w3)) : (int)gridDim.x;
   const int units = EPI == EPI_QKV ? (mi == 0 ? un0 : (mi == 1 ? un1 : un2)) : un0;
-  const int nwg = wge - wgb, wi = bx - wgb;
+  const int wi = bx - wgb;
+  const int ub = EPI == EPI_QKV ? (mi == 0 ? ub0 : (mi == 1 ? ub1 : ub2)) : ub0, ur = EPI == EPI_QKV ? (mi == 0 ? ur0 : (mi == 1 ? ur1 : ur2)) : ur0;
+  (void)wge; (void)units;
   Job jb{};
   jb.nseg = (EPI == EPI_GLU || EPI == EPI_RESID2) ? 2 : 1;
   jb.rgpu = a.rgpu;
@@ -74,10 +82,9 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
   jb.mat[0].n = 0; jb.mat[0].k = K;
   if constexpr (EPI == EPI_GLU) { jb.mat[1].base = b1; jb.mat[1].bytes = by1; jb.mat[1].type = ty1; jb.mat[1].n = 0; jb.mat[1].k = K; } else jb.mat[1] = jb.mat[0];
   jb.nrows = mi == 0 ? nr0 : (mi == 1 ? nr1 : nr2);
-  jb.u0 = (int)((long long)wi * units / nwg); jb.u1 = (int)((long long)(wi + 1) * units / nwg);
+  jb.u0 = wi * ub + min(wi, ur); jb.u1 = jb.u0 + ub + (wi < ur ? 1 : 0);
   jb.sel = a.expert_sel; jb.sel_mode = EPI == EPI_RESID2 ? 2 : 1;
-  jb.upe = EPI == EPI_RESID2 ? units : units / (a.slots > 1 ? a.slots : 1);
-  if (jb.upe < 1) jb.upe = 1;
+  jb.upe = a.upe;
   jb.ergs = (a.nrows[0] + g.R - 1) / g.R;
   jb.tl = a.tl;
   const int mode = act_mode_for(jb.mat[0].type);
@@ -178,7 +185,7 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
     for (int c = 0; c < NCOLS; ++c) { posv[c] = a.positions[c]; slotv[c] = mi == 0 ? 0 : (int)a.slot_mapping[c]; }
     auto load_aux = [&](int row) {  // RoPE factors of the row's pair for every column; identity for v and unrotated dims (x*1 - y*0 = x exactly).  Unconditional loads.
       AuxV<NCOLS> v;
-      const int pair_i = (int)((unsigned)row % (unsigned)a.head_dim) >> 1;
+      const int pair_i = (row & (a.head_dim - 1)) >> 1;
       const bool rot = mi < 2 && pair_i < a.rot_pairs;
       const int pi = min(pair_i, a.rot_pairs - 1);
 #pragma unroll
@@ -207,7 +214,7 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
       const int row = row0 + rr;                   // this lane's row; its pair partner sits lpr lanes away (R = 1: in prev)
       const bool odd = single ? true : (row & 1) != 0;
       const int lr = single ? row - 1 : (row & ~1);  // even row of the pair
-      const int head = (int)((unsigned)lr / (unsigned)a.head_dim), dd = lr - head * a.head_dim;
+      const int head = lr >> a.hd_shift, dd = lr & (a.head_dim - 1);
       // where the two results live: adjacent dims (interleaved RoPE), or dims i and i + head_dim / 2 when the rows were stored in pair order (v: never)
       const bool nx = a.neox && mi < 2;
       const int d0 = nx ? dd >> 1 : dd, d1 = nx ? d0 + (a.head_dim >> 1) : dd + 1;
@@ -225,14 +232,14 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
           } else {
             const int slot = slotv[c];
             if (slot >= 0) {
-              const unsigned blk = (unsigned)slot / (unsigned)a.block_size, off = (unsigned)slot % (unsigned)a.block_size;
+              const unsigned blk = (unsigned)slot >> a.bs_shift, off = (unsigned)slot & (unsigned)(a.block_size - 1);
               uint16_t *kc = (uint16_t *)a.k_cache, *vc = (uint16_t *)a.v_cache;
               const uint16_t xb = a.kv_f16 ? float_to_half_bits(x) : float_to_bf16_bits(x), yb = a.kv_f16 ? float_to_half_bits(y) : float_to_bf16_bits(y);
               if (mi == 1) {
                 const int X = a.cache_x;
-                const size_t hb = ((size_t)blk * a.num_kv_heads + head) * (size_t)(a.head_dim / X);
-                if (wr0) kc[(hb + (unsigned)d0 / (unsigned)X) * a.block_size * X + off * X + (unsigned)d0 % (unsigned)X] = xb;
-                if (wr1) kc[(hb + (unsigned)d1 / (unsigned)X) * a.block_size * X + off * X + (unsigned)d1 % (unsigned)X] = yb;
+                const size_t hb = ((size_t)blk * a.num_kv_heads + head) * (size_t)(a.head_dim >> a.x_shift);
+                if (wr0) kc[(hb + ((unsigned)d0 >> a.x_shift)) * a.block_size * X + off * X + ((unsigned)d0 & (unsigned)(X - 1))] = xb;
+                if (wr1) kc[(hb + ((unsigned)d1 >> a.x_shift)) * a.block_size * X + off * X + ((unsigned)d1 & (unsigned)(X - 1))] = yb;
               } else {
                 const size_t o = (((size_t)blk * a.num_kv_heads + head) * a.head_dim + dd) * a.block_size + off;
                 if (wr0) vc[o] = xb;

@@ -309,6 +309,13 @@ template <int EPI> struct Launch {
       grid = a.units[0] < 256 ? a.units[0] : 256;
     }
     if (grid < 1) return -1;
+    // the units of a tensor over its workgroups, and the units per expert slot: divisions done here, not at the head of every workgroup
+    for (int i = 0; i < (EPI == EPI_QKV ? 3 : 1); ++i) {
+      const int nwg = EPI == EPI_QKV ? a.wg0[i + 1] - a.wg0[i] : grid;
+      a.ubase[i] = a.units[i] / nwg; a.urem[i] = a.units[i] % nwg;
+    }
+    a.upe = EPI == EPI_RESID2 ? a.units[0] : a.units[0] / (a.slots > 1 ? a.slots : 1);
+    if (a.upe < 1) a.upe = 1;
     size_t lds = (act_bytes(a.K, NCI) + 15) & ~(size_t)15;
     if (lds > LDS_IMG_MAX) return -2;
     int tmask = 0;
@@ -393,6 +400,9 @@ static int dec_qkv_impl(const mrs_dec_mat_c *wq, const mrs_dec_mat_c *wk, const 
   a.x = h; a.ldx = ldh; a.norm_w = norm_w; a.eps = eps; a.q_out = q_out; a.k_cache = k_cache; a.v_cache = v_cache; a.slot_mapping = slot_mapping;
   a.positions = positions; a.cos_t = cos_t; a.sin_t = sin_t; a.head_dim = head_dim; a.rot_pairs = rot_pairs; a.num_kv_heads = num_kv_heads;
   a.block_size = block_size; a.cache_x = 8; a.kv_f16 = kv_dtype == 0;
+  auto lg2 = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
+  a.hd_shift = lg2(head_dim); a.bs_shift = lg2(block_size); a.x_shift = lg2(a.cache_x);
+  if (a.hd_shift < 0 || a.bs_shift < 0 || head_dim < a.cache_x) return -1;  // powers of two (every head size the engine's attention takes, every block size of the reference's cache)
   return Launch<EPI_QKV>::run(a, b, (hipStream_t)stream);
 }
 extern "C" int mrs_dec_qkv(const mrs_dec_mat_c *wq, const mrs_dec_mat_c *wk, const mrs_dec_mat_c *wv, const float *h, int ldh, const float *norm_w, float eps,
