@@ -125,13 +125,15 @@ __host__ __device__ inline int act_dw(int mode) { return mode == ACT_Q80 ? 12 : 
 __host__ __device__ inline int act_cq(int K) { return ((K / 256 + 3) / 4) * 256 + 16; }                                                   // bytes of one chunk of one column
 __host__ __device__ inline int act_sp(int K) { return 4 * ((K / 256 + 3) / 4); }  // superblock slots of a row in the d / bs regions: the 4 x Cs slots of a row group's tiles (>= S)
 __host__ __device__ inline size_t act_bytes(int K, int ncols) { return (size_t)ncols * ((size_t)4 * act_cq(K) + (size_t)act_sp(K) * (48 + ACT_BS * 4)); }  // both modes fit
+// chunk p = sb / Cs of superblock sb < 4 Cs, without the integer division (a run-time divisor: ~40 instructions and a reciprocal's latency per superblock quantized)
+__host__ __device__ inline int chunk_of(int sb, int Cs) { return (sb >= Cs ? 1 : 0) + (sb >= 2 * Cs ? 1 : 0) + (sb >= 3 * Cs ? 1 : 0); }
 struct Act {
   const char *q;
   const float *d;
   const int *bs;
   int K, S, dw, Cs, CQ, Sp;
   // byte offset of superblock sb's quants inside its column
-  __device__ __forceinline__ int qoff(int sb) const { const int p = sb / Cs; return p * CQ + (sb - p * Cs) * 256; }
+  __device__ __forceinline__ int qoff(int sb) const { const int p = chunk_of(sb, Cs); return p * CQ + (sb - p * Cs) * 256; }
   __device__ __forceinline__ size_t qcol(int c) const { return (size_t)c * 4 * CQ; }
 };
 __device__ __forceinline__ Act act_view(char *smem, int K, int ncols, int mode) {
@@ -152,7 +154,7 @@ __device__ __forceinline__ void quantize_multi(const float4 (&v)[N], const int (
   int *b0p = (int *)(img + (size_t)ncols * 4 * CQ + (size_t)ncols * Sp * dw * 4) + (size_t)c * Sp * ACT_BS;
   int qo[N];
 #pragma unroll
-  for (int n = 0; n < N; ++n) { const int sbn = live[n] ? sb[n] : 0, p = sbn / Cs; qo[n] = p * CQ + (sbn - p * Cs) * 256; }
+  for (int n = 0; n < N; ++n) { const int sbn = live[n] ? sb[n] : 0, p = chunk_of(sbn, Cs); qo[n] = p * CQ + (sbn - p * Cs) * 256; }
   if (mode == ACT_Q8K) {
     float amax[N], mx[N];
     bool tie = false;
