@@ -49,7 +49,8 @@ typedef struct { const void *planes; int type; long long n, k; } mrs_dec_mat; /*
 int mrs_dec_supported(int ggml_type);                         /* q4_k q5_k q6_k q8_0 */
 size_t mrs_dec_repack_bytes(int ggml_type, long long n, long long k); /* 0 = unsupported type / shape */
 int mrs_dec_repack(const void *gguf_blocks, int ggml_type, long long n, long long k, void *planes, void *stream);
-/* RmsNorm + q/k/v projections + interleaved RoPE + KV-cache write (kv_dtype: 1 = bf16, 0 = f16 pages); q_out f32 [b][nq] */
+/* RmsNorm + q/k/v projections + interleaved RoPE + KV-cache write (kv_dtype: 1 = bf16, 0 = f16 pages); q_out f32 [b][nq].  head_dim and block_size must be
+ * powers of two, head_dim >= 8 (-1 otherwise: the epilogue indexes heads, cache blocks and the cache's x-groups with shifts and masks) */
 int mrs_dec_qkv(const mrs_dec_mat *wq, const mrs_dec_mat *wk, const mrs_dec_mat *wv, const float *h, int ldh, const float *norm_w, float eps,
                 float *q_out, void *k_cache, void *v_cache, const int64_t *slot_mapping, const int32_t *positions, const float *cos_t,
                 const float *sin_t, int head_dim, int rot_pairs, int num_kv_heads, int block_size, int kv_dtype, int b, void *stream);

@@ -312,6 +312,36 @@ def test_image_gate_up_qkv_host_emulation(oracle):
     check_image_qkv(oracle, HostBackend(), "Q4_K", "Q4_K", 2, 2, 256, 2, 1)
 
 
+def test_image_entry_points_refuse_what_they_cannot_do_host_emulation(oracle):
+    """argument checks of the batched-image entry points (return -1, nothing launched): column counts outside 1..8, K not a multiple of 256, a misaligned image, a weight
+    type without a decode layout, a missing image; mrs_dec_qkv refuses head sizes that are not powers of two (its epilogue indexes with shifts and masks)"""
+    O, be = oracle, HostBackend()
+    k, b = 512, 2
+    x = be.buf(np.ones((8, k), np.float32))
+    nbytes = be.sym("mrs_dec_act_image_bytes", [C.c_int, C.c_int], C.c_size_t)(k, 8)
+    img = be.buf(np.zeros(nbytes + 64, np.uint8))
+    base = (img.ptr + 15) & ~15
+    fn = be.sym("mrs_dec_act_image", ACT_IMG, C.c_int)
+    assert fn(x.ptr, k, None, 0.0, k, O.Q4_K, b, base, be.stream) == 0
+    for bad in ((x.ptr, k, None, 0.0, k, O.Q4_K, 0, base), (x.ptr, k, None, 0.0, k, O.Q4_K, 9, base), (x.ptr, k, None, 0.0, 300, O.Q4_K, b, base),
+                (x.ptr, k, None, 0.0, k, O.Q4_K, b, base + 4), (x.ptr, k, None, 0.0, k, 0, b, base), (None, k, None, 0.0, k, O.Q4_K, b, base), (x.ptr, k, None, 0.0, k, O.Q4_K, b, None)):
+        assert fn(*bad, be.stream) == -1, bad
+    t = O.Q4_K
+    keep, m = repack(be, O, t, _weights(O, t, 16, k, 1), 16, k)
+    out = be.buf(np.zeros((b, 16), np.float32))
+    assert be.sym("mrs_dec_gate_up_img", GLU_IMG, C.c_int)(C.byref(m), C.byref(m), 16, None, 0, out.ptr, 16, b, be.stream) == -1
+    assert be.sym("mrs_dec_proj_img", PROJ_IMG_, C.c_int)(C.byref(m), 16, None, out.ptr, 16, 0, 1.0, b, be.stream) == -1
+    # head size 96 (not a power of two): refused by the q / k / v phase
+    hd, heads = 96, 2
+    kq, mq = repack(be, O, t, _weights(O, t, heads * hd, k, 2), heads * hd, k)
+    nw, qb = be.buf(np.ones(k, np.float32)), be.buf(np.zeros((1, heads * hd), np.float32))
+    kc, vc = be.buf(np.zeros((2, heads, hd // 8, 32, 8), np.uint16)), be.buf(np.zeros((2, heads, hd, 32), np.uint16))
+    sb, pb = be.buf(np.zeros(1, np.int64)), be.buf(np.zeros(1, np.int32))
+    cs = be.buf(np.ones((4, hd // 2), np.float32))
+    assert be.sym("mrs_dec_qkv", QKV, C.c_int)(C.byref(mq), C.byref(mq), C.byref(mq), x.ptr, k, nw.ptr, 1e-5, qb.ptr, kc.ptr, vc.ptr, sb.ptr, pb.ptr, cs.ptr, cs.ptr, hd, hd // 2,
+                                               heads, 32, 1, 1, be.stream) == -1
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("tname,n,k,b,norm", [("Q4_K", 4096, 14336, 8, False), ("Q6_K", 4096, 14336, 5, False), ("Q4_K", 2048, 4096, 8, True), ("Q6_K", 512, 28672, 8, False),
                                               ("Q4_K", 1000, 4096, 2, True)])
