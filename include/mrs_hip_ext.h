@@ -216,7 +216,7 @@ typedef struct {  /* all device pointers, owned by the caller */
 
 size_t mrs_llama_workspace_bytes(const mrs_llama_config *cfg);
 /* ---- prompts in the decode engine's arithmetic (csrc/ext_gemm_qi.hip, round 4): the role of the reference CPU prompt path (QMatMul f32 fallback per activation
- * row, mistralrs-quant/src/gguf/mod.rs:465-478): Q8_K activation rows x Q4_K / Q6_K weights as EXACT integers on v_mfma_f32_32x32x16_f16, combined in the f32
+ * row, mistralrs-quant/src/gguf/mod.rs:465-478): Q8_K activation rows x Q4_K / Q5_K / Q6_K weights as EXACT integers on v_mfma_f32_32x32x16_f16, combined in the f32
  * order of the decode engine -- row t of the result equals mrs_dec_proj on row t bit for bit.
  * mrs_gemm_qi_repack: GGUF blocks [n][k / 256] -> the MFMA-order copy (load time).  mrs_qi_quantize: x f32 [T][ldx] (RmsNorm in the engine's order when norm_w;
  * x2 != NULL: rows are silu(x) * x2, xtmp = f32 scratch [T][K]) -> the GEMM's operand buffers `act` (mrs_qi_act_bytes).  mrs_gemm_qi: out[t * ldo + n] (+)= W[n] . act[t].

@@ -12,6 +12,9 @@
 //   * Q4_K: the operand is sc q (<= 945); the first and the second eight runs of a superblock go to two accumulators (<= 15.5 M each), (float)isum = XA + XB is
 //     one rounding of the exact integer -- what (float)int gives; msum = sum_j m_j bsum_j is one more MFMA per superblock (K = the 16 run sums of the Q8_K
 //     block, mins duplicated per run);
+//   * Q5_K (round 5): the operand is sc (q - 16) (|.| <= 1008: one packed fma for sc q, one packed add for - 16 sc), two accumulators like Q4_K (<= 16.5 M each), and the
+//     16 sum_j sc_j bsum_j the offset leaves out is one more MFMA (S); isum = XA + XB + 16 S is formed in int32 (a superblock's sum reaches 64 M: two f32 additions
+//     would round twice) and converted once; the mins' M as for Q4_K;
 //   * per superblock and output ONE f32 term T (the decode engine's expression), terms added left to right inside each of the row's four runs of
 //     superblocks, the four run sums left to right (dec_core2.cuh header).
 // Operands: weights in an MFMA-order copy made at load time (mrs_gemm_qi_repack: per 32-row panel and superblock, every lane's 16 bytes of a piece
@@ -35,9 +38,9 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-constexpr int REC_Q4K = 4096 + 512 + 128, REC_Q6K = 8192 + 512 + 128;
+constexpr int REC_Q4K = 4096 + 512 + 128, REC_Q6K = 8192 + 512 + 128, REC_Q5K = REC_Q6K;  // Q5_K: the 5-bit values as bytes, like Q6_K's 6-bit ones
 __host__ __device__ constexpr int rec_bytes_qi(int type) { return type == T_Q4_K ? REC_Q4K : REC_Q6K; }
-__host__ __device__ inline bool qi_type(int t) { return t == T_Q4_K || t == T_Q6_K; }
+__host__ __device__ inline bool qi_type(int t) { return t == T_Q4_K || t == T_Q5_K || t == T_Q6_K; }
 __host__ __device__ inline size_t qi_tensor_bytes(int type, long long n, long long k) { return (size_t)((n + 31) / 32) * (size_t)(k / 256) * rec_bytes_qi(type); }
 
 // the k order inside a group of 8 operand slots: slot jj holds element PERM[jj] (the half2 registers of the weight operand are (e0, e2), (e1, e3), (e4, e6), (e5, e7):
@@ -76,6 +79,28 @@ __global__ void __launch_bounds__(256) qi_repack_kernel(const uint8_t *__restric
       }
       *(v4u *)(rec + 4096 + (size_t)nn * 16) = *(const v4u *)buf;
       *(uint32_t *)(rec + 4608 + (size_t)nn * 4) = have ? ((uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24)) : 0u;
+    }
+  } else if constexpr (TYPE == T_Q5_K) {  // block_q5_K (176 B): d, dmin, scales[12], qh[32], qs[128]; the 5-bit values as bytes (0 .. 31) in Q6_K's piece order
+    const uint8_t *b = src + ((size_t)row * S + sb) * 176, *qh = b + 16, *qs = b + 48;
+    // dequantize_row_q5_K: 64 values per j: low nibbles of qs[32 j ..] with bit 2 j of qh, then the high nibbles with bit 2 j + 1
+    auto q5 = [&](int e) { const int j = e >> 6, w = e & 63, l = w & 31, up = w >> 5;
+                           const int lo = up ? (qs[32 * j + l] >> 4) : (qs[32 * j + l] & 15), hi = (qh[l] >> (2 * j + up)) & 1; return lo | (hi << 4); };
+    for (int g = 0; g < 8; ++g) {  // piece g: runs 2g, 2g + 1 (= sub-block g); the lane's 8 elements 8 hf .. 8 hf + 7 of each
+      for (int k = 0; k < 8; ++k) { buf[k] = have ? (uint8_t)q5((2 * g) * 16 + 8 * hf + k) : 0; buf[8 + k] = have ? (uint8_t)q5((2 * g + 1) * 16 + 8 * hf + k) : 0; }
+      *(v4u *)(rec + ((size_t)g * 64 + lane) * 16) = *(const v4u *)buf;
+    }
+    if (hf == 0) {
+      const int nn = lane & 31;
+      for (int g = 0; g < 8; ++g) {  // get_scale_min_k4
+        uint8_t sc = 0, mn = 0;
+        if (have) {
+          const uint8_t *p = b + 4;
+          if (g < 4) { sc = p[g] & 63; mn = p[g + 4] & 63; } else { sc = (p[g + 4] & 15) | ((p[g - 4] >> 6) << 4); mn = (p[g + 4] >> 4) | ((p[g] >> 6) << 4); }
+        }
+        buf[g] = sc; buf[8 + g] = mn;
+      }
+      *(v4u *)(rec + 8192 + (size_t)nn * 16) = *(const v4u *)buf;
+      *(uint32_t *)(rec + 8704 + (size_t)nn * 4) = have ? ((uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24)) : 0u;
     }
   } else {  // Q6_K: the 6-bit values as bytes (0 .. 63), 16 int8 scales, d
     const uint8_t *b = src + ((size_t)row * S + sb) * 210, *ql = b, *qh = b + 128;
@@ -249,7 +274,15 @@ __global__ void __launch_bounds__(GT) gemm_qi_kernel(const GemmArgs a) {
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
       for (int v = 0; v < 16; ++v) { X[tt][v] = 0.f; X2[tt][v] = 0.f; }
-    auto act_frag = [&](int tt, int run_i) -> h8 { return *(const h8 *)(act_s + aoff[run_i] + tt * (32 * 512)); };
+    // Q5_K: the 16 fragment offsets are recomputed per superblock from an opaque copy of the lane's row (kept as loop invariants -- aoff[] -- they are what tips this
+    // branch over 256 registers: 6 spilled dwords)
+    constexpr bool RECOMP = TYPE == T_Q5_K;
+    int nnv = nn;
+    if constexpr (RECOMP) MRS_OPAQUE_TID(nnv);
+    auto act_frag = [&](int tt, int run_i) -> h8 {
+      if constexpr (RECOMP) return *(const h8 *)(act_s + trow * 512 + (((2 * run_i + hf) ^ nnv) << 4) + tt * (32 * 512));
+      else return *(const h8 *)(act_s + aoff[run_i] + tt * (32 * 512));
+    };
     const bool cfirst = (sb % Cs) == 0;
     const f2 keep2 = cfirst ? f2{0.f, 0.f} : f2{1.f, 1.f};  // the first term of a run of superblocks starts its sum (0 * run + t), the others add (1 * run + t: exact)
     if constexpr (TYPE == T_Q4_K) {
@@ -309,6 +342,64 @@ __global__ void __launch_bounds__(GT) gemm_qi_kernel(const GemmArgs a) {
             const f2 mm = (f2{dmin, dmin} * yd2) * f2{M[v], M[v + 1]};
             const f2 t = __builtin_elementwise_fma(f2{d, d} * yd2, If, -mm);
             const f2 r = __builtin_elementwise_fma(f2{run[tt][v], run[tt][v + 1]}, keep2, t);  // run * 1 + t, or (first superblock of a run) run * 0 + t
+            run[tt][v] = r[0]; run[tt][v + 1] = r[1];
+          }
+        }
+      }
+    } else if constexpr (TYPE == T_Q5_K) {
+      // operand = sc (q - 16), |.| <= 1008: (1024 + q) sc - 1024 sc = sc q exactly (one packed fma; 1024 sc <= 64512 is an f16 value), then - 16 sc (1040 sc is not an
+      // f16 value for sc = 63, so the offset takes a second packed add).  Runs 0 .. 7 and 8 .. 15 go to two accumulators (<= 128 x 1008 x 128 = 16.5 M < 2^24 each,
+      // exact); the 16 sc_j bsum terms the offset leaves out are one more MFMA (S, like the mins' M); isum = XA + XB + 16 S is added as int32 and converted once --
+      // what the CPU path's (float)int is.
+      unsigned mg = 0x64006400u;
+      MRS_OPAQUE_TID(mg);
+      auto b2 = [&](unsigned v) -> h2 { return as_h2((v & 0x00FF00FFu) | mg); };  // (1024 + u0, 1024 + u1)
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const float scf = (float)byte_of(g < 4 ? wr.hs.x : wr.hs.y, g & 3);
+        const h2 sc = h2{(_Float16)scf, (_Float16)scf}, off = h2{(_Float16)(-1024.0f * scf), (_Float16)(-1024.0f * scf)}, o16 = h2{(_Float16)(-16.0f * scf), (_Float16)(-16.0f * scf)};
+        auto opnd = [&](unsigned v) -> h2 { return pkfma(b2(v), sc, off) + o16; };
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {  // run 2 g + h
+          const unsigned d0 = h == 0 ? wr.q[g].x : wr.q[g].z, d1 = h == 0 ? wr.q[g].y : wr.q[g].w;
+          const h8 w = mk_h8(opnd(d0), opnd(d0 >> 8), opnd(d1), opnd(d1 >> 8));
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) {
+            const h8 af = act_frag(tt, 2 * g + h);
+            if (g < 4) X[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, w, X[tt], 0, 0, 0);
+            else X2[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, w, X2[tt], 0, 0, 0);
+          }
+        }
+      }
+      // M = sum_run m_{run / 2} bsum_run, S = sum_run sc_{run / 2} bsum_run: operand slot (hf, jj) <-> run 8 hf + jj -> sub-block 4 hf + jj / 2
+      const unsigned mw = hf ? wr.hs.w : wr.hs.z, sw = hf ? wr.hs.y : wr.hs.x;
+      h8 wm, ws;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const _Float16 mk = (_Float16)(float)byte_of(mw, k), sk = (_Float16)(float)byte_of(sw, k);
+        wm[2 * k] = mk; wm[2 * k + 1] = mk; ws[2 * k] = sk; ws[2 * k + 1] = sk;
+      }
+      const float d = half_bits_to_float((uint16_t)(wr.hd & 0xffff)), dmin = half_bits_to_float((uint16_t)(wr.hd >> 16));
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const h8 bsf = *(const h8 *)(bs_s + (trow + 32 * tt) * 32 + hf * 16);
+        f16v zero;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) zero[v] = 0.f;
+        const f16v M = __builtin_amdgcn_mfma_f32_32x32x16_f16(bsf, wm, zero, 0, 0, 0);
+        const f16v Sx = __builtin_amdgcn_mfma_f32_32x32x16_f16(bsf, ws, zero, 0, 0, 0);
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const float4 y4 = *(const float4 *)(yd_s + wt * 64 + tt * 32 + 8 * q4 + 4 * hf);
+#pragma unroll
+          for (int k = 0; k < 4; k += 2) {
+            const int v = 4 * q4 + k;
+            const f2 yd2 = k == 0 ? f2{y4.x, y4.y} : f2{y4.z, y4.w};
+            const int i0 = ((int)X[tt][v] + (int)X2[tt][v]) + 16 * (int)Sx[v], i1 = ((int)X[tt][v + 1] + (int)X2[tt][v + 1]) + 16 * (int)Sx[v + 1];
+            const f2 If = f2{(float)i0, (float)i1};  // (float)isum
+            const f2 mm = (f2{dmin, dmin} * yd2) * f2{M[v], M[v + 1]};
+            const f2 t = __builtin_elementwise_fma(f2{d, d} * yd2, If, -mm);
+            const f2 r = __builtin_elementwise_fma(f2{run[tt][v], run[tt][v + 1]}, keep2, t);
             run[tt][v] = r[0]; run[tt][v + 1] = r[1];
           }
         }
@@ -403,12 +494,13 @@ extern "C" size_t mrs_gemm_qi_repack_bytes(int type, long long n, long long k) {
   if (!qi::qi_type(type) || n <= 0 || k <= 0 || k % 256) return 0;
   return qi::qi_tensor_bytes(type, n, k);
 }
-// GGUF blocks [n][k / 256] (q4_k / q6_k) -> the MFMA-order copy mrs_gemm_qi reads
+// GGUF blocks [n][k / 256] (q4_k / q5_k / q6_k) -> the MFMA-order copy mrs_gemm_qi reads
 extern "C" int mrs_gemm_qi_repack(const void *gguf_blocks, int type, long long n, long long k, void *dst, void *stream) {
   if (!mrs_gemm_qi_repack_bytes(type, n, k) || !gguf_blocks || !dst) return -1;
   const long long total = ((n + 31) / 32) * (k / 256) * 64;
   const dim3 grid((unsigned)((total + 255) / 256));
   if (type == T_Q4_K) hipLaunchKernelGGL(qi::qi_repack_kernel<T_Q4_K>, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t *)gguf_blocks, (uint8_t *)dst, n, (int)k, total);
+  else if (type == T_Q5_K) hipLaunchKernelGGL(qi::qi_repack_kernel<T_Q5_K>, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t *)gguf_blocks, (uint8_t *)dst, n, (int)k, total);
   else hipLaunchKernelGGL(qi::qi_repack_kernel<T_Q6_K>, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t *)gguf_blocks, (uint8_t *)dst, n, (int)k, total);
   return 0;
 }
@@ -462,6 +554,7 @@ extern "C" int mrs_gemm_qi_ws(const void *w_qi, int type, int N, int K, const vo
   a.ksplit = 1; a.part = nullptr;
   if ((int)(grid.x * grid.y) < split_max && K / 256 >= 4 && N % 4 == 0 && workspace && workspace_bytes >= (size_t)4 * T * N * 4) { a.ksplit = 4; a.part = (float *)workspace; grid.z = 4; }
   if (type == T_Q4_K) { auto kern = qi::gemm_qi_kernel<T_Q4_K>; lds_attr_once((const void *)kern, 158 * 1024); hipLaunchKernelGGL(kern, grid, dim3(qi::GT), qi::LDS_TOTAL, (hipStream_t)stream, a); }
+  else if (type == T_Q5_K) { auto kern = qi::gemm_qi_kernel<T_Q5_K>; lds_attr_once((const void *)kern, 158 * 1024); hipLaunchKernelGGL(kern, grid, dim3(qi::GT), qi::LDS_TOTAL, (hipStream_t)stream, a); }
   else { auto kern = qi::gemm_qi_kernel<T_Q6_K>; lds_attr_once((const void *)kern, 158 * 1024); hipLaunchKernelGGL(kern, grid, dim3(qi::GT), qi::LDS_TOTAL, (hipStream_t)stream, a); }
   if (a.ksplit > 1) hipLaunchKernelGGL(qi::gemm_qi_reduce_kernel, dim3((unsigned)(((size_t)T * N / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a.part, out, T, N, ldo, accumulate);
   return 0;

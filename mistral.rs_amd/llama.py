@@ -393,7 +393,7 @@ class Llama:
 
     def prefill(self, tokens, start_pos: int = 0, seq: int = 0) -> torch.Tensor:
         """Prompt processing of one sequence (mrs_llama_prefill): returns the last token's logits [vocab] and leaves K/V of every prompt token in the
-        sequence's pages.  With the decode engine and Q4_K / Q6_K linears (`prefill_is_exact`) the prompt runs in the decode engine's arithmetic -- Q8_K
+        sequence's pages.  With the decode engine and Q4_K / Q5_K / Q6_K linears (`prefill_is_exact`) the prompt runs in the decode engine's arithmetic -- Q8_K
         activation rows x exact-integer MFMA GEMMs, the decode kernels' attention per query -- and every logit and KV page equals what a token-by-token
         decode produces; otherwise on the bf16 matrix cores (dequantized weights).  Mirrors the prompt branch of the reference
         (PagedAttention::forward try_regular_prompt + reshape_and_cache, paged_attention.rs:1413-1475)."""

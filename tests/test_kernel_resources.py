@@ -60,3 +60,12 @@ def test_decode_attention_two_waves_per_simd(kernels):
     assert len(ks) >= 8
     for k in ks:
         assert k["vgpr_count"] <= 136 and not k.get("private_segment_fixed_size", 0) and not k.get("vgpr_spill_count", 0), (k["demangled"], k)
+
+
+def test_exact_prompt_gemm_no_scratch(kernels):
+    """gemm_qi_kernel<Q4_K / Q5_K / Q6_K> (two waves per SIMD: 256 registers each): the Q5_K branch was brought under the limit on purpose (its first forms spilled 6-48
+    registers, whole 16-register accumulator tuples at worst)"""
+    ks = _sel(kernels, r"gemm_qi_kernel<1[234]>")
+    assert len(ks) == 3
+    for k in ks:
+        assert k["vgpr_count"] <= 256 and not k.get("private_segment_fixed_size", 0) and not k.get("vgpr_spill_count", 0), (k["demangled"], k)

@@ -9,7 +9,7 @@ import pytest
 
 from tests.abi_backends import GpuBackend, HostBackend
 from tests.test_dec_engine import ATTN2
-from tests.test_dec_model import Q4KM, _mk
+from tests.test_dec_model import Q4KM, Q5, _mk
 
 VP, CI = C.c_void_p, C.c_int
 PA = [VP, VP, VP, VP, VP, VP] + [CI] * 8 + [C.c_float, CI, CI, CI, CI, VP]
@@ -59,16 +59,17 @@ def test_prompt_attention_equals_decode_attention_gpu(oracle, dev, heads, kvh, T
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kv", ["bf16", "f16"])
-def test_prefill_equals_token_by_token_decode_and_engine_order_oracle(oracle, dev, request, kv):
-    """2-layer Q4_K_M model: prefill(prompt) leaves the SAME KV pages and returns the SAME logits as decoding the prompt token by token, both equal
+@pytest.mark.parametrize("kv,mix", [("bf16", "q4km"), ("f16", "q4km"), ("bf16", "q5")])
+def test_prefill_equals_token_by_token_decode_and_engine_order_oracle(oracle, dev, request, kv, mix):
+    """2-layer Q4_K_M model (q5: Q5_K linears + Q6_K down / output, round 5): prefill(prompt) leaves the SAME KV pages and returns the SAME logits as decoding the prompt token by token, both equal
     LlamaRef(mode="engine") bit for bit, and decoding on from the prefilled pages stays bit-identical to the oracle (greedy)."""
     import torch
     from oracle import llama_ref
     emu = request.config.getoption("--host-emulation")
     n_prompt, n_more = (9, 2) if emu else (70, 16)
-    cfg, w, m1, cos, sin = _mk(oracle, dev, Q4KM(oracle), kv)
-    _, _, m2, _, _ = _mk(oracle, dev, Q4KM(oracle), kv)
+    types = {"q4km": Q4KM, "q5": Q5}[mix](oracle)
+    cfg, w, m1, cos, sin = _mk(oracle, dev, types, kv)
+    _, _, m2, _, _ = _mk(oracle, dev, types, kv)
     assert m1.prefill_is_exact
     ref = llama_ref.LlamaRef(cfg, w, cos, sin, mode="engine", kv_dtype=kv)
     prompt = [(1000 + 37 * i) % cfg.vocab_size for i in range(n_prompt)]
@@ -83,7 +84,7 @@ def test_prefill_equals_token_by_token_decode_and_engine_order_oracle(oracle, de
         assert torch.equal(k1.view(torch.int16), k2.view(torch.int16)), f"layer {layer}: K pages written by prefill != pages written by decode"
         assert torch.equal(v1.view(torch.int16), v2.view(torch.int16)), f"layer {layer}: V pages written by prefill != pages written by decode"
     # the same prompt in two chunks (second chunk at start_pos > 0 attends the pages of the first): same pages, same logits
-    _, _, m3, _, _ = _mk(oracle, dev, Q4KM(oracle), kv)
+    _, _, m3, _, _ = _mk(oracle, dev, types, kv)
     cut = n_prompt // 2 + 1
     m3.prefill(prompt[:cut], 0)
     lc = m3.prefill(prompt[cut:], cut).float().cpu().numpy()
