@@ -747,6 +747,16 @@ def main():
         except Exception as e:  # the baseline is a reported extra, never fatal
             import traceback
             out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port", "sample": f"failed: {e}: {traceback.format_exc()[-400:]}"}
+    if rank == 0 and world == 1 and not a.no_extra and not a.small and B == 1 and a.quant == "q4_k_m" and not moe and cfg.max_batch >= 8 and not a.shard_shapes:
+        # side field, never fatal: the same model decoding 4 and 8 sequences per step (the reference's MMVQ contract: batch 1-8 from one weight pass, mmvq_gguf.cu:724-792;
+        # what the scheduler feeds).  `value` stays the batch-1 line BASELINE.json names.
+        try:
+            out["batched_decode"] = {"note": "same weights, b sequences per step (same prompt in b sets of pages), 64 timed steps after 8 warm-up steps; tokens/s = b * steps / time"}
+            for bb in (4, 8):
+                rb = timed_run(model, cfg, a.prompt_len, 64, 8, bb, sync, world, dev)
+                out["batched_decode"][str(bb)] = {"tokens_per_sec": round(bb * 64 / rb["t_all"], 2), "ms_per_step": round(1e3 * rb["t_all"] / 64, 4)}
+        except Exception as e:
+            out["batched_decode"] = {"failed": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not a.no_extra and not a.small and B == 1 and a.quant == "q4_k_m" and a.model in ("auto", "8b") and not a.shard_shapes:
         out["extra_configs"] = {}
         del model
