@@ -83,7 +83,8 @@ int mrs_dec_attention(float *out_f32, void *img_out, unsigned *ticket, float *pa
                       int max_context_len, int num_seqs, int num_heads, int head_size, int max_blocks_per_seq, int q_stride, int kv_block_stride,
                       int kv_head_stride, int kv_dtype, int sliding_window /* > 0: attend the last W positions only (Mistral), 0 = all */, void *stream);
 size_t mrs_dec_proj_img_max_bytes(void); /* largest activation image mrs_dec_proj_img takes (the LDS budget) */
-/* GEMV on a pre-quantized activation image (K-quant weights only) */
+/* GEMV on a pre-quantized activation image: Q8_K quantization for K-quant weights (what mrs_dec_attention writes), Q8_0 for Q8_0 weights (mrs_dec_act_image with that
+ * weight type); the image carries no tag -- the caller pairs image and weight */
 int mrs_dec_proj_img(const mrs_dec_mat *w, int n, const void *x_img, float *out, int ld_out, int mode, float resid_scale, int b, void *stream);
 /* Batched decode (b = 2..8): the activation image built ONCE per phase instead of by each of the 256 GEMV workgroups.  mrs_dec_act_image: x [b][ldx] f32
  * (-> RmsNorm when norm_w) -> img_out (16-byte aligned, mrs_dec_act_image_bytes(k, b) bytes: one image per column group that fits LDS) for weights of type

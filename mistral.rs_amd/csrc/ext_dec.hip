@@ -467,10 +467,11 @@ extern "C" int mrs_dec_proj(const mrs_dec_mat_c *w, int n, const int32_t *expert
   return mode ? Launch<EPI_RESID>::run(a, b, (hipStream_t)stream) : Launch<EPI_STORE>::run(a, b, (hipStream_t)stream);
 }
 
-// o_proj & friends on activations the producer already quantized (mrs_dec_attention): x_img = the LDS image of b columns of k values
+// o_proj & friends on activations the producer already quantized: x_img = the LDS image of b columns of k values, in the quantization w's type takes (Q8_K for the
+// K-quants: what mrs_dec_attention writes; Q8_0 for Q8_0 weights: mrs_dec_act_image with that weight type -- the caller pairs them, the image carries no tag)
 extern "C" int mrs_dec_proj_img(const mrs_dec_mat_c *w, int n, const void *x_img, float *out, int ld_out, int mode, float resid_scale, int b, void *stream) {
   GemvArgs a{};
-  if (!w || !x_img || !make_mat(a.m[0], w->planes, w->type, w->n, w->k) || n <= 0 || w->n != n || act_mode_for(w->type) != ACT_Q8K) return -1;
+  if (!w || !x_img || !make_mat(a.m[0], w->planes, w->type, w->n, w->k) || n <= 0 || w->n != n) return -1;
   a.nrows[0] = n; a.K = (int)w->k; a.x_img = x_img; a.out = out; a.out_stride = ld_out; a.resid_scale = resid_scale;
   return mode ? Launch<EPI_RESID>::run(a, b, (hipStream_t)stream) : Launch<EPI_STORE>::run(a, b, (hipStream_t)stream);
 }

@@ -502,11 +502,11 @@ class Llama {
         if (image(ws.h, d, bl.post_attention_layernorm, d, bl.dgate.type) || mrs_dec_gate_up_img(&bl.dgate, &bl.dup, ff, ws.act_img, 0, ws.act, ff, b, s))
           return fail("mrs_dec_gate_up_img refused");
       } else if (mrs_dec_gate_up(&bl.dgate, &bl.dup, ff, nullptr, ws.h, d, bl.post_attention_layernorm, cfg.rms_eps, 0, ws.act, ff, b, s)) return fail("mrs_dec_gate_up refused");
-      const int drc = imgb && bl.ddown.type != Q8_0 ? (image(ws.act, ff, nullptr, ff, bl.ddown.type) || mrs_dec_proj_img(&bl.ddown, d, ws.act_img, ws.h, d, 1, rs, b, s))
+      const int drc = imgb ? (image(ws.act, ff, nullptr, ff, bl.ddown.type) || mrs_dec_proj_img(&bl.ddown, d, ws.act_img, ws.h, d, 1, rs, b, s))
                                                     : mrs_dec_proj(&bl.ddown, d, nullptr, ws.act, ff, nullptr, 0.f, ws.h, d, 1, rs, nullptr, b, s);
       if (drc || all_reduce(ws.h, (size_t)b * d, s)) return fail("down_proj failed: %s", g_last_error.c_str());
     }
-    const int lrc = imgb && dlm_head.type != Q8_0 ? (image(ws.h, d, ln_f, d, dlm_head.type) || mrs_dec_proj_img(&dlm_head, cfg.vocab_size, ws.act_img, bufs.logits, cfg.vocab_size, 0, 1.0f, b, s))
+    const int lrc = imgb ? (image(ws.h, d, ln_f, d, dlm_head.type) || mrs_dec_proj_img(&dlm_head, cfg.vocab_size, ws.act_img, bufs.logits, cfg.vocab_size, 0, 1.0f, b, s))
                                                   : mrs_dec_proj(&dlm_head, cfg.vocab_size, nullptr, ws.h, d, ln_f, cfg.rms_eps, bufs.logits, cfg.vocab_size, 0, 1.0f, nullptr, b, s);
     if (lrc) return fail("lm_head refused");
     return 0;

@@ -300,7 +300,7 @@ def check_image_qkv(O, be, tq, tv, heads, kvh, k, b, neox):
     assert np.count_nonzero(res[1][0]) > 0 and np.count_nonzero(res[1][1]) > 0
 
 
-@pytest.mark.parametrize("tname,n,k,b,norm", [("Q4_K", 24, 1024, 3, True), ("Q6_K", 16, 512, 8, False), ("Q4_K", 8, 14336, 8, False), ("Q5_K", 12, 768, 5, True)])
+@pytest.mark.parametrize("tname,n,k,b,norm", [("Q4_K", 24, 1024, 3, True), ("Q6_K", 16, 512, 8, False), ("Q4_K", 8, 14336, 8, False), ("Q5_K", 12, 768, 5, True), ("Q8_0", 16, 512, 4, True)])
 def test_image_proj_host_emulation(oracle, tname, n, k, b, norm):
     check_image_proj(oracle, HostBackend(), tname, n, k, b, norm)  # (k = 14336, b = 8: two column groups of four)
 
@@ -344,7 +344,7 @@ def test_image_entry_points_refuse_what_they_cannot_do_host_emulation(oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("tname,n,k,b,norm", [("Q4_K", 4096, 14336, 8, False), ("Q6_K", 4096, 14336, 5, False), ("Q4_K", 2048, 4096, 8, True), ("Q6_K", 512, 28672, 8, False),
-                                              ("Q4_K", 1000, 4096, 2, True)])
+                                              ("Q4_K", 1000, 4096, 2, True), ("Q8_0", 1024, 4096, 8, True), ("Q8_0", 512, 14336, 6, False)])
 def test_image_proj_gpu(oracle, dev, tname, n, k, b, norm):
     check_image_proj(oracle, GpuBackend(dev), tname, n, k, b, norm)
 
