@@ -248,6 +248,11 @@ class Llama:
         self._p2p = p2p
         self._L.mrs_llama_set_p2p.argtypes = [C.c_void_p, C.c_void_p]
         self._chk(self._L.mrs_llama_set_p2p(self._h, p2p.handle if p2p is not None else None))
+        # a captured decode graph has the OLD route's kernels and its Comm struct baked in by value: replaying it after a detach would keep running the dead route
+        # (sticky error state -> NaN sums -> greedy tokens from NaN logits, and nobody reads the error word any more).  Drop it; replay() raises until
+        # capture_decode_graph() is called again.
+        self._graph = None
+        self._replays_left = None
 
     def p2p_error(self) -> int:
         """THIS rank's error word of the peer-mailbox route (blocking device read; call where the host synchronises anyway -- after a run of decode steps, before
@@ -382,6 +387,8 @@ class Llama:
             t.copy_(v)
 
     def replay(self) -> None:
+        if self._graph is None:
+            raise RuntimeError("replay(): no decode graph is captured (set_p2p() / p2p_sync_error() drop the graph of the old all-reduce route: capture_decode_graph() again)")
         # the captured step advances device-side state; refuse to run it past the buffers it indexes (tokens_out, block table, RoPE tables)
         if self._replays_left is None:  # one read-back per set_state(): replays that stay inside the context window and the token buffer
             b = getattr(self, "_graph_batch", None) or self.positions.numel()  # only the sequences of the captured batch count (stale entries of earlier, larger batches do not)

@@ -5,6 +5,7 @@ set -u
 export TMPDIR=/tmp
 OUT=gpurun_out/${1:-final}
 mkdir -p $OUT
+python -c "import bench; print(bench.source_digest())" > $OUT/source_digest.txt
 timeout 1800 python -m pytest tests -q -m gpu -rf > $OUT/pytest_gpu_full.log 2>&1
 (grep -E "passed|failed|error|FAILED|Fatal|fault" $OUT/pytest_gpu_full.log | tail -12) > $OUT/pytest_gpu.log
 (timeout 900 python bench.py 2>&1 | tail -1) > $OUT/bench_default.log
