@@ -444,6 +444,66 @@ def first_flip_leg(model, cfg, ref_w, positions=6):
     return out
 
 
+def moe_parity_leg(dev, layers=4, P=16, D=4):
+    """Parity record of the configs[4] leg: a `layers`-layer model of Mixtral-8x7B's layer shape (8 experts, top-2, hidden 4096, ffn 14336),
+    N(0, 0.02^2) weights through the device ISQ quantizers, on the GPU and on the host cores:
+      (1) bit-exact claims, GPU vs GPU: prefill(prompt) == decoding the prompt token by token (last-position logits and every K / V page) -- the prompt runs in the decode
+          engine's arithmetic (grouped exact GEMMs over the expert-sorted routes, csrc/ext_gemm_qi.hip);
+      (2) distances to the CPU restatement (oracle/llama_ref.py mode "engine"; its router / expert combination is an f64 restatement of SparseMoeBlock::forward, so this is a
+          tolerance, not bit identity): last prompt position + D teacher-forced decode positions, max |dlogit| / max |logit| and arg-max agreement."""
+    import gc
+    import numpy as np
+    import torch
+    from mistralrs_amd.llama import LlamaConfig, rope_tables
+    from oracle import llama_ref, oracle as O
+    O.build()
+    cfg = LlamaConfig.mixtral_8x7b(max_batch=1, max_context_len=64, max_position_embeddings=8192)
+    cfg.num_layers = layers
+    model = build_model(cfg, dev, seed=0, max_new_tokens=8, quant="q4_k_m", weights="gaussian")
+    exact = bool(model.prefill_is_exact)
+    prompt = [(1000 + i % 2048) % cfg.vocab_size for i in range(P)]
+    nb = (P + cfg.block_size - 1) // cfg.block_size
+
+    def pages():
+        out = []
+        for kc, vc in zip(model.key_caches, model.value_caches):
+            blk = model.block_tables[0, :nb].long()
+            out.append((kc[blk].clone().view(torch.int16), vc[blk].clone().view(torch.int16)))
+        return out
+    f32 = lambda t: t.float().cpu().numpy()
+    lp = f32(model.prefill(prompt, 0))
+    pp = pages()
+    for pos, t in enumerate(prompt):
+        model.set_state([t], [pos])
+        ld = f32(model.forward_logits(1)[0])
+    pd = pages()
+    same_pages = all(bool(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])) for a, b in zip(pp, pd))
+    w = host_weights(model)
+    cos, sin = rope_tables(cfg)
+    O.set_threads(min(64, os.cpu_count() or 1))
+    ref = llama_ref.LlamaRef(cfg, w, cos, sin, kv_dtype="bf16", mode="engine", attn_bpw=1)
+    for pos, t in enumerate(prompt):
+        lc = np.asarray(ref.step(t, pos), dtype=np.float32)
+    rel, agree = [float(np.abs(ld - lc).max() / np.abs(lc).max())], [int(ld.argmax() == lc.argmax())]
+    tok = int(lc.argmax())
+    for i in range(D):
+        lc = np.asarray(ref.step(tok, P + i), dtype=np.float32)
+        model.set_state([tok], [P + i])
+        g = f32(model.forward_logits(1)[0])
+        rel.append(float(np.abs(g - lc).max() / np.abs(lc).max()))
+        agree.append(int(g.argmax() == lc.argmax()))
+        tok = int(lc.argmax())
+    out = {"model": f"{layers} layers of Mixtral-8x7B's shape (8 experts, top-2), N(0, 0.02^2) through the device ISQ quantizers (Q4_K_M type map)", "prompt_tokens": P, "decode_positions": D,
+           "prompt_arithmetic": "decode engine's (exact)" if exact else "bf16-operand MFMA",
+           "prefill_logits_equal_token_by_token_decode": bool(np.array_equal(lp, ld)), "kv_pages_prefill_equal_token_by_token_decode": bool(same_pages),
+           "vs_cpu_restatement_max_logit_error_over_max_logit": [round(x, 6) for x in rel], "argmax_agree_with_cpu_restatement": f"{sum(agree)} / {len(agree)}",
+           "oracle_pinned": False}
+    del model, ref, w
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
 def extra_config(kind, dev, steps=64, warmup=4, prompt_len=512):
     """A second BASELINE.json configuration on the same GPU, after the headline run (N = 1, default flags only): the same timed_run() on a freshly built model.
     kind: "70b" = configs[3]'s model (Llama-3-70B Q4_K_M, 2048-token prompt) on ONE GPU (40 GB of weights); "q8_0_isq" = configs[2] (Llama-3-8B, every linear quantized in situ from bf16 to Q8_0 on the GPU), "mixtral" = configs[4]'s model on ONE GPU
@@ -461,8 +521,8 @@ def extra_config(kind, dev, steps=64, warmup=4, prompt_len=512):
         name, wdesc = "Llama-3-70B GGUF Q4_K_M on ONE GPU (configs[3]'s model; its TP = 8 form is `bench.py --gpus 8`)", "N(0, 0.02^2) through the device ISQ quantizers"
     elif kind == "mixtral":
         cfg = LlamaConfig.mixtral_8x7b(max_batch=1, max_context_len=max_ctx, max_position_embeddings=max(8192, max_ctx))
-        model = build_model(cfg, dev, seed=0, max_new_tokens=warmup + steps + 8, quant="q4_k_m", weights="blocks")
-        name, wdesc = "Mixtral-8x7B-shaped (8 experts, top-2) GGUF Q4_K_M, TP=1", "random valid block bytes (46.7 B parameters: the gaussian + quantize pass is skipped to bound the run)"
+        model = build_model(cfg, dev, seed=0, max_new_tokens=warmup + steps + 8, quant="q4_k_m", weights="gaussian")
+        name, wdesc = "Mixtral-8x7B-shaped (8 experts, top-2) GGUF Q4_K_M, TP=1", "N(0, 0.02^2) through the device ISQ quantizers (46.7 B parameters, expert stacks quantized as [8 x 14336, 4096] tensors)"
     else:
         cfg = LlamaConfig.llama3_8b(max_batch=1, max_context_len=max_ctx, max_position_embeddings=max(8192, max_ctx))
         model = build_model(cfg, dev, seed=0, max_new_tokens=warmup + steps + 8, quant="q8_0_isq", weights="gaussian")
@@ -490,6 +550,11 @@ def extra_config(kind, dev, steps=64, warmup=4, prompt_len=512):
     del model
     gc.collect()
     torch.cuda.empty_cache()
+    if kind == "mixtral":
+        try:
+            out["parity"] = moe_parity_leg(dev)
+        except Exception as e:  # reported extra
+            out["parity"] = {"failed": f"{type(e).__name__}: {e}"}
     return out
 
 

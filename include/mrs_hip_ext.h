@@ -70,6 +70,9 @@ int mrs_dec_proj_top2(const mrs_dec_mat *w, int n, const int32_t *expert_sel, co
 /* (RmsNorm when norm_w) + GEMV; mode 0: out = W x; mode 1: out = out * resid_scale + s * W x with s = *acc_scale (NULL: 1) */
 int mrs_dec_proj(const mrs_dec_mat *w, int n, const int32_t *expert_sel, const float *x, int ldx, const float *norm_w, float eps, float *out,
                  int ld_out, int mode, float resid_scale, const float *acc_scale, int b, void *stream);
+/* lm_head of a greedy batch-1 step: out = W . RmsNorm(x) and the launch's arg-max as a packed key -> atomicMax(*amax) (u64, zero before the launch; see
+ * mrs_sample_advance_embed) */
+int mrs_dec_proj_argmax(const mrs_dec_mat *w, int n, const float *x, int ldx, const float *norm_w, float eps, float *out, int ld_out, void *amax, void *stream);
 /* bytes of the pre-quantized activation image of b columns of k values (the layout the GEMV prologue builds in LDS) */
 size_t mrs_dec_act_image_bytes(int k, int b);
 /* Decode attention of the engine in ONE launch (round 3 default): split-KV waves (32-token blocks, f32 online softmax through the reference's
@@ -102,6 +105,12 @@ int mrs_hqq_gemv(int bits, int dtype, const void *wq, const void *scale, const v
                  int N, int K, int b, void *stream);
 /* quantized (or f32/f16/bf16) embedding rows -> f32; role of QuantMethod::embedding_forward (lib.rs:1561, gguf/mod.rs:436) */
 int mrs_embedding(const void *table, int type, const int32_t *ids, float *out, int K, int tokens, void *stream);
+/* round 6, greedy batch-1 step: the arg-max of lm_head folded into its epilogue (mrs_dec_proj_argmax: one u64 packed (value, index) maximum, zero before the launch) and
+ * ONE launch that turns it into the next id, advances the device-resident decode state (mrs_sample_greedy_advance's updates) and gathers the next id's embedding row into
+ * h_next (mrs_embedding's values) -- the role of sample_cuda_top1_row (mistralrs-core/src/ops.rs:2206) + the next step's embedding lookup. */
+int mrs_sample_advance_embed(int32_t *next_ids, int32_t *tokens_out, int tokens_out_stride, int32_t *step_counter, int32_t *positions, uint32_t *context_lens,
+                             int64_t *slot_mapping, const uint32_t *block_tables, int max_blocks, int block_size, void *scratch, const void *table, int type, float *h_next,
+                             int K, void *stream);
 /* f32 rows -> Q8_1 blocks: same bytes as launch_mmvq_gguf_quantize_q8_1_f32 with kx_padded = 32*stride_blocks */
 int mrs_quantize_rows_q8_1(const float *x, void *y, int K, int stride_blocks, int rows, void *stream);
 /* greedy top-1 (first maximum wins) + on-device advance of the decode state, so a captured decode step
@@ -223,7 +232,7 @@ size_t mrs_llama_workspace_bytes(const mrs_llama_config *cfg);
  * x2 != NULL: rows are silu(x) * x2, xtmp = f32 scratch [T][K]) -> the GEMM's operand buffers `act` (mrs_qi_act_bytes).  mrs_gemm_qi: out[t * ldo + n] (+)= W[n] . act[t].
  * mrs_prefill_attention_exact: causal attention of T prompt tokens over the paged cache, per token exactly mrs_dec_attention's arithmetic (context_lens[t] =
  * position + 1, block_table = the sequence's row, max_context_len = the model's).  Returns 0; -1 bad arguments / type; -2 shape beyond the kernel's LDS budget. */
-size_t mrs_gemm_qi_repack_bytes(int ggml_type, long long n, long long k); /* 0 = unsupported type (q4_k, q6_k) / shape (k % 256) */
+size_t mrs_gemm_qi_repack_bytes(int ggml_type, long long n, long long k); /* 0 = unsupported type (q4_k, q5_k, q6_k, q8_0 are taken) / shape (k % 256) */
 int mrs_gemm_qi_repack(const void *gguf_blocks, int ggml_type, long long n, long long k, void *dst, void *stream);
 size_t mrs_qi_act_bytes(int T, int K);
 int mrs_qi_quantize(const float *x, const float *x2, int ldx, const float *norm_w, float eps, int T, int K, void *act, float *xtmp, void *stream);
@@ -235,8 +244,21 @@ int mrs_gemm_qi_ws(const void *w_qi, int ggml_type, int N, int K, const void *ac
 int mrs_prefill_attention_exact(const float *q, const void *k_cache, const void *v_cache, const uint32_t *block_table, const uint32_t *context_lens, float *out, int T,
                                 int num_heads, int num_kv_heads, int head_size, int block_size, int q_stride, int kv_block_stride, int kv_head_stride, float scale,
                                 int max_context_len, int kv_dtype, int sliding_window, int max_prompt_ctx /* largest context_lens[t], or 0 */, void *stream);
-int mrs_llama_set_qi_tensor(void *model, const char *name, const void *planes); /* MFMA-order copy of a dense linear registered with mrs_llama_set_tensor */
-int mrs_llama_prefill_is_exact(void *model); /* 1: mrs_llama_prefill runs in the decode engine's arithmetic (every dense linear has its MFMA-order copy, decode engine on, TP = 1, no experts) */
+/* round 6 -- the other vec_dot partners and callers of the reference path (gguf/mod.rs:465-478; moe/experts/backends.rs:969-1100; distributed/layers.rs:965-975):
+ * mrs_qi_quantize_for: the operand rows in the format the weight type multiplies with (q8_0 weights: Q8_0 blocks per 32 values; K-quants: Q8_K; mrs_qi_quantize = the
+ * K-quant form).  mrs_gemm_qi* take q8_0 weights too: one v_mfma_i32_32x32x32_i8 per block of 32, p_b = ((float)isum_b dw_b) dx_b, terms added in block order.
+ * mrs_gemm_qi_win: the grouped form for sparse-MoE prompts: `act` holds T_total operand rows, only rows [win[0], win[1]) -- device ints, e.g. launch_moe_dispatch's
+ * expert_bounds + e -- are multiplied and only those rows of `out` are written; max_rows (host) bounds the window and sizes the grid.
+ * mrs_qi_gather_rows: operand rows of T tokens -> R = T * top_k rows in the order of `sorted_routes` (flat route index t * top_k + slot per sorted position), and
+ * inv[route] = its sorted position.  mrs_moe_fold_exact: h[t] <- fold over slots of h * (slot == 0 ? resid_scale : 1) + y_sorted[inv[t * top_k + slot]] * weights[..]
+ * (the decode step's RESID epilogue per expert slot).  mrs_resid_scale_add_f32: h <- h * resid_scale + y (tensor-parallel row-parallel projections before the all-reduce). */
+int mrs_qi_quantize_for(int w_ggml_type, const float *x, const float *x2, int ldx, const float *norm_w, float eps, int T, int K, void *act, float *xtmp, void *stream);
+int mrs_gemm_qi_win(const void *w_qi, int ggml_type, int N, int K, const void *act, int T_total, const int *win, int max_rows, float *out, int ldo, int accumulate, void *stream);
+int mrs_qi_gather_rows(int w_ggml_type, const void *act_src, int T, void *act_dst, int R, int K, const int *sorted_routes, int top_k, int *inv, void *stream);
+int mrs_moe_fold_exact(float *h, float resid_scale, const float *y_sorted, const int *inv, const float *weights, int T, int d, int top_k, void *stream);
+int mrs_resid_scale_add_f32(float *h, float resid_scale, const float *y, size_t n, void *stream);
+int mrs_llama_set_qi_tensor(void *model, const char *name, const void *planes); /* MFMA-order copy of a linear (dense, or a stacked expert tensor) registered with mrs_llama_set_tensor */
+int mrs_llama_prefill_is_exact(void *model); /* 1: mrs_llama_prefill runs in the decode engine's arithmetic (every linear has its MFMA-order copy, decode engine on; tensor-parallel shards and sparse-MoE layers included) */
 /* prompt arithmetic: 1 = the decode engine's (default where mrs_llama_prefill_is_exact allows it), 0 = bf16-operand MFMA GEMMs + MFMA flash attention (faster TTFT,
  * logits within ~1e-2 of the engine's instead of identical), -1 = follow the MRS_PREFILL_EXACT environment variable */
 int mrs_llama_set_prefill_mode(void *model, int exact);
@@ -259,6 +281,11 @@ int mrs_llama_set_kv_cache(void *model, int layer, void *key_cache, void *value_
 int mrs_llama_set_buffers(void *model, const mrs_llama_buffers *bufs);
 /* one decode step for b sequences: embedding -> L x Block -> norm -> lm_head -> greedy sample + state advance */
 int mrs_llama_decode_step(void *model, int b, void *stream);
+/* the chained greedy step (batch 1, decode engine): like mrs_llama_decode_step, but it expects the hidden-state buffer to hold the embedding row of input_ids already
+ * (left there by the previous chained step, or by mrs_llama_embed_state after the host changed input_ids) -- what Llama.capture_decode_graph captures */
+int mrs_llama_decode_step_chained(void *model, int b, void *stream);
+int mrs_llama_embed_state(void *model, int b, void *stream);
+int mrs_llama_chained_ok(void *model, int b);
 /* same graph without sampling: leaves logits [b, vocab] (parity tests read them) */
 int mrs_llama_forward_logits(void *model, int b, void *stream);
 /* Prefill of T prompt tokens of ONE sequence (role of the prompt branch of Llama::forward_embeds + PagedAttention::forward,

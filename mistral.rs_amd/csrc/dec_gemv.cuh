@@ -31,8 +31,17 @@ struct GemvArgs {
   int ubase[3], urem[3], upe; // a tensor's units over its workgroups: workgroup wi takes ubase + (wi < urem) units from wi * ubase + min(wi, urem) (computed by the launcher:
                               // the kernel used to open with two 64-bit and one 32-bit integer division -- ~300 scalar instructions ahead of the first request of every
                               // launch); upe = units per expert slot
+  unsigned long long *amax;   // EPI_STORE, one column (round 6): the launch's arg-max folded into the epilogue -- atomicMax of the packed (value, index) key of the
+                              // workgroup's largest output (ext_decode.hip pack_max: largest value, lowest index; what argmax_partial_kernel computes from the stored
+                              // logits in a launch of its own, sample_cuda_top1_row's role, mistralrs-core/src/ops.rs:2206); nullptr = off
   unsigned long long *tl;
 };
+// order-preserving key of (value, index): larger value wins, then the smaller index (== ext_decode.hip pack_max)
+__device__ __forceinline__ unsigned long long pack_max_key(float v, int idx) {
+  unsigned u = __float_as_uint(v);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ((unsigned long long)u << 32) | (unsigned)(0x7fffffff - idx);
+}
 
 // TMASK: which weight formats a kernel instantiation contains (bit 0 Q4_K, 1 Q5_K, 2 Q6_K, 3 Q8_0).  One kernel with all four carries the register
 // footprint of the fattest format; the QKV phase (three tensors, usually two formats, the heaviest epilogue) is instantiated per format set.
@@ -50,7 +59,7 @@ __host__ __device__ constexpr int tmask_of(int type) { return type == T_Q4_K ? T
 template <int N> struct AuxV { float a[N], b[N]; };
 
 template <int NCOLS, int EPI, int TMASK, bool RING2>
-__device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float *red, int *ctr) {
+__device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float *red, int *ctr, unsigned long long *best) {
   const int tid0 = tid_opaque();
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6), lane = tid0 & 63;
   const int K = a.K;
@@ -133,7 +142,10 @@ __device__ __forceinline__ void gemv_phase(const GemvArgs &a, char *smem, float 
         for (int c = 0; c < NCOLS; ++c) {
           float *o = a.out + (size_t)c * a.out_stride + row0 + rr;
           if constexpr (EPI == EPI_RESID) *o = ax.a[c] * a.resid_scale + sum[c] * ascale;
-          else *o = sum[c];
+          else {
+            *o = sum[c];
+            if constexpr (NCOLS == 1) { if (a.amax) { const unsigned long long key = pack_max_key(sum[c], row0 + rr); *best = key > *best ? key : *best; } }
+          }
         }
       }
     };
@@ -259,7 +271,24 @@ __global__ void __launch_bounds__(NT) dec_gemv_kernel(const GemvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ float red[8 * 8];  // RMSNorm partials: [column][wave]
   __shared__ int ctr;           // the workgroup's unit counter
-  gemv_phase<NCOLS, EPI, TMASK, RING2>(a, smem, red, &ctr);
+  if constexpr (EPI == EPI_STORE && NCOLS == 1) {
+    __shared__ unsigned long long wbest[NW];
+    unsigned long long best = 0ull;
+    gemv_phase<NCOLS, EPI, TMASK, RING2>(a, smem, red, &ctr, &best);
+    if (a.amax) {  // kernel-argument uniform
+      const int tid = tid_opaque();
+#pragma unroll
+      for (int m = 32; m > 0; m >>= 1) { const unsigned long long o = __shfl_xor(best, m, 64); best = o > best ? o : best; }
+      if ((tid & 63) == 0) wbest[tid >> 6] = best;
+      __syncthreads();
+      if (tid == 0) {
+        unsigned long long b2 = wbest[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) b2 = wbest[w] > b2 ? wbest[w] : b2;
+        if (b2) atomicMax(a.amax, b2);  // one per workgroup (~12 ns each on one address); a workgroup without rows keeps 0
+      }
+    }
+  } else gemv_phase<NCOLS, EPI, TMASK, RING2>(a, smem, red, &ctr, nullptr);
 }
 
 

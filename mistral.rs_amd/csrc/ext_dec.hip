@@ -467,6 +467,17 @@ extern "C" int mrs_dec_proj(const mrs_dec_mat_c *w, int n, const int32_t *expert
   return mode ? Launch<EPI_RESID>::run(a, b, (hipStream_t)stream) : Launch<EPI_STORE>::run(a, b, (hipStream_t)stream);
 }
 
+// lm_head of a greedy decode step (round 6): out = W . RmsNorm(x) for ONE column, and the arg-max of the launch folded into its epilogue: every workgroup's largest
+// output as a packed (value, index) key -> atomicMax(amax) (amax: one u64, zero before the launch; mrs_sample_advance_embed consumes and re-zeroes it).  The role of
+// sample_cuda_top1_row (mistralrs-core/src/ops.rs:2206): one pass over the logits, here while they are still in registers.
+extern "C" int mrs_dec_proj_argmax(const mrs_dec_mat_c *w, int n, const float *x, int ldx, const float *norm_w, float eps, float *out, int ld_out, void *amax, void *stream) {
+  GemvArgs a{};
+  if (!w || !amax || !make_mat(a.m[0], w->planes, w->type, w->n, w->k) || n <= 0 || w->n != n) return -1;
+  a.nrows[0] = n; a.K = (int)w->k; a.x = x; a.ldx = ldx; a.norm_w = norm_w; a.eps = eps; a.out = out; a.out_stride = ld_out; a.resid_scale = 1.0f;
+  a.amax = (unsigned long long *)amax;
+  return Launch<EPI_STORE>::run(a, 1, (hipStream_t)stream);
+}
+
 // o_proj & friends on activations the producer already quantized: x_img = the LDS image of b columns of k values, in the quantization w's type takes (Q8_K for the
 // K-quants: what mrs_dec_attention writes; Q8_0 for Q8_0 weights: mrs_dec_act_image with that weight type -- the caller pairs them, the image carries no tag)
 extern "C" int mrs_dec_proj_img(const mrs_dec_mat_c *w, int n, const void *x_img, float *out, int ld_out, int mode, float resid_scale, int b, void *stream) {

@@ -463,6 +463,38 @@ __global__ void __launch_bounds__(64) sample_advance_kernel(const SampleArgs a) 
   if (c == 0) *a.step_counter = step + 1;
 }
 
+// round 6, batch 1: sample_advance_kernel + the NEXT step's embedding gather in one launch (the captured decode graph then opens with layer 0's qkv: the step is two
+// launches shorter -- argmax_partial_kernel lives in lm_head's epilogue, mrs_dec_proj_argmax, and embedding_kernel here).  a.scratch[0] holds the packed maximum.
+struct EmbedNext { const uint8_t *table; int type; float *h; int K; };
+__global__ void __launch_bounds__(256) sample_advance_embed_kernel(const SampleArgs a, const EmbedNext e) {
+  __shared__ int s_idx;
+  if (threadIdx.x == 0) {
+    const int idx = 0x7fffffff - (int)(a.scratch[0] & 0xffffffffu);
+    a.scratch[0] = 0;
+    a.next_ids[0] = idx;
+    const int step = *a.step_counter;
+    if (a.tokens_out && step < a.tokens_out_stride) a.tokens_out[step] = idx;
+    const int pos = a.positions[0] + 1;
+    a.positions[0] = pos;
+    a.context_lens[0] = (uint32_t)pos + 1;
+    const int blk = pos / a.block_size;
+    a.slot_mapping[0] = blk < a.max_blocks ? (int64_t)a.block_tables[blk] * a.block_size + pos % a.block_size : (int64_t)-1;
+    *a.step_counter = step + 1;
+    s_idx = idx;
+  }
+  __syncthreads();
+  const int64_t id = s_idx;
+  const int K = e.K;
+  float *o = e.h;
+  if (e.type == 0) { const float *src = (const float *)e.table + id * K; for (int i = threadIdx.x; i < K; i += 256) o[i] = src[i]; return; }
+  if (e.type == 1) { const uint16_t *src = (const uint16_t *)e.table + id * K; for (int i = threadIdx.x; i < K; i += 256) o[i] = half_bits_to_float(src[i]); return; }
+  if (e.type == 30) { const uint16_t *src = (const uint16_t *)e.table + id * K; for (int i = threadIdx.x; i < K; i += 256) o[i] = bf16_bits_to_float(src[i]); return; }
+  const uint8_t *row = e.table + (size_t)id * hot_row_bytes(e.type, K);
+  for (int s = threadIdx.x; s < K / 32; s += 256) {
+    MRS_HOT_TYPE_SWITCH(e.type, dequant_slice<TT>(row, s, o);)
+  }
+}
+
 // f32 [rows][K] -> Q8_1 blocks, same bytes as launch_mmvq_gguf_quantize_q8_1_f32 (used after attention)
 __global__ void __launch_bounds__(256) quantize_rows_kernel(const float *__restrict__ x, uint8_t *__restrict__ y, int K, int stride_blocks) {
   const int c = blockIdx.y;
@@ -683,6 +715,18 @@ extern "C" int mrs_embedding(const void *table, int type, const int32_t *ids, fl
 extern "C" int mrs_quantize_rows_q8_1(const float *x, void *y, int K, int stride_blocks, int rows, void *stream) {
   if (rows <= 0) return 0;
   hipLaunchKernelGGL(quantize_rows_kernel, dim3((stride_blocks * 32 + 255) / 256, rows), dim3(256), 0, (hipStream_t)stream, x, (uint8_t *)y, K, stride_blocks);
+  return 0;
+}
+
+// batch 1, the maximum already in scratch[0] (mrs_dec_proj_argmax): next id, state advance and h_next = embedding row of the next id (mrs_embedding's values)
+extern "C" int mrs_sample_advance_embed(int32_t *next_ids, int32_t *tokens_out, int tokens_out_stride, int32_t *step_counter, int32_t *positions, uint32_t *context_lens,
+                                        int64_t *slot_mapping, const uint32_t *block_tables, int max_blocks, int block_size, void *scratch, const void *table, int type,
+                                        float *h_next, int K, void *stream) {
+  if (!scratch || !table || !h_next || K <= 0 || !(type == 0 || type == 1 || type == 30 || hot_type(type))) return -1;
+  SampleArgs a{nullptr, 0, 1, next_ids, tokens_out, tokens_out_stride, step_counter, positions, context_lens, slot_mapping, block_tables, max_blocks, block_size,
+               (unsigned long long *)scratch};
+  EmbedNext e{(const uint8_t *)table, type, h_next, K};
+  hipLaunchKernelGGL(sample_advance_embed_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a, e);
   return 0;
 }
 

@@ -40,7 +40,8 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 constexpr int REC_Q4K = 4096 + 512 + 128, REC_Q6K = 8192 + 512 + 128, REC_Q5K = REC_Q6K;  // Q5_K: the 5-bit values as bytes, like Q6_K's 6-bit ones
 __host__ __device__ constexpr int rec_bytes_qi(int type) { return type == T_Q4_K ? REC_Q4K : REC_Q6K; }
-__host__ __device__ inline bool qi_type(int t) { return t == T_Q4_K || t == T_Q5_K || t == T_Q6_K; }
+// Q8_0 (round 6): a "superblock" = 8 consecutive blocks of 32; the record holds the int8 quants as they are (8 pieces) + the 8 f16 block scales per row
+__host__ __device__ inline bool qi_type(int t) { return t == T_Q4_K || t == T_Q5_K || t == T_Q6_K || t == T_Q8_0; }
 __host__ __device__ inline size_t qi_tensor_bytes(int type, long long n, long long k) { return (size_t)((n + 31) / 32) * (size_t)(k / 256) * rec_bytes_qi(type); }
 
 // the k order inside a group of 8 operand slots: slot jj holds element PERM[jj] (the half2 registers of the weight operand are (e0, e2), (e1, e3), (e4, e6), (e5, e7):
@@ -102,6 +103,18 @@ __global__ void __launch_bounds__(256) qi_repack_kernel(const uint8_t *__restric
       *(v4u *)(rec + 8192 + (size_t)nn * 16) = *(const v4u *)buf;
       *(uint32_t *)(rec + 8704 + (size_t)nn * 4) = have ? ((uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24)) : 0u;
     }
+  } else if constexpr (TYPE == T_Q8_0) {  // 8 x block_q8_0 (34 B: f16 d, 32 int8): piece g = block g, the lane's bytes 16 hf .. 16 hf + 15 (the i8 MFMA's k order)
+    const uint8_t *b = src + ((size_t)row * S + sb) * 272;
+    for (int g = 0; g < 8; ++g) {
+      for (int k = 0; k < 16; ++k) buf[k] = have ? b[34 * g + 2 + 16 * hf + k] : 0;
+      *(v4u *)(rec + ((size_t)g * 64 + lane) * 16) = *(const v4u *)buf;
+    }
+    if (hf == 0) {
+      const int nn = lane & 31;
+      for (int g = 0; g < 8; ++g) { buf[2 * g] = have ? b[34 * g] : 0; buf[2 * g + 1] = have ? b[34 * g + 1] : 0; }
+      *(v4u *)(rec + 8192 + (size_t)nn * 16) = *(const v4u *)buf;
+      *(uint32_t *)(rec + 8704 + (size_t)nn * 4) = 0u;
+    }
   } else {  // Q6_K: the 6-bit values as bytes (0 .. 63), 16 int8 scales, d
     const uint8_t *b = src + ((size_t)row * S + sb) * 210, *ql = b, *qh = b + 128;
     auto q6 = [&](int e) { const int hh = e / 128, pos = e % 32, qt = (e % 128) / 32, ii = hh * 64 + pos + (qt % 2) * 32;
@@ -128,6 +141,8 @@ struct QuantArgs {
   const float *x, *x2; int ldx; const float *norm_w; float eps; int K, T;
   _Float16 *qf; float *yd; _Float16 *bsf;
   float *xtmp;  // GLU: f32 scratch [T][K] for the activated row (the prologue reads its input from memory)
+  int mode;     // ACT_Q8K (K-quant weights) / ACT_Q80 (Q8_0 weights: quantize_row_q8_0 per 32 values; outputs q8 [S][T][256] int8 in element order at `qf`, the block
+                // scales f32(f16(d)) block-major [S][8][T] at `bsf`)
 };
 template <bool GLU>
 __global__ void __launch_bounds__(NT) qi_quantize_kernel(const QuantArgs a) {
@@ -147,9 +162,22 @@ __global__ void __launch_bounds__(NT) qi_quantize_kernel(const QuantArgs a) {
   }
   const int qw = __builtin_amdgcn_readfirstlane(tid >> 6);
   const ActRegs<1> pre = act_issue_all<1>(xr, (unsigned)K * 4u, a.norm_w, K, qw);
-  act_finish_all<1>(smem, red, pre, xr, K, a.norm_w, a.eps, K, ACT_Q8K, qw);
+  act_finish_all<1>(smem, red, pre, xr, K, a.norm_w, a.eps, K, a.mode, qw);
   __syncthreads();
-  const Act act = act_view(smem, K, 1, ACT_Q8K);
+  const Act act = act_view(smem, K, 1, a.mode);
+  if (a.mode == ACT_Q80) {
+    int8_t *q8 = (int8_t *)a.qf;
+    float *yd8 = (float *)a.bsf;
+    for (int gi = tid; gi < S * 16; gi += NT) {  // 16-byte chunks of the superblock's 256 quants
+      const int sb = gi >> 4, ch = gi & 15;
+      *(v4u *)(q8 + ((size_t)sb * a.T + t) * 256 + ch * 16) = *(const v4u *)(act.q + act.qoff(sb) + ch * 16);
+    }
+    for (int i = tid; i < S * 8; i += NT) {
+      const int sb = i >> 3, b = i & 7;
+      yd8[((size_t)sb * 8 + b) * a.T + t] = act.d[(size_t)sb * act.dw + b];
+    }
+    return;
+  }
   // thread -> (superblock, group of 8 elements): 32 groups per superblock
   for (int gi = tid; gi < S * 32; gi += NT) {
     const int sb = gi >> 5, g8 = gi & 31;
@@ -172,6 +200,8 @@ struct GemmArgs {
   const _Float16 *qf; const float *yd; const _Float16 *bsf;
   float *out; int ldo; int accumulate;  // out[t * ldo + n] (+)= row sum
   float *part; int ksplit;              // ksplit = 4: workgroup z multiplies run z of the row's superblocks only and writes its sum to part[z][t][n]; the reduce kernel combines
+  const int *win;                       // device {begin, end}: only the operand rows [begin, end) take part (one expert's routes of a grouped MoE prompt GEMM: the bounds
+                                        // come from launch_moe_dispatch on the device, the grid is sized for the worst case and tiles past `end` leave); nullptr = all T rows
 };
 constexpr int TN = 128, TT = 128;                   // workgroup tile: weight rows x tokens
 constexpr int GT = 512;                             // 8 waves: 4 (32-row panels) x 2 (64-token halves); two waves per SIMD overlap each other's MFMA and VALU phases
@@ -199,7 +229,10 @@ __global__ void __launch_bounds__(GT) gemm_qi_kernel(const GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = tid_opaque(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nn = lane & 31, hf = lane >> 5;
-  const int n0 = blockIdx.x * TN, t0 = blockIdx.y * TT;
+  const int n0 = blockIdx.x * TN;
+  const int tbeg = a.win ? __builtin_amdgcn_readfirstlane(a.win[0]) : 0, tend = a.win ? __builtin_amdgcn_readfirstlane(a.win[1]) : a.T;
+  const int t0 = tbeg + blockIdx.y * TT;
+  if (t0 >= tend) return;  // workgroup-uniform
   const int wn = wave & 3, wt = wave >> 2;  // the wave's 32-row panel / 64-token half of the tile
   const int S = a.K / 256, Cs = (S + 3) / 4;
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, (short)0, (int)a.w_bytes, 0x00020000);
@@ -216,7 +249,7 @@ __global__ void __launch_bounds__(GT) gemm_qi_kernel(const GemmArgs a) {
   // stage superblock sb of the tile's tokens into buffer `buf` by LDS-DMA.  acts: 128 rows x 32 chunks of 16 B, chunk ch of row tr at position ch ^ (tr & 31);
   // a DMA instruction fills 1 KiB = 2 rows lane by lane, so lane l of the instruction for rows (2 i, 2 i + 1) fetches chunk (l & 31) ^ (tr & 31) of row
   // tr = 2 i + (l >> 5).  Rows past T re-read the last token (their outputs are never stored).
-  const int tlast = a.T - 1 - t0;  // last existing row of the tile
+  const int tlast = tend - 1 - t0;  // last existing row of the tile
   auto stage = [&](int sb, int buf) {
     char *base = smem + buf * LDS_BUF;
     const char *gq = (const char *)a.qf + ((size_t)sb * a.T + t0) * 512;
@@ -256,7 +289,7 @@ __global__ void __launch_bounds__(GT) gemm_qi_kernel(const GemmArgs a) {
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
           const int t = t0 + wt * 64 + tt * 32 + 8 * (v >> 2) + 4 * hf + (v & 3);
-          if (n < a.N && t < a.T) a.part[((size_t)blockIdx.z * a.T + t) * a.N + n] = 0.f;
+          if (n < a.N && t < tend) a.part[((size_t)blockIdx.z * a.T + t) * a.N + n] = 0.f;
         }
     }
     return;
@@ -464,8 +497,147 @@ __global__ void __launch_bounds__(GT) gemm_qi_kernel(const GemmArgs a) {
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
       const int t = t0 + wt * 64 + tt * 32 + 8 * (v >> 2) + 4 * hf + (v & 3);
-      if (n < a.N && t < a.T) {
+      if (n < a.N && t < tend) {
         if (a.ksplit > 1) a.part[((size_t)blockIdx.z * a.T + t) * a.N + n] = run[tt][v];  // one run per workgroup: its sum, combined by gemm_qi_reduce_kernel
+        else {
+          float *o = a.out + (size_t)t * a.ldo + n;
+          *o = a.accumulate ? *o + pend[tt][v] : pend[tt][v];
+        }
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ Q8_0 weights x Q8_0 activation rows (round 6; BASELINE configs[2])
+// The decode engine's Q8_0 term (dec_core2.cuh Tile<T_Q8_0>, oracle term_q8_0): per 32-value block the exact integer dot, p_b = ((float)isum_b dw_b) dx_b, the
+// superblock's T = p_0 + p_1 + ... + p_7 left to right; superblock terms and runs combine as for the K-quants.  One v_mfma_i32_32x32x32_i8 IS one block of 32 tokens x 32
+// weight rows (K = 32, int32 accumulate: exact); the fix-up (convert, two multiplies, one add per output and block) runs on the vector ALU beside the other wave's
+// MFMAs.  Same tile, staging and split scheme as gemm_qi_kernel; LDS per superblock: 128 tokens x 256 int8 (16-byte chunks XOR-swizzled by token & 15) + the block
+// scales [8][128] f32, double buffered by LDS-DMA.
+typedef int i4v __attribute__((ext_vector_type(4)));
+typedef int i16v __attribute__((ext_vector_type(16)));
+constexpr int L8_ACT = TT * 256, L8_YD = 8 * TT * 4, L8_BUF = L8_ACT + L8_YD, L8_TOTAL = 2 * L8_BUF;
+__global__ void __launch_bounds__(GT) gemm_q80_kernel(const GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = tid_opaque(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nn = lane & 31, hf = lane >> 5;
+  const int n0 = blockIdx.x * TN;
+  const int tbeg = a.win ? a.win[0] : 0, tend = a.win ? a.win[1] : a.T;  // the launch's token rows [tbeg, tend) of the operand buffers (one expert's routes; all rows when dense)
+  const int t0 = tbeg + blockIdx.y * TT;
+  if (t0 >= tend) return;
+  const int wn = wave & 3, wt = wave >> 2;
+  const int S = a.K / 256, Cs = (S + 3) / 4;
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, (short)0, (int)a.w_bytes, 0x00020000);
+  constexpr int REC = REC_Q6K;
+  struct WRegs { v4u q[8]; v4u hs; };
+  const unsigned panel = (unsigned)((n0 + wn * 32) >> 5);
+  // the weight registers are a ring in place: piece b of superblock sb + 1 is requested as soon as piece b of sb has been multiplied (a second register set for
+  // the next superblock spilled 68 VGPRs)
+  auto rec_of = [&](int sb) { return (panel * (unsigned)S + (unsigned)sb) * (unsigned)REC; };
+  auto load_piece = [&](WRegs &wr, unsigned rec, int c) { wr.q[c] = __builtin_amdgcn_raw_buffer_load_b128(rw, rec + (unsigned)(c * 64 + lane) * 16u, 0, 0); };
+  auto load_hs = [&](WRegs &wr, unsigned rec) { wr.hs = __builtin_amdgcn_raw_buffer_load_b128(rw, rec + 8192u + (unsigned)nn * 16u, 0, 0); };
+  auto load_w = [&](WRegs &wr, int sb) {
+    const unsigned rec = rec_of(sb);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) load_piece(wr, rec, c);
+    load_hs(wr, rec);
+  };
+  const int tlast = tend - 1 - t0;
+  const int8_t *q8 = (const int8_t *)a.qf;
+  const float *yd8 = (const float *)a.bsf;
+  auto stage = [&](int sb, int buf) {
+    char *base = smem + buf * L8_BUF;
+    const char *gq = (const char *)q8 + ((size_t)sb * a.T + t0) * 256;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // one DMA instruction = 1 KiB = 4 token rows; lane l -> row 4 quad + (l >> 4), chunk position l & 15
+      const int quad = wave * 4 + i;
+      const int tr = 4 * quad + (lane >> 4), trc = min(tr, tlast);
+      MRS_GLDS16(gq + (size_t)trc * 256 + (((lane & 15) ^ (tr & 15)) << 4), base + quad * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {  // block scales: wave w stages block w, 64 tokens per instruction
+      const int tr = i * 64 + lane;
+      MRS_GLDS4((const char *)yd8 + (((size_t)sb * 8 + wave) * a.T + t0 + min(tr, tlast)) * 4, base + L8_ACT + (wave * TT + i * 64) * 4);
+    }
+  };
+  float run[2][16], pend[2][16];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) { run[tt][v] = 0.f; pend[tt][v] = 0.f; }
+  WRegs wr;
+  const int sb_begin = a.ksplit > 1 ? (int)blockIdx.z * Cs : 0, sb_end = a.ksplit > 1 ? min(S, sb_begin + Cs) : S;
+  if (sb_begin >= sb_end) {
+    if (a.ksplit > 1) {  // a run without superblocks contributes +0
+      const int n = n0 + wn * 32 + nn;
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int t = t0 + wt * 64 + tt * 32 + 8 * (v >> 2) + 4 * hf + (v & 3);
+          if (n < a.N && t < tend) a.part[((size_t)blockIdx.z * a.T + t) * a.N + n] = 0.f;
+        }
+    }
+    return;
+  }
+  load_w(wr, sb_begin); stage(sb_begin, sb_begin & 1);
+  const int trow = wt * 64 + nn;
+  const i16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int sb = sb_begin; sb < sb_end; ++sb) {
+    const int buf = sb & 1;
+    MRS_WAIT_VMCNT0();
+    __syncthreads();
+    const bool more = sb + 1 < sb_end;
+    const unsigned rec_next = more ? rec_of(sb + 1) : 0xF0000000u;  // past the tensor: zeros, no traffic (the request stays unconditional: exact waits)
+    if (more) stage(sb + 1, buf ^ 1);
+    const char *act_s = smem + buf * L8_BUF;
+    const float *yd_s = (const float *)(act_s + L8_ACT);
+    float Tt[2][16];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const unsigned hw = b < 2 ? wr.hs.x : b < 4 ? wr.hs.y : b < 6 ? wr.hs.z : wr.hs.w;
+      const float dwb = half_bits_to_float((uint16_t)((b & 1) ? (hw >> 16) : (hw & 0xffffu)));
+      const i4v wq = __builtin_bit_cast(i4v, wr.q[b]);
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const i4v af = *(const i4v *)(act_s + (trow + 32 * tt) * 256 + (((2 * b + hf) ^ (nn & 15)) << 4));
+        const i16v is = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, wq, zero, 0, 0, 0);
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const float4 y4 = *(const float4 *)(yd_s + b * TT + wt * 64 + tt * 32 + 8 * q4 + 4 * hf);
+          const float yy[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int v = 4 * q4 + k;
+            const float p = ((float)is[v] * dwb) * yy[k];
+            Tt[tt][v] = b == 0 ? p : Tt[tt][v] + p;
+          }
+        }
+      }
+      load_piece(wr, rec_next, b);
+      if (b == 7) load_hs(wr, rec_next);
+      __builtin_amdgcn_sched_barrier(0);  // one block at a time: hoisting the MFMAs of later blocks keeps 16 result registers each alive (37 spilled VGPRs)
+    }
+    const bool cfirst = (sb % Cs) == 0;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) run[tt][v] = cfirst ? Tt[tt][v] : run[tt][v] + Tt[tt][v];
+    if ((sb + 1) % Cs == 0 || sb + 1 == sb_end) {
+      const bool first = sb < Cs;
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) pend[tt][v] = first ? run[tt][v] : pend[tt][v] + run[tt][v];
+    }
+  }
+  const int n = n0 + wn * 32 + nn;
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int t = t0 + wt * 64 + tt * 32 + 8 * (v >> 2) + 4 * hf + (v & 3);
+      if (n < a.N && t < tend) {
+        if (a.ksplit > 1) a.part[((size_t)blockIdx.z * a.T + t) * a.N + n] = run[tt][v];
         else {
           float *o = a.out + (size_t)t * a.ldo + n;
           *o = a.accumulate ? *o + pend[tt][v] : pend[tt][v];
@@ -501,6 +673,7 @@ extern "C" int mrs_gemm_qi_repack(const void *gguf_blocks, int type, long long n
   const dim3 grid((unsigned)((total + 255) / 256));
   if (type == T_Q4_K) hipLaunchKernelGGL(qi::qi_repack_kernel<T_Q4_K>, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t *)gguf_blocks, (uint8_t *)dst, n, (int)k, total);
   else if (type == T_Q5_K) hipLaunchKernelGGL(qi::qi_repack_kernel<T_Q5_K>, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t *)gguf_blocks, (uint8_t *)dst, n, (int)k, total);
+  else if (type == T_Q8_0) hipLaunchKernelGGL(qi::qi_repack_kernel<T_Q8_0>, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t *)gguf_blocks, (uint8_t *)dst, n, (int)k, total);
   else hipLaunchKernelGGL(qi::qi_repack_kernel<T_Q6_K>, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t *)gguf_blocks, (uint8_t *)dst, n, (int)k, total);
   return 0;
 }
@@ -520,10 +693,16 @@ static void qi_split(void *buf, int T, int K, _Float16 **qf, float **yd, _Float1
 }
 // x f32 [T][ldx] (-> RmsNorm with norm_w in the engine's order when norm_w != NULL) -> Q8_K per row -> operand buffers `act` (mrs_qi_act_bytes).
 // x2 != NULL: the row is silu(x) * x2 (the gate / up epilogue of the decode engine), xtmp = f32 scratch [T][K].
+// mrs_qi_quantize_for: the image format the weight type `w_type` multiplies with (Q8_0 weights: Q8_0 blocks; K-quants: Q8_K) -- GgufMatMul::forward_raw's
+// per-format vec_dot partner (gguf/mod.rs:465-478)
+extern "C" int mrs_qi_quantize_for(int w_type, const float *x, const float *x2, int ldx, const float *norm_w, float eps, int T, int K, void *act, float *xtmp, void *stream);
 extern "C" int mrs_qi_quantize(const float *x, const float *x2, int ldx, const float *norm_w, float eps, int T, int K, void *act, float *xtmp, void *stream) {
-  if (!x || !act || T <= 0 || K <= 0 || K % 256 || (x2 && !xtmp)) return -1;
+  return mrs_qi_quantize_for(T_Q4_K, x, x2, ldx, norm_w, eps, T, K, act, xtmp, stream);
+}
+extern "C" int mrs_qi_quantize_for(int w_type, const float *x, const float *x2, int ldx, const float *norm_w, float eps, int T, int K, void *act, float *xtmp, void *stream) {
+  if (!x || !act || T <= 0 || K <= 0 || K % 256 || (x2 && !xtmp) || !qi::qi_type(w_type)) return -1;
   qi::QuantArgs a{};
-  a.x = x; a.x2 = x2; a.ldx = ldx; a.norm_w = norm_w; a.eps = eps; a.K = K; a.T = T; a.xtmp = xtmp;
+  a.x = x; a.x2 = x2; a.ldx = ldx; a.norm_w = norm_w; a.eps = eps; a.K = K; a.T = T; a.xtmp = xtmp; a.mode = dec2::act_mode_for(w_type);
   qi_split(act, T, K, &a.qf, &a.yd, &a.bsf);
   const size_t lds = (dec2::act_bytes(K, 1) + 15) & ~(size_t)15;
   if (lds > 158 * 1024) return -2;
@@ -539,24 +718,115 @@ extern "C" int mrs_gemm_qi_ws(const void *w_qi, int type, int N, int K, const vo
 extern "C" int mrs_gemm_qi(const void *w_qi, int type, int N, int K, const void *act, int T, float *out, int ldo, int accumulate, void *stream) {
   return mrs_gemm_qi_ws(w_qi, type, N, K, act, T, out, ldo, accumulate, nullptr, 0, stream);
 }
+// mrs_gemm_qi_win: the grouped form (MoE prompts): `act` holds T_total operand rows, only rows [win[0], win[1]) (device ints) are multiplied and only those rows of `out`
+// are written; `max_rows` (host) bounds end - begin and sizes the grid.  No split launch (the expert GEMMs fill the chip).
+static int gemm_qi_launch(const void *w_qi, int type, int N, int K, const void *act, int T, const int *win, int max_rows, float *out, int ldo, int accumulate, void *workspace,
+                          size_t workspace_bytes, void *stream);
+extern "C" int mrs_gemm_qi_win(const void *w_qi, int type, int N, int K, const void *act, int T_total, const int *win, int max_rows, float *out, int ldo, int accumulate, void *stream) {
+  if (!win || max_rows <= 0 || max_rows > T_total) return -1;
+  return gemm_qi_launch(w_qi, type, N, K, act, T_total, win, max_rows, out, ldo, accumulate, nullptr, 0, stream);
+}
 extern "C" int mrs_gemm_qi_ws(const void *w_qi, int type, int N, int K, const void *act, int T, float *out, int ldo, int accumulate, void *workspace, size_t workspace_bytes,
                               void *stream) {
+  return gemm_qi_launch(w_qi, type, N, K, act, T, nullptr, T, out, ldo, accumulate, workspace, workspace_bytes, stream);
+}
+static int gemm_qi_launch(const void *w_qi, int type, int N, int K, const void *act, int T, const int *win, int max_rows, float *out, int ldo, int accumulate, void *workspace,
+                          size_t workspace_bytes, void *stream) {
   if (!w_qi || !act || !out || !qi::qi_type(type) || N <= 0 || T <= 0 || K <= 0 || K % 256) return -1;
   qi::GemmArgs a{};
   a.w = (const uint8_t *)w_qi; a.w_bytes = (unsigned)qi::qi_tensor_bytes(type, N, K); a.type = type; a.N = N; a.K = K; a.T = T;
   _Float16 *qf, *bsf; float *yd;
   qi_split((void *)act, T, K, &qf, &yd, &bsf);
   if ((size_t)(K / 256) * T * 512 >= 0x7fffffffull || qi::qi_tensor_bytes(type, N, K) >= 0xffffff00ull) return -2;
-  a.qf = qf; a.yd = yd; a.bsf = bsf; a.out = out; a.ldo = ldo; a.accumulate = accumulate;
-  dim3 grid((N + qi::TN - 1) / qi::TN, (T + qi::TT - 1) / qi::TT);
+  a.qf = qf; a.yd = yd; a.bsf = bsf; a.out = out; a.ldo = ldo; a.accumulate = accumulate; a.win = win;
+  dim3 grid((N + qi::TN - 1) / qi::TN, (max_rows + qi::TT - 1) / qi::TT);
   // few workgroups (o_proj / down_proj of a 512-token prompt: 128): one workgroup per run of superblocks, then the reduce -- the same additions in the same order
   static const int split_max = [] { const char *e = getenv("MRS_GEMM_QI_SPLIT_BELOW"); return e ? atoi(e) : 200; }();
   a.ksplit = 1; a.part = nullptr;
-  if ((int)(grid.x * grid.y) < split_max && K / 256 >= 4 && N % 4 == 0 && workspace && workspace_bytes >= (size_t)4 * T * N * 4) { a.ksplit = 4; a.part = (float *)workspace; grid.z = 4; }
-  if (type == T_Q4_K) { auto kern = qi::gemm_qi_kernel<T_Q4_K>; lds_attr_once((const void *)kern, 158 * 1024); hipLaunchKernelGGL(kern, grid, dim3(qi::GT), qi::LDS_TOTAL, (hipStream_t)stream, a); }
+  if (!win && (int)(grid.x * grid.y) < split_max && K / 256 >= 4 && N % 4 == 0 && workspace && workspace_bytes >= (size_t)4 * T * N * 4) { a.ksplit = 4; a.part = (float *)workspace; grid.z = 4; }
+  if (type == T_Q8_0) { auto kern = qi::gemm_q80_kernel; lds_attr_once((const void *)kern, 158 * 1024); hipLaunchKernelGGL(kern, grid, dim3(qi::GT), qi::L8_TOTAL, (hipStream_t)stream, a); }
+  else if (type == T_Q4_K) { auto kern = qi::gemm_qi_kernel<T_Q4_K>; lds_attr_once((const void *)kern, 158 * 1024); hipLaunchKernelGGL(kern, grid, dim3(qi::GT), qi::LDS_TOTAL, (hipStream_t)stream, a); }
   else if (type == T_Q5_K) { auto kern = qi::gemm_qi_kernel<T_Q5_K>; lds_attr_once((const void *)kern, 158 * 1024); hipLaunchKernelGGL(kern, grid, dim3(qi::GT), qi::LDS_TOTAL, (hipStream_t)stream, a); }
   else { auto kern = qi::gemm_qi_kernel<T_Q6_K>; lds_attr_once((const void *)kern, 158 * 1024); hipLaunchKernelGGL(kern, grid, dim3(qi::GT), qi::LDS_TOTAL, (hipStream_t)stream, a); }
   if (a.ksplit > 1) hipLaunchKernelGGL(qi::gemm_qi_reduce_kernel, dim3((unsigned)(((size_t)T * N / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a.part, out, T, N, ldo, accumulate);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ MoE prompts in the decode engine's arithmetic (round 6; BASELINE configs[4])
+// The decode step of a sparse-MoE layer (host/runtime.cpp forward_engine; SparseMoeBlock::forward, models/mixtral.rs:280-304) multiplies ONE token's quantized row by its
+// top-k experts' gate / up rows, quantizes silu(g) * u per expert slot, multiplies by that expert's down rows and folds the slots into the residual stream in slot order:
+// h <- (h * rs + w_0 s_0) * 1 + w_1 s_1 ...  A prompt does the same per token through the grouped form of the exact GEMM: the tokens' operand rows are gathered into
+// expert-sorted order (launch_moe_dispatch's table), every expert multiplies its window of rows (mrs_gemm_qi_win), and the fold below restores slot order per token.
+namespace mrs {
+namespace qi {
+// operand rows of `src` (T rows) -> `dst` (R rows): dst row r = src row sorted[r] / tk (sorted == nullptr: r / tk ... unused); inv[sorted[r]] = r.  One workgroup per row r.
+__global__ void __launch_bounds__(256) qi_gather_rows_kernel(const char *__restrict__ src, char *__restrict__ dst, int T, int R, int S, int mode, const int *__restrict__ sorted,
+                                                             int tk, int *__restrict__ inv, size_t off1s, size_t off2s, size_t off1d, size_t off2d) {
+  const int r = blockIdx.x, route = sorted[r], t = route / tk;
+  if (threadIdx.x == 0 && inv) inv[route] = r;
+  if (mode == ACT_Q80) {  // q8 [S][rows][256] at 0; block scales [S][8][rows] f32 at off2
+    for (int i = threadIdx.x; i < S * 16; i += 256) {
+      const int sb = i >> 4, ch = i & 15;
+      *(v4u *)(dst + ((size_t)sb * R + r) * 256 + ch * 16) = *(const v4u *)(src + ((size_t)sb * T + t) * 256 + ch * 16);
+    }
+    for (int i = threadIdx.x; i < S * 8; i += 256) ((float *)(dst + off2d))[(size_t)i * R + r] = ((const float *)(src + off2s))[(size_t)i * T + t];
+  } else {  // qf [S][rows][256] f16 at 0; yd [S][rows] f32 at off1; bsf [S][rows][16] f16 at off2
+    for (int i = threadIdx.x; i < S * 32; i += 256) {
+      const int sb = i >> 5, ch = i & 31;
+      *(v4u *)(dst + ((size_t)sb * R + r) * 512 + ch * 16) = *(const v4u *)(src + ((size_t)sb * T + t) * 512 + ch * 16);
+    }
+    for (int i = threadIdx.x; i < S * 2; i += 256) {
+      const int sb = i >> 1, ch = i & 1;
+      *(v4u *)(dst + off2d + ((size_t)sb * R + r) * 32 + ch * 16) = *(const v4u *)(src + off2s + ((size_t)sb * T + t) * 32 + ch * 16);
+    }
+    for (int sb = threadIdx.x; sb < S; sb += 256) ((float *)(dst + off1d))[(size_t)sb * R + r] = ((const float *)(src + off1s))[(size_t)sb * T + t];
+  }
+}
+// h[t][n] <- fold over the token's slots sl = 0 .. tk - 1 of  h * (sl == 0 ? rs : 1) + y[inv[t * tk + sl]][n] * w[t * tk + sl]  (two roundings per slot, the RESID
+// epilogue's expression: dec_gemv.cuh EPI_RESID / EPI_RESID2)
+__global__ void __launch_bounds__(256) moe_fold_exact_kernel(float *__restrict__ h, float rs, const float *__restrict__ y, const int *__restrict__ inv, const float *__restrict__ w,
+                                                            int d, int tk) {
+  const int t = blockIdx.x;
+  for (int n = threadIdx.x * 4; n < d; n += 1024) {
+    float4 v = *(const float4 *)(h + (size_t)t * d + n);
+    for (int sl = 0; sl < tk; ++sl) {
+      const float ws = w[(size_t)t * tk + sl], sc = sl == 0 ? rs : 1.0f;
+      const float4 yy = *(const float4 *)(y + (size_t)inv[(size_t)t * tk + sl] * d + n);
+      v.x = v.x * sc + yy.x * ws; v.y = v.y * sc + yy.y * ws; v.z = v.z * sc + yy.z * ws; v.w = v.w * sc + yy.w * ws;
+    }
+    *(float4 *)(h + (size_t)t * d + n) = v;
+  }
+}
+// h <- h * rs + y  (tensor-parallel row-parallel projections of a prompt: the decode step's RESID epilogue with resid_scale = 1 / world, then ONE sum all-reduce of h)
+__global__ void __launch_bounds__(256) resid_scale_add_kernel(float *__restrict__ h, float rs, const float *__restrict__ y, size_t n) {
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) {
+    if (i + 4 <= n) {
+      float4 a = *(float4 *)(h + i); const float4 b = *(const float4 *)(y + i);
+      a.x = a.x * rs + b.x * 1.0f; a.y = a.y * rs + b.y * 1.0f; a.z = a.z * rs + b.z * 1.0f; a.w = a.w * rs + b.w * 1.0f;
+      *(float4 *)(h + i) = a;
+    } else for (size_t j = i; j < n; ++j) h[j] = h[j] * rs + y[j] * 1.0f;
+  }
+}
+}  // namespace qi
+}  // namespace mrs
+extern "C" int mrs_qi_gather_rows(int w_type, const void *act_src, int T, void *act_dst, int R, int K, const int *sorted_routes, int top_k, int *inv, void *stream) {
+  if (!act_src || !act_dst || !sorted_routes || T <= 0 || R <= 0 || K <= 0 || K % 256 || top_k <= 0 || !qi::qi_type(w_type)) return -1;
+  _Float16 *qs, *bs, *qd, *bd; float *ys, *yd;
+  qi_split((void *)act_src, T, K, &qs, &ys, &bs);
+  qi_split(act_dst, R, K, &qd, &yd, &bd);
+  hipLaunchKernelGGL(qi::qi_gather_rows_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, (const char *)act_src, (char *)act_dst, T, R, K / 256, dec2::act_mode_for(w_type),
+                     sorted_routes, top_k, inv, (size_t)((char *)ys - (char *)qs), (size_t)((char *)bs - (char *)qs), (size_t)((char *)yd - (char *)qd), (size_t)((char *)bd - (char *)qd));
+  return 0;
+}
+extern "C" int mrs_moe_fold_exact(float *h, float resid_scale, const float *y_sorted, const int *inv, const float *weights, int T, int d, int top_k, void *stream) {
+  if (!h || !y_sorted || !inv || !weights || T <= 0 || d <= 0 || d % 4 || top_k <= 0) return -1;
+  hipLaunchKernelGGL(qi::moe_fold_exact_kernel, dim3(T), dim3(256), 0, (hipStream_t)stream, h, resid_scale, y_sorted, inv, weights, d, top_k);
+  return 0;
+}
+extern "C" int mrs_resid_scale_add_f32(float *h, float resid_scale, const float *y, size_t n, void *stream) {
+  if (!n) return 0;
+  size_t g = (n / 4 + 255) / 256; if (g > 2048) g = 2048; if (g < 1) g = 1;
+  hipLaunchKernelGGL(qi::resid_scale_add_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, h, resid_scale, y, n);
   return 0;
 }
 
@@ -659,6 +929,200 @@ __global__ void __launch_bounds__(256) prefill_attn_exact_kernel(const dec::Attn
       o[lane] = ao[lane] * inv; o[lane + 64] = ao[lane + 64] * inv;
     }
 }
+// ------------------------------------------------------------------------------------------------ the same attention on the matrix cores (round 6)
+// prefill_attn_exact_kernel spends a prompt's attention on the vector ALU (224 us per layer at 512 tokens: 30 % of the default TTFT; quadratic: most of a 2048-token
+// prompt).  v_mfma_f32_32x32x2_f32 takes f32 operands and IS the f32 FMA chain over k, bit for bit (d = fma(a1, b1, fma(a0, b0, c)): profiles/experiments/
+// mfma_f32_probe.hip on the MI355X; MI355X_MICROARCH.md, matrix cores), so the decode kernel's chains run on it unchanged:
+//   scores   s = chain over dims 0 .. 63 (acc0) + chain over dims 64 .. 127 (acc1): 32 + 32 MFMAs per 32 tokens x 32 queries (the decode wave's two halves)
+//   P . V    o = chain over the block's 32 tokens in ascending order, started from the split's running o * alpha (or 0): 16 MFMAs per 32 dims x 32 queries
+// and everything between them is the decode kernel's per-element arithmetic (scale, mask, fast_exp_ref, the pairwise 32-token sum tree of its DPP reduction).  Per QUERY
+// the splits (bpw blocks each), their online-softmax recurrence and the merge over splits are attn_split_core's / attn_merge_core's, evaluated for 32 queries at once.
+// Workgroup = 4 waves = one (query head, tile of 32 consecutive prompt tokens); K / V blocks in groups of four:
+//   phase 1: wave w computes block 4 g + w's scores, probabilities (-> LDS), block sum, alpha and (last block of a split) the merge weight fast_exp(m_split - M);
+//   phase 2: wave w owns dims 32 w .. 32 w + 31 of the output: P . V of the group's blocks in ascending order, the split recurrences and the merge sums --
+//            the f32 additions of one query happen in the decode order although four waves share the work.
+// M (the maximum over the query's splits, needed by every merge weight) comes from a first pass over the scores (pass A: block maxima only).
+template <class CT> __device__ __forceinline__ float cvt16_lo(unsigned w);
+template <class CT> __device__ __forceinline__ float cvt16_hi(unsigned w);
+template <> __device__ __forceinline__ float cvt16_lo<bf16_t>(unsigned w) { return __uint_as_float(w << 16); }
+template <> __device__ __forceinline__ float cvt16_hi<bf16_t>(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+template <> __device__ __forceinline__ float cvt16_lo<f16_t>(unsigned w) { return half_bits_to_float((uint16_t)(w & 0xffffu)); }
+template <> __device__ __forceinline__ float cvt16_hi<f16_t>(unsigned w) { return half_bits_to_float((uint16_t)(w >> 16)); }
+#ifndef MRS_MFMA_F32_K1_FIRST
+#define MRS_MFMA_F32_K1_FIRST 0  // 1: the instruction adds k = 1 before k = 0 (then the lane halves swap dims / tokens); the probe says 0 on gfx950
+#endif
+constexpr int PM_NW = 4;                                   // waves per workgroup
+constexpr int PM_Q = 64 * 64 * 4;                          // Q operand [64 steps][64 lanes] f32
+constexpr int PM_P = PM_NW * 32 * 32 * 4;                  // probabilities of the group's blocks [slot][token][query] f32
+constexpr int PM_SC = PM_NW * 3 * 32 * 4;                  // per slot and query: block sum, alpha, merge weight
+// + per block and query the block maximum of pass A: 128 bytes per 32-token block of the longest context (sized by the launcher)
+template <class CT>
+__global__ void __launch_bounds__(64 * PM_NW) prefill_attn_mfma_kernel(const dec::AttnArgs a, int max_blocks_lds) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = tid_opaque(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, hf = lane >> 5;
+  const int kp = MRS_MFMA_F32_K1_FIRST ? 1 - hf : hf;  // which element of a pair (dims 2 s, 2 s + 1 / tokens 2 s, 2 s + 1) this lane half supplies so that the chain ascends
+  const int head = blockIdx.x, G = a.num_heads / a.num_kv_heads, kvh = head / G;
+  const int tile = (int)gridDim.y - 1 - (int)blockIdx.y;  // longest contexts first
+  const int T = a.num_seqs, bpw = a.bpw;
+  const int t_q = min(tile * 32 + j, T - 1);
+  const bool q_live = tile * 32 + j < T;
+  float *q_s = (float *)smem;
+  float *p_s = (float *)(smem + PM_Q);
+  float *sc_s = (float *)(smem + PM_Q + PM_P);
+  float *mx_s = (float *)(smem + PM_Q + PM_P + PM_SC);  // [block][query], max_blocks_lds blocks
+  (void)max_blocks_lds;
+  // ---- the tile's queries as the B operand of the score MFMAs: step s <-> dims 2 s, 2 s + 1; lane (query j, half) holds q[j][2 s + kp]
+  {
+    const float *qg = a.q + (size_t)t_q * a.q_stride + (size_t)head * 128;
+    for (int m = wave; m < 32; m += PM_NW) {  // float4 = dims 4 m .. 4 m + 3 -> steps 2 m, 2 m + 1
+      const float4 v = *(const float4 *)(qg + 4 * m);
+      q_s[(2 * m) * 64 + lane] = kp ? v.y : v.x;
+      q_s[(2 * m + 1) * 64 + lane] = kp ? v.w : v.z;
+    }
+  }
+  const int ctx = (int)a.context_lens[t_q];
+  const int lo = a.window > 0 && ctx > a.window ? ctx - a.window : 0;
+  const int t_last = min(tile * 32 + 31, T - 1);
+  const int ctx_max = (int)a.context_lens[t_last];  // consecutive prompt positions: the tile's last token has the longest context
+  const int nblk = (ctx_max + 31) / 32;
+  const uint32_t *bt = a.block_tables;
+  __syncthreads();
+  f16v zero;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) zero[v] = 0.f;
+  // scores of block b for the 32 queries: lane (query j, half hf) gets tokens i = 8 (v / 4) + 4 hf + v % 4 (the accumulator layout); masked + scaled; returns the block max
+  auto scores = [&](int b, float (&val)[16], bool (&ok)[16]) -> float {
+    const size_t base = (size_t)bt[b] * a.kv_block_stride + (size_t)kvh * a.kv_head_stride;
+    const uint16_t *kb = a.k_cache + base + (size_t)j * 8;  // A operand: lane (token j, half) supplies K[token j][2 s + kp]; chunk c = dims 8 c .. 8 c + 7
+    f16v acc0 = zero, acc1 = zero;
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      v4u kr[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) kr[c] = *(const v4u *)(kb + (size_t)(h2 * 8 + c) * 32 * 8);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const unsigned w4[4] = {kr[c].x, kr[c].y, kr[c].z, kr[c].w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int s = (h2 * 8 + c) * 4 + u;
+          const float kv = kp ? cvt16_hi<CT>(w4[u]) : cvt16_lo<CT>(w4[u]);
+          const float qv = q_s[s * 64 + lane];
+          if (h2 == 0) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kv, qv, acc0, 0, 0, 0);
+          else acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kv, qv, acc1, 0, 0, 0);
+        }
+      }
+    }
+    float mx = -FLT_MAX;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int pos = b * 32 + 8 * (v >> 2) + 4 * hf + (v & 3);
+      ok[v] = pos < ctx && pos >= lo;
+      const float sv = acc0[v] + acc1[v];
+      val[v] = ok[v] ? sv * a.scale : -FLT_MAX;
+      mx = fmaxf(mx, val[v]);
+    }
+    return fmaxf(mx, __shfl_xor(mx, 32, 64));
+  };
+  // ---- pass A: block maxima (wave w: blocks w, w + 4, ...)
+  for (int b = wave; b < nblk; b += PM_NW) {
+    float val[16]; bool ok[16];
+    const float mx = scores(b, val, ok);
+    if (hf == 0) mx_s[b * 32 + j] = mx;
+  }
+  __syncthreads();
+  // per query: the running maximum inside every split and M = the maximum over the splits -- all from the block maxima (a maximum is exact in any order)
+  float M = -FLT_MAX;
+  for (int b = 0; b < nblk; ++b) M = fmaxf(M, mx_s[b * 32 + j]);
+  // ---- pass B
+  f16v acc = zero, osp = zero;  // merge accumulator and the current split's running output: dims 32 wave + 8 (v / 4) + 4 hf + v % 4 of query j
+  float s_all = 0.f, l_run = 0.f;
+  for (int g0 = 0; g0 < nblk; g0 += PM_NW) {
+    {  // phase 1
+      const int b = g0 + wave;
+      if (b < nblk) {
+        float val[16]; bool ok[16];
+        const float mx = scores(b, val, ok);
+        const int b0 = (b / bpw) * bpw;  // first block of the split
+        float m_before = -FLT_MAX;
+        for (int bb = b0; bb < b; ++bb) m_before = fmaxf(m_before, mx_s[bb * 32 + j]);
+        const float mn = fmaxf(m_before, mx);
+        float pv[16];
+#pragma unroll
+        for (int v = 0; v < 16; ++v) pv[v] = ok[v] ? fast_exp_ref(val[v] - mn) : 0.f;
+        // the decode wave's sum over the block's 32 tokens: pairwise tree in token order (xor 1, xor 2, half-row mirror, row mirror, xor 16 of its DPP reduction)
+        float q4[4];
+#pragma unroll
+        for (int aa = 0; aa < 4; ++aa) q4[aa] = (pv[4 * aa] + pv[4 * aa + 1]) + (pv[4 * aa + 2] + pv[4 * aa + 3]);  // tokens 8 aa + 4 hf + 0 .. 3
+        float o8[4];
+#pragma unroll
+        for (int aa = 0; aa < 4; ++aa) o8[aa] = q4[aa] + __shfl_xor(q4[aa], 32, 64);  // tokens 8 aa .. 8 aa + 7
+        const float ps = (o8[0] + o8[1]) + (o8[2] + o8[3]);
+        float *pw = p_s + (size_t)wave * 1024;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) pw[(8 * (v >> 2) + 4 * hf + (v & 3)) * 32 + j] = pv[v];
+        if (hf == 0) {
+          float *sw = sc_s + (size_t)wave * 96;
+          sw[j] = ps;
+          sw[32 + j] = b == b0 ? 0.f : fast_exp_ref(m_before - mn);  // alpha (unused for the first block of a split)
+          const bool last = (b + 1) % bpw == 0 || b + 1 == nblk;
+          sw[64 + j] = last ? fast_exp_ref(mn - M) : 0.f;              // the split's merge weight: its final maximum is mn
+        }
+      }
+    }
+    __syncthreads();
+    {  // phase 2: dims 32 wave .. + 31
+      const int nb = min(PM_NW, nblk - g0);
+      for (int sl = 0; sl < nb; ++sl) {
+        const int b = g0 + sl;
+        const bool first = b % bpw == 0, last = (b + 1) % bpw == 0 || b + 1 == nblk;
+        const float *sw = sc_s + (size_t)sl * 96;
+        const float ps = sw[j], alpha = sw[32 + j], wsp = sw[64 + j];
+        // A operand: lane (dim row i = lane & 31 of the wave's 32 dims, half) supplies V[dim][token 2 s + kp]: dword s of the dim's 32-token row, low / high half
+        const size_t base = (size_t)bt[b] * a.kv_block_stride + (size_t)kvh * a.kv_head_stride;
+        const uint16_t *vb = a.v_cache + base + (size_t)(32 * wave + j) * 32;
+        v4u vr[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) vr[c] = *(const v4u *)(vb + c * 8);
+        f16v o;
+        if (first) { o = zero; l_run = ps; }
+        else {
+#pragma unroll
+          for (int v = 0; v < 16; ++v) o[v] = osp[v] * alpha;
+          l_run = l_run * alpha + ps;
+        }
+        const float *pr = p_s + (size_t)sl * 1024;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const unsigned w4[4] = {vr[c].x, vr[c].y, vr[c].z, vr[c].w};
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int s = 4 * c + u, tok = 2 * s + kp;
+            float vv = kp ? cvt16_hi<CT>(w4[u]) : cvt16_lo<CT>(w4[u]);
+            vv = b * 32 + tok < ctx_max ? vv : 0.f;  // slots past the tile's longest context may hold anything (the decode kernel zeroes past ITS context: those p are 0)
+            o = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, pr[tok * 32 + j], o, 0, 0, 0);
+          }
+        }
+        osp = o;
+        if (last) {  // attn_merge_core: s += l_j w_j;  acc += o_j w_j  (multiply and add separate)
+          const float lw = l_run * wsp;
+          s_all = s_all + lw;
+#pragma unroll
+          for (int v = 0; v < 16; ++v) { const float t0 = o[v] * wsp; acc[v] = acc[v] + t0; }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (!q_live) return;
+  const float inv = 1.0f / s_all;
+  float *og = a.out + ((size_t)(tile * 32 + j) * a.num_heads + head) * 128 + 32 * wave;
+#pragma unroll
+  for (int aa = 0; aa < 4; ++aa)
+    *(float4 *)(og + 8 * aa + 4 * hf) = make_float4(acc[4 * aa] * inv, acc[4 * aa + 1] * inv, acc[4 * aa + 2] * inv, acc[4 * aa + 3] * inv);
+}
+
 }  // namespace qi
 }  // namespace mrs
 
@@ -679,6 +1143,18 @@ extern "C" int mrs_prefill_attention_exact(const float *q, const void *k_cache, 
   // (w_j, l_j) per split live in LDS: as many splits as the longest context of this prompt needs (<= 64 by the rule above)
   const int need_ctx = max_prompt_ctx > 0 && max_prompt_ctx < max_context_len ? max_prompt_ctx : max_context_len;
   a.max_splits = std::max(1, std::min(64, (((need_ctx + 31) / 32) + a.bpw - 1) / a.bpw));
+  // round 6: the matrix-core form (prefill_attn_mfma_kernel: the same chains on v_mfma_f32_32x32x2_f32); MRS_PREFILL_ATTN_MFMA=0 keeps the vector-ALU kernel
+  static const int use_mfma = [] { const char *e = getenv("MRS_PREFILL_ATTN_MFMA"); return e ? atoi(e) : 1; }();
+  {
+    const int nb = (need_ctx + 31) / 32;
+    const size_t lds_m = (size_t)mrs::qi::PM_Q + mrs::qi::PM_P + mrs::qi::PM_SC + (size_t)nb * 128;
+    if (use_mfma && lds_m <= 158 * 1024) {
+      const dim3 gm(num_heads, (T + 31) / 32);
+      if (kv_dtype == 1) { auto kern = mrs::qi::prefill_attn_mfma_kernel<mrs::bf16_t>; mrs::lds_attr_once((const void *)kern, 158 * 1024); hipLaunchKernelGGL(kern, gm, dim3(64 * mrs::qi::PM_NW), lds_m, (hipStream_t)stream, a, nb); }
+      else { auto kern = mrs::qi::prefill_attn_mfma_kernel<mrs::f16_t>; mrs::lds_attr_once((const void *)kern, 158 * 1024); hipLaunchKernelGGL(kern, gm, dim3(64 * mrs::qi::PM_NW), lds_m, (hipStream_t)stream, a, nb); }
+      return 0;
+    }
+  }
   static const int qw_env = [] { const char *e = getenv("MRS_PREFILL_ATTN_QW"); return e ? atoi(e) : 0; }();
   int qw = qw_env > 0 ? qw_env : 4;  // prompt tokens per wave
   auto lds_for = [&](int w) { return 4 * ((size_t)w * G * 128 * 2 + (size_t)G * 32 + (size_t)w * G * a.max_splits * 2 + (size_t)w * G * 64) * 4; };

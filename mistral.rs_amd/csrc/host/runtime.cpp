@@ -429,12 +429,15 @@ class Llama {
     }
     return true;
   }
-  int forward_engine(int b, hipStream_t s) const {
+  // chained (round 6, batch 1): ws.h already holds the embedding row of input_ids (the previous step's mrs_sample_advance_embed, or mrs_llama_embed_state after the host
+  // changed the state) and lm_head folds the arg-max into its epilogue: the captured step is two launches shorter (no embedding_kernel, no argmax_partial_kernel)
+  int forward_engine(int b, hipStream_t s, bool chained = false) const {
     const float rs = 1.0f / (float)std::max(1, (int)cfg.world_size);
     const int d = cfg.hidden_size, hd = cfg.head_dim, nq = cfg.num_heads * hd, ff = cfg.intermediate_size, kvd = cfg.kv_f16 ? 0 : 1;
     const int bs = cfg.block_size, kvh = cfg.num_kv_heads;
     const int eff_max = std::min(cfg.max_blocks_per_seq * bs, cfg.max_context_len);
-    if (wte->embedding_forward_raw(bufs.input_ids, b, ws.h, s)) return -1;
+    if (chained && b != 1) return fail("chained decode step: batch 1 only");
+    if (!chained && wte->embedding_forward_raw(bufs.input_ids, b, ws.h, s)) return -1;
     // Batched steps: every GEMV workgroup would normalise + quantize all b activation columns itself (256 times the same work, 17-25 us of a 40-60 us launch at
     // b = 8); from MRS_DEC_IMG_MIN_B columns on the image of a phase is built once by mrs_dec_act_image (b workgroups) and the GEMVs copy it -- same bytes.
     static const int img_min_b = [] { const char *e = getenv("MRS_DEC_IMG_MIN_B"); return e ? atoi(e) : 2; }();
@@ -506,8 +509,9 @@ class Llama {
                                                     : mrs_dec_proj(&bl.ddown, d, nullptr, ws.act, ff, nullptr, 0.f, ws.h, d, 1, rs, nullptr, b, s);
       if (drc || all_reduce(ws.h, (size_t)b * d, s)) return fail("down_proj failed: %s", g_last_error.c_str());
     }
-    const int lrc = imgb ? (image(ws.h, d, ln_f, d, dlm_head.type) || mrs_dec_proj_img(&dlm_head, cfg.vocab_size, ws.act_img, bufs.logits, cfg.vocab_size, 0, 1.0f, b, s))
-                                                  : mrs_dec_proj(&dlm_head, cfg.vocab_size, nullptr, ws.h, d, ln_f, cfg.rms_eps, bufs.logits, cfg.vocab_size, 0, 1.0f, nullptr, b, s);
+    const int lrc = chained ? mrs_dec_proj_argmax(&dlm_head, cfg.vocab_size, ws.h, d, ln_f, cfg.rms_eps, bufs.logits, cfg.vocab_size, ws.sample_scratch, s)
+                    : imgb ? (image(ws.h, d, ln_f, d, dlm_head.type) || mrs_dec_proj_img(&dlm_head, cfg.vocab_size, ws.act_img, bufs.logits, cfg.vocab_size, 0, 1.0f, b, s))
+                           : mrs_dec_proj(&dlm_head, cfg.vocab_size, nullptr, ws.h, d, ln_f, cfg.rms_eps, bufs.logits, cfg.vocab_size, 0, 1.0f, nullptr, b, s);
     if (lrc) return fail("lm_head refused");
     return 0;
   }
@@ -536,6 +540,7 @@ class Llama {
       b += align(r * (pad_to((int)ff, MATRIX_ROW_PADDING) / 32) * 36);               // Q8_1 rows of the routes' activations
       b += align(t * d * 4);                                                         // sum of the weighted expert outputs
       if (T > prefill_big_min()) b += align(t * d * 2) + align(r * ff * 2);         // bf16 slabs of the normed tokens and of the routes' activations
+      b += align(r * 4) + align(r * d * 4) + align(mrs_qi_act_bytes((int)r, (int)d)) + align(mrs_qi_act_bytes((int)r, (int)ff));  // exact path: inverse route table, per-route down outputs, gathered / per-route operand rows
     }
     return b + 4096;
   }
@@ -594,18 +599,46 @@ class Llama {
   bool prefill_exact_ok() const {
     static const int env_want = [] { const char *e = getenv("MRS_PREFILL_EXACT"); return e ? atoi(e) : 1; }();
     const int want = prefill_mode >= 0 ? prefill_mode : env_want;
-    if (!want || cfg.use_fused != 2 || !engine_ok() || cfg.world_size > 1 || cfg.num_experts > 0 || cfg.head_dim != 128 || cfg.block_size != 32) return false;
+    // round 6: tensor-parallel shards (the row-parallel projections write h * (1 / world) + W_shard . y like the decode step's RESID epilogue, then the same ONE sum
+    // all-reduce of h) and sparse-MoE layers (moe_ffn_exact) run in the engine's arithmetic too
+    if (!want || cfg.use_fused != 2 || !engine_ok() || cfg.head_dim != 128 || cfg.block_size != 32) return false;
     const int G = cfg.num_heads / std::max(1, (int)cfg.num_kv_heads);
     if (cfg.num_heads % cfg.num_kv_heads || (G != 1 && G != 2 && G != 4 && G != 8)) return false;
+    const bool moe = cfg.num_experts > 0;
     for (const Block &bl : blocks) {
       const GgufMatMul *ls[7] = {bl.q_proj.get(), bl.k_proj.get(), bl.v_proj.get(), bl.o_proj.get(), bl.gate_proj.get(), bl.up_proj.get(), bl.down_proj.get()};
-      for (const GgufMatMul *l : ls)
-        if (!l || !l->get_qtensor() || !l->get_qtensor()->qi) return false;
+      for (int i = 0; i < (moe ? 4 : 7); ++i)
+        if (!ls[i] || !ls[i]->get_qtensor() || !ls[i]->get_qtensor()->qi) return false;
+      if (moe && (!bl.gate_exps.qi || !bl.up_exps.qi || !bl.down_exps.qi || !bl.router || bl.gate_exps.dtype != bl.up_exps.dtype || cfg.intermediate_size % 32 || cfg.hidden_size % 32)) return false;
     }
     return dlm_head.planes != nullptr;
   }
-  int prefill_exact(const mrs_llama_prefill_args &pa, int T, float *h, float *q, float *k, float *v, float *attn, float *g, float *u, float *act, void *qact,
-                    void *qws, size_t qws_bytes, hipStream_t s) const {
+  struct MoeExactBufs { int32_t *ids, *sorted, *inv, *bounds, *counts, *cursors; float *w, *y; void *qact_g, *qact_r; };  // routes = T * top_k rows in expert-sorted order
+  // SparseMoeBlock::forward of a prompt in the decode step's arithmetic: the step's router kernel on every token, the tokens' Q8_K / Q8_0 rows gathered into
+  // expert-sorted order, every expert's gate / up / down as one window of the exact GEMM, silu(g) * u quantized per route, the slots folded into h in slot order
+  int moe_ffn_exact(const Block &bl, int T, float *h, float *g, float *u, float *act, void *qact, const MoeExactBufs &m, hipStream_t s) const {
+    const int d = cfg.hidden_size, ff = cfg.intermediate_size, E = cfg.num_experts, tk = cfg.num_experts_per_tok, R = T * tk;
+    const float rs = 1.0f / (float)std::max(1, (int)cfg.world_size);
+    const int rrc = mrs_moe_router_topk_norm(h, bl.post_attention_layernorm, cfg.rms_eps, bl.router, T, E, d, tk, 1, m.ids, m.w, s);
+    if (rrc) return fail("prefill (exact): moe router refused (%d)", rrc);  // (-3, rows beyond 64 KiB, takes the two-launch router in the decode step: not a shape of this path)
+    launch_moe_dispatch(m.ids, m.bounds, m.sorted, nullptr, R, E, tk, m.counts, m.cursors, s);
+    const int tg = bl.gate_exps.dtype, td = bl.down_exps.dtype;
+    if (mrs_qi_quantize_for(tg, h, nullptr, d, bl.post_attention_layernorm, cfg.rms_eps, T, d, qact, nullptr, s)) return fail("prefill (exact): activation quantizer refused K=%d", d);
+    if (mrs_qi_gather_rows(tg, qact, T, m.qact_g, R, d, m.sorted, tk, m.inv, s)) return fail("prefill (exact): operand gather refused");
+    const size_t pg = mrs_gemm_qi_repack_bytes(tg, ff, d), pd = mrs_gemm_qi_repack_bytes(td, d, ff);  // bytes of one expert's panels
+    for (int e = 0; e < E; ++e) {
+      if (mrs_gemm_qi_win((const char *)bl.gate_exps.qi + (size_t)e * pg, tg, ff, d, m.qact_g, R, m.bounds + e, T, g, ff, 0, s) ||
+          mrs_gemm_qi_win((const char *)bl.up_exps.qi + (size_t)e * pg, tg, ff, d, m.qact_g, R, m.bounds + e, T, u, ff, 0, s))
+        return fail("prefill (exact): expert gate / up GEMM refused (ggml dtype %d)", tg);
+    }
+    if (mrs_qi_quantize_for(td, g, u, ff, nullptr, 0.f, R, ff, m.qact_r, act, s)) return fail("prefill (exact): activation quantizer refused K=%d", ff);
+    for (int e = 0; e < E; ++e)
+      if (mrs_gemm_qi_win((const char *)bl.down_exps.qi + (size_t)e * pd, td, d, ff, m.qact_r, R, m.bounds + e, T, m.y, d, 0, s)) return fail("prefill (exact): expert down GEMM refused (ggml dtype %d)", td);
+    if (mrs_moe_fold_exact(h, rs, m.y, m.inv, m.w, T, d, tk, s)) return fail("prefill (exact): moe fold refused");
+    return all_reduce(h, (size_t)T * d, s) ? fail("prefill (exact): moe all-reduce failed: %s", g_last_error.c_str()) : 0;
+  }
+  int prefill_exact(const mrs_llama_prefill_args &pa, int T, float *h, float *xn, float *q, float *k, float *v, float *attn, float *g, float *u, float *act, void *qact,
+                    void *qws, size_t qws_bytes, const MoeExactBufs &mx, hipStream_t s) const {
     const int d = cfg.hidden_size, hd = cfg.head_dim, nq = cfg.num_heads * hd, nkv = cfg.num_kv_heads * hd, ff = cfg.intermediate_size;
     const int bs = cfg.block_size, kvh = cfg.num_kv_heads, kvd = cfg.kv_f16 ? 0 : 1;
     const int eff_max = std::min(cfg.max_blocks_per_seq * bs, cfg.max_context_len);
@@ -614,21 +647,51 @@ class Llama {
       const QTensor *w = m.get_qtensor();
       return mrs_gemm_qi_ws(w->qi, w->dtype, N, K, qact, T, out, N, acc, N <= std::max(d, nq) ? qws : nullptr, qws_bytes, s) ? fail("prefill (exact): mrs_gemm_qi refused ggml dtype %d (N=%d K=%d)", w->dtype, N, K) : 0;
     };
+    // o_proj / down_proj: h <- h + W . x;  tensor parallel: h <- h * (1 / world) + W_shard . x on every rank (the decode step's RESID epilogue, two roundings), then ONE
+    // sum all-reduce of h (distributed/layers.rs:965-975) -- the same sums as the decode step whenever the all-reduce adds the ranks in the same order (world 2: always;
+    // the peer-mailbox route: rank order for every message it takes)
+    const float rs = 1.0f / (float)std::max(1, (int)cfg.world_size);
+    auto row_parallel = [&](const GgufMatMul &m, int N, int K, const float *x, const float *x2, int ldx, float *xtmp) -> int {
+      const int ty = m.get_qtensor()->dtype;
+      if (mrs_qi_quantize_for(ty, x, x2, ldx, nullptr, 0.f, T, K, qact, xtmp, s)) return fail("prefill (exact): activation quantizer refused K=%d (ggml dtype %d)", K, ty);
+      if (cfg.world_size <= 1) return lin(m, N, K, h, 1);
+      if (lin(m, N, K, xn, 0) || mrs_resid_scale_add_f32(h, rs, xn, (size_t)T * N, s)) return -1;
+      return all_reduce(h, (size_t)T * N, s) ? fail("prefill (exact): all-reduce failed: %s", g_last_error.c_str()) : 0;
+    };
+    // one activation image per vec_dot partner (gguf/mod.rs:465-478: Q8_K rows for the K-quants, Q8_0 rows for Q8_0 weights): projections that share their input share
+    // the image when their weight formats ask for the same one (every model of BASELINE.json's configs: one image per group)
+    auto group = [&](std::initializer_list<const GgufMatMul *> ms, std::initializer_list<int> Ns, std::initializer_list<float *> outs, int K, const float *x, const float *x2, int ldx,
+                     const float *nw, float *xtmp, int acc) -> int {
+      std::vector<const GgufMatMul *> m(ms);
+      std::vector<int> n(Ns);
+      std::vector<float *> o(outs);
+      std::vector<bool> done(m.size(), false);
+      for (size_t i = 0; i < m.size(); ++i) {
+        if (done[i]) continue;
+        const int ty = m[i]->get_qtensor()->dtype, mode = ty == Q8_0 ? 1 : 0;
+        if (mrs_qi_quantize_for(ty, x, x2, ldx, nw, cfg.rms_eps, T, K, qact, xtmp, s)) return fail("prefill (exact): activation quantizer refused K=%d (ggml dtype %d)", K, ty);
+        for (size_t j = i; j < m.size(); ++j)
+          if (!done[j] && ((m[j]->get_qtensor()->dtype == Q8_0) ? 1 : 0) == mode) { if (lin(*m[j], n[j], K, o[j], acc)) return -1; done[j] = true; }
+      }
+      return 0;
+    };
     if (wte->embedding_forward_raw(pa.token_ids, T, h, s)) return -1;
     for (size_t li = 0; li < blocks.size(); ++li) {
       const Block &bl = blocks[li];
-      if (mrs_qi_quantize(h, nullptr, d, bl.input_layernorm, cfg.rms_eps, T, d, qact, nullptr, s)) return fail("prefill (exact): activation quantizer refused K=%d", d);
-      if (lin(*bl.q_proj, nq, d, q, 0) || lin(*bl.k_proj, nkv, d, k, 0) || lin(*bl.v_proj, nkv, d, v, 0)) return -1;
+      if (group({bl.q_proj.get(), bl.k_proj.get(), bl.v_proj.get()}, {nq, nkv, nkv}, {q, k, v}, d, h, nullptr, d, bl.input_layernorm, nullptr, 0)) return -1;
       rotary_embedding_positions(q, k, (void *)bufs.cos_table, (void *)bufs.sin_table, (void *)pa.positions, cfg.rope_interleaved ? 0 : 1, hd, T,
                                  cfg.rot_dim / 2, cfg.max_context_len, cfg.num_heads, cfg.num_kv_heads, nq, nkv, 2, st);
       reshape_and_cache(k, v, bl.key_cache, bl.value_cache, (int64_t *)pa.slot_mapping, T, cfg.num_kv_heads, hd, bs, 8, nkv, nkv, s, 2, kvd == 1 ? 1 : 0, nullptr, nullptr);
       if (mrs_prefill_attention_exact(q, bl.key_cache, bl.value_cache, pa.block_tables, pa.context_lens, attn, T, cfg.num_heads, kvh, hd, bs, nq, kvh * hd * bs, hd * bs,
                                       1.0f / sqrtf((float)hd), eff_max, kvd, cfg.sliding_window, pa.start_pos + T, s))
         return fail("prefill (exact): attention refused the shape");
-      if (mrs_qi_quantize(attn, nullptr, nq, nullptr, 0.f, T, nq, qact, nullptr, s) || lin(*bl.o_proj, d, nq, h, 1)) return -1;
-      if (mrs_qi_quantize(h, nullptr, d, bl.post_attention_layernorm, cfg.rms_eps, T, d, qact, nullptr, s)) return -1;
-      if (lin(*bl.gate_proj, ff, d, g, 0) || lin(*bl.up_proj, ff, d, u, 0)) return -1;
-      if (mrs_qi_quantize(g, u, ff, nullptr, 0.f, T, ff, qact, act, s) || lin(*bl.down_proj, d, ff, h, 1)) return -1;
+      if (row_parallel(*bl.o_proj, d, nq, attn, nullptr, nq, nullptr)) return -1;
+      if (cfg.num_experts > 0) {
+        if (moe_ffn_exact(bl, T, h, g, u, act, qact, mx, s)) return -1;
+        continue;
+      }
+      if (group({bl.gate_proj.get(), bl.up_proj.get()}, {ff, ff}, {g, u}, d, h, nullptr, d, bl.post_attention_layernorm, nullptr, 0)) return -1;
+      if (row_parallel(*bl.down_proj, d, ff, g, u, ff, act)) return -1;
     }
     // ctx.logits: only the last prompt token reaches lm_head (llama.rs:514-517): the decode engine's final norm + lm_head launch
     if (mrs_dec_proj(&dlm_head, cfg.vocab_size, nullptr, h + (size_t)(T - 1) * d, d, ln_f, cfg.rms_eps, pa.logits, cfg.vocab_size, 0, 1.0f, nullptr, 1, s))
@@ -652,7 +715,16 @@ class Llama {
       void *qact = take(mrs_qi_act_bytes(T, std::max(std::max(d, nq), ff)));
       const size_t qws_bytes = mrs_gemm_qi_workspace_bytes(T, std::max(d, nq));
       void *qws = take(qws_bytes);
-      return prefill_exact(pa, T, h, q, k, v, attn, g, u, act, qact, qws, qws_bytes, s);
+      MoeExactBufs mx{};
+      if (cfg.num_experts > 0) {  // routes = T * top_k rows in expert-sorted order; g / u / act become [routes][ff]
+        const size_t tk = (size_t)cfg.num_experts_per_tok, r = t * tk, E = (size_t)cfg.num_experts;
+        g = (float *)take(r * ff * 4); u = (float *)take(r * ff * 4); act = (float *)take(r * ff * 4);
+        mx.ids = (int32_t *)take(r * 4); mx.w = (float *)take(r * 4); mx.sorted = (int32_t *)take(r * 4); mx.inv = (int32_t *)take(r * 4);
+        mx.bounds = (int32_t *)take((E + 1) * 4); mx.counts = (int32_t *)take(E * 4); mx.cursors = (int32_t *)take(E * 4);
+        mx.y = (float *)take(r * d * 4);
+        mx.qact_g = take(mrs_qi_act_bytes((int)r, d)); mx.qact_r = take(mrs_qi_act_bytes((int)r, ff));
+      }
+      return prefill_exact(pa, T, h, xn, q, k, v, attn, g, u, act, qact, qws, qws_bytes, mx, s);
     }
     MoePrefillBufs moe{};
     if (cfg.num_experts > 0) {
@@ -828,6 +900,28 @@ class Llama {
     return 0;
   }
 
+  // ---- the chained greedy step (round 6): forward_engine without the embedding launch + lm_head with the arg-max in its epilogue + ONE launch that samples, advances
+  //      the device-resident state and gathers the NEXT token's embedding row into ws.h.  Same logits, same token as decode_step (tests/test_dec_model.py).
+  bool chained_ok(int b) const {
+    static const bool on = [] { const char *e = getenv("MRS_DEC_CHAINED"); return !e || atoi(e) != 0; }();
+    return on && b == 1 && cfg.use_fused == 2 && engine_ok() && wte && wte->get_qtensor();
+  }
+  int embed_state(int b, hipStream_t s) const {
+    if (check_ready(b)) return -1;
+    return wte->embedding_forward_raw(bufs.input_ids, b, ws.h, s);
+  }
+  int decode_step_chained(int b, hipStream_t s) const {
+    if (check_ready(b)) return -1;
+    if (!chained_ok(b)) return fail("chained decode step: needs the decode engine at batch 1");
+    if (cfg.sliding_window > 0 && !attn2) return fail("sliding_window %d needs the decode engine with its default attention", cfg.sliding_window);
+    if (forward_engine(b, s, true)) return -1;
+    const QTensor *e = wte->get_qtensor();
+    if (mrs_sample_advance_embed(bufs.input_ids, bufs.tokens_out, bufs.tokens_out_stride, bufs.step_counter, bufs.positions, bufs.context_lens, bufs.slot_mapping,
+                                 bufs.block_tables, cfg.max_blocks_per_seq, cfg.block_size, ws.sample_scratch, e->data, e->dtype, ws.h, (int)e->cols, s))
+      return fail("mrs_sample_advance_embed refused (embedding dtype %d)", e->dtype);
+    return 0;
+  }
+
   double decode_bytes(int b, int ctx) const {
     double t = 0;
     for (const Block &bl : blocks)
@@ -965,6 +1059,15 @@ extern "C" int mrs_llama_set_qi_tensor(void *mm, const char *cname, const void *
     if (rest == "ffn_gate.weight") return bind(b.gate_proj);
     if (rest == "ffn_up.weight") return bind(b.up_proj);
     if (rest == "ffn_down.weight") return bind(b.down_proj);
+    auto bind_exps = [&](const mrs_host::QTensor &t) {  // stacked experts [E * n][k]: expert e's panels start at e * n / 32 (n % 32 == 0 is checked at use)
+      if (!t.data) return mrs_host::fail("MFMA layout for %s: register the tensor with mrs_llama_set_tensor first", cname);
+      if (!mrs_gemm_qi_repack_bytes(t.dtype, t.rows, t.cols)) return mrs_host::fail("MFMA-order copy for %s: ggml dtype %d / shape not supported", cname, t.dtype);
+      t.qi = planes;
+      return 0;
+    };
+    if (rest == "ffn_gate_exps.weight") return bind_exps(b.gate_exps);
+    if (rest == "ffn_up_exps.weight") return bind_exps(b.up_exps);
+    if (rest == "ffn_down_exps.weight") return bind_exps(b.down_exps);
   }
   return mrs_host::fail("MFMA layout: tensor %s has no prompt-GEMM role", cname);
 }
@@ -981,6 +1084,9 @@ extern "C" int mrs_llama_set_kv_cache(void *m, int layer, void *k, void *v) {
 }
 extern "C" int mrs_llama_set_buffers(void *m, const mrs_llama_buffers *b) { return ((Llama *)m)->set_buffers(*b); }
 extern "C" int mrs_llama_decode_step(void *m, int b, void *stream) { return ((Llama *)m)->decode_step(b, (hipStream_t)stream); }
+extern "C" int mrs_llama_decode_step_chained(void *m, int b, void *stream) { return ((Llama *)m)->decode_step_chained(b, (hipStream_t)stream); }
+extern "C" int mrs_llama_embed_state(void *m, int b, void *stream) { return ((Llama *)m)->embed_state(b, (hipStream_t)stream); }
+extern "C" int mrs_llama_chained_ok(void *m, int b) { return ((Llama *)m)->chained_ok(b) ? 1 : 0; }
 extern "C" int mrs_llama_forward_logits(void *m, int b, void *stream) { return ((Llama *)m)->forward_logits(b, (hipStream_t)stream); }
 extern "C" double mrs_llama_decode_bytes(void *m, int b, int ctx) { return ((Llama *)m)->decode_bytes(b, ctx); }
 extern "C" size_t mrs_llama_prefill_workspace_bytes(const mrs_llama_config *cfg, int T) { return Llama::prefill_workspace_bytes(*cfg, T); }

@@ -220,6 +220,8 @@ class Llama:
         self._chk(L.mrs_llama_set_buffers(self._h, C.byref(b)))
         self._graph = None
         self._replays_left = None
+        self._graph_chained = False  # the captured step is the chained one (mrs_llama_decode_step_chained): it expects the hidden-state buffer to hold embedding(input_ids)
+        self._need_embed = True      # ... which is stale whenever the host changed input_ids or ran an eager step since the last replay
 
     # -------------------------------------------------------------------------------------------------
     def _err(self) -> str:
@@ -311,7 +313,7 @@ class Llama:
                     self._chk(self._L.mrs_llama_set_dec_tensor(self._h, name.encode(), planes.data_ptr()))
             # MFMA-order copy for the exact-integer prompt GEMM (ext_gemm_qi.hip): dense per-layer linears of the types it takes; with every one present the
             # runner prefills in the decode engine's arithmetic (Llama::prefill_exact).  A third copy of the same bits, made once.
-            if self._engine_wanted and self._exact_prefill_wanted and name.startswith("blk.") and "_exps" not in name:
+            if self._engine_wanted and self._exact_prefill_wanted and name.startswith("blk."):  # dense linears and stacked expert tensors (round 6: sparse-MoE prompts too)
                 nb2 = self._L.mrs_gemm_qi_repack_bytes(t.dtype.id, t.shape[0], t.shape[1])
                 if nb2:
                     qi = torch.empty(nb2, dtype=torch.uint8, device=self.device)
@@ -344,6 +346,7 @@ class Llama:
         self.context_lens[:b] = torch.tensor((pos + 1).astype(np.int32), device=self.device)
         self.slot_mapping[:b] = torch.tensor(slots, device=self.device)
         self._replays_left = None  # recomputed from the device state at the next replay()
+        self._need_embed = True
 
     @property
     def decode_path(self) -> str:
@@ -360,31 +363,56 @@ class Llama:
 
     def forward_logits(self, b: int) -> torch.Tensor:
         self._set_mode()
+        self._need_embed = True  # the eager step overwrites the hidden-state buffer
         self._chk(self._L.mrs_llama_forward_logits(self._h, b, self._stream()))
         return self.logits[:b]
 
     def decode_step(self, b: int = 1) -> None:
         self._set_mode()
+        self._need_embed = True
         self._chk(self._L.mrs_llama_decode_step(self._h, b, self._stream()))
+
+    def _chained_ok(self, b: int) -> bool:
+        """Round 6: a greedy batch-1 step of the decode engine can run "chained" -- the next token's embedding row is gathered by the launch that samples it and lm_head folds
+        the arg-max into its epilogue (two launches fewer per step).  The graph then relies on the hidden-state buffer between replays: replay() refreshes it after any
+        host-side change of the state."""
+        self._set_mode()
+        self._L.mrs_llama_chained_ok.argtypes = [C.c_void_p, C.c_int]
+        return bool(self._L.mrs_llama_chained_ok(self._h, b))
+
+    def _step_for_graph(self, b: int) -> None:
+        if self._graph_chained:
+            self._L.mrs_llama_decode_step_chained.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+            self._chk(self._L.mrs_llama_decode_step_chained(self._h, b, self._stream()))
+        else:
+            self.decode_step(b)
+
+    def _embed_state(self, b: int) -> None:
+        self._L.mrs_llama_embed_state.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        self._chk(self._L.mrs_llama_embed_state(self._h, b, self._stream()))
 
     def capture_decode_graph(self, b: int = 1) -> None:
         """Capture one decode step (forward + greedy sample + state advance) into a HIP graph."""
         self._graph_batch = b
+        self._graph_chained = self._chained_ok(b)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):  # warm-up outside capture (lazy module loads, attribute sets)
             saved = [t.clone() for t in (self.input_ids, self.positions, self.context_lens, self.slot_mapping, self.step_counter)]
-            self.decode_step(b)
+            if self._graph_chained:
+                self._embed_state(b)
+            self._step_for_graph(b)
             torch.cuda.current_stream().synchronize()
             for t, v in zip((self.input_ids, self.positions, self.context_lens, self.slot_mapping, self.step_counter), saved):
                 t.copy_(v)
         torch.cuda.current_stream().wait_stream(s)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self.decode_step(b)
+            self._step_for_graph(b)
         self._graph = g
         for t, v in zip((self.input_ids, self.positions, self.context_lens, self.slot_mapping, self.step_counter), saved):
             t.copy_(v)
+        self._need_embed = True  # the restored input_ids are not what the warm-up / capture left in the hidden-state buffer
 
     def replay(self) -> None:
         if self._graph is None:
@@ -396,6 +424,9 @@ class Llama:
         if self._replays_left <= 0:
             raise ValueError("replay(): the decode graph would run past max_new_tokens / max_context_len; set_state() to a new position first")
         self._replays_left -= 1
+        if self._graph_chained and self._need_embed:
+            self._embed_state(self._graph_batch)  # eager, on the current stream, ahead of the graph: the chained step starts from embedding(input_ids)
+            self._need_embed = False
         self._graph.replay()
 
     def prefill(self, tokens, start_pos: int = 0, seq: int = 0) -> torch.Tensor:

@@ -339,6 +339,19 @@ def test_engine_graph_loop_batch_and_chunked_prefill(oracle, dev, request):
         m2.replay()
     torch.cuda.synchronize()
     assert m2.tokens_out[0, :24].tolist() == eager
+    # round 6: the captured batch-1 step is the CHAINED one (arg-max in lm_head's epilogue, the next token's embedding row gathered by the sampling launch): the graph
+    # relies on the hidden-state buffer between replays -- a host-side state change (set_state) or an eager step in between must refresh it
+    assert m2._graph_chained, "the decode engine's batch-1 graph should be the chained step"
+    assert torch.equal(m2.logits[0], m.logits[0]), "logits of the last chained step != the eager step's"
+    m2.set_state([eager[9]], [len(prompt) + 10])  # rewind both to position + 10 (pages of earlier positions hold the same tokens)
+    m2.step_counter.zero_()
+    for _ in range(3):
+        m2.replay()
+    m2.forward_logits(1)  # an eager step between replays: it recomputes the SAME position (the state was advanced by the graph) and clobbers the hidden-state buffer
+    for _ in range(3):
+        m2.replay()
+    torch.cuda.synchronize()
+    assert m2.tokens_out[0, :6].tolist() == eager[10:16], (m2.tokens_out[0, :6].tolist(), eager[10:16])
     # batch: sequence 0 alone vs sequences (0, 1) together
     cfg3, w3, m3, _, _ = _mk(oracle, dev, Q4KM(oracle), "bf16")
     for pos in range(6):
@@ -347,6 +360,29 @@ def test_engine_graph_loop_batch_and_chunked_prefill(oracle, dev, request):
         m.set_state([prompt[pos]], [pos])  # m's sequence 0 is rewound: positions < pos hold the same tokens
         alone = m.forward_logits(1)[0]
         assert torch.equal(both[0], alone), f"batched != single at position {pos}"
+
+
+def test_chained_greedy_step_equals_plain_step(oracle, dev, request):
+    """Round 6: the chained batch-1 step (mrs_llama_decode_step_chained: no embedding launch -- the previous step's sampling launch gathered the row --, arg-max in lm_head's
+    epilogue, ONE launch for next id + state advance + next embedding row) produces the same logits, tokens and device state as mrs_llama_decode_step, step by step
+    (eager launches: runs on the host emulation too; the captured form is test_engine_graph_loop_batch_and_chunked_prefill)."""
+    import torch
+    n = 3 if request.config.getoption("--host-emulation") else 12
+    cfg, w, m1, cos, sin = _mk(oracle, dev, Q4KM(oracle), "bf16")
+    _, _, m2, _, _ = _mk(oracle, dev, Q4KM(oracle), "bf16")
+    assert m2._chained_ok(1) and not m2._chained_ok(2)
+    for m in (m1, m2):
+        m.set_state([1000 % cfg.vocab_size], [0])
+        m.step_counter.zero_()
+    m2._graph_chained = True
+    m2._embed_state(1)
+    for i in range(n):
+        m1.decode_step(1)
+        m2._step_for_graph(1)
+        assert torch.equal(m1.logits[0], m2.logits[0]), f"step {i}: logits differ"
+        for a, b in ((m1.input_ids, m2.input_ids), (m1.positions, m2.positions), (m1.context_lens, m2.context_lens), (m1.slot_mapping, m2.slot_mapping), (m1.step_counter, m2.step_counter)):
+            assert torch.equal(a[:1], b[:1]), f"step {i}: device state differs"
+    assert m1.tokens_out[0, :n].tolist() == m2.tokens_out[0, :n].tolist()
 
 
 @pytest.mark.parametrize("mix", ["q4km", "q8"])

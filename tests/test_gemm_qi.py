@@ -34,8 +34,8 @@ def run_gemm(O, be, tname, n, k, T, norm, glu=False, acc=False, seed=0, packed=N
     x2b = be.buf(x2) if glu else None
     nwb = be.buf(nw) if norm else None
     tmp = be.buf(np.zeros((T, k), np.float32)) if glu else None
-    rc = be.sym("mrs_qi_quantize", [VP, VP, CI, VP, C.c_float, CI, CI, VP, VP, VP], CI)(xb.ptr, x2b.ptr if glu else None, k, nwb.ptr if norm else None, 1e-5, T, k, act.ptr,
-                                                                                           tmp.ptr if glu else None, be.stream)
+    rc = be.sym("mrs_qi_quantize_for", [CI, VP, VP, CI, VP, C.c_float, CI, CI, VP, VP, VP], CI)(t, xb.ptr, x2b.ptr if glu else None, k, nwb.ptr if norm else None, 1e-5, T, k, act.ptr,
+                                                                                                   tmp.ptr if glu else None, be.stream)
     assert rc == 0, rc
     base = rng.standard_normal((T, n)).astype(np.float32) if acc else np.full((T, n), np.nan, np.float32)
     ob = be.buf(base.copy())
@@ -57,7 +57,7 @@ def run_gemm(O, be, tname, n, k, T, norm, glu=False, acc=False, seed=0, packed=N
     return packed, x, got
 
 
-CASES = [("Q5_K", 40, 512, 5, 0), ("Q5_K", 66, 1280, 34, 1), ("Q5_K", 32, 2816, 3, 0), ("Q4_K", 40, 512, 5, 0), ("Q4_K", 36, 1280, 4, 1), ("Q4_K", 130, 1024, 33, 1), ("Q4_K", 64, 4096, 7, 1), ("Q4_K", 33, 2816, 3, 0), ("Q6_K", 40, 512, 5, 0), ("Q6_K", 70, 1024, 130, 1),
+CASES = [("Q8_0", 40, 512, 5, 0), ("Q8_0", 66, 1280, 34, 1), ("Q8_0", 130, 1024, 133, 1), ("Q8_0", 32, 2816, 3, 0), ("Q5_K", 40, 512, 5, 0), ("Q5_K", 66, 1280, 34, 1), ("Q5_K", 32, 2816, 3, 0), ("Q4_K", 40, 512, 5, 0), ("Q4_K", 36, 1280, 4, 1), ("Q4_K", 130, 1024, 33, 1), ("Q4_K", 64, 4096, 7, 1), ("Q4_K", 33, 2816, 3, 0), ("Q6_K", 40, 512, 5, 0), ("Q6_K", 70, 1024, 130, 1),
          ("Q6_K", 32, 3584, 4, 0)]
 
 
@@ -70,6 +70,7 @@ def test_gemm_qi_glu_and_accumulate_host_emulation(oracle):
     run_gemm(oracle, HostBackend(), "Q4_K", 48, 768, 6, 0, glu=True, seed=1)
     run_gemm(oracle, HostBackend(), "Q6_K", 36, 512, 9, 0, acc=True, seed=2)
     run_gemm(oracle, HostBackend(), "Q5_K", 40, 768, 6, 0, glu=True, acc=True, seed=3)
+    run_gemm(oracle, HostBackend(), "Q8_0", 40, 768, 6, 0, glu=True, acc=True, seed=4)
 
 
 def q5k_extreme_blocks(n, k):
@@ -108,7 +109,7 @@ def test_gemm_qi_q5k_extreme_magnitudes_gpu(oracle, dev):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("tname,n,k,T,norm", CASES + [("Q4_K", 4096, 4096, 512, 1), ("Q5_K", 2048, 4096, 300, 1), ("Q5_K", 512, 14336, 129, 0), ("Q4_K", 1024, 14336, 300, 0), ("Q6_K", 1024, 4096, 512, 1), ("Q6_K", 512, 14336, 129, 0),
-                                                     ("Q4_K", 28672, 4096, 64, 1)])
+                                                     ("Q4_K", 28672, 4096, 64, 1), ("Q8_0", 4096, 4096, 512, 1), ("Q8_0", 1024, 14336, 300, 0)])
 def test_gemm_qi_gpu(oracle, dev, tname, n, k, T, norm):
     run_gemm(oracle, GpuBackend(dev), tname, n, k, T, norm, seed=n + k + T)
 
@@ -117,6 +118,7 @@ def test_gemm_qi_gpu(oracle, dev, tname, n, k, T, norm):
 def test_gemm_qi_glu_and_accumulate_gpu(oracle, dev):
     run_gemm(oracle, GpuBackend(dev), "Q4_K", 512, 14336, 70, 0, glu=True, seed=1)
     run_gemm(oracle, GpuBackend(dev), "Q6_K", 4096, 4096, 200, 0, acc=True, seed=2)
+    run_gemm(oracle, GpuBackend(dev), "Q8_0", 512, 14336, 70, 0, glu=True, acc=True, seed=3)
 
 
 @pytest.mark.gpu

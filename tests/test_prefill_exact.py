@@ -58,33 +58,42 @@ def test_prompt_attention_equals_decode_attention_gpu(oracle, dev, heads, kvh, T
     check_attention(oracle, GpuBackend(dev), heads, kvh, T, max_ctx, kvd, window, start)
 
 
+Q80 = lambda O: dict(embd=O.Q8_0, q=O.Q8_0, k=O.Q8_0, v=O.Q8_0, o=O.Q8_0, gate=O.Q8_0, up=O.Q8_0, down=O.Q8_0, output=O.Q8_0)  # BASELINE configs[2]: every linear Q8_0 (ISQ)
+MIXED = lambda O: dict(embd=O.Q4_K, q=O.Q8_0, k=O.Q8_0, v=O.Q8_0, o=O.Q4_K, gate=O.Q4_K, up=O.Q4_K, down=O.Q8_0, output=O.Q6_K)  # both activation formats in one model
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("kv,mix", [("bf16", "q4km"), ("f16", "q4km"), ("bf16", "q5")])
+@pytest.mark.parametrize("kv,mix", [("bf16", "q4km"), ("f16", "q4km"), ("bf16", "q5"), ("bf16", "q8_0"), ("bf16", "mixed"), ("bf16", "moe4"), ("bf16", "moe4-q8_0")])
 def test_prefill_equals_token_by_token_decode_and_engine_order_oracle(oracle, dev, request, kv, mix):
-    """2-layer Q4_K_M model (q5: Q5_K linears + Q6_K down / output, round 5): prefill(prompt) leaves the SAME KV pages and returns the SAME logits as decoding the prompt token by token, both equal
+    """2-layer Q4_K_M model (q5: Q5_K linears + Q6_K down / output, round 5; q8_0: every linear Q8_0 = configs[2]; moe4: 4 experts, top-2 = configs[4]'s layer shape, round 6):
+    prefill(prompt) leaves the SAME KV pages and returns the SAME logits as decoding the prompt token by token, both equal
     LlamaRef(mode="engine") bit for bit, and decoding on from the prefilled pages stays bit-identical to the oracle (greedy)."""
     import torch
     from oracle import llama_ref
     emu = request.config.getoption("--host-emulation")
     n_prompt, n_more = (9, 2) if emu else (70, 16)
-    types = {"q4km": Q4KM, "q5": Q5}[mix](oracle)
-    cfg, w, m1, cos, sin = _mk(oracle, dev, types, kv)
-    _, _, m2, _, _ = _mk(oracle, dev, types, kv)
+    types = {"q4km": Q4KM, "q5": Q5, "q8_0": Q80, "mixed": MIXED, "moe4": Q4KM, "moe4-q8_0": Q80}[mix](oracle)
+    experts = 4 if mix.startswith("moe4") else 0
+    cfg, w, m1, cos, sin = _mk(oracle, dev, types, kv, experts=experts)
+    _, _, m2, _, _ = _mk(oracle, dev, types, kv, experts=experts)
     assert m1.prefill_is_exact
     ref = llama_ref.LlamaRef(cfg, w, cos, sin, mode="engine", kv_dtype=kv)
+    # sparse-MoE layers: the oracle's router / expert combination is an f64 restatement (tests/test_dec_model.py holds the engine to it statistically), not the engine's
+    # f32 order -- the bit-exact claim of those cases is prefill == token-by-token decode (logits, KV pages, chunked == one pass, decoding on from the pages)
+    bit_oracle = experts == 0
     prompt = [(1000 + 37 * i) % cfg.vocab_size for i in range(n_prompt)]
     lp = m1.prefill(prompt, 0).float().cpu().numpy()
     for pos, t in enumerate(prompt):
-        want = ref.step(t, pos)
+        want = ref.step(t, pos) if bit_oracle else None
         m2.set_state([t], [pos])
         ld = m2.forward_logits(1)[0].float().cpu().numpy()
-        assert np.array_equal(ld, want), f"decode position {pos} differs from the engine-order oracle"
+        assert not bit_oracle or np.array_equal(ld, want), f"decode position {pos} differs from the engine-order oracle"
     assert np.array_equal(lp, ld), f"prefill logits differ from token-by-token decode: max |d| = {float(np.abs(lp - ld).max()):.3e}"
     for layer, (k1, k2, v1, v2) in enumerate(zip(m1.key_caches, m2.key_caches, m1.value_caches, m2.value_caches)):
         assert torch.equal(k1.view(torch.int16), k2.view(torch.int16)), f"layer {layer}: K pages written by prefill != pages written by decode"
         assert torch.equal(v1.view(torch.int16), v2.view(torch.int16)), f"layer {layer}: V pages written by prefill != pages written by decode"
     # the same prompt in two chunks (second chunk at start_pos > 0 attends the pages of the first): same pages, same logits
-    _, _, m3, _, _ = _mk(oracle, dev, types, kv)
+    _, _, m3, _, _ = _mk(oracle, dev, types, kv, experts=experts)
     cut = n_prompt // 2 + 1
     m3.prefill(prompt[:cut], 0)
     lc = m3.prefill(prompt[cut:], cut).float().cpu().numpy()
@@ -93,8 +102,11 @@ def test_prefill_equals_token_by_token_decode_and_engine_order_oracle(oracle, de
         assert torch.equal(k1.view(torch.int16), k3.view(torch.int16)) and torch.equal(v1.view(torch.int16), v3.view(torch.int16)), f"layer {layer}: chunked prefill pages differ"
     tok = int(lp.argmax())
     for pos in range(n_prompt, n_prompt + n_more):
-        want = ref.step(tok, pos)
         m1.set_state([tok], [pos])
         got = m1.forward_logits(1)[0].float().cpu().numpy()
-        assert np.array_equal(got, want), f"position {pos} after the prefill differs from the engine-order oracle"
+        if bit_oracle:
+            assert np.array_equal(got, ref.step(tok, pos)), f"position {pos} after the prefill differs from the engine-order oracle"
+        else:  # the runner that decoded the prompt token by token continues from ITS pages: same logits
+            m2.set_state([tok], [pos])
+            assert np.array_equal(got, m2.forward_logits(1)[0].float().cpu().numpy()), f"position {pos}: decoding on from prefilled pages differs from decoding on from decoded pages"
         tok = int(got.argmax())
