@@ -698,14 +698,18 @@ def main():
             r = timed_run(model, cfg, a.prompt_len, a.steps, a.warmup, a.batch, sync, world, dev)
     prompt, ttft, prefill_flops, B, t_all, dev_s, toks = r["prompt"], r["ttft"], r["prefill_flops"], r["B"], r["t_all"], r["dev_s"], r["toks"]
     prefill_exact = bool(model.prefill_is_exact)
-    ttft_bf16 = None
+    ttft_bf16, ttft_bf16_fused = None, None
     if prefill_exact and world == 1:  # the same prompt through the bf16-operand MFMA GEMMs + flash attention (selectable: Llama.set_prefill_mode(0) / MRS_PREFILL_EXACT=0)
-        model.set_prefill_mode(0)
-        model.prefill(prompt, 0, seq=min(1, cfg.max_batch - 1))
-        sync()
-        t0 = time.perf_counter()
-        int(model.prefill(prompt, 0, seq=min(1, cfg.max_batch - 1)).argmax())
-        ttft_bf16 = time.perf_counter() - t0
+        def timed_prefill(mode):
+            model.set_prefill_mode(mode)
+            model.prefill(prompt, 0, seq=min(1, cfg.max_batch - 1))
+            sync()
+            t0 = time.perf_counter()
+            int(model.prefill(prompt, 0, seq=min(1, cfg.max_batch - 1)).argmax())
+            return time.perf_counter() - t0
+        ttft_bf16 = timed_prefill(0)  # library bf16 GEMMs on the bf16 shadow copy of the weights when the model has one (csrc/ext_gemm_lt.hip), else the fused block dequant
+        if model.bf16_shadow:
+            ttft_bf16_fused = timed_prefill(2)  # A / B: the fused block-dequant -> bf16 MFMA kernels of rounds 2-5 on the same prompt
         model.set_prefill_mode(-1)
 
     # ---------------- roofline of the dominant kernel: the decode engine's gate/up phase (RMSNorm + Q8_K quantize + 2 x [ffn, d] GEMV + SiLU*up),
@@ -820,6 +824,10 @@ def main():
         rl["in_graph"]["frac"] = round(kern_bytes / (rl["in_graph"]["us_per_launch"] * 1e-6) / HBM_PEAK, 4)
     if ttft_bf16 is not None:
         out["prefill_bf16"] = {"tokens_per_sec": round(a.prompt_len / ttft_bf16, 1), "ttft_ms": round(1e3 * ttft_bf16, 2), "frac": round(prefill_flops / ttft_bf16 / MFMA_PEAK, 4),
+                               "gemm": ("hipBLASLt bf16 x bf16 -> f32 on a bf16 shadow copy of the dense linears (dequantized once at load: 2 bytes per weight)" if model.bf16_shadow
+                                        else "fused block dequant -> bf16 MFMA (mrs_gemm_q_bf16_multi)"),
+                               **({"fused_dequant_kernels": {"tokens_per_sec": round(a.prompt_len / ttft_bf16_fused, 1), "ttft_ms": round(1e3 * ttft_bf16_fused, 2),
+                                                             "frac": round(prefill_flops / ttft_bf16_fused / MFMA_PEAK, 4)}} if ttft_bf16_fused else {}),
                                "note": "same prompt through the selectable bf16-operand path (Llama.set_prefill_mode(0) / MRS_PREFILL_EXACT=0): faster, but its logits and KV pages are "
                                        "only close to (not identical with) the decode engine's -- the default keeps the reference CPU arithmetic"}
     if ar is not None:

@@ -261,7 +261,16 @@ int mrs_llama_set_qi_tensor(void *model, const char *name, const void *planes); 
 int mrs_llama_prefill_is_exact(void *model); /* 1: mrs_llama_prefill runs in the decode engine's arithmetic (every linear has its MFMA-order copy, decode engine on; tensor-parallel shards and sparse-MoE layers included) */
 /* prompt arithmetic: 1 = the decode engine's (default where mrs_llama_prefill_is_exact allows it), 0 = bf16-operand MFMA GEMMs + MFMA flash attention (faster TTFT,
  * logits within ~1e-2 of the engine's instead of identical), -1 = follow the MRS_PREFILL_EXACT environment variable */
-int mrs_llama_set_prefill_mode(void *model, int exact);
+int mrs_llama_set_prefill_mode(void *model, int exact); /* 2 = the bf16 path with the fused block-dequant kernels forced (A / B against the bf16 shadow copy) */
+/* round 6: the selectable bf16 prompt path on a bf16 SHADOW COPY of the dense linears (csrc/ext_gemm_lt.hip): rows [n][k] bf16 from mrs_dequantize(..., 30) at load time,
+ * registered per tensor; with one for every dense linear, prefill mode 0 runs plain bf16 x bf16 -> f32 library GEMMs (hipBLASLt) on bf16 activation rows.
+ * mrs_lt_gemm_bf16: out f32 [T][ldo] (+)= x [T][K] . w [N][K]^T; first call per shape plans (not inside a stream capture). */
+int mrs_llama_set_bf16_tensor(void *model, const char *name, const void *rows_bf16);
+int mrs_llama_bf16_shadow_ok(void *model);
+int mrs_lt_gemm_bf16(const void *w_bf16, const void *x_bf16, float *out, int ldo, int N, int K, int T, int accumulate, void *stream);
+int mrs_rows_f32_to_bf16(const float *x, int ldx, int M, int K, void *y, void *stream);
+int mrs_rows_glu_bf16(const float *g, const float *u, int ld, int M, int N, void *y, void *stream);
+int mrs_rows_rms_norm_bf16(const float *x, const float *w, int M, int K, float eps, void *y, void *stream);
 /* diagnostics: pull a byte range through the Infinity Cache (ext_prefetch.hip); one wave of K-deep v_mfma_f32_32x32x16_f16 on caller operands (the exactness
  * premise of mrs_gemm_qi, tests/test_gemm_qi.py) */
 int mrs_l3_prefetch(const void *p, size_t bytes, int workgroups, void *sink, void *stream);

@@ -957,7 +957,7 @@ constexpr int PM_P = PM_NW * 32 * 32 * 4;                  // probabilities of t
 constexpr int PM_SC = PM_NW * 3 * 32 * 4;                  // per slot and query: block sum, alpha, merge weight
 // + per block and query the block maximum of pass A: 128 bytes per 32-token block of the longest context (sized by the launcher)
 template <class CT>
-__global__ void __launch_bounds__(64 * PM_NW) prefill_attn_mfma_kernel(const dec::AttnArgs a, int max_blocks_lds) {
+__global__ void __launch_bounds__(64 * PM_NW, 2) prefill_attn_mfma_kernel(const dec::AttnArgs a, int max_blocks_lds) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = tid_opaque(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, hf = lane >> 5;
@@ -991,27 +991,32 @@ __global__ void __launch_bounds__(64 * PM_NW) prefill_attn_mfma_kernel(const dec
   f16v zero;
 #pragma unroll
   for (int v = 0; v < 16; ++v) zero[v] = 0.f;
-  // scores of block b for the 32 queries: lane (query j, half hf) gets tokens i = 8 (v / 4) + 4 hf + v % 4 (the accumulator layout); masked + scaled; returns the block max
-  auto scores = [&](int b, float (&val)[16], bool (&ok)[16]) -> float {
-    const size_t base = (size_t)bt[b] * a.kv_block_stride + (size_t)kvh * a.kv_head_stride;
-    const uint16_t *kb = a.k_cache + base + (size_t)j * 8;  // A operand: lane (token j, half) supplies K[token j][2 s + kp]; chunk c = dims 8 c .. 8 c + 7
+  // K of a block as the A operand of the score MFMAs: lane (token j, half) supplies K[token j][2 s + kp]; chunk c = dims 8 c .. 8 c + 7 (16 bytes).  The 16 chunk
+  // registers are a ring in place: chunk c of the NEXT block the wave will score is requested as soon as chunk c of the current one has been converted (a block's
+  // loads used to sit exposed in front of its MFMAs; a second register set costs the occupancy: 220 + 48 registers)
+  auto k_ptr = [&](int b) { return a.k_cache + (size_t)bt[b] * a.kv_block_stride + (size_t)kvh * a.kv_head_stride + (size_t)j * 8; };
+  auto load_k = [&](int b, v4u (&kr)[16]) {
+    const uint16_t *kb = k_ptr(b);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) kr[c] = *(const v4u *)(kb + (size_t)c * 32 * 8);
+  };
+  // scores of block b for the 32 queries: lane (query j, half hf) gets tokens i = 8 (v / 4) + 4 hf + v % 4 (the accumulator layout); masked + scaled; returns the block max.
+  // b_next: the block whose K replaces the registers (b itself when there is none: the reload is then unused, the code stays straight-line)
+  auto scores = [&](v4u (&kr)[16], int b, int b_next, float (&val)[16], bool (&ok)[16]) -> float {
+    const uint16_t *kn = k_ptr(b_next);
     f16v acc0 = zero, acc1 = zero;
 #pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2) {
-      v4u kr[8];
+    for (int c = 0; c < 16; ++c) {
+      const unsigned w4[4] = {kr[c].x, kr[c].y, kr[c].z, kr[c].w};
+      float kv[4];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) kr[c] = *(const v4u *)(kb + (size_t)(h2 * 8 + c) * 32 * 8);
+      for (int u = 0; u < 4; ++u) kv[u] = kp ? cvt16_hi<CT>(w4[u]) : cvt16_lo<CT>(w4[u]);
+      kr[c] = *(const v4u *)(kn + (size_t)c * 32 * 8);
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const unsigned w4[4] = {kr[c].x, kr[c].y, kr[c].z, kr[c].w};
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int s = (h2 * 8 + c) * 4 + u;
-          const float kv = kp ? cvt16_hi<CT>(w4[u]) : cvt16_lo<CT>(w4[u]);
-          const float qv = q_s[s * 64 + lane];
-          if (h2 == 0) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kv, qv, acc0, 0, 0, 0);
-          else acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kv, qv, acc1, 0, 0, 0);
-        }
+      for (int u = 0; u < 4; ++u) {
+        const float qv = q_s[(c * 4 + u) * 64 + lane];
+        if (c < 8) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[u], qv, acc0, 0, 0, 0);
+        else acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[u], qv, acc1, 0, 0, 0);
       }
     }
     float mx = -FLT_MAX;
@@ -1025,10 +1030,12 @@ __global__ void __launch_bounds__(64 * PM_NW) prefill_attn_mfma_kernel(const dec
     }
     return fmaxf(mx, __shfl_xor(mx, 32, 64));
   };
-  // ---- pass A: block maxima (wave w: blocks w, w + 4, ...)
+  v4u kcur[16];
+  // ---- pass A: block maxima (wave w: blocks w, w + 4, ...); its last call reloads the wave's first block for pass B
+  if (wave < nblk) load_k(wave, kcur);
   for (int b = wave; b < nblk; b += PM_NW) {
     float val[16]; bool ok[16];
-    const float mx = scores(b, val, ok);
+    const float mx = scores(kcur, b, b + PM_NW < nblk ? b + PM_NW : wave, val, ok);
     if (hf == 0) mx_s[b * 32 + j] = mx;
   }
   __syncthreads();
@@ -1038,12 +1045,21 @@ __global__ void __launch_bounds__(64 * PM_NW) prefill_attn_mfma_kernel(const dec
   // ---- pass B
   f16v acc = zero, osp = zero;  // merge accumulator and the current split's running output: dims 32 wave + 8 (v / 4) + 4 hf + v % 4 of query j
   float s_all = 0.f, l_run = 0.f;
+  // V of block b, dims 32 wave .. + 31, as the A operand of the P . V MFMAs: lane (dim row, half) supplies V[dim][token 2 s + kp] = dword s of the dim's 32-token row
+  auto load_v = [&](int b, v4u (&vr)[4]) {
+    const size_t base = (size_t)bt[b] * a.kv_block_stride + (size_t)kvh * a.kv_head_stride;
+    const uint16_t *vb = a.v_cache + base + (size_t)(32 * wave + j) * 32;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) vr[c] = *(const v4u *)(vb + c * 8);
+  };
   for (int g0 = 0; g0 < nblk; g0 += PM_NW) {
+    v4u vcur[4], vnext[4];
+    load_v(g0, vcur);  // phase 2's first block: in flight during phase 1
     {  // phase 1
       const int b = g0 + wave;
       if (b < nblk) {
         float val[16]; bool ok[16];
-        const float mx = scores(b, val, ok);
+        const float mx = scores(kcur, b, b + PM_NW < nblk ? b + PM_NW : b, val, ok);  // the next group's block arrives during phase 2
         const int b0 = (b / bpw) * bpw;  // first block of the split
         float m_before = -FLT_MAX;
         for (int bb = b0; bb < b; ++bb) m_before = fmaxf(m_before, mx_s[bb * 32 + j]);
@@ -1076,15 +1092,10 @@ __global__ void __launch_bounds__(64 * PM_NW) prefill_attn_mfma_kernel(const dec
       const int nb = min(PM_NW, nblk - g0);
       for (int sl = 0; sl < nb; ++sl) {
         const int b = g0 + sl;
+        if (sl + 1 < nb) load_v(b + 1, vnext);
         const bool first = b % bpw == 0, last = (b + 1) % bpw == 0 || b + 1 == nblk;
         const float *sw = sc_s + (size_t)sl * 96;
         const float ps = sw[j], alpha = sw[32 + j], wsp = sw[64 + j];
-        // A operand: lane (dim row i = lane & 31 of the wave's 32 dims, half) supplies V[dim][token 2 s + kp]: dword s of the dim's 32-token row, low / high half
-        const size_t base = (size_t)bt[b] * a.kv_block_stride + (size_t)kvh * a.kv_head_stride;
-        const uint16_t *vb = a.v_cache + base + (size_t)(32 * wave + j) * 32;
-        v4u vr[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) vr[c] = *(const v4u *)(vb + c * 8);
         f16v o;
         if (first) { o = zero; l_run = ps; }
         else {
@@ -1095,7 +1106,7 @@ __global__ void __launch_bounds__(64 * PM_NW) prefill_attn_mfma_kernel(const dec
         const float *pr = p_s + (size_t)sl * 1024;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const unsigned w4[4] = {vr[c].x, vr[c].y, vr[c].z, vr[c].w};
+          const unsigned w4[4] = {vcur[c].x, vcur[c].y, vcur[c].z, vcur[c].w};
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int s = 4 * c + u, tok = 2 * s + kp;
@@ -1111,6 +1122,8 @@ __global__ void __launch_bounds__(64 * PM_NW) prefill_attn_mfma_kernel(const dec
 #pragma unroll
           for (int v = 0; v < 16; ++v) { const float t0 = o[v] * wsp; acc[v] = acc[v] + t0; }
         }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) vcur[c] = vnext[c];
       }
     }
     __syncthreads();

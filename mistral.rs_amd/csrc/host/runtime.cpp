@@ -69,6 +69,7 @@ struct QTensor {
   int dtype = -1;
   int64_t rows = 0, cols = 0;
   mutable const void *qi = nullptr;  // MFMA-order copy for the exact-integer prompt GEMM of ext_gemm_qi.hip (mrs_gemm_qi_repack; caller-owned, optional)
+  mutable const void *bf16 = nullptr;  // bf16 shadow copy [rows][cols] (mrs_dequantize at load time; caller-owned, optional): the selectable bf16 prompt path then runs plain library GEMMs (ext_gemm_lt.hip)
   size_t nbytes() const { const auto *t = type_info(dtype); return t ? (size_t)rows * (cols / t->block) * t->bytes : 0; }
 };
 
@@ -94,6 +95,7 @@ typedef void (*plain_fn)(const void *, const void *, void *, int, int, int, int,
 typedef void (*glu_fn)(const void *, const void *, const void *, void *, int, int, int, int, int, int, void *);
 typedef void (*qkv_fn)(const void *, const void *, const void *, const void *, void *, void *, void *, int, int, int, int, int, int, void *);
 
+static void *lookup_quiet(const char *sym) { return dlsym(RTLD_DEFAULT, sym); }  // optional entry points (absent from the host-emulation build)
 static void *lookup(const std::string &sym) {  // resolved once per (symbol) and cached
   static std::vector<std::pair<std::string, void *>> cache;
   for (auto &e : cache) if (e.first == sym) return e.second;
@@ -595,10 +597,19 @@ class Llama {
   //      (ext_gemm_qi.hip), attention = the decode kernels' per-block partials and merge per query token, RoPE / cache write / SiLU / residual adds = the decode
   //      expressions.  A prompt token's hidden states, KV pages and logits are bit for bit what a token-by-token decode produces (tests/test_prefill_exact.py);
   //      the role in the reference is the CPU prompt path (QMatMul f32 fallback per row, gguf/mod.rs:465-478; attention/backends/cpu).
-  int prefill_mode = -1;  // -1: MRS_PREFILL_EXACT (default 1); 0: bf16-operand MFMA prompt GEMMs (mrs_gemm_q_bf16_multi + flash attention); 1: exact path
+  int prefill_mode = -1;  // -1: MRS_PREFILL_EXACT (default 1); 0: bf16-operand MFMA prompt GEMMs (library GEMMs on the bf16 shadow copy when every dense linear has one, else mrs_gemm_q_bf16_multi; + flash attention); 1: exact path; 2: as 0 with the fused-dequant kernels forced
+  bool bf16_shadow_ok() const {
+    if (cfg.num_experts > 0 || blocks.empty()) return false;
+    for (const Block &bl : blocks) {
+      const GgufMatMul *ls[7] = {bl.q_proj.get(), bl.k_proj.get(), bl.v_proj.get(), bl.o_proj.get(), bl.gate_proj.get(), bl.up_proj.get(), bl.down_proj.get()};
+      for (const GgufMatMul *l : ls)
+        if (!l || !l->get_qtensor() || !l->get_qtensor()->bf16) return false;
+    }
+    return true;
+  }
   bool prefill_exact_ok() const {
     static const int env_want = [] { const char *e = getenv("MRS_PREFILL_EXACT"); return e ? atoi(e) : 1; }();
-    const int want = prefill_mode >= 0 ? prefill_mode : env_want;
+    const int want = prefill_mode >= 0 ? (prefill_mode == 1 ? 1 : 0) : env_want;
     // round 6: tensor-parallel shards (the row-parallel projections write h * (1 / world) + W_shard . y like the decode step's RESID epilogue, then the same ONE sum
     // all-reduce of h) and sparse-MoE layers (moe_ffn_exact) run in the engine's arithmetic too
     if (!want || cfg.use_fused != 2 || !engine_ok() || cfg.head_dim != 128 || cfg.block_size != 32) return false;
@@ -794,6 +805,48 @@ class Llama {
     const int bs = cfg.block_size, kvh = cfg.num_kv_heads;
     const int eff_max = std::min(cfg.max_blocks_per_seq * bs, cfg.max_context_len);
     const int parts = (eff_max + 511) / 512;
+    // ---- round 6: every dense linear has a bf16 shadow copy -> the prompt GEMMs are plain bf16 library GEMMs (ext_gemm_lt.hip: hipBLASLt), the activations bf16 ROWS;
+    //      same arithmetic as the fused-dequant kernels below (weights rounded to bf16 once, f32 accumulation) in the library's summation order.  prefill_mode 2 forces the
+    //      fused-dequant kernels (A / B).
+    typedef int (*lt_gemm_fn)(const void *, const void *, float *, int, int, int, int, int, void *);
+    typedef int (*lt_rows_fn)(const float *, int, int, int, void *, void *);
+    typedef int (*lt_glu_fn)(const float *, const float *, int, int, int, void *, void *);
+    typedef int (*lt_norm_fn)(const float *, const float *, int, int, float, void *, void *);
+    static const lt_gemm_fn lt_gemm = (lt_gemm_fn)lookup_quiet("mrs_lt_gemm_bf16");
+    static const lt_rows_fn lt_rows = (lt_rows_fn)lookup_quiet("mrs_rows_f32_to_bf16");
+    static const lt_glu_fn lt_glu = (lt_glu_fn)lookup_quiet("mrs_rows_glu_bf16");
+    static const lt_norm_fn lt_norm = (lt_norm_fn)lookup_quiet("mrs_rows_rms_norm_bf16");
+    if (big && bf16_shadow_ok() && prefill_mode != 2 && lt_gemm && lt_rows && lt_glu && lt_norm && cfg.num_experts == 0 && cfg.head_dim == 128 && cfg.block_size == 32 &&
+        d % 8 == 0 && nq % 8 == 0 && ff % 8 == 0) {
+      auto lgemm = [&](const GgufMatMul &m, int N, int K, float *out, int acc) -> int {
+        const int rc = lt_gemm(m.get_qtensor()->bf16, xb, out, N, N, K, T, acc, s);
+        return rc ? fail("prefill (bf16 shadow): library GEMM refused N=%d K=%d T=%d (%d)", N, K, T, rc) : 0;
+      };
+      for (size_t li = 0; li < blocks.size(); ++li) {
+        const Block &bl = blocks[li];
+        if (!bl.q_proj || !bl.key_cache) return fail("layer %zu is incomplete", li);
+        if (lt_norm(h, bl.input_layernorm, T, d, cfg.rms_eps, xb, s)) return fail("prefill (bf16 shadow): hidden size must be a multiple of 8");
+        if (lgemm(*bl.q_proj, nq, d, q, 0) || lgemm(*bl.k_proj, nkv, d, k, 0) || lgemm(*bl.v_proj, nkv, d, v, 0)) return -1;
+        rotary_embedding_positions(q, k, (void *)bufs.cos_table, (void *)bufs.sin_table, (void *)pa.positions, cfg.rope_interleaved ? 0 : 1, hd, T,
+                                   cfg.rot_dim / 2, cfg.max_context_len, cfg.num_heads, cfg.num_kv_heads, nq, nkv, 2, st);
+        reshape_and_cache(k, v, bl.key_cache, bl.value_cache, (int64_t *)pa.slot_mapping, T, cfg.num_kv_heads, hd, bs, 8, nkv, nkv, s, 2, 1, nullptr, nullptr);
+        if (mrs_prefill_attention_window_f32_bf16(q, bl.key_cache, bl.value_cache, pa.block_tables, attn, T, start_pos, cfg.num_heads, kvh, hd, bs, nq, nq,
+                                                  kvh * hd * bs, hd * bs, 1.0f / sqrtf((float)hd), cfg.sliding_window, s) != 0)
+          return fail("prefill (bf16 shadow): the MFMA flash attention refused the shape (head_dim 128, block 32)");
+        if (lt_rows(attn, nq, T, nq, xb, s)) return -1;
+        if (cfg.world_size > 1) { if (lgemm(*bl.o_proj, d, nq, xn, 0) || all_reduce(xn, t * d, s) || mrs_vec_add_f32(h, xn, t * d, s)) return -1; }
+        else if (lgemm(*bl.o_proj, d, nq, h, 1)) return -1;
+        if (lt_norm(h, bl.post_attention_layernorm, T, d, cfg.rms_eps, xb, s)) return -1;
+        if (lgemm(*bl.gate_proj, ff, d, g, 0) || lgemm(*bl.up_proj, ff, d, u, 0)) return -1;
+        if (lt_glu(g, u, ff, T, ff, xb, s)) return -1;
+        if (cfg.world_size > 1) { if (lgemm(*bl.down_proj, d, ff, xn, 0) || all_reduce(xn, t * d, s) || mrs_vec_add_f32(h, xn, t * d, s)) return -1; }
+        else if (lgemm(*bl.down_proj, d, ff, h, 1)) return -1;
+      }
+      const QTensor *lm = lm_head->get_qtensor();
+      if (!mrs_decode_gemv_supported(lm->dtype)) return fail("prefill (bf16 shadow): lm_head dtype %d", lm->dtype);
+      if (mrs_decode_norm_proj(lm->data, lm->dtype, cfg.vocab_size, d, h + (t - 1) * d, ln_f, cfg.rms_eps, pa.logits, cfg.vocab_size, 1, s)) return fail("prefill: lm_head refused");
+      return 0;
+    }
     const bool use_v1 = (parts == 1 || (long)T * cfg.num_heads > 512);  // paged_attention.rs:302-307 (only consulted when the MFMA flash kernel refuses the shape)
     for (size_t li = 0; li < blocks.size(); ++li) {
       const Block &bl = blocks[li];
@@ -1071,6 +1124,27 @@ extern "C" int mrs_llama_set_qi_tensor(void *mm, const char *cname, const void *
   }
   return mrs_host::fail("MFMA layout: tensor %s has no prompt-GEMM role", cname);
 }
+// bf16 shadow copy (mrs_dequantize(..., out_dtype = 30), caller-owned) of a dense linear already registered with mrs_llama_set_tensor: with one for every dense linear the
+// selectable bf16 prompt path (mrs_llama_set_prefill_mode(model, 0)) runs plain bf16 library GEMMs (csrc/ext_gemm_lt.hip)
+extern "C" int mrs_llama_set_bf16_tensor(void *mm, const char *cname, const void *rows_bf16) {
+  Llama &m = *(Llama *)mm;
+  const std::string name = cname;
+  int layer = -1, consumed = 0;
+  if (sscanf(cname, "blk.%d.%n", &layer, &consumed) == 1 && consumed > 0 && layer >= 0 && layer < m.cfg.num_layers) {
+    mrs_host::Block &b = m.blocks[layer];
+    const std::string rest = name.substr(consumed);
+    const std::unique_ptr<mrs_host::GgufMatMul> *slot = rest == "attn_q.weight" ? &b.q_proj : rest == "attn_k.weight" ? &b.k_proj : rest == "attn_v.weight" ? &b.v_proj
+        : rest == "attn_output.weight" ? &b.o_proj : rest == "ffn_gate.weight" ? &b.gate_proj : rest == "ffn_up.weight" ? &b.up_proj : rest == "ffn_down.weight" ? &b.down_proj : nullptr;
+    if (slot) {
+      const mrs_host::QTensor *t = *slot ? (*slot)->get_qtensor() : nullptr;
+      if (!t || !t->data) return mrs_host::fail("bf16 shadow for %s: register the tensor with mrs_llama_set_tensor first", cname);
+      t->bf16 = rows_bf16;
+      return 0;
+    }
+  }
+  return mrs_host::fail("bf16 shadow: tensor %s has no prompt-GEMM role", cname);
+}
+extern "C" int mrs_llama_bf16_shadow_ok(void *m) { return ((Llama *)m)->bf16_shadow_ok() ? 1 : 0; }
 extern "C" int mrs_llama_set_mode(void *m, int use_fused) {
   if (use_fused < 0 || use_fused > 2) return mrs_host::fail("mrs_llama_set_mode: 0, 1 or 2");
   ((Llama *)m)->cfg.use_fused = use_fused;

@@ -166,6 +166,16 @@ class Llama:
         L.mrs_gemm_qi_repack.argtypes = [C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p]
         L.mrs_llama_set_qi_tensor.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
         self._exact_prefill_wanted = os.environ.get("MRS_PREFILL_EXACT", "1") not in ("", "0")
+        # bf16 shadow copy of the dense linears for the SELECTABLE bf16 prompt path (csrc/ext_gemm_lt.hip: plain library GEMMs instead of the fused block dequant): 2 bytes
+        # per weight.  MRS_PREFILL_BF16_SHADOW = 1 / 0 / auto (default): auto takes it when the copy stays below MRS_BF16_SHADOW_MAX_GB (24): Llama-3-8B yes (14 GB),
+        # Llama-3-70B no (137 GB next to three other copies of the weights)
+        d_, ff_ = cfg.hidden_size, cfg.intermediate_size
+        shadow_bytes = 2.0 * cfg.num_layers * (2 * cfg.num_heads * cfg.head_dim * d_ + 2 * cfg.num_kv_heads * cfg.head_dim * d_ + 3 * ff_ * d_)
+        want = os.environ.get("MRS_PREFILL_BF16_SHADOW", "auto")
+        self._bf16_shadow_wanted = (want == "1" or (want == "auto" and shadow_bytes <= float(os.environ.get("MRS_BF16_SHADOW_MAX_GB", "24")) * 2 ** 30)) \
+            and not cfg.num_experts and device.type == "cuda"
+        L.mrs_dequantize.argtypes = [C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.mrs_llama_set_bf16_tensor.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
         L.mrs_last_error.restype = C.c_char_p
         c = _Cfg(cfg.hidden_size, cfg.intermediate_size, cfg.num_layers, cfg.num_heads, cfg.num_kv_heads, cfg.head_dim,
                  cfg.vocab_size, cfg.head_dim, int(cfg.rope_interleaved), cfg.rms_eps, cfg.block_size, cfg.max_blocks_per_seq,
@@ -320,6 +330,11 @@ class Llama:
                     self._chk(self._L.mrs_gemm_qi_repack(t.data.data_ptr(), t.dtype.id, t.shape[0], t.shape[1], qi.data_ptr(), self._stream()))
                     self._keep[name + "#qi"] = qi
                     self._chk(self._L.mrs_llama_set_qi_tensor(self._h, name.encode(), qi.data_ptr()))
+            if self._bf16_shadow_wanted and name.startswith("blk.") and "_exps" not in name:
+                sh = torch.empty(t.shape[0], t.shape[1], dtype=torch.bfloat16, device=self.device)
+                self._chk(self._L.mrs_dequantize(t.data.data_ptr(), t.dtype.id, t.shape[0], t.shape[1], sh.data_ptr(), 30, self._stream()))
+                self._keep[name + "#bf16"] = sh
+                self._chk(self._L.mrs_llama_set_bf16_tensor(self._h, name.encode(), sh.data_ptr()))
         else:
             t = t.to(self.device, torch.float32).contiguous()
             self._keep[name] = t
@@ -466,9 +481,16 @@ class Llama:
         return bool(self._L.mrs_llama_prefill_is_exact(self._h))
 
     def set_prefill_mode(self, exact: int) -> None:
-        """1: prompts in the decode engine's arithmetic (default where available), 0: bf16-operand MFMA GEMMs + flash attention, -1: MRS_PREFILL_EXACT."""
+        """1: prompts in the decode engine's arithmetic (default where available), 0: bf16-operand MFMA GEMMs + flash attention (plain library GEMMs on the bf16 shadow
+        copy of the weights when the model has one, else the fused block-dequant kernels), 2: as 0 with the fused block-dequant kernels forced, -1: MRS_PREFILL_EXACT."""
         self._L.mrs_llama_set_prefill_mode.argtypes = [C.c_void_p, C.c_int]
         self._chk(self._L.mrs_llama_set_prefill_mode(self._h, int(exact)))
+
+    @property
+    def bf16_shadow(self) -> bool:
+        """True when every dense linear has a bf16 shadow copy: set_prefill_mode(0) then runs the prompt GEMMs as plain bf16 library GEMMs (csrc/ext_gemm_lt.hip)."""
+        self._L.mrs_llama_bf16_shadow_ok.argtypes = [C.c_void_p]
+        return bool(self._L.mrs_llama_bf16_shadow_ok(self._h))
 
     def prefill_flops(self, T: int) -> float:
         return float(self._L.mrs_llama_prefill_flops(self._h, T))
