@@ -963,7 +963,12 @@ __global__ void __launch_bounds__(64 * PM_NW, 2) prefill_attn_mfma_kernel(const 
   const int j = lane & 31, hf = lane >> 5;
   const int kp = MRS_MFMA_F32_K1_FIRST ? 1 - hf : hf;  // which element of a pair (dims 2 s, 2 s + 1 / tokens 2 s, 2 s + 1) this lane half supplies so that the chain ascends
   const int head = blockIdx.x, G = a.num_heads / a.num_kv_heads, kvh = head / G;
-  const int tile = (int)gridDim.y - 1 - (int)blockIdx.y;  // longest contexts first
+  // longest contexts first; when the whole grid is resident at once (two workgroups per CU: heads x tiles <= 512) the second half of the dispatch order runs the SHORT
+  // tiles in ascending order, so that the two workgroups sharing a CU's matrix pipes are (longest, shortest), (second longest, second shortest), ...: every CU gets the
+  // same number of blocks (a 512-token prompt: 17 per pair instead of 24 .. 10)
+  const int nty = (int)gridDim.y, hy = (nty + 1) / 2;
+  const bool paired = (int)gridDim.x * nty <= 512 && nty > 1;
+  const int tile = !paired ? nty - 1 - (int)blockIdx.y : ((int)blockIdx.y < hy ? nty - 1 - (int)blockIdx.y : (int)blockIdx.y - hy);
   const int T = a.num_seqs, bpw = a.bpw;
   const int t_q = min(tile * 32 + j, T - 1);
   const bool q_live = tile * 32 + j < T;

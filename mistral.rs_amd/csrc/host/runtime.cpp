@@ -818,27 +818,40 @@ class Llama {
     static const lt_norm_fn lt_norm = (lt_norm_fn)lookup_quiet("mrs_rows_rms_norm_bf16");
     if (big && bf16_shadow_ok() && prefill_mode != 2 && lt_gemm && lt_rows && lt_glu && lt_norm && cfg.num_experts == 0 && cfg.head_dim == 128 && cfg.block_size == 32 &&
         d % 8 == 0 && nq % 8 == 0 && ff % 8 == 0) {
-      auto lgemm = [&](const GgufMatMul &m, int N, int K, float *out, int acc) -> int {
-        const int rc = lt_gemm(m.get_qtensor()->bf16, xb, out, N, N, K, T, acc, s);
+      auto lgemm_at = [&](const void *wb, int N, int K, float *out, int ldo, int acc) -> int {
+        const int rc = lt_gemm(wb, xb, out, ldo, N, K, T, acc, s);
         return rc ? fail("prefill (bf16 shadow): library GEMM refused N=%d K=%d T=%d (%d)", N, K, T, rc) : 0;
       };
+      auto lgemm = [&](const GgufMatMul &m, int N, int K, float *out, int acc) -> int { return lgemm_at(m.get_qtensor()->bf16, N, K, out, N, acc); };
       for (size_t li = 0; li < blocks.size(); ++li) {
         const Block &bl = blocks[li];
         if (!bl.q_proj || !bl.key_cache) return fail("layer %zu is incomplete", li);
         if (lt_norm(h, bl.input_layernorm, T, d, cfg.rms_eps, xb, s)) return fail("prefill (bf16 shadow): hidden size must be a multiple of 8");
-        if (lgemm(*bl.q_proj, nq, d, q, 0) || lgemm(*bl.k_proj, nkv, d, k, 0) || lgemm(*bl.v_proj, nkv, d, v, 0)) return -1;
-        rotary_embedding_positions(q, k, (void *)bufs.cos_table, (void *)bufs.sin_table, (void *)pa.positions, cfg.rope_interleaved ? 0 : 1, hd, T,
-                                   cfg.rot_dim / 2, cfg.max_context_len, cfg.num_heads, cfg.num_kv_heads, nq, nkv, 2, st);
-        reshape_and_cache(k, v, bl.key_cache, bl.value_cache, (int64_t *)pa.slot_mapping, T, cfg.num_kv_heads, hd, bs, 8, nkv, nkv, s, 2, 1, nullptr, nullptr);
-        if (mrs_prefill_attention_window_f32_bf16(q, bl.key_cache, bl.value_cache, pa.block_tables, attn, T, start_pos, cfg.num_heads, kvh, hd, bs, nq, nq,
+        // q / k / v (and gate / up) shadow rows laid out back to back by the loader (llama.py) = ONE GEMM of N = nq + 2 nkv (2 ff) rows: the role of fast_mmq::fused_qkv /
+        // fused_glu (one launch per shared input); the outputs are column ranges of one [T][N] buffer, which rotary / reshape_and_cache / the attention kernel take by stride
+        const char *qb = (const char *)bl.q_proj->get_qtensor()->bf16, *kb = (const char *)bl.k_proj->get_qtensor()->bf16, *vb = (const char *)bl.v_proj->get_qtensor()->bf16;
+        const bool qkv_fused = kb == qb + (size_t)nq * d * 2 && vb == kb + (size_t)nkv * d * 2 && (size_t)(nq + 2 * nkv) <= (size_t)ff;
+        float *qp = q, *kp = k, *vp = v;
+        int qs = nq, ks = nkv;
+        if (qkv_fused) {
+          const int nqkv = nq + 2 * nkv;
+          if (lgemm_at(qb, nqkv, d, g, nqkv, 0)) return -1;  // g [T][ff] is free until the FFN
+          qp = g; kp = g + nq; vp = g + nq + nkv; qs = ks = nqkv;
+        } else if (lgemm(*bl.q_proj, nq, d, q, 0) || lgemm(*bl.k_proj, nkv, d, k, 0) || lgemm(*bl.v_proj, nkv, d, v, 0)) return -1;
+        rotary_embedding_positions(qp, kp, (void *)bufs.cos_table, (void *)bufs.sin_table, (void *)pa.positions, cfg.rope_interleaved ? 0 : 1, hd, T,
+                                   cfg.rot_dim / 2, cfg.max_context_len, cfg.num_heads, cfg.num_kv_heads, qs, ks, 2, st);
+        reshape_and_cache(kp, vp, bl.key_cache, bl.value_cache, (int64_t *)pa.slot_mapping, T, cfg.num_kv_heads, hd, bs, 8, ks, ks, s, 2, 1, nullptr, nullptr);
+        if (mrs_prefill_attention_window_f32_bf16(qp, bl.key_cache, bl.value_cache, pa.block_tables, attn, T, start_pos, cfg.num_heads, kvh, hd, bs, qs, nq,
                                                   kvh * hd * bs, hd * bs, 1.0f / sqrtf((float)hd), cfg.sliding_window, s) != 0)
           return fail("prefill (bf16 shadow): the MFMA flash attention refused the shape (head_dim 128, block 32)");
         if (lt_rows(attn, nq, T, nq, xb, s)) return -1;
         if (cfg.world_size > 1) { if (lgemm(*bl.o_proj, d, nq, xn, 0) || all_reduce(xn, t * d, s) || mrs_vec_add_f32(h, xn, t * d, s)) return -1; }
         else if (lgemm(*bl.o_proj, d, nq, h, 1)) return -1;
         if (lt_norm(h, bl.post_attention_layernorm, T, d, cfg.rms_eps, xb, s)) return -1;
-        if (lgemm(*bl.gate_proj, ff, d, g, 0) || lgemm(*bl.up_proj, ff, d, u, 0)) return -1;
-        if (lt_glu(g, u, ff, T, ff, xb, s)) return -1;
+        const char *gb = (const char *)bl.gate_proj->get_qtensor()->bf16, *ub = (const char *)bl.up_proj->get_qtensor()->bf16;
+        if (ub == gb + (size_t)ff * d * 2 && u == g + t * ff) {  // one GEMM of 2 ff rows into [T][2 ff] = the g and u buffers, which the workspace holds back to back
+          if (lgemm_at(gb, 2 * ff, d, g, 2 * ff, 0) || lt_glu(g, g + ff, 2 * ff, T, ff, xb, s)) return -1;
+        } else if (lgemm(*bl.gate_proj, ff, d, g, 0) || lgemm(*bl.up_proj, ff, d, u, 0) || lt_glu(g, u, ff, T, ff, xb, s)) return -1;
         if (cfg.world_size > 1) { if (lgemm(*bl.down_proj, d, ff, xn, 0) || all_reduce(xn, t * d, s) || mrs_vec_add_f32(h, xn, t * d, s)) return -1; }
         else if (lgemm(*bl.down_proj, d, ff, h, 1)) return -1;
       }

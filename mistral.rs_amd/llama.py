@@ -331,9 +331,21 @@ class Llama:
                     self._keep[name + "#qi"] = qi
                     self._chk(self._L.mrs_llama_set_qi_tensor(self._h, name.encode(), qi.data_ptr()))
             if self._bf16_shadow_wanted and name.startswith("blk.") and "_exps" not in name:
-                sh = torch.empty(t.shape[0], t.shape[1], dtype=torch.bfloat16, device=self.device)
+                # q / k / v and gate / up of a layer share one buffer, rows back to back: the runner then multiplies them in ONE library GEMM (fused_qkv / fused_glu role)
+                layer, role = name.split(".")[1], name.split(".")[2]
+                cfg = self.cfg
+                nq, nkv, ff, d = cfg.num_heads * cfg.head_dim, cfg.num_kv_heads * cfg.head_dim, cfg.intermediate_size, cfg.hidden_size
+                group = {"attn_q": ("qkv", 0, nq + 2 * nkv), "attn_k": ("qkv", nq, nq + 2 * nkv), "attn_v": ("qkv", nq + nkv, nq + 2 * nkv),
+                         "ffn_gate": ("gu", 0, 2 * ff), "ffn_up": ("gu", ff, 2 * ff)}.get(role)
+                if group is not None and t.shape[1] == d:
+                    key = f"blk.{layer}.{group[0]}#bf16"
+                    if key not in self._keep:
+                        self._keep[key] = torch.empty(group[2], d, dtype=torch.bfloat16, device=self.device)
+                    sh = self._keep[key][group[1]: group[1] + t.shape[0]]
+                else:
+                    sh = torch.empty(t.shape[0], t.shape[1], dtype=torch.bfloat16, device=self.device)
+                    self._keep[name + "#bf16"] = sh
                 self._chk(self._L.mrs_dequantize(t.data.data_ptr(), t.dtype.id, t.shape[0], t.shape[1], sh.data_ptr(), 30, self._stream()))
-                self._keep[name + "#bf16"] = sh
                 self._chk(self._L.mrs_llama_set_bf16_tensor(self._h, name.encode(), sh.data_ptr()))
         else:
             t = t.to(self.device, torch.float32).contiguous()
