@@ -328,28 +328,40 @@ __global__ void __launch_bounds__(GT) gemm_qi_kernel(const GemmArgs a) {
       auto lo4 = [&](unsigned v, h2 sc, h2 off) -> h2 { return pkfma(as_h2((v & 0x000F000Fu) | mg), sc, off); };
       auto hi4 = [&](unsigned v, h2 sc16, h2 off) -> h2 { return pkfma(as_h2((v & 0x00F000F0u) | mg), sc16, off); };
       const unsigned s01[2] = {wr.hs.x, wr.hs.y};
+      // Activation fragments are read ONE GROUP AHEAD (round 6): the code used to ask for a group's four fragments and wait for them (s_waitcnt lgkmcnt(0)) right in front
+      // of its MFMAs -- 8 exposed LDS round trips per superblock and wave with two waves per SIMD to hide them (MFMA pipes 25 % busy, profiles/round4_pmc.md).  Group (c, h)
+      // = runs 4 c + h (low nibbles) and 4 c + 2 + h (high) for both token tiles; scheduling barriers keep the read of group g + 1 in front of the operand build of group g.
+      h8 fr[2][4];
+      auto read_group = [&](int gi, h8 (&f)[4]) {
+        const int c = gi >> 1, h = gi & 1;
+        f[0] = act_frag(0, 4 * c + h); f[1] = act_frag(0, 4 * c + 2 + h); f[2] = act_frag(1, 4 * c + h); f[3] = act_frag(1, 4 * c + 2 + h);
+      };
+      read_group(0, fr[0]);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
+      for (int gi = 0; gi < 8; ++gi) {
+        const int c = gi >> 1, h = gi & 1;
+        if (gi + 1 < 8) read_group(gi + 1, fr[(gi + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
         const float sa = (float)byte_of(s01[c >> 1], 2 * (c & 1)), sb2 = (float)byte_of(s01[c >> 1], 2 * (c & 1) + 1);
         const h2 sl = h2{(_Float16)sa, (_Float16)sa}, ol = h2{(_Float16)(-1024.0f * sa), (_Float16)(-1024.0f * sa)};
         const h2 sh = h2{(_Float16)(sb2 * 0.0625f), (_Float16)(sb2 * 0.0625f)}, oh = h2{(_Float16)(-64.0f * sb2), (_Float16)(-64.0f * sb2)};
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const unsigned d0 = h == 0 ? wr.q[c].x : wr.q[c].z, d1 = h == 0 ? wr.q[c].y : wr.q[c].w;
-          const unsigned e0 = d0 >> 8, e1 = d1 >> 8;
-          const h8 wlo = mk_h8(lo4(d0, sl, ol), lo4(e0, sl, ol), lo4(d1, sl, ol), lo4(e1, sl, ol));
-          const h8 whi = mk_h8(hi4(d0, sh, oh), hi4(e0, sh, oh), hi4(d1, sh, oh), hi4(e1, sh, oh));
-#pragma unroll
-          for (int tt = 0; tt < 2; ++tt) {
-            if (c < 2) {
-              X[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(act_frag(tt, 4 * c + h), wlo, X[tt], 0, 0, 0);
-              X[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(act_frag(tt, 4 * c + 2 + h), whi, X[tt], 0, 0, 0);
-            } else {
-              X2[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(act_frag(tt, 4 * c + h), wlo, X2[tt], 0, 0, 0);
-              X2[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(act_frag(tt, 4 * c + 2 + h), whi, X2[tt], 0, 0, 0);
-            }
-          }
+        const unsigned d0 = h == 0 ? wr.q[c].x : wr.q[c].z, d1 = h == 0 ? wr.q[c].y : wr.q[c].w;
+        const unsigned e0 = d0 >> 8, e1 = d1 >> 8;
+        const h8 wlo = mk_h8(lo4(d0, sl, ol), lo4(e0, sl, ol), lo4(d1, sl, ol), lo4(e1, sl, ol));
+        const h8 whi = mk_h8(hi4(d0, sh, oh), hi4(e0, sh, oh), hi4(d1, sh, oh), hi4(e1, sh, oh));
+        const h8 (&f)[4] = fr[gi & 1];
+        if (c < 2) {
+          X[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[0], wlo, X[0], 0, 0, 0);
+          X[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[2], wlo, X[1], 0, 0, 0);
+          X[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[1], whi, X[0], 0, 0, 0);
+          X[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[3], whi, X[1], 0, 0, 0);
+        } else {
+          X2[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[0], wlo, X2[0], 0, 0, 0);
+          X2[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[2], wlo, X2[1], 0, 0, 0);
+          X2[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[1], whi, X2[0], 0, 0, 0);
+          X2[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[3], whi, X2[1], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
       // M = sum_run m_{run / 2} bsum_run: operand slot (hf, jj) <-> run 8 hf + jj -> sub-block 4 hf + jj / 2
       const unsigned mw = hf ? wr.hs.w : wr.hs.z;
@@ -592,14 +604,18 @@ __global__ void __launch_bounds__(GT) gemm_q80_kernel(const GemmArgs a) {
     const char *act_s = smem + buf * L8_BUF;
     const float *yd_s = (const float *)(act_s + L8_ACT);
     float Tt[2][16];
+    auto act_frag8 = [&](int tt, int b) { return *(const i4v *)(act_s + (trow + 32 * tt) * 256 + (((2 * b + hf) ^ (nn & 15)) << 4)); };
+    i4v afn[2] = {act_frag8(0, 0), act_frag8(1, 0)};  // the fragments are read one block ahead of their MFMAs
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
       const unsigned hw = b < 2 ? wr.hs.x : b < 4 ? wr.hs.y : b < 6 ? wr.hs.z : wr.hs.w;
       const float dwb = half_bits_to_float((uint16_t)((b & 1) ? (hw >> 16) : (hw & 0xffffu)));
       const i4v wq = __builtin_bit_cast(i4v, wr.q[b]);
+      const i4v afc[2] = {afn[0], afn[1]};
+      if (b + 1 < 8) { afn[0] = act_frag8(0, b + 1); afn[1] = act_frag8(1, b + 1); }
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
-        const i4v af = *(const i4v *)(act_s + (trow + 32 * tt) * 256 + (((2 * b + hf) ^ (nn & 15)) << 4));
+        const i4v af = afc[tt];
         const i16v is = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, wq, zero, 0, 0, 0);
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
