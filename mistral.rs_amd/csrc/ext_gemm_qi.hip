@@ -777,10 +777,10 @@ static int gemm_qi_launch(const void *w_qi, int type, int N, int K, const void *
   static const int split_max = [] { const char *e = getenv("MRS_GEMM_QI_SPLIT_BELOW"); return e ? atoi(e) : 200; }();
   a.ksplit = 1; a.part = nullptr;
   if (!win && (int)(grid.x * grid.y) < split_max && K / 256 >= 4 && N % 4 == 0 && workspace && workspace_bytes >= (size_t)4 * T * N * 4) { a.ksplit = 4; a.part = (float *)workspace; grid.z = 4; }
-  if (type == T_Q8_0) { auto kern = qi::gemm_q80_kernel; lds_attr_once((const void *)kern, 158 * 1024); hipLaunchKernelGGL(kern, grid, dim3(qi::GT), qi::L8_TOTAL, (hipStream_t)stream, a); }
-  else if (type == T_Q4_K) { auto kern = qi::gemm_qi_kernel<T_Q4_K>; lds_attr_once((const void *)kern, 158 * 1024); hipLaunchKernelGGL(kern, grid, dim3(qi::GT), qi::LDS_TOTAL, (hipStream_t)stream, a); }
-  else if (type == T_Q5_K) { auto kern = qi::gemm_qi_kernel<T_Q5_K>; lds_attr_once((const void *)kern, 158 * 1024); hipLaunchKernelGGL(kern, grid, dim3(qi::GT), qi::LDS_TOTAL, (hipStream_t)stream, a); }
-  else { auto kern = qi::gemm_qi_kernel<T_Q6_K>; lds_attr_once((const void *)kern, 158 * 1024); hipLaunchKernelGGL(kern, grid, dim3(qi::GT), qi::LDS_TOTAL, (hipStream_t)stream, a); }
+  if (type == T_Q8_0) { auto kern = qi::gemm_q80_kernel; lds_attr_once((const void *)kern, qi::L8_TOTAL); hipLaunchKernelGGL(kern, grid, dim3(qi::GT), qi::L8_TOTAL, (hipStream_t)stream, a); }
+  else if (type == T_Q4_K) { auto kern = qi::gemm_qi_kernel<T_Q4_K>; lds_attr_once((const void *)kern, qi::LDS_TOTAL); hipLaunchKernelGGL(kern, grid, dim3(qi::GT), qi::LDS_TOTAL, (hipStream_t)stream, a); }
+  else if (type == T_Q5_K) { auto kern = qi::gemm_qi_kernel<T_Q5_K>; lds_attr_once((const void *)kern, qi::LDS_TOTAL); hipLaunchKernelGGL(kern, grid, dim3(qi::GT), qi::LDS_TOTAL, (hipStream_t)stream, a); }
+  else { auto kern = qi::gemm_qi_kernel<T_Q6_K>; lds_attr_once((const void *)kern, qi::LDS_TOTAL); hipLaunchKernelGGL(kern, grid, dim3(qi::GT), qi::LDS_TOTAL, (hipStream_t)stream, a); }
   if (a.ksplit > 1) hipLaunchKernelGGL(qi::gemm_qi_reduce_kernel, dim3((unsigned)(((size_t)T * N / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a.part, out, T, N, ldo, accumulate);
   return 0;
 }
