@@ -206,8 +206,8 @@ struct GemmArgs {
 constexpr int TN = 128, TT = 128;                   // workgroup tile: weight rows x tokens
 constexpr int GT = 512;                             // 8 waves: 4 (32-row panels) x 2 (64-token halves); two waves per SIMD overlap each other's MFMA and VALU phases
 constexpr int LDS_ACT = TT * 512, LDS_YD = TT * 4, LDS_BS = TT * 32;
-constexpr int LDS_BUF = LDS_ACT;       // one superblock of the tile's tokens' f16 quants; two buffers: the next superblock arrives by LDS-DMA during the MFMAs
-constexpr int LDS_TOTAL = 2 * LDS_BUF;  // (the block scales and run sums of the two buffers live in static arrays: see gemm_qi_kernel)
+constexpr int LDS_BUF = LDS_ACT + LDS_YD + LDS_BS;  // one superblock of the tile's tokens; two buffers: the next superblock arrives by LDS-DMA during the MFMAs
+constexpr int LDS_TOTAL = 2 * LDS_BUF;
 
 // async global -> LDS copy, 16 / 4 bytes per lane: LDS destination = wave-uniform base + lane * size (the hardware's rule), source address per lane
 #ifndef MRS_GLDS16
@@ -259,28 +259,13 @@ __global__ void __launch_bounds__(GT) gemm_qi_kernel(const GemmArgs a) {
       const int tr = 2 * pair + hf, trc = min(tr, tlast);
       MRS_GLDS16(gq + (size_t)trc * 512 + (((lane & 31) ^ (tr & 31)) << 4), base + pair * 1024);
     }
-  };
-  // Block scales (128 floats) and run sums (128 x 32 B) of the tile's tokens: plain loads into registers one superblock ahead + ds_write at the end of the iteration, into
-  // STATIC arrays.  They used to travel by LDS-DMA into the dynamic buffer like the quants; hipcc cannot tell the two halves of that buffer apart, so the first ds_read of
-  // yd / bs in the fix-up was preceded by `s_waitcnt vmcnt(0)` -- in the MIDDLE of every iteration the wave waited for the DMA and the weights of the NEXT superblock it
-  // had just requested (round 6: the reason the MFMA pipes were 25 % busy with 34 MFMAs + ~420 VALU per superblock and wave).  Distinct LDS objects cannot alias a DMA.
-  __shared__ __attribute__((aligned(16))) float yd_sh[2][TT];
-  __shared__ __attribute__((aligned(16))) char bs_sh[2][TT * 32];
-  float ydr = 0.f;
-  v4u bsr = v4u{0u, 0u, 0u, 0u};
-  // (every wave requests both, from clamped addresses: a load under a run-time branch is a value merged at the end of the branch, i.e. a wait for it right there)
-  constexpr bool HAS_BS = TYPE != T_Q6_K;  // Q6_K has no mins: its fix-up reads the block scales only
-  auto load_ydbs = [&](int sb) {  // requested BEFORE the DMA pieces: waiting for these registers does not wait for the DMA behind them
-    const int tr = min((wave & 1) * 64 + lane, tlast);
-    ydr = a.yd[(size_t)sb * a.T + t0 + tr];
-    if constexpr (HAS_BS) {
-      const int tb = min(((wave - 2) & 3) * 32 + (lane >> 1), tlast);
-      bsr = *(const v4u *)((const char *)a.bsf + ((size_t)sb * a.T + t0 + tb) * 32 + (lane & 1) * 16);
+    if (wave < 2) {  // yd: 128 floats = 2 instructions of 64 x 4 B
+      const int tr = wave * 64 + lane;
+      MRS_GLDS4((const char *)a.yd + ((size_t)sb * a.T + t0 + min(tr, tlast)) * 4, base + LDS_ACT + wave * 256);
+    } else if (wave < 6) {  // run sums: 128 rows x 32 B = 4 instructions of 1 KiB
+      const int i = wave - 2, tr = i * 32 + (lane >> 1);
+      MRS_GLDS16((const char *)a.bsf + ((size_t)sb * a.T + t0 + min(tr, tlast)) * 32 + (lane & 1) * 16, base + LDS_ACT + LDS_YD + i * 1024);
     }
-  };
-  auto store_ydbs = [&](int buf) {
-    if (wave < 2) yd_sh[buf][wave * 64 + lane] = ydr;
-    else if (HAS_BS && wave < 6) *(v4u *)(bs_sh[buf] + (wave - 2) * 1024 + lane * 16) = bsr;
   };
   f16v run[2], pend[2];
 #pragma unroll
@@ -289,7 +274,7 @@ __global__ void __launch_bounds__(GT) gemm_qi_kernel(const GemmArgs a) {
     for (int v = 0; v < 16; ++v) { run[tt][v] = 0.f; pend[tt][v] = 0.f; }
   WRegs wr, wnx;
   const int sb_first = a.ksplit > 1 ? (int)blockIdx.z * ((a.K / 256 + 3) / 4) : 0;
-  if (sb_first < a.K / 256) { load_ydbs(sb_first); load_w(wr, sb_first); stage(sb_first, sb_first & 1); store_ydbs(sb_first & 1); }
+  if (sb_first < a.K / 256) { load_w(wr, sb_first); stage(sb_first, sb_first & 1); }
   const int trow = wt * 64 + nn;  // + 32 tt: the token row whose fragment this lane supplies
   // fragment of run r for this lane: chunk (2 r + hf) ^ (row & 31) of its token row; row & 31 == nn for both token tiles, so the 16 offsets are computed once
   int aoff[16];
@@ -313,10 +298,10 @@ __global__ void __launch_bounds__(GT) gemm_qi_kernel(const GemmArgs a) {
     const int buf = sb & 1;
     MRS_WAIT_VMCNT0();  // this wave's DMA pieces of superblock sb (and the weights of sb) have landed
     __syncthreads();    // everyone's have, and every wave has finished reading the other buffer
-    if (sb + 1 < sb_end) { load_ydbs(sb + 1); stage(sb + 1, buf ^ 1); load_w(wnx, sb + 1); }
+    if (sb + 1 < sb_end) { stage(sb + 1, buf ^ 1); load_w(wnx, sb + 1); }
     const char *act_s = smem + buf * LDS_BUF;
-    const float *yd_s = yd_sh[buf];
-    const char *bs_s = bs_sh[buf];
+    const float *yd_s = (const float *)(act_s + LDS_ACT);
+    const char *bs_s = act_s + LDS_ACT + LDS_YD;
     f16v X[2], X2[2];
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
@@ -515,7 +500,7 @@ __global__ void __launch_bounds__(GT) gemm_qi_kernel(const GemmArgs a) {
 #pragma unroll
         for (int v = 0; v < 16; ++v) pend[tt][v] = first ? run[tt][v] : pend[tt][v] + run[tt][v];
     }
-    if (sb + 1 < sb_end) { wr = wnx; store_ydbs(buf ^ 1); }  // the other buffer's yd / bs were last read in the previous iteration: every wave has passed this iteration's barrier
+    if (sb + 1 < sb_end) wr = wnx;
   }
   // store: lane holds column n, rows t = 8 (v / 4) + 4 hf + v % 4 of each MFMA tile
   const int n = n0 + wn * 32 + nn;
@@ -542,7 +527,7 @@ __global__ void __launch_bounds__(GT) gemm_qi_kernel(const GemmArgs a) {
 // scales [8][128] f32, double buffered by LDS-DMA.
 typedef int i4v __attribute__((ext_vector_type(4)));
 typedef int i16v __attribute__((ext_vector_type(16)));
-constexpr int L8_ACT = TT * 256, L8_BUF = L8_ACT, L8_TOTAL = 2 * L8_BUF;
+constexpr int L8_ACT = TT * 256, L8_YD = 8 * TT * 4, L8_BUF = L8_ACT + L8_YD, L8_TOTAL = 2 * L8_BUF;
 __global__ void __launch_bounds__(GT) gemm_q80_kernel(const GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = tid_opaque(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -580,22 +565,18 @@ __global__ void __launch_bounds__(GT) gemm_q80_kernel(const GemmArgs a) {
       const int tr = 4 * quad + (lane >> 4), trc = min(tr, tlast);
       MRS_GLDS16(gq + (size_t)trc * 256 + (((lane & 15) ^ (tr & 15)) << 4), base + quad * 1024);
     }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {  // block scales: wave w stages block w, 64 tokens per instruction
+      const int tr = i * 64 + lane;
+      MRS_GLDS4((const char *)yd8 + (((size_t)sb * 8 + wave) * a.T + t0 + min(tr, tlast)) * 4, base + L8_ACT + (wave * TT + i * 64) * 4);
+    }
   };
-  // block scales [8][128] f32 of the tile's tokens: plain loads one superblock ahead + ds_write at the end of the iteration, into a STATIC array (see gemm_qi_kernel: a
-  // ds_read of the DMA buffer's other half costs `s_waitcnt vmcnt(0)` in the middle of the iteration); wave w carries block w
-  __shared__ __attribute__((aligned(16))) float yd_sh[2][8 * TT];
-  float ydr0 = 0.f, ydr1 = 0.f;
-  auto load_yd = [&](int sb) {
-    const float *src = yd8 + ((size_t)sb * 8 + wave) * a.T + t0;
-    ydr0 = src[min(lane, tlast)]; ydr1 = src[min(64 + lane, tlast)];
-  };
-  auto store_yd = [&](int buf) { yd_sh[buf][wave * TT + lane] = ydr0; yd_sh[buf][wave * TT + 64 + lane] = ydr1; };
   float run[2][16], pend[2][16];
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
     for (int v = 0; v < 16; ++v) { run[tt][v] = 0.f; pend[tt][v] = 0.f; }
-  WRegs wr, wnx;
+  WRegs wr;
   const int sb_begin = a.ksplit > 1 ? (int)blockIdx.z * Cs : 0, sb_end = a.ksplit > 1 ? min(S, sb_begin + Cs) : S;
   if (sb_begin >= sb_end) {
     if (a.ksplit > 1) {  // a run without superblocks contributes +0
@@ -610,7 +591,7 @@ __global__ void __launch_bounds__(GT) gemm_q80_kernel(const GemmArgs a) {
     }
     return;
   }
-  load_yd(sb_begin); load_w(wr, sb_begin); stage(sb_begin, sb_begin & 1); store_yd(sb_begin & 1);
+  load_w(wr, sb_begin); stage(sb_begin, sb_begin & 1);
   const int trow = wt * 64 + nn;
   const i16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int sb = sb_begin; sb < sb_end; ++sb) {
@@ -618,9 +599,10 @@ __global__ void __launch_bounds__(GT) gemm_q80_kernel(const GemmArgs a) {
     MRS_WAIT_VMCNT0();
     __syncthreads();
     const bool more = sb + 1 < sb_end;
-    if (more) { load_yd(sb + 1); stage(sb + 1, buf ^ 1); load_w(wnx, sb + 1); }
+    const unsigned rec_next = more ? rec_of(sb + 1) : 0xF0000000u;  // past the tensor: zeros, no traffic (the request stays unconditional: exact waits)
+    if (more) stage(sb + 1, buf ^ 1);
     const char *act_s = smem + buf * L8_BUF;
-    const float *yd_s = yd_sh[buf];
+    const float *yd_s = (const float *)(act_s + L8_ACT);
     float Tt[2][16];
     auto act_frag8 = [&](int tt, int b) { return *(const i4v *)(act_s + (trow + 32 * tt) * 256 + (((2 * b + hf) ^ (nn & 15)) << 4)); };
     i4v afn[2] = {act_frag8(0, 0), act_frag8(1, 0)};  // the fragments are read one block ahead of their MFMAs
@@ -647,6 +629,8 @@ __global__ void __launch_bounds__(GT) gemm_q80_kernel(const GemmArgs a) {
           }
         }
       }
+      load_piece(wr, rec_next, b);
+      if (b == 7) load_hs(wr, rec_next);
       __builtin_amdgcn_sched_barrier(0);  // one block at a time: hoisting the MFMAs of later blocks keeps 16 result registers each alive (37 spilled VGPRs)
     }
     const bool cfirst = (sb % Cs) == 0;
@@ -661,7 +645,6 @@ __global__ void __launch_bounds__(GT) gemm_q80_kernel(const GemmArgs a) {
 #pragma unroll
         for (int v = 0; v < 16; ++v) pend[tt][v] = first ? run[tt][v] : pend[tt][v] + run[tt][v];
     }
-    if (more) { wr = wnx; store_yd(buf ^ 1); }
   }
   const int n = n0 + wn * 32 + nn;
 #pragma unroll
@@ -777,10 +760,10 @@ static int gemm_qi_launch(const void *w_qi, int type, int N, int K, const void *
   static const int split_max = [] { const char *e = getenv("MRS_GEMM_QI_SPLIT_BELOW"); return e ? atoi(e) : 200; }();
   a.ksplit = 1; a.part = nullptr;
   if (!win && (int)(grid.x * grid.y) < split_max && K / 256 >= 4 && N % 4 == 0 && workspace && workspace_bytes >= (size_t)4 * T * N * 4) { a.ksplit = 4; a.part = (float *)workspace; grid.z = 4; }
-  if (type == T_Q8_0) { auto kern = qi::gemm_q80_kernel; lds_attr_once((const void *)kern, qi::L8_TOTAL); hipLaunchKernelGGL(kern, grid, dim3(qi::GT), qi::L8_TOTAL, (hipStream_t)stream, a); }
-  else if (type == T_Q4_K) { auto kern = qi::gemm_qi_kernel<T_Q4_K>; lds_attr_once((const void *)kern, qi::LDS_TOTAL); hipLaunchKernelGGL(kern, grid, dim3(qi::GT), qi::LDS_TOTAL, (hipStream_t)stream, a); }
-  else if (type == T_Q5_K) { auto kern = qi::gemm_qi_kernel<T_Q5_K>; lds_attr_once((const void *)kern, qi::LDS_TOTAL); hipLaunchKernelGGL(kern, grid, dim3(qi::GT), qi::LDS_TOTAL, (hipStream_t)stream, a); }
-  else { auto kern = qi::gemm_qi_kernel<T_Q6_K>; lds_attr_once((const void *)kern, qi::LDS_TOTAL); hipLaunchKernelGGL(kern, grid, dim3(qi::GT), qi::LDS_TOTAL, (hipStream_t)stream, a); }
+  if (type == T_Q8_0) { auto kern = qi::gemm_q80_kernel; lds_attr_once((const void *)kern, 158 * 1024); hipLaunchKernelGGL(kern, grid, dim3(qi::GT), qi::L8_TOTAL, (hipStream_t)stream, a); }
+  else if (type == T_Q4_K) { auto kern = qi::gemm_qi_kernel<T_Q4_K>; lds_attr_once((const void *)kern, 158 * 1024); hipLaunchKernelGGL(kern, grid, dim3(qi::GT), qi::LDS_TOTAL, (hipStream_t)stream, a); }
+  else if (type == T_Q5_K) { auto kern = qi::gemm_qi_kernel<T_Q5_K>; lds_attr_once((const void *)kern, 158 * 1024); hipLaunchKernelGGL(kern, grid, dim3(qi::GT), qi::LDS_TOTAL, (hipStream_t)stream, a); }
+  else { auto kern = qi::gemm_qi_kernel<T_Q6_K>; lds_attr_once((const void *)kern, 158 * 1024); hipLaunchKernelGGL(kern, grid, dim3(qi::GT), qi::LDS_TOTAL, (hipStream_t)stream, a); }
   if (a.ksplit > 1) hipLaunchKernelGGL(qi::gemm_qi_reduce_kernel, dim3((unsigned)(((size_t)T * N / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a.part, out, T, N, ldo, accumulate);
   return 0;
 }
