@@ -403,6 +403,125 @@ def test_p2p_all_reduce_two_processes_on_one_gpu(dev, request):
         assert bad == -232, f"rank {rank}: {bad} mismatching / flagged calls"
 
 
+def _tp2_one_gpu_worker(rank, port, q):
+    """One of TWO tensor-parallel ranks sharing the ONE GPU: its shard of a 2-layer model on the C++ runner, every row-parallel all-reduce (decode AND the prompt's
+    [T, hidden] messages: the mailboxes are sized for them) on the peer-mailbox route -- no RCCL, which refuses two ranks on one device."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import mistralrs_amd  # noqa: F401
+    from mistralrs_amd import distributed as D
+    from mistralrs_amd.gguf import GgmlDType, QTensor
+    from mistralrs_amd.llama import Llama, LlamaConfig
+    from oracle import llama_ref
+    from oracle import oracle as O
+    O.build()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    world = 2
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        heads, kvh, hd, hidden, ff, vocab = 4, 2, 128, 512, 1024, 256
+        types = dict(embd=O.Q4_K, q=O.Q4_K, k=O.Q4_K, v=O.Q6_K, o=O.Q4_K, gate=O.Q4_K, up=O.Q4_K, down=O.Q6_K, output=O.Q6_K)
+        full = LlamaConfig(hidden_size=hidden, intermediate_size=ff, num_layers=2, num_heads=heads, num_kv_heads=kvh, vocab_size=vocab, head_dim=hd,
+                           rope_theta=10000.0, max_position_embeddings=256, max_batch=2, max_context_len=96, decode_engine=True)
+        w = llama_ref.synth_weights(full, types, seed=3)
+
+        def build(cfg, r, ws):
+            m = Llama(cfg, dev, max_new_tokens=32)
+            total = {"num_kv_heads": kvh, "head_dim": hd, "num_experts": 0}
+            for name, val in w.items():
+                if isinstance(val, tuple):
+                    dt = GgmlDType.from_id(val[0])
+                    qt = QTensor.from_numpy(dt, (val[1].shape[0], val[1].shape[1] // dt.type_size * dt.block_size), val[1], dev)
+                    sh = D.llama_tensor_shard(name, total, r, ws)
+                    m.set_tensor(name, D.shard_qtensor(qt, sh) if sh is not None else qt)
+                else:
+                    m.set_tensor(name, torch.from_numpy(val))
+            return m
+        lh, lkv, lff = D.local_dims(heads, kvh, ff, world)
+        tp_cfg = LlamaConfig(hidden_size=hidden, intermediate_size=lff, num_layers=2, num_heads=lh, num_kv_heads=lkv, vocab_size=vocab, head_dim=hd, rope_theta=10000.0,
+                             max_position_embeddings=256, max_batch=2, max_context_len=96, tp_world_size=world, tp_rank=rank, decode_engine=True)
+        try:
+            p2p = D.P2PAllReduce(rank, world, dev, max_elems=64 * hidden)  # a 40-token prompt's [T, hidden] sums fit the mailboxes: every all-reduce takes this route
+        except RuntimeError as e:
+            q.put((rank, f"unavailable: {e}", None))
+            return
+        prompt = [(7 * i + 3) % vocab for i in range(40)]
+        mt, mp_ = build(tp_cfg, rank, world), build(tp_cfg, rank, world)
+        for m in (mt, mp_):
+            m.set_p2p(p2p)
+        # (1) prompt in the decode engine's arithmetic on the shards == token-by-token decode on the shards (logits and pages), bit for bit
+        lp = mp_.prefill(prompt, 0).clone()
+        for pos, t in enumerate(prompt):
+            mt.set_state([t], [pos])
+            ld = mt.forward_logits(1)[0].clone()
+        exact = bool(mp_.prefill_is_exact) and bool(torch.equal(lp, ld)) and all(
+            bool(torch.equal(k1.view(torch.int16), k2.view(torch.int16)) and torch.equal(v1.view(torch.int16), v2.view(torch.int16)))
+            for k1, k2, v1, v2 in zip(mp_.key_caches, mt.key_caches, mp_.value_caches, mt.value_caches))
+        # (2) the captured (chained) decode graph with the p2p all-reduce kernels inside, 12 replays, against eager steps on the other runner
+        tok = int(lp.argmax())
+        for m in (mt, mp_):
+            m.set_state([tok], [len(prompt)])
+            m.step_counter.zero_()
+        mp_.capture_decode_graph(1)
+        for _ in range(12):
+            mp_.replay()
+            mt.decode_step(1)
+        torch.cuda.synchronize()
+        graph_ok = mp_.tokens_out[0, :12].tolist() == mt.tokens_out[0, :12].tolist() and bool(torch.equal(mp_.logits[0], mt.logits[0])) and p2p.error() == 0
+        # (3) every rank holds the same logits; rank 0 compares with the unsharded runner
+        got = [torch.zeros_like(lp.cpu()) for _ in range(world)]
+        dist.all_gather(got, lp.cpu())
+        same = all(bool(torch.equal(g, got[0])) for g in got)
+        rel = None
+        if rank == 0:
+            m1 = build(full, 0, 1)
+            ref = m1.prefill(prompt, 0)
+            rel = float((lp - ref).abs().max() / ref.abs().max())
+        dist.barrier()
+        torch.cuda.synchronize()
+        for m in (mt, mp_):
+            m.set_p2p(None)
+        dist.barrier()
+        p2p.close()
+        q.put((rank, None, (exact, graph_ok, same, rel)))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_tensor_parallel_runner_two_processes_on_one_gpu(dev, request):
+    """The tensor-parallel runner at world 2 ON THE DEVICE: two processes share the one GPU, each runs its shard (column-parallel q / k / v / gate / up, row-parallel o / down,
+    one kv head per rank) with every sum all-reduce on the peer-mailbox route across the two address spaces -- eager steps, the exact prompt path, and the captured decode
+    graph with the all-reduce kernels inside (`distributed/layers.rs:965-975`, `mistralrs-core/src/distributed.rs:569-795`).  Checks: prefill == token-by-token decode on
+    the shards bit for bit (logits, KV pages), graph replays == eager steps, identical logits on both ranks, and the sharded result within the partial-sum tolerance of the
+    unsharded runner.  What stays unmeasured: RCCL at world > 1 and the xGMI links (one device here)."""
+    if request.config.getoption("--host-emulation"):
+        pytest.skip("needs two HIP contexts on a device")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 37500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_tp2_one_gpu_worker, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, err, val in res:
+        assert err is None, f"rank {rank}: {err}"
+        exact, graph_ok, same, rel = val
+        assert exact, f"rank {rank}: tensor-parallel prefill != token-by-token decode on the same shards"
+        assert graph_ok, f"rank {rank}: captured decode graph (p2p all-reduce inside) != eager steps"
+        assert same, "ranks disagree on the logits"
+        if rel is not None:
+            assert rel <= 3e-2, rel
+
+
 @pytest.mark.gpu
 def test_p2p_all_reduce_class_world1_ipc_handle_on_fine_grained_memory(dev):
     """`P2PAllReduce` set-up on one rank: the mailbox comes from hipExtMallocWithFlags (uncached: a peer's store must reach a kernel that is already
