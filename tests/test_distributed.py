@@ -403,7 +403,7 @@ def test_p2p_all_reduce_two_processes_on_one_gpu(dev, request):
         assert bad == -232, f"rank {rank}: {bad} mismatching / flagged calls"
 
 
-def _tp2_one_gpu_worker(rank, port, q):
+def _tp2_one_gpu_worker(rank, port, q, experts=0):
     """One of TWO tensor-parallel ranks sharing the ONE GPU: its shard of a 2-layer model on the C++ runner, every row-parallel all-reduce (decode AND the prompt's
     [T, hidden] messages: the mailboxes are sized for them) on the peer-mailbox route -- no RCCL, which refuses two ranks on one device."""
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -424,25 +424,30 @@ def _tp2_one_gpu_worker(rank, port, q):
     try:
         heads, kvh, hd, hidden, ff, vocab = 4, 2, 128, 512, 1024, 256
         types = dict(embd=O.Q4_K, q=O.Q4_K, k=O.Q4_K, v=O.Q6_K, o=O.Q4_K, gate=O.Q4_K, up=O.Q4_K, down=O.Q6_K, output=O.Q6_K)
+        moe = dict(num_experts=experts, num_experts_per_tok=2) if experts else {}
         full = LlamaConfig(hidden_size=hidden, intermediate_size=ff, num_layers=2, num_heads=heads, num_kv_heads=kvh, vocab_size=vocab, head_dim=hd,
-                           rope_theta=10000.0, max_position_embeddings=256, max_batch=2, max_context_len=96, decode_engine=True)
+                           rope_theta=10000.0, max_position_embeddings=256, max_batch=2, max_context_len=96, decode_engine=True, **moe)
         w = llama_ref.synth_weights(full, types, seed=3)
 
         def build(cfg, r, ws):
             m = Llama(cfg, dev, max_new_tokens=32)
-            total = {"num_kv_heads": kvh, "head_dim": hd, "num_experts": 0}
+            total = {"num_kv_heads": kvh, "head_dim": hd, "num_experts": experts}
             for name, val in w.items():
                 if isinstance(val, tuple):
                     dt = GgmlDType.from_id(val[0])
                     qt = QTensor.from_numpy(dt, (val[1].shape[0], val[1].shape[1] // dt.type_size * dt.block_size), val[1], dev)
                     sh = D.llama_tensor_shard(name, total, r, ws)
-                    m.set_tensor(name, D.shard_qtensor(qt, sh) if sh is not None else qt)
+                    if sh is not None and "_exps" in name:
+                        qt = D.shard_stacked_experts(qt, experts, D.Shard(sh.dim, sh.rank, sh.world_size))  # every expert cut like a dense FFN matrix
+                    elif sh is not None:
+                        qt = D.shard_qtensor(qt, sh)
+                    m.set_tensor(name, qt)
                 else:
                     m.set_tensor(name, torch.from_numpy(val))
             return m
         lh, lkv, lff = D.local_dims(heads, kvh, ff, world)
         tp_cfg = LlamaConfig(hidden_size=hidden, intermediate_size=lff, num_layers=2, num_heads=lh, num_kv_heads=lkv, vocab_size=vocab, head_dim=hd, rope_theta=10000.0,
-                             max_position_embeddings=256, max_batch=2, max_context_len=96, tp_world_size=world, tp_rank=rank, decode_engine=True)
+                             max_position_embeddings=256, max_batch=2, max_context_len=96, tp_world_size=world, tp_rank=rank, decode_engine=True, **moe)
         try:
             p2p = D.P2PAllReduce(rank, world, dev, max_elems=64 * hidden)  # a 40-token prompt's [T, hidden] sums fit the mailboxes: every all-reduce takes this route
         except RuntimeError as e:
@@ -493,19 +498,21 @@ def _tp2_one_gpu_worker(rank, port, q):
 
 
 @pytest.mark.gpu
-def test_tensor_parallel_runner_two_processes_on_one_gpu(dev, request):
+@pytest.mark.parametrize("experts", [0, 4])
+def test_tensor_parallel_runner_two_processes_on_one_gpu(dev, request, experts):
     """The tensor-parallel runner at world 2 ON THE DEVICE: two processes share the one GPU, each runs its shard (column-parallel q / k / v / gate / up, row-parallel o / down,
     one kv head per rank) with every sum all-reduce on the peer-mailbox route across the two address spaces -- eager steps, the exact prompt path, and the captured decode
     graph with the all-reduce kernels inside (`distributed/layers.rs:965-975`, `mistralrs-core/src/distributed.rs:569-795`).  Checks: prefill == token-by-token decode on
     the shards bit for bit (logits, KV pages), graph replays == eager steps, identical logits on both ranks, and the sharded result within the partial-sum tolerance of the
-    unsharded runner.  What stays unmeasured: RCCL at world > 1 and the xGMI links (one device here)."""
+    unsharded runner.  experts = 4: sparse-MoE layers, every expert sharded on the ffn dimension, one all-reduce per MoE block (moe/experts/mod.rs:332-339).  What stays
+    unmeasured: RCCL at world > 1 and the xGMI links (one device here)."""
     if request.config.getoption("--host-emulation"):
         pytest.skip("needs two HIP contexts on a device")
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 37500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_tp2_one_gpu_worker, args=(r, port, q)) for r in range(2)]
+    port = 37500 + os.getpid() % 2000 + experts
+    procs = [ctx.Process(target=_tp2_one_gpu_worker, args=(r, port, q, experts)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=900) for _ in range(2)]
