@@ -479,7 +479,7 @@ def check_attention_handoff_reuse(O, be, iters, heads=32, kvh=8, ctx=700, max_ct
                 hd * bs, 1, 0, be.stream)
         assert rc == 1
         res = got.numpy()
-        eng = O.attention_engine(q_np[0].reshape(heads, hd), k, v, scale, 1, 0)
+        eng = O.attention_engine(q_np[0].reshape(heads, hd), k, v, scale, 1 if mbs <= 64 else (mbs + 63) // 64, 0)  # blocks per split: mrs_dec_attention's rule
         assert np.array_equal(res[0].reshape(heads, hd), eng), ("stale hand-off?", it, float(np.abs(res[0].reshape(heads, hd) - eng).max()))
         assert not ticket.numpy().any()
 
@@ -491,6 +491,33 @@ def test_attention_handoff_reuse_host_emulation(oracle):
 @pytest.mark.gpu
 def test_attention_handoff_reuse_gpu(oracle, dev):
     check_attention_handoff_reuse(oracle, GpuBackend(dev), 80)
+
+
+@pytest.mark.gpu
+def test_attention_handoff_under_uneven_load_long_context_gpu(oracle, dev):
+    """ADVICE round 5 (the relaxed ticket): the same hand-off with 63 splits per kv head (context 4000 of 4096: every XCD takes part, the merging workgroup reads 63 partials
+    per head) while a side stream keeps part of the chip busy with large copies -- uneven load and a warm merging CU are the conditions under which a stale partial would
+    show (MI355X_MICROARCH.md, "test every hand-off under UNEVEN load").  60 calls on the same buffers, each equal to the engine-order restatement bit for bit."""
+    import torch
+    side = torch.cuda.Stream()
+    a, b = torch.empty(48 << 20, dtype=torch.uint8, device=dev), torch.empty(48 << 20, dtype=torch.uint8, device=dev)
+    stop = {"n": 0}
+
+    class LoadedBackend(GpuBackend):
+        def sym(self, name, argtypes, restype=None):
+            f = super().sym(name, argtypes, restype)
+            if name != "mrs_dec_attention":
+                return f
+
+            def g(*args):
+                with torch.cuda.stream(side):  # ~30 us of copies on a third of the CUs' memory pipes around every attention launch
+                    for _ in range(2 + stop["n"] % 3):
+                        b.copy_(a, non_blocking=True)
+                stop["n"] += 1
+                return f(*args)
+            return g
+    check_attention_handoff_reuse(oracle, LoadedBackend(dev), 60, heads=32, kvh=8, ctx=4000, max_ctx=4096)
+    torch.cuda.synchronize()
 
 
 @pytest.mark.gpu
