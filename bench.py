@@ -539,14 +539,30 @@ def extra_config(kind, dev, steps=64, warmup=4, prompt_len=512):
            "step_roofline_frac": round(step_bytes * (steps / r["t_all"]) / HBM_PEAK, 4), "prefill_tokens_per_sec": round(prompt_len / r["ttft"], 1),
            "ttft_ms": round(1e3 * r["ttft"], 2), "prefill_arithmetic": "decode engine's (exact)" if model.prefill_is_exact else "bf16-operand MFMA",
            "decode_path": model.decode_path, "build_s": round(t_build, 1)}
-    if kind == "70b" and model.prefill_is_exact:  # long prompt: also the selectable bf16-operand path (what a tensor-parallel run uses)
-        model.set_prefill_mode(0)
-        model.prefill(r["prompt"], 0)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        int(model.prefill(r["prompt"], 0).argmax())
-        tb = time.perf_counter() - t0
-        out["prefill_bf16"] = {"tokens_per_sec": round(prompt_len / tb, 1), "ttft_ms": round(1e3 * tb, 2), "frac": round(r["prefill_flops"] / tb / MFMA_PEAK, 4)}
+    if kind == "70b" and model.prefill_is_exact:  # long prompt: also the selectable bf16-operand path
+        def bf16_ttft():
+            model.set_prefill_mode(0)
+            model.prefill(r["prompt"], 0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            int(model.prefill(r["prompt"], 0).argmax())
+            return time.perf_counter() - t0
+        tb = bf16_ttft()
+        out["prefill_bf16"] = {"tokens_per_sec": round(prompt_len / tb, 1), "ttft_ms": round(1e3 * tb, 2), "frac": round(r["prefill_flops"] / tb / MFMA_PEAK, 4),
+                               "gemm": "fused block dequant -> bf16 MFMA (the 137 GB bf16 shadow copy is not taken by default next to three other copies of the weights)"}
+        # the MI355X-first variant of the same leg: 288 GB of HBM hold the bf16 shadow copy of the 70B model as well (GGUF 41 + decode tiles 43 + MFMA-order panels 44 +
+        # shadow 137 GB): built after everything above has been recorded -- if it does not fit, the note says so and nothing else is affected
+        try:
+            if model.build_bf16_shadow():
+                ts = bf16_ttft()
+                out["prefill_bf16_shadow"] = {"tokens_per_sec": round(prompt_len / ts, 1), "ttft_ms": round(1e3 * ts, 2), "frac": round(r["prefill_flops"] / ts / MFMA_PEAK, 4),
+                                              "gemm": "hipBLASLt on a bf16 shadow copy of the dense linears (137 GB), built after loading", "hbm_in_use_gb": round(torch.cuda.memory_allocated() / 2 ** 30, 1)}
+        except Exception as e:  # torch.OutOfMemoryError or a library refusal
+            out["prefill_bf16_shadow"] = {"failed": f"{type(e).__name__}: {str(e)[:200]}"}
+        try:
+            model.drop_bf16_shadow()
+        except Exception:
+            pass
     del model
     gc.collect()
     torch.cuda.empty_cache()

@@ -331,27 +331,49 @@ class Llama:
                     self._keep[name + "#qi"] = qi
                     self._chk(self._L.mrs_llama_set_qi_tensor(self._h, name.encode(), qi.data_ptr()))
             if self._bf16_shadow_wanted and name.startswith("blk.") and "_exps" not in name:
-                # q / k / v and gate / up of a layer share one buffer, rows back to back: the runner then multiplies them in ONE library GEMM (fused_qkv / fused_glu role)
-                layer, role = name.split(".")[1], name.split(".")[2]
-                cfg = self.cfg
-                nq, nkv, ff, d = cfg.num_heads * cfg.head_dim, cfg.num_kv_heads * cfg.head_dim, cfg.intermediate_size, cfg.hidden_size
-                group = {"attn_q": ("qkv", 0, nq + 2 * nkv), "attn_k": ("qkv", nq, nq + 2 * nkv), "attn_v": ("qkv", nq + nkv, nq + 2 * nkv),
-                         "ffn_gate": ("gu", 0, 2 * ff), "ffn_up": ("gu", ff, 2 * ff)}.get(role)
-                if group is not None and t.shape[1] == d:
-                    key = f"blk.{layer}.{group[0]}#bf16"
-                    if key not in self._keep:
-                        self._keep[key] = torch.empty(group[2], d, dtype=torch.bfloat16, device=self.device)
-                    sh = self._keep[key][group[1]: group[1] + t.shape[0]]
-                else:
-                    sh = torch.empty(t.shape[0], t.shape[1], dtype=torch.bfloat16, device=self.device)
-                    self._keep[name + "#bf16"] = sh
-                self._chk(self._L.mrs_dequantize(t.data.data_ptr(), t.dtype.id, t.shape[0], t.shape[1], sh.data_ptr(), 30, self._stream()))
-                self._chk(self._L.mrs_llama_set_bf16_tensor(self._h, name.encode(), sh.data_ptr()))
+                self._make_bf16_shadow(name, t)
         else:
             t = t.to(self.device, torch.float32).contiguous()
             self._keep[name] = t
             rows, cols = (1, t.numel()) if t.dim() == 1 else t.shape
             self._chk(self._L.mrs_llama_set_tensor(self._h, name.encode(), t.data_ptr(), 0, rows, cols))
+
+    def _make_bf16_shadow(self, name: str, t) -> None:
+        # q / k / v and gate / up of a layer share one buffer, rows back to back: the runner then multiplies them in ONE library GEMM (fused_qkv / fused_glu role)
+        layer, role = name.split(".")[1], name.split(".")[2]
+        cfg = self.cfg
+        nq, nkv, ff, d = cfg.num_heads * cfg.head_dim, cfg.num_kv_heads * cfg.head_dim, cfg.intermediate_size, cfg.hidden_size
+        group = {"attn_q": ("qkv", 0, nq + 2 * nkv), "attn_k": ("qkv", nq, nq + 2 * nkv), "attn_v": ("qkv", nq + nkv, nq + 2 * nkv),
+                 "ffn_gate": ("gu", 0, 2 * ff), "ffn_up": ("gu", ff, 2 * ff)}.get(role)
+        if group is not None and t.shape[1] == d:
+            key = f"blk.{layer}.{group[0]}#bf16"
+            if key not in self._keep:
+                self._keep[key] = torch.empty(group[2], d, dtype=torch.bfloat16, device=self.device)
+            sh = self._keep[key][group[1]: group[1] + t.shape[0]]
+        else:
+            sh = torch.empty(t.shape[0], t.shape[1], dtype=torch.bfloat16, device=self.device)
+            self._keep[name + "#bf16"] = sh
+        self._chk(self._L.mrs_dequantize(t.data.data_ptr(), t.dtype.id, t.shape[0], t.shape[1], sh.data_ptr(), 30, self._stream()))
+        self._chk(self._L.mrs_llama_set_bf16_tensor(self._h, name.encode(), sh.data_ptr()))
+
+    def build_bf16_shadow(self) -> bool:
+        """Make the bf16 shadow copy of every dense linear AFTER loading (a model that was built without it: `MRS_PREFILL_BF16_SHADOW=auto` skips models whose copy exceeds
+        MRS_BF16_SHADOW_MAX_GB).  Raises torch.OutOfMemoryError when it does not fit; returns `bf16_shadow`."""
+        if self.cfg.num_experts:
+            return False
+        for name, t in list(self._keep.items()):
+            if isinstance(t, QTensor) and name.startswith("blk.") and "#" not in name and "_exps" not in name:
+                self._make_bf16_shadow(name, t)
+        torch.cuda.current_stream().synchronize()
+        return self.bf16_shadow
+
+    def drop_bf16_shadow(self) -> None:
+        """Release the shadow copies (the runner falls back to the fused block-dequant kernels on the bf16 path)."""
+        self._L.mrs_llama_set_bf16_tensor.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
+        for name in [n for n in self._keep if isinstance(self._keep[n], QTensor) and n.startswith("blk.") and "_exps" not in n]:
+            self._L.mrs_llama_set_bf16_tensor(self._h, name.encode(), None)
+        for k in [k for k in self._keep if k.endswith("#bf16")]:
+            del self._keep[k]
 
     def decode_bytes(self, b: int, context_len: int) -> float:
         return float(self._L.mrs_llama_decode_bytes(self._h, b, context_len))
