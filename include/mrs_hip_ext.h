@@ -132,6 +132,11 @@ int mrs_moe_router_topk(const float *x_normed, const float *gate_w /* f32 [E][K]
 /* router on the un-normed hidden state: RmsNorm(h) * norm_w (bit-identical to mrs_rms_norm_f32) inside the router's workgroup; -3: K * 4 bytes > 64 KiB of LDS */
 int mrs_moe_router_topk_norm(const float *h, const float *norm_w, float eps, const float *gate_w, int tokens, int n_experts, int K, int top_k, int renormalize,
                              int32_t *ids, float *weights, void *stream);
+/* the same as n_experts workgroups per token + the last arriver's softmax / top-k (round 6; same ids and weights bit for bit).  scratch: mrs_moe_router_split_scratch_bytes
+ * bytes, zero before the first call (it returns to zero) */
+size_t mrs_moe_router_split_scratch_bytes(int tokens, int n_experts);
+int mrs_moe_router_topk_norm_split(const float *h, const float *norm_w, float eps, const float *gate_w, int tokens, int n_experts, int K, int top_k, int renormalize,
+                                   int32_t *ids, float *weights, void *scratch, void *stream);
 int mrs_moe_decode_gate_up(const void *wg, const void *wu, size_t expert_stride_bytes, const int32_t *expert_sel, int type, int n, int K,
                            const float *h, const float *norm_w, float eps, int activation, void *y_out, int y_out_stride, void *stream);
 int mrs_moe_decode_down(const void *w, size_t expert_stride_bytes, const int32_t *expert_sel, const float *topk_weight, int type, int n, int K,

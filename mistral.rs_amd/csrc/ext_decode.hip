@@ -658,6 +658,84 @@ __global__ void __launch_bounds__(1024) moe_router_kernel(const float *__restric
     if (logits_out) for (int e = 0; e < E; ++e) logits_out[(size_t)tok * E + e] = lg[e];
   }
 }
+// Round 6: the same router as E workgroups per token (one expert's logit each) + the last arriver's softmax / top-k.  moe_router_kernel<true> computes all E logits in ONE
+// workgroup: 8 x 16 KB of router rows through one CU's memory pipe = most of its 9.4 us (12 % of a Mixtral decode layer).  Here every workgroup repeats the RmsNorm (the NORM
+// variant's arithmetic: same thread <-> element mapping, same reduction order), wave 0 computes the logit of expert blockIdx.x with the one-wave-per-expert chain of the kernel
+// above, publishes it write-through and draws a ticket; the workgroup that draws the last one reads the E logits past L1 and runs the serial softmax / top-k code unchanged:
+// same ids, same weights, bit for bit (tests/test_moe.py).  scratch: per token E floats + one u32 ticket (zero at rest; the kernel leaves it zero).
+#ifndef MRS_WAIT_VMCNT0
+#define MRS_WAIT_VMCNT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+__global__ void __launch_bounds__(256) moe_router_split_kernel(const float *__restrict__ x, const float *__restrict__ gate_w, int E, int K, int top_k, int renormalize,
+                                                               int32_t *__restrict__ ids, float *__restrict__ weights, const float *__restrict__ norm_w, float eps,
+                                                               float *__restrict__ scratch) {
+  __shared__ float lg[64];
+  __shared__ float red[4];
+  __shared__ int last_s;
+  extern __shared__ __attribute__((aligned(16))) char xn_s[];
+  const int e = blockIdx.x, tok = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const float *xr = x + (size_t)tok * K;
+  float *xn = (float *)xn_s;
+  const int nvec = K / 4;
+  float sum = 0.f;
+  for (int v = tid; v < nvec; v += 256) {
+    const float4 t = *(const float4 *)(xr + 4 * v);
+    sum = fmaf(t.x, t.x, sum); sum = fmaf(t.y, t.y, sum); sum = fmaf(t.z, t.z, sum); sum = fmaf(t.w, t.w, sum);
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red[wave] = sum;
+  __syncthreads();
+  const float inv = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)K + eps);
+  for (int v = tid; v < nvec; v += 256) {
+    const float4 t = *(const float4 *)(xr + 4 * v), w = *(const float4 *)(norm_w + 4 * v);
+    *(float4 *)(xn + 4 * v) = make_float4(t.x * inv * w.x, t.y * inv * w.y, t.z * inv * w.z, t.w * inv * w.w);
+  }
+  __syncthreads();
+  float *slog = scratch + (size_t)tok * (E + 1);
+  unsigned *ticket = (unsigned *)(slog + E);
+  if (wave == 0) {
+    float s = 0.f;
+    const float *wr = gate_w + (size_t)e * K;
+#pragma unroll 8
+    for (int i = lane * 4; i < K; i += 256) {
+      const float4 a4 = *(const float4 *)(xn + i), w4 = *(const float4 *)(wr + i);
+      s = fmaf(a4.x, w4.x, s); s = fmaf(a4.y, w4.y, s); s = fmaf(a4.z, w4.z, s); s = fmaf(a4.w, w4.w, s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+      __hip_atomic_store(slog + e, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through
+      MRS_WAIT_VMCNT0();
+      last_s = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(E - 1);
+      if (last_s) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
+  if (!last_s) return;
+  if (tid < E) lg[tid] = __hip_atomic_load(slog + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1: past L1
+  __syncthreads();
+  if (tid == 0) {  // moe_router_kernel's serial softmax / top-k, unchanged
+    float mx = -INFINITY;
+    for (int j = 0; j < E; ++j) mx = fmaxf(mx, lg[j]);
+    float den = 0.f;
+    for (int j = 0; j < E; ++j) den += expf(lg[j] - mx);
+    float sel = 0.f;
+    unsigned long long used = 0;
+    for (int k = 0; k < top_k; ++k) {
+      int best = -1; float bv = -INFINITY;
+      for (int j = 0; j < E; ++j) if (!((used >> j) & 1ull) && lg[j] > bv) { bv = lg[j]; best = j; }
+      if (best < 0) {
+        for (int j = 0; j < E && best < 0; ++j) if (!((used >> j) & 1ull)) best = j;
+        bv = lg[best];
+      }
+      used |= 1ull << best;
+      const float p = expf(bv - mx) / den;
+      ids[(size_t)tok * top_k + k] = best;
+      weights[(size_t)tok * top_k + k] = p;
+      sel += p;
+    }
+    if (renormalize) for (int k = 0; k < top_k; ++k) weights[(size_t)tok * top_k + k] /= sel;
+  }
+}
 }  // namespace mrs
 extern "C" int mrs_moe_router_topk(const float *x, const float *gate_w, int tokens, int n_experts, int K, int top_k, int renormalize, int32_t *ids,
                                    float *weights, float *logits_out, void *stream) {
@@ -677,6 +755,18 @@ extern "C" int mrs_moe_router_topk_norm(const float *h, const float *norm_w, flo
   const int waves = n_experts < 4 ? 4 : (n_experts > 16 ? 16 : n_experts);
   hipLaunchKernelGGL(mrs::moe_router_kernel<true>, dim3(tokens), dim3(64 * waves), (size_t)K * 4, (hipStream_t)stream, h, gate_w, n_experts, K, top_k, renormalize, ids,
                      weights, (float *)nullptr, norm_w, eps);
+  return 0;
+}
+
+// scratch: tokens * (n_experts + 1) * 4 bytes, zero before the first call (the tickets return to zero); -3: row too long for LDS (callers fall back to mrs_moe_router_topk_norm)
+extern "C" size_t mrs_moe_router_split_scratch_bytes(int tokens, int n_experts) { return (size_t)tokens * (size_t)(n_experts + 1) * 4; }
+extern "C" int mrs_moe_router_topk_norm_split(const float *h, const float *norm_w, float eps, const float *gate_w, int tokens, int n_experts, int K, int top_k, int renormalize,
+                                              int32_t *ids, float *weights, void *scratch, void *stream) {
+  if (tokens <= 0) return 0;
+  if (n_experts < 1 || n_experts > 64 || top_k < 1 || top_k > n_experts || (K & 3) || !norm_w || !scratch) return -1;
+  if ((size_t)K * 4 > 64 * 1024) return -3;
+  hipLaunchKernelGGL(mrs::moe_router_split_kernel, dim3(n_experts, tokens), dim3(256), (size_t)K * 4, (hipStream_t)stream, h, gate_w, n_experts, K, top_k, renormalize, ids, weights,
+                     norm_w, eps, (float *)scratch);
   return 0;
 }
 

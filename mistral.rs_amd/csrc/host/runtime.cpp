@@ -182,6 +182,7 @@ struct Workspace {  // carve-up of the caller's scratch
   float *moe_w;             // [B][top_k]
   void *moe_y;              // [top_k] Q8_1 rows of the selected experts' activations
   float *moe_act;           // decode engine: [top_k][intermediate] f32 activations of the selected experts
+  void *moe_router_scratch; // [B][experts + 1]: logits + arrival ticket of the split router (mrs_moe_router_topk_norm_split; zero at rest)
   void *attn_img;           // decode engine: Q8_K activation image of the attention result (mrs_dec_attention / mrs_dec_attention_q8k -> mrs_dec_proj_img)
   unsigned *attn_ticket;    // decode engine: [max_batch][kv heads] arrival counters of mrs_dec_attention (zero at rest)
   void *act_img;            // decode engine, batched steps: the activation image of a phase, built once (mrs_dec_act_image -> mrs_dec_*_img); hidden or ffn width, <= 8 columns
@@ -233,6 +234,7 @@ class Llama {
       const size_t k = std::max(1, (int)c.num_experts_per_tok);
       t += align(B * k * 4) * 2 + align(k * (pad_to(c.intermediate_size, MATRIX_ROW_PADDING) / 32) * 36);
       t += align(k * (size_t)c.intermediate_size * 4);
+      t += align(mrs_moe_router_split_scratch_bytes((int)B, (int)c.num_experts));
     }
     return t + 4096;
   }
@@ -263,6 +265,7 @@ class Llama {
       ws.moe_ids = (int32_t *)take(B * k * 4); ws.moe_w = (float *)take(B * k * 4);
       ws.moe_y = take(k * (pad_to(cfg.intermediate_size, MATRIX_ROW_PADDING) / 32) * 36);
       ws.moe_act = (float *)take(k * (size_t)cfg.intermediate_size * 4);
+      ws.moe_router_scratch = take(mrs_moe_router_split_scratch_bytes((int)B, (int)cfg.num_experts));
     }
     // zero once: Q8_1 padding blocks beyond K are never written by the fused epilogues; sample scratch must start at 0
     if (hipMemset(b.workspace, 0, b.workspace_bytes) != hipSuccess) return fail("hipMemset(workspace) failed");
@@ -480,7 +483,10 @@ class Llama {
         // TP (moe/experts/mod.rs:332-339): every expert is sharded on the ffn dimension like a dense FFN; h <- h / world + sum of the local experts' partial
         // outputs, then ONE all-reduce per MoE block (the router is replicated: every rank picks the same experts)
         const int E = cfg.num_experts, tk = cfg.num_experts_per_tok;
-        const int rrc = mrs_moe_router_topk_norm(ws.h, bl.post_attention_layernorm, cfg.rms_eps, bl.router, b, E, d, tk, 1, ws.moe_ids, ws.moe_w, s);  // norm inside the router
+        // (round 6) E workgroups per token + the last arriver's top-k: the same ids and weights as the one-workgroup router, bit for bit, without 8 router rows through one CU
+        static const bool split_router = [] { const char *e = getenv("MRS_MOE_ROUTER_SPLIT"); return !e || atoi(e) != 0; }();
+        const int rrc = split_router ? mrs_moe_router_topk_norm_split(ws.h, bl.post_attention_layernorm, cfg.rms_eps, bl.router, b, E, d, tk, 1, ws.moe_ids, ws.moe_w, ws.moe_router_scratch, s)
+                                     : mrs_moe_router_topk_norm(ws.h, bl.post_attention_layernorm, cfg.rms_eps, bl.router, b, E, d, tk, 1, ws.moe_ids, ws.moe_w, s);  // norm inside the router
         if (rrc == -3) {
           mrs_rms_norm_f32(ws.h, bl.post_attention_layernorm, ws.xn, b, d, cfg.rms_eps, (int64_t)(intptr_t)s);
           if (mrs_moe_router_topk(ws.xn, bl.router, b, E, d, tk, 1, ws.moe_ids, ws.moe_w, nullptr, s)) return fail("moe router refused (experts %d, top-k %d)", E, tk);

@@ -55,3 +55,27 @@ def test_bf16_shadow_prefill_matches_the_fused_dequant_prefill_and_the_exact_one
     assert float(np.abs(shadow - fused).max()) <= 5e-3 * scale, float(np.abs(shadow - fused).max()) / scale  # same bf16 arithmetic, different f32 summation order
     assert float(np.abs(shadow - exact).max()) <= 6e-2 * scale, float(np.abs(shadow - exact).max()) / scale  # bf16 operands vs the int8 reference arithmetic
     assert int(shadow.argmax()) == int(fused.argmax())
+
+
+@pytest.mark.gpu
+def test_shadow_built_after_loading_and_dropped(oracle, dev, request, monkeypatch):
+    """Llama.build_bf16_shadow() on a model loaded without the copy (what bench.py's 70B leg does once everything else is recorded) gives the logits of a model loaded with
+    it; drop_bf16_shadow() returns the bf16 path to the fused block-dequant kernels."""
+    if request.config.getoption("--host-emulation"):
+        pytest.skip("hipBLASLt needs the device")
+    from tests.test_dec_model import Q4KM, _mk
+    cfg, w, m_auto, cos, sin = _mk(oracle, dev, Q4KM(oracle), "bf16")
+    monkeypatch.setenv("MRS_PREFILL_BF16_SHADOW", "0")
+    _, _, m, _, _ = _mk(oracle, dev, Q4KM(oracle), "bf16")
+    assert m_auto.bf16_shadow and not m.bf16_shadow
+    prompt = [(1000 + 37 * i) % cfg.vocab_size for i in range(40)]
+    m.set_prefill_mode(0)
+    m_auto.set_prefill_mode(0)
+    fused = m.prefill(prompt, 0).float().cpu().numpy()  # no copy: mode 0 = the fused kernels
+    assert m.build_bf16_shadow()
+    got = m.prefill(prompt, 0).float().cpu().numpy()
+    want = m_auto.prefill(prompt, 0).float().cpu().numpy()
+    assert np.array_equal(got, want), "shadow built after loading != shadow built while loading"
+    m.drop_bf16_shadow()
+    assert not m.bf16_shadow
+    assert np.array_equal(m.prefill(prompt, 0).float().cpu().numpy(), fused)

@@ -619,6 +619,16 @@ def _check_router_norm(be, tokens, E, K, topk):
     assert be.sym("mrs_moe_router_topk_norm", RN, C.c_int)(hb.ptr, nb.ptr, 1e-5, gb.ptr, tokens, E, K, topk, 1, ids_b.ptr, w_b.ptr, be.stream) == 0
     np.testing.assert_array_equal(ids_b.numpy(), ids_a.numpy())
     np.testing.assert_array_equal(w_b.numpy(), w_a.numpy())
+    # round 6: the split router (one workgroup per expert and token + the last arriver's top-k), twice on the same scratch (the tickets must return to zero)
+    nbytes = be.sym("mrs_moe_router_split_scratch_bytes", [C.c_int, C.c_int], C.c_size_t)(tokens, E)
+    scratch = be.buf(np.zeros(nbytes, np.uint8))
+    RS = RN[:-1] + [C.c_void_p, C.c_void_p]
+    for _ in range(2):
+        ids_c, w_c = be.buf(np.full((tokens, topk), -1, np.int32)), be.buf(np.zeros((tokens, topk), np.float32))
+        assert be.sym("mrs_moe_router_topk_norm_split", RS, C.c_int)(hb.ptr, nb.ptr, 1e-5, gb.ptr, tokens, E, K, topk, 1, ids_c.ptr, w_c.ptr, scratch.ptr, be.stream) == 0
+        np.testing.assert_array_equal(ids_c.numpy(), ids_a.numpy())
+        np.testing.assert_array_equal(w_c.numpy(), w_a.numpy())
+    assert not scratch.numpy().view(np.uint32).reshape(tokens, E + 1)[:, E].any(), "router tickets must be zero at rest"
 
 
 @pytest.mark.parametrize("tokens,E,K,topk", [(1, 8, 4096, 2), (3, 4, 512, 2), (2, 16, 1024, 3), (1, 3, 256, 1)])
