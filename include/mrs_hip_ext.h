@@ -98,6 +98,17 @@ int mrs_dec_qkv_img(const mrs_dec_mat *wq, const mrs_dec_mat *wk, const mrs_dec_
                     const int64_t *slot_mapping, const int32_t *positions, const float *cos_t, const float *sin_t, int head_dim, int rot_pairs,
                     int num_kv_heads, int block_size, int kv_dtype, int b, int neox, void *stream);
 int mrs_dec_gate_up_img(const mrs_dec_mat *wg, const mrs_dec_mat *wu, int n, const void *x_img, int activation, float *act_out, int ld_out, int b, void *stream);
+/* Batched decode on the matrix cores (round 6, csrc/ext_dec_mm.hip): the same launches as mrs_dec_proj_img / mrs_dec_gate_up_img / mrs_dec_qkv_img (interleaved RoPE) for
+ * b = 1..8 columns, on the MFMA-order copy of the weights (mrs_gemm_qi_repack) instead of the decode-layout copy: integer dots on v_mfma_i32_32x32x32_i8, the engine's f32 order --
+ * the same bits as the vector-ALU kernels.  Reference role: MMVQ's batch 1..8 from one weight pass (kernels/mmvq_gguf/mmvq_gguf.cu:724-792, gguf/fast_mmvq.rs:52).
+ * x_img = mrs_dec_act_image(.., weight type, b, ..).  mrs_dec_mm_supported: the type is one the route takes and k x b fits its LDS budget. */
+int mrs_dec_mm_supported(int type, int k, int b);
+void mrs_dec_mm_timeline(void *buf); /* experiments: [grid * 4][8] u64 s_memrealtime stamps of the following mrs_dec_mm_* launches, or NULL (off) */
+int mrs_dec_mm_proj(const void *qi, int type, int n, int k, const void *x_img, float *out, int ld_out, int mode, float resid_scale, int b, void *stream);
+int mrs_dec_mm_gate_up(const void *qi_gate, const void *qi_up, int type, int n, int k, const void *x_img, int activation, float *act_out, int ld_out, int b, void *stream);
+int mrs_dec_mm_qkv(const void *qi_q, int type_q, int nq, const void *qi_k, int type_k, int nk, const void *qi_v, int type_v, int nv, int k, const void *x_img, float *q_out,
+                   void *k_cache, void *v_cache, const int64_t *slot_mapping, const int32_t *positions, const float *cos_t, const float *sin_t, int head_dim, int rot_pairs,
+                   int num_kv_heads, int block_size, int kv_dtype, int b, void *stream);
 /* Fused HQQ dequant-GEMV for decode (ext_hqq_gemv.hip): out [b][ldo] = x [b][ldx] . W^T (+ bias) straight from the packed 4-bit / 8-bit HQQ tensor (group 64, axis 0),
  * b <= 8; dtype 0 = f32, 1 = f16, 2 = bf16 for x / scale / zero / bias / out.  Role: HqqLayer::forward_raw (hqq/mod.rs:1092-1100,1163-1171) without materialising
  * dequantize_w(); the dequantized values are bit-identical to dequantize_{4,8}bit_u8_kernel_*.  -1 = outside the fused kernel (keep dequantize + dense matmul). */

@@ -56,7 +56,7 @@ def libraries():
     optional = {
         "libmistralrsquant.so": ["quant_ops.hip", "mmq.hip", "moe.hip", "gemv.hip", "hqq.hip"],
         "libmistralrscuda.so": ["core_ops.hip", "sampling.hip"],
-        "libmrs_hip_ext.so": ["ext_decode.hip", "ext_dec.hip", "ext_gemm.hip", "ext_gemm_qi.hip", "ext_attn_prefill.hip", "ext_comm.hip", "ext_p2p.hip", "ext_hqq_gemv.hip", "ext_isq.hip", "ext_prefetch.hip", "ext_gemm_lt.hip",
+        "libmrs_hip_ext.so": ["ext_decode.hip", "ext_dec.hip", "ext_dec_mm.hip", "ext_gemm.hip", "ext_gemm_qi.hip", "ext_attn_prefill.hip", "ext_comm.hip", "ext_p2p.hip", "ext_hqq_gemv.hip", "ext_isq.hip", "ext_prefetch.hip", "ext_gemm_lt.hip",
                               "host/runtime.cpp", "host/kv_cache_manager.cpp"],
     }
     # experiment knob (default off): MRS_DECODE_MIN_WAVES=4 caps the decode GEMV kernels at 128 VGPRs (csrc/ext_decode.hip); use with --force

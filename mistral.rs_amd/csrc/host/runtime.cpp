@@ -448,9 +448,20 @@ class Llama {
     static const int img_min_b = [] { const char *e = getenv("MRS_DEC_IMG_MIN_B"); return e ? atoi(e) : 2; }();
     const bool imgb = b >= img_min_b && b >= 2 && b <= 8;
     auto image = [&](const float *x, int ldx, const float *nw, int k, int wtype) { return mrs_dec_act_image(x, ldx, nw, cfg.rms_eps, k, wtype, b, ws.act_img, s); };
+    // (round 6) batched steps on the matrix cores (ext_dec_mm.hip): the same launches on the MFMA-order copy of the weights the exact prompt path keeps (QTensor::qi) -- integer
+    // dots on v_mfma_i32_32x32x32_i8 instead of 535 VALU per 8-column tile, the same bits.  MRS_DEC_MM=0 keeps the vector-ALU kernels; MRS_DEC_MM_MIN_B: smallest batch that takes it.
+    static const int mm_min_b = [] { const char *e = getenv("MRS_DEC_MM"); if (e && atoi(e) == 0) return 1 << 30; const char *m = getenv("MRS_DEC_MM_MIN_B"); return m ? atoi(m) : 2; }();
+    const bool mmb = imgb && b >= mm_min_b;
+    auto qi_of = [](const std::unique_ptr<GgufMatMul> &l) -> const void * { return l && l->get_qtensor() ? l->get_qtensor()->qi : nullptr; };
+    auto mm_ok = [&](const void *qi, int type, int k) { return mmb && qi && mrs_dec_mm_supported(type, k, b); };
     for (const Block &bl : blocks) {
       // rotate-half RoPE: the caller registered q / k decode planes in pair order (mrs_dec_qkv_neox; llama.py permutes the rows before the repack)
-      if (imgb) {
+      if (imgb && cfg.rope_interleaved && mm_ok(qi_of(bl.q_proj), bl.dq.type, d) && mm_ok(qi_of(bl.k_proj), bl.dk.type, d) && mm_ok(qi_of(bl.v_proj), bl.dv.type, d)) {
+        if (image(ws.h, d, bl.input_layernorm, d, bl.dq.type) ||
+            mrs_dec_mm_qkv(qi_of(bl.q_proj), bl.dq.type, (int)bl.dq.n, qi_of(bl.k_proj), bl.dk.type, (int)bl.dk.n, qi_of(bl.v_proj), bl.dv.type, (int)bl.dv.n, d, ws.act_img, ws.q,
+                           bl.key_cache, bl.value_cache, bufs.slot_mapping, bufs.positions, bufs.cos_table, bufs.sin_table, hd, cfg.rot_dim / 2, kvh, bs, kvd, b, s))
+          return fail("mrs_dec_mm_qkv refused the layer");
+      } else if (imgb) {
         if (image(ws.h, d, bl.input_layernorm, d, bl.dq.type) ||
             mrs_dec_qkv_img(&bl.dq, &bl.dk, &bl.dv, ws.act_img, ws.q, bl.key_cache, bl.value_cache, bufs.slot_mapping, bufs.positions, bufs.cos_table, bufs.sin_table, hd,
                             cfg.rot_dim / 2, kvh, bs, kvd, b, cfg.rope_interleaved ? 0 : 1, s))
@@ -465,7 +476,8 @@ class Llama {
                                           bl.key_cache, bl.value_cache, kvh, 1.0f / sqrtf((float)hd), bufs.block_tables, bufs.context_lens, bs, eff_max, b, cfg.num_heads, hd,
                                           cfg.max_blocks_per_seq, nq, kvh * hd * bs, hd * bs, kvd, cfg.sliding_window, s);
         if (rc2 < 0) return fail("mrs_dec_attention refused the shape");
-        const int prc = rc2 == 1 ? mrs_dec_proj_img(&bl.dout, d, ws.attn_img, ws.h, d, 1, rs, b, s)
+        const int prc = rc2 == 1 ? (mm_ok(qi_of(bl.o_proj), bl.dout.type, nq) ? mrs_dec_mm_proj(qi_of(bl.o_proj), bl.dout.type, d, nq, ws.attn_img, ws.h, d, 1, rs, b, s)
+                                                                                : mrs_dec_proj_img(&bl.dout, d, ws.attn_img, ws.h, d, 1, rs, b, s))
                                  : mrs_dec_proj(&bl.dout, d, nullptr, ws.attn, nq, nullptr, 0.f, ws.h, d, 1, rs, nullptr, b, s);
         if (prc || all_reduce(ws.h, (size_t)b * d, s)) return fail("o_proj failed (%d): %s", prc, g_last_error.c_str());
       } else {
@@ -510,15 +522,22 @@ class Llama {
         continue;
       }
       if (imgb) {
-        if (image(ws.h, d, bl.post_attention_layernorm, d, bl.dgate.type) || mrs_dec_gate_up_img(&bl.dgate, &bl.dup, ff, ws.act_img, 0, ws.act, ff, b, s))
+        const bool mmg = mm_ok(qi_of(bl.gate_proj), bl.dgate.type, d) && qi_of(bl.up_proj);
+        if (image(ws.h, d, bl.post_attention_layernorm, d, bl.dgate.type) ||
+            (mmg ? mrs_dec_mm_gate_up(qi_of(bl.gate_proj), qi_of(bl.up_proj), bl.dgate.type, ff, d, ws.act_img, 0, ws.act, ff, b, s)
+                 : mrs_dec_gate_up_img(&bl.dgate, &bl.dup, ff, ws.act_img, 0, ws.act, ff, b, s)))
           return fail("mrs_dec_gate_up_img refused");
       } else if (mrs_dec_gate_up(&bl.dgate, &bl.dup, ff, nullptr, ws.h, d, bl.post_attention_layernorm, cfg.rms_eps, 0, ws.act, ff, b, s)) return fail("mrs_dec_gate_up refused");
-      const int drc = imgb ? (image(ws.act, ff, nullptr, ff, bl.ddown.type) || mrs_dec_proj_img(&bl.ddown, d, ws.act_img, ws.h, d, 1, rs, b, s))
+      const int drc = imgb ? (image(ws.act, ff, nullptr, ff, bl.ddown.type) ||
+                              (mm_ok(qi_of(bl.down_proj), bl.ddown.type, ff) ? mrs_dec_mm_proj(qi_of(bl.down_proj), bl.ddown.type, d, ff, ws.act_img, ws.h, d, 1, rs, b, s)
+                                                                               : mrs_dec_proj_img(&bl.ddown, d, ws.act_img, ws.h, d, 1, rs, b, s)))
                                                     : mrs_dec_proj(&bl.ddown, d, nullptr, ws.act, ff, nullptr, 0.f, ws.h, d, 1, rs, nullptr, b, s);
       if (drc || all_reduce(ws.h, (size_t)b * d, s)) return fail("down_proj failed: %s", g_last_error.c_str());
     }
     const int lrc = chained ? mrs_dec_proj_argmax(&dlm_head, cfg.vocab_size, ws.h, d, ln_f, cfg.rms_eps, bufs.logits, cfg.vocab_size, ws.sample_scratch, s)
-                    : imgb ? (image(ws.h, d, ln_f, d, dlm_head.type) || mrs_dec_proj_img(&dlm_head, cfg.vocab_size, ws.act_img, bufs.logits, cfg.vocab_size, 0, 1.0f, b, s))
+                    : imgb ? (image(ws.h, d, ln_f, d, dlm_head.type) ||
+                              (mm_ok(qi_of(lm_head), dlm_head.type, d) ? mrs_dec_mm_proj(qi_of(lm_head), dlm_head.type, cfg.vocab_size, d, ws.act_img, bufs.logits, cfg.vocab_size, 0, 1.0f, b, s)
+                                                                        : mrs_dec_proj_img(&dlm_head, cfg.vocab_size, ws.act_img, bufs.logits, cfg.vocab_size, 0, 1.0f, b, s)))
                            : mrs_dec_proj(&dlm_head, cfg.vocab_size, nullptr, ws.h, d, ln_f, cfg.rms_eps, bufs.logits, cfg.vocab_size, 0, 1.0f, nullptr, b, s);
     if (lrc) return fail("lm_head refused");
     return 0;
@@ -1141,6 +1160,7 @@ extern "C" int mrs_llama_set_qi_tensor(void *mm, const char *cname, const void *
     if (rest == "ffn_up_exps.weight") return bind_exps(b.up_exps);
     if (rest == "ffn_down_exps.weight") return bind_exps(b.down_exps);
   }
+  if (name == "output.weight") return bind(m.lm_head);  // (round 6) lm_head of the batched decode steps on the matrix cores (ext_dec_mm.hip); prompts do not read it
   return mrs_host::fail("MFMA layout: tensor %s has no prompt-GEMM role", cname);
 }
 // bf16 shadow copy (mrs_dequantize(..., out_dtype = 30), caller-owned) of a dense linear already registered with mrs_llama_set_tensor: with one for every dense linear the

@@ -322,8 +322,9 @@ class Llama:
                     self._keep[name + "#dec"] = planes
                     self._chk(self._L.mrs_llama_set_dec_tensor(self._h, name.encode(), planes.data_ptr()))
             # MFMA-order copy for the exact-integer prompt GEMM (ext_gemm_qi.hip): dense per-layer linears of the types it takes; with every one present the
-            # runner prefills in the decode engine's arithmetic (Llama::prefill_exact).  A third copy of the same bits, made once.
-            if self._engine_wanted and self._exact_prefill_wanted and name.startswith("blk."):  # dense linears and stacked expert tensors (round 6: sparse-MoE prompts too)
+            # runner prefills in the decode engine's arithmetic (Llama::prefill_exact).  A third copy of the same bits, made once.  Batched decode steps (2..8 sequences)
+            # stream THIS copy through the matrix cores (csrc/ext_dec_mm.hip), lm_head included when the model is sized for batches.
+            if self._engine_wanted and self._exact_prefill_wanted and (name.startswith("blk.") or (name == "output.weight" and self.cfg.max_batch > 1)):  # dense linears and stacked expert tensors (round 6: sparse-MoE prompts too)
                 nb2 = self._L.mrs_gemm_qi_repack_bytes(t.dtype.id, t.shape[0], t.shape[1])
                 if nb2:
                     qi = torch.empty(nb2, dtype=torch.uint8, device=self.device)

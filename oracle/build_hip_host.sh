@@ -34,7 +34,7 @@ for spec in q4_0:2:q4_0 q4_1:3:q4_1 q5_0:6:q5_0 q5_1:7:q5_1 q8_0:8:q8_0 q2_k:10:
 done
 for nc in 1 2 3 4 5 6 7 8; do cc ext_dec_gemv_nc$nc ext_dec_gemv.hip -DMRS_DEC_NC=$nc; done
 cc mmvq_q8_1 mmvq_inst.hip -DMRS_TAG=q8_1 -DMRS_TYPE=9 -DMRS_MOE_TAG=q8_1 -DMRS_MOE_ONLY  # Q8_1 weights: MoE launchers only
-for f in mmvq_quantize mmq moe gemv quant_ops core_ops sampling hqq ext_isq ext_decode ext_dec ext_p2p ext_hqq_gemv ext_gemm ext_gemm_qi ext_attn_prefill kv_cache_ops; do cc $f $f.hip; done
+for f in mmvq_quantize mmq moe gemv quant_ops core_ops sampling hqq ext_isq ext_decode ext_dec ext_dec_mm ext_p2p ext_hqq_gemv ext_gemm ext_gemm_qi ext_attn_prefill kv_cache_ops; do cc $f $f.hip; done
 # the C++ runner (plain host code: it finds the launchers with dlsym(RTLD_DEFAULT), so it only works in a process that loaded THIS library
 # RTLD_GLOBAL and not the product libraries -- `pytest --host-emulation`); the RCCL entry points are hip_host/comm_shim.c
 mkdir -p "$OUT/src/host"

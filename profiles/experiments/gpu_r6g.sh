@@ -1,0 +1,24 @@
+#!/bin/bash
+# round 6, call G: batched decode on the matrix cores (ext_dec_mm.hip): bit-identity tests on the device, per-phase launch times against the vector-ALU kernels, batched bench lines
+export TMPDIR=/tmp
+O=gpurun_out/r6g; mkdir -p $O
+timeout 900 python -m pytest tests/test_dec_mm.py -q -m gpu -x -rf > $O/pytest_mm.log 2>&1; tail -5 $O/pytest_mm.log | cut -c1-300
+timeout 900 python -m pytest tests/test_dec_model.py tests/test_llama_runner.py -q -m gpu -rf -k "batch or graph" > $O/pytest_model.log 2>&1; tail -5 $O/pytest_model.log | cut -c1-300
+for b in 8 4 2; do
+  timeout 300 python scripts/bench_dec.py --b $b --img > $O/dec_img_b$b.log 2>&1
+  timeout 300 python scripts/bench_dec.py --b $b --mm > $O/dec_mm_b$b.log 2>&1
+  echo "== b=$b img"; cut -c1-160 $O/dec_img_b$b.log | tail -6; echo "== b=$b mm"; cut -c1-160 $O/dec_mm_b$b.log | tail -6
+done
+run() { name=$1; shift; (timeout 700 python bench.py --no-cpu-baseline --no-dropin --no-extra "$@" 2>&1 | tail -1) > $O/line_$name.log; python - "$O/line_$name.log" "$name" <<'PY'
+import json, sys
+try:
+    j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print(sys.argv[2], "tok/s", j["value"], "ms", j["ms_per_step"], "step_frac", j.get("step_roofline_frac"))
+except Exception as e:
+    print(sys.argv[2], "FAILED", e, open(sys.argv[1]).read()[-400:])
+PY
+}
+run b8_mm --batch 8 --steps 64
+MRS_DEC_MM=0 run b8_valu --batch 8 --steps 64
+run b4_mm --batch 4 --steps 64
+run b2_mm --batch 2 --steps 64

@@ -20,7 +20,10 @@ def main():
     ap.add_argument("--timeline", action="store_true", help="instead of timing: one cold launch per phase with the s_memrealtime stamps of dec_core2.cuh (MRS_TL2), medians per wave group")
     ap.add_argument("--hot", action="store_true", help="two rotating buffers per phase, replayed 8 x inside the graph: the weights stay in the 256 MiB Infinity Cache")
     ap.add_argument("--img", action="store_true", help="batched steps: the GEMV phases on an activation image built ONCE by mrs_dec_act_image (not timed here), as the runner does for b >= 2")
+    ap.add_argument("--mm", action="store_true", help="with --img: the matrix-core route of batched steps (mrs_dec_mm_*, csrc/ext_dec_mm.hip) on the MFMA-order copy of the same tensors")
     a = ap.parse_args()
+    if a.mm:
+        a.img = True
     import torch
     import mistralrs_amd  # noqa: F401
     from mistralrs_amd import _lib
@@ -34,13 +37,24 @@ def main():
     L.mrs_dec_repack.argtypes = [C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p]
     st = torch.cuda.current_stream().cuda_stream
     b = a.b
+    L.mrs_gemm_qi_repack_bytes.restype = C.c_size_t
+    L.mrs_gemm_qi_repack_bytes.argtypes = [C.c_int, C.c_longlong, C.c_longlong]
+    L.mrs_gemm_qi_repack.argtypes = [C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p]
+    L.mrs_dec_mm_proj.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]
+    L.mrs_dec_mm_gate_up.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.mrs_dec_mm_qkv.argtypes = [C.c_void_p, C.c_int, C.c_int] * 3 + [C.c_int, C.c_void_p] + [C.c_void_p] * 7 + [C.c_int] * 6 + [C.c_void_p]
 
     def make(dt, n, k, seed):
         w = random_qtensor(dt, n, k, dev, seed)
         nb = L.mrs_dec_repack_bytes(dt.id, n, k)
         p = torch.empty(nb, dtype=torch.uint8, device=dev)
         assert L.mrs_dec_repack(w.data.data_ptr(), dt.id, n, k, p.data_ptr(), st) == 0
-        return w, p, Mat(p.data_ptr(), dt.id, n, k)
+        qi = None
+        if a.mm:
+            qi = torch.empty(L.mrs_gemm_qi_repack_bytes(dt.id, n, k), dtype=torch.uint8, device=dev)
+            assert L.mrs_gemm_qi_repack(w.data.data_ptr(), dt.id, n, k, qi.data_ptr(), st) == 0
+            p = torch.empty(16, dtype=torch.uint8, device=dev)  # the decode-layout copy is not read: keep HBM for the rotation
+        return w, p, Mat(p.data_ptr(), dt.id, n, k), qi
 
     d, ff, nq, nkv, hd = 4096, 14336, 4096, 1024, 128
     h = torch.randn(b, d, device=dev)
@@ -93,6 +107,9 @@ def main():
         if a.img:
             new = lambda st: L.mrs_dec_qkv_img(C.byref(ws[0][2]), C.byref(ws[1][2]), C.byref(ws[2][2]), img_h.data_ptr(), q_out.data_ptr(), kc.data_ptr(), vc.data_ptr(),
                                                slots.data_ptr(), pos.data_ptr(), cos.data_ptr(), sin.data_ptr(), hd, hd // 2, 8, 32, 1, b, 0, st)
+        if a.mm:
+            new = lambda st: L.mrs_dec_mm_qkv(ws[0][3].data_ptr(), 12, nq, ws[1][3].data_ptr(), 12, nkv, ws[2][3].data_ptr(), 14, nkv, d, img_h.data_ptr(), q_out.data_ptr(), kc.data_ptr(),
+                                              vc.data_ptr(), slots.data_ptr(), pos.data_ptr(), cos.data_ptr(), sin.data_ptr(), hd, hd // 2, 8, 32, 1, b, st)
         old = lambda st: L.mrs_decode_qkv(ws[0][0].data.data_ptr(), ws[1][0].data.data_ptr(), ws[2][0].data.data_ptr(), 12, 12, 14, nq, nkv, nkv, d, h.data_ptr(), nw.data_ptr(), 1e-5,
                                        q_out.data_ptr(), kc.data_ptr(), vc.data_ptr(), slots.data_ptr(), pos.data_ptr(), cos.data_ptr(), sin.data_ptr(), hd, hd // 2, 8, 32, b, st)
         return ws, new, old, nbytes(*[w[0] for w in ws])
@@ -104,6 +121,8 @@ def main():
             if a.img:
                 im = img_act if k == ff else img_attn
                 new = lambda st: L.mrs_dec_proj_img(C.byref(ws[0][2]), n, im.data_ptr(), h.data_ptr(), d, 1, 1.0, b, st)
+                if a.mm:
+                    new = lambda st: L.mrs_dec_mm_proj(ws[0][3].data_ptr(), dt.id, n, k, im.data_ptr(), h.data_ptr(), d, 1, 1.0, b, st)
             old = lambda st: L.mrs_decode_proj(ws[0][0].data.data_ptr(), dt.id, n, k, ybuf.data_ptr(), stride, h.data_ptr(), d, 1, b, st)
             return ws, new, old, nbytes(ws[0][0])
         return f
@@ -113,6 +132,8 @@ def main():
         new = lambda st: L.mrs_dec_gate_up(C.byref(ws[0][2]), C.byref(ws[1][2]), ff, None, h.data_ptr(), d, nw.data_ptr(), 1e-5, 0, act.data_ptr(), ff, b, st)
         if a.img:
             new = lambda st: L.mrs_dec_gate_up_img(C.byref(ws[0][2]), C.byref(ws[1][2]), ff, img_h.data_ptr(), 0, act.data_ptr(), ff, b, st)
+        if a.mm:
+            new = lambda st: L.mrs_dec_mm_gate_up(ws[0][3].data_ptr(), ws[1][3].data_ptr(), 12, ff, d, img_h.data_ptr(), 0, act.data_ptr(), ff, b, st)
         old = lambda st: L.mrs_decode_gate_up(ws[0][0].data.data_ptr(), ws[1][0].data.data_ptr(), 12, ff, d, h.data_ptr(), nw.data_ptr(), 1e-5, 0, yb.data_ptr(), 14336 // 32, b, st)
         return ws, new, old, nbytes(ws[0][0], ws[1][0])
 
@@ -121,6 +142,8 @@ def main():
         new = lambda st: L.mrs_dec_proj(C.byref(ws[0][2]), 128256, None, h.data_ptr(), d, nw.data_ptr(), 1e-5, logits.data_ptr(), 128256, 0, 1.0, None, b, st)
         if a.img:
             new = lambda st: L.mrs_dec_proj_img(C.byref(ws[0][2]), 128256, img_h.data_ptr(), logits.data_ptr(), 128256, 0, 1.0, b, st)
+        if a.mm:
+            new = lambda st: L.mrs_dec_mm_proj(ws[0][3].data_ptr(), 14, 128256, d, img_h.data_ptr(), logits.data_ptr(), 128256, 0, 1.0, b, st)
         old = lambda st: L.mrs_decode_norm_proj(ws[0][0].data.data_ptr(), 14, 128256, d, h.data_ptr(), nw.data_ptr(), 1e-5, logits.data_ptr(), 128256, b, st)
         return ws, new, old, nbytes(ws[0][0])
 
@@ -164,6 +187,25 @@ def main():
                 assert inst[1](stc) == 0
                 torch.cuda.synchronize()
             L.mrs_dec_timeline(None, 0)
+            if a.mm:
+                tm = torch.zeros(512 * 4 * 8, dtype=torch.int64, device=dev)
+                L.mrs_dec_mm_timeline.argtypes = [C.c_void_p]
+                L.mrs_dec_mm_timeline(tm.data_ptr())
+                assert insts[6 % len(insts)][1](stc) == 0
+                torch.cuda.synchronize()
+                L.mrs_dec_mm_timeline(None)
+                t = tm.cpu().numpy().reshape(512, 4, 8).astype(np.float64)
+                used = t[:, :, 0] > 0
+                t0 = t[:, :, 0][used].min()
+                rel = (t - t0) / 100.0
+                def mm_med(i):
+                    v = rel[:, :, i][t[:, :, i] > 0]
+                    return (round(float(np.median(v)), 2), round(float(v.max()), 2)) if v.size else None
+                print(name, "mm (median, max us over waves): entry", mm_med(0), "ring issued", mm_med(1), "image stored", mm_med(2), "barrier", mm_med(3), "records done (last unit)", mm_med(4),
+                      "sums published", mm_med(5), "end", mm_med(6), "workgroups", int(used.any(axis=1).sum()), flush=True)
+                del insts
+                torch.cuda.empty_cache()
+                continue
             t = tl.cpu().numpy().reshape(256, 8, 16).astype(np.float64)
             used = t[:, :, 0] > 0
             t0 = t[:, :, 0][used].min()
