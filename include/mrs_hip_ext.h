@@ -103,6 +103,7 @@ int mrs_dec_gate_up_img(const mrs_dec_mat *wg, const mrs_dec_mat *wu, int n, con
  * the same bits as the vector-ALU kernels.  Reference role: MMVQ's batch 1..8 from one weight pass (kernels/mmvq_gguf/mmvq_gguf.cu:724-792, gguf/fast_mmvq.rs:52).
  * x_img = mrs_dec_act_image(.., weight type, b, ..).  mrs_dec_mm_supported: the type is one the route takes and k x b fits its LDS budget. */
 int mrs_dec_mm_supported(int type, int k, int b);
+unsigned long long mrs_dec_mm_launch_count(void); /* launches of the route since the library was loaded */
 void mrs_dec_mm_timeline(void *buf); /* experiments: [grid * 4][8] u64 s_memrealtime stamps of the following mrs_dec_mm_* launches, or NULL (off) */
 int mrs_dec_mm_proj(const void *qi, int type, int n, int k, const void *x_img, float *out, int ld_out, int mode, float resid_scale, int b, void *stream);
 int mrs_dec_mm_gate_up(const void *qi_gate, const void *qi_up, int type, int n, int k, const void *x_img, int activation, float *act_out, int ld_out, int b, void *stream);

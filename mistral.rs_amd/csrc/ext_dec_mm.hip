@@ -484,6 +484,7 @@ __global__ void __launch_bounds__(MT) MRS_MM_WAVES_PER_EU(1, 1) dec_mm_kernel_de
 }
 
 static unsigned long long *g_mm_tl = nullptr;
+static unsigned long long g_mm_launches = 0;  // launches of this route since the library was loaded (tests: did a batched step really take it?)
 static int launch(const MmArgs &a0, hipStream_t s) {
   MmArgs a = a0;
   a.tl = g_mm_tl;
@@ -503,6 +504,7 @@ static int launch(const MmArgs &a0, hipStream_t s) {
   const int cap = 256 * std::min<int>(std::min(wg_per_cu, fit), std::max<size_t>(1, ((size_t)160 * 1024) / lds));
   const int grid = std::min(a.units, cap);
   auto go = [&](auto kern) {
+    ++g_mm_launches;
     lds_attr_once((const void *)kern, 158 * 1024);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MT), lds, s, a);
     return hipGetLastError() == hipSuccess ? 0 : -4;
@@ -557,6 +559,7 @@ static bool base(MmArgs &a, const void *x_img, int k, int b, int type0) {
 using namespace mrs;
 using namespace mrs::mm;
 
+extern "C" unsigned long long mrs_dec_mm_launch_count(void) { return g_mm_launches; }
 extern "C" void mrs_dec_mm_timeline(void *buf) { g_mm_tl = (unsigned long long *)buf; }  // experiments: [grid * 4 waves][8] u64 stamps of the next launches, or NULL
 // Can the batched matrix-core route take a launch of this weight type / reduction length / column count?  (K-quants and Q8_0; the LDS budget bounds k x b)
 extern "C" int mrs_dec_mm_supported(int type, int k, int b) {

@@ -69,3 +69,15 @@ def test_exact_prompt_gemm_no_scratch(kernels):
     assert len(ks) == 3
     for k in ks:
         assert k["vgpr_count"] <= 256 and not k.get("private_segment_fixed_size", 0) and not k.get("vgpr_spill_count", 0), (k["demangled"], k)
+
+
+def test_matrix_core_batched_decode_no_scratch(kernels):
+    """dec_mm_kernel* (csrc/ext_dec_mm.hip, round 6).  The first form of this kernel kept EVERY local (and a copy of the argument block) in scratch memory: its by-reference
+    lambdas selected between captured variables, hipcc turned that into run-time offsets into the closure object, and the closure could not be dissolved (688 bytes of stack per
+    lane, 2071 scratch instructions, waterfall loops around every buffer load).  Two workgroups per CU for the Q4_K kernel (<= 256 registers), no spills anywhere."""
+    ks = _sel(kernels, r"dec_mm_kernel")
+    assert len(ks) >= 7
+    for k in ks:
+        assert not k.get("private_segment_fixed_size", 0) and not k.get("vgpr_spill_count", 0), (k["demangled"], k)
+    q4 = _sel(kernels, r"dec_mm_kernel_q4k")
+    assert len(q4) == 1 and q4[0]["vgpr_count"] <= 256, q4
