@@ -287,13 +287,15 @@ __device__ __forceinline__ void finish_unit(const MmArgs &a, const float *ex, in
   }
 }
 
-template <int TMASK, bool DEEP>
+template <int TMASK>
 __device__ __forceinline__ void dec_mm_body(const MmArgs &a, char *smem) {
   constexpr bool ONLY4 = TMASK == TM_Q4K;
   constexpr int NPC = ONLY4 ? 4 : 8;
-  // records in flight per wave.  DEEP: launches of at most one workgroup per CU (<= 256 panels: o_proj, down_proj, q / k / v): four waves per CU have to keep the CU's
-  // share of the HBM stream in flight by themselves -- with 3 x 4.6 KB per wave a CU drew 24 GB/s (down_proj 16 us for 33 MB); 512 registers per lane are there to be used
-  constexpr int R = DEEP ? (ONLY4 ? 8 : 4) : (ONLY4 ? 3 : 2);
+  // Records in flight per wave.  Measured and NOT adopted on the launches of <= 256 panels (o_proj, down_proj, q / k / v: one workgroup per CU at best): rings of 8 / 4 records
+  // at one wave per SIMD (o_proj 8.1 -> 10.3 us, down_proj 16.2 -> 20.3) and eight waves per workgroup, two per run of superblocks, their terms exchanged through LDS at a
+  // barrier per step (o_proj 7.95 -> 8.63, down_proj 15.7 -> 16.2): neither more bytes in flight nor more waves per CU moves these launches -- a CU draws ~25 GB/s through
+  // this path and 128 panels occupy 128 CUs (profiles/round6_decode.md section 5).
+  constexpr int R = ONLY4 ? 3 : 2;
   const int tid = tid_opaque(), lane = tid & 63, p = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave p = run p of the row's superblocks
   const int nn = lane & 31, hf = lane >> 5;
   const int K = a.K, S = K / 256, Cs = (S + 3) / 4, Sp = 4 * Cs, CQ = act_cq(K), QCS = qcs_of(K), nc = a.nc;
@@ -469,20 +471,13 @@ __device__ __forceinline__ void dec_mm_body(const MmArgs &a, char *smem) {
 // three and funnels every MFMA of a record through one accumulator tuple (exposed MFMA latency x 9 per record).
 __global__ void __launch_bounds__(MT) MRS_MM_WAVES_PER_EU(2, 2) dec_mm_kernel_q4k(const MmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  dec_mm_body<TM_Q4K, false>(a, smem);
+  dec_mm_body<TM_Q4K>(a, smem);
 }
 template <int TMASK>
 __global__ void __launch_bounds__(MT) MRS_MM_WAVES_PER_EU(1, 2) dec_mm_kernel(const MmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  dec_mm_body<TMASK, false>(a, smem);
+  dec_mm_body<TMASK>(a, smem);
 }
-// one workgroup per CU, a deep ring (see dec_mm_body)
-template <int TMASK>
-__global__ void __launch_bounds__(MT) MRS_MM_WAVES_PER_EU(1, 1) dec_mm_kernel_deep(const MmArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  dec_mm_body<TMASK, true>(a, smem);
-}
-
 static unsigned long long *g_mm_tl = nullptr;
 static unsigned long long g_mm_launches = 0;  // launches of this route since the library was loaded (tests: did a batched step really take it?)
 static int launch(const MmArgs &a0, hipStream_t s) {
@@ -509,18 +504,6 @@ static int launch(const MmArgs &a0, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MT), lds, s, a);
     return hipGetLastError() == hipSuccess ? 0 : -4;
   };
-  static const int deep_on = [] { const char *e = getenv("MRS_DEC_MM_DEEP"); return e ? atoi(e) : 1; }();
-  if (deep_on > 1 && a.units <= 256) {  // (measured slower: o_proj 8.1 -> 10.3 us, down_proj 16.2 -> 20.3 us; kept for experiments: MRS_DEC_MM_DEEP=2)
-    switch (tmask) {
-    case TM_Q4K: return go(dec_mm_kernel_deep<TM_Q4K>);
-    case TM_Q6K: return go(dec_mm_kernel_deep<TM_Q6K>);
-    case TM_Q5K: return go(dec_mm_kernel_deep<TM_Q5K>);
-    case TM_Q80: return go(dec_mm_kernel_deep<TM_Q80>);
-    case TM_Q4K | TM_Q6K: return go(dec_mm_kernel_deep<TM_Q4K | TM_Q6K>);
-    case TM_Q5K | TM_Q6K: return go(dec_mm_kernel_deep<TM_Q5K | TM_Q6K>);
-    default: return go(dec_mm_kernel_deep<TM_Q4K | TM_Q5K | TM_Q6K>);
-    }
-  }
   switch (tmask) {
   case TM_Q4K: return go(dec_mm_kernel_q4k);
   case TM_Q6K: return go(dec_mm_kernel<TM_Q6K>);

@@ -450,7 +450,7 @@ class Llama {
     auto image = [&](const float *x, int ldx, const float *nw, int k, int wtype) { return mrs_dec_act_image(x, ldx, nw, cfg.rms_eps, k, wtype, b, ws.act_img, s); };
     // (round 6) batched steps on the matrix cores (ext_dec_mm.hip): the same launches on the MFMA-order copy of the weights the exact prompt path keeps (QTensor::qi) -- integer
     // dots on v_mfma_i32_32x32x32_i8 instead of 535 VALU per 8-column tile, the same bits.  MRS_DEC_MM=0 keeps the vector-ALU kernels; MRS_DEC_MM_MIN_B: smallest batch that takes it.
-    static const int mm_min_b = [] { const char *e = getenv("MRS_DEC_MM"); if (e && atoi(e) == 0) return 1 << 30; const char *m = getenv("MRS_DEC_MM_MIN_B"); return m ? atoi(m) : 4; }();  // measured (MI355X, 8B Q4_K_M): batch 2 / 3 / 4 / 8 = 779 / 1026 / 1518 / 2722 tok/s here, 824 / 1103 / 1315 / 1685 on the vector ALU
+    static const int mm_min_b = [] { const char *e = getenv("MRS_DEC_MM"); if (e && atoi(e) == 0) return 1 << 30; const char *m = getenv("MRS_DEC_MM_MIN_B"); return m ? atoi(m) : 3; }();  // measured (MI355X, 8B Q4_K_M): batch 2 / 3 / 4 / 8 = 760 / 1128 / 1518 / 2722 tok/s here, 824 / 1103 / 1315 / 1685 on the vector ALU
     const bool mmb = imgb && b >= mm_min_b;
     auto qi_of = [](const std::unique_ptr<GgufMatMul> &l) -> const void * { return l && l->get_qtensor() ? l->get_qtensor()->qi : nullptr; };
     auto mm_ok = [&](const void *qi, int type, int k) { return mmb && qi && mrs_dec_mm_supported(type, k, b); };

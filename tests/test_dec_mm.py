@@ -105,7 +105,7 @@ def check_mm_qkv(O, be, tq, tv, heads, kvh, k, b, kvd=1):
 
 
 @pytest.mark.parametrize("tname,n,k,b,norm", [("Q4_K", 40, 1024, 3, True), ("Q6_K", 32, 512, 8, False), ("Q5_K", 33, 768, 5, True), ("Q8_0", 64, 512, 4, True),
-                                              ("Q4_K", 32, 3584, 8, False), ("Q4_K", 16, 256, 1, False)])
+                                              ("Q4_K", 32, 3584, 8, False), ("Q4_K", 16, 256, 1, False), ("Q6_K", 64, 1792, 2, False), ("Q4_K", 96, 2560, 8, True)])
 def test_mm_proj_host_emulation(oracle, tname, n, k, b, norm):
     check_mm_proj(oracle, HostBackend(), tname, n, k, b, norm)  # (n = 33 / 40 / 16: a ragged last panel; k = 768: runs of one superblock, the fourth empty; k = 256: three empty runs)
 
@@ -129,7 +129,7 @@ def test_mm_entry_points_refuse_what_they_cannot_do_host_emulation(oracle):
     img = _act_image(be, t, x, None, k, b)
     out = be.buf(np.zeros((b, n), np.float32))
     sup = be.sym("mrs_dec_mm_supported", [C.c_int, C.c_int, C.c_int], C.c_int)
-    assert sup(t, k, 8) == 1 and sup(t, k, 9) == 0 and sup(t, 300, 2) == 0 and sup(0, k, 2) == 0 and sup(t, 28672, 8) == 0 and sup(t, 28672, 4) == 1
+    assert sup(t, k, 8) == 1 and sup(t, k, 9) == 0 and sup(t, 300, 2) == 0 and sup(0, k, 2) == 0 and sup(t, 28672, 8) == 0 and sup(t, 28672, 4) == 1 and sup(t, 14336, 8) == 1
     fn = be.sym("mrs_dec_mm_proj", MM_PROJ, C.c_int)
     assert fn(qi.ptr, t, n, k, img.ptr, out.ptr, n, 0, 1.0, b, be.stream) == 0
     for bad in ((None, t, n, k, img.ptr, out.ptr, n, 0, 1.0, b), (qi.ptr, 0, n, k, img.ptr, out.ptr, n, 0, 1.0, b), (qi.ptr, t, n, 300, img.ptr, out.ptr, n, 0, 1.0, b),
