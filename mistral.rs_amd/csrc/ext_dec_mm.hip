@@ -101,14 +101,15 @@ __device__ __forceinline__ void term(const Rec<NPC> &w, int sb, const char *qcol
     }
   } else {
     int isum[4] = {0, 0, 0, 0};
+    i16v dq[TYPE == T_Q4_K ? 4 : 1];  // Q4_K: the results of the second group of MFMAs wait here for the mins' MFMA to be issued
     if constexpr (TYPE == T_Q4_K) {
       // piece c: bytes 0 .. 7 = qs[32 c + 8 hf ..], 8 .. 15 = qs[32 c + 16 + 8 hf ..]: low nibbles = elements 64 c + {8 hf .., 16 + 8 hf ..} (sub-block 2 c), high = + 32 (2 c + 1)
       // FOUR independent MFMAs per group, then their scale products (first GPU run: hipcc funnelled every MFMA of a record through one accumulator tuple -- read the
       // four live results back, overwrite -- and a record cost a wave 0.66 us: nine exposed MFMA latencies; the scheduling barriers keep a group's MFMAs together)
-#pragma unroll
-      for (int g2 = 0; g2 < 2; ++g2) {
-        i16v d[4];
-        i4v wa[4], wb[4];
+      // Schedule of a record (scheduling barriers pin it; one wave per SIMD has nobody to hide a latency behind): operands of the first four sub-blocks | their MFMAs |
+      // LDS reads + unpack of the other four and the mins' operand WHILE those run | scale products of the first four | MFMAs of the other four + the mins' MFMA (issued
+      // by the caller's code right behind) | scale products.
+      auto operands = [&](int g2, i4v (&wa)[4], i4v (&wb)[4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int c = 2 * g2 + h;
@@ -117,16 +118,25 @@ __device__ __forceinline__ void term(const Rec<NPC> &w, int sb, const char *qcol
           wa[2 * h] = mk_i4(*(const v2u *)(qa), *(const v2u *)(qa + 16)); wa[2 * h + 1] = mk_i4(*(const v2u *)(qa + 32), *(const v2u *)(qa + 48));
           wb[2 * h] = __builtin_bit_cast(i4v, lo); wb[2 * h + 1] = __builtin_bit_cast(i4v, hi);
         }
-        __builtin_amdgcn_sched_barrier(0);  // operands ready | the four MFMAs back to back (four accumulator tuples) | their results
-#pragma unroll
-        for (int h = 0; h < 4; ++h) d[h] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wa[h], wb[h], zero, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        const unsigned scw = g2 == 0 ? w.hs.x : w.hs.y;
+      };
+      auto products = [&](unsigned scw, const i16v (&d)[4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           isum[i] += (__mul24(byte_of(scw, 0), d[0][i]) + __mul24(byte_of(scw, 1), d[1][i])) + (__mul24(byte_of(scw, 2), d[2][i]) + __mul24(byte_of(scw, 3), d[3][i]));
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      };
+      i4v wa0[4], wb0[4], wa1[4], wb1[4];
+      operands(0, wa0, wb0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int h = 0; h < 4; ++h) dq[h] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wa0[h], wb0[h], zero, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      operands(1, wa1, wb1);  // in the shadow of the four MFMAs above
+      __builtin_amdgcn_sched_barrier(0);
+      products(w.hs.x, dq);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int h = 0; h < 4; ++h) dq[h] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wa1[h], wb1[h], zero, 0, 0, 0);
+      // (their scale products follow the mins' MFMA below: its operand build runs in the shadow of these four)
     } else if constexpr (TYPE == T_Q5_K) {
       // piece g = sub-block g, the 5-bit values as bytes: bytes 0 .. 7 = elements 32 g + 8 hf .., 8 .. 15 = 32 g + 16 + 8 hf ..
 #pragma unroll
@@ -185,7 +195,14 @@ __device__ __forceinline__ void term(const Rec<NPC> &w, int sb, const char *qcol
       for (int k = 0; k < 4; ++k) { const _Float16 mk = (_Float16)(float)byte_of(mw, k); wm[2 * k] = mk; wm[2 * k + 1] = mk; }
     }
     const f16v zf = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (TYPE == T_Q4_K) __builtin_amdgcn_sched_barrier(0);
     const f16v M = __builtin_amdgcn_mfma_f32_32x32x16_f16(bsf, wm, zf, 0, 0, 0);
+    if constexpr (TYPE == T_Q4_K) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        isum[i] += (__mul24(byte_of(w.hs.y, 0), dq[0][i]) + __mul24(byte_of(w.hs.y, 1), dq[1][i])) + (__mul24(byte_of(w.hs.y, 2), dq[2][i]) + __mul24(byte_of(w.hs.y, 3), dq[3][i]));
+    }
     const float4 y4 = *(const float4 *)(ydp + 4 * hf * 4);
     const float yy[4] = {y4.x, y4.y, y4.z, y4.w};
     const float d = half_bits_to_float((uint16_t)(w.hd & 0xffff));
