@@ -308,13 +308,10 @@ template <int TMASK>
 __device__ __forceinline__ void dec_mm_body(const MmArgs &a, char *smem) {
   constexpr bool ONLY4 = TMASK == TM_Q4K;
   constexpr int NPC = ONLY4 ? 4 : 8;
-  // Records in flight per wave: 3 x 4.6 KB (Q4_K) / 2 x 8.6 KB.  What the ablations of call S say about a record: with NO arithmetic at all the launches take the same time
-  // (gate + up 17.6 -> 16.2 us, o_proj 7.9 -> 7.7); without the LDS reads or the nibble unpack: the same; with half of the weight pieces never requested: gate + up 11.9 us --
-  // a launch is ~6 us of fixed cost (requests of image + ring through the CU's one texture addresser, the image's L2 round trip, barrier, epilogue) + its bytes at 5.7 TB/s when
-  // every CU has two workgroups (gate + up, lm_head) and ~3.1 TB/s when 128 panels occupy 128 CUs.  Measured and NOT adopted for those launches (o_proj, down_proj, q / k / v):
-  // deeper rings at one workgroup per CU -- 8 / 4 records (call L: o_proj 8.1 -> 10.3 us; ring + image requests overflow the 6-bit vmcnt) and 5 / 3 records (call T: 8.0 -> 9.2,
-  // down_proj 16.5 -> 19.4: more requests in flight per CU make every one of them slower, as dec_core2.cuh found for the batch-1 kernels); eight waves per workgroup, two per
-  // run of superblocks (call P: 7.95 -> 8.63); half-panel units on all 256 CUs (call Q: 8.2 -> 8.4; the request COUNT per CU stays the same).
+  // Records in flight per wave.  Measured and NOT adopted on the launches of <= 256 panels (o_proj, down_proj, q / k / v: one workgroup per CU at best): rings of 8 / 4 records
+  // at one wave per SIMD (o_proj 8.1 -> 10.3 us, down_proj 16.2 -> 20.3) and eight waves per workgroup, two per run of superblocks, their terms exchanged through LDS at a
+  // barrier per step (o_proj 7.95 -> 8.63, down_proj 15.7 -> 16.2): neither more bytes in flight nor more waves per CU moves these launches -- a CU draws ~25 GB/s through
+  // this path and 128 panels occupy 128 CUs (profiles/round6_decode.md section 5).
   constexpr int R = ONLY4 ? 3 : 2;
   const int tid = tid_opaque(), lane = tid & 63, p = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave p = run p of the row's superblocks
   const int nn = lane & 31, hf = lane >> 5;
@@ -367,12 +364,8 @@ __device__ __forceinline__ void dec_mm_body(const MmArgs &a, char *smem) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int i = j0 + j * 64 + lane;
-        r0[j] = v4u{0u, 0u, 0u, 0u}; r1[j] = v4u{0u, 0u, 0u, 0u};
-        if (j0 + j * 64 < nv) {  // wave-uniform: a request that is dead for the whole wave still costs the CU's texture addresser 16 cycles -- 18 of the 32 image requests of a
-                                 // wave were such at K = 4096 (8 waves per CU: ~1 us of the 6 us in front of gate + up's first MFMA)
-          if (h0) r0[j] = __builtin_amdgcn_raw_buffer_load_b128(ri, i < nv ? s0 + (unsigned)i * 16u : PAST, 0, 0);
-          if (h1) r1[j] = __builtin_amdgcn_raw_buffer_load_b128(ri, i < nv ? s1 + (unsigned)i * 16u : PAST, 0, 0);
-        }
+        r0[j] = __builtin_amdgcn_raw_buffer_load_b128(ri, h0 && i < nv ? s0 + (unsigned)i * 16u : PAST, 0, 0);
+        r1[j] = __builtin_amdgcn_raw_buffer_load_b128(ri, h1 && i < nv ? s1 + (unsigned)i * 16u : PAST, 0, 0);
       }
     };
     auto st_batch = [&](int j0) __attribute__((always_inline)) {
@@ -393,8 +386,6 @@ __device__ __forceinline__ void dec_mm_body(const MmArgs &a, char *smem) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int i = i0 + j * MT + tid;
-        bq[j] = v4u{0u, 0u, 0u, 0u}; dv[j] = 0u;
-        if (i0 + j * MT >= nsc) continue;  // workgroup-uniform: nothing of this round exists
         if (q80) {
           const int sb = i >> 6, g = (i >> 3) & 7, c = i & 7;
           bq[j] = v4u{0u, 0u, 0u, 0u};

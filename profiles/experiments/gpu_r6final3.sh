@@ -3,8 +3,8 @@
 # THIS build), the other bench lines of profiles/round6_bench_lines.md, the batched lines on both routes, and the kernel trace of a batch-8 step
 cd /root/repo
 export TMPDIR=/tmp
-bash scripts/profile_round.sh r6final2
-O=gpurun_out/r6final2
+bash scripts/profile_round.sh r6final3
+O=gpurun_out/r6final3
 run() { name=$1; shift; (timeout 700 python bench.py --no-cpu-baseline --no-dropin --no-extra "$@" 2>&1 | tail -1) > $O/line_$name.log; python - "$O/line_$name.log" "$name" <<'PY'
 import json, sys
 try:
